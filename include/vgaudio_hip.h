@@ -1,0 +1,143 @@
+/*
+ * vgaudio_hip.h -- C ABI of libvgaudio_hip.so, the MI355X (gfx950) batch
+ * audio-codec engine that drops in behind VGAudio's IAudioFormat seam.
+ *
+ * Every entry point names the reference interface it replaces (paths relative
+ * to /root/reference/src/).  Signatures use plain pointers and sizes only; the
+ * caller owns (and, from C#, pins) every buffer, the callee keeps no pointer
+ * past return.  All exports are thread-safe and re-entrant: host-buffer
+ * entry points create and destroy their own HIP stream; *_device entry points
+ * run on the caller's stream and never synchronise it.
+ *
+ * Errors: the reference throws .NET exceptions; here every fallible function
+ * returns an int status that the managed shim maps back:
+ *   VGA_OK                 0
+ *   VGA_ERR_ARGUMENT      -1   ArgumentException
+ *   VGA_ERR_OUT_OF_RANGE  -2   ArgumentOutOfRangeException
+ *   VGA_ERR_INVALID_DATA  -3   InvalidDataException
+ *   VGA_ERR_INVALID_OP    -4   InvalidOperationException
+ *   VGA_ERR_DEVICE        -5   HIP runtime failure / no gfx950 device (no CPU fallback exists)
+ * vga_last_error() returns a thread-local message for the last failure.
+ */
+#ifndef VGAUDIO_HIP_H
+#define VGAUDIO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGA_OK 0
+#define VGA_ERR_ARGUMENT (-1)
+#define VGA_ERR_OUT_OF_RANGE (-2)
+#define VGA_ERR_INVALID_DATA (-3)
+#define VGA_ERR_INVALID_OP (-4)
+#define VGA_ERR_DEVICE (-5)
+
+const char *vga_last_error(void);
+/* number of visible HIP devices (0 when none; never fails) */
+int vga_device_count(void);
+/* selects the device for the calling thread (one process per GPU: LOCAL_RANK) */
+int vga_set_device(int device);
+/* library version string */
+const char *vga_version(void);
+
+/* ======================================================================
+ * GC-ADPCM (Nintendo DSP-ADPCM)
+ * ====================================================================== */
+
+/* VGAudio/Codecs/GcAdpcm/GcAdpcmMath.cs:11-47 (host-side, no device needed) */
+int vga_gcadpcm_nibble_count_to_sample_count(int nibble_count);
+int vga_gcadpcm_sample_count_to_nibble_count(int sample_count);
+int vga_gcadpcm_nibble_to_sample(int nibble);
+int vga_gcadpcm_sample_to_nibble(int sample);
+int vga_gcadpcm_sample_count_to_byte_count(int sample_count);
+int vga_gcadpcm_byte_count_to_sample_count(int byte_count);
+
+/* Replaces the body of GcAdpcmFormat.EncodeFromPcm16
+ * (VGAudio/Formats/GcAdpcm/GcAdpcmFormat.cs:58-74 + EncodeChannel :129-135):
+ * for every channel, CalculateCoefficients (GcAdpcmCoefficients.cs:9) then
+ * Encode (GcAdpcmEncoder.cs:14).  pcm[c] -> sample_count shorts (planar, the
+ * layout of Pcm16Format.Channels); coefs_out -> nch*16 shorts; adpcm_out[c] ->
+ * vga_gcadpcm_sample_count_to_byte_count(sample_count) bytes.  hist1/hist2 are
+ * GcAdpcmParameters.History1/2 (0 when config is null). */
+int vga_gcadpcm_encode_batch(const int16_t *const *pcm, int nch, int sample_count,
+                             int16_t hist1, int16_t hist2,
+                             int16_t *coefs_out, uint8_t *const *adpcm_out);
+
+/* Static-codec level, batched: GcAdpcmCoefficients.CalculateCoefficients
+ * (GcAdpcmCoefficients.cs:9) for nch channels of `length` samples. */
+int vga_gcadpcm_calculate_coefficients_batch(const int16_t *const *pcm, int nch, int length,
+                                             int16_t *coefs_out);
+
+/* GcAdpcmEncoder.Encode (GcAdpcmEncoder.cs:14) with caller-supplied coefs.
+ * coefs: nch*16.  sample_count == -1 means pcm_length (CodecParameters.SampleCount,
+ * VGAudio/Codecs/CodecParameters.cs:6); sample_count > pcm_length -> VGA_ERR_ARGUMENT
+ * (the reference's Array.Copy throws).  hist1/hist2: per-channel arrays (nch) or NULL for 0. */
+int vga_gcadpcm_encode_with_coefs_batch(const int16_t *const *pcm, int nch, int pcm_length,
+                                        int sample_count, const int16_t *coefs,
+                                        const int16_t *hist1, const int16_t *hist2,
+                                        uint8_t *const *adpcm_out);
+
+/* Replaces the body of GcAdpcmFormat.ToPcm16 (GcAdpcmFormat.cs:42-54 ->
+ * GcAdpcmChannel.GetPcmAudio -> GcAdpcmDecoder.Decode, GcAdpcmDecoder.cs:10-54).
+ * adpcm[c] holds sample_count_to_byte_count(sample_count) bytes, coefs nch*16,
+ * hist1/hist2 per-channel arrays or NULL; pcm_out[c] -> sample_count shorts.
+ * A predictor index > 7 in a frame header -> VGA_ERR_ARGUMENT (IndexOutOfRange in C#). */
+int vga_gcadpcm_decode_batch(const uint8_t *const *adpcm, const int16_t *coefs, int nch,
+                             int sample_count, const int16_t *hist1, const int16_t *hist2,
+                             int16_t *const *pcm_out);
+
+/* ---- dsptool-compatible single-channel exports -------------------------
+ * Same names/signatures as the cdecl entry points VGAudio.Tools binds from
+ * Nintendo's dsptool DLLs (VGAudio.Tools/GcAdpcm/DspToolDll.cs:16-29,94-108;
+ * struct layout VGAudio.Tools/GcAdpcm/Native.cs:18-32), so `VGAudio.Tools
+ * gcadpcm` can A/B this library unchanged as an "OpenSource"-type DLL. */
+#pragma pack(push, 1)
+typedef struct {
+    int16_t coef[16];
+    uint16_t gain;
+    uint16_t pred_scale;
+    int16_t yn1;
+    int16_t yn2;
+    uint16_t loop_pred_scale;
+    int16_t loop_yn1;
+    int16_t loop_yn2;
+} ADPCMINFO;
+#pragma pack(pop)
+
+void encode(int16_t *src, uint8_t *dst, ADPCMINFO *cxt, uint32_t samples);
+void decode(uint8_t *src, int16_t *dst, ADPCMINFO *cxt, uint32_t samples);
+void correlateCoefs(int16_t *src, uint32_t samples, int16_t *coefsOut);
+/* one 14-sample frame: src = 16 shorts (2 history + 14), reconstructed in place */
+void encodeFrame(int16_t *src, uint8_t *dst, int16_t *coefs, uint8_t one);
+
+/* ---- device-resident GC-ADPCM (inputs/outputs already in HBM) ----------
+ * d_pcm: planar, channel c at d_pcm + c*pcm_pitch (pitch in samples, even,
+ * base 4-byte aligned).  d_adpcm: channel c at d_adpcm + c*adpcm_pitch
+ * (bytes, multiple of 8, base 8-byte aligned).  stream: hipStream_t. */
+size_t vga_gcadpcm_coefs_workspace_bytes(int nch, int length);
+int vga_gcadpcm_coefs_device(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length,
+                             int16_t *d_coefs, void *d_workspace, size_t workspace_bytes,
+                             void *stream);
+int vga_gcadpcm_encode_device(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count,
+                              const int16_t *d_coefs, const int16_t *d_hist1, const int16_t *d_hist2,
+                              uint8_t *d_adpcm, int64_t adpcm_pitch, void *stream);
+int vga_gcadpcm_decode_device(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs,
+                              int nch, int sample_count, const int16_t *d_hist1, const int16_t *d_hist2,
+                              int16_t *d_pcm, int64_t pcm_pitch, int *d_status, void *stream);
+
+/* ======================================================================
+ * Synthetic PCM16 source for benchmarks/tests: integer-only,
+ * counter-based; bit-identical to vgaudio_amd/synth.py.  d_params: nch x 4
+ * uint32 {f_inc, phi, amp, lfo_inc}; channel ids first_channel..+nch.
+ * ====================================================================== */
+int vga_synth_pcm16_device(int16_t *d_pcm, int64_t pcm_pitch, int nch, int length,
+                           int first_channel, const uint32_t *d_params, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

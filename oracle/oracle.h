@@ -1,0 +1,104 @@
+/*
+ * oracle.h -- CPU restatement of the VGAudio codec hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / reported CPU baseline.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/src/VGAudio/).  The reference is C#; no .NET toolchain is
+ * available in this image, so the reference itself cannot be built.  Parity
+ * is pinned on the reference's own known-answer tests (see tests/), on
+ * hand-derivable vectors, and on encoder/decoder self-consistency.
+ *
+ * Numeric model reproduced: RyuJIT x64 (SSE2 scalar f32/f64, no FMA
+ * contraction, unchecked int32 wrap-around, arithmetic >>, truncating
+ * integer division, Math.Round = ties-to-even).
+ * Build flags: -O2 -ffp-contract=off -fexcess-precision=standard -fwrapv.
+ */
+#ifndef VGAUDIO_ORACLE_H
+#define VGAUDIO_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- GC-ADPCM size math: Codecs/GcAdpcm/GcAdpcmMath.cs:7-47 ---- */
+int vgo_gc_nibble_count_to_sample_count(int nibble_count);
+int vgo_gc_sample_count_to_nibble_count(int sample_count);
+int vgo_gc_nibble_to_sample(int nibble);
+int vgo_gc_sample_to_nibble(int sample);
+int vgo_gc_sample_count_to_byte_count(int sample_count);
+int vgo_gc_byte_count_to_sample_count(int byte_count);
+
+/* ---- GC-ADPCM codec ---- */
+/* Codecs/GcAdpcm/GcAdpcmCoefficients.cs:9-110 */
+void vgo_gc_calculate_coefficients(const int16_t *pcm, int length, int16_t coefs[16]);
+/* Codecs/GcAdpcm/GcAdpcmEncoder.cs:14-46.  sample_count == -1 -> pcm_length.
+ * out must hold vgo_gc_sample_count_to_byte_count(sample_count) bytes.
+ * Returns 0, or -1 if sample_count > pcm_length (the reference throws). */
+int vgo_gc_encode(const int16_t *pcm, int pcm_length, const int16_t coefs[16],
+                  int sample_count, int16_t hist1, int16_t hist2, uint8_t *out);
+/* Codecs/GcAdpcm/GcAdpcmEncoder.cs:48-94 (one frame, in/out 16 shorts). */
+void vgo_gc_encode_frame(int16_t pcm_inout[16], int sample_count, uint8_t adpcm_out[8],
+                         const int16_t coefs[16]);
+/* Codecs/GcAdpcm/GcAdpcmDecoder.cs:10-54 */
+void vgo_gc_decode(const uint8_t *adpcm, const int16_t coefs[16], int sample_count,
+                   int16_t hist1, int16_t hist2, int16_t *pcm_out);
+
+/* Formats/GcAdpcm/GcAdpcmFormat.cs:58-74,129-135 -- batch driver with the
+ * reference's scheduling (one task per channel on `threads` workers; the
+ * reference uses Parallel.For).  pcm: planar, channel c at pcm + c*pitch.
+ * adpcm_out: channel c at adpcm_out + c*out_pitch.  coefs_out: nch*16. */
+void vgo_gc_encode_batch(const int16_t *pcm, long pitch, int nch, int sample_count,
+                         int16_t *coefs_out, uint8_t *adpcm_out, long out_pitch,
+                         int threads);
+void vgo_gc_decode_batch(const uint8_t *adpcm, long in_pitch, const int16_t *coefs, int nch,
+                         int sample_count, int16_t *pcm_out, long out_pitch, int threads);
+
+/* Formats/GcAdpcm/GcAdpcmSeekTable.cs:25-38 (CreateSeekTable).
+ * table_out holds 2*ceil(n/samples_per_entry) shorts. */
+void vgo_gc_create_seek_table(const int16_t *pcm, int n, int samples_per_entry, int16_t *table_out);
+
+/* statistics of the last vgo_gc_encode call on this thread: number of
+ * quantise passes executed by DspEncodeCoef (GcAdpcmEncoder.cs:127-170)
+ * histogrammed by trip count 1..15 (index 0 unused). */
+void vgo_gc_trip_histogram(uint64_t hist_out[16]);
+
+/* ---- CRI ADX ---- Codecs/CriAdx/CriAdxCodec.cs */
+typedef struct {
+    int sample_rate;         /* 48000 */
+    int highpass_frequency;  /* 500 */
+    int frame_size;          /* 18 */
+    int version;             /* 4 */
+    int16_t history;         /* in/out for encode (CriAdxCodec.cs:73) */
+    int padding;
+    int type;                /* 2 Fixed, 3 Linear, 4 Exponential */
+    int filter;
+} vgo_adx_params;
+
+void vgo_adx_default_params(vgo_adx_params *p);
+/* CriAdxCodec.cs:173-184 */
+void vgo_adx_calculate_coefficients(int highpass_freq, int sample_rate, int16_t coefs[2]);
+/* number of bytes Encode allocates: frameCount * FrameSize (CriAdxCodec.cs:59-66) */
+int vgo_adx_encoded_size(int pcm_length, const vgo_adx_params *p);
+/* CriAdxCodec.cs:56-105; updates p->history like the reference */
+void vgo_adx_encode(const int16_t *pcm, int pcm_length, vgo_adx_params *p, uint8_t *out);
+/* CriAdxCodec.cs:9-54 */
+void vgo_adx_decode(const uint8_t *adpcm, int sample_count, const vgo_adx_params *p, int16_t *pcm_out);
+/* Formats/CriAdx/CriAdxHelpers.cs:7-31 */
+int vgo_adx_nibble_count_to_sample_count(int nibble_count, int frame_size);
+int vgo_adx_sample_count_to_nibble_count(int sample_count, int frame_size);
+int vgo_adx_sample_count_to_byte_count(int sample_count, int frame_size);
+void vgo_adx_encode_batch(const int16_t *pcm, long pitch, int nch, int pcm_length,
+                          const vgo_adx_params *p, uint8_t *out, long out_pitch,
+                          int16_t *history_out, int threads);
+void vgo_adx_decode_batch(const uint8_t *adpcm, long in_pitch, int nch, int sample_count,
+                          const vgo_adx_params *p, int16_t *pcm_out, long out_pitch, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

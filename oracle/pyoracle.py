@@ -1,0 +1,205 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module (see oracle/oracle.h).  The product package `vgaudio_amd` never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h")) or f == "Makefile"]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _declare(_LIB)
+    return _LIB
+
+
+class AdxParams(C.Structure):
+    _fields_ = [("sample_rate", C.c_int), ("highpass_frequency", C.c_int), ("frame_size", C.c_int),
+                ("version", C.c_int), ("history", C.c_int16), ("padding", C.c_int), ("type", C.c_int),
+                ("filter", C.c_int)]
+
+
+def _declare(L):
+    i16p, u8p, i = C.POINTER(C.c_int16), C.POINTER(C.c_uint8), C.c_int
+    for name in ("nibble_count_to_sample_count", "sample_count_to_nibble_count", "nibble_to_sample",
+                 "sample_to_nibble", "sample_count_to_byte_count", "byte_count_to_sample_count"):
+        f = getattr(L, "vgo_gc_" + name)
+        f.argtypes, f.restype = [i], i
+    L.vgo_gc_calculate_coefficients.argtypes = [i16p, i, i16p]
+    L.vgo_gc_calculate_coefficients.restype = None
+    L.vgo_gc_encode.argtypes = [i16p, i, i16p, i, C.c_int16, C.c_int16, u8p]
+    L.vgo_gc_encode.restype = i
+    L.vgo_gc_encode_frame.argtypes = [i16p, i, u8p, i16p]
+    L.vgo_gc_encode_frame.restype = None
+    L.vgo_gc_decode.argtypes = [u8p, i16p, i, C.c_int16, C.c_int16, i16p]
+    L.vgo_gc_decode.restype = None
+    L.vgo_gc_encode_batch.argtypes = [i16p, C.c_long, i, i, i16p, u8p, C.c_long, i]
+    L.vgo_gc_encode_batch.restype = None
+    L.vgo_gc_decode_batch.argtypes = [u8p, C.c_long, i16p, i, i, i16p, C.c_long, i]
+    L.vgo_gc_decode_batch.restype = None
+    L.vgo_gc_create_seek_table.argtypes = [i16p, i, i, i16p]
+    L.vgo_gc_create_seek_table.restype = None
+    L.vgo_gc_trip_histogram.argtypes = [C.POINTER(C.c_uint64)]
+    L.vgo_gc_trip_histogram.restype = None
+    ap = C.POINTER(AdxParams)
+    L.vgo_adx_default_params.argtypes = [ap]
+    L.vgo_adx_calculate_coefficients.argtypes = [i, i, i16p]
+    L.vgo_adx_encoded_size.argtypes = [i, ap]
+    L.vgo_adx_encoded_size.restype = i
+    L.vgo_adx_encode.argtypes = [i16p, i, ap, u8p]
+    L.vgo_adx_encode.restype = None
+    L.vgo_adx_decode.argtypes = [u8p, i, ap, i16p]
+    L.vgo_adx_decode.restype = None
+    for name in ("nibble_count_to_sample_count", "sample_count_to_nibble_count", "sample_count_to_byte_count"):
+        f = getattr(L, "vgo_adx_" + name)
+        f.argtypes, f.restype = [i, i], i
+    L.vgo_adx_encode_batch.argtypes = [i16p, C.c_long, i, i, ap, u8p, C.c_long, i16p, i]
+    L.vgo_adx_encode_batch.restype = None
+    L.vgo_adx_decode_batch.argtypes = [u8p, C.c_long, i, i, ap, i16p, C.c_long, i]
+    L.vgo_adx_decode_batch.restype = None
+
+
+def _i16(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int16))
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+# ---------------- GC-ADPCM ----------------
+def gc_sample_count_to_byte_count(n):
+    return lib().vgo_gc_sample_count_to_byte_count(int(n))
+
+
+def gc_calculate_coefficients(pcm):
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    coefs = np.zeros(16, dtype=np.int16)
+    lib().vgo_gc_calculate_coefficients(_i16(pcm), len(pcm), _i16(coefs))
+    return coefs
+
+
+def gc_encode(pcm, coefs, sample_count=-1, hist1=0, hist2=0):
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    coefs = np.ascontiguousarray(coefs, dtype=np.int16)
+    n = len(pcm) if sample_count == -1 else sample_count
+    out = np.zeros(gc_sample_count_to_byte_count(n), dtype=np.uint8)
+    rc = lib().vgo_gc_encode(_i16(pcm), len(pcm), _i16(coefs), sample_count, hist1, hist2, _u8(out))
+    if rc != 0:
+        raise ValueError("sample_count exceeds pcm length")
+    return out
+
+
+def gc_encode_frame(pcm16, coefs, sample_count=14):
+    buf = np.ascontiguousarray(pcm16, dtype=np.int16).copy()
+    coefs = np.ascontiguousarray(coefs, dtype=np.int16)
+    out = np.zeros(8, dtype=np.uint8)
+    lib().vgo_gc_encode_frame(_i16(buf), sample_count, _u8(out), _i16(coefs))
+    return out, buf
+
+
+def gc_decode(adpcm, coefs, sample_count, hist1=0, hist2=0):
+    adpcm = np.ascontiguousarray(adpcm, dtype=np.uint8)
+    coefs = np.ascontiguousarray(coefs, dtype=np.int16)
+    out = np.zeros(sample_count, dtype=np.int16)
+    lib().vgo_gc_decode(_u8(adpcm), _i16(coefs), sample_count, hist1, hist2, _i16(out))
+    return out
+
+
+def gc_trip_histogram():
+    h = (C.c_uint64 * 16)()
+    lib().vgo_gc_trip_histogram(h)
+    return np.array(list(h), dtype=np.uint64)
+
+
+def gc_encode_batch(pcm2d, threads=1):
+    """pcm2d: [nch, n] int16 -> (coefs [nch,16], adpcm [nch, bytes])"""
+    pcm2d = np.ascontiguousarray(pcm2d, dtype=np.int16)
+    nch, n = pcm2d.shape
+    nb = gc_sample_count_to_byte_count(n)
+    coefs = np.zeros((nch, 16), dtype=np.int16)
+    out = np.zeros((nch, nb), dtype=np.uint8)
+    lib().vgo_gc_encode_batch(_i16(pcm2d), n, nch, n, _i16(coefs), _u8(out), nb, threads)
+    return coefs, out
+
+
+def gc_decode_batch(adpcm2d, coefs, sample_count, threads=1):
+    adpcm2d = np.ascontiguousarray(adpcm2d, dtype=np.uint8)
+    coefs = np.ascontiguousarray(coefs, dtype=np.int16)
+    nch, nb = adpcm2d.shape
+    out = np.zeros((nch, sample_count), dtype=np.int16)
+    lib().vgo_gc_decode_batch(_u8(adpcm2d), nb, _i16(coefs), nch, sample_count, _i16(out), sample_count, threads)
+    return out
+
+
+def gc_create_seek_table(pcm, samples_per_entry):
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    entries = -(-len(pcm) // samples_per_entry)
+    out = np.zeros(entries * 2, dtype=np.int16)
+    lib().vgo_gc_create_seek_table(_i16(pcm), len(pcm), samples_per_entry, _i16(out))
+    return out
+
+
+# ---------------- ADX ----------------
+def adx_params(**kw):
+    p = AdxParams()
+    lib().vgo_adx_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def adx_calculate_coefficients(highpass, sample_rate):
+    c = np.zeros(2, dtype=np.int16)
+    lib().vgo_adx_calculate_coefficients(highpass, sample_rate, _i16(c))
+    return c
+
+
+def adx_encode(pcm, params):
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    out = np.zeros(lib().vgo_adx_encoded_size(len(pcm), C.byref(params)), dtype=np.uint8)
+    lib().vgo_adx_encode(_i16(pcm), len(pcm), C.byref(params), _u8(out))
+    return out
+
+
+def adx_decode(adpcm, sample_count, params):
+    adpcm = np.ascontiguousarray(adpcm, dtype=np.uint8)
+    out = np.zeros(sample_count, dtype=np.int16)
+    lib().vgo_adx_decode(_u8(adpcm), sample_count, C.byref(params), _i16(out))
+    return out
+
+
+def adx_encode_batch(pcm2d, params, threads=1):
+    pcm2d = np.ascontiguousarray(pcm2d, dtype=np.int16)
+    nch, n = pcm2d.shape
+    nb = lib().vgo_adx_encoded_size(n, C.byref(params))
+    out = np.zeros((nch, nb), dtype=np.uint8)
+    hist = np.zeros(nch, dtype=np.int16)
+    lib().vgo_adx_encode_batch(_i16(pcm2d), n, nch, n, C.byref(params), _u8(out), nb, _i16(hist), threads)
+    return out, hist
+
+
+def adx_decode_batch(adpcm2d, sample_count, params, threads=1):
+    adpcm2d = np.ascontiguousarray(adpcm2d, dtype=np.uint8)
+    nch, nb = adpcm2d.shape
+    out = np.zeros((nch, sample_count), dtype=np.int16)
+    lib().vgo_adx_decode_batch(_u8(adpcm2d), nb, nch, sample_count, C.byref(params), _i16(out), sample_count, threads)
+    return out

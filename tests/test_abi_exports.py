@@ -1,0 +1,60 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol that
+include/vgaudio_hip.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vgaudio_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//.*", "", text)
+    text = re.sub(r"^\s*#.*$", "", text, flags=re.M)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", text)
+    return sorted(set(names))
+
+
+def test_header_symbols_exported():
+    from vgaudio_amd import _lib
+    names = _declared_symbols()
+    assert "vga_gcadpcm_encode_batch" in names and "encodeFrame" in names
+    L = ctypes.CDLL(_lib.SO_PATH)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, f"not exported: {missing}"
+    # and the ctypes table covers the header
+    assert not [n for n in names if n not in _lib.SIGNATURES], "ctypes SIGNATURES missing entries"
+
+
+def test_host_side_size_math_needs_no_gpu():
+    from vgaudio_amd.gcadpcm import GcAdpcmMath
+    # Tests/Formats/GcAdpcm/GcAdpcmHelpersTests.cs:8-79
+    assert GcAdpcmMath.NibbleToSample(100010) == 87508
+    assert GcAdpcmMath.SampleToNibble(87508) == 100010
+    assert GcAdpcmMath.NibbleCountToSampleCount(100000) == 87500
+    assert GcAdpcmMath.SampleCountToNibbleCount(87500) == 100000
+    assert [GcAdpcmMath.SampleCountToByteCount(n) for n in (0, 1, 2, 3, 13, 14, 15, 87500)] == \
+        [0, 2, 2, 3, 8, 8, 10, 50000]
+
+
+def test_fails_loudly_without_device():
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import vgaudio_amd
+    from vgaudio_amd.gcadpcm import GcAdpcmCoefficients
+    with pytest.raises(vgaudio_amd.DeviceError):
+        GcAdpcmCoefficients.CalculateCoefficients(np.zeros(28, dtype=np.int16))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "vgaudio_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "pyoracle" not in src and "liboracle" not in src and "oracle/" not in src, f

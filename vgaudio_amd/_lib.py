@@ -1,0 +1,113 @@
+"""ctypes binding of libvgaudio_hip.so (the C ABI in include/vgaudio_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is
+visible, calls fail loudly (VgaError / OSError).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libvgaudio_hip.so")
+
+VGA_OK = 0
+VGA_ERR_ARGUMENT = -1
+VGA_ERR_OUT_OF_RANGE = -2
+VGA_ERR_INVALID_DATA = -3
+VGA_ERR_INVALID_OP = -4
+VGA_ERR_DEVICE = -5
+
+
+class VgaError(RuntimeError):
+    """Base class; subclasses mirror the .NET exception the reference throws."""
+    code = None
+
+
+class ArgumentError(VgaError, ValueError):           # ArgumentException
+    code = VGA_ERR_ARGUMENT
+
+
+class ArgumentOutOfRangeError(ArgumentError):        # ArgumentOutOfRangeException
+    code = VGA_ERR_OUT_OF_RANGE
+
+
+class InvalidDataError(VgaError):                    # InvalidDataException
+    code = VGA_ERR_INVALID_DATA
+
+
+class InvalidOperationError(VgaError):               # InvalidOperationException
+    code = VGA_ERR_INVALID_OP
+
+
+class DeviceError(VgaError):                         # HIP failure / no device
+    code = VGA_ERR_DEVICE
+
+
+_EXC = {e.code: e for e in (ArgumentError, ArgumentOutOfRangeError, InvalidDataError, InvalidOperationError,
+                            DeviceError)}
+
+_lib = None
+
+i16p = C.POINTER(C.c_int16)
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+i16pp = C.POINTER(i16p)
+u8pp = C.POINTER(u8p)
+vp = C.c_void_p
+i64 = C.c_int64
+ci = C.c_int
+
+
+class ADPCMINFO(C.Structure):
+    _pack_ = 1
+    _fields_ = [("coef", C.c_int16 * 16), ("gain", C.c_uint16), ("pred_scale", C.c_uint16), ("yn1", C.c_int16),
+                ("yn2", C.c_int16), ("loop_pred_scale", C.c_uint16), ("loop_yn1", C.c_int16), ("loop_yn2", C.c_int16)]
+
+
+# name -> (restype, argtypes); every symbol include/vgaudio_hip.h declares
+SIGNATURES = {
+    "vga_last_error": (C.c_char_p, []),
+    "vga_device_count": (ci, []),
+    "vga_set_device": (ci, [ci]),
+    "vga_version": (C.c_char_p, []),
+    "vga_gcadpcm_nibble_count_to_sample_count": (ci, [ci]),
+    "vga_gcadpcm_sample_count_to_nibble_count": (ci, [ci]),
+    "vga_gcadpcm_nibble_to_sample": (ci, [ci]),
+    "vga_gcadpcm_sample_to_nibble": (ci, [ci]),
+    "vga_gcadpcm_sample_count_to_byte_count": (ci, [ci]),
+    "vga_gcadpcm_byte_count_to_sample_count": (ci, [ci]),
+    "vga_gcadpcm_encode_batch": (ci, [i16pp, ci, ci, C.c_int16, C.c_int16, i16p, u8pp]),
+    "vga_gcadpcm_calculate_coefficients_batch": (ci, [i16pp, ci, ci, i16p]),
+    "vga_gcadpcm_encode_with_coefs_batch": (ci, [i16pp, ci, ci, ci, i16p, i16p, i16p, u8pp]),
+    "vga_gcadpcm_decode_batch": (ci, [u8pp, i16p, ci, ci, i16p, i16p, i16pp]),
+    "encode": (None, [i16p, u8p, C.POINTER(ADPCMINFO), C.c_uint32]),
+    "decode": (None, [u8p, i16p, C.POINTER(ADPCMINFO), C.c_uint32]),
+    "correlateCoefs": (None, [i16p, C.c_uint32, i16p]),
+    "encodeFrame": (None, [i16p, u8p, i16p, C.c_uint8]),
+    "vga_gcadpcm_coefs_workspace_bytes": (C.c_size_t, [ci, ci]),
+    "vga_gcadpcm_coefs_device": (ci, [vp, i64, ci, ci, vp, vp, C.c_size_t, vp]),
+    "vga_gcadpcm_encode_device": (ci, [vp, i64, ci, ci, vp, vp, vp, vp, i64, vp]),
+    "vga_gcadpcm_decode_device": (ci, [vp, i64, vp, ci, ci, vp, vp, vp, i64, vp, vp]),
+    "vga_synth_pcm16_device": (ci, [vp, i64, ci, ci, ci, vp, vp]),
+}
+
+
+def lib():
+    """Load the shared library (built in-tree by `python -m vgaudio_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise OSError(f"{SO_PATH} not found: run `python -m vgaudio_amd.build` (hipcc, gfx950). "
+                          "There is no CPU fallback.")
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc == VGA_OK:
+        return
+    msg = lib().vga_last_error().decode("utf-8", "replace")
+    raise _EXC.get(rc, VgaError)(msg or f"vgaudio_hip error {rc}")

@@ -1,0 +1,53 @@
+// common.hpp -- shared host-side helpers for libvgaudio_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/vgaudio_hip.h"
+
+namespace vga {
+
+void set_error(const char *fmt, ...);
+
+// status helper: HIP failure -> VGA_ERR_DEVICE with message
+#define VGA_HIP_TRY(expr)                                                              \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            vga::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                           __FILE__, __LINE__);                                        \
+            return VGA_ERR_DEVICE;                                                     \
+        }                                                                              \
+    } while (0)
+
+// RAII device buffer (host-buffer entry points only)
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) {
+        bytes = n;
+        return hipMalloc(&p, n ? n : 1);
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct Stream {
+    hipStream_t s = nullptr;
+    ~Stream() { if (s) (void)hipStreamDestroy(s); }
+    hipError_t create() { return hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
+};
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// fails loudly when no gfx950 device is present: there is no CPU fallback.
+int require_device();
+
+}  // namespace vga
