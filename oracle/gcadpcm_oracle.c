@@ -416,6 +416,9 @@ void vgo_gc_calculate_coefficients(const int16_t *source, int length, int16_t co
 /* ---------------- GcAdpcmEncoder.cs ---------------- */
 
 static __thread uint64_t g_trip_hist[16];
+static __thread int g_nonterminating;
+
+int vgo_gc_last_encode_hit_nontermination(void) { return g_nonterminating; }
 
 void vgo_gc_trip_histogram(uint64_t hist_out[16]) { memcpy(hist_out, g_trip_hist, sizeof g_trip_hist); }
 
@@ -484,6 +487,15 @@ static void dsp_encode_coef(const int16_t pcm_in[16], int sample_count, const in
             if (++scale_power >= 12)
                 scale_power = 11;
 
+        /* NON-TERMINATION HAZARD of the reference: when the pass at scalePower 12 still has
+           maxOverflow > 248, the bump loop above resets scalePower to 11 and the identical pass
+           repeats forever (reachable only when hostile coefs make the int32 predictor wrap; not
+           with CalculateCoefficients output, whose |c0| < 4096, |c1| < 2048).  The oracle stops
+           after the first pass at 12 and flags it; the HIP kernel has the same guard. */
+        if (scale_power < 12 && max_overflow > 1 && scale == (1 << 12) * 2048) {
+            g_nonterminating = 1;
+            break;
+        }
     } while (scale_power < 12 && max_overflow > 1);
 
     g_trip_hist[trips < 15 ? trips : 15]++;
@@ -541,6 +553,7 @@ int vgo_gc_encode(const int16_t *pcm, int pcm_length, const int16_t coefs[16], i
     if (sample_count == -1) sample_count = pcm_length;
     if (sample_count > pcm_length || sample_count < 0) return -1;
     memset(g_trip_hist, 0, sizeof g_trip_hist);
+    g_nonterminating = 0;
 
     int16_t pcm_buffer[2 + SAMPLES_PER_FRAME];
     uint8_t adpcm_buffer[BYTES_PER_FRAME];

@@ -66,6 +66,9 @@ void vgo_gc_create_seek_table(const int16_t *pcm, int n, int samples_per_entry, 
  * quantise passes executed by DspEncodeCoef (GcAdpcmEncoder.cs:127-170)
  * histogrammed by trip count 1..15 (index 0 unused). */
 void vgo_gc_trip_histogram(uint64_t hist_out[16]);
+/* 1 if the last vgo_gc_encode on this thread reached the state in which the reference's
+ * retry loop (GcAdpcmEncoder.cs:127-170) never terminates (see gcadpcm_oracle.c). */
+int vgo_gc_last_encode_hit_nontermination(void);
 
 /* ---- CRI ADX ---- Codecs/CriAdx/CriAdxCodec.cs */
 typedef struct {

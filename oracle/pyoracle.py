@@ -59,6 +59,8 @@ def _declare(L):
     L.vgo_gc_create_seek_table.restype = None
     L.vgo_gc_trip_histogram.argtypes = [C.POINTER(C.c_uint64)]
     L.vgo_gc_trip_histogram.restype = None
+    L.vgo_gc_last_encode_hit_nontermination.argtypes = []
+    L.vgo_gc_last_encode_hit_nontermination.restype = i
     ap = C.POINTER(AdxParams)
     L.vgo_adx_default_params.argtypes = [ap]
     L.vgo_adx_calculate_coefficients.argtypes = [i, i, i16p]
@@ -122,6 +124,10 @@ def gc_decode(adpcm, coefs, sample_count, hist1=0, hist2=0):
     out = np.zeros(sample_count, dtype=np.int16)
     lib().vgo_gc_decode(_u8(adpcm), _i16(coefs), sample_count, hist1, hist2, _i16(out))
     return out
+
+
+def gc_last_encode_hit_nontermination():
+    return bool(lib().vgo_gc_last_encode_hit_nontermination())
 
 
 def gc_trip_histogram():

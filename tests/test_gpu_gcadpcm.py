@@ -73,17 +73,23 @@ def test_encode_matches_oracle_edge_inputs_and_coefs(n):
     chans = _edge_channels(n, rng)
     names = list(chans)
     pcm = [chans[k] for k in names]
-    # real coefs, then hostile ones (int32 wrap-around in pred, GcAdpcmEncoder.cs:138)
+    # real coefs, then hostile ones.  |c| <= 16383 keeps the int32 predictor from wrapping, so the
+    # reference's retry loop provably terminates; the full-range set can reach the state where
+    # the reference loops forever (GcAdpcmEncoder.cs:166-170) -- oracle and kernel carry the same
+    # termination guard, and still have to agree byte for byte.
     real = np.stack([po.gc_calculate_coefficients(p) for p in pcm])
-    hostile = rng.integers(-32768, 32768, real.shape).astype(np.int16)
-    hostile[0] = 32767
-    hostile[1] = -32768
+    bounded = rng.integers(-16383, 16384, real.shape).astype(np.int16)
+    wrapping = rng.integers(-32768, 32768, real.shape).astype(np.int16)
+    wrapping[0] = 32767
+    wrapping[1] = -32768
     zero = np.zeros_like(real)
-    for coefs in (real, hostile, zero):
+    for label, coefs in (("real", real), ("bounded", bounded), ("zero", zero), ("wrapping", wrapping)):
         got = GcAdpcmEncoder.Encode(pcm, coefs)
         for i, name in enumerate(names):
             want = po.gc_encode(pcm[i], coefs[i])
-            assert (got[i] == want).all(), (name, int(np.argmax(got[i] != want)))
+            if label != "wrapping":
+                assert not po.gc_last_encode_hit_nontermination(), (label, name)
+            assert (got[i] == want).all(), (label, name, int(np.argmax(got[i] != want)))
 
 
 @pytest.mark.parametrize("n", [1, 2, 13, 14, 15, 27, 28, 29, 141])

@@ -152,3 +152,22 @@ def test_batch_matches_single():
     dec = po.gc_decode_batch(adpcm, coefs, pcm.shape[1], threads=2)
     for c in range(5):
         assert (po.gc_decode(adpcm[c], coefs[c], pcm.shape[1]) == dec[c]).all()
+
+
+def test_reference_nontermination_hazard_is_guarded_and_flagged():
+    """With coefficients large enough to wrap the int32 predictor the reference's retry loop
+    (GcAdpcmEncoder.cs:127-170) can repeat the scalePower-12 pass forever; the oracle stops and
+    flags it.  Coefficients from CalculateCoefficients never get there."""
+    n = 14 * 300 + 3
+    pcm = np.full(n, 32767, dtype=np.int16)
+    coefs = np.full(16, -32768, dtype=np.int16)
+    out = po.gc_encode(pcm, coefs)                    # returns (the C# reference would spin)
+    assert po.gc_last_encode_hit_nontermination()
+    assert len(out) == po.gc_sample_count_to_byte_count(n)
+    po.gc_encode(pcm, po.gc_calculate_coefficients(pcm))
+    assert not po.gc_last_encode_hit_nontermination()
+    rng = np.random.default_rng(3)
+    noise = rng.integers(-32768, 32768, n).astype(np.int16)
+    for _ in range(20):                               # |c| <= 16383: the predictor cannot wrap
+        po.gc_encode(noise, rng.integers(-16383, 16384, 16).astype(np.int16))
+        assert not po.gc_last_encode_hit_nontermination()

@@ -4,6 +4,7 @@ There is no CPU fallback: if the shared library is missing or no HIP device is
 visible, calls fail loudly (VgaError / OSError).
 """
 import ctypes as C
+import importlib.util
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -91,6 +92,24 @@ SIGNATURES = {
 }
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process: PyTorch wheels bundle their own libamdhip64 (SONAME
+    libamdhip64.so.7, same as /opt/rocm's).  If this library were loaded first it would bind
+    /opt/rocm's copy, torch would then load its own, and the second HSA runtime in the process
+    reports "no ROCm-capable device".  Pre-loading torch's copy (when torch is installed) makes
+    both resolve to the same runtime regardless of import order.  Without torch (C#/C++ hosts)
+    the system ROCm runtime is used."""
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load the shared library (built in-tree by `python -m vgaudio_amd.build`)."""
     global _lib
@@ -98,6 +117,7 @@ def lib():
         if not os.path.exists(SO_PATH):
             raise OSError(f"{SO_PATH} not found: run `python -m vgaudio_amd.build` (hipcc, gfx950). "
                           "There is no CPU fallback.")
+        _preload_torch_hip_runtime()
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)

@@ -165,12 +165,18 @@ __global__ __launch_bounds__(64) void gc_encode_kernel(
 
         int scale_power = initial_scale_power(x, c0, c1);
         PassResult r;
+        bool at_max;
         do {
             scale_power++;
+            at_max = scale_power >= 12;
             r = quantise_pass(x, c0, c1, scale_power);
             for (int v = r.max_overflow + 8; v > 256; v >>= 1)
                 if (++scale_power >= 12) scale_power = 11;
-        } while (scale_power < 12 && r.max_overflow > 1);
+            // TERMINATION GUARD: if the pass at scalePower 12 still overflows by > 248 the
+            // reference resets scalePower to 11 and repeats the identical pass forever
+            // (only reachable when coefs make the int32 predictor wrap; never with
+            // CalculateCoefficients output).  We stop after the first pass at 12.
+        } while (scale_power < 12 && r.max_overflow > 1 && !at_max);
 
         // argmin over the 8 predictors, first index wins ties (GcAdpcmEncoder.cs:66-76):
         // key = total<<3 | p is unique per lane; payload = the winner's history pair.

@@ -19,12 +19,18 @@ N_FREQ = 96
 _MASK64 = (1 << 64) - 1
 
 
+_FT = None
+
+
 def freq_table():
     """96 phase increments; inc[0] = 55 Hz @ 48 kHz; each step * 69433/65536 (~2^(1/12))."""
-    inc = [4921183]  # round(55 / 48000 * 2**32)
-    for _ in range(N_FREQ - 1):
-        inc.append((inc[-1] * 69433) >> 16)
-    return np.array(inc, dtype=np.uint32)
+    global _FT
+    if _FT is None:
+        inc = [4921183]  # round(55 / 48000 * 2**32)
+        for _ in range(N_FREQ - 1):
+            inc.append((inc[-1] * 69433) >> 16)
+        _FT = np.array(inc, dtype=np.uint32)
+    return _FT
 
 
 def _splitmix64(x):
