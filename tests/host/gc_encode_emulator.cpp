@@ -1,0 +1,99 @@
+// gc_encode_emulator.cpp -- host-side lane emulator of gc_encode_kernel's per-frame control
+// flow (16 lanes per channel: 8 predictors x 2 speculative scale candidates), built from
+// the SAME header the kernel uses (vgaudio_amd/csrc/gc_encode_core.hpp).  TEST ONLY: lets the
+// CPU suite check the exact-arithmetic shortcuts and the candidate-resolution state machine
+// against the oracle without a GPU.  Compiled by tests/test_host_gc_encode_core.py.
+#include "../../vgaudio_amd/csrc/gc_encode_core.hpp"
+#include <cstring>
+
+using namespace vga::gc;
+
+extern "C" {
+
+// exhaustive check of halvings() against the reference's while loop (GcAdpcmEncoder.cs:119-123)
+int emu_check_halvings(void)
+{
+    for (int md0 = -32768; md0 <= 32767; md0++) {
+        int md = md0, sp = 0;
+        while (sp <= 12 && (md > 7 || md < -8)) { md /= 2; sp++; }
+        if (sp != halvings(md0)) return md0 == 0 ? 1 : md0;
+    }
+    return 0;
+}
+
+// compare pass_fast against pass_literal on one frame; returns 0 ok, 1 mismatch, 2 fast not exact
+int emu_compare_pass(const int16_t *x16, int c0, int c1, int scale_power)
+{
+    int x[16];
+    for (int i = 0; i < 16; i++) x[i] = x16[i];
+    const PassOut f = pass_fast(x, c0, c1, scale_power);
+    if (!f.exact) return 2;
+    const PassOut l = pass_literal(x, c0, c1, scale_power);
+    const bool same = f.wa == l.wa && f.wb == l.wb && f.total == l.total && f.max_overflow == l.max_overflow &&
+                      f.o12 == l.o12 && f.o13 == l.o13;
+    return same ? 0 : 1;
+}
+
+// stats[0] frames, [1] lanes whose fast pass was inexact, [2] pairs resolved by A, [3] by B,
+// [4] pairs needing resume, [5] pre-scan ties, [6] frames taking the 64-bit argmin path
+int emu_encode(const int16_t *pcm, int sample_count, const int16_t *coefs, int16_t hist1, int16_t hist2,
+               uint8_t *out, uint64_t *stats)
+{
+    int x[16];
+    x[0] = hist2;
+    x[1] = hist1;
+    const int full_frames = sample_count / 14;
+    const int tail = sample_count - full_frames * 14;
+    const int frames = full_frames + (tail ? 1 : 0);
+    for (int f = 0; f < frames; f++) {
+        for (int s = 0; s < 14; s++) {
+            const int idx = f * 14 + s;
+            x[2 + s] = idx < sample_count ? pcm[idx] : 0;
+        }
+        stats[0]++;
+        uint64_t best_key = ~0ull;
+        int best_p = 0, best_sp = 0;
+        PassOut best = {};
+        bool wide = false;
+        for (int p = 0; p < 8; p++) {
+            const int c0 = coefs[2 * p], c1 = coefs[2 * p + 1];
+            // pre-scan split over the two candidate lanes (samples 0..6 / 7..13), then combined
+            int dmax_a = 0, dmin_a = 0, dmax_b = 0, dmin_b = 0;
+            prescan_range(x, c0, c1, 0, 7, dmax_a, dmin_a);
+            prescan_range(x, c0, c1, 7, 14, dmax_b, dmin_b);
+            int s1 = first_scale_power_from_range(imax(dmax_a, dmax_b), imin(dmin_a, dmin_b));
+            if (s1 == -100) {
+                stats[5]++;
+                s1 = first_scale_power_from_md(prescan_sequential(x, c0, c1));
+            }
+            PassOut cand[2];
+            for (int c = 0; c < 2; c++) {
+                const int sp = imin(s1 + c, 12);
+                cand[c] = pass_fast(x, c0, c1, sp);
+                if (!cand[c].exact) { stats[1]++; cand[c] = pass_literal(x, c0, c1, sp); }
+            }
+            const Resolve z = resolve_candidates(s1, cand[0].max_overflow, cand[1].max_overflow);
+            PassOut fin;
+            int fin_sp;
+            if (z.final_a) { fin = cand[0]; fin_sp = s1; stats[2]++; }
+            else if (z.final_b) { fin = cand[1]; fin_sp = s1 + 1; stats[3]++; }
+            else { fin = resume_passes(x, c0, c1, z.resume_sp, fin_sp); stats[4]++; }
+            if (fin.total >= (1ull << 28)) wide = true;
+            const uint64_t key = (fin.total << 4) | (uint64_t)(p << 1);
+            if (key < best_key) { best_key = key; best_p = p; best = fin; best_sp = fin_sp; }
+        }
+        if (wide) stats[6]++;
+        uint8_t frame[8];
+        uint32_t d0, d1;
+        frame_words(best, best_p, best_sp, d0, d1);
+        memcpy(frame, &d0, 4);
+        memcpy(frame + 4, &d1, 4);
+        const int nbytes = f < full_frames ? 8 : (tail + 2 + 1) / 2;
+        memcpy(out + (size_t)f * 8, frame, (size_t)nbytes);
+        x[0] = best.o12;
+        x[1] = best.o13;
+    }
+    return 0;
+}
+
+}  // extern "C"

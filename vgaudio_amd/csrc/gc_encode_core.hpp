@@ -1,0 +1,300 @@
+// gc_encode_core.hpp -- per-lane arithmetic of the GC-ADPCM frame encoder, shared by
+// the gfx950 kernel (gcadpcm_kernels.hip) and the host-side lane emulator that the
+// CPU test-suite uses to check these shortcuts against the literal reference formula
+// (tests/host/gc_encode_emulator.cpp).  No codec result is ever produced on the CPU in
+// the product path; the host build of this header exists for testing only.
+//
+// Reference: VGAudio/Codecs/GcAdpcm/GcAdpcmEncoder.cs:96-171 (DspEncodeCoef).
+//
+// Three exact reformulations of the reference's arithmetic are used; each is proven in
+// DESIGN.md "GC-ADPCM encode: exact shortcuts" and exercised exhaustively by the tests:
+//  (S1) pre-scan (:107-124): the signed maxDistance only needs max(d), min(d) over the
+//       frame unless +M and -M both occur (rare; sequential rescan then), and the
+//       halving loop has a closed form in clz().
+//  (S2) quantise (:140-144): (int)((double)((float)d / 2^k) +- 0.4999999f) equals
+//       (r + 2^(k-1) - 1 + (d < 0)) >> k  (arithmetic shift) with r = (int)(float)d.
+//  (S3) totalDistance (:161-162) is an exact integer; 32-bit accumulation is exact under the
+//       overflow bound checked per frame (pass_fast); otherwise the pass is redone literally
+//       with a 64-bit sum.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define VGA_HD __host__ __device__ __forceinline__
+#else
+#define VGA_HD inline
+#endif
+
+// 24-bit multiply (operands are 16/17-bit here) and an optimisation barrier that keeps hipcc from
+// re-associating the negated coefficients back into "mad, then subtract" (one extra dependent op).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VGA_MUL24(a, b) __mul24((a), (b))
+#define VGA_OPAQUE(v) asm("" : "+v"(v))
+#else
+#define VGA_MUL24(a, b) ((a) * (b))
+#define VGA_OPAQUE(v) ((void)0)
+#endif
+
+namespace vga {
+namespace gc {
+
+VGA_HD int imin(int a, int b) { return a < b ? a : b; }
+VGA_HD int imax(int a, int b) { return a > b ? a : b; }
+VGA_HD int clamp16i(int v) { return imin(imax(v, -32768), 32767); }
+VGA_HD int clamp4i(int v) { return imin(imax(v, -8), 7); }
+
+VGA_HD int bit_length(unsigned v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return v ? 32 - __builtin_clz(v) : 0;
+#else
+    int n = 0;
+    while (v) { n++; v >>= 1; }
+    return n;
+#endif
+}
+
+// number of `maxDistance /= 2` steps of GcAdpcmEncoder.cs:119-123 for a signed maxDistance
+// in [-32768, 32767]  (closed form of: while (sp <= 12 && (md > 7 || md < -8)) { md /= 2; sp++; })
+VGA_HD int halvings(int md)
+{
+    if (md >= 0) {
+        const int n = bit_length((unsigned)md) - 3;
+        return n > 0 ? n : 0;
+    }
+    const unsigned a = (unsigned)(-md);            // truncating /2 on a negative = halving the magnitude
+    int n = bit_length(a) - 4;
+    if (n < 0) n = 0;
+    if ((a >> n) > 8u) n++;
+    return n;
+}
+
+// literal sequential pre-scan (GcAdpcmEncoder.cs:107-115); used for the rare +M/-M tie
+VGA_HD int prescan_sequential(const int (&x)[16], int c0, int c1)
+{
+    int max_distance = 0;
+    for (int s = 0; s < 14; s++) {
+        const int predicted = (x[s] * c1 + x[s + 1] * c0) / 2048;
+        int distance = clamp16i(x[s + 2] - predicted);
+        const int ad = distance < 0 ? -distance : distance;
+        const int am = max_distance < 0 ? -max_distance : max_distance;
+        if (ad > am) max_distance = distance;
+    }
+    return max_distance;
+}
+
+// running max/min of the unclamped pre-scan distances of samples [s_begin, s_end)
+VGA_HD void prescan_range(const int (&x)[16], int c0, int c1, int s_begin, int s_end, int &dmax, int &dmin)
+{
+    for (int s = s_begin; s < s_end; s++) {
+        const int predicted = (x[s] * c1 + x[s + 1] * c0) / 2048;
+        const int d = x[s + 2] - predicted;
+        dmax = imax(dmax, d);
+        dmin = imin(dmin, d);
+    }
+}
+
+// Scale power of the FIRST quantise pass (value after the do-loop's first ++), given the
+// frame-wide max/min of the unclamped distances.  Returns -100 when the signed maximum is
+// ambiguous (+M and -M both present, M > 0): caller must use prescan_sequential().
+VGA_HD int first_scale_power_from_range(int dmax, int dmin)
+{
+    const int pos = imax(clamp16i(dmax), 0);
+    const int neg = imax(-clamp16i(dmin), 0);
+    if (pos == neg && pos != 0) return -100;
+    const int md = pos > neg ? pos : -neg;
+    const int n = halvings(md);
+    return n <= 1 ? 0 : n - 1;                      // (n<=1 ? -1 : n-2) + 1
+}
+
+VGA_HD int first_scale_power_from_md(int md)
+{
+    const int n = halvings(md);
+    return n <= 1 ? 0 : n - 1;
+}
+
+// scalePower after the overflow bump loop of GcAdpcmEncoder.cs:166-168
+VGA_HD int apply_bumps(int scale_power, int max_overflow)
+{
+    for (int v = max_overflow + 8; v > 256; v >>= 1)
+        if (++scale_power >= 12) scale_power = 11;
+    return scale_power;
+}
+
+struct PassOut {
+    uint32_t wa, wb;     // nibbles 0..5 / 6..13, big-endian nibble order (nibble 0 most significant)
+    uint64_t total;      // totalDistance
+    int max_overflow;
+    int o12, o13;        // reconstructed samples 12, 13
+    bool exact;          // false: the fast pass could not prove itself exact -> redo with pass_literal
+};
+
+VGA_HD uint32_t bswap32(uint32_t v)
+{
+    return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24);
+}
+
+// The 8 frame bytes as two little-endian dwords: byte 0 = header (predictor<<4 | scale),
+// bytes 1..7 = nibbles hi-first (GcAdpcmEncoder.cs:83-93).
+VGA_HD void frame_words(const PassOut &r, int predictor, int scale_power, uint32_t &d0, uint32_t &d1)
+{
+    const uint32_t header = (uint32_t)((predictor << 4) | (scale_power & 0xF));
+    d0 = bswap32((header << 24) | r.wa);
+    d1 = bswap32(r.wb);
+}
+
+// Literal quantise pass: the reference's own float/double formula (:127-164), 64-bit total.
+VGA_HD PassOut pass_literal(const int (&x)[16], int c0, int c1, int scale_power)
+{
+    PassOut r;
+    const int k = scale_power + 11;
+    const int scale = 1 << k;
+    union { uint32_t u; float f; } inv;
+    inv.u = (uint32_t)(127 - k) << 23;             // exact 2^-k: the f32 divide by 2^k is this multiply
+    uint32_t wa = 0, wb = 0;
+    uint64_t total = 0;
+    int max_overflow = 0;
+    int o0 = x[0], o1 = x[1];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int s = 0; s < 14; s++) {
+        const int predicted = o0 * c1 + o1 * c0;
+        const int distance = x[s + 2] * 2048 - predicted;
+        const float fq = (float)distance * inv.f;
+        const double half = (distance > 0) ? (double)0.4999999f : -(double)0.4999999f;
+        const int unclamped = (int)((double)fq + half);
+        const int q = clamp4i(unclamped);
+        const int ov = unclamped - q;
+        max_overflow = imax(max_overflow, ov < 0 ? -ov : ov);
+        if (s < 6) wa = (wa << 4) | ((uint32_t)q & 0xFu);
+        else       wb = (wb << 4) | ((uint32_t)q & 0xFu);
+        const int corrected = predicted + q * scale;
+        const int recon = clamp16i((corrected + 1024) >> 11);
+        const int d = x[s + 2] - recon;
+        total += (uint64_t)(uint32_t)(d * d);
+        o0 = o1;
+        o1 = recon;
+    }
+    r.wa = wa; r.wb = wb; r.total = total; r.max_overflow = max_overflow; r.o12 = o0; r.o13 = o1;
+    r.exact = true;
+    return r;
+}
+
+// r = (int)(float)d : the reference's int -> float rounding (round-to-nearest-even to 24 bits),
+// back as an integer.  |d| >= 2^31 - 64 rounds to 2^31, which does not fit: the hardware
+// conversion saturates (host: same by hand) and the caller's overflow limit rejects the frame.
+VGA_HD int round_through_f32(int d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)(float)d;                       // v_cvt_f32_i32 + v_cvt_i32_f32 (saturating)
+#else
+    const float f = (float)d;
+    if (f >= 2147483648.0f) return 2147483647;
+    return (int)f;
+#endif
+}
+
+// Fast quantise pass: integer-only, 9 dependent VALU ops per sample
+// (mad, cvt, cvt, add3, ashr, med3, lshl_add, ashr, med3) instead of the f32/f64 detour.
+//   d      = in*2048 - (o0*c1 + o1*c0)                       (two mads with negated coefs)
+//   r      = (int)(float)d                                   the reference's float rounding
+//   qb     = clamp(((r + bias8 + (d<0)) >> k), 0, 15)        biased nibble q+8; bias8 = 2^(k-1)-1 + 8*2^k   (S2)
+//   recon  = clamp16(((in*2048 + 1024 - 8*2^k - d) + (qb << k)) >> 11)
+// The nibbles are accumulated biased (one shift-or each) and un-biased by one XOR 0x888...8.
+// r.exact == false (frame must be redone with pass_literal) when the 32-bit sum of squared
+// errors could overflow (S3): with |c0|+|c1| <= 32767 the predictor cannot wrap, and then
+// |in - recon| <= (ov + 1/2) * 2^(k-11) + 2 where ov is the pass's max overflow; we require that
+// bound to stay <= 17 500 (14 * 17500^2 < 2^32), which also rules out int32 overflow in qb.
+VGA_HD PassOut pass_fast(const int (&x)[16], int c0, int c1, int scale_power)
+{
+    PassOut r;
+    const int k = scale_power + 11;
+    const int eight_k = 8 << k;
+    const int bias8 = (1 << (k - 1)) - 1 + eight_k;
+    int kconst = 1024 - eight_k;
+    int nc0 = -c0, nc1 = -c1;
+    VGA_OPAQUE(kconst);
+    VGA_OPAQUE(nc0);
+    VGA_OPAQUE(nc1);
+    uint32_t wa = 0, wb = 0;
+    uint32_t total = 0;
+    int qmax = 8, qmin = 8;                                         // biased: q + 8
+    int o0 = x[0], o1 = x[1];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int s = 0; s < 14; s++) {
+        const int in2048 = x[s + 2] * 2048;
+        int base = VGA_MUL24(o0, nc1) + in2048;                     // off the dependent chain (o0 is one step old)
+        VGA_OPAQUE(base);
+        const int d = VGA_MUL24(o1, nc0) + base;                    // == in2048 - predicted (mod 2^32)
+        const int rd = round_through_f32(d);
+        const int unclamped8 = (int)(rd + bias8 + (int)((uint32_t)d >> 31)) >> k;
+        const int qb = imin(imax(unclamped8, 0), 15);
+        qmax = imax(qmax, unclamped8);
+        qmin = imin(qmin, unclamped8);
+        if (s < 6) wa = (wa << 4) | (uint32_t)qb;
+        else       wb = (wb << 4) | (uint32_t)qb;
+        const int pr = (in2048 + kconst) - d;                       // predicted + 1024 - 8*2^k
+        const int recon = clamp16i((pr + (int)((uint32_t)qb << k)) >> 11);
+        const int e = x[s + 2] - recon;
+        total += (uint32_t)VGA_MUL24(e, e);
+        o0 = o1;
+        o1 = recon;
+    }
+    const int ov = imax(imax(qmax - 15, -qmin), 0);                // max(q-7, -8-q, 0) on the biased values
+    const int ac0 = c0 < 0 ? -c0 : c0, ac1 = c1 < 0 ? -c1 : c1;
+    r.exact = ac0 + ac1 <= 32767 && ov <= 17497 && (((2 * ov + 1) << (k - 11)) <= 34996);
+    r.wa = wa ^ 0x00888888u;
+    r.wb = wb ^ 0x88888888u;
+    r.total = total;
+    r.max_overflow = ov;
+    r.o12 = o0; r.o13 = o1;
+    return r;
+}
+
+// ---- speculative two-candidate resolution --------------------------------------------
+// Lane A ran the pass at s1, lane B at s1+1 (the scale the reference tries next when A
+// overflows without a bump).  From the two overflows alone every lane can tell which of
+// the two passes (if any) is the one the reference's do-loop ends on.
+struct Resolve {
+    bool final_a;        // the reference stops after the pass at s1
+    bool final_b;        // ... after the pass at s1+1
+    int resume_sp;       // otherwise: value of scalePower when the do-loop is re-entered
+};
+
+VGA_HD Resolve resolve_candidates(int s1, int ov_a, int ov_b)
+{
+    Resolve z;
+    z.final_a = z.final_b = false;
+    z.resume_sp = 0;
+    const int sp_a = apply_bumps(s1, ov_a);
+    if (!(sp_a < 12 && ov_a > 1)) { z.final_a = true; return z; }
+    if (sp_a != s1) { z.resume_sp = sp_a; return z; }        // bumped: next pass is not s1+1
+    const int s2 = s1 + 1;
+    const int sp_b = apply_bumps(s2, ov_b);
+    if (!(sp_b < 12 && ov_b > 1)) { z.final_b = true; return z; }
+    z.resume_sp = sp_b;
+    return z;
+}
+
+// Continue the reference's do-loop from `scale_power` (value before the ++).
+// Includes the termination guard documented in gcadpcm_kernels.hip / oracle.
+VGA_HD PassOut resume_passes(const int (&x)[16], int c0, int c1, int scale_power, int &final_sp)
+{
+    PassOut r;
+    bool at_max;
+    do {
+        scale_power++;
+        at_max = scale_power >= 12;
+        r = pass_fast(x, c0, c1, scale_power);
+        if (!r.exact) r = pass_literal(x, c0, c1, scale_power);
+        scale_power = apply_bumps(scale_power, r.max_overflow);
+    } while (scale_power < 12 && r.max_overflow > 1 && !at_max);
+    final_sp = scale_power;     // the reference's `out scalePower` (== the pass scale on a regular exit)
+    return r;
+}
+
+}  // namespace gc
+}  // namespace vga

@@ -118,7 +118,7 @@ __device__ __forceinline__ void unpack_frame(const uint32_t (&w)[7], int (&x)[16
     }
 }
 
-__global__ __launch_bounds__(64) void gc_encode_kernel(
+__global__ __launch_bounds__(64) void gc_encode_kernel_v1(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int sample_count,
     const int16_t *__restrict__ coefs, const int16_t *__restrict__ hist1,
     const int16_t *__restrict__ hist2, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch)
@@ -726,12 +726,12 @@ int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, i
     return VGA_OK;
 }
 
-int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
+int launch_encode_v1(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
                   const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,
                   hipStream_t stream)
 {
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
-    hipLaunchKernelGGL(gc_encode_kernel, dim3((nch + 7) / 8), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
+    hipLaunchKernelGGL(gc_encode_kernel_v1, dim3((nch + 7) / 8), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
                        sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch);
     VGA_HIP_TRY(hipGetLastError());
     return VGA_OK;
