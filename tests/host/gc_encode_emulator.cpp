@@ -72,7 +72,9 @@ int emu_encode(const int16_t *pcm, int sample_count, const int16_t *coefs, int16
                 cand[c] = pass_fast(x, c0, c1, sp);
                 if (!cand[c].exact) { stats[1]++; cand[c] = pass_literal(x, c0, c1, sp); }
             }
-            const Resolve z = resolve_candidates(s1, cand[0].max_overflow, cand[1].max_overflow);
+            const bool bump = imax(cand[0].max_overflow, cand[1].max_overflow) > 248;
+            const Resolve z = bump ? resolve_candidates(s1, cand[0].max_overflow, cand[1].max_overflow)
+                                   : resolve_candidates_nobump(s1, cand[0].max_overflow, cand[1].max_overflow);
             PassOut fin;
             int fin_sp;
             if (z.final_a) { fin = cand[0]; fin_sp = s1; stats[2]++; }

@@ -279,6 +279,17 @@ VGA_HD Resolve resolve_candidates(int s1, int ov_a, int ov_b)
     return z;
 }
 
+// Same decision when neither overflow can trigger the bump loop (max_overflow + 8 <= 256):
+// straight-line, no loops -- the kernel's common path.
+VGA_HD Resolve resolve_candidates_nobump(int s1, int ov_a, int ov_b)
+{
+    Resolve z;
+    z.final_a = !(s1 < 12 && ov_a > 1);
+    z.final_b = !z.final_a && !(s1 + 1 < 12 && ov_b > 1);
+    z.resume_sp = s1 + 1;
+    return z;
+}
+
 // Continue the reference's do-loop from `scale_power` (value before the ++).
 // Includes the termination guard documented in gcadpcm_kernels.hip / oracle.
 VGA_HD PassOut resume_passes(const int (&x)[16], int c0, int c1, int scale_power, int &final_sp)

@@ -114,8 +114,10 @@ __global__ __launch_bounds__(64) void gc_encode_kernel(
             if (!r.exact) r = pass_literal(x, c0, c1, final_sp);
         }
         const int ov_other = dpp<DPP_QUAD_XOR1>(r.max_overflow);
-        const Resolve z = resolve_candidates(s1, cand_b ? ov_other : r.max_overflow,
-                                             cand_b ? r.max_overflow : ov_other);
+        const int ov_a = cand_b ? ov_other : r.max_overflow;
+        const int ov_b = cand_b ? r.max_overflow : ov_other;
+        Resolve z = resolve_candidates_nobump(s1, ov_a, ov_b);
+        if (__any(imax(ov_a, ov_b) > 248)) z = resolve_candidates(s1, ov_a, ov_b);   // bump loop: rare
         bool fin = cand_b ? z.final_b : z.final_a;
         const bool resume = !cand_b && !z.final_a && !z.final_b;
         if (__any(resume)) {

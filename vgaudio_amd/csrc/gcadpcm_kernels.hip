@@ -23,6 +23,8 @@
 #include "common.hpp"
 #include "gcadpcm_kernels.hpp"
 
+#include <cstdlib>
+
 namespace vga {
 namespace gc {
 
@@ -514,7 +516,7 @@ __device__ __forceinline__ void load_frame16(const int16_t *src, int f, int leng
 
 // One workgroup per channel; whole CalculateCoefficients (:9-110).
 // records: [nch][frames] double2 scratch in HBM (NaN r1 marks "no record").
-__global__ __launch_bounds__(COEF_BLOCK) void gc_coefs_kernel(
+__global__ __launch_bounds__(COEF_BLOCK) void gc_coefs_kernel_v1(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int length,
     double2 *__restrict__ records, int16_t *__restrict__ coefs_out)
 {
@@ -676,6 +678,199 @@ __global__ __launch_bounds__(COEF_BLOCK) void gc_coefs_kernel(
     }
 }
 
+// ---------------------------------------------------------------- coefficients, v2
+// One WAVE per channel, no cross-wave synchronisation, high occupancy (the chip's VALU
+// throughput needs >= 4 waves per SIMD; tools/ubench_valu.hip).  Per 64-record chunk:
+//   1. every lane: record -> (bucket index, d1, d2)            [parallel]
+//   2. stable partition of the chunk by bucket (ballot + mbcnt) into one compacted LDS array:
+//      bucket b occupies [start_b, start_b + n_b), in record order
+//   3. lane (bucket, component) adds ITS bucket's entries in order -> the f64 roundings are
+//      the reference's (GcAdpcmCoefficients.cs:67-72, :383-385); the loop runs max_b n_b
+//      iterations instead of 64 compare-and-add steps per accumulator.
+// MatrixFilter's mtx[1][1] and ContrastVectors' `val` are the same expression
+// ((r2*r1 + -r1) / (1 - r2*r2), sign flips are exact), so one f64 divide serves both.
+__device__ __forceinline__ int lane_rank(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+__global__ __launch_bounds__(64) void gc_coefs_kernel(
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int length,
+    double2 *__restrict__ records, int16_t *__restrict__ coefs_out)
+{
+    __shared__ double s_d[2][64];      // compacted (d1, d2) of the current chunk, bucket-major
+    __shared__ double s_vb[8][3];      // vecBest
+    __shared__ double s_cw[8][3];      // val1, val2, val3 of ContrastVectors per codeword
+    __shared__ double s_sum[8][3];     // bufferList
+    __shared__ int s_cnt[8];           // buffer1
+
+    const int ch = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
+    const int frames = (length + 13) / 14;
+    double2 *rec = records + (int64_t)ch * frames;
+    const int my_bucket = lane >> 1;   // accumulator lanes: lane < 16
+    const int my_comp = lane & 1;
+
+    // ---- pass 0: per-frame records (:40-61) + ordered mean of MatrixFilter outputs (:63-74)
+    double acc = 0.0;
+    int cnt = 0;
+    for (int base = 0; base < frames; base += 64) {
+        const int f = base + lane;
+        bool valid = false;
+        double d1 = 0.0, d2 = 0.0;
+        if (f < frames) {
+            int x[16];
+            load_frame16(src, f, length, x);
+            const Record r = frame_record(x);
+            valid = r.valid;
+            if (valid) {
+                matrix_filter(r.r1, r.r2, d1, d2);
+                rec[f] = make_double2(r.r1, r.r2);
+            } else {
+                rec[f] = make_double2(__builtin_nan(""), 0.0);
+            }
+        }
+        const uint64_t mask = __ballot(valid);
+        const int n = __popcll(mask);
+        if (valid) {
+            const int slot = lane_rank(mask);
+            s_d[0][slot] = d1;
+            s_d[1][slot] = d2;
+        }
+        __syncthreads();
+        if (lane < 2)
+            for (int i = 0; i < n; i++) acc += s_d[lane][i];
+        cnt += n;
+        __syncthreads();
+    }
+    if (lane < 2) s_sum[0][1 + lane] = acc;
+    __syncthreads();
+    if (lane == 0) {
+        double vec1[3];
+        vec1[0] = 1.0;
+        vec1[1] = s_sum[0][1];
+        vec1[2] = s_sum[0][2];
+        vec1[1] /= cnt;
+        vec1[2] /= cnt;
+        double vb[3];
+        merge_finish_record(vec1, vb);
+        s_vb[0][0] = vb[0]; s_vb[0][1] = vb[1]; s_vb[0][2] = vb[2];
+    }
+    __syncthreads();
+
+    // ---- 3 splits x 2 Lloyd iterations (:77-91, FilterRecords :344-396)
+    for (int w = 0; w < 3; w++) {
+        const int half = 1 << w;
+        const int exp = 2 << w;
+        if (lane < half) {
+            s_vb[half + lane][0] = (0.01 * 0.0) + s_vb[lane][0];
+            s_vb[half + lane][1] = (0.01 * -1.0) + s_vb[lane][1];
+            s_vb[half + lane][2] = (0.01 * 0.0) + s_vb[lane][2];
+        }
+        __syncthreads();
+
+        for (int iter = 0; iter < 2; iter++) {
+            if (lane < exp) {
+                const double a = s_vb[lane][0], b = s_vb[lane][1], c = s_vb[lane][2];
+                s_cw[lane][0] = (a * a) + (b * b) + (c * c);
+                s_cw[lane][1] = (a * b) + (b * c);
+                s_cw[lane][2] = a * c;
+            }
+            __syncthreads();
+            double cw1[8], cw2[8], cw3[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                cw1[i] = s_cw[i < exp ? i : 0][0];
+                cw2[i] = s_cw[i < exp ? i : 0][1];
+                cw3[i] = s_cw[i < exp ? i : 0][2];
+            }
+
+            acc = 0.0;
+            cnt = 0;
+            for (int base = 0; base < frames; base += 64) {
+                const int f = base + lane;
+                bool valid = false;
+                int idx = 0;
+                double d1 = 0.0, d2 = 0.0;
+                if (f < frames) {
+                    const double2 r = rec[f];
+                    if (r.x == r.x) {
+                        valid = true;
+                        // ContrastVectors :335-342 (val) == MatrixFilter :295-296 (mtx[1][1])
+                        const double val = (r.y * r.x + -r.x) / (1.0 - r.y * r.y);
+                        const double bterm = (-r.x * val + -r.y);
+                        const double val_x2 = 2.0 * val, bterm_x2 = 2.0 * bterm;
+                        double value = 1.0e30;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            if (i < exp) {
+                                const double t = cw1[i] + (val_x2 * cw2[i]) + (bterm_x2 * cw3[i]);
+                                if (t < value) { value = t; idx = i; }
+                            }
+                        }
+                        d1 = 0.0 + val * 1.0;                       // dst[1] = 0.0 + mtx[1][1]*dst[0]
+                        d2 = (0.0 + (-r.x) * d1) + (-r.y) * 1.0;    // dst[2]
+                    }
+                }
+                // stable partition by bucket
+                int slot = 0, my_start = 0, my_n = 0, start = 0, max_n = 0;
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    if (b < exp) {
+                        const bool mine = valid && idx == b;
+                        const uint64_t m = __ballot(mine);
+                        const int n_b = __popcll(m);
+                        if (mine) slot = start + lane_rank(m);
+                        if (my_bucket == b) { my_start = start; my_n = n_b; }
+                        start += n_b;
+                        max_n = max(max_n, n_b);
+                    }
+                }
+                if (valid) {
+                    s_d[0][slot] = d1;
+                    s_d[1][slot] = d2;
+                }
+                __syncthreads();
+                if (lane < 16) {
+                    const double *sd = &s_d[my_comp][my_start];
+                    for (int i = 0; i < max_n; i++)
+                        if (i < my_n) acc += sd[i];
+                    cnt += my_n;
+                }
+                __syncthreads();
+            }
+            if (lane < 2 * exp) {
+                s_sum[my_bucket][1 + my_comp] = acc;
+                if (my_comp == 0) s_cnt[my_bucket] = cnt;
+            }
+            __syncthreads();
+            if (lane < exp) {
+                double bl[3];
+                const int n = s_cnt[lane];
+                bl[0] = (double)n;                  // bufferList[i][0] sums 1.0 per record
+                bl[1] = s_sum[lane][1];
+                bl[2] = s_sum[lane][2];
+                if (n > 0) { bl[0] /= n; bl[1] /= n; bl[2] /= n; }
+                double vb[3] = {s_vb[lane][0], s_vb[lane][1], s_vb[lane][2]};
+                merge_finish_record(bl, vb);
+                s_vb[lane][0] = vb[0]; s_vb[lane][1] = vb[1]; s_vb[lane][2] = vb[2];
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- output :94-108
+    if (lane < 16) {
+        const int z = lane >> 1;
+        const double d = -s_vb[z][1 + (lane & 1)] * 2048.0;
+        int out;
+        if (d > 0.0) out = (d > 32767.0) ? 32767 : (int)__builtin_rint(d);
+        else out = (d < -32768.0) ? -32768 : ((d != d) ? 0 : (int)__builtin_rint(d));
+        coefs_out[ch * 16 + lane] = (int16_t)out;
+    }
+}
+
 // ---------------------------------------------------------------- synthetic PCM (synth.py)
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 {
@@ -720,8 +915,17 @@ int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, i
                  void *d_workspace, hipStream_t stream)
 {
     if (nch <= 0) return VGA_OK;
-    hipLaunchKernelGGL(gc_coefs_kernel, dim3(nch), dim3(COEF_BLOCK), 0, stream, d_pcm, pcm_pitch, nch, length,
-                       reinterpret_cast<double2 *>(d_workspace), d_coefs);
+    // A/B switch for measurements only: VGA_GC_COEFS_IMPL=v1 selects the first kernel
+    static const bool use_v1 = [] {
+        const char *e = getenv("VGA_GC_COEFS_IMPL");
+        return e && e[0] == 'v' && e[1] == '1';
+    }();
+    if (use_v1)
+        hipLaunchKernelGGL(gc_coefs_kernel_v1, dim3(nch), dim3(COEF_BLOCK), 0, stream, d_pcm, pcm_pitch, nch, length,
+                           reinterpret_cast<double2 *>(d_workspace), d_coefs);
+    else
+        hipLaunchKernelGGL(gc_coefs_kernel, dim3(nch), dim3(64), 0, stream, d_pcm, pcm_pitch, nch, length,
+                           reinterpret_cast<double2 *>(d_workspace), d_coefs);
     VGA_HIP_TRY(hipGetLastError());
     return VGA_OK;
 }
