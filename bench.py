@@ -45,6 +45,23 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cpus():
+    """CPUs this process may actually use: min(affinity, cgroup quota).  The GPU box reports 256
+    logical CPUs but caps the container with cpu.max (e.g. 1600000/100000 = 16 CPUs)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"{os.cpu_count()} logical CPUs visible"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period) + 0.5))
+            if q < n:
+                note += f", cgroup cpu.max limits this container to {q}"
+                n = q
+    except (OSError, ValueError):
+        pass
+    return n, note
+
+
 def main():
     args = parse()
     import numpy as np
@@ -150,8 +167,8 @@ def main():
 
         cpu = None
         if not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
-            cch = args.cpu_channels or min(nch, max(2 * threads, min(12 * threads, 1536)))
+            threads, cpu_note = usable_cpus()
+            cch = args.cpu_channels or min(nch, 24 * threads)
             host = pcm[:cch, :n].cpu().numpy()
             po.lib()
             t1 = time.perf_counter()
@@ -159,8 +176,8 @@ def main():
             dt = time.perf_counter() - t1
             cpu = {"value": round(cch * n / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
                    "sample": f"{cch} of the same channels x {n} samples, one task per channel on {threads} threads "
-                             f"(C restatement of GcAdpcmFormat.EncodeFromPcm16; the C# reference cannot be built here), "
-                             f"{dt:.1f} s wall"}
+                             f"({cpu_note}); C restatement of GcAdpcmFormat.EncodeFromPcm16 (the C# reference cannot "
+                             f"be built here), {dt:.1f} s wall"}
 
         out = {"metric": "Msamples/s encoded (GC-ADPCM, 4096 ch) at 1/2/4/8 GPUs; % HBM roofline",
                "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,

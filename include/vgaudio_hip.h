@@ -130,6 +130,54 @@ int vga_gcadpcm_decode_device(const uint8_t *d_adpcm, int64_t adpcm_pitch, const
                               int16_t *d_pcm, int64_t pcm_pitch, int *d_status, void *stream);
 
 /* ======================================================================
+ * CRI ADX
+ * ====================================================================== */
+
+/* VGAudio/Codecs/CriAdx/CriAdxParameters.cs:5-12 (same fields, same defaults via
+ * vga_adx_default_params).  type: 2 Fixed, 3 Linear, 4 Exponential (CriAdxType.cs). */
+typedef struct {
+    int sample_rate;        /* 48000 */
+    int highpass_frequency; /* 500 */
+    int frame_size;         /* 18 */
+    int version;            /* 4 */
+    int16_t history;        /* decoder start history (CriAdxCodec.cs:16-17) */
+    int padding;            /* alignment samples (CriAdxFormat.cs:62) */
+    int type;               /* 3 */
+    int filter;             /* Fixed type only: 0..3 */
+} vga_adx_params;
+
+void vga_adx_default_params(vga_adx_params *p);
+/* CriAdxCodec.CalculateCoefficients (CriAdxCodec.cs:173-184) */
+int vga_adx_calculate_coefficients(int highpass_freq, int sample_rate, int16_t *coefs_out /*[2]*/);
+/* VGAudio/Formats/CriAdx/CriAdxHelpers.cs:7-31 */
+int vga_adx_nibble_count_to_sample_count(int nibble_count, int frame_size);
+int vga_adx_sample_count_to_nibble_count(int sample_count, int frame_size);
+int vga_adx_sample_count_to_byte_count(int sample_count, int frame_size);
+/* bytes CriAdxCodec.Encode allocates: ceil((pcm_length + padding) / samplesPerFrame) * FrameSize
+ * (CriAdxCodec.cs:59-66); negative on invalid parameters */
+int vga_adx_encoded_byte_count(int pcm_length, const vga_adx_params *p);
+
+/* Replaces the Parallel.For body of CriAdxFormat.EncodeFromPcm16 (Formats/CriAdx/CriAdxFormat.cs:67-81
+ * -> CriAdxCodec.Encode, CriAdxCodec.cs:56-105).  pcm[c]: pcm_length shorts; out[c]:
+ * vga_adx_encoded_byte_count bytes; history_out[c] (may be NULL) receives channelConfig.History
+ * (= pcm[c][0] for version 4 without padding, CriAdxCodec.cs:73).  Empty PCM with version 4 and
+ * no padding -> VGA_ERR_ARGUMENT (the reference reads pcm[0]). */
+int vga_adx_encode_batch(const int16_t *const *pcm, int nch, int pcm_length, const vga_adx_params *p,
+                         uint8_t *const *out, int16_t *history_out);
+/* Replaces the Parallel.For body of CriAdxFormat.ToPcm16 (CriAdxFormat.cs:37-49 -> CriAdxCodec.Decode,
+ * CriAdxCodec.cs:9-54).  adpcm[c]: adpcm_length bytes each.  A stream shorter than the decoder
+ * reads, or a frame naming a filter outside the coefficient table, -> VGA_ERR_ARGUMENT. */
+int vga_adx_decode_batch(const uint8_t *const *adpcm, int adpcm_length, int nch, int sample_count,
+                         const vga_adx_params *p, int16_t *const *pcm_out);
+/* device-resident variants (pitches: pcm in samples, bytes for ADX data and even) */
+int vga_adx_encode_device(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_length,
+                          const vga_adx_params *p, uint8_t *d_out, int64_t out_pitch,
+                          int16_t *d_history_out, void *stream);
+int vga_adx_decode_device(const uint8_t *d_adpcm, int64_t in_pitch, int adpcm_length, int nch,
+                          int sample_count, const vga_adx_params *p, int16_t *d_pcm,
+                          int64_t pcm_pitch, int *d_status, void *stream);
+
+/* ======================================================================
  * Synthetic PCM16 source for benchmarks/tests: integer-only,
  * counter-based; bit-identical to vgaudio_amd/synth.py.  d_params: nch x 4
  * uint32 {f_inc, phi, amp, lfo_inc}; channel ids first_channel..+nch.

@@ -1,0 +1,109 @@
+"""GPU parity tests for CRI ADX (BASELINE config 3 shape at reduced channel count): the HIP
+path through the C ABI must be bit-exact with the CPU oracle for encode and decode."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from vgaudio_amd import synth
+from vgaudio_amd.criadx import CriAdxCodec, CriAdxFormat, CriAdxParameters, CriAdxType
+from vgaudio_amd.gcadpcm import Pcm16Format
+
+pytestmark = pytest.mark.gpu
+
+CASES = [dict(Type=3), dict(Type=4), dict(Type=2, Filter=0), dict(Type=2, Filter=1), dict(Type=2, Filter=2),
+         dict(Type=2, Filter=3), dict(Type=3, Version=3), dict(Type=4, Version=3), dict(Type=3, FrameSize=34),
+         dict(Type=3, Padding=70), dict(Type=4, Padding=33), dict(Type=2, Filter=2, Padding=64),
+         dict(Type=3, SampleRate=22050)]
+
+
+def _op(kw):
+    m = dict(Type="type", Filter="filter", Version="version", FrameSize="frame_size", Padding="padding",
+             SampleRate="sample_rate", History="history", HighpassFrequency="highpass_frequency")
+    return po.adx_params(**{m[k]: v for k, v in kw.items()})
+
+
+def _edge_channels(n, rng):
+    t = np.arange(n)
+    return [synth.generate(1, n)[0], synth.sine(n), np.zeros(n, np.int16),
+            np.where((t // 5) % 2 == 0, 32767, -32768).astype(np.int16),
+            rng.integers(-32768, 32768, n).astype(np.int16), rng.integers(-4, 5, n).astype(np.int16),
+            np.full(n, -32768, np.int16), np.where(t % 61 == 0, 32767, 0).astype(np.int16)]
+
+
+@pytest.mark.parametrize("kw", CASES, ids=[str(c) for c in CASES])
+@pytest.mark.parametrize("n", [32 * 300, 32 * 300 + 13])
+def test_encode_decode_match_oracle(kw, n):
+    rng = np.random.default_rng(n)
+    chans = _edge_channels(n, rng)
+    cfg = CriAdxParameters(**kw)
+    enc = CriAdxCodec.Encode(chans, cfg)
+    for i, pcm in enumerate(chans):
+        p = _op(kw)
+        want = po.adx_encode(pcm, p)
+        assert len(enc[i]) == len(want) and (enc[i] == want).all(), (i, int(np.argmax(enc[i] != want)))
+        assert int(np.atleast_1d(cfg.History)[i]) == p.history
+    # decoder: CriAdxFormat.ToPcm16 starts from History 0 (CriAdxFormat.cs:39-48)
+    dkw = {k: v for k, v in kw.items() if k != "Filter"}
+    dec = CriAdxCodec.Decode(enc, n, CriAdxParameters(**dkw))
+    for i in range(len(chans)):
+        want = po.adx_decode(enc[i], n, _op(dkw))
+        assert (dec[i] == want).all(), i
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65])
+def test_ragged_lengths(n):
+    rng = np.random.default_rng(n)
+    pcm = rng.integers(-20000, 20000, (3, n)).astype(np.int16)
+    for kw in (dict(Type=3), dict(Type=4, Version=3), dict(Type=2, Filter=3, Padding=5)):
+        enc = CriAdxCodec.Encode(list(pcm), CriAdxParameters(**kw))
+        for c in range(3):
+            assert (enc[c] == po.adx_encode(pcm[c], _op(kw))).all()
+
+
+def test_decode_random_bitstreams_and_history():
+    rng = np.random.default_rng(9)
+    n = 32 * 200 + 5
+    frames = -(-n // 32)
+    data = rng.integers(0, 256, (40, frames * 18)).astype(np.uint8)
+    data[:, 0::18] &= 0x1F                       # filter 0 (the only one Linear/Exponential streams may name)
+    for kw in (dict(Type=3, History=1234), dict(Type=3, Version=3, History=-77), dict(Type=4)):
+        if kw["Type"] == 4:
+            data[:, 0::18] = 0
+            data[:, 1::18] %= 13
+        dec = CriAdxCodec.Decode(list(data), n, CriAdxParameters(**kw))
+        for c in range(40):
+            assert (dec[c] == po.adx_decode(data[c], n, _op(kw))).all(), (kw, c)
+    fixed = data.copy()
+    fixed[:, 0::18] = rng.integers(0, 4, fixed[:, 0::18].shape).astype(np.uint8) << 5
+    dec = CriAdxCodec.Decode(list(fixed), n, CriAdxParameters(Type=2))
+    for c in range(40):
+        assert (dec[c] == po.adx_decode(fixed[c], n, _op(dict(Type=2)))).all()
+
+
+def test_errors():
+    import vgaudio_amd
+    with pytest.raises(vgaudio_amd.ArgumentError):
+        CriAdxCodec.Encode(np.zeros(0, np.int16), CriAdxParameters())            # reads pcm[0]
+    with pytest.raises(vgaudio_amd.ArgumentError):
+        CriAdxCodec.Encode(np.zeros(32, np.int16), CriAdxParameters(Type=2, Filter=4))
+    with pytest.raises(vgaudio_amd.ArgumentError):
+        CriAdxCodec.Decode(np.zeros(17, np.uint8), 32)                           # stream too short
+    bad = np.zeros(18, np.uint8)
+    bad[0] = 0x20                                                                # filter 1 in a Linear stream
+    with pytest.raises(vgaudio_amd.ArgumentError):
+        CriAdxCodec.Decode(bad, 32)
+
+
+def test_format_roundtrip_config3_shape_reduced():
+    """BASELINE configs[2]: ADX encode+decode round trip, bit-exact check (128 channels x 10 s here)."""
+    pcm = synth.generate(128, 480000)
+    fmt = CriAdxFormat().EncodeFromPcm16(Pcm16Format(list(pcm), 48000))
+    want, hist = po.adx_encode_batch(pcm, po.adx_params(), threads=8)
+    for c in range(128):
+        assert (fmt.Channels[c].Audio == want[c]).all() and fmt.Channels[c].History == hist[c]
+    back = fmt.ToPcm16()
+    wdec = po.adx_decode_batch(want, 480000, po.adx_params(), threads=8)
+    for c in range(128):
+        assert (back.Channels[c] == wdec[c]).all()
+    err = np.stack(back.Channels).astype(float) - pcm
+    assert np.sqrt((err ** 2).mean()) < 0.12 * np.sqrt((pcm.astype(float) ** 2).mean())   # 4-bit ADPCM, fixed high-pass predictor

@@ -89,7 +89,24 @@ SIGNATURES = {
     "vga_gcadpcm_encode_device": (ci, [vp, i64, ci, ci, vp, vp, vp, vp, i64, vp]),
     "vga_gcadpcm_decode_device": (ci, [vp, i64, vp, ci, ci, vp, vp, vp, i64, vp, vp]),
     "vga_synth_pcm16_device": (ci, [vp, i64, ci, ci, ci, vp, vp]),
+    "vga_adx_default_params": (None, [vp]),
+    "vga_adx_calculate_coefficients": (ci, [ci, ci, i16p]),
+    "vga_adx_nibble_count_to_sample_count": (ci, [ci, ci]),
+    "vga_adx_sample_count_to_nibble_count": (ci, [ci, ci]),
+    "vga_adx_sample_count_to_byte_count": (ci, [ci, ci]),
+    "vga_adx_encoded_byte_count": (ci, [ci, vp]),
+    "vga_adx_encode_batch": (ci, [i16pp, ci, ci, vp, u8pp, i16p]),
+    "vga_adx_decode_batch": (ci, [u8pp, ci, ci, ci, vp, i16pp]),
+    "vga_adx_encode_device": (ci, [vp, i64, ci, ci, vp, vp, i64, vp, vp]),
+    "vga_adx_decode_device": (ci, [vp, i64, ci, ci, ci, vp, vp, i64, vp, vp]),
 }
+
+
+class AdxParams(C.Structure):
+    """vga_adx_params (include/vgaudio_hip.h) == CriAdxParameters."""
+    _fields_ = [("sample_rate", C.c_int), ("highpass_frequency", C.c_int), ("frame_size", C.c_int),
+                ("version", C.c_int), ("history", C.c_int16), ("padding", C.c_int), ("type", C.c_int),
+                ("filter", C.c_int)]
 
 
 def _preload_torch_hip_runtime():

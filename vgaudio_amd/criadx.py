@@ -1,0 +1,156 @@
+"""Host-side mirror of the reference's CRI ADX codec and format classes, routed through the C
+ABI into the HIP kernels.  Mirrors (paths relative to /root/reference/src/VGAudio/):
+  CriAdxType         Codecs/CriAdx/CriAdxType.cs
+  CriAdxParameters   Codecs/CriAdx/CriAdxParameters.cs:5-12
+  CriAdxCodec        Codecs/CriAdx/CriAdxCodec.cs:9 (Decode), :56 (Encode), :173 (CalculateCoefficients)
+  CriAdxHelpers      Formats/CriAdx/CriAdxHelpers.cs:7-31
+  CriAdxChannel/Format  Formats/CriAdx/CriAdxFormat.cs:34-88
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, i16p, u8p
+from .gcadpcm import Pcm16Format, _as_channels, _i16, _ptr_array
+
+
+class CriAdxType:
+    Fixed = 2
+    Linear = 3
+    Exponential = 4
+
+
+class CriAdxParameters:
+    def __init__(self, SampleRate=48000, HighpassFrequency=500, FrameSize=18, Version=4, History=0, Padding=0,
+                 Type=CriAdxType.Linear, Filter=0, Progress=None):
+        self.SampleRate, self.HighpassFrequency, self.FrameSize = SampleRate, HighpassFrequency, FrameSize
+        self.Version, self.History, self.Padding, self.Type, self.Filter = Version, History, Padding, Type, Filter
+        self.Progress = Progress
+
+    def _c(self):
+        return _lib.AdxParams(self.SampleRate, self.HighpassFrequency, self.FrameSize, self.Version,
+                              int(self.History), self.Padding, self.Type, self.Filter)
+
+
+class CriAdxHelpers:
+    @staticmethod
+    def NibbleCountToSampleCount(n, frameSize):
+        return _lib.lib().vga_adx_nibble_count_to_sample_count(int(n), frameSize)
+
+    @staticmethod
+    def SampleCountToNibbleCount(n, frameSize):
+        return _lib.lib().vga_adx_sample_count_to_nibble_count(int(n), frameSize)
+
+    @staticmethod
+    def SampleCountToByteCount(n, frameSize):
+        return _lib.lib().vga_adx_sample_count_to_byte_count(int(n), frameSize)
+
+
+class CriAdxCodec:
+    @staticmethod
+    def CalculateCoefficients(highpassFreq, sampleRate):
+        c = np.zeros(2, dtype=np.int16)
+        check(_lib.lib().vga_adx_calculate_coefficients(highpassFreq, sampleRate, _i16(c)))
+        return c
+
+    @staticmethod
+    def Encode(pcm, config):
+        """byte[] Encode(short[] pcm, CriAdxParameters config); sets config.History like the reference
+        (CriAdxCodec.cs:73).  A list / 2-D array encodes a batch (History then becomes an array)."""
+        chans, single = _as_channels(pcm, np.int16)
+        nch = len(chans)
+        n = len(chans[0]) if nch else 0
+        if any(len(c) != n for c in chans):
+            raise _lib.ArgumentError("channels of one batch must have equal length")
+        cp = config._c()
+        nbytes = _lib.lib().vga_adx_encoded_byte_count(n, C.byref(cp))
+        if nbytes < 0:
+            check(nbytes)
+        outs = [np.zeros(nbytes, dtype=np.uint8) for _ in range(nch)]
+        hist = np.zeros(max(nch, 1), dtype=np.int16)
+        check(_lib.lib().vga_adx_encode_batch(_ptr_array(i16p, chans), nch, n, C.byref(cp), _ptr_array(u8p, outs),
+                                               _i16(hist)))
+        config.History = int(hist[0]) if single else hist[:nch].copy()
+        if config.Progress is not None:
+            config.Progress.ReportAdd(nbytes // config.FrameSize * nch)
+        return outs[0] if single else outs
+
+    @staticmethod
+    def Decode(adpcm, sampleCount, config=None):
+        config = config or CriAdxParameters()
+        chans, single = _as_channels(adpcm, np.uint8)
+        nch = len(chans)
+        nb = len(chans[0]) if nch else 0
+        if any(len(c) != nb for c in chans):
+            raise _lib.ArgumentError("channels of one batch must have equal length")
+        cp = config._c()
+        outs = [np.zeros(max(sampleCount, 0), dtype=np.int16) for _ in range(nch)]
+        check(_lib.lib().vga_adx_decode_batch(_ptr_array(u8p, chans), nb, nch, sampleCount, C.byref(cp),
+                                               _ptr_array(i16p, outs)))
+        return outs[0] if single else outs
+
+
+class CriAdxChannel:
+    def __init__(self, audio, history=0, version=4):
+        self.Audio, self.History, self.Version = audio, history, version
+
+
+def _get_next_multiple(value, multiple):
+    # Utilities/Helpers.cs GetNextMultiple
+    if multiple <= 0:
+        return value
+    if value % multiple == 0:
+        return value
+    return value + multiple - value % multiple
+
+
+class CriAdxFormat:
+    """IAudioFormat for CRI ADX; EncodeFromPcm16 / ToPcm16 are one batched GPU call each."""
+
+    def __init__(self, channels=None, sampleCount=0, sampleRate=48000, frameSize=18, highpassFrequency=500,
+                 alignmentSamples=0, type_=CriAdxType.Linear, version=4, looping=False, loopStart=0, loopEnd=0):
+        self.Channels = list(channels) if channels is not None else []
+        self.UnalignedSampleCount = sampleCount
+        self.SampleRate, self.FrameSize, self.HighpassFrequency = sampleRate, frameSize, highpassFrequency
+        self.AlignmentSamples, self.Type, self.Version = alignmentSamples, type_, version
+        self.Looping, self.UnalignedLoopStart, self.UnalignedLoopEnd = looping, loopStart, loopEnd
+
+    @property
+    def ChannelCount(self):
+        return len(self.Channels)
+
+    @property
+    def SampleCount(self):
+        return self.UnalignedSampleCount + self.AlignmentSamples
+
+    def EncodeFromPcm16(self, pcm16, config=None):
+        config = config or CriAdxParameters()
+        spf = (config.FrameSize - 2) * 2
+        multiple = spf * 2 if pcm16.ChannelCount == 1 else spf
+        loop_start = pcm16.LoopStart if pcm16.Looping else 0
+        alignment = _get_next_multiple(loop_start, multiple) - loop_start                  # CriAdxFormat.cs:59-62
+        if config.Progress is not None:
+            frames = -(-CriAdxHelpers.SampleCountToByteCount(pcm16.SampleCount, config.FrameSize) // config.FrameSize)
+            config.Progress.SetTotal(frames * pcm16.ChannelCount)
+        ch_cfg = CriAdxParameters(SampleRate=pcm16.SampleRate, FrameSize=config.FrameSize, Padding=alignment,
+                                  Filter=config.Filter, Type=config.Type, Version=config.Version,
+                                  Progress=config.Progress)
+        if pcm16.ChannelCount:
+            audio = CriAdxCodec.Encode(pcm16.Channels, ch_cfg)
+            hist = np.atleast_1d(ch_cfg.History)
+        else:
+            audio, hist = [], []
+        chans = [CriAdxChannel(audio[i], int(hist[i]), ch_cfg.Version) for i in range(pcm16.ChannelCount)]
+        return CriAdxFormat(chans, pcm16.SampleCount, pcm16.SampleRate, config.FrameSize, 500, alignment, config.Type,
+                            config.Version, pcm16.Looping, pcm16.LoopStart, pcm16.LoopEnd)
+
+    def ToPcm16(self):
+        if not self.Channels:
+            return Pcm16Format([], self.SampleRate)
+        opts = CriAdxParameters(SampleRate=self.SampleRate, FrameSize=self.FrameSize, Padding=self.AlignmentSamples,
+                                HighpassFrequency=self.HighpassFrequency, Type=self.Type, Version=self.Version)
+        pcm = CriAdxCodec.Decode([c.Audio for c in self.Channels], self.UnalignedSampleCount, opts)   # :39-48
+        out = Pcm16Format(pcm, self.SampleRate)
+        out.Looping, out.LoopStart, out.LoopEnd = self.Looping, self.UnalignedLoopStart, self.UnalignedLoopEnd
+        return out
