@@ -77,11 +77,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from vgaudio_amd import _lib, device as vdev
+    from vgaudio_amd import _lib, device as vdev, distributed as vdist
     _lib.check(_lib.lib().vga_set_device(local_rank))
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        vdist.init("nccl", dev)
 
     nch = args.channels
     n = int(round(args.seconds * 48000))
@@ -127,12 +126,10 @@ def main():
     enc_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs])) if args.steps else 0.0
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = vdist.max_over_ranks(elapsed, dev)
         # the only exchange: 32 B/channel of coefficients gathered for the caller (RCCL over xGMI)
-        gathered = [torch.empty_like(coefs) for _ in range(world)]
-        dist.all_gather(gathered, coefs)
+        all_coefs = vdist.gather_channel_metadata(coefs, [nch] * world)
+        assert all_coefs.shape[0] == nch * world
 
     samples_per_step = nch * n * world
     ms_per_step = elapsed / max(args.steps, 1) * 1e3

@@ -1,0 +1,70 @@
+"""world_size-2 gloo test of the N>1 path on CPU: contiguous channel sharding, no data-path
+collective, one all_gather of the per-channel coefficients, max-over-ranks timing.  Each rank's
+"device work" is stood in for by the oracle (checker) so the gathered result can be compared
+with a single-process run over all channels."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from vgaudio_amd.distributed import shard_channels
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_channels_partition():
+    for total in (0, 1, 7, 8, 4096, 32768, 4097):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_channels(total, world, r) for r in range(world)]
+            assert sum(c for _, c in blocks) == total
+            pos = 0
+            for first, count in blocks:
+                assert first == pos and count in (total // world, total // world + 1)
+                pos += count
+    assert shard_channels(32768, 8, 3) == (3 * 4096, 4096)      # BASELINE configs[4]: 4096 per GPU
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, time
+    sys.path.insert(0, {root!r})
+    import numpy as np, torch, torch.distributed as dist
+    from vgaudio_amd import distributed as vd, synth
+    from oracle import pyoracle as po
+    rank, local_rank, world = vd.env_world()
+    vd.init("gloo")
+    total, n = 7, 14 * 200 + 3
+    first, count = vd.shard_channels(total, world, rank)
+    counts = [vd.shard_channels(total, world, r)[1] for r in range(world)]
+    pcm = synth.generate(count, n, first_channel=first)           # each rank generates only its shard
+    t0 = time.perf_counter()
+    coefs, adpcm = po.gc_encode_batch(pcm, threads=1)
+    dt = time.perf_counter() - t0
+    allc = vd.gather_channel_metadata(torch.from_numpy(coefs), counts)
+    tmax = vd.max_over_ranks(dt, torch.device("cpu"))
+    assert tmax >= dt
+    np.save(os.path.join({out!r}, f"adpcm_{{rank}}.npy"), adpcm)
+    if rank == 0:
+        np.save(os.path.join({out!r}, "coefs_all.npy"), allc.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_two_rank_gloo_sharded_encode(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    from oracle import pyoracle as po
+    from vgaudio_amd import synth
+    pcm = synth.generate(7, 14 * 200 + 3)
+    coefs, adpcm = po.gc_encode_batch(pcm)
+    got = np.load(tmp_path / "coefs_all.npy")
+    assert (got == coefs).all()
+    parts = np.concatenate([np.load(tmp_path / f"adpcm_{r}.npy") for r in range(2)])
+    assert (parts == adpcm).all()
