@@ -101,6 +101,43 @@ void vgo_adx_encode_batch(const int16_t *pcm, long pitch, int nch, int pcm_lengt
 void vgo_adx_decode_batch(const uint8_t *adpcm, long in_pitch, int nch, int sample_count,
                           const vgo_adx_params *p, int16_t *pcm_out, long out_pitch, int threads);
 
+
+/* ---- CRI HCA ---- Codecs/CriHca (all files), Utilities/{Mdct,BitWriter,BitReader,Crc16}.cs */
+typedef struct {            /* Codecs/CriHca/HcaInfo.cs:5-50 (fields the codec path uses) */
+    int channel_count, sample_rate, sample_count, frame_count;
+    int inserted_samples, appended_samples, header_size, frame_size;
+    int min_resolution, max_resolution, track_count, channel_config;
+    int total_band_count, base_band_count, stereo_band_count, hfr_band_count;
+    int bands_per_hfr_group, hfr_group_count;
+    int looping, loop_start_frame, loop_end_frame, pre_loop_samples, post_loop_samples;
+    int use_ath_curve, comment_length;
+} vgo_hca_info;
+
+typedef struct {            /* Codecs/CriHca/CriHcaParameters.cs:3-15; quality: 1 Highest .. 5 Lowest, 0 NotSet */
+    int quality, bitrate, limit_bitrate, channel_count, sample_rate, sample_count;
+    int looping, loop_start, loop_end;
+} vgo_hca_params;
+
+/* CriHcaEncoder.Initialize (CriHcaEncoder.cs:61-114): 0, or -2 (ArgumentOutOfRange) */
+int vgo_hca_encoder_init(const vgo_hca_params *c, vgo_hca_info *h, int *post_samples_out, int *buffer_pre_samples_out);
+/* CriHcaFormat.EncodeFromPcm16 (Formats/CriHca/CriHcaFormat.cs:34-84): pcm planar (channel c at
+ * pcm + c*pitch); frames_out = frame_count*frame_size bytes.  0, -2, -3 (InvalidData: bitrate too low) */
+int vgo_hca_encode(const int16_t *pcm, long pitch, const vgo_hca_params *c, vgo_hca_info *info_out, uint8_t *frames_out);
+/* CriHcaDecoder.Decode (CriHcaDecoder.cs:11-45): pcm_out planar, sample_count samples per channel */
+int vgo_hca_decode(const vgo_hca_info *h, const uint8_t *frames, int16_t *pcm_out, long pitch);
+int vgo_hca_encode_batch(const int16_t *pcm, long stream_pitch, long ch_pitch, int nstreams, const vgo_hca_params *p,
+                         uint8_t *frames, long frames_pitch, int threads);
+int vgo_hca_decode_batch(const vgo_hca_info *info, const uint8_t *frames, long frames_pitch, int nstreams,
+                         int16_t *pcm_out, long stream_pitch, long ch_pitch, int threads);
+/* test hooks */
+int vgo_hca_table(const char *name, double *out, int cap);
+uint16_t vgo_crc16(const uint8_t *data, int size);                       /* Utilities/Crc16.cs:12-18 */
+int vgo_bitwriter_write(uint8_t *buf, int buf_len, int position, int value, int bit_count);  /* BitWriter.cs:26-70 */
+void vgo_mdct_run(const double *in, int blocks, double *out, int inverse);   /* Mdct.cs:63-119, 128-point, HCA scale */
+int vgo_hca_debug_last_frame(const int16_t *pcm, long pitch, const vgo_hca_params *c, int frames,
+                             int *noise_level, int *eval_boundary, int *scale_factors, int *resolution,
+                             int *quantized, double *spectra);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,7 @@ def lib():
     if _LIB is None:
         _LIB = C.CDLL(build())
         _declare(_LIB)
+        _declare_hca(_LIB)
     return _LIB
 
 
@@ -77,6 +78,41 @@ def _declare(L):
     L.vgo_adx_encode_batch.restype = None
     L.vgo_adx_decode_batch.argtypes = [u8p, C.c_long, i, i, ap, i16p, C.c_long, i]
     L.vgo_adx_decode_batch.restype = None
+
+
+class HcaInfo(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "channel_count", "sample_rate", "sample_count", "frame_count", "inserted_samples", "appended_samples",
+        "header_size", "frame_size", "min_resolution", "max_resolution", "track_count", "channel_config",
+        "total_band_count", "base_band_count", "stereo_band_count", "hfr_band_count", "bands_per_hfr_group",
+        "hfr_group_count", "looping", "loop_start_frame", "loop_end_frame", "pre_loop_samples", "post_loop_samples",
+        "use_ath_curve", "comment_length")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class HcaParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("quality", "bitrate", "limit_bitrate", "channel_count", "sample_rate",
+                                       "sample_count", "looping", "loop_start", "loop_end")]
+
+
+def _declare_hca(L):
+    i16p, u8p, i, dp = C.POINTER(C.c_int16), C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int)
+    hp, pp = C.POINTER(HcaInfo), C.POINTER(HcaParams)
+    L.vgo_hca_encoder_init.argtypes = [pp, hp, ip, ip]
+    L.vgo_hca_encode.argtypes = [i16p, C.c_long, pp, hp, u8p]
+    L.vgo_hca_decode.argtypes = [hp, u8p, i16p, C.c_long]
+    L.vgo_hca_encode_batch.argtypes = [i16p, C.c_long, C.c_long, i, pp, u8p, C.c_long, i]
+    L.vgo_hca_decode_batch.argtypes = [hp, u8p, C.c_long, i, i16p, C.c_long, C.c_long, i]
+    L.vgo_hca_table.argtypes = [C.c_char_p, dp, i]
+    L.vgo_crc16.argtypes = [u8p, i]
+    L.vgo_crc16.restype = C.c_uint16
+    L.vgo_bitwriter_write.argtypes = [u8p, i, i, i, i]
+    L.vgo_mdct_run.argtypes = [dp, i, dp, i]
+    L.vgo_mdct_run.restype = None
+    L.vgo_hca_debug_last_frame.argtypes = [i16p, C.c_long, pp, i, ip, ip, ip, ip, ip, dp]
 
 
 def _i16(a):
@@ -209,3 +245,95 @@ def adx_decode_batch(adpcm2d, sample_count, params, threads=1):
     out = np.zeros((nch, sample_count), dtype=np.int16)
     lib().vgo_adx_decode_batch(_u8(adpcm2d), nb, nch, sample_count, C.byref(params), _i16(out), sample_count, threads)
     return out
+
+
+# ---------------- HCA ----------------
+HCA_QUALITY = {"NotSet": 0, "Highest": 1, "High": 2, "Middle": 3, "Low": 4, "Lowest": 5}
+
+
+def hca_params(channel_count, sample_count, sample_rate=48000, quality="High", bitrate=0, limit_bitrate=False,
+               looping=False, loop_start=0, loop_end=0):
+    return HcaParams(HCA_QUALITY[quality] if isinstance(quality, str) else quality, bitrate, int(limit_bitrate),
+                     channel_count, sample_rate, sample_count, int(looping), loop_start, loop_end)
+
+
+def hca_init(params):
+    info = HcaInfo()
+    post, pre = C.c_int(), C.c_int()
+    rc = lib().vgo_hca_encoder_init(C.byref(params), C.byref(info), C.byref(post), C.byref(pre))
+    return rc, info
+
+
+def hca_encode(pcm2d, params):
+    """pcm2d [nch, n] -> (rc, HcaInfo, frames [frame_count, frame_size] uint8)"""
+    pcm2d = np.ascontiguousarray(pcm2d, dtype=np.int16)
+    rc, info = hca_init(params)
+    if rc:
+        return rc, info, None
+    frames = np.zeros((info.frame_count, info.frame_size), dtype=np.uint8)
+    rc = lib().vgo_hca_encode(_i16(pcm2d), pcm2d.shape[1], C.byref(params), C.byref(info), _u8(frames))
+    return rc, info, frames
+
+
+def hca_decode(info, frames):
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    out = np.zeros((info.channel_count, max(info.sample_count, 1)), dtype=np.int16)
+    rc = lib().vgo_hca_decode(C.byref(info), _u8(frames), _i16(out), out.shape[1])
+    return rc, out[:, :info.sample_count]
+
+
+def hca_encode_batch(pcm3d, params, threads=1):
+    """pcm3d [nstreams, nch, n] -> (rc, info, frames [nstreams, frame_count*frame_size])"""
+    pcm3d = np.ascontiguousarray(pcm3d, dtype=np.int16)
+    ns, nch, n = pcm3d.shape
+    rc, info = hca_init(params)
+    if rc:
+        return rc, info, None
+    fb = info.frame_count * info.frame_size
+    frames = np.zeros((ns, fb), dtype=np.uint8)
+    rc = lib().vgo_hca_encode_batch(_i16(pcm3d), nch * n, n, ns, C.byref(params), _u8(frames), fb, threads)
+    return rc, info, frames
+
+
+def hca_decode_batch(info, frames2d, threads=1):
+    frames2d = np.ascontiguousarray(frames2d, dtype=np.uint8)
+    ns = frames2d.shape[0]
+    n = max(info.sample_count, 1)
+    out = np.zeros((ns, info.channel_count, n), dtype=np.int16)
+    rc = lib().vgo_hca_decode_batch(C.byref(info), _u8(frames2d), frames2d.shape[1], ns, _i16(out),
+                                    info.channel_count * n, n, threads)
+    return rc, out[:, :, :info.sample_count]
+
+
+def hca_table(name):
+    buf = np.zeros(256, dtype=np.float64)
+    n = lib().vgo_hca_table(name.encode(), buf.ctypes.data_as(C.POINTER(C.c_double)), 256)
+    return buf[:n].copy()
+
+
+def crc16(data):
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    return int(lib().vgo_crc16(_u8(data), len(data)))
+
+
+def mdct_run(blocks2d, inverse=False):
+    x = np.ascontiguousarray(blocks2d, dtype=np.float64)
+    out = np.zeros_like(x)
+    dp = C.POINTER(C.c_double)
+    lib().vgo_mdct_run(x.ctypes.data_as(dp), x.shape[0], out.ctypes.data_as(dp), int(inverse))
+    return out
+
+
+def hca_debug_last_frame(pcm2d, params, frames):
+    pcm2d = np.ascontiguousarray(pcm2d, dtype=np.int16)
+    nch = pcm2d.shape[0]
+    nl, eb = C.c_int(), C.c_int()
+    sf = np.zeros((nch, 128), np.int32)
+    res = np.zeros((nch, 128), np.int32)
+    q = np.zeros((nch, 8, 128), np.int32)
+    sp = np.zeros((nch, 8, 128), np.float64)
+    ip = C.POINTER(C.c_int)
+    rc = lib().vgo_hca_debug_last_frame(_i16(pcm2d), pcm2d.shape[1], C.byref(params), frames, C.byref(nl), C.byref(eb),
+                                        sf.ctypes.data_as(ip), res.ctypes.data_as(ip), q.ctypes.data_as(ip),
+                                        sp.ctypes.data_as(C.POINTER(C.c_double)))
+    return rc, nl.value, eb.value, sf, res, q, sp

@@ -1,0 +1,175 @@
+"""Pins the HCA part of the CPU oracle (oracle/hca_oracle.c).
+
+What the reference's own tests pin (and is checked bit-exactly here):
+  Tests/Formats/CriHca/CriHcaTableTests.cs:8-115  -> generated f64 tables == GeneratedTables literals,
+                                                     packed tables == UnpackedTables literals
+  Tests/Utilities/MdctTests.cs:18-59              -> sin/cos/shuffle tables == PreBuiltMdctTables
+What they do NOT pin (parity unpinned): encoder/decoder output, RunMdct/RunImdct,
+BitWriter, Crc16 -- covered by hand-derivable vectors and invariants below.
+"""
+import json
+import math
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from vgaudio_amd import synth
+
+FIX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hca_tables.json")))
+
+
+def _f64(h):
+    return struct.unpack(">d", bytes.fromhex(h))[0]
+
+
+def _bits(x):
+    return struct.unpack(">q", struct.pack(">d", float(x)))[0]
+
+
+@pytest.mark.parametrize("name", ["DequantizerScalingTable", "QuantizerStepSize", "QuantizerScalingTable",
+                                  "QuantizerInverseStepSize", "IntensityRatioTable", "IntensityRatioBoundsTable",
+                                  "ScaleConversionTable"])
+def test_generated_tables_match_reference_golden(name):
+    want = [_f64(h) for h in FIX["generated_tables_test"][name]]
+    got = po.hca_table(name)
+    assert len(got) == len(want) and all(_bits(a) == _bits(b) for a, b in zip(got, want))
+
+
+def test_packed_tables_match_reference_unpacked_golden():
+    p, u = FIX["packed"], FIX["unpacked_tables_test"]
+    for k in p:
+        assert (p[k] == u["MdctWindowF"]) if k == "MdctWindow" else (p[k] == u[k]), k
+    win = po.hca_table("MdctWindow")
+    assert [_bits(x) for x in win] == [_bits(_f64(h)) for h in u["MdctWindow"]]      # f32 -> f64 widening
+
+
+def test_formulas_reproduce_golden_with_this_libm():
+    """CriHcaTables.cs:54-78 / Mdct.cs:183-195 evaluated with glibc give the golden bits (so the
+    reference's generators and the harvested literals agree on this platform)."""
+    g = FIX["generated_tables_test"]
+    for x in range(64):
+        v = math.sqrt(128) * math.pow(math.pow(2, 53.0 / 128), x - 63)
+        assert _bits(v) == _bits(_f64(g["DequantizerScalingTable"][x]))
+        assert _bits(1 / v) == _bits(_f64(g["QuantizerScalingTable"][x]))
+    for x in range(128):
+        v = math.pow(math.pow(2, 53.0 / 128), x - 64) if 1 < x < 127 else 0
+        assert _bits(v) == _bits(_f64(g["ScaleConversionTable"][x]))
+    m = FIX["prebuilt_mdct_tables_test"]
+    for b in range(9):
+        size = 1 << b
+        for i in range(size):
+            a = math.pi * (4 * i + 1) / (4 * size)
+            assert _bits(math.sin(a)) == _bits(_f64(m["SinTables"][b][i]))
+            assert _bits(math.cos(a)) == _bits(_f64(m["CosTables"][b][i]))
+            rev = int(format(i ^ (i // 2), f"0{b}b")[::-1], 2) if b else 0
+            assert m["ShuffleTables"][b][i] == rev
+
+
+def test_dead_zone_table_definition():
+    # CriHcaTables.cs:68-78: bits(step/2) - (maxValue + 1)
+    step = po.hca_table("QuantizerStepSize")
+    dz = po.hca_table("QuantizerDeadZone")
+    maxv = FIX["generated_tables_test"]["ResolutionMaxValue"]
+    for i in range(16):
+        assert _bits(dz[i]) == _bits(step[i] / 2) - (maxv[i] + 1)
+
+
+def test_crc16_check_value_and_bitwriter_patterns():
+    assert po.crc16(np.frombuffer(b"123456789", np.uint8)) == 0xFEE8      # CRC-16 poly 0x8005 init 0 MSB-first
+    L = po.lib()
+    import ctypes as C
+    buf = np.zeros(16, np.uint8)
+    pos = 0
+    writes = [(0xFFFF, 16), (0x155, 9), (0x2A, 7), (5, 3), (0x1FFFF, 17), (1, 1), (0xABCDE, 20), (0x1234567, 25),
+              (0, 0), (3, 2)]
+    for value, bits in writes:
+        pos = L.vgo_bitwriter_write(buf.ctypes.data_as(C.POINTER(C.c_uint8)), 16, pos, value, bits)
+    want = "".join(format(v, f"0{b}b") if b else "" for v, b in writes)
+    assert pos == len(want) == 100
+    assert "".join(format(x, "08b") for x in buf)[:pos] == want          # MSB-first, big-endian bit order
+    # the last 16 bits of a buffer can only be reached through the fallback path (checksum write)
+    pos = L.vgo_bitwriter_write(buf.ctypes.data_as(C.POINTER(C.c_uint8)), 16, 112, 0xBEEF, 16)
+    assert pos == 128 and buf[14] == 0xBE and buf[15] == 0xEF
+    assert L.vgo_bitwriter_write(buf.ctypes.data_as(C.POINTER(C.c_uint8)), 16, 120, 0, 9) == -1   # throws in C#
+
+
+def test_mdct_tdac_reconstruction():
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, (12, 128))
+    y = po.mdct_run(po.mdct_run(x), inverse=True)
+    # MDCT->IMDCT with the HCA window and sqrt(2/N) scaling reproduces the input delayed by one block
+    assert np.abs(y[1:] - x[:-1]).max() < 1e-6
+
+
+@pytest.mark.parametrize("nch,quality,n", [(1, "High", 10000), (2, "High", 48000), (2, "Highest", 20000),
+                                           (2, "Low", 48000), (2, "Lowest", 48000), (1, "Lowest", 30000),
+                                           (4, "Middle", 12345), (6, "Low", 9000), (8, "High", 5000)])
+def test_encode_decode_invariants(nch, quality, n):
+    pcm = synth.generate(nch, n)
+    p = po.hca_params(nch, n, quality=quality)
+    rc, info, frames = po.hca_encode(pcm, p)
+    assert rc == 0
+    assert info.frame_count == -(-(n + info.inserted_samples) // 1024) and frames.shape == (info.frame_count, info.frame_size)
+    assert (frames[:, :2] == 255).all()                                  # sync word
+    assert all(po.crc16(f) == 0 for f in frames)                         # CRC over frame incl. checksum
+    rc, dec = po.hca_decode(info, frames)
+    assert rc == 0 and dec.shape == (nch, n)
+    err = dec.astype(float) - pcm
+    snr = 10 * np.log10((pcm.astype(float) ** 2).mean() / (err ** 2).mean())
+    assert snr > (12 if quality in ("Low", "Lowest") else 25), snr
+
+
+def test_derived_parameters_config4():
+    # stereo 48 kHz "High" -> bitrate 256000, 682-byte frames, bands 128/128/0, no HFR
+    rc, info = po.hca_init(po.hca_params(2, 2_880_000))
+    d = info.as_dict()
+    assert rc == 0 and d["frame_size"] == 682 and d["total_band_count"] == 128 and d["base_band_count"] == 128
+    assert d["stereo_band_count"] == 0 and d["hfr_group_count"] == 0 and d["frame_count"] == 2813
+    assert d["inserted_samples"] == 128 and d["appended_samples"] == 2813 * 1024 - 128 - 2_880_000
+    # Low quality exercises HFR + intensity stereo
+    rc, info = po.hca_init(po.hca_params(2, 48000, quality="Lowest"))
+    assert info.hfr_group_count > 0 and info.stereo_band_count > 0
+
+
+def test_silence_and_errors():
+    p = po.hca_params(2, 4096)
+    rc, info, frames = po.hca_encode(np.zeros((2, 4096), np.int16), p)
+    assert rc == 0
+    rc, dec = po.hca_decode(info, frames)
+    assert rc == 0 and not dec.any()
+    assert po.hca_init(po.hca_params(9, 1000))[0] == -2                  # "HCA channel count must be 8 or below"
+    bad = frames.copy()
+    bad[3, 0] = 0
+    assert po.hca_decode(info, bad)[0] == -3                             # "Invalid frame header"
+    rc, _, _ = po.hca_encode(synth.generate(2, 8192), po.hca_params(2, 8192, bitrate=2000))
+    assert rc == -3                                                      # "Bitrate is set too low."
+
+
+def test_looping_layout():
+    n = 20000
+    pcm = synth.generate(2, n)
+    p = po.hca_params(2, n, looping=True, loop_start=3000, loop_end=18000)
+    rc, info, frames = po.hca_encode(pcm, p)
+    assert rc == 0 and info.looping == 1
+    ls = info.loop_start_frame * 1024 + info.pre_loop_samples - info.inserted_samples
+    le = (info.loop_end_frame + 1) * 1024 - info.post_loop_samples - info.inserted_samples
+    assert (ls, le) == (3000, 18000) and info.pre_loop_samples == 128    # MDCT delay: 128 samples into a frame
+    rc, dec = po.hca_decode(info, frames)
+    err = dec[:, 2000:17000].astype(float) - pcm[:, 2000:17000]
+    assert rc == 0 and 10 * np.log10((pcm.astype(float) ** 2).mean() / (err ** 2).mean()) > 25
+
+
+def test_batch_matches_single():
+    pcm = np.stack([synth.generate(2, 9000, first_channel=2 * s) for s in range(5)])
+    p = po.hca_params(2, 9000)
+    rc, info, fr = po.hca_encode_batch(pcm, p, threads=3)
+    assert rc == 0
+    for s in range(5):
+        _, _, f1 = po.hca_encode(pcm[s], p)
+        assert (fr[s] == f1.reshape(-1)).all()
+    rc, dec = po.hca_decode_batch(info, fr, threads=2)
+    for s in range(5):
+        assert (dec[s] == po.hca_decode(info, fr[s].reshape(info.frame_count, info.frame_size))[1]).all()
