@@ -178,6 +178,59 @@ int vga_adx_decode_device(const uint8_t *d_adpcm, int64_t in_pitch, int adpcm_le
                           int64_t pcm_pitch, int *d_status, void *stream);
 
 /* ======================================================================
+ * CRI HCA
+ * ====================================================================== */
+
+/* VGAudio/Codecs/CriHca/HcaInfo.cs:5-50 (the fields the codec path reads or derives) */
+typedef struct {
+    int channel_count, sample_rate, sample_count, frame_count;
+    int inserted_samples, appended_samples, header_size, frame_size;
+    int min_resolution, max_resolution, track_count, channel_config;
+    int total_band_count, base_band_count, stereo_band_count, hfr_band_count;
+    int bands_per_hfr_group, hfr_group_count;
+    int looping, loop_start_frame, loop_end_frame, pre_loop_samples, post_loop_samples;
+    int use_ath_curve, comment_length;
+} vga_hca_info;
+
+/* VGAudio/Codecs/CriHca/CriHcaParameters.cs:3-15.  quality: CriHcaQuality (0 NotSet, 1 Highest,
+ * 2 High, 3 Middle, 4 Low, 5 Lowest). */
+typedef struct {
+    int quality, bitrate, limit_bitrate, channel_count, sample_rate, sample_count;
+    int looping, loop_start, loop_end;
+} vga_hca_params;
+
+/* CriHcaEncoder.Initialize (VGAudio/Codecs/CriHca/CriHcaEncoder.cs:61-114): derives bitrate, frame
+ * size, band counts, channel configuration, loop/header layout, frame count.  More than 8 channels or
+ * an invalid channel mapping -> VGA_ERR_OUT_OF_RANGE (ArgumentOutOfRangeException). */
+int vga_hca_encoder_initialize(const vga_hca_params *config, vga_hca_info *info_out);
+
+/* Replaces CriHcaFormat.EncodeFromPcm16 (VGAudio/Formats/CriHca/CriHcaFormat.cs:34-84: Initialize +
+ * the serial frame loop over CriHcaEncoder.Encode, CriHcaEncoder.cs:126-286) for a batch of
+ * `nstreams` equally shaped streams.  pcm: nstreams*channel_count planar pointers (stream-major,
+ * sample_count shorts each); frames_out[s]: frame_count*frame_size bytes (from
+ * vga_hca_encoder_initialize).  "Bitrate is set too low." -> VGA_ERR_INVALID_DATA.  Looping
+ * streams: VGA_ERR_INVALID_OP (not yet on the device path). */
+int vga_hca_encode_batch(const int16_t *const *pcm, int nstreams, const vga_hca_params *config,
+                         vga_hca_info *info_out, uint8_t *const *frames_out);
+/* Replaces CriHcaFormat.ToPcm16 (CriHcaFormat.cs:26-32 -> CriHcaDecoder.Decode,
+ * VGAudio/Codecs/CriHca/CriHcaDecoder.cs:11-192).  frames[s]: frame_count*frame_size bytes;
+ * pcm_out: nstreams*channel_count pointers, info->sample_count shorts each.  Invalid sync word ->
+ * VGA_ERR_INVALID_DATA ("Invalid frame header"). */
+int vga_hca_decode_batch(const vga_hca_info *info, const uint8_t *const *frames, int nstreams,
+                         int16_t *const *pcm_out);
+/* device-resident variants: pcm stream s / channel c at d_pcm + s*stream_pitch + c*ch_pitch (samples);
+ * frames of stream s at d_frames + s*frames_pitch (even; decode: 4-byte aligned with >= 8 bytes of
+ * slack after frame_count*frame_size).  *d_status receives flag bits (1 bad sync, 2 bad scale-factor
+ * delta, 4 bitrate too low, 8 boundary search failed). */
+size_t vga_hca_decode_workspace_bytes(const vga_hca_info *info, int nstreams);
+int vga_hca_encode_device(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams,
+                          int pcm_length, const vga_hca_info *info, uint8_t *d_frames,
+                          int64_t frames_pitch, int *d_status, void *stream);
+int vga_hca_decode_device(const vga_hca_info *info, const uint8_t *d_frames, int64_t frames_pitch,
+                          int nstreams, int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch,
+                          void *d_workspace, size_t workspace_bytes, int *d_status, void *stream);
+
+/* ======================================================================
  * Synthetic PCM16 source for benchmarks/tests: integer-only,
  * counter-based; bit-identical to vgaudio_amd/synth.py.  d_params: nch x 4
  * uint32 {f_inc, phi, amp, lfo_inc}; channel ids first_channel..+nch.

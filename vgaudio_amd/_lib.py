@@ -99,7 +99,29 @@ SIGNATURES = {
     "vga_adx_decode_batch": (ci, [u8pp, ci, ci, ci, vp, i16pp]),
     "vga_adx_encode_device": (ci, [vp, i64, ci, ci, vp, vp, i64, vp, vp]),
     "vga_adx_decode_device": (ci, [vp, i64, ci, ci, ci, vp, vp, i64, vp, vp]),
+    "vga_hca_encoder_initialize": (ci, [vp, vp]),
+    "vga_hca_encode_batch": (ci, [i16pp, ci, vp, vp, u8pp]),
+    "vga_hca_decode_batch": (ci, [vp, u8pp, ci, i16pp]),
+    "vga_hca_decode_workspace_bytes": (C.c_size_t, [vp, ci]),
+    "vga_hca_encode_device": (ci, [vp, i64, i64, ci, ci, vp, vp, i64, vp, vp]),
+    "vga_hca_decode_device": (ci, [vp, vp, i64, ci, vp, i64, i64, vp, C.c_size_t, vp, vp]),
 }
+
+
+class HcaInfoC(C.Structure):
+    """vga_hca_info (include/vgaudio_hip.h) == HcaInfo."""
+    _fields_ = [(n, C.c_int) for n in (
+        "channel_count", "sample_rate", "sample_count", "frame_count", "inserted_samples", "appended_samples",
+        "header_size", "frame_size", "min_resolution", "max_resolution", "track_count", "channel_config",
+        "total_band_count", "base_band_count", "stereo_band_count", "hfr_band_count", "bands_per_hfr_group",
+        "hfr_group_count", "looping", "loop_start_frame", "loop_end_frame", "pre_loop_samples", "post_loop_samples",
+        "use_ath_curve", "comment_length")]
+
+
+class HcaParamsC(C.Structure):
+    """vga_hca_params == CriHcaParameters."""
+    _fields_ = [(n, C.c_int) for n in ("quality", "bitrate", "limit_bitrate", "channel_count", "sample_rate",
+                                       "sample_count", "looping", "loop_start", "loop_end")]
 
 
 class AdxParams(C.Structure):

@@ -1,0 +1,145 @@
+"""Host-side mirror of the reference's CRI HCA classes, routed through the C ABI into the HIP kernels.
+Mirrors (paths relative to /root/reference/src/VGAudio/):
+  CriHcaQuality      Codecs/CriHca/CriHcaQuality.cs
+  CriHcaParameters   Codecs/CriHca/CriHcaParameters.cs:3-15
+  HcaInfo            Codecs/CriHca/HcaInfo.cs:5-59
+  CriHcaEncoder      Codecs/CriHca/CriHcaEncoder.cs:49 (InitializeNew) -- parameters only; frames are encoded in batches
+  CriHcaDecoder      Codecs/CriHca/CriHcaDecoder.cs:11 (Decode)
+  CriHcaFormat       Formats/CriHca/CriHcaFormat.cs:26-84
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, i16p, u8p
+from .gcadpcm import Pcm16Format, _ptr_array
+
+
+class CriHcaQuality:
+    NotSet, Highest, High, Middle, Low, Lowest = range(6)
+
+
+class CriHcaParameters:
+    def __init__(self, Quality=CriHcaQuality.High, Bitrate=0, LimitBitrate=False, ChannelCount=0, SampleRate=0,
+                 SampleCount=-1, Looping=False, LoopStart=0, LoopEnd=0, Progress=None):
+        self.Quality, self.Bitrate, self.LimitBitrate = Quality, Bitrate, LimitBitrate
+        self.ChannelCount, self.SampleRate, self.SampleCount = ChannelCount, SampleRate, SampleCount
+        self.Looping, self.LoopStart, self.LoopEnd, self.Progress = Looping, LoopStart, LoopEnd, Progress
+
+    def _c(self):
+        return _lib.HcaParamsC(self.Quality, self.Bitrate, int(self.LimitBitrate), self.ChannelCount, self.SampleRate,
+                               self.SampleCount, int(self.Looping), self.LoopStart, self.LoopEnd)
+
+
+class HcaInfo:
+    """Thin attribute view over vga_hca_info with the reference's property names."""
+    _MAP = dict(ChannelCount="channel_count", SampleRate="sample_rate", SampleCount="sample_count",
+                FrameCount="frame_count", InsertedSamples="inserted_samples", AppendedSamples="appended_samples",
+                HeaderSize="header_size", FrameSize="frame_size", MinResolution="min_resolution",
+                MaxResolution="max_resolution", TrackCount="track_count", ChannelConfig="channel_config",
+                TotalBandCount="total_band_count", BaseBandCount="base_band_count",
+                StereoBandCount="stereo_band_count", HfrBandCount="hfr_band_count",
+                BandsPerHfrGroup="bands_per_hfr_group", HfrGroupCount="hfr_group_count", Looping="looping",
+                LoopStartFrame="loop_start_frame", LoopEndFrame="loop_end_frame", PreLoopSamples="pre_loop_samples",
+                PostLoopSamples="post_loop_samples", UseAthCurve="use_ath_curve", CommentLength="comment_length")
+
+    def __init__(self, c=None):
+        object.__setattr__(self, "c", c if c is not None else _lib.HcaInfoC())
+
+    def __getattr__(self, name):
+        return getattr(self.c, HcaInfo._MAP[name])
+
+    def __setattr__(self, name, value):
+        setattr(self.c, HcaInfo._MAP[name], int(value))
+
+    @property
+    def LoopStartSample(self):
+        return self.LoopStartFrame * 1024 + self.PreLoopSamples - self.InsertedSamples
+
+    @property
+    def LoopEndSample(self):
+        return (self.LoopEndFrame + 1) * 1024 - self.PostLoopSamples - self.InsertedSamples
+
+
+class CriHcaEncoder:
+    """Only the parameter derivation is exposed per stream; frames are produced by the batched
+    CriHcaFormat.EncodeFromPcm16 (the reference's encoder is a stateful serial object)."""
+
+    def __init__(self, hca):
+        self.Hca = hca
+
+    @property
+    def FrameSize(self):
+        return self.Hca.FrameSize
+
+    @staticmethod
+    def InitializeNew(config):
+        info = _lib.HcaInfoC()
+        cp = config._c()
+        check(_lib.lib().vga_hca_encoder_initialize(C.byref(cp), C.byref(info)))
+        return CriHcaEncoder(HcaInfo(info))
+
+
+class CriHcaDecoder:
+    @staticmethod
+    def Decode(hca, audio, config=None):
+        """short[][] Decode(HcaInfo, byte[][] audio); `audio` is [FrameCount][FrameSize] for one stream, or a
+        list of such arrays for a batch of streams with the same HcaInfo."""
+        single = isinstance(audio, np.ndarray) and audio.ndim == 2
+        streams = [audio] if single else list(audio)
+        flat = [np.ascontiguousarray(a, dtype=np.uint8).reshape(-1) for a in streams]
+        need = hca.FrameCount * hca.FrameSize
+        if any(len(f) < need for f in flat):
+            raise _lib.ArgumentError("audio shorter than FrameCount * FrameSize")
+        nch, n = hca.ChannelCount, max(hca.SampleCount, 0)
+        outs = [np.zeros(n, dtype=np.int16) for _ in range(len(streams) * nch)]
+        check(_lib.lib().vga_hca_decode_batch(C.byref(hca.c), _ptr_array(u8p, flat), len(streams),
+                                               _ptr_array(i16p, outs)))
+        if config is not None and config.Progress is not None:
+            config.Progress.SetTotal(hca.FrameCount * len(streams))
+            config.Progress.ReportAdd(hca.FrameCount * len(streams))
+        per = [outs[s * nch:(s + 1) * nch] for s in range(len(streams))]
+        return per[0] if single else per
+
+
+class CriHcaFormat:
+    def __init__(self, audioData=None, hca=None):
+        self.AudioData = audioData     # [FrameCount][FrameSize] uint8
+        self.Hca = hca
+
+    @property
+    def ChannelCount(self):
+        return self.Hca.ChannelCount if self.Hca else 0
+
+    def EncodeFromPcm16(self, pcm16, config=None):
+        return CriHcaFormat.EncodeBatchFromPcm16([pcm16], config)[0]
+
+    @staticmethod
+    def EncodeBatchFromPcm16(pcm16_list, config=None):
+        """One GPU call for a batch of equally shaped streams (the reference's batch mode runs one serial
+        CriHcaFormat.EncodeFromPcm16 per file under Parallel.ForEach, Cli/Batch.cs:24-25)."""
+        config = config or CriHcaParameters()
+        first = pcm16_list[0]
+        for p in pcm16_list:
+            if (p.ChannelCount, p.SampleCount, p.SampleRate) != (first.ChannelCount, first.SampleCount, first.SampleRate):
+                raise _lib.ArgumentError("streams of one batch must share channel count, length and sample rate")
+        config.ChannelCount, config.SampleRate, config.SampleCount = first.ChannelCount, first.SampleRate, first.SampleCount
+        config.Looping, config.LoopStart, config.LoopEnd = first.Looping, first.LoopStart, first.LoopEnd
+        enc = CriHcaEncoder.InitializeNew(config)                      # CriHcaFormat.cs:44
+        hca = enc.Hca
+        if config.Progress is not None:
+            config.Progress.SetTotal(hca.FrameCount * len(pcm16_list))
+        chans = [c for p in pcm16_list for c in p.Channels]
+        outs = [np.zeros(hca.FrameCount * hca.FrameSize, dtype=np.uint8) for _ in pcm16_list]
+        info = _lib.HcaInfoC()
+        cp = config._c()
+        check(_lib.lib().vga_hca_encode_batch(_ptr_array(i16p, chans), len(pcm16_list), C.byref(cp), C.byref(info),
+                                               _ptr_array(u8p, outs)))
+        if config.Progress is not None:
+            config.Progress.ReportAdd(hca.FrameCount * len(pcm16_list))
+        return [CriHcaFormat(o.reshape(hca.FrameCount, hca.FrameSize), HcaInfo(info)) for o in outs]
+
+    def ToPcm16(self, config=None):
+        pcm = CriHcaDecoder.Decode(self.Hca, self.AudioData, config)
+        return Pcm16Format(pcm, self.Hca.SampleRate)

@@ -1,0 +1,386 @@
+// capi_hca.hip -- C-ABI entry points for CRI HCA (see include/vgaudio_hip.h).
+// Host side: CriHcaEncoder.Initialize (stream parameters), channel typing, ATH curve; the per-frame
+// work is entirely in hca_encode_kernel.hip / hca_decode_kernels.hip.
+#include "common.hpp"
+#include "hca_kernels.hpp"
+
+#include <cmath>
+#include <mutex>
+
+namespace hosttab {
+#include "hca_tables_host.inc"
+}
+
+using namespace vga;
+
+namespace {
+
+int divide_by_round_up(int v, int d) { return (int)std::ceil((double)v / d); }        // Extensions.cs:145
+int get_next_multiple(int value, int multiple)                                        // Helpers.cs:71-80
+{
+    if (multiple <= 0) return value;
+    if (value % multiple == 0) return value;
+    return value + multiple - value % multiple;
+}
+int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// CriHcaEncoder.cs:288-324
+int calculate_bitrate(const vga_hca_info &h, int quality, int bitrate, int limit_bitrate)
+{
+    const int pcm_bitrate = h.sample_rate * h.channel_count * 16;
+    const int max_bitrate = pcm_bitrate / 4;
+    int min_bitrate = 0;
+    int ratio = 6;
+    switch (quality) {
+    case 1: ratio = 4; break;
+    case 2: ratio = 6; break;
+    case 3: ratio = 8; break;
+    case 4: ratio = h.channel_count == 1 ? 10 : 12; break;
+    case 5: ratio = h.channel_count == 1 ? 12 : 16; break;
+    default: break;
+    }
+    bitrate = bitrate != 0 ? bitrate : pcm_bitrate / ratio;
+    if (limit_bitrate) min_bitrate = std::min(h.channel_count == 1 ? 42666 : 32000 * h.channel_count, pcm_bitrate / 6);
+    return clampi(bitrate, min_bitrate, max_bitrate);
+}
+
+// CriHcaEncoder.cs:326-368
+void calculate_band_counts(vga_hca_info &h, int bitrate, int cutoff_freq)
+{
+    h.frame_size = bitrate * 1024 / h.sample_rate / 8;
+    int num_groups = 0;
+    const int pcm_bitrate = h.sample_rate * h.channel_count * 16;
+    int hfr_ratio, cutoff_ratio;
+    if (h.channel_count <= 1 || pcm_bitrate / bitrate <= 6) { hfr_ratio = 6; cutoff_ratio = 12; }
+    else { hfr_ratio = 8; cutoff_ratio = 16; }
+    if (bitrate < pcm_bitrate / cutoff_ratio)
+        cutoff_freq = std::min(cutoff_freq, cutoff_ratio * bitrate / (32 * h.channel_count));
+    const int total_band_count = (int)std::nearbyint(cutoff_freq * 256.0 / h.sample_rate);        // Math.Round
+    const int hfr_start_band = (int)std::min((double)total_band_count,
+                                             std::nearbyint((hfr_ratio * bitrate * 128.0) / pcm_bitrate));
+    const int stereo_start_band = hfr_ratio == 6 ? hfr_start_band : (hfr_start_band + 1) / 2;
+    const int hfr_band_count = total_band_count - hfr_start_band;
+    const int bands_per_group = divide_by_round_up(hfr_band_count, 8);
+    if (bands_per_group > 0) num_groups = divide_by_round_up(hfr_band_count, bands_per_group);
+    h.total_band_count = total_band_count;
+    h.base_band_count = stereo_start_band;
+    h.stereo_band_count = hfr_start_band - stereo_start_band;
+    h.hfr_group_count = num_groups;
+    h.bands_per_hfr_group = bands_per_group;
+}
+
+// CriHcaFrame.cs:33-52
+void channel_types(const vga_hca_info &h, int types[8])
+{
+    for (int i = 0; i < 8; i++) types[i] = hca::CH_DISCRETE;
+    const int cpt = h.channel_count / (h.track_count > 0 ? h.track_count : 1);
+    if (h.stereo_band_count == 0 || cpt == 1) return;
+    const int P = hca::CH_STEREO_PRIMARY, S = hca::CH_STEREO_SECONDARY, D = hca::CH_DISCRETE;
+    const int t2[] = {P, S}, t3[] = {P, S, D}, t4a[] = {P, S, D, D}, t4b[] = {P, S, P, S}, t5a[] = {P, S, D, D, D},
+              t5b[] = {P, S, D, P, S}, t6[] = {P, S, D, D, P, S}, t7[] = {P, S, D, D, P, S, D},
+              t8[] = {P, S, D, D, P, S, P, S};
+    const int *src = nullptr;
+    switch (cpt) {
+    case 2: src = t2; break;
+    case 3: src = t3; break;
+    case 4: src = h.channel_config != 0 ? t4a : t4b; break;
+    case 5: src = h.channel_config > 2 ? t5a : t5b; break;
+    case 6: src = t6; break;
+    case 7: src = t7; break;
+    case 8: src = t8; break;
+    default: break;
+    }
+    if (src) for (int i = 0; i < cpt; i++) types[i] = src[i];
+}
+
+int make_device_info(const vga_hca_info &h, hca::DeviceInfo &d)
+{
+    if (h.channel_count < 1 || h.channel_count > 8 || h.frame_size < 8 || h.frame_size > 0xFFFF || h.frame_count < 0 ||
+        h.total_band_count < 0 || h.total_band_count > 128 || h.base_band_count < 0 || h.stereo_band_count < 0 ||
+        h.base_band_count + h.stereo_band_count > 128 || h.hfr_group_count < 0 || h.hfr_group_count > 8 ||
+        (h.hfr_group_count > 0 && h.bands_per_hfr_group <= 0)) {
+        set_error("HcaInfo is inconsistent (channels %d, frame size %d, bands %d/%d/%d, hfr groups %d)", h.channel_count,
+                  h.frame_size, h.total_band_count, h.base_band_count, h.stereo_band_count, h.hfr_group_count);
+        return VGA_ERR_ARGUMENT;
+    }
+    memset(&d, 0, sizeof d);
+    d.nch = h.channel_count;
+    d.frame_size = h.frame_size;
+    d.frame_count = h.frame_count;
+    d.sample_count = h.sample_count;
+    d.inserted_samples = h.inserted_samples;
+    d.total_band_count = h.total_band_count;
+    d.base_band_count = h.base_band_count;
+    d.stereo_band_count = h.stereo_band_count;
+    d.hfr_band_count = h.hfr_band_count;
+    d.bands_per_hfr_group = h.bands_per_hfr_group;
+    d.hfr_group_count = h.hfr_group_count;
+    int types[8];
+    channel_types(h, types);
+    for (int i = 0; i < 8; i++) {
+        d.channel_type[i] = types[i];
+        d.coded_count[i] = types[i] == hca::CH_STEREO_SECONDARY ? h.base_band_count
+                                                                 : h.base_band_count + h.stereo_band_count;
+    }
+    if (h.use_ath_curve) {                                     // CriHcaFrame.ScaleAthCurve :60-83
+        int acc = 0, i;
+        for (i = 0; i < 128; i++) {
+            acc += h.sample_rate;
+            const int index = acc >> 13;
+            if (index >= 654) break;
+            d.ath_curve[i] = hosttab::HCA_AthCurve[index];
+        }
+        for (; i < 128; i++) d.ath_curve[i] = 0xff;
+    }
+    return VGA_OK;
+}
+
+// x^(8k) mod (x^16 + x^15 + x^2 + 1), k = 0..4095, uploaded once per device
+struct CrcPow {
+    std::mutex mu;
+    uint16_t *dev[64] = {};
+} g_crc_pow;
+
+int crc_pow_table(const uint16_t **out)
+{
+    int device = 0;
+    VGA_HIP_TRY(hipGetDevice(&device));
+    if (device < 0 || device >= 64) { set_error("device index out of range"); return VGA_ERR_DEVICE; }
+    std::lock_guard<std::mutex> lock(g_crc_pow.mu);
+    if (!g_crc_pow.dev[device]) {
+        static uint16_t host[4096];
+        unsigned v = 1;                      // x^0
+        for (int k = 0; k < 4096; k++) {
+            host[k] = (uint16_t)v;
+            for (int j = 0; j < 8; j++) v = ((v << 1) ^ ((v & 0x8000u) ? 0x8005u : 0u)) & 0xFFFFu;
+        }
+        uint16_t *d = nullptr;
+        VGA_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), sizeof host));
+        VGA_HIP_TRY(hipMemcpy(d, host, sizeof host, hipMemcpyHostToDevice));
+        g_crc_pow.dev[device] = d;
+    }
+    *out = g_crc_pow.dev[device];
+    return VGA_OK;
+}
+
+int status_to_error(int status)
+{
+    if (status & 4) { set_error("Bitrate is set too low."); return VGA_ERR_INVALID_DATA; }     // CriHcaEncoder.cs:471
+    if (status & 8) { set_error("evaluation boundary search failed (NotImplementedException in the reference)"); return VGA_ERR_INVALID_OP; }
+    if (status & 1) { set_error("Invalid frame header"); return VGA_ERR_INVALID_DATA; }        // CriHcaPacking.cs:76
+    if (status & 2) { set_error("scale-factor delta out of range (frame state would be stale in the reference)"); return VGA_ERR_INVALID_DATA; }
+    return VGA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// CriHcaEncoder.Initialize (CriHcaEncoder.cs:61-114)
+int vga_hca_encoder_initialize(const vga_hca_params *c, vga_hca_info *h)
+{
+    if (!c || !h) { set_error("null argument"); return VGA_ERR_ARGUMENT; }
+    memset(h, 0, sizeof *h);
+    if (c->channel_count > 8 || c->channel_count < 1) {
+        set_error("HCA channel count must be 8 or below");
+        return VGA_ERR_OUT_OF_RANGE;
+    }
+    if (c->sample_rate <= 0 || c->sample_count < 0) { set_error("bad sample rate / count"); return VGA_ERR_ARGUMENT; }
+    const int cutoff = c->sample_rate / 2;
+    h->channel_count = c->channel_count;
+    h->track_count = 1;
+    h->sample_count = c->sample_count;
+    h->sample_rate = c->sample_rate;
+    h->min_resolution = 1;
+    h->max_resolution = 15;
+    h->inserted_samples = hca::SPSF;
+    const int bitrate = calculate_bitrate(*h, c->quality, c->bitrate, c->limit_bitrate);
+    if (bitrate <= 0) { set_error("bitrate resolves to %d", bitrate); return VGA_ERR_OUT_OF_RANGE; }
+    calculate_band_counts(*h, bitrate, cutoff);
+    if (h->bands_per_hfr_group > 0) {                           // HcaInfo.CalculateHfrValues :52-58
+        h->hfr_band_count = h->total_band_count - h->base_band_count - h->stereo_band_count;
+        h->hfr_group_count = divide_by_round_up(h->hfr_band_count, h->bands_per_hfr_group);
+    }
+    {                                                           // SetChannelConfiguration :370-381
+        const int cpt = h->channel_count / h->track_count;
+        const int cfg = hosttab::HCA_DefaultChannelMapping[cpt];
+        if (hosttab::HCA_ValidChannelMappings[cpt - 1][cfg] != 1) {
+            set_error("Channel mapping is not valid.");
+            return VGA_ERR_OUT_OF_RANGE;
+        }
+        h->channel_config = cfg;
+    }
+    int input_sample_count = h->sample_count;
+    if (c->looping) {
+        h->looping = 1;
+        h->sample_count = std::min(c->loop_end, c->sample_count);
+        h->inserted_samples += get_next_multiple(c->loop_start, hca::SPF) - c->loop_start;
+        {                                                       // CalculateLoopInfo :383-398
+            const int ls = c->loop_start + h->inserted_samples, le = c->loop_end + h->inserted_samples;
+            h->loop_start_frame = ls / hca::SPF;
+            h->pre_loop_samples = ls % hca::SPF;
+            h->loop_end_frame = le / hca::SPF;
+            h->post_loop_samples = hca::SPF - le % hca::SPF;
+            if (h->post_loop_samples == hca::SPF) { h->loop_end_frame--; h->post_loop_samples = 0; }
+        }
+        input_sample_count = std::min(get_next_multiple(h->sample_count, hca::SPSF), c->sample_count);
+        input_sample_count += hca::SPSF * 2;
+    }
+    {                                                           // CalculateHeaderSize :400-418
+        h->header_size = get_next_multiple(96 + h->comment_length, 32);
+        if (h->looping) {
+            const int off = h->header_size + h->frame_size * h->loop_start_frame;
+            const int padding_bytes = get_next_multiple(off, 2048) - off;
+            const int padding_frames = padding_bytes / h->frame_size;
+            h->inserted_samples += padding_frames * hca::SPF;
+            h->loop_start_frame += padding_frames;
+            h->loop_end_frame += padding_frames;
+            h->header_size += padding_bytes % h->frame_size;
+        }
+    }
+    const int total_samples = input_sample_count + h->inserted_samples;
+    h->frame_count = divide_by_round_up(total_samples, hca::SPF);
+    h->appended_samples = h->frame_count * hca::SPF - h->inserted_samples - input_sample_count;
+    return VGA_OK;
+}
+
+size_t vga_hca_decode_workspace_bytes(const vga_hca_info *h, int nstreams)
+{
+    if (!h || nstreams <= 0 || h->frame_count <= 0 || h->channel_count < 1 || h->channel_count > 8) return 0;
+    return hca::unpack_record_bytes(h->channel_count) * (size_t)h->frame_count * (size_t)nstreams;
+}
+
+int vga_hca_encode_device(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, int pcm_length,
+                          const vga_hca_info *h, uint8_t *d_frames, int64_t frames_pitch, int *d_status, void *stream)
+{
+    if (!h) { set_error("null HcaInfo"); return VGA_ERR_ARGUMENT; }
+    if (h->looping) { set_error("looping HCA encode is not implemented on the device path yet"); return VGA_ERR_INVALID_OP; }
+    // fewer bits than sync + noise level + checksum + one 3-bit channel header each: the reference's
+    // CalculateNoiseLevel necessarily ends in InvalidDataException (CriHcaEncoder.cs:469-472)
+    if (h->channel_count >= 1 && h->channel_count <= 8 && h->frame_size * 8 < 48 + 3 * h->channel_count + 16) {
+        set_error("Bitrate is set too low.");
+        return VGA_ERR_INVALID_DATA;
+    }
+    hca::DeviceInfo d;
+    if (int rc = make_device_info(*h, d)) return rc;
+    if (nstreams < 0 || pcm_length < 0 || (frames_pitch & 1) || frames_pitch < (int64_t)h->frame_count * h->frame_size ||
+        ch_pitch < pcm_length || stream_pitch < ch_pitch * h->channel_count) {
+        set_error("bad sizes / pitches for vga_hca_encode_device");
+        return VGA_ERR_ARGUMENT;
+    }
+    const uint16_t *pow = nullptr;
+    if (int rc = crc_pow_table(&pow)) return rc;
+    return hca::launch_encode(d_pcm, stream_pitch, ch_pitch, nstreams, pcm_length, d, d_frames, frames_pitch, pow,
+                              d_status, (hipStream_t)stream);
+}
+
+int vga_hca_decode_device(const vga_hca_info *h, const uint8_t *d_frames, int64_t frames_pitch, int nstreams,
+                          int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, void *d_workspace,
+                          size_t workspace_bytes, int *d_status, void *stream)
+{
+    if (!h) { set_error("null HcaInfo"); return VGA_ERR_ARGUMENT; }
+    hca::DeviceInfo d;
+    if (int rc = make_device_info(*h, d)) return rc;
+    if (nstreams < 0 || (frames_pitch & 3) || ((uintptr_t)d_frames & 3) ||
+        frames_pitch < (int64_t)h->frame_count * h->frame_size + 8 || ch_pitch < h->sample_count ||
+        stream_pitch < ch_pitch * h->channel_count || workspace_bytes < vga_hca_decode_workspace_bytes(h, nstreams)) {
+        set_error("bad sizes / pitches / workspace for vga_hca_decode_device (frames need 4-byte alignment and 8 bytes of slack)");
+        return VGA_ERR_ARGUMENT;
+    }
+    return hca::launch_decode(d_frames, frames_pitch, nstreams, d, d_pcm, stream_pitch, ch_pitch, d_workspace, d_status,
+                              (hipStream_t)stream);
+}
+
+// CriHcaFormat.EncodeFromPcm16 (Formats/CriHca/CriHcaFormat.cs:34-84) for a batch of equally shaped streams.
+// pcm: nstreams*channel_count planar pointers (stream-major); frames_out[s]: frame_count*frame_size bytes.
+int vga_hca_encode_batch(const int16_t *const *pcm, int nstreams, const vga_hca_params *p, vga_hca_info *info_out,
+                         uint8_t *const *frames_out)
+{
+    vga_hca_info h;
+    if (int rc = vga_hca_encoder_initialize(p, &h)) return rc;
+    if (info_out) *info_out = h;
+    if (nstreams < 0) { set_error("negative stream count"); return VGA_ERR_ARGUMENT; }
+    if (nstreams == 0) return VGA_OK;
+    if (!pcm || !frames_out) { set_error("null array"); return VGA_ERR_ARGUMENT; }
+    const int nch = h.channel_count, n = p->sample_count;
+    for (int i = 0; i < nstreams * nch; i++)
+        if (!pcm[i] && n > 0) { set_error("pcm[%d] is null", i); return VGA_ERR_ARGUMENT; }
+    for (int i = 0; i < nstreams; i++)
+        if (!frames_out[i]) { set_error("frames_out[%d] is null", i); return VGA_ERR_ARGUMENT; }
+    if (int rc = require_device()) return rc;
+    Stream st;
+    VGA_HIP_TRY(st.create());
+    DevBuf d_pcm, d_frames, d_status;
+    const int64_t ch_pitch = round_up(n > 0 ? n : 1, 8);
+    const int64_t stream_pitch = ch_pitch * nch;
+    const int64_t fbytes = (int64_t)h.frame_count * h.frame_size;
+    const int64_t frames_pitch = round_up(fbytes + 8, 16);
+    VGA_HIP_TRY(d_pcm.alloc((size_t)nstreams * stream_pitch * 2));
+    VGA_HIP_TRY(d_frames.alloc((size_t)nstreams * frames_pitch));
+    VGA_HIP_TRY(d_status.alloc(sizeof(int)));
+    VGA_HIP_TRY(hipMemsetAsync(d_status.p, 0, sizeof(int), st.s));
+    for (int i = 0; i < nstreams * nch; i++)
+        if (n > 0)
+            VGA_HIP_TRY(hipMemcpyAsync(d_pcm.as<int16_t>() + (int64_t)i * ch_pitch, pcm[i], (size_t)n * 2,
+                                       hipMemcpyHostToDevice, st.s));
+    if (int rc = vga_hca_encode_device(d_pcm.as<int16_t>(), stream_pitch, ch_pitch, nstreams, n, &h, d_frames.as<uint8_t>(),
+                                       frames_pitch, d_status.as<int>(), st.s))
+        return rc;
+    int status = 0;
+    VGA_HIP_TRY(hipMemcpyAsync(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost, st.s));
+    for (int i = 0; i < nstreams; i++)
+        VGA_HIP_TRY(hipMemcpyAsync(frames_out[i], d_frames.as<uint8_t>() + (int64_t)i * frames_pitch, (size_t)fbytes,
+                                   hipMemcpyDeviceToHost, st.s));
+    VGA_HIP_TRY(hipStreamSynchronize(st.s));
+    return status_to_error(status);
+}
+
+// CriHcaFormat.ToPcm16 (CriHcaFormat.cs:26-32 -> CriHcaDecoder.Decode, CriHcaDecoder.cs:11-29), batched.
+int vga_hca_decode_batch(const vga_hca_info *h, const uint8_t *const *frames, int nstreams, int16_t *const *pcm_out)
+{
+    if (!h) { set_error("null HcaInfo"); return VGA_ERR_ARGUMENT; }
+    hca::DeviceInfo d;
+    if (int rc = make_device_info(*h, d)) return rc;
+    if (nstreams < 0 || h->sample_count < 0) { set_error("negative size"); return VGA_ERR_ARGUMENT; }
+    if (nstreams == 0) return VGA_OK;
+    if (!frames || !pcm_out) { set_error("null array"); return VGA_ERR_ARGUMENT; }
+    const int nch = h->channel_count;
+    for (int i = 0; i < nstreams; i++)
+        if (!frames[i] && h->frame_count > 0) { set_error("frames[%d] is null", i); return VGA_ERR_ARGUMENT; }
+    for (int i = 0; i < nstreams * nch; i++)
+        if (!pcm_out[i] && h->sample_count > 0) { set_error("pcm_out[%d] is null", i); return VGA_ERR_ARGUMENT; }
+    if (int rc = require_device()) return rc;
+    Stream st;
+    VGA_HIP_TRY(st.create());
+    DevBuf d_pcm, d_frames, d_status, d_ws;
+    const int n = h->sample_count;
+    const int64_t ch_pitch = round_up(n > 0 ? n : 1, 8);
+    const int64_t stream_pitch = ch_pitch * nch;
+    const int64_t fbytes = (int64_t)h->frame_count * h->frame_size;
+    const int64_t frames_pitch = round_up(fbytes + 8, 16);
+    VGA_HIP_TRY(d_pcm.alloc((size_t)nstreams * stream_pitch * 2));
+    VGA_HIP_TRY(hipMemsetAsync(d_pcm.p, 0, (size_t)nstreams * stream_pitch * 2, st.s));
+    VGA_HIP_TRY(d_frames.alloc((size_t)nstreams * frames_pitch));
+    VGA_HIP_TRY(hipMemsetAsync(d_frames.p, 0, (size_t)nstreams * frames_pitch, st.s));
+    VGA_HIP_TRY(d_status.alloc(sizeof(int)));
+    VGA_HIP_TRY(hipMemsetAsync(d_status.p, 0, sizeof(int), st.s));
+    const size_t wsb = vga_hca_decode_workspace_bytes(h, nstreams);
+    VGA_HIP_TRY(d_ws.alloc(wsb));
+    for (int i = 0; i < nstreams; i++)
+        if (fbytes > 0)
+            VGA_HIP_TRY(hipMemcpyAsync(d_frames.as<uint8_t>() + (int64_t)i * frames_pitch, frames[i], (size_t)fbytes,
+                                       hipMemcpyHostToDevice, st.s));
+    if (int rc = vga_hca_decode_device(h, d_frames.as<uint8_t>(), frames_pitch, nstreams, d_pcm.as<int16_t>(), stream_pitch,
+                                       ch_pitch, d_ws.p, wsb, d_status.as<int>(), st.s))
+        return rc;
+    int status = 0;
+    VGA_HIP_TRY(hipMemcpyAsync(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost, st.s));
+    for (int i = 0; i < nstreams * nch; i++)
+        if (n > 0)
+            VGA_HIP_TRY(hipMemcpyAsync(pcm_out[i], d_pcm.as<int16_t>() + (int64_t)i * ch_pitch, (size_t)n * 2,
+                                       hipMemcpyDeviceToHost, st.s));
+    VGA_HIP_TRY(hipStreamSynchronize(st.s));
+    return status_to_error(status);
+}
+
+}  // extern "C"

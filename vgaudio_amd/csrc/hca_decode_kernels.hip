@@ -1,0 +1,313 @@
+// hca_decode_kernels.hip -- CRI HCA decoder for gfx950.
+//
+// Replaces VGAudio/Codecs/CriHca/CriHcaDecoder.cs:11-192 and the unpack half of
+// VGAudio/Codecs/CriHca/CriHcaPacking.cs:10-229 (+ Utilities/BitReader.cs, Mdct.RunImdct Mdct.cs:94-119).
+//
+// Two kernels, because the two halves want opposite shapes:
+//   hca_unpack_kernel : the frame bitstream is variable-length coded -> serial inside a frame, but
+//                       every frame of every stream is independent.  lane = frame, 64 frames per wave;
+//                       control flow is uniform across lanes (same band counts), only data differs.
+//                       Output: scale factors, resolutions, intensity/HFR scales and the quantised
+//                       spectra (int16) in a per-frame record in HBM.
+//   hca_imdct_kernel  : workgroup = (stream, frame): dequantise, high-frequency reconstruction,
+//                       intensity stereo, 128-point DCT-IV (exact staged butterflies), window +
+//                       overlap-add, PCM16.  The IMDCT overlap (`_imdctPrevious`) is the only
+//                       inter-frame state; instead of carrying it, each workgroup recomputes the
+//                       previous frame's last sub-frame (9 transforms per channel instead of 8), so
+//                       all frames stay independent.
+// A frame whose scale-factor delta decoding fails keeps stale state in the reference
+// (UnpackFrameHeader returns false, CriHcaPacking.cs:84); that is sequential state a lane-per-frame
+// decoder cannot reproduce -- such frames (corrupt streams only) are flagged in *status (bit 1), an
+// invalid sync word in bit 0 (the reference throws InvalidDataException).
+#include "common.hpp"
+#include "hca_device.hpp"
+#include "hca_kernels.hpp"
+
+namespace vga {
+namespace hca {
+
+// ---- per-frame record written by the unpacker ------------------------------------------------
+// [0] noise level (u16) [2] evaluation boundary (u8) [3] flags (u8); then per channel 272 bytes:
+// scale factors[128], resolutions[128], intensity[8], hfr scales[8]; then int16 q[8][nch][128].
+__host__ __device__ inline size_t record_channel_offset(int c) { return 16 + (size_t)c * 272; }
+__host__ __device__ inline size_t record_q_offset(int nch) { return 16 + (size_t)nch * 272; }
+size_t unpack_record_bytes(int nch) { return (16 + (size_t)nch * 272 + (size_t)8 * nch * 128 * 2 + 15) / 16 * 16; }
+
+struct BitCursor {
+    const uint32_t *base;   // 4-byte aligned start of the stream's frame data
+    int64_t frame_bit0;     // absolute bit position of this frame inside the stream
+    int frame_bits;
+    int pos;                // bit position inside the frame (BitReader.Position)
+
+    // BitReader.PeekInt (BitReader.cs:51-92): MSB-first; bits past the end of the frame read as 0
+    __device__ __forceinline__ int peek(int bits) const
+    {
+        if (bits == 0) return 0;
+        const int64_t a = frame_bit0 + pos;
+        const int64_t w = a >> 5;
+        const uint64_t hi = __builtin_bswap32(base[w]);
+        const uint64_t lo = __builtin_bswap32(base[w + 1]);
+        const uint64_t win = (hi << 32) | lo;
+        int v = (int)((win << (a & 31)) >> (64 - bits));
+        const int avail = frame_bits - pos;
+        if (bits > avail) {
+            if (avail <= 0) return 0;
+            v = (v >> (bits - avail)) << (bits - avail);
+        }
+        return v;
+    }
+    __device__ __forceinline__ int read(int bits)
+    {
+        const int v = peek(bits);
+        pos += bits;
+        return v;
+    }
+};
+
+__global__ __launch_bounds__(64) void hca_unpack_kernel(
+    const uint8_t *__restrict__ frames, int64_t stream_pitch, int nstreams, DeviceInfo info,
+    uint8_t *__restrict__ records, size_t record_bytes, int *__restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_res[];   // [nch][128][64]
+    const int lane = threadIdx.x;
+    const int64_t gid = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t total = (int64_t)nstreams * info.frame_count;
+    const bool live = gid < total;
+    const int64_t id = live ? gid : total - 1;
+    const int stream = (int)(id / info.frame_count);
+    const int frame = (int)(id % info.frame_count);
+    const int nch = info.nch;
+
+    BitCursor r;
+    r.base = reinterpret_cast<const uint32_t *>(frames + (int64_t)stream * stream_pitch);
+    r.frame_bit0 = (int64_t)frame * info.frame_size * 8;
+    r.frame_bits = info.frame_size * 8;
+    r.pos = 0;
+    uint8_t *rec = records + (size_t)id * record_bytes;
+
+    int flags = 0;
+    if (r.read(16) != 0xffff) flags |= 1;
+    const int noise_level = r.read(9);
+    const int eval_boundary = r.read(7);
+
+    for (int c = 0; c < nch; c++) {
+        uint8_t *rc = rec + record_channel_offset(c);
+        const int count = info.coded_count[c];
+        // ReadScaleFactors / DeltaDecode (CriHcaPacking.cs:111-130, :185-211)
+        const int delta_bits = r.read(3);
+        int prev = 0;
+        bool failed = false;
+        const int max_delta = delta_bits > 0 ? 1 << (delta_bits - 1) : 0;
+        for (int i = 0; i < 128; i++) {
+            int sf = 0;
+            if (i < count && delta_bits != 0) {
+                if (delta_bits >= 6 || i == 0) {
+                    sf = r.read(6);
+                } else if (!failed) {
+                    const int delta = r.peek(delta_bits) - (max_delta - 1);   // ReadOffsetBinary, positive bias
+                    r.pos += delta_bits;
+                    if (delta < max_delta) {
+                        sf = prev + delta;
+                        if (sf < 0 || sf > 63) { failed = true; sf = 0; }
+                    } else {
+                        sf = r.read(6);
+                    }
+                }
+                prev = sf;
+            }
+            // delta_bits == 0: Array.Clear of ALL 128 scale factors (:114-118); >= count stay 0 here
+            if (live) rc[i] = (uint8_t)sf;
+            int res = 0;
+            if (i < count) {
+                const int noise = info.ath_curve[i] + noise_level - (i < eval_boundary ? 1 : 0);
+                res = calculate_resolution(sf, noise);
+            }
+            if (live) rc[128 + i] = (uint8_t)res;
+            s_res[((size_t)c * 128 + i) * 64 + lane] = (uint8_t)res;
+        }
+        if (failed) flags |= 2;
+        if (info.channel_type[c] == CH_STEREO_SECONDARY) {
+            for (int i = 0; i < 8; i++) { const int v = r.read(4); if (live) rc[256 + i] = (uint8_t)v; }
+        } else if (info.hfr_group_count > 0) {
+            for (int i = 0; i < info.hfr_group_count; i++) { const int v = r.read(6); if (live) rc[264 + i] = (uint8_t)v; }
+        }
+    }
+
+    // ReadSpectralCoefficients (:148-183)
+    int16_t *q = reinterpret_cast<int16_t *>(rec + record_q_offset(nch));
+    for (int sf = 0; sf < SUBFRAMES; sf++) {
+        for (int c = 0; c < nch; c++) {
+            const int count = info.coded_count[c];
+            int16_t *qrow = q + ((size_t)sf * nch + c) * 128;
+            for (int s = 0; s < count; s++) {
+                const int resolution = s_res[((size_t)c * 128 + s) * 64 + lane];
+                int bits = HCA_QuantizedSpectrumMaxBits[resolution];
+                const int code = r.peek(bits);
+                int value;
+                if (resolution < 8) {
+                    bits = HCA_QuantizedSpectrumBits[resolution][code];
+                    value = HCA_QuantizedSpectrumValue[resolution][code];
+                } else {
+                    value = code / 2 * (1 - (code % 2 * 2));
+                    if (value == 0) bits--;
+                }
+                r.pos += bits;
+                if (live) qrow[s] = (int16_t)value;
+            }
+        }
+    }
+    if (live) {
+        rec[0] = (uint8_t)(noise_level & 0xff);
+        rec[1] = (uint8_t)(noise_level >> 8);
+        rec[2] = (uint8_t)eval_boundary;
+        rec[3] = (uint8_t)flags;
+        if (flags && status) atomicOr(status, flags);
+    }
+}
+
+// ---- dequantise + IMDCT ----------------------------------------------------------------------
+// LDS: spec[nch][9][128] f64 (slot 0 = previous frame's sub-frame 7, slots 1..8 = this frame),
+//      tmp[8][128] f64 butterfly scratch, dct[9][128] f64 per channel pass.
+__global__ __launch_bounds__(256) void hca_imdct_kernel(
+    const uint8_t *__restrict__ records, size_t record_bytes, int nstreams, DeviceInfo info,
+    int16_t *__restrict__ pcm, int64_t stream_pitch, int64_t ch_pitch)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_mem[];
+    const int nch = info.nch;
+    double *spec = s_mem;                               // [nch][9][128]
+    double *tmp = spec + (size_t)nch * 9 * 128;         // [8][128]
+    double *dct = tmp + 8 * 128;                        // [9][128]
+    double *gain = dct + 9 * 128;                       // [2][nch][128]: previous frame, this frame
+
+    const int tid = threadIdx.x;
+    const int stream = blockIdx.x / info.frame_count;
+    const int frame = blockIdx.x % info.frame_count;
+    const uint8_t *rec_cur = records + ((size_t)stream * info.frame_count + frame) * record_bytes;
+    const uint8_t *rec_prev = frame > 0 ? rec_cur - record_bytes : nullptr;
+
+    // CalculateGain (CriHcaDecoder.cs:108-114)
+    for (int i = tid; i < 2 * nch * 128; i += 256) {
+        const int which = i / (nch * 128), c = (i / 128) % nch, s = i % 128;
+        const uint8_t *rec = which == 0 ? rec_prev : rec_cur;
+        double g = 0.0;
+        if (rec && s < info.coded_count[c]) {
+            const uint8_t *rc = rec + record_channel_offset(c);
+            g = f64_bits(HCA_DequantizerScalingTableBits[rc[s]]) * f64_bits(HCA_QuantizerStepSizeBits[rc[128 + s]]);
+        }
+        gain[i] = g;
+    }
+    __syncthreads();
+
+    // DequantizeFrame (:83-100): spectra = q * gain; bands >= coded count are zero (:180)
+    for (int i = tid; i < nch * 9 * 128; i += 256) {
+        const int c = i / (9 * 128), slot = (i / 128) % 9, s = i % 128;
+        const uint8_t *rec = slot == 0 ? rec_prev : rec_cur;
+        const int sf = slot == 0 ? 7 : slot - 1;
+        double v = 0.0;
+        if (rec && s < info.coded_count[c]) {
+            const int16_t *q = reinterpret_cast<const int16_t *>(rec + record_q_offset(nch));
+            v = (double)(int)q[((size_t)sf * nch + c) * 128 + s] * gain[((slot == 0 ? 0 : 1) * nch + c) * 128 + s];
+        }
+        spec[i] = v;
+    }
+    __syncthreads();
+
+    // ReconstructHighFrequency (:116-145)
+    if (info.hfr_group_count > 0) {
+        const int total_band_count = min(info.total_band_count, 127);
+        const int hfr_start = info.base_band_count + info.stereo_band_count;
+        const int hfr_bands = min(info.hfr_band_count, total_band_count - info.hfr_band_count);
+        for (int i = tid; i < nch * 9 * hfr_bands; i += 256) {
+            const int c = i / (9 * hfr_bands), slot = (i / hfr_bands) % 9, band = i % hfr_bands;
+            if (info.channel_type[c] == CH_STEREO_SECONDARY) continue;
+            const uint8_t *rec = slot == 0 ? rec_prev : rec_cur;
+            if (!rec) continue;
+            const int group = band / info.bands_per_hfr_group;
+            if (group >= info.hfr_group_count) continue;
+            const uint8_t *rc = rec + record_channel_offset(c);
+            const int high = hfr_start + band, low = hfr_start - band - 1;
+            const int index = (int)rc[264 + group] - (int)rc[low] + 64;
+            double *sp = spec + ((size_t)c * 9 + slot) * 128;
+            sp[high] = f64_bits(HCA_ScaleConversionTableBits[index & 127]) * sp[low];
+        }
+        __syncthreads();
+    }
+    // ApplyIntensityStereo (:147-166)
+    if (info.stereo_band_count > 0) {
+        const int nb = info.total_band_count - info.base_band_count;
+        for (int i = tid; i < nch * 9 * nb; i += 256) {
+            const int c = i / (9 * nb), slot = (i / nb) % 9, b = info.base_band_count + i % nb;
+            if (info.channel_type[c] != CH_STEREO_PRIMARY) continue;
+            const uint8_t *rec = slot == 0 ? rec_prev : rec_cur;
+            if (!rec) continue;
+            const int sf = slot == 0 ? 7 : slot - 1;
+            const int iq = rec[record_channel_offset(c + 1) + 256 + sf];
+            const double ratio_l = f64_bits(HCA_IntensityRatioTableBits[min(iq, 14)]);
+            const double ratio_r = ratio_l - 2.0;
+            double *l = spec + ((size_t)c * 9 + slot) * 128;
+            double *rr = spec + ((size_t)(c + 1) * 9 + slot) * 128;
+            const double lv = l[b];
+            rr[b] = lv * ratio_r;
+            l[b] = lv * ratio_l;
+        }
+        __syncthreads();
+    }
+
+    // RunImdct (:168-177 -> Mdct.cs:94-119) + PcmFloatToShort (:179-192) + CopyPcmToOutput (:31-45)
+    const int grp = tid >> 5, t = tid & 31;
+    for (int c = 0; c < nch; c++) {
+        const double *sp = spec + (size_t)c * 9 * 128;
+        // 9 transforms: slots 1..8 on the 8 groups, then slot 0 on group 0
+        dct4_128(sp + (size_t)(1 + grp) * 128, tmp + grp * 128, dct + (size_t)(1 + grp) * 128, t, [] { __syncthreads(); });
+        __syncthreads();
+        dct4_128(sp, tmp + grp * 128, grp == 0 ? dct : tmp + grp * 128 + 0, t, [] { __syncthreads(); });
+        __syncthreads();
+        // window + overlap-add: out(slot) needs `previous` produced from slot-1's transform
+        int16_t *dst = pcm + (int64_t)stream * stream_pitch + (int64_t)c * ch_pitch;
+        for (int i = tid; i < 8 * 128; i += 256) {
+            const int slot = 1 + i / 128, j = i % 128;
+            const double *dc = dct + (size_t)slot * 128;        // this sub-frame's dctOut
+            const double *dp = dct + (size_t)(slot - 1) * 128;  // the one before
+            const bool have_prev = slot > 1 || frame > 0;
+            double out;
+            if (j < 64) {
+                const double prev = have_prev ? mdct_window(127 - j) * -dp[63 - j] : 0.0;       // _imdctPrevious[i]
+                out = mdct_window(j) * dc[j + 64] + prev;
+            } else {
+                const int k = j - 64;
+                const double prev = have_prev ? mdct_window(63 - k) * dp[k] : 0.0;              // _imdctPrevious[i+half]
+                out = mdct_window(k + 64) * -dc[127 - k] - prev;
+            }
+            // (int)(x * 32768): RyuJIT cvttsd2si semantics, then Clamp16
+            const double scaled = out * 32768.0;
+            int sample = (scaled > -2147483649.0 && scaled < 2147483648.0) ? (int)scaled : (int)0x80000000;
+            sample = min(max(sample, -32768), 32767);
+            const int64_t tpos = (int64_t)frame * SPF + (slot - 1) * SPSF + j - info.inserted_samples;
+            if (tpos >= 0 && tpos < info.sample_count) dst[tpos] = (int16_t)sample;
+        }
+        __syncthreads();
+    }
+}
+
+int launch_decode(const uint8_t *d_frames, int64_t frames_pitch, int nstreams, const DeviceInfo &info, int16_t *d_pcm,
+                  int64_t stream_pitch, int64_t ch_pitch, void *d_workspace, int *d_status, hipStream_t stream)
+{
+    if (nstreams <= 0 || info.frame_count <= 0) return VGA_OK;
+    const size_t rb = unpack_record_bytes(info.nch);
+    const int64_t total = (int64_t)nstreams * info.frame_count;
+    const size_t lds1 = (size_t)info.nch * 128 * 64;
+    hipLaunchKernelGGL(hca_unpack_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), lds1, stream, d_frames,
+                       frames_pitch, nstreams, info, reinterpret_cast<uint8_t *>(d_workspace), rb, d_status);
+    VGA_HIP_TRY(hipGetLastError());
+    const size_t lds2 = ((size_t)info.nch * 9 * 128 + 8 * 128 + 9 * 128 + (size_t)2 * info.nch * 128) * sizeof(double);
+    if (lds2 > 64 * 1024)
+        VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hca_imdct_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    hipLaunchKernelGGL(hca_imdct_kernel, dim3((unsigned)total), dim3(256), lds2, stream,
+                       reinterpret_cast<const uint8_t *>(d_workspace), rb, nstreams, info, d_pcm, stream_pitch, ch_pitch);
+    VGA_HIP_TRY(hipGetLastError());
+    return VGA_OK;
+}
+
+}  // namespace hca
+}  // namespace vga

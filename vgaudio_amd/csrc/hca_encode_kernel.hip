@@ -1,0 +1,524 @@
+// hca_encode_kernel.hip -- CRI HCA frame encoder for gfx950.
+//
+// Replaces CriHcaEncoder.EncodeFrame and its stages (VGAudio/Codecs/CriHca/CriHcaEncoder.cs:271-286,
+// :420-858), CriHcaPacking.PackFrame (CriHcaPacking.cs:17-58, :231-295), Mdct.RunMdct
+// (VGAudio/Utilities/Mdct.cs:63-92) and the non-looping streaming shell (:126-269): frame k of a
+// stream encodes samples [1024k, 1024k+1024) of "input followed by zeros", with the previous 128
+// samples as MDCT overlap -- so, unlike the reference's stateful encoder, every frame is independent.
+//
+// workgroup = (stream, frame), 256 threads.  All arithmetic is the reference's f64 in the same
+// operation order (-ffp-contract=off); order-dependent f64 sums (intensity-stereo energies, HFR group
+// averages) are done by one lane each; the bit-allocation searches (CalculateUsedBits, ~16 evaluations)
+// are block reductions; packing is a block-wide prefix sum of code lengths + LDS atomic ORs; the
+// CRC-16 is computed in parallel from per-chunk CRCs multiplied by x^(8*bytes_after) mod 0x18005.
+#include "common.hpp"
+#include "hca_device.hpp"
+#include "hca_kernels.hpp"
+
+namespace vga {
+namespace hca {
+
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// CriHcaEncoder.cs:691-709
+__device__ __forceinline__ int find_scale_factor(double value)
+{
+    unsigned low = 0, high = 63;
+    while (low < high) {
+        const unsigned mid = (low + high) / 2;
+        if (f64_bits(HCA_DequantizerScalingTableBits[mid]) <= value) low = mid + 1;
+        else high = mid;
+    }
+    return (int)low;
+}
+
+__device__ __forceinline__ double inv_step(int res) { return f64_bits(HCA_QuantizerInverseStepSizeBits[res]); }
+
+// CriHcaTables.cs:68-78
+__device__ __forceinline__ double dead_zone(int res)
+{
+    const double boundary = f64_bits(HCA_QuantizerStepSizeBits[res]) / 2;
+    return __longlong_as_double(__double_as_longlong(boundary) - (long long)(HCA_ResolutionMaxValue[res] + 1));
+}
+
+// (int)double for values known to be small
+__device__ __forceinline__ int trunc_i(double d) { return (int)d; }
+
+// multiply in GF(2)[x] / (x^16 + x^15 + x^2 + 1)
+__device__ __forceinline__ unsigned gf_mul(unsigned a, unsigned b)
+{
+    unsigned r = 0;
+#pragma unroll
+    for (int i = 15; i >= 0; i--) {
+        r = ((r << 1) ^ ((r & 0x8000u) ? 0x8005u : 0u)) & 0xFFFFu;
+        if ((a >> i) & 1u) r ^= b;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void hca_encode_kernel(
+    const int16_t *__restrict__ pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, int pcm_length,
+    DeviceInfo info, uint8_t *__restrict__ frames, int64_t frames_pitch, const uint16_t *__restrict__ crc_pow,
+    int *__restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_mem[];
+    const int nch = info.nch;
+    double *spectra = s_mem;                               // [nch][8][128]
+    // region B is shared: the MDCT staging (xin, tmp, dctin) is dead before `scaled` is written
+    const size_t region_b = (size_t)nch * 1024 > 25 * 128 ? (size_t)nch * 1024 : 25 * 128;
+    double *scaled = spectra + (size_t)nch * 1024;         // [nch][128][8]
+    double *xin = scaled;                                  // [9][128]
+    double *tmp = xin + 9 * 128;                           // [8][128]
+    double *dctin = tmp + 8 * 128;                         // [8][128]
+    double *hfr_avg = scaled + region_b;                   // [nch][8]
+    double *eratio = hfr_avg + nch * 8;                    // [nch][8]
+    double *dz = eratio + nch * 8;                         // [16]
+    int *sfac = reinterpret_cast<int *>(dz + 16);          // [nch][128]
+    int *ires = sfac + nch * 128;                          // [nch][128]
+    int *red = ires + nch * 128;                           // [264]
+    int *hlb = red + 264;                                  // [nch] header length bits
+    int *dbits = hlb + 8;                                  // [nch] scale-factor delta bits
+    int *cand = dbits + 8;                                 // [nch][8]
+    int *empty = cand + 64;                                // [nch]
+    int *intensity = empty + 8;                            // [nch][8]
+    int *hfrs = intensity + 64;                            // [nch][8]
+    int *scan = hfrs + 64;                                 // [256]
+    uint32_t *fbuf = reinterpret_cast<uint32_t *>(scan + 256);   // frame bits, big-endian words
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int stream = blockIdx.x / info.frame_count;
+    const int frame = blockIdx.x % info.frame_count;
+    const int fwords = (info.frame_size + 3) / 4 + 2;
+
+    auto block_sum = [&](int v) -> int {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        const int total = red[0] + red[1] + red[2] + red[3];
+        __syncthreads();
+        return total;
+    };
+    auto put_bits = [&](int off, unsigned value, int nbits) {
+        if (nbits <= 0) return;
+        const uint64_t win = (uint64_t)value << (64 - nbits - (off & 31));
+        const unsigned hi = (unsigned)(win >> 32), lo = (unsigned)win;
+        if (hi) atomicOr(&fbuf[off >> 5], hi);
+        if (lo) atomicOr(&fbuf[(off >> 5) + 1], lo);
+    };
+
+    for (int i = tid; i < fwords; i += 256) fbuf[i] = 0;
+    if (tid < 16) dz[tid] = dead_zone(tid);
+
+    // ---- PcmToFloat (:845-858) + RunMdct (:834-843 -> Mdct.cs:63-92), channel by channel
+    const int grp = tid >> 5, t = tid & 31;
+    for (int c = 0; c < nch; c++) {
+        const int16_t *src = pcm + (int64_t)stream * stream_pitch + (int64_t)c * ch_pitch;
+        for (int i = tid; i < 9 * 128; i += 256) {
+            const int64_t pos = (int64_t)frame * SPF - SPSF + i;
+            const int sample = (pos >= 0 && pos < pcm_length) ? (int)src[pos] : 0;
+            xin[i] = sample * (1.0 / 32768.0);
+        }
+        __syncthreads();
+        {
+            const double *in = xin + (grp + 1) * 128, *prev = xin + grp * 128;
+            double *din = dctin + grp * 128;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int i = t + 32 * k;
+                const double a = mdct_window(63 - i) * -in[64 + i];
+                const double b = mdct_window(64 + i) * in[63 - i];
+                const double cc = mdct_window(i) * prev[i];
+                const double d = mdct_window(127 - i) * prev[127 - i];
+                din[i] = a - b;
+                din[64 + i] = cc - d;
+            }
+        }
+        __syncthreads();
+        dct4_128(dctin + grp * 128, tmp + grp * 128, spectra + ((size_t)c * 8 + grp) * 128, t, [] { __syncthreads(); });
+        __syncthreads();
+    }
+
+    // ---- EncodeIntensityStereo (:711-764)
+    if (info.stereo_band_count > 0) {
+        if (tid < nch * 8) {
+            const int c = tid / 8, sf = tid % 8;
+            if (info.channel_type[c] == CH_STEREO_PRIMARY) {
+                const double *l = spectra + ((size_t)c * 8 + sf) * 128;
+                const double *r = spectra + ((size_t)(c + 1) * 8 + sf) * 128;
+                double energy_l = 0, energy_r = 0, energy_total = 0;
+                for (int b = info.base_band_count; b < info.total_band_count; b++) {
+                    energy_l += fabs(l[b]);
+                    energy_r += fabs(r[b]);
+                    energy_total += fabs(l[b] + r[b]);
+                }
+                energy_total *= 2;
+                const double energy_lr = energy_r + energy_l;
+                const double stored = 2 * energy_l / energy_lr;
+                double ratio = energy_lr / energy_total;
+                ratio = clampd(ratio, 0.5, 1.4142135623730951 / 2);
+                int quantized = 1;
+                if (energy_r > 0 || energy_l > 0) {
+                    while (quantized < 13 && f64_bits(HCA_IntensityRatioBoundsTableBits[quantized]) >= stored) quantized++;
+                } else {
+                    quantized = 0;
+                    ratio = 1;
+                }
+                intensity[(c + 1) * 8 + sf] = quantized;
+                eratio[c * 8 + sf] = ratio;
+            }
+        }
+        __syncthreads();
+        const int nb = info.total_band_count - info.base_band_count;
+        for (int i = tid; i < nch * 8 * nb; i += 256) {
+            const int c = i / (8 * nb), sf = (i / nb) % 8, b = info.base_band_count + i % nb;
+            if (info.channel_type[c] != CH_STEREO_PRIMARY) continue;
+            double *l = spectra + ((size_t)c * 8 + sf) * 128;
+            double *r = spectra + ((size_t)(c + 1) * 8 + sf) * 128;
+            l[b] = (l[b] + r[b]) * eratio[c * 8 + sf];
+            r[b] = 0;
+        }
+        __syncthreads();
+    }
+
+    // ---- CalculateScaleFactors (:673-689)
+    for (int i = tid; i < nch * 128; i += 256) {
+        const int c = i / 128, b = i % 128;
+        int sfv = 0;
+        if (b < info.coded_count[c]) {
+            double mx = 0;
+            for (int sf = 0; sf < 8; sf++) {
+                const double coeff = fabs(spectra[((size_t)c * 8 + sf) * 128 + b]);
+                mx = coeff > mx ? coeff : mx;
+            }
+            sfv = find_scale_factor(mx);
+        }
+        sfac[i] = sfv;
+    }
+    __syncthreads();
+    // ---- ScaleSpectra (:651-671)
+    for (int i = tid; i < nch * 1024; i += 256) {
+        const int c = i / 1024, b = (i / 8) % 128, sf = i % 8;
+        const int sfv = sfac[c * 128 + b];
+        double v = 0;
+        if (b < info.coded_count[c] && sfv != 0)
+            v = clampd(spectra[((size_t)c * 8 + sf) * 128 + b] * f64_bits(HCA_QuantizerScalingTableBits[sfv]),
+                       -0.999999999999, 0.999999999999);
+        scaled[i] = v;
+    }
+    __syncthreads();
+
+    // ---- CalculateHfrGroupAverages (:766-793) + CalculateHfrScale (:795-832)
+    if (info.hfr_group_count > 0) {
+        if (tid < nch * 8) {
+            const int c = tid / 8, group = tid % 8;
+            if (group < info.hfr_group_count && info.channel_type[c] != CH_STEREO_SECONDARY) {
+                const int hfr_start = info.stereo_band_count + info.base_band_count;
+                double sum = 0.0;
+                int count = 0;
+                int band = hfr_start + group * info.bands_per_hfr_group;
+                for (int i = 0; i < info.bands_per_hfr_group && band < SPSF; band++, i++) {
+                    for (int sf = 0; sf < 8; sf++) sum += fabs(spectra[((size_t)c * 8 + sf) * 128 + band]);
+                    count += 8;
+                }
+                double avg = sum / count;
+                const int lim = min(info.hfr_band_count, info.total_band_count - info.hfr_band_count);
+                sum = 0.0;
+                count = 0;
+                band = group * info.bands_per_hfr_group;
+                for (int i = 0; i < info.bands_per_hfr_group && band < lim; band++, i++) {
+                    for (int sf = 0; sf < 8; sf++) sum += fabs(scaled[((size_t)c * 128 + (hfr_start - band - 1)) * 8 + sf]);
+                    count += 8;
+                }
+                const double average = sum / count;
+                if (average > 0.0) {
+                    const double inv = 1.0 / average;
+                    avg *= inv < 1.4142135623730951 ? inv : 1.4142135623730951;
+                }
+                hfrs[c * 8 + group] = find_scale_factor(avg);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- CalculateFrameHeaderLength (:599-649)
+    auto header_lengths = [&]() {
+        if (tid < nch * 5) {
+            const int c = tid / 5, db = 1 + tid % 5;
+            const int max_delta = (1 << (db - 1)) - 1;
+            int length = 3 + 6;
+            for (int band = 1; band < info.coded_count[c]; band++) {
+                const int delta = sfac[c * 128 + band] - sfac[c * 128 + band - 1];
+                length += abs(delta) > max_delta ? db + 6 : db;
+            }
+            cand[c * 8 + db] = length;
+        } else if (tid >= 64 && tid < 64 + nch) {
+            const int c = tid - 64;
+            int e = 1;
+            for (int i = 0; i < info.coded_count[c]; i++)
+                if (sfac[c * 128 + i] != 0) { e = 0; break; }
+            empty[c] = e;
+        }
+        __syncthreads();
+        if (tid < nch) {
+            const int c = tid;
+            int len, db;
+            if (empty[c]) { len = 3; db = 0; }
+            else {
+                db = 6;
+                len = 3 + 6 * info.coded_count[c];
+                for (int k = 1; k < 6; k++)
+                    if (cand[c * 8 + k] < len) { len = cand[c * 8 + k]; db = k; }
+            }
+            if (info.channel_type[c] == CH_STEREO_SECONDARY) len += 32;
+            else if (info.hfr_group_count > 0) len += 6 * info.hfr_group_count;
+            hlb[c] = len;
+            dbits[c] = db;
+        }
+        __syncthreads();
+    };
+    header_lengths();
+
+    // ---- CalculateUsedBits (:554-597) as a block reduction
+    auto used_bits = [&](int noise_level, int eval_boundary) -> int {
+        int partial = 0;
+        for (int i = tid; i < nch * 128; i += 256) {
+            const int c = i / 128, b = i % 128;
+            if (b >= info.coded_count[c]) continue;
+            const int noise = b < eval_boundary ? noise_level - 1 : noise_level;
+            const int res = calculate_resolution(sfac[i], noise);
+            const double *x = scaled + (size_t)i * 8;
+            if (res >= 8) {
+                const int bits = HCA_QuantizedSpectrumMaxBits[res] - 1;
+                const double d = dz[res];
+#pragma unroll
+                for (int sf = 0; sf < 8; sf++) partial += bits + (fabs(x[sf]) >= d ? 1 : 0);
+            } else {
+                const double inv = inv_step(res);
+                const double up = inv + 1;
+                const int down = trunc_i(inv + 0.5 - 8);
+#pragma unroll
+                for (int sf = 0; sf < 8; sf++) {
+                    const int q = trunc_i(x[sf] * inv + up) - down;
+                    partial += HCA_QuantizeSpectrumBits[res][q];
+                }
+            }
+        }
+        int total = block_sum(partial) + 16 + 16 + 16;
+        for (int c = 0; c < nch; c++) total += hlb[c];
+        return total;
+    };
+
+    // ---- CalculateNoiseLevel (:457-485) / BinarySearchLevel (:502-523)
+    const int available = info.frame_size * 8;
+    auto search_level = [&]() -> int {
+        int low = 0, high = 255, mid_value = 0;
+        while (low != high) {
+            const int mid = (low + high) / 2;
+            mid_value = used_bits(mid, 0);
+            if (mid_value > available) low = mid + 1;
+            else high = mid;
+        }
+        return (low == 255 && mid_value > available) ? -1 : low;
+    };
+    int level = search_level();
+    int highest_band = info.base_band_count + info.stereo_band_count - 1;
+    bool too_low = false;
+    while (level < 0) {
+        highest_band -= 2;
+        if (highest_band < 0) { too_low = true; break; }
+        if (tid < nch) {
+            sfac[tid * 128 + highest_band + 1] = 0;
+            sfac[tid * 128 + highest_band + 2] = 0;
+        }
+        __syncthreads();
+        header_lengths();
+        level = search_level();
+    }
+    if (too_low) {                       // InvalidDataException("Bitrate is set too low.")
+        if (tid == 0 && status) atomicOr(status, 4);
+        level = 255;
+    }
+    // ---- CalculateEvaluationBoundary (:487-500) / BinarySearchBoundary (:525-552)
+    int boundary = 0;
+    if (level != 0) {
+        int low = 0, high = 127;
+        while (abs(high - low) > 1) {
+            const int mid = (low + high) / 2;
+            const int mid_value = used_bits(level, mid);
+            if (available < mid_value) high = mid - 1;
+            else low = mid;
+        }
+        if (low == high) boundary = low < 127 ? low : -1;
+        else {
+            const int hi_value = used_bits(level, high);
+            boundary = hi_value > available ? low : high;
+        }
+        if (boundary < 0) {               // NotImplementedException in the reference
+            if (tid == 0 && status) atomicOr(status, 8);
+            boundary = 0;
+        }
+    }
+
+    // ---- CalculateFrameResolutions (:441-455)
+    for (int i = tid; i < nch * 128; i += 256) {
+        const int c = i / 128, b = i % 128;
+        ires[i] = b < info.coded_count[c] ? calculate_resolution(sfac[i], b < boundary ? level - 1 : level) : 0;
+    }
+    __syncthreads();
+
+    // ---- PackFrame (CriHcaPacking.cs:17-58); a frame the reference refuses ("Bitrate is set too low.")
+    // is left zero -- its codes would not fit the frame
+    if (tid == 0 && !too_low) fbuf[0] = 0xFFFF0000u | ((unsigned)level << 7) | (unsigned)boundary;
+    if (tid < nch && !too_low) {
+        // WriteScaleFactors (:262-295) + intensity / HFR scales; one lane per channel
+        const int c = tid;
+        int off = 32;
+        for (int k = 0; k < c; k++) off += hlb[k];
+        const int db = dbits[c];
+        const int *sc = sfac + c * 128;
+        put_bits(off, (unsigned)db, 3);
+        off += 3;
+        if (db == 6) {
+            for (int i = 0; i < info.coded_count[c]; i++) { put_bits(off, (unsigned)sc[i], 6); off += 6; }
+        } else if (db != 0) {
+            put_bits(off, (unsigned)sc[0], 6);
+            off += 6;
+            const int max_delta = (1 << (db - 1)) - 1;
+            const unsigned escape = (1u << db) - 1;
+            for (int i = 1; i < info.coded_count[c]; i++) {
+                const int delta = sc[i] - sc[i - 1];
+                if (abs(delta) > max_delta) {
+                    put_bits(off, escape, db);
+                    off += db;
+                    put_bits(off, (unsigned)sc[i], 6);
+                    off += 6;
+                } else {
+                    put_bits(off, (unsigned)(max_delta + delta), db);
+                    off += db;
+                }
+            }
+        }
+        if (info.channel_type[c] == CH_STEREO_SECONDARY) {
+            for (int i = 0; i < 8; i++) { put_bits(off, (unsigned)intensity[c * 8 + i], 4); off += 4; }
+        } else if (info.hfr_group_count > 0) {
+            for (int i = 0; i < info.hfr_group_count; i++) { put_bits(off, (unsigned)hfrs[c * 8 + i], 6); off += 6; }
+        }
+    }
+    // WriteSpectra (:238-260) in (sub-frame, channel, band) order: slot = (sf*nch + c)*128 + band;
+    // QuantizeSpectra (:420-439) on the fly
+    {
+        const int per_thread = nch * 4;               // nch*8*128 / 256, divides 128
+        auto code_of = [&](int slot, unsigned &code, int &nbits) {
+            const int sf = slot / (nch * 128), c = (slot / 128) % nch, band = slot % 128;
+            const int res = ires[c * 128 + band];
+            code = 0;
+            nbits = 0;
+            if (res == 0) return;
+            const double inv = inv_step(res);
+            const double up = inv + 1;
+            const int down = trunc_i(inv + 0.5);
+            const int q = trunc_i(scaled[((size_t)c * 128 + band) * 8 + sf] * inv + up) - down;
+            if (res < 8) {
+                nbits = HCA_QuantizeSpectrumBits[res][q + 8];
+                code = HCA_QuantizeSpectrumValue[res][q + 8];
+            } else {
+                nbits = HCA_QuantizedSpectrumMaxBits[res] - 1;
+                code = (unsigned)abs(q);
+                if (q != 0) { code = (code << 1) | (q > 0 ? 0u : 1u); nbits++; }
+            }
+        };
+        int local = 0;
+        for (int k = 0; k < per_thread; k++) {
+            unsigned code;
+            int nbits;
+            code_of(tid * per_thread + k, code, nbits);
+            local += nbits;
+        }
+        // exclusive scan of `local` over the 256 threads
+        scan[tid] = local;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int v = tid >= o ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        int off = 32 + scan[tid] - local;
+        for (int c = 0; c < nch; c++) off += hlb[c];
+        for (int k = 0; k < per_thread && !too_low; k++) {
+            unsigned code;
+            int nbits;
+            code_of(tid * per_thread + k, code, nbits);
+            put_bits(off, code, nbits);
+            off += nbits;
+        }
+    }
+    __syncthreads();
+
+    // ---- WriteChecksum (:231-236): CRC-16 (poly 0x8005, init 0) over the first frame_size-2 bytes
+    {
+        const int nbytes = info.frame_size - 2;
+        const int chunk = (nbytes + 255) / 256;
+        const int begin = tid * chunk, end = min(begin + chunk, nbytes);
+        unsigned crc = 0;
+        for (int i = begin; i < end; i++) {
+            const unsigned byte = (fbuf[i >> 2] >> (24 - 8 * (i & 3))) & 0xFFu;
+            crc ^= byte << 8;
+#pragma unroll
+            for (int j = 0; j < 8; j++) crc = ((crc << 1) ^ ((crc & 0x8000u) ? 0x8005u : 0u)) & 0xFFFFu;
+        }
+        unsigned part = (begin < end) ? gf_mul(crc, crc_pow[nbytes - end]) : 0u;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) part ^= (unsigned)__shfl_xor((int)part, o);
+        if (lane == 0) red[wave] = (int)part;
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned total = (unsigned)(red[0] ^ red[1] ^ red[2] ^ red[3]) & 0xFFFFu;
+            const int pos = nbytes;        // big-endian 16-bit value at the last two bytes
+            fbuf[pos >> 2] |= (total >> 8) << (24 - 8 * (pos & 3));
+            fbuf[(pos + 1) >> 2] |= (total & 0xFF) << (24 - 8 * ((pos + 1) & 3));
+        }
+        __syncthreads();
+    }
+
+    // ---- store the frame (frame offsets are even: 2-byte stores)
+    {
+        uint16_t *dst = reinterpret_cast<uint16_t *>(frames + (int64_t)stream * frames_pitch + (int64_t)frame * info.frame_size);
+        for (int i = tid; i < info.frame_size / 2; i += 256) {
+            const int b = 2 * i;
+            const unsigned b0 = (fbuf[b >> 2] >> (24 - 8 * (b & 3))) & 0xFFu;
+            const unsigned b1 = (fbuf[(b + 1) >> 2] >> (24 - 8 * ((b + 1) & 3))) & 0xFFu;
+            dst[i] = (uint16_t)(b0 | (b1 << 8));
+        }
+        if ((info.frame_size & 1) && tid == 0) {
+            const int b = info.frame_size - 1;
+            frames[(int64_t)stream * frames_pitch + (int64_t)frame * info.frame_size + b] =
+                (uint8_t)((fbuf[b >> 2] >> (24 - 8 * (b & 3))) & 0xFFu);
+        }
+    }
+}
+
+int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, int pcm_length,
+                  const DeviceInfo &info, uint8_t *d_frames, int64_t frames_pitch, const uint16_t *d_crc_pow,
+                  int *d_status, hipStream_t stream)
+{
+    if (nstreams <= 0 || info.frame_count <= 0) return VGA_OK;
+    const int nch = info.nch;
+    const size_t region_b = (size_t)nch * 1024 > 25 * 128 ? (size_t)nch * 1024 : 25 * 128;
+    const size_t doubles = (size_t)nch * 1024 + region_b + (size_t)nch * 16 + 16;
+    const size_t ints = (size_t)nch * 256 + 264 + 8 + 8 + 64 + 8 + 64 + 64 + 256;
+    const size_t lds = doubles * 8 + ints * 4 + ((size_t)(info.frame_size + 3) / 4 + 2) * 4;
+    if (lds > 64 * 1024)
+        VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hca_encode_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(hca_encode_kernel, dim3((unsigned)((int64_t)nstreams * info.frame_count)), dim3(256), lds, stream,
+                       d_pcm, stream_pitch, ch_pitch, nstreams, pcm_length, info, d_frames, frames_pitch, d_crc_pow,
+                       d_status);
+    VGA_HIP_TRY(hipGetLastError());
+    return VGA_OK;
+}
+
+}  // namespace hca
+}  // namespace vga
