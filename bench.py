@@ -152,10 +152,19 @@ def main():
             verified += 1
 
         enc_bytes = ENC_BYTES_PER_SAMPLE * nch * n
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
+        # correction, + WRITE_SIZE; profiles/r01_pmc_traffic.json).  Only valid for the profiled shape.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if nch == 4096 and n == 2880000:
+                traffic = round(pmc["gc_encode_kernel"]["traffic_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         achieved = enc_bytes / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
         roofline = {"bound": "hbm", "kernel": "gc_encode_kernel", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": None, "algorithmic_bytes_per_launch": enc_bytes, "launch_ms": round(enc_ms, 3),
+                    "traffic": traffic, "algorithmic_bytes_per_launch": enc_bytes, "launch_ms": round(enc_ms, 3),
                     "other_kernels": {"gc_coefs_kernel": {
                         "launch_ms": round(coef_ms, 3),
                         "achieved": round(COEF_BYTES_PER_SAMPLE * nch * n / (coef_ms * 1e-3) / 1e9, 2) if coef_ms > 0 else 0.0}},
