@@ -69,7 +69,10 @@ __global__ __launch_bounds__(64) void hca_unpack_kernel(
     uint8_t *__restrict__ records, size_t record_bytes, int *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_res[];   // [nch][128][64]
+    __shared__ LdsTables T;
     const int lane = threadIdx.x;
+    load_tables(T, lane, 64);
+    __syncthreads();
     const int64_t gid = (int64_t)blockIdx.x * 64 + lane;
     const int64_t total = (int64_t)nstreams * info.frame_count;
     const bool live = gid < total;
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(64) void hca_unpack_kernel(
             int res = 0;
             if (i < count) {
                 const int noise = info.ath_curve[i] + noise_level - (i < eval_boundary ? 1 : 0);
-                res = calculate_resolution(sf, noise);
+                res = calculate_resolution(T, sf, noise);
             }
             if (live) rc[128 + i] = (uint8_t)res;
             s_res[((size_t)c * 128 + i) * 64 + lane] = (uint8_t)res;
@@ -141,12 +144,12 @@ __global__ __launch_bounds__(64) void hca_unpack_kernel(
             int16_t *qrow = q + ((size_t)sf * nch + c) * 128;
             for (int s = 0; s < count; s++) {
                 const int resolution = s_res[((size_t)c * 128 + s) * 64 + lane];
-                int bits = HCA_QuantizedSpectrumMaxBits[resolution];
+                int bits = T.max_bits[resolution];
                 const int code = r.peek(bits);
                 int value;
                 if (resolution < 8) {
-                    bits = HCA_QuantizedSpectrumBits[resolution][code];
-                    value = HCA_QuantizedSpectrumValue[resolution][code];
+                    bits = T.dec_bits[resolution][code];
+                    value = T.dec_value[resolution][code];
                 } else {
                     value = code / 2 * (1 - (code % 2 * 2));
                     if (value == 0) bits--;
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(256) void hca_imdct_kernel(
     int16_t *__restrict__ pcm, int64_t stream_pitch, int64_t ch_pitch)
 {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
+    __shared__ LdsTables T;
     const int nch = info.nch;
     double *spec = s_mem;                               // [nch][9][128]
     double *tmp = spec + (size_t)nch * 9 * 128;         // [8][128]
@@ -180,6 +184,8 @@ __global__ __launch_bounds__(256) void hca_imdct_kernel(
     double *gain = dct + 9 * 128;                       // [2][nch][128]: previous frame, this frame
 
     const int tid = threadIdx.x;
+    load_tables(T, tid, 256);
+    __syncthreads();
     const int stream = blockIdx.x / info.frame_count;
     const int frame = blockIdx.x % info.frame_count;
     const uint8_t *rec_cur = records + ((size_t)stream * info.frame_count + frame) * record_bytes;
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256) void hca_imdct_kernel(
         double g = 0.0;
         if (rec && s < info.coded_count[c]) {
             const uint8_t *rc = rec + record_channel_offset(c);
-            g = f64_bits(HCA_DequantizerScalingTableBits[rc[s]]) * f64_bits(HCA_QuantizerStepSizeBits[rc[128 + s]]);
+            g = T.dequant_scale[rc[s]] * T.step[rc[128 + s]];
         }
         gain[i] = g;
     }
@@ -258,9 +264,9 @@ __global__ __launch_bounds__(256) void hca_imdct_kernel(
     for (int c = 0; c < nch; c++) {
         const double *sp = spec + (size_t)c * 9 * 128;
         // 9 transforms: slots 1..8 on the 8 groups, then slot 0 on group 0
-        dct4_128(sp + (size_t)(1 + grp) * 128, tmp + grp * 128, dct + (size_t)(1 + grp) * 128, t, [] { __syncthreads(); });
+        dct4_128(T, sp + (size_t)(1 + grp) * 128, tmp + grp * 128, dct + (size_t)(1 + grp) * 128, t, [] { __syncthreads(); });
         __syncthreads();
-        dct4_128(sp, tmp + grp * 128, grp == 0 ? dct : tmp + grp * 128 + 0, t, [] { __syncthreads(); });
+        dct4_128(T, sp, tmp + grp * 128, grp == 0 ? dct : tmp + grp * 128 + 0, t, [] { __syncthreads(); });
         __syncthreads();
         // window + overlap-add: out(slot) needs `previous` produced from slot-1's transform
         int16_t *dst = pcm + (int64_t)stream * stream_pitch + (int64_t)c * ch_pitch;
@@ -271,12 +277,12 @@ __global__ __launch_bounds__(256) void hca_imdct_kernel(
             const bool have_prev = slot > 1 || frame > 0;
             double out;
             if (j < 64) {
-                const double prev = have_prev ? mdct_window(127 - j) * -dp[63 - j] : 0.0;       // _imdctPrevious[i]
-                out = mdct_window(j) * dc[j + 64] + prev;
+                const double prev = have_prev ? T.window[127 - j] * -dp[63 - j] : 0.0;       // _imdctPrevious[i]
+                out = T.window[j] * dc[j + 64] + prev;
             } else {
                 const int k = j - 64;
-                const double prev = have_prev ? mdct_window(63 - k) * dp[k] : 0.0;              // _imdctPrevious[i+half]
-                out = mdct_window(k + 64) * -dc[127 - k] - prev;
+                const double prev = have_prev ? T.window[63 - k] * dp[k] : 0.0;              // _imdctPrevious[i+half]
+                out = T.window[k + 64] * -dc[127 - k] - prev;
             }
             // (int)(x * 32768): RyuJIT cvttsd2si semantics, then Clamp16
             const double scaled = out * 32768.0;

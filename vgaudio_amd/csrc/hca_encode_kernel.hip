@@ -21,24 +21,15 @@ namespace hca {
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // CriHcaEncoder.cs:691-709
-__device__ __forceinline__ int find_scale_factor(double value)
+__device__ __forceinline__ int find_scale_factor(const LdsTables &T, double value)
 {
     unsigned low = 0, high = 63;
     while (low < high) {
         const unsigned mid = (low + high) / 2;
-        if (f64_bits(HCA_DequantizerScalingTableBits[mid]) <= value) low = mid + 1;
+        if (T.dequant_scale[mid] <= value) low = mid + 1;
         else high = mid;
     }
     return (int)low;
-}
-
-__device__ __forceinline__ double inv_step(int res) { return f64_bits(HCA_QuantizerInverseStepSizeBits[res]); }
-
-// CriHcaTables.cs:68-78
-__device__ __forceinline__ double dead_zone(int res)
-{
-    const double boundary = f64_bits(HCA_QuantizerStepSizeBits[res]) / 2;
-    return __longlong_as_double(__double_as_longlong(boundary) - (long long)(HCA_ResolutionMaxValue[res] + 1));
 }
 
 // (int)double for values known to be small
@@ -62,18 +53,18 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     int *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
+    __shared__ LdsTables T;
     const int nch = info.nch;
     double *spectra = s_mem;                               // [nch][8][128]
     // region B is shared: the MDCT staging (xin, tmp, dctin) is dead before `scaled` is written
-    const size_t region_b = (size_t)nch * 1024 > 25 * 128 ? (size_t)nch * 1024 : 25 * 128;
+    const size_t region_b = (size_t)nch * 1024 > 19 * 128 ? (size_t)nch * 1024 : 19 * 128;
     double *scaled = spectra + (size_t)nch * 1024;         // [nch][128][8]
-    double *xin = scaled;                                  // [9][128]
-    double *tmp = xin + 9 * 128;                           // [8][128]
+    double *tmp = scaled;                                  // [8][128]
     double *dctin = tmp + 8 * 128;                         // [8][128]
+    int16_t *xin = reinterpret_cast<int16_t *>(dctin + 8 * 128);   // [9][128] raw samples (2.3 KB of the 3 x 128 doubles)
     double *hfr_avg = scaled + region_b;                   // [nch][8]
     double *eratio = hfr_avg + nch * 8;                    // [nch][8]
-    double *dz = eratio + nch * 8;                         // [16]
-    int *sfac = reinterpret_cast<int *>(dz + 16);          // [nch][128]
+    int *sfac = reinterpret_cast<int *>(eratio + nch * 8); // [nch][128]
     int *ires = sfac + nch * 128;                          // [nch][128]
     int *red = ires + nch * 128;                           // [264]
     int *hlb = red + 264;                                  // [nch] header length bits
@@ -109,7 +100,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     };
 
     for (int i = tid; i < fwords; i += 256) fbuf[i] = 0;
-    if (tid < 16) dz[tid] = dead_zone(tid);
+    load_tables(T, tid, 256);
 
     // ---- PcmToFloat (:845-858) + RunMdct (:834-843 -> Mdct.cs:63-92), channel by channel
     const int grp = tid >> 5, t = tid & 31;
@@ -117,26 +108,27 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
         const int16_t *src = pcm + (int64_t)stream * stream_pitch + (int64_t)c * ch_pitch;
         for (int i = tid; i < 9 * 128; i += 256) {
             const int64_t pos = (int64_t)frame * SPF - SPSF + i;
-            const int sample = (pos >= 0 && pos < pcm_length) ? (int)src[pos] : 0;
-            xin[i] = sample * (1.0 / 32768.0);
+            xin[i] = (pos >= 0 && pos < pcm_length) ? src[pos] : (int16_t)0;
         }
         __syncthreads();
         {
-            const double *in = xin + (grp + 1) * 128, *prev = xin + grp * 128;
+            // PcmToFloat: pcm * (1.0 / 32768.0), applied on the fly
+            const int16_t *in = xin + (grp + 1) * 128, *prev = xin + grp * 128;
             double *din = dctin + grp * 128;
+            constexpr double K = 1.0 / 32768.0;
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const int i = t + 32 * k;
-                const double a = mdct_window(63 - i) * -in[64 + i];
-                const double b = mdct_window(64 + i) * in[63 - i];
-                const double cc = mdct_window(i) * prev[i];
-                const double d = mdct_window(127 - i) * prev[127 - i];
+                const double a = T.window[63 - i] * -(in[64 + i] * K);
+                const double b = T.window[64 + i] * (in[63 - i] * K);
+                const double cc = T.window[i] * (prev[i] * K);
+                const double d = T.window[127 - i] * (prev[127 - i] * K);
                 din[i] = a - b;
                 din[64 + i] = cc - d;
             }
         }
         __syncthreads();
-        dct4_128(dctin + grp * 128, tmp + grp * 128, spectra + ((size_t)c * 8 + grp) * 128, t, [] { __syncthreads(); });
+        dct4_128(T, dctin + grp * 128, tmp + grp * 128, spectra + ((size_t)c * 8 + grp) * 128, t, [] { __syncthreads(); });
         __syncthreads();
     }
 
@@ -192,7 +184,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
                 const double coeff = fabs(spectra[((size_t)c * 8 + sf) * 128 + b]);
                 mx = coeff > mx ? coeff : mx;
             }
-            sfv = find_scale_factor(mx);
+            sfv = find_scale_factor(T, mx);
         }
         sfac[i] = sfv;
     }
@@ -203,7 +195,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
         const int sfv = sfac[c * 128 + b];
         double v = 0;
         if (b < info.coded_count[c] && sfv != 0)
-            v = clampd(spectra[((size_t)c * 8 + sf) * 128 + b] * f64_bits(HCA_QuantizerScalingTableBits[sfv]),
+            v = clampd(spectra[((size_t)c * 8 + sf) * 128 + b] * T.quant_scale[sfv],
                        -0.999999999999, 0.999999999999);
         scaled[i] = v;
     }
@@ -236,7 +228,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
                     const double inv = 1.0 / average;
                     avg *= inv < 1.4142135623730951 ? inv : 1.4142135623730951;
                 }
-                hfrs[c * 8 + group] = find_scale_factor(avg);
+                hfrs[c * 8 + group] = find_scale_factor(T, avg);
             }
         }
         __syncthreads();
@@ -287,21 +279,21 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
             const int c = i / 128, b = i % 128;
             if (b >= info.coded_count[c]) continue;
             const int noise = b < eval_boundary ? noise_level - 1 : noise_level;
-            const int res = calculate_resolution(sfac[i], noise);
+            const int res = calculate_resolution(T, sfac[i], noise);
             const double *x = scaled + (size_t)i * 8;
             if (res >= 8) {
-                const int bits = HCA_QuantizedSpectrumMaxBits[res] - 1;
-                const double d = dz[res];
+                const int bits = T.max_bits[res] - 1;
+                const double d = T.dead_zone[res];
 #pragma unroll
                 for (int sf = 0; sf < 8; sf++) partial += bits + (fabs(x[sf]) >= d ? 1 : 0);
             } else {
-                const double inv = inv_step(res);
+                const double inv = T.inv_step[res];
                 const double up = inv + 1;
                 const int down = trunc_i(inv + 0.5 - 8);
 #pragma unroll
                 for (int sf = 0; sf < 8; sf++) {
                     const int q = trunc_i(x[sf] * inv + up) - down;
-                    partial += HCA_QuantizeSpectrumBits[res][q];
+                    partial += T.enc_bits[res][q];
                 }
             }
         }
@@ -364,7 +356,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     // ---- CalculateFrameResolutions (:441-455)
     for (int i = tid; i < nch * 128; i += 256) {
         const int c = i / 128, b = i % 128;
-        ires[i] = b < info.coded_count[c] ? calculate_resolution(sfac[i], b < boundary ? level - 1 : level) : 0;
+        ires[i] = b < info.coded_count[c] ? calculate_resolution(T, sfac[i], b < boundary ? level - 1 : level) : 0;
     }
     __syncthreads();
 
@@ -416,15 +408,15 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
             code = 0;
             nbits = 0;
             if (res == 0) return;
-            const double inv = inv_step(res);
+            const double inv = T.inv_step[res];
             const double up = inv + 1;
             const int down = trunc_i(inv + 0.5);
             const int q = trunc_i(scaled[((size_t)c * 128 + band) * 8 + sf] * inv + up) - down;
             if (res < 8) {
-                nbits = HCA_QuantizeSpectrumBits[res][q + 8];
-                code = HCA_QuantizeSpectrumValue[res][q + 8];
+                nbits = T.enc_bits[res][q + 8];
+                code = T.enc_value[res][q + 8];
             } else {
-                nbits = HCA_QuantizedSpectrumMaxBits[res] - 1;
+                nbits = T.max_bits[res] - 1;
                 code = (unsigned)abs(q);
                 if (q != 0) { code = (code << 1) | (q > 0 ? 0u : 1u); nbits++; }
             }
@@ -506,8 +498,8 @@ int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, 
 {
     if (nstreams <= 0 || info.frame_count <= 0) return VGA_OK;
     const int nch = info.nch;
-    const size_t region_b = (size_t)nch * 1024 > 25 * 128 ? (size_t)nch * 1024 : 25 * 128;
-    const size_t doubles = (size_t)nch * 1024 + region_b + (size_t)nch * 16 + 16;
+    const size_t region_b = (size_t)nch * 1024 > 19 * 128 ? (size_t)nch * 1024 : 19 * 128;
+    const size_t doubles = (size_t)nch * 1024 + region_b + (size_t)nch * 16;
     const size_t ints = (size_t)nch * 256 + 264 + 8 + 8 + 64 + 8 + 64 + 64 + 256;
     const size_t lds = doubles * 8 + ints * 4 + ((size_t)(info.frame_size + 3) / 4 + 2) * 4;
     if (lds > 64 * 1024)
