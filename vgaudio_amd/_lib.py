@@ -8,7 +8,8 @@ import importlib.util
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libvgaudio_hip.so")
+# VGAUDIO_HIP_LIBRARY: load a different build of the same ABI (kernel experiments, tools/variants/)
+SO_PATH = os.environ.get("VGAUDIO_HIP_LIBRARY") or os.path.join(_HERE, "libvgaudio_hip.so")
 
 VGA_OK = 0
 VGA_ERR_ARGUMENT = -1

@@ -206,7 +206,8 @@ VGA_HD int round_through_f32(int d)
 // errors could overflow (S3): with |c0|+|c1| <= 32767 the predictor cannot wrap, and then
 // |in - recon| <= (ov + 1/2) * 2^(k-11) + 2 where ov is the pass's max overflow; we require that
 // bound to stay <= 17 500 (14 * 17500^2 < 2^32), which also rules out int32 overflow in qb.
-VGA_HD PassOut pass_fast(const int (&x)[16], int c0, int c1, int scale_power)
+// in2048[s] = x[s + 2] * 2048 supplied by the caller (the kernel's helper wave precomputes it per tile)
+VGA_HD PassOut pass_fast_core(const int (&x)[16], const int (&in2048v)[14], int c0, int c1, int scale_power)
 {
     PassOut r;
     const int k = scale_power + 11;
@@ -225,7 +226,7 @@ VGA_HD PassOut pass_fast(const int (&x)[16], int c0, int c1, int scale_power)
 #pragma unroll
 #endif
     for (int s = 0; s < 14; s++) {
-        const int in2048 = x[s + 2] * 2048;
+        const int in2048 = in2048v[s];
         int base = VGA_MUL24(o0, nc1) + in2048;                     // off the dependent chain (o0 is one step old)
         VGA_OPAQUE(base);
         const int d = VGA_MUL24(o1, nc0) + base;                    // == in2048 - predicted (mod 2^32)
@@ -252,6 +253,16 @@ VGA_HD PassOut pass_fast(const int (&x)[16], int c0, int c1, int scale_power)
     r.max_overflow = ov;
     r.o12 = o0; r.o13 = o1;
     return r;
+}
+
+VGA_HD PassOut pass_fast(const int (&x)[16], int c0, int c1, int scale_power)
+{
+    int in2048v[14];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int s = 0; s < 14; s++) in2048v[s] = x[s + 2] * 2048;
+    return pass_fast_core(x, in2048v, c0, c1, scale_power);
 }
 
 // ---- speculative two-candidate resolution --------------------------------------------
