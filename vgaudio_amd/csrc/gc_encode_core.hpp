@@ -195,60 +195,66 @@ VGA_HD int round_through_f32(int d)
 #endif
 }
 
-// Fast quantise pass: integer-only, 9 dependent VALU ops per sample
+// Fast quantise pass: integer-only, 16 VALU ops per sample of which 9 are on the dependent chain
 // (mad, cvt, cvt, add3, ashr, med3, lshl_add, ashr, med3) instead of the f32/f64 detour.
 //   d      = in*2048 - (o0*c1 + o1*c0)                       (two mads with negated coefs)
 //   r      = (int)(float)d                                   the reference's float rounding
-//   qb     = clamp(((r + bias8 + (d<0)) >> k), 0, 15)        biased nibble q+8; bias8 = 2^(k-1)-1 + 8*2^k   (S2)
-//   recon  = clamp16(((in*2048 + 1024 - 8*2^k - d) + (qb << k)) >> 11)
-// The nibbles are accumulated biased (one shift-or each) and un-biased by one XOR 0x888...8.
+//   u      = (r + 2^(k-1) - 1 + (d<0)) >> k                  unclamped nibble  (S2)
+//   q      = clamp(u, -8, 7)
+//   recon  = clamp16(((in*2048 + 1024 - d) + (q << k)) >> 11)       (in*2048 + 1024 - d == predicted + 1024)
+// The nibbles are accumulated SIGNED (w = w*16 + q, one shift-add each); adding 0x888..8 turns the sum
+// into the packing of the biased nibbles q+8 and the XOR with 0x888..8 un-biases them (two ops per word).
+// The overflow is recovered from the running max/min of u (one max3/min3 per two samples).
 // r.exact == false (frame must be redone with pass_literal) when the 32-bit sum of squared
 // errors could overflow (S3): with |c0|+|c1| <= 32767 the predictor cannot wrap, and then
 // |in - recon| <= (ov + 1/2) * 2^(k-11) + 2 where ov is the pass's max overflow; we require that
-// bound to stay <= 17 500 (14 * 17500^2 < 2^32), which also rules out int32 overflow in qb.
-// in2048[s] = x[s + 2] * 2048 supplied by the caller (the kernel's helper wave precomputes it per tile)
-VGA_HD PassOut pass_fast_core(const int (&x)[16], const int (&in2048v)[14], int c0, int c1, int scale_power)
+// bound to stay <= 17 500 (14 * 17500^2 < 2^32), which also rules out int32 overflow in u.
+// in2048v[s] = x[s + 2] * 2048 and in2048p[s] = x[s + 2] * 2048 + 1024 are supplied by the caller (the
+// kernel's helper wave precomputes them per tile).
+VGA_HD PassOut pass_fast_core(const int (&x)[16], const int (&in2048v)[14], const int (&in2048p)[14], int c0, int c1,
+                              int scale_power)
 {
     PassOut r;
     const int k = scale_power + 11;
-    const int eight_k = 8 << k;
-    const int bias8 = (1 << (k - 1)) - 1 + eight_k;
-    int kconst = 1024 - eight_k;
+    int bias = (1 << (k - 1)) - 1;
     int nc0 = -c0, nc1 = -c1;
-    VGA_OPAQUE(kconst);
+    VGA_OPAQUE(bias);
     VGA_OPAQUE(nc0);
     VGA_OPAQUE(nc1);
     uint32_t wa = 0, wb = 0;
     uint32_t total = 0;
-    int qmax = 8, qmin = 8;                                         // biased: q + 8
+    int umax = 0, umin = 0;
+    int u_prev = 0;
     int o0 = x[0], o1 = x[1];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int s = 0; s < 14; s++) {
-        const int in2048 = in2048v[s];
-        int base = VGA_MUL24(o0, nc1) + in2048;                     // off the dependent chain (o0 is one step old)
+        int base = VGA_MUL24(o0, nc1) + in2048v[s];                 // off the dependent chain (o0 is one step old)
         VGA_OPAQUE(base);
         const int d = VGA_MUL24(o1, nc0) + base;                    // == in2048 - predicted (mod 2^32)
         const int rd = round_through_f32(d);
-        const int unclamped8 = (int)(rd + bias8 + (int)((uint32_t)d >> 31)) >> k;
-        const int qb = imin(imax(unclamped8, 0), 15);
-        qmax = imax(qmax, unclamped8);
-        qmin = imin(qmin, unclamped8);
-        if (s < 6) wa = (wa << 4) | (uint32_t)qb;
-        else       wb = (wb << 4) | (uint32_t)qb;
-        const int pr = (in2048 + kconst) - d;                       // predicted + 1024 - 8*2^k
-        const int recon = clamp16i((pr + (int)((uint32_t)qb << k)) >> 11);
+        const int u = (int)((uint32_t)rd + (uint32_t)bias + ((uint32_t)d >> 31)) >> k;
+        const int q = imin(imax(u, -8), 7);
+        if (s & 1) {
+            umax = imax(imax(umax, u_prev), u);
+            umin = imin(imin(umin, u_prev), u);
+        }
+        u_prev = u;
+        if (s < 6) wa = (wa << 4) + (uint32_t)q;
+        else       wb = (wb << 4) + (uint32_t)q;
+        const uint32_t pr = (uint32_t)in2048p[s] - (uint32_t)d;        // predicted + 1024
+        const int recon = clamp16i((int)(pr + ((uint32_t)q << k)) >> 11);
         const int e = x[s + 2] - recon;
         total += (uint32_t)VGA_MUL24(e, e);
         o0 = o1;
         o1 = recon;
     }
-    const int ov = imax(imax(qmax - 15, -qmin), 0);                // max(q-7, -8-q, 0) on the biased values
+    const int ov = imax(imax(umax - 7, -8 - umin), 0);
     const int ac0 = c0 < 0 ? -c0 : c0, ac1 = c1 < 0 ? -c1 : c1;
     r.exact = ac0 + ac1 <= 32767 && ov <= 17497 && (((2 * ov + 1) << (k - 11)) <= 34996);
-    r.wa = wa ^ 0x00888888u;
-    r.wb = wb ^ 0x88888888u;
+    r.wa = ((wa + 0x00888888u) ^ 0x00888888u) & 0x00FFFFFFu;
+    r.wb = (wb + 0x88888888u) ^ 0x88888888u;
     r.total = total;
     r.max_overflow = ov;
     r.o12 = o0; r.o13 = o1;
@@ -257,12 +263,15 @@ VGA_HD PassOut pass_fast_core(const int (&x)[16], const int (&in2048v)[14], int 
 
 VGA_HD PassOut pass_fast(const int (&x)[16], int c0, int c1, int scale_power)
 {
-    int in2048v[14];
+    int in2048v[14], in2048p[14];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int s = 0; s < 14; s++) in2048v[s] = x[s + 2] * 2048;
-    return pass_fast_core(x, in2048v, c0, c1, scale_power);
+    for (int s = 0; s < 14; s++) {
+        in2048v[s] = x[s + 2] * 2048;
+        in2048p[s] = in2048v[s] + 1024;
+    }
+    return pass_fast_core(x, in2048v, in2048p, c0, c1, scale_power);
 }
 
 // ---- speculative two-candidate resolution --------------------------------------------
@@ -299,6 +308,23 @@ VGA_HD Resolve resolve_candidates_nobump(int s1, int ov_a, int ov_b)
     z.final_b = !z.final_a && !(s1 + 1 < 12 && ov_b > 1);
     z.resume_sp = s1 + 1;
     return z;
+}
+
+// Continue the reference's do-loop from `scale_power` (value before the ++), precomputed in*2048 arrays.
+VGA_HD PassOut resume_passes_core(const int (&x)[16], const int (&in2048v)[14], const int (&in2048p)[14], int c0,
+                                  int c1, int scale_power, int &final_sp)
+{
+    PassOut r;
+    bool at_max;
+    do {
+        scale_power++;
+        at_max = scale_power >= 12;
+        r = pass_fast_core(x, in2048v, in2048p, c0, c1, scale_power);
+        if (!r.exact) r = pass_literal(x, c0, c1, scale_power);
+        scale_power = apply_bumps(scale_power, r.max_overflow);
+    } while (scale_power < 12 && r.max_overflow > 1 && !at_max);
+    final_sp = scale_power;     // the reference's `out scalePower` (== the pass scale on a regular exit)
+    return r;
 }
 
 // Continue the reference's do-loop from `scale_power` (value before the ++).

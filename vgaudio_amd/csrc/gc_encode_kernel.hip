@@ -55,194 +55,6 @@ __device__ __forceinline__ unsigned row16_reduce(unsigned v, Op op)
     return v;
 }
 
-__global__ __launch_bounds__(64) void gc_encode_kernel_v2(
-    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int sample_count,
-    const int16_t *__restrict__ coefs, const int16_t *__restrict__ hist1,
-    const int16_t *__restrict__ hist2, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch)
-{
-    __shared__ uint32_t s_in[2][4][16][7];    // two 16-frame input tiles per channel group
-    __shared__ uint2 s_out[4][16];            // one 16-frame output tile per channel group
-    const int lane = threadIdx.x;
-    const int grp = lane >> 4;
-    const int l16 = lane & 15;
-    const int p = l16 >> 1;
-    const bool cand_b = (l16 & 1) != 0;
-    const int ch_raw = blockIdx.x * 4 + grp;
-    const bool live = ch_raw < nch;
-    const int ch = live ? ch_raw : nch - 1;
-
-    const int c0 = coefs[ch * 16 + 2 * p];
-    const int c1 = coefs[ch * 16 + 2 * p + 1];
-    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
-    uint8_t *dst = adpcm + (int64_t)ch * adpcm_pitch;
-
-    const int full_frames = sample_count / 14;
-    const int tail = sample_count - full_frames * 14;
-
-    int x[16];
-    x[0] = hist2 ? hist2[ch] : 0;   // pcmBuffer[0] = History2 (GcAdpcmEncoder.cs:24)
-    x[1] = hist1 ? hist1[ch] : 0;   // pcmBuffer[1] = History1 (:25)
-
-    // One frame: x[2..15] already hold the 14 input samples (zero padded), x[0..1] the history.
-    auto encode_frame = [&](int f, int slot, bool full) __attribute__((always_inline)) {
-        // ---- pre-scan (:107-124), split over the two candidate lanes
-        int s1;
-        {
-            int y[9];
-#pragma unroll
-            for (int t = 0; t < 9; t++) y[t] = cand_b ? x[7 + t] : x[t];
-            int dmax = 0, dmin = 0;
-#pragma unroll
-            for (int s = 0; s < 7; s++) {
-                const int predicted = (y[s] * c1 + y[s + 1] * c0) / 2048;
-                const int d = y[s + 2] - predicted;
-                dmax = imax(dmax, d);
-                dmin = imin(dmin, d);
-            }
-            dmax = imax(dmax, dpp<DPP_QUAD_XOR1>(dmax));
-            dmin = imin(dmin, dpp<DPP_QUAD_XOR1>(dmin));
-            s1 = first_scale_power_from_range(dmax, dmin);
-            if (__any(s1 == -100)) {
-                if (s1 == -100) s1 = first_scale_power_from_md(prescan_sequential(x, c0, c1));
-            }
-        }
-
-        // ---- speculative quantise pass: A at s1, B at s1+1
-        int final_sp = imin(s1 + (cand_b ? 1 : 0), 12);
-        PassOut r = pass_fast(x, c0, c1, final_sp);
-        if (__any(!r.exact)) {
-            if (!r.exact) r = pass_literal(x, c0, c1, final_sp);
-        }
-        const int ov_other = dpp<DPP_QUAD_XOR1>(r.max_overflow);
-        const int ov_a = cand_b ? ov_other : r.max_overflow;
-        const int ov_b = cand_b ? r.max_overflow : ov_other;
-        Resolve z = resolve_candidates_nobump(s1, ov_a, ov_b);
-        if (__any(imax(ov_a, ov_b) > 248)) z = resolve_candidates(s1, ov_a, ov_b);   // bump loop: rare
-        bool fin = cand_b ? z.final_b : z.final_a;
-        const bool resume = !cand_b && !z.final_a && !z.final_b;
-        if (__any(resume)) {
-            if (resume) {
-                r = resume_passes(x, c0, c1, z.resume_sp, final_sp);
-                fin = true;
-            }
-        }
-
-        // ---- argmin over the 8 predictors, first index wins ties (:66-76)
-        int winner;
-        const bool wide = __any(fin && r.total >= (1ull << 28));
-        if (!wide) {
-            const unsigned key = fin ? (((unsigned)r.total << 4) | (unsigned)l16) : 0xFFFFFFFFu;
-            const unsigned best = row16_reduce(key, [](unsigned a, unsigned b) { return a < b ? a : b; });
-            winner = (int)(best & 15u);
-        } else {
-            uint64_t key = fin ? ((r.total << 4) | (uint64_t)l16) : ~0ull;
-#define VGA_MIN64_STAGE(CTRL)                                                              \
-            {                                                                              \
-                const unsigned olo = (unsigned)dpp<CTRL>((int)(uint32_t)key);              \
-                const unsigned ohi = (unsigned)dpp<CTRL>((int)(uint32_t)(key >> 32));      \
-                const uint64_t okey = ((uint64_t)ohi << 32) | olo;                         \
-                key = okey < key ? okey : key;                                             \
-            }
-            VGA_MIN64_STAGE(DPP_QUAD_XOR1)
-            VGA_MIN64_STAGE(DPP_QUAD_XOR2)
-            VGA_MIN64_STAGE(DPP_ROW_HALF_MIRROR)
-            VGA_MIN64_STAGE(DPP_ROW_MIRROR)
-#undef VGA_MIN64_STAGE
-            winner = (int)(key & 15u);
-        }
-        const bool won = l16 == winner;
-        const unsigned pay = row16_reduce(won ? ((unsigned)(r.o12 & 0xFFFF) | ((unsigned)r.o13 << 16)) : 0u,
-                                          [](unsigned a, unsigned b) { return a | b; });
-
-        if (won) {
-            uint32_t d0, d1;
-            frame_words(r, p, final_sp, d0, d1);
-            if (full) {
-                s_out[grp][slot] = make_uint2(d0, d1);          // flushed 16 frames at a time
-            } else if (live) {
-                // partial last frame: SampleCountToByteCount(tail) bytes (:38)
-                const int nbytes = (tail + 2 + 1) / 2;
-                const uint64_t both = ((uint64_t)d1 << 32) | d0;
-                for (int b = 0; b < nbytes; b++) dst[(int64_t)f * 8 + b] = (uint8_t)(both >> (8 * b));
-            }
-        }
-        x[0] = (int)(int16_t)(pay & 0xFFFF);   // pcmBuffer[0] = pcmBuffer[14] (:40)
-        x[1] = (int)pay >> 16;                 // pcmBuffer[1] = pcmBuffer[15] (:41)
-    };
-
-    auto unpack = [&](const uint32_t (&w)[7]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 7; i++) {
-            x[2 + 2 * i] = (int)(int16_t)(w[i] & 0xFFFF);
-            x[3 + 2 * i] = (int)w[i] >> 16;
-        }
-    };
-    // Block pipeline over 16-frame tiles (all global traffic is coalesced and off the per-frame path):
-    //   * lane l fetches frame (l & 15) of its channel's NEXT tile: 7 dwords, 16 lanes = 448
-    //     contiguous bytes per channel, issued a whole tile (~16 x 0.4 us) before they are needed;
-    //   * the tile being encoded is read from LDS (same address for the 16 lanes of a channel ->
-    //     broadcast), ping-ponged one frame ahead in registers;
-    //   * winners drop their 8-byte frames into LDS; every 16 frames lane l stores frame (l & 15)
-    //     of its channel: 128 contiguous bytes per channel.
-    auto tile_load = [&](uint32_t (&w)[7], int tile) __attribute__((always_inline)) {
-        const int fr = imin(tile * 16 + l16, full_frames - 1);       // clamped: stays inside the channel
-        const uint32_t *p32 = reinterpret_cast<const uint32_t *>(src + (int64_t)fr * 14);
-#pragma unroll
-        for (int i = 0; i < 7; i++) w[i] = p32[i];
-    };
-    auto tile_to_lds = [&](const uint32_t (&w)[7], int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 7; i++) s_in[buf][grp][l16][i] = w[i];
-    };
-    auto lds_frame = [&](uint32_t (&w)[7], int buf, int j) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 7; i++) w[i] = s_in[buf][grp][j][i];
-    };
-
-    if (full_frames > 0) {
-        const int tiles = (full_frames + 15) / 16;
-        uint32_t stage[7];
-        tile_load(stage, 0);
-        tile_to_lds(stage, 0);
-        if (tiles > 1) tile_load(stage, 1);
-        __syncthreads();
-        for (int tile = 0; tile < tiles; tile++) {
-            const int cur = tile & 1;
-            const int fb = tile * 16;
-            const int nf = imin(16, full_frames - fb);
-            uint32_t wa[7], wb[7];
-            lds_frame(wa, cur, 0);
-            int j = 0;
-            for (; j + 1 < nf; j += 2) {
-                lds_frame(wb, cur, j + 1);
-                unpack(wa);
-                encode_frame(fb + j, j, true);
-                lds_frame(wa, cur, imin(j + 2, 15));
-                unpack(wb);
-                encode_frame(fb + j + 1, j + 1, true);
-            }
-            if (j < nf) {
-                unpack(wa);
-                encode_frame(fb + j, j, true);
-            }
-            // next tile into the idle LDS buffer first (its loads are a whole tile old), the flush
-            // store last, so no vmcnt wait ever sits behind a store that was just issued
-            if (tile + 1 < tiles) {
-                tile_to_lds(stage, cur ^ 1);
-                if (tile + 2 < tiles) tile_load(stage, tile + 2);
-            }
-            __syncthreads();
-            if (live && fb + l16 < full_frames)
-                *reinterpret_cast<uint2 *>(dst + (int64_t)(fb + l16) * 8) = s_out[grp][l16];
-        }
-    }
-    if (tail) {
-#pragma unroll
-        for (int s = 0; s < 14; s++) x[2 + s] = (s < tail) ? (int)src[(int64_t)full_frames * 14 + s] : 0;
-        encode_frame(full_frames, 0, false);
-    }
-}
-
 
 // =====================================================================================================
 // gc_encode_kernel -- serial wave + helper wave per workgroup (128 threads, 4 channels).
@@ -268,6 +80,7 @@ constexpr int TF = VGA_ENC_TILE;   // frames per tile (<= 16: one helper lane pe
 struct GcTile {
     int x[4][TF][16];          // [channel group][frame][sample]  (14 used)
     int in2048[4][TF][16];     // x * 2048
+    int in2048p[4][TF][16];    // x * 2048 + 1024
     uint32_t pre[4][TF][8];    // per predictor: clamp16(max d) & 0xFFFF | clamp16(min d) << 16, over s = 2..13
 };
 #ifdef VGA_ENC_MARKS   // analysis builds: region markers in the assembly listing
@@ -368,6 +181,11 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
             mr[1] = make_int4(in[4] * 2048, in[5] * 2048, in[6] * 2048, in[7] * 2048);
             mr[2] = make_int4(in[8] * 2048, in[9] * 2048, in[10] * 2048, in[11] * 2048);
             mr[3] = make_int4(in[12] * 2048, in[13] * 2048, 0, 0);
+            int4 *qr = reinterpret_cast<int4 *>(&T.in2048p[grp][l16][0]);
+            qr[0] = make_int4(in[0] * 2048 + 1024, in[1] * 2048 + 1024, in[2] * 2048 + 1024, in[3] * 2048 + 1024);
+            qr[1] = make_int4(in[4] * 2048 + 1024, in[5] * 2048 + 1024, in[6] * 2048 + 1024, in[7] * 2048 + 1024);
+            qr[2] = make_int4(in[8] * 2048 + 1024, in[9] * 2048 + 1024, in[10] * 2048 + 1024, in[11] * 2048 + 1024);
+            qr[3] = make_int4(in[12] * 2048 + 1024, in[13] * 2048 + 1024, 0, 0);
             uint32_t pre[8];
 #pragma unroll
             for (int p = 0; p < 8; p++) {
@@ -415,10 +233,13 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
     const bool cand_b = (l16 & 1) != 0;
     const int c0 = coefs[ch * 16 + 2 * p];
     const int c1 = coefs[ch * 16 + 2 * p + 1];
+    const bool coef_ok = (c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1) <= 32767;   // predictor cannot wrap int32
     int h0 = hist2 ? hist2[ch] : 0;   // pcmBuffer[0] = History2 (GcAdpcmEncoder.cs:24)
     int h1 = hist1 ? hist1[ch] : 0;   // pcmBuffer[1] = History1 (:25)
+    VGA_OPAQUE(h0);
+    VGA_OPAQUE(h1);
 
-    struct Row { int x[16]; int m[14]; uint32_t pre; };
+    struct Row { int x[16]; int m[14]; int mp[14]; uint32_t pre; };
     auto read_row = [&](const GcTile &T, int j, Row &R) {
         const int4 *xr = reinterpret_cast<const int4 *>(&T.x[grp][j][0]);
         const int4 *mr = reinterpret_cast<const int4 *>(&T.in2048[grp][j][0]);
@@ -429,6 +250,11 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
         x[10] = a2.x; x[11] = a2.y; x[12] = a2.z; x[13] = a2.w; x[14] = a3.x; x[15] = a3.y;
         m[0] = b0.x; m[1] = b0.y; m[2] = b0.z; m[3] = b0.w; m[4] = b1.x; m[5] = b1.y; m[6] = b1.z; m[7] = b1.w;
         m[8] = b2.x; m[9] = b2.y; m[10] = b2.z; m[11] = b2.w; m[12] = b3.x; m[13] = b3.y;
+        const int4 *qr = reinterpret_cast<const int4 *>(&T.in2048p[grp][j][0]);
+        const int4 e0 = qr[0], e1 = qr[1], e2 = qr[2], e3 = qr[3];
+        int *mp = R.mp;
+        mp[0] = e0.x; mp[1] = e0.y; mp[2] = e0.z; mp[3] = e0.w; mp[4] = e1.x; mp[5] = e1.y; mp[6] = e1.z; mp[7] = e1.w;
+        mp[8] = e2.x; mp[9] = e2.y; mp[10] = e2.z; mp[11] = e2.w; mp[12] = e3.x; mp[13] = e3.y;
         R.pre = T.pre[grp][j][p];
     };
     auto pack = [](const int (&x)[16]) {
@@ -451,6 +277,10 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
             const int dmax = imax(imax((int)(int16_t)(R.pre & 0xFFFF), d0), d1);
             const int dmin = imin(imin((int)R.pre >> 16, d0), d1);
             s1 = first_scale_power_from_range(dmax, dmin);
+#ifdef VGA_ABL_PRESCAN      // ablation (timing only): scale from the helper's range alone
+            s1 = first_scale_power_from_range((int)(int16_t)(R.pre & 0xFFFF), (int)R.pre >> 16);
+            if (s1 == -100) s1 = 3;
+#endif
 #if !defined(VGA_EXPERIMENT_NO_COLD) && !defined(VGA_X_NO_TIE)
             if (__any(s1 == -100)) {                   // +M and -M both present: first occurrence decides
                 if (s1 == -100) s1 = first_scale_power_from_md(prescan_sequential_cold(pack(x), c0, c1));
@@ -460,41 +290,36 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
         VGA_MARK("prescan_end");
         // ---- first trip: candidate A at s1, B at s1+1 (speculation on the loop of :127-170)
         int final_sp = imin(s1 + (cand_b ? 1 : 0), 12);
-        PassOut r = pass_fast_core(x, R.m, c0, c1, final_sp);
-#if !defined(VGA_EXPERIMENT_NO_COLD) && !defined(VGA_X_NO_LITERAL)
-        if (__any(!r.exact)) {                         // 32-bit error sum not provably exact: literal pass
-            if (!r.exact) r = pass_literal_cold(pack(x), c0, c1, final_sp);
-        }
-#endif
+        const bool at_cap = final_sp >= 12;            // the loop never goes past 12: this pass ends it
+        const unsigned ov_limit = at_cap ? 3u : 248u;  // see `rare` below
+        PassOut r = pass_fast_core(x, R.m, R.mp, c0, c1, final_sp);
         VGA_MARK("pass_end");
-        const int ov_other = dpp<DPP_QUAD_XOR1>(r.max_overflow);
-        const int ov_a = cand_b ? ov_other : r.max_overflow;
-        const int ov_b = cand_b ? r.max_overflow : ov_other;
-        Resolve z = resolve_candidates_nobump(s1, ov_a, ov_b);
-#if !defined(VGA_EXPERIMENT_NO_COLD) && !defined(VGA_X_NO_BUMP)
-        if (__any(imax(ov_a, ov_b) > 248)) z = resolve_cold(s1, ov_a, ov_b);   // scale bumps (:160-168): rare
-#endif
-        bool fin = cand_b ? z.final_b : z.final_a;
-#if !defined(VGA_EXPERIMENT_NO_COLD) && !defined(VGA_X_NO_RESUME)
-        // ---- third and later trips (about 10 % of wave-frames): the A lane of the pair carries on
-        const bool resume = !cand_b && !z.final_a && !z.final_b;
-        if (__any(resume)) {
-            if (resume) {
-                const ResumeOut o = resume_cold(pack(x), c0, c1, z.resume_sp);
-                r = o.r;
-                final_sp = o.final_sp;
+        // Straight-line resolution, valid when no lane is `rare`:
+        //   * no overflow can start the bump loop (:166-168 needs max_overflow + 8 > 256),
+        //   * the 32-bit error sum of every lane that can become final is exact (gc_encode_core.hpp S3:
+        //     final lanes have overflow <= 1, or <= 3 at the cap, so (2 ov + 1) << (k - 11) <= 34996),
+        //   * (total << 4) of the final lanes fits the 32-bit argmin key (`wide` otherwise; lanes that
+        //     overflowed are not final and their error sums -- often huge -- are never looked at).
+        // eff = overflow as the loop condition sees it (a pass at the cap ends the loop whatever it overflowed).
+        const unsigned total32 = (unsigned)r.total;
+        const bool rare = !coef_ok || (unsigned)r.max_overflow > ov_limit;
+        const int eff = at_cap ? 0 : r.max_overflow;
+        const int eff_other = dpp<DPP_QUAD_XOR1>(eff);
+        // A is final iff its pass did not overflow by more than 1; B is final iff A is not and B did not.
+        bool fin = eff < 2 && (eff_other | (cand_b ? 0 : 2)) >= 2;
+        const bool resume = !cand_b && imin(eff, eff_other) >= 2;     // both overflowed: A carries on at s1+2
+        const bool wide = fin && total32 >= (1u << 28);
+        int winner;
+#if !defined(VGA_EXPERIMENT_NO_COLD)
+        if (__builtin_expect(__any(rare || resume || wide), 0)) {
+            // ---- cold block (resume: ~40 % of wave-frames on audio; rare: hostile input only)
+            const bool redo = __any(rare);             // whole frame again, the reference's loop as written
+            if (redo) fin = false;
+            if (!cand_b && (redo || resume)) {
+                r = resume_passes_core(x, R.m, R.mp, c0, c1, redo ? s1 - 1 : s1 + 1, final_sp);
                 fin = true;
             }
-        }
-#endif
-        VGA_MARK("resolve_end");
-        // ---- argmin over the 8 predictors, first index wins ties (:66-76)
-        int winner;
-        if (!__any(fin && r.total >= (1ull << 28))) {
-            const unsigned key = fin ? (((unsigned)r.total << 4) | (unsigned)l16) : 0xFFFFFFFFu;
-            const unsigned best = row16_reduce(key, [](unsigned a, unsigned b) { return a < b ? a : b; });
-            winner = (int)(best & 15u);
-        } else {
+            // argmin over the 8 predictors, first index wins ties (:66-76); 64-bit keys
             uint64_t key = fin ? ((r.total << 4) | (uint64_t)l16) : ~0ull;
 #define VGA_MIN64_STAGE(CTRL)                                                          \
             {                                                                          \
@@ -509,8 +334,19 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
             VGA_MIN64_STAGE(DPP_ROW_MIRROR)
 #undef VGA_MIN64_STAGE
             winner = (int)(key & 15u);
+        } else
+#endif
+        {
+            const unsigned key = fin ? ((total32 << 4) | (unsigned)l16) : 0xFFFFFFFFu;
+            const unsigned best = row16_reduce(key, [](unsigned a, unsigned b) { return a < b ? a : b; });
+            winner = (int)(best & 15u);
         }
+        VGA_MARK("resolve_end");
         const bool won = l16 == winner;
+#ifdef VGA_ABL_PAY          // ablation (timing only): every lane continues from its own history
+        const unsigned pay_own = (unsigned)(r.o12 & 0xFFFF) | ((unsigned)r.o13 << 16);
+#define row16_reduce(v, f) pay_own
+#endif
         const unsigned pay = row16_reduce(won ? ((unsigned)(r.o12 & 0xFFFF) | ((unsigned)r.o13 << 16)) : 0u,
                                           [](unsigned a, unsigned b) { return a | b; });
         if (won) {
@@ -518,8 +354,13 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
             frame_words(r, p, final_sp, d0, d1);
             s_out[buf][grp][j] = make_uint2(d0, d1);          // flushed by the helper, 16 frames at a time
         }
+#ifdef VGA_ABL_PAY
+#undef row16_reduce
+#endif
         h0 = (int)(int16_t)(pay & 0xFFFF);   // pcmBuffer[0] = pcmBuffer[14] (:40)
         h1 = (int)pay >> 16;                 // pcmBuffer[1] = pcmBuffer[15] (:41)
+        VGA_OPAQUE(h0);                      // hide the 16-bit range: keeps the 24-bit multiplies the next frame
+        VGA_OPAQUE(h1);                      // asks for (the compiler otherwise widens them to 64-bit mads)
         VGA_MARK("frame_end");
     };
 
@@ -566,16 +407,8 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_c
     if (use_v1)
         return launch_encode_v1(d_pcm, pcm_pitch, nch, sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch,
                                 stream);
-    static const bool use_v2 = [] {
-        const char *e = getenv("VGA_GC_ENCODE_IMPL");
-        return e && e[0] == 'v' && e[1] == '2';
-    }();
-    if (use_v2)
-        hipLaunchKernelGGL(gc_encode_kernel_v2, dim3((nch + 3) / 4), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
-                           sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch);
-    else
-        hipLaunchKernelGGL(gc_encode_kernel, dim3((nch + 3) / 4), dim3(128), 0, stream, d_pcm, pcm_pitch, nch,
-                           sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch);
+    hipLaunchKernelGGL(gc_encode_kernel, dim3((nch + 3) / 4), dim3(128), 0, stream, d_pcm, pcm_pitch, nch,
+                       sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch);
     VGA_HIP_TRY(hipGetLastError());
     return VGA_OK;
 }
