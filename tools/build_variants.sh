@@ -1,13 +1,14 @@
 #!/bin/bash
-# Builds experimental variants of gc_encode_kernel.hip (different -D switches) as full libraries under
+# Builds experimental variants of the GC-ADPCM kernels (different -D switches) as full libraries under
 # tools/variants/ (git-ignored, shipped to the GPU box by gpurun).  usage: build_variants.sh name:"-DX -DY" ...
 set -e
 cd "$(dirname "$0")/.."
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fwrapv -fno-fast-math -w"
+VARIED="gc_encode_kernel gcadpcm_kernels"
 mkdir -p tools/variants/obj
 for f in vgaudio_amd/csrc/*.hip; do
   b=$(basename $f .hip)
-  [ "$b" = gc_encode_kernel ] && continue
+  case " $VARIED " in *" $b "*) continue;; esac
   if [ ! -f tools/variants/obj/$b.o ] || [ $f -nt tools/variants/obj/$b.o ]; then
     /opt/rocm/bin/hipcc $FLAGS -c $f -o tools/variants/obj/$b.o &
   fi
@@ -15,13 +16,14 @@ done
 wait
 for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}
-  ( /opt/rocm/bin/hipcc $FLAGS $defs -c vgaudio_amd/csrc/gc_encode_kernel.hip -o tools/variants/obj/enc_$name.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC tools/variants/obj/*.o -o /dev/null 2>/dev/null; true ) &
+  for v in $VARIED; do
+    /opt/rocm/bin/hipcc $FLAGS $defs -c vgaudio_amd/csrc/$v.hip -o tools/variants/obj/var_${name}_$v.o &
+  done
 done
 wait
 for spec in "$@"; do
   name=${spec%%:*}
-  others=$(ls tools/variants/obj/*.o | grep -v "/enc_")
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $others tools/variants/obj/enc_$name.o -o tools/variants/libvga_$name.so
+  others=$(ls tools/variants/obj/*.o | grep -v "/var_")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $others tools/variants/obj/var_${name}_*.o -o tools/variants/libvga_$name.so
   echo built tools/variants/libvga_$name.so
 done

@@ -195,13 +195,13 @@ VGA_HD int round_through_f32(int d)
 #endif
 }
 
-// Fast quantise pass: integer-only, 16 VALU ops per sample of which 9 are on the dependent chain
-// (mad, cvt, cvt, add3, ashr, med3, lshl_add, ashr, med3) instead of the f32/f64 detour.
+// Fast quantise pass: integer-only, 16 VALU ops per sample of which 8 are on the dependent chain
+// (mad, cvt, cvt, add3, ashr, med3, lshl_add, med3) instead of the f32/f64 detour.
 //   d      = in*2048 - (o0*c1 + o1*c0)                       (two mads with negated coefs)
 //   r      = (int)(float)d                                   the reference's float rounding
 //   u      = (r + 2^(k-1) - 1 + (d<0)) >> k                  unclamped nibble  (S2)
 //   q      = clamp(u, -8, 7)
-//   recon  = clamp16(((in*2048 + 1024 - d) + (q << k)) >> 11)       (in*2048 + 1024 - d == predicted + 1024)
+//   recon  = clamp16(((in*2048 + 1024 - d) >> 11) + (q << (k-11)))  (in*2048 + 1024 - d == predicted + 1024)
 // The nibbles are accumulated SIGNED (w = w*16 + q, one shift-add each); adding 0x888..8 turns the sum
 // into the packing of the biased nibbles q+8 and the XOR with 0x888..8 un-biases them (two ops per word).
 // The overflow is recovered from the running max/min of u (one max3/min3 per two samples).
@@ -216,6 +216,7 @@ VGA_HD PassOut pass_fast_core(const int (&x)[16], const int (&in2048v)[14], cons
 {
     PassOut r;
     const int k = scale_power + 11;
+    const int km11 = scale_power;
     int bias = (1 << (k - 1)) - 1;
     int nc0 = -c0, nc1 = -c1;
     VGA_OPAQUE(bias);
@@ -243,8 +244,10 @@ VGA_HD PassOut pass_fast_core(const int (&x)[16], const int (&in2048v)[14], cons
         u_prev = u;
         if (s < 6) wa = (wa << 4) + (uint32_t)q;
         else       wb = (wb << 4) + (uint32_t)q;
-        const uint32_t pr = (uint32_t)in2048p[s] - (uint32_t)d;        // predicted + 1024
-        const int recon = clamp16i((int)(pr + ((uint32_t)q << k)) >> 11);
+        // (predicted + 1024 + q * 2^k) >> 11 with the shift taken off the dependent chain: q * 2^k is a
+        // multiple of 2^11 (k >= 11), so it passes through the floor
+        const int pr11 = (int)((uint32_t)in2048p[s] - (uint32_t)d) >> 11;
+        const int recon = clamp16i(pr11 + (int)((uint32_t)q << km11));
         const int e = x[s + 2] - recon;
         total += (uint32_t)VGA_MUL24(e, e);
         o0 = o1;

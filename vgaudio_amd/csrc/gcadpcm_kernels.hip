@@ -694,11 +694,30 @@ __device__ __forceinline__ int lane_rank(uint64_t mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
+// acc += sd[0] + sd[1] + ... + sd[n-1], strictly in that order (the reference's running sums are
+// order-dependent f64 adds, GcAdpcmCoefficients.cs:68-71 / :374-380).  The LDS reads are issued in
+// batches of 8 ahead of the dependent adds; slots past n contribute +0.0, which leaves a sum that
+// started at +0.0 unchanged bit for bit.  trip: wave-uniform upper bound of n.
+__device__ __forceinline__ double ordered_sum(double acc, const double *sd, int n, int trip)
+{
+    for (int i = 0; i < trip; i += 8) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = sd[i + j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc += (i + j < n) ? v[j] : 0.0;
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(64) void gc_coefs_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int length,
     double2 *__restrict__ records, int16_t *__restrict__ coefs_out)
 {
-    __shared__ double s_d[2][64];      // compacted (d1, d2) of the current chunk, bucket-major
+    // compacted (d1, d2) of the current chunk, bucket-major; two buffers (chunk parity) so one barrier per
+    // chunk is enough; rows are padded because ordered_sum() reads whole batches up to the LARGEST bucket's
+    // size past each bucket's start (start + max_n + 7 <= 63 + 64 + 7)
+    __shared__ double s_d[2][2][136];
     __shared__ double s_vb[8][3];      // vecBest
     __shared__ double s_cw[8][3];      // val1, val2, val3 of ContrastVectors per codeword
     __shared__ double s_sum[8][3];     // bufferList
@@ -715,14 +734,19 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     // ---- pass 0: per-frame records (:40-61) + ordered mean of MatrixFilter outputs (:63-74)
     double acc = 0.0;
     int cnt = 0;
-    for (int base = 0; base < frames; base += 64) {
+    int par = 0;
+    for (int base = 0; base < frames; base += 64, par ^= 1) {
         const int f = base + lane;
         bool valid = false;
         double d1 = 0.0, d2 = 0.0;
         if (f < frames) {
             int x[16];
             load_frame16(src, f, length, x);
+#ifdef VGA_CABL_NOREC
+            Record r; r.valid = true; r.r1 = x[2] * 1e-5; r.r2 = x[3] * 1e-5;
+#else
             const Record r = frame_record(x);
+#endif
             valid = r.valid;
             if (valid) {
                 matrix_filter(r.r1, r.r2, d1, d2);
@@ -735,15 +759,16 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
         const int n = __popcll(mask);
         if (valid) {
             const int slot = lane_rank(mask);
-            s_d[0][slot] = d1;
-            s_d[1][slot] = d2;
+            s_d[par][0][slot] = d1;
+            s_d[par][1][slot] = d2;
         }
         __syncthreads();
-        if (lane < 2)
-            for (int i = 0; i < n; i++) acc += s_d[lane][i];
+#ifndef VGA_CABL_NOACC
+        if (lane < 2) acc = ordered_sum(acc, &s_d[par][lane][0], n, n);
+#endif
         cnt += n;
-        __syncthreads();
     }
+    __syncthreads();
     if (lane < 2) s_sum[0][1 + lane] = acc;
     __syncthreads();
     if (lane == 0) {
@@ -760,7 +785,11 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     __syncthreads();
 
     // ---- 3 splits x 2 Lloyd iterations (:77-91, FilterRecords :344-396)
+#ifdef VGA_CABL_NOLLOYD
+    for (int w = 0; w < 0; w++) {
+#else
     for (int w = 0; w < 3; w++) {
+#endif
         const int half = 1 << w;
         const int exp = 2 << w;
         if (lane < half) {
@@ -788,13 +817,16 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
 
             acc = 0.0;
             cnt = 0;
-            for (int base = 0; base < frames; base += 64) {
+            const double2 no_rec = make_double2(__builtin_nan(""), 0.0);
+            double2 r_next = lane < frames ? rec[lane] : no_rec;
+            for (int base = 0; base < frames; base += 64, par ^= 1) {
                 const int f = base + lane;
                 bool valid = false;
                 int idx = 0;
                 double d1 = 0.0, d2 = 0.0;
-                if (f < frames) {
-                    const double2 r = rec[f];
+                const double2 r = r_next;
+                r_next = f + 64 < frames ? rec[f + 64] : no_rec;     // in flight during this chunk
+                {
                     if (r.x == r.x) {
                         valid = true;
                         // ContrastVectors :335-342 (val) == MatrixFilter :295-296 (mtx[1][1])
@@ -828,18 +860,18 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
                     }
                 }
                 if (valid) {
-                    s_d[0][slot] = d1;
-                    s_d[1][slot] = d2;
+                    s_d[par][0][slot] = d1;
+                    s_d[par][1][slot] = d2;
                 }
                 __syncthreads();
                 if (lane < 16) {
-                    const double *sd = &s_d[my_comp][my_start];
-                    for (int i = 0; i < max_n; i++)
-                        if (i < my_n) acc += sd[i];
+#ifndef VGA_CABL_NOACC
+                    acc = ordered_sum(acc, &s_d[par][my_comp][my_start], my_n, max_n);
+#endif
                     cnt += my_n;
                 }
-                __syncthreads();
             }
+            __syncthreads();
             if (lane < 2 * exp) {
                 s_sum[my_bucket][1 + my_comp] = acc;
                 if (my_comp == 0) s_cnt[my_bucket] = cnt;
