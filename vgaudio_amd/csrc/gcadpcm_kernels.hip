@@ -695,17 +695,19 @@ __device__ __forceinline__ int lane_rank(uint64_t mask)
 }
 
 // acc += sd[0] + sd[1] + ... + sd[n-1], strictly in that order (the reference's running sums are
-// order-dependent f64 adds, GcAdpcmCoefficients.cs:68-71 / :374-380).  The LDS reads are issued in
-// batches of 8 ahead of the dependent adds; slots past n contribute +0.0, which leaves a sum that
-// started at +0.0 unchanged bit for bit.  trip: wave-uniform upper bound of n.
+// order-dependent f64 adds, GcAdpcmCoefficients.cs:68-71 / :374-380).  sd is the 64-byte aligned start of a
+// bucket whose slots n .. ceil8(n)-1 hold +0.0 (adding +0.0 leaves a sum that started at +0.0 unchanged bit
+// for bit), so whole batches of 8 are read with b128 loads and added unconditionally.
+// trip: wave-uniform upper bound of n.
 __device__ __forceinline__ double ordered_sum(double acc, const double *sd, int n, int trip)
 {
     for (int i = 0; i < trip; i += 8) {
-        double v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = sd[i + j];
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc += (i + j < n) ? v[j] : 0.0;
+        if (i < n) {
+            const double2 *p = reinterpret_cast<const double2 *>(sd + i);
+            const double2 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+            acc += v0.x; acc += v0.y; acc += v1.x; acc += v1.y;
+            acc += v2.x; acc += v2.y; acc += v3.x; acc += v3.y;
+        }
     }
     return acc;
 }
@@ -714,10 +716,9 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int length,
     double2 *__restrict__ records, int16_t *__restrict__ coefs_out)
 {
-    // compacted (d1, d2) of the current chunk, bucket-major; two buffers (chunk parity) so one barrier per
-    // chunk is enough; rows are padded because ordered_sum() reads whole batches up to the LARGEST bucket's
-    // size past each bucket's start (start + max_n + 7 <= 63 + 64 + 7)
-    __shared__ double s_d[2][2][136];
+    // compacted (d1, d2) of the current chunk, bucket-major, every bucket starting on a multiple of 8 slots and
+    // zero-padded to the next one (<= 64 + 8 * 7 slots); two buffers (chunk parity): one barrier per chunk
+    __shared__ __align__(64) double s_d[2][2][128];
     __shared__ double s_vb[8][3];      // vecBest
     __shared__ double s_cw[8][3];      // val1, val2, val3 of ContrastVectors per codeword
     __shared__ double s_sum[8][3];     // bufferList
@@ -730,6 +731,12 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     double2 *rec = records + (int64_t)ch * frames;
     const int my_bucket = lane >> 1;   // accumulator lanes: lane < 16
     const int my_comp = lane & 1;
+
+    // one wave: its LDS operations execute in program order, so the fill needs no barrier before the writes
+    auto zero_fill = [&](int par) {
+        reinterpret_cast<double2 *>(&s_d[par][0][0])[lane] = make_double2(0.0, 0.0);
+        reinterpret_cast<double2 *>(&s_d[par][1][0])[lane] = make_double2(0.0, 0.0);
+    };
 
     // ---- pass 0: per-frame records (:40-61) + ordered mean of MatrixFilter outputs (:63-74)
     double acc = 0.0;
@@ -757,6 +764,7 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
         }
         const uint64_t mask = __ballot(valid);
         const int n = __popcll(mask);
+        zero_fill(par);
         if (valid) {
             const int slot = lane_rank(mask);
             s_d[par][0][slot] = d1;
@@ -855,10 +863,11 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
                         const int n_b = __popcll(m);
                         if (mine) slot = start + lane_rank(m);
                         if (my_bucket == b) { my_start = start; my_n = n_b; }
-                        start += n_b;
+                        start += (n_b + 7) & ~7;
                         max_n = max(max_n, n_b);
                     }
                 }
+                zero_fill(par);
                 if (valid) {
                     s_d[par][0][slot] = d1;
                     s_d[par][1][slot] = d2;
