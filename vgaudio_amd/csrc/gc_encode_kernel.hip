@@ -310,16 +310,38 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
         const bool resume = !cand_b && imin(eff, eff_other) >= 2;     // both overflowed: A carries on at s1+2
         const bool wide = fin && total32 >= (1u << 28);
         int winner;
+        bool need64 = false;
 #if !defined(VGA_EXPERIMENT_NO_COLD)
         if (__builtin_expect(__any(rare || resume || wide), 0)) {
             // ---- cold block (resume: ~40 % of wave-frames on audio; rare: hostile input only)
             const bool redo = __any(rare);             // whole frame again, the reference's loop as written
-            if (redo) fin = false;
-            if (!cand_b && (redo || resume)) {
-                r = resume_passes_core(x, R.m, R.mp, c0, c1, redo ? s1 - 1 : s1 + 1, final_sp);
+            if (redo) {
+                fin = false;
+                if (!cand_b) {
+                    r = resume_passes_core(x, R.m, R.mp, c0, c1, s1 - 1, final_sp);
+                    fin = true;
+                }
+            } else if (resume) {
+                // third and later trips of the A lane, same straight-line tests as the first trip
+                int sp = s1 + 1;                       // < 12: neither candidate was at the cap
+                for (;;) {
+                    sp++;
+                    r = pass_fast_core(x, R.m, R.mp, c0, c1, sp);
+                    const bool cap = sp >= 12;
+                    if ((unsigned)r.max_overflow > (cap ? 3u : 248u)) {      // bump loop / inexact sum: generic
+                        r = resume_passes_core(x, R.m, R.mp, c0, c1, sp - 1, final_sp);
+                        break;
+                    }
+                    final_sp = sp;
+                    if (cap || r.max_overflow <= 1) break;
+                }
                 fin = true;
             }
-            // argmin over the 8 predictors, first index wins ties (:66-76); 64-bit keys
+            need64 = __any(fin && (r.total >> 28) != 0);
+        }
+#endif
+        // ---- argmin over the 8 predictors, first index wins ties (:66-76)
+        if (__builtin_expect(need64, 0)) {
             uint64_t key = fin ? ((r.total << 4) | (uint64_t)l16) : ~0ull;
 #define VGA_MIN64_STAGE(CTRL)                                                          \
             {                                                                          \
@@ -334,10 +356,8 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
             VGA_MIN64_STAGE(DPP_ROW_MIRROR)
 #undef VGA_MIN64_STAGE
             winner = (int)(key & 15u);
-        } else
-#endif
-        {
-            const unsigned key = fin ? ((total32 << 4) | (unsigned)l16) : 0xFFFFFFFFu;
+        } else {
+            const unsigned key = fin ? (((unsigned)r.total << 4) | (unsigned)l16) : 0xFFFFFFFFu;
             const unsigned best = row16_reduce(key, [](unsigned a, unsigned b) { return a < b ? a : b; });
             winner = (int)(best & 15u);
         }

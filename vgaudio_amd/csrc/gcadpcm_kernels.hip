@@ -712,6 +712,15 @@ __device__ __forceinline__ double ordered_sum(double acc, const double *sd, int 
     return acc;
 }
 
+// The workgroup is ONE wave: its LDS operations execute in program order, so making another lane's
+// LDS write visible needs no s_barrier -- only the LDS counter and a compiler ordering point.
+// __syncthreads() would also drain vmcnt, i.e. wait for the record prefetch of the NEXT chunk
+// (a full HBM round trip per chunk: 48 % of the wave's cycles were SQ_WAIT_ANY, profiles/r01_d_sq_counters.md).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 __global__ __launch_bounds__(64) void gc_coefs_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int length,
     double2 *__restrict__ records, int16_t *__restrict__ coefs_out)
@@ -742,25 +751,40 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     double acc = 0.0;
     int cnt = 0;
     int par = 0;
+    // PCM prefetch, one chunk ahead: frames whose 16-sample window [14 f - 2, 14 f + 14) lies inside the
+    // channel are read as 8 dwords with a clamped (always valid) frame index -- unconditional loads, see
+    // the record prefetch below; frame 0 and the zero-padded tail take load_frame16()'s slow path.
+    const int f_hi = (length - 14) / 14;               // last frame with a full window
+    const bool have_interior = f_hi >= 1;
+    uint32_t w[8];
+    auto prefetch = [&](int f) {
+        const int fp = min(max(f, 1), max(f_hi, 1));
+        const uint32_t *p32 = reinterpret_cast<const uint32_t *>(src + (int64_t)fp * 14 - 2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = p32[i];
+    };
+    if (have_interior) prefetch(lane);
     for (int base = 0; base < frames; base += 64, par ^= 1) {
         const int f = base + lane;
         bool valid = false;
         double d1 = 0.0, d2 = 0.0;
+        int x[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            x[2 * i] = (int)(int16_t)(w[i] & 0xFFFF);
+            x[2 * i + 1] = (int)w[i] >> 16;
+        }
+        if (have_interior) prefetch(f + 64);           // in flight during this chunk
         if (f < frames) {
-            int x[16];
-            load_frame16(src, f, length, x);
+            if (!(have_interior && f >= 1 && f <= f_hi)) load_frame16(src, f, length, x);
 #ifdef VGA_CABL_NOREC
             Record r; r.valid = true; r.r1 = x[2] * 1e-5; r.r2 = x[3] * 1e-5;
 #else
             const Record r = frame_record(x);
 #endif
             valid = r.valid;
-            if (valid) {
-                matrix_filter(r.r1, r.r2, d1, d2);
-                rec[f] = make_double2(r.r1, r.r2);
-            } else {
-                rec[f] = make_double2(__builtin_nan(""), 0.0);
-            }
+            if (valid) matrix_filter(r.r1, r.r2, d1, d2);
+            rec[f] = valid ? make_double2(r.r1, r.r2) : make_double2(__builtin_nan(""), 0.0);
         }
         const uint64_t mask = __ballot(valid);
         const int n = __popcll(mask);
@@ -770,7 +794,7 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
             s_d[par][0][slot] = d1;
             s_d[par][1][slot] = d2;
         }
-        __syncthreads();
+        wave_lds_sync();
 #ifndef VGA_CABL_NOACC
         if (lane < 2) acc = ordered_sum(acc, &s_d[par][lane][0], n, n);
 #endif
@@ -825,17 +849,18 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
 
             acc = 0.0;
             cnt = 0;
-            const double2 no_rec = make_double2(__builtin_nan(""), 0.0);
-            double2 r_next = lane < frames ? rec[lane] : no_rec;
+            // record prefetch, one chunk ahead.  The loads are unconditional (clamped index): a load under
+            // a lane-divergent condition makes the compiler wait for it right at the join.
+            double2 r_next = rec[min(lane, frames - 1)];
             for (int base = 0; base < frames; base += 64, par ^= 1) {
                 const int f = base + lane;
                 bool valid = false;
                 int idx = 0;
                 double d1 = 0.0, d2 = 0.0;
                 const double2 r = r_next;
-                r_next = f + 64 < frames ? rec[f + 64] : no_rec;     // in flight during this chunk
+                r_next = rec[min(f + 64, frames - 1)];               // in flight during this chunk
                 {
-                    if (r.x == r.x) {
+                    if (f < frames && r.x == r.x) {
                         valid = true;
                         // ContrastVectors :335-342 (val) == MatrixFilter :295-296 (mtx[1][1])
                         const double val = (r.y * r.x + -r.x) / (1.0 - r.y * r.y);
@@ -872,7 +897,7 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
                     s_d[par][0][slot] = d1;
                     s_d[par][1][slot] = d2;
                 }
-                __syncthreads();
+                wave_lds_sync();
                 if (lane < 16) {
 #ifndef VGA_CABL_NOACC
                     acc = ordered_sum(acc, &s_d[par][my_comp][my_start], my_n, max_n);
