@@ -24,6 +24,7 @@
 #include "gcadpcm_kernels.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace vga {
 namespace gc {
@@ -816,35 +817,22 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     }
     __syncthreads();
 
-    // ---- 3 splits x 2 Lloyd iterations (:77-91, FilterRecords :344-396)
-#ifdef VGA_CABL_NOLLOYD
-    for (int w = 0; w < 0; w++) {
-#else
-    for (int w = 0; w < 3; w++) {
-#endif
-        const int half = 1 << w;
-        const int exp = 2 << w;
-        if (lane < half) {
-            s_vb[half + lane][0] = (0.01 * 0.0) + s_vb[lane][0];
-            s_vb[half + lane][1] = (0.01 * -1.0) + s_vb[lane][1];
-            s_vb[half + lane][2] = (0.01 * 0.0) + s_vb[lane][2];
-        }
-        __syncthreads();
-
+    auto lloyd_iterations = [&](auto exp_c) {
+        constexpr int EXP = decltype(exp_c)::value;
         for (int iter = 0; iter < 2; iter++) {
-            if (lane < exp) {
+            if (lane < EXP) {
                 const double a = s_vb[lane][0], b = s_vb[lane][1], c = s_vb[lane][2];
                 s_cw[lane][0] = (a * a) + (b * b) + (c * c);
                 s_cw[lane][1] = (a * b) + (b * c);
                 s_cw[lane][2] = a * c;
             }
             __syncthreads();
-            double cw1[8], cw2[8], cw3[8];
+            double cw1[EXP], cw2[EXP], cw3[EXP];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                cw1[i] = s_cw[i < exp ? i : 0][0];
-                cw2[i] = s_cw[i < exp ? i : 0][1];
-                cw3[i] = s_cw[i < exp ? i : 0][2];
+            for (int i = 0; i < EXP; i++) {
+                cw1[i] = s_cw[i][0];
+                cw2[i] = s_cw[i][1];
+                cw3[i] = s_cw[i][2];
             }
 
             acc = 0.0;
@@ -859,38 +847,32 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
                 double d1 = 0.0, d2 = 0.0;
                 const double2 r = r_next;
                 r_next = rec[min(f + 64, frames - 1)];               // in flight during this chunk
-                {
-                    if (f < frames && r.x == r.x) {
-                        valid = true;
-                        // ContrastVectors :335-342 (val) == MatrixFilter :295-296 (mtx[1][1])
-                        const double val = (r.y * r.x + -r.x) / (1.0 - r.y * r.y);
-                        const double bterm = (-r.x * val + -r.y);
-                        const double val_x2 = 2.0 * val, bterm_x2 = 2.0 * bterm;
-                        double value = 1.0e30;
+                if (f < frames && r.x == r.x) {
+                    valid = true;
+                    // ContrastVectors :335-342 (val) == MatrixFilter :295-296 (mtx[1][1])
+                    const double val = (r.y * r.x + -r.x) / (1.0 - r.y * r.y);
+                    const double bterm = (-r.x * val + -r.y);
+                    const double val_x2 = 2.0 * val, bterm_x2 = 2.0 * bterm;
+                    double value = 1.0e30;
 #pragma unroll
-                        for (int i = 0; i < 8; i++) {
-                            if (i < exp) {
-                                const double t = cw1[i] + (val_x2 * cw2[i]) + (bterm_x2 * cw3[i]);
-                                if (t < value) { value = t; idx = i; }
-                            }
-                        }
-                        d1 = 0.0 + val * 1.0;                       // dst[1] = 0.0 + mtx[1][1]*dst[0]
-                        d2 = (0.0 + (-r.x) * d1) + (-r.y) * 1.0;    // dst[2]
+                    for (int i = 0; i < EXP; i++) {
+                        const double t = cw1[i] + (val_x2 * cw2[i]) + (bterm_x2 * cw3[i]);
+                        if (t < value) { value = t; idx = i; }
                     }
+                    d1 = 0.0 + val * 1.0;                       // dst[1] = 0.0 + mtx[1][1]*dst[0]
+                    d2 = (0.0 + (-r.x) * d1) + (-r.y) * 1.0;    // dst[2]
                 }
                 // stable partition by bucket
                 int slot = 0, my_start = 0, my_n = 0, start = 0, max_n = 0;
 #pragma unroll
-                for (int b = 0; b < 8; b++) {
-                    if (b < exp) {
-                        const bool mine = valid && idx == b;
-                        const uint64_t m = __ballot(mine);
-                        const int n_b = __popcll(m);
-                        if (mine) slot = start + lane_rank(m);
-                        if (my_bucket == b) { my_start = start; my_n = n_b; }
-                        start += (n_b + 7) & ~7;
-                        max_n = max(max_n, n_b);
-                    }
+                for (int b = 0; b < EXP; b++) {
+                    const bool mine = valid && idx == b;
+                    const uint64_t m = __ballot(mine);
+                    const int n_b = __popcll(m);
+                    if (mine) slot = start + lane_rank(m);
+                    if (my_bucket == b) { my_start = start; my_n = n_b; }
+                    start += (n_b + 7) & ~7;
+                    max_n = max(max_n, n_b);
                 }
                 zero_fill(par);
                 if (valid) {
@@ -898,7 +880,7 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
                     s_d[par][1][slot] = d2;
                 }
                 wave_lds_sync();
-                if (lane < 16) {
+                if (lane < 2 * EXP) {
 #ifndef VGA_CABL_NOACC
                     acc = ordered_sum(acc, &s_d[par][my_comp][my_start], my_n, max_n);
 #endif
@@ -906,12 +888,12 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
                 }
             }
             __syncthreads();
-            if (lane < 2 * exp) {
+            if (lane < 2 * EXP) {
                 s_sum[my_bucket][1 + my_comp] = acc;
                 if (my_comp == 0) s_cnt[my_bucket] = cnt;
             }
             __syncthreads();
-            if (lane < exp) {
+            if (lane < EXP) {
                 double bl[3];
                 const int n = s_cnt[lane];
                 bl[0] = (double)n;                  // bufferList[i][0] sums 1.0 per record
@@ -924,6 +906,26 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
             }
             __syncthreads();
         }
+    };
+
+    // ---- 3 splits x 2 Lloyd iterations (:77-91, FilterRecords :344-396)
+#ifdef VGA_CABL_NOLLOYD
+    for (int w = 0; w < 0; w++) {
+#else
+    for (int w = 0; w < 3; w++) {
+#endif
+        const int half = 1 << w;
+        if (lane < half) {
+            s_vb[half + lane][0] = (0.01 * 0.0) + s_vb[lane][0];
+            s_vb[half + lane][1] = (0.01 * -1.0) + s_vb[lane][1];
+            s_vb[half + lane][2] = (0.01 * 0.0) + s_vb[lane][2];
+        }
+        __syncthreads();
+
+        // the two Lloyd iterations of this split, specialised on the codebook size (no per-codeword branches)
+        if (w == 0) lloyd_iterations(std::integral_constant<int, 2>{});
+        else if (w == 1) lloyd_iterations(std::integral_constant<int, 4>{});
+        else lloyd_iterations(std::integral_constant<int, 8>{});
     }
 
     // ---- output :94-108
