@@ -166,6 +166,19 @@ def main():
                 traffic = round(pmc["gc_encode_kernel"]["traffic_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
+        # What actually binds the kernel: wave-instruction issue.  From the committed SQ
+        # counter pass (profiles/r01_d_sq_counters.json): VALU-active quad-cycles / (SIMDs x kernel quad-cycles).
+        issue = None
+        try:
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r01_d_sq_counters.json")))["gc_encode_kernel"]
+            if nch == 4096 and n == 2880000:
+                clk_quads = sq["SQ_WAVE_CYCLES"] / sq["SQ_WAVES"]          # every wave lives the whole launch
+                issue = {"valu_wave_instructions_per_launch": round(sq["SQ_INSTS_VALU"]),
+                         "valu_issue_frac": round(sq["SQ_ACTIVE_INST_VALU"] / (1024 * clk_quads), 3),
+                         "profiled_launch_ms": round(sq["_dur_ms"], 1),
+                         "note": "1024 SIMDs x one wave-instruction per 4 cycles; profiled launch, not this run"}
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            pass
         achieved = enc_bytes / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
         roofline = {"bound": "hbm", "kernel": "gc_encode_kernel", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -174,7 +187,8 @@ def main():
                         "launch_ms": round(coef_ms, 3),
                         "achieved": round(COEF_BYTES_PER_SAMPLE * nch * n / (coef_ms * 1e-3) / 1e9, 2) if coef_ms > 0 else 0.0}},
                     "pipeline_achieved": round(PIPE_BYTES_PER_SAMPLE * nch * n / ((coef_ms + enc_ms) * 1e-3) / 1e9, 2)
-                    if coef_ms + enc_ms > 0 else 0.0}
+                    if coef_ms + enc_ms > 0 else 0.0,
+                    "issue": issue}
 
         cpu = None
         if not args.no_cpu_baseline:

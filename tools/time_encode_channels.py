@@ -3,7 +3,7 @@ import sys, torch, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vgaudio_amd import device as vdev
 d = torch.device('cuda:0'); n = 720000
-for nch in (4096, 8192, 16384, 32768):
+for nch in (2048, 4096, 8192):
     pcm = vdev.synth_pcm(nch, n, d); coefs = vdev.gc_coefs(pcm, n); out = vdev.alloc_adpcm(nch, n, d)
     vdev.gc_encode(pcm, n, coefs, out=out); torch.cuda.synchronize()
     ts = []

@@ -5,25 +5,20 @@
 //
 // ADPCM is a serial recurrence inside a channel (the reconstructed samples 12,13 of frame
 // k are the history of frame k+1, :40-41; sample s+1 needs reconstructed sample s, :138,160),
-// so time = frames x (length of the dependent chain per frame).  The design shortens that
-// chain instead of chasing bandwidth:
+// so time = frames x (wave-instructions per frame): the kernel is bound by VALU issue (one
+// instruction per 4 cycles per SIMD for this mix), not by HBM.
 //
 //  * lane = (channel, predictor, scale candidate): 16 lanes per channel, 4 channels per
-//    wave64, one wave per workgroup -> 1024 workgroups for 4096 channels, one per SIMD.
+//    encoder wave; a helper wave per workgroup prepares 16-frame tiles in LDS (below).
 //  * Speculation on the retry loop (:127-170): the reference's first quantise pass is one
 //    scale too small 93 % of the time and exactly right 6 %, so candidate A runs the pass
-//    at scale s1 and candidate B at s1+1 IN PARALLEL LANES; resolve_candidates() decides
-//    from the two overflow values which one the reference ends on.  The residual ~0.3 %
-//    (overflow bumps, third pass) re-enters the literal loop under a wave-uniform branch.
-//  * The quantise pass is integer-only (7 dependent VALU ops per sample instead of the
-//    float/double detour); exactness is proven a posteriori per frame (gc_encode_core.hpp
-//    S2/S3), otherwise the literal pass is re-run.
-//  * The 14-sample pre-scan (:107-115) needs only input samples: the two candidate lanes
-//    split it (7 samples each) and merge max/min with one DPP op each.
+//    at scale s1 and candidate B at s1+1 IN PARALLEL LANES; two compares on the exchanged
+//    overflow values decide which one the reference ends on.  Third trips, overflow bumps
+//    and everything else that is rare sit behind ONE wave-uniform branch per frame.
+//  * The quantise pass is integer-only (16 VALU ops per sample, 8 on the dependent chain,
+//    instead of the float/double detour); exactness conditions in gc_encode_core.hpp S2/S3.
 //  * 8-predictor argmin + winner-history broadcast: v_min_u32 / v_or_b32 with DPP operands
 //    (quad_perm, row_half_mirror, row_mirror) -- 8 VALU ops, no LDS.
-//  * PCM is read straight from the planar layout with 7 dword loads per frame, prefetched
-//    one frame ahead (the loop is latency-bound at ~0.3 TB/s aggregate, far below HBM).
 #include "common.hpp"
 #include "gc_encode_core.hpp"
 #include "gcadpcm_kernels.hpp"
@@ -89,7 +84,6 @@ struct GcTile {
 #define VGA_MARK(name)
 #endif
 struct X16 { int v[16]; };
-struct ResumeOut { PassOut r; int final_sp; };
 
 #ifdef VGA_ENC_COLD_OUTLINE      // experiment switch: measured 267 ms out of line vs 260 ms inline at configs[1]
 #define VGA_COLD __device__ __noinline__
@@ -97,15 +91,7 @@ struct ResumeOut { PassOut r; int final_sp; };
 #define VGA_COLD __device__ __forceinline__
 #endif
 
-// Rare paths, out of line so the per-frame loop stays small (arguments by value: the hot copy of the
-// frame stays in registers, the cold copy may live wherever the callee likes).
-VGA_COLD PassOut pass_literal_cold(X16 xs, int c0, int c1, int scale_power)
-{
-    int x[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = xs.v[i];
-    return pass_literal(x, c0, c1, scale_power);
-}
+// Rare +M/-M tie of the pre-scan (argument by value: the hot copy of the frame stays in registers).
 VGA_COLD int prescan_sequential_cold(X16 xs, int c0, int c1)
 {
     int x[16];
@@ -113,16 +99,6 @@ VGA_COLD int prescan_sequential_cold(X16 xs, int c0, int c1)
     for (int i = 0; i < 16; i++) x[i] = xs.v[i];
     return prescan_sequential(x, c0, c1);
 }
-VGA_COLD ResumeOut resume_cold(X16 xs, int c0, int c1, int scale_power)
-{
-    int x[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = xs.v[i];
-    ResumeOut o;
-    o.r = resume_passes(x, c0, c1, scale_power, o.final_sp);
-    return o;
-}
-VGA_COLD Resolve resolve_cold(int s1, int ov_a, int ov_b) { return resolve_candidates(s1, ov_a, ov_b); }
 
 __global__ __launch_bounds__(128) void gc_encode_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int sample_count,
