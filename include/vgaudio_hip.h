@@ -209,7 +209,8 @@ int vga_hca_encoder_initialize(const vga_hca_params *config, vga_hca_info *info_
  * `nstreams` equally shaped streams.  pcm: nstreams*channel_count planar pointers (stream-major,
  * sample_count shorts each); frames_out[s]: frame_count*frame_size bytes (from
  * vga_hca_encoder_initialize).  "Bitrate is set too low." -> VGA_ERR_INVALID_DATA.  Looping
- * streams: VGA_ERR_INVALID_OP (not yet on the device path). */
+ * streams: the encoder's pre-audio / replayed loop audio / trailing zeros (CriHcaEncoder.cs:170-254)
+ * are reproduced from the loop fields of the HcaInfo. */
 int vga_hca_encode_batch(const int16_t *const *pcm, int nstreams, const vga_hca_params *config,
                          vga_hca_info *info_out, uint8_t *const *frames_out);
 /* Replaces CriHcaFormat.ToPcm16 (CriHcaFormat.cs:26-32 -> CriHcaDecoder.Decode,

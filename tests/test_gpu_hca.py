@@ -103,3 +103,36 @@ def test_config4_shape_reduced_roundtrip():
         err = np.stack(dec[i]).astype(float) - streams[i]
         snr = 10 * np.log10((streams[i].astype(float) ** 2).mean() / (err ** 2).mean())
         assert snr > 30, snr
+
+
+@pytest.mark.parametrize("nch,quality,n,loop_start,loop_end", [
+    (2, "High", 20000, 3000, 18000),      # plain loop
+    (2, "High", 20000, 0, 20000),         # whole stream
+    (1, "Middle", 9000, 1, 8999),         # loop start just after a frame boundary: > 1024 samples of pre-audio
+    (2, "Low", 5000, 4700, 4990),         # short loop at the end: replayed audio crosses the last chunk
+    (2, "High", 5000, 1024, 6000),        # loop end past the data: HcaInfo.SampleCount = min(loop end, n)
+    (2, "High", 3000, 2990, 3000),        # ten-sample loop, replay reads past the PCM (stale chunk tail)
+    (1, "Lowest", 1500, 1030, 1100),      # loop inside the second chunk
+    (4, "Middle", 12345, 5000, 12000)])
+def test_looping_encode_and_decode_match_oracle(nch, quality, n, loop_start, loop_end):
+    """CriHcaEncoder's input stream for looping files (pre-audio, replayed loop audio, CriHcaEncoder.cs:170-254)."""
+    streams = _streams(2, nch, n, "synth")
+    pcms = [Pcm16Format(list(s), 48000) for s in streams]
+    for pcm in pcms:    # set directly: WithLoop rejects a loop end past the data, CriHcaEncoder clamps it (:84)
+        pcm.Looping, pcm.LoopStart, pcm.LoopEnd = True, loop_start, loop_end
+    fmts = CriHcaFormat.EncodeBatchFromPcm16(pcms, CriHcaParameters(Quality=Q[quality]))
+    p = po.hca_params(nch, n, quality=quality, looping=True, loop_start=loop_start, loop_end=loop_end)
+    for s, fmt in zip(streams, fmts):
+        rc, info, want = po.hca_encode(s, p)
+        assert rc == 0
+        for k, v in info.as_dict().items():
+            assert getattr(fmt.Hca.c, k) == v, k
+        assert fmt.AudioData.shape == want.shape
+        bad = np.argwhere(fmt.AudioData != want)
+        assert bad.size == 0, (bad[0].tolist(), len(bad))
+    dec = CriHcaDecoder.Decode(fmts[0].Hca, [fmt.AudioData for fmt in fmts])
+    for fmt, d in zip(fmts, dec):
+        rc, want = po.hca_decode(info, fmt.AudioData)
+        assert rc == 0
+        for c in range(nch):
+            assert (d[c] == want[c]).all(), (c, int(np.argmax(d[c] != want[c])))

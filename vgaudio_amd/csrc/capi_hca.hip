@@ -254,7 +254,6 @@ int vga_hca_encode_device(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch
                           const vga_hca_info *h, uint8_t *d_frames, int64_t frames_pitch, int *d_status, void *stream)
 {
     if (!h) { set_error("null HcaInfo"); return VGA_ERR_ARGUMENT; }
-    if (h->looping) { set_error("looping HCA encode is not implemented on the device path yet"); return VGA_ERR_INVALID_OP; }
     // fewer bits than sync + noise level + checksum + one 3-bit channel header each: the reference's
     // CalculateNoiseLevel necessarily ends in InvalidDataException (CriHcaEncoder.cs:469-472)
     if (h->channel_count >= 1 && h->channel_count <= 8 && h->frame_size * 8 < 48 + 3 * h->channel_count + 16) {
@@ -268,9 +267,25 @@ int vga_hca_encode_device(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch
         set_error("bad sizes / pitches for vga_hca_encode_device");
         return VGA_ERR_ARGUMENT;
     }
+    // the encoder's input stream (hca_device.hpp PcmMap), from the fields CriHcaEncoder.Initialize derived
+    hca::PcmMap m;
+    const int input_samples = h->frame_count * hca::SPF - h->inserted_samples - h->appended_samples;
+    const int pre = h->inserted_samples - hca::SPSF;
+    if (pre < 0 || h->sample_count < 0 || h->sample_count > pcm_length || input_samples < h->sample_count) {
+        set_error("HcaInfo does not describe this PCM (sample count %d of %d, inserted %d, appended %d)", h->sample_count,
+                  pcm_length, h->inserted_samples, h->appended_samples);
+        return VGA_ERR_ARGUMENT;
+    }
+    m.zero_pre = pre > hca::SPF ? (divide_by_round_up(pre, hca::SPF) - 1) * hca::SPF : 0;
+    m.pre_end = pre;
+    m.main_end = pre + h->sample_count;
+    m.post_end = m.main_end + (h->looping ? input_samples - h->sample_count : 0);   // not looping: _postAudio is all zero
+    m.loop_start = h->loop_start_frame * hca::SPF + h->pre_loop_samples - h->inserted_samples;
+    m.last_chunk = h->sample_count > 0 ? (h->sample_count - 1) / hca::SPF : 0;
+    m.raw_len = pcm_length;
     const uint16_t *pow = nullptr;
     if (int rc = crc_pow_table(&pow)) return rc;
-    return hca::launch_encode(d_pcm, stream_pitch, ch_pitch, nstreams, pcm_length, d, d_frames, frames_pitch, pow,
+    return hca::launch_encode(d_pcm, stream_pitch, ch_pitch, nstreams, m, d, d_frames, frames_pitch, pow,
                               d_status, (hipStream_t)stream);
 }
 

@@ -29,6 +29,35 @@ struct DeviceInfo {
     uint8_t ath_curve[128];
 };
 
+// The encoder's input stream as CriHcaEncoder.Encode assembles it in its 1024-sample buffer
+// (VGAudio/Codecs/CriHca/CriHcaEncoder.cs:170-254): [frames of the cleared buffer][copies of sample 0]
+// [the PCM up to HcaInfo.SampleCount][loop audio replayed from the loop start][zeros].  Stream index u
+// (0 = first sample of frame 0's buffer) -> raw sample index or "zero".
+struct PcmMap {
+    int zero_pre;    // u < zero_pre: whole pre-audio frames, encoded from the cleared buffer (:175-180)
+    int pre_end;     // u < pre_end: pcm[0] (:182-188); pre_end = InsertedSamples - 128
+    int main_end;    // u < main_end: pcm[u - pre_end] (:192-207)
+    int post_end;    // u < post_end: _postAudio[u - main_end] (:209-232), else 0 (:234-240)
+    int loop_start;  // raw index _postAudio was saved from (SaveLoopAudio :244-254)
+    int last_chunk;  // index of the last 1024-sample chunk CriHcaFormat.EncodeFromPcm16 feeds (:52-68)
+    int raw_len;     // samples per channel in the caller's PCM
+};
+
+__device__ __forceinline__ int16_t fetch_pcm(const PcmMap &m, const int16_t *__restrict__ src, int64_t u)
+{
+    if (u < m.zero_pre || u >= m.post_end) return 0;      // also u < 0: the MDCT starts from a cleared state
+    if (u < m.pre_end) return m.raw_len > 0 ? src[0] : (int16_t)0;
+    if (u < m.main_end) return src[u - m.pre_end];
+    // _postAudio[k] was copied from the caller's chunk buffer while chunks 0..last_chunk went by; a chunk
+    // the PCM does not fill keeps the previous chunk's samples in its tail (the reference reuses one
+    // buffer, CriHcaFormat.cs:50-56), and what no chunk reached stays 0
+    const int a = m.loop_start + (int)(u - m.main_end);
+    const int chunk = a >> 10;
+    if (a < 0 || chunk > m.last_chunk) return 0;
+    if (a < m.raw_len) return src[a];
+    return chunk >= 1 ? src[a - 1024] : (int16_t)0;
+}
+
 __device__ __forceinline__ double f64_bits(uint64_t b) { return __longlong_as_double((long long)b); }
 
 // sqrt(2.0 / 128) (CriHcaChannel.cs:19): exactly 0.125

@@ -48,7 +48,7 @@ __device__ __forceinline__ unsigned gf_mul(unsigned a, unsigned b)
 }
 
 __global__ __launch_bounds__(256) void hca_encode_kernel(
-    const int16_t *__restrict__ pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, int pcm_length,
+    const int16_t *__restrict__ pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, PcmMap map,
     DeviceInfo info, uint8_t *__restrict__ frames, int64_t frames_pitch, const uint16_t *__restrict__ crc_pow,
     int *__restrict__ status)
 {
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
         const int16_t *src = pcm + (int64_t)stream * stream_pitch + (int64_t)c * ch_pitch;
         for (int i = tid; i < 9 * 128; i += 256) {
             const int64_t pos = (int64_t)frame * SPF - SPSF + i;
-            xin[i] = (pos >= 0 && pos < pcm_length) ? src[pos] : (int16_t)0;
+            xin[i] = fetch_pcm(map, src, pos);
         }
         __syncthreads();
         {
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     }
 }
 
-int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, int pcm_length,
+int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, const PcmMap &map,
                   const DeviceInfo &info, uint8_t *d_frames, int64_t frames_pitch, const uint16_t *d_crc_pow,
                   int *d_status, hipStream_t stream)
 {
@@ -506,7 +506,7 @@ int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, 
         VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hca_encode_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(hca_encode_kernel, dim3((unsigned)((int64_t)nstreams * info.frame_count)), dim3(256), lds, stream,
-                       d_pcm, stream_pitch, ch_pitch, nstreams, pcm_length, info, d_frames, frames_pitch, d_crc_pow,
+                       d_pcm, stream_pitch, ch_pitch, nstreams, map, info, d_frames, frames_pitch, d_crc_pow,
                        d_status);
     VGA_HIP_TRY(hipGetLastError());
     return VGA_OK;

@@ -18,7 +18,7 @@ int launch_decode(const uint8_t *d_frames, int64_t frames_pitch, int nstreams, c
                   int64_t stream_pitch, int64_t ch_pitch, void *d_workspace, int *d_status, hipStream_t stream);
 
 // d_crc_pow: uint16[4096], x^(8k) mod 0x18005 (built by the host)
-int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, int pcm_length,
+int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, const PcmMap &map,
                   const DeviceInfo &info, uint8_t *d_frames, int64_t frames_pitch, const uint16_t *d_crc_pow,
                   int *d_status, hipStream_t stream);
 

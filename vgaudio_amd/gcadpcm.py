@@ -169,6 +169,22 @@ class Pcm16Format:
     def ChannelCount(self):
         return len(self.Channels)
 
+    def WithLoop(self, loop, loopStart=None, loopEnd=None):
+        """AudioFormatBaseBuilder.WithLoop (Formats/AudioFormatBaseBuilder.cs:23-58), applied in place."""
+        if not loop:
+            self.Looping, self.LoopStart, self.LoopEnd = False, 0, 0
+            return self
+        if loopStart is None and loopEnd is None:
+            loopStart, loopEnd = 0, self.SampleCount
+        if loopStart < 0 or loopStart > self.SampleCount:
+            raise _lib.ArgumentOutOfRangeError("Loop points must be less than the number of samples and non-negative.")
+        if loopEnd < 0 or loopEnd > self.SampleCount:
+            raise _lib.ArgumentOutOfRangeError("Loop points must be less than the number of samples and non-negative.")
+        if loopEnd < loopStart:
+            raise _lib.ArgumentOutOfRangeError("The loop end must be greater than the loop start")
+        self.Looping, self.LoopStart, self.LoopEnd = True, loopStart, loopEnd
+        return self
+
 
 class GcAdpcmChannel:
     def __init__(self, adpcm, coefs, sampleCount):
