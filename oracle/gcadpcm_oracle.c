@@ -634,6 +634,142 @@ void vgo_gc_create_seek_table(const int16_t *pcm, int n, int samples_per_entry, 
     }
 }
 
+/* ---------------- channel metadata (Formats/GcAdpcm) ---------------- */
+static int get_next_multiple_i(int value, int multiple)      /* Utilities/Helpers.cs:71-80 */
+{
+    if (multiple <= 0) return value;
+    if (value % multiple == 0) return value;
+    return value + multiple - value % multiple;
+}
+
+/* Utilities/Helpers.cs:82-83 */
+static int loop_points_are_aligned(int loop_start, int multiple)
+{
+    return !(multiple != 0 && loop_start % multiple != 0);
+}
+
+int vgo_gc_channel_layout_for(const vgo_gc_channel_params *p, vgo_gc_channel_layout *out)
+{
+    memset(out, 0, sizeof *out);
+    out->alignment_needed = !loop_points_are_aligned(p->loop_start, p->loop_alignment_multiple);
+    out->loop_start_aligned = p->loop_start;
+    out->sample_count_aligned = p->sample_count;
+    if (out->alignment_needed) {                                 /* GcAdpcmAlignment.cs:29-31 */
+        out->loop_start_aligned = get_next_multiple_i(p->loop_start, p->loop_alignment_multiple);
+        out->sample_count_aligned = p->loop_end + (out->loop_start_aligned - p->loop_start);
+    }
+    if (p->samples_per_seek_table_entry != 0)                    /* GcAdpcmSeekTable.cs:27 */
+        out->seek_table_entries = divide_by_round_up(out->sample_count_aligned, p->samples_per_seek_table_entry);
+    return 0;
+}
+
+/* GcAdpcmAlignment.cs:20-63 */
+int vgo_gc_alignment(int multiple, int loop_start, int loop_end, const uint8_t *adpcm, const int16_t coefs[16],
+                     vgo_gc_channel_layout *L, uint8_t *adpcm_aligned, int16_t *pcm_aligned)
+{
+    vgo_gc_channel_params p = {loop_end, 1, loop_start, loop_end, multiple, 0};
+    vgo_gc_channel_layout_for(&p, L);
+    if (!L->alignment_needed) return 0;
+
+    int loop_length = loop_end - loop_start;
+    int sample_count_aligned = L->sample_count_aligned;
+    int frames_to_keep = loop_end / SAMPLES_PER_FRAME;
+    int bytes_to_keep = frames_to_keep * BYTES_PER_FRAME;
+    int samples_to_keep = frames_to_keep * SAMPLES_PER_FRAME;
+    int samples_to_encode = sample_count_aligned - samples_to_keep;
+    if (loop_length <= 0 && loop_end - samples_to_keep < samples_to_encode) return -4;   /* :47 would spin */
+
+    int16_t *old_pcm = (int16_t *)calloc((size_t)(loop_end > 0 ? loop_end : 1), sizeof(int16_t));
+    vgo_gc_decode(adpcm, coefs, loop_end, 0, 0, old_pcm);                       /* :41-42 */
+    memcpy(pcm_aligned, old_pcm, (size_t)loop_end * sizeof(int16_t));           /* :43 */
+    int16_t *new_pcm = (int16_t *)calloc((size_t)(samples_to_encode > 0 ? samples_to_encode : 1), sizeof(int16_t));
+    memcpy(new_pcm, old_pcm + samples_to_keep, (size_t)(loop_end - samples_to_keep) * sizeof(int16_t));   /* :46 */
+    for (int cur = loop_end - samples_to_keep; cur < samples_to_encode; cur += loop_length) {              /* :48-51 */
+        int len = samples_to_encode - cur < loop_length ? samples_to_encode - cur : loop_length;
+        memcpy(new_pcm + cur, pcm_aligned + loop_start, (size_t)len * sizeof(int16_t));
+    }
+    int16_t h1 = samples_to_keep < 1 ? 0 : old_pcm[samples_to_keep - 1];       /* :54-55 */
+    int16_t h2 = samples_to_keep < 2 ? 0 : old_pcm[samples_to_keep - 2];
+
+    int new_bytes = vgo_gc_sample_count_to_byte_count(samples_to_encode);
+    uint8_t *new_adpcm = (uint8_t *)calloc((size_t)(new_bytes > 0 ? new_bytes : 1), 1);
+    vgo_gc_encode(new_pcm, samples_to_encode, coefs, samples_to_encode, h1, h2, new_adpcm);   /* :57 */
+    memcpy(adpcm_aligned, adpcm, (size_t)bytes_to_keep);                                       /* :58 */
+    memcpy(adpcm_aligned + bytes_to_keep, new_adpcm, (size_t)new_bytes);                       /* :59 */
+
+    int16_t *decoded = (int16_t *)calloc((size_t)(samples_to_encode > 0 ? samples_to_encode : 1), sizeof(int16_t));
+    vgo_gc_decode(new_adpcm, coefs, samples_to_encode, h1, h2, decoded);                       /* :61 */
+    memcpy(pcm_aligned + samples_to_keep, decoded, (size_t)samples_to_encode * sizeof(int16_t));   /* :62 */
+    free(old_pcm); free(new_pcm); free(new_adpcm); free(decoded);
+    return 0;
+}
+
+/* GcAdpcmLoopContext.cs:17-26, GcAdpcmDecoder.GetPredictorScale (GcAdpcmDecoder.cs:56-59) */
+void vgo_gc_loop_context(const uint8_t *adpcm, const int16_t *pcm, int loop_start, int16_t out[3])
+{
+    out[0] = (int16_t)adpcm[loop_start / SAMPLES_PER_FRAME * BYTES_PER_FRAME];
+    out[1] = loop_start < 1 ? 0 : (pcm ? pcm[loop_start - 1] : 0);
+    out[2] = loop_start < 2 ? 0 : (pcm ? pcm[loop_start - 2] : 0);
+}
+
+/* GcAdpcmChannel.cs:31-55 with GcAdpcmChannelBuilder.cs:148-202 for a channel that has no previous
+ * alignment / loop context / seek table (GetCloneBuilder of a 3-argument GcAdpcmChannel, :62-95) */
+int vgo_gc_build_channel(const uint8_t *adpcm, const int16_t coefs[16], const vgo_gc_channel_params *p,
+                         vgo_gc_channel_layout *layout_out, uint8_t *adpcm_out, int16_t *pcm_out,
+                         int16_t *seek_table_out, int16_t loop_context_out[3])
+{
+    vgo_gc_channel_layout L;
+    vgo_gc_channel_layout_for(p, &L);
+    if (layout_out) *layout_out = L;
+    int rc = 0;
+    int nbytes = vgo_gc_sample_count_to_byte_count(L.sample_count_aligned);
+    uint8_t *aligned_adpcm = (uint8_t *)calloc((size_t)(nbytes > 0 ? nbytes : 1), 1);
+    int16_t *aligned_pcm = (int16_t *)calloc((size_t)(L.sample_count_aligned > 0 ? L.sample_count_aligned : 1), sizeof(int16_t));
+    int have_pcm = 0;
+    if (L.alignment_needed) {                                    /* GetAlignment :148-165 */
+        vgo_gc_channel_layout tmp;
+        rc = vgo_gc_alignment(p->loop_alignment_multiple, p->loop_start, p->loop_end, adpcm, coefs, &tmp, aligned_adpcm,
+                              aligned_pcm);
+        have_pcm = 1;
+    } else {
+        memcpy(aligned_adpcm, adpcm, (size_t)nbytes);
+    }
+    if (!rc) {
+        /* GetLoopContext :167-181: LoopContextStart defaults to 0, so a loop start of 0 takes the
+         * "current loop context is valid" branch and yields the default context (0, 0, 0) */
+        int16_t ctx[3] = {0, 0, 0};
+        if (L.loop_start_aligned != 0) {
+            if (!have_pcm) {                                     /* EnsurePcmDecoded :202 */
+                vgo_gc_decode(aligned_adpcm, coefs, L.sample_count_aligned, 0, 0, aligned_pcm);
+                have_pcm = 1;
+            }
+            /* :179 passes Adpcm (the ORIGINAL stream), AlignedPcm, AlignedLoopStart */
+            if (L.loop_start_aligned / SAMPLES_PER_FRAME * BYTES_PER_FRAME >= vgo_gc_sample_count_to_byte_count(p->sample_count))
+                rc = -2;
+            else
+                vgo_gc_loop_context(adpcm, aligned_pcm, L.loop_start_aligned, ctx);
+        }
+        if (loop_context_out) memcpy(loop_context_out, ctx, sizeof ctx);
+    }
+    if (!rc && p->samples_per_seek_table_entry != 0) {           /* GetSeekTable :183-200 */
+        if (!have_pcm) {
+            vgo_gc_decode(aligned_adpcm, coefs, L.sample_count_aligned, 0, 0, aligned_pcm);
+            have_pcm = 1;
+        }
+        if (seek_table_out)
+            vgo_gc_create_seek_table(aligned_pcm, L.sample_count_aligned, p->samples_per_seek_table_entry, seek_table_out);
+    }
+    if (!rc) {
+        if (adpcm_out) memcpy(adpcm_out, aligned_adpcm, (size_t)nbytes);
+        if (pcm_out) {                                           /* GetPcmAudio (GcAdpcmChannel.cs:57-60) */
+            if (!have_pcm) vgo_gc_decode(aligned_adpcm, coefs, L.sample_count_aligned, 0, 0, aligned_pcm);
+            memcpy(pcm_out, aligned_pcm, (size_t)L.sample_count_aligned * sizeof(int16_t));
+        }
+    }
+    free(aligned_adpcm); free(aligned_pcm);
+    return rc;
+}
+
 /* ---------------- batch drivers (GcAdpcmFormat.cs:58-74,129-135; :42-54) ---------------- */
 typedef struct {
     const int16_t *pcm; long pitch; int nch; int n;

@@ -58,6 +58,41 @@ void vgo_gc_encode_batch(const int16_t *pcm, long pitch, int nch, int sample_cou
 void vgo_gc_decode_batch(const uint8_t *adpcm, long in_pitch, const int16_t *coefs, int nch,
                          int sample_count, int16_t *pcm_out, long out_pitch, int threads);
 
+/* ---- GC-ADPCM channel metadata: what GcAdpcmChannelBuilder derives when a channel is built
+ * (Formats/GcAdpcm/GcAdpcmChannelBuilder.cs:148-202), SURVEY.md 8f rank 1 ---- */
+typedef struct {
+    int sample_count;                   /* GcAdpcmChannelBuilder.SampleCount (unaligned) */
+    int looping, loop_start, loop_end;  /* WithLoop; not looping -> 0, 0 (:103-120) */
+    int loop_alignment_multiple;        /* WithLoopAlignment (:64-68); 0 = none */
+    int samples_per_seek_table_entry;   /* WithSamplesPerSeekTableEntry (:78-87); 0 = no seek table */
+} vgo_gc_channel_params;
+typedef struct {
+    int alignment_needed;               /* GcAdpcmAlignment.AlignmentNeeded (GcAdpcmAlignment.cs:25) */
+    int loop_start_aligned;             /* LoopStartAligned, or loop_start when no alignment is needed */
+    int sample_count_aligned;           /* SampleCountAligned, or sample_count */
+    int seek_table_entries;             /* DivideByRoundUp(pcm length, samples per entry), or 0 */
+} vgo_gc_channel_layout;
+/* size math only; returns 0 */
+int vgo_gc_channel_layout_for(const vgo_gc_channel_params *p, vgo_gc_channel_layout *out);
+/* GcAdpcmAlignment ctor (GcAdpcmAlignment.cs:20-63).  adpcm_aligned_out: SampleCountToByteCount(
+ * sample_count_aligned) bytes, pcm_aligned_out: sample_count_aligned shorts (only written when
+ * alignment is needed).  Returns 0; -4 when loop_start == loop_end needs alignment (the reference's
+ * fill loop `currentSample += loopLength` never ends). */
+int vgo_gc_alignment(int multiple, int loop_start, int loop_end, const uint8_t *adpcm, const int16_t coefs[16],
+                     vgo_gc_channel_layout *layout, uint8_t *adpcm_aligned_out, int16_t *pcm_aligned_out);
+/* GcAdpcmLoopContext(byte[] adpcm, short[] pcm, int loopStart) (GcAdpcmLoopContext.cs:17-26): out = pred/scale
+ * byte, hist1, hist2.  pcm may be NULL (hist 0). */
+void vgo_gc_loop_context(const uint8_t *adpcm, const int16_t *pcm, int loop_start, int16_t out[3]);
+/* GcAdpcmChannel(GcAdpcmChannelBuilder) for a freshly encoded channel (GcAdpcmChannel.cs:31-55 ->
+ * GetAlignment / GetLoopContext / GetSeekTable, no previous caches).  Outputs sized by
+ * vgo_gc_channel_layout_for; any of them may be NULL.  adpcm_out / pcm_out receive GetAdpcmAudio() /
+ * the decoded PCM the builder ends up holding (aligned or not).  Returns 0, -4 (see vgo_gc_alignment)
+ * or -2 when the loop context's pred/scale byte lies past the ORIGINAL adpcm array (the reference
+ * reads b.Adpcm, not the aligned copy, :179 -- IndexOutOfRangeException). */
+int vgo_gc_build_channel(const uint8_t *adpcm, const int16_t coefs[16], const vgo_gc_channel_params *p,
+                         vgo_gc_channel_layout *layout_out, uint8_t *adpcm_out, int16_t *pcm_out,
+                         int16_t *seek_table_out, int16_t loop_context_out[3]);
+
 /* Formats/GcAdpcm/GcAdpcmSeekTable.cs:25-38 (CreateSeekTable).
  * table_out holds 2*ceil(n/samples_per_entry) shorts. */
 void vgo_gc_create_seek_table(const int16_t *pcm, int n, int samples_per_entry, int16_t *table_out);

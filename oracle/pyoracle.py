@@ -200,6 +200,78 @@ def gc_create_seek_table(pcm, samples_per_entry):
     return out
 
 
+class GcChannelParams(C.Structure):
+    """vgo_gc_channel_params"""
+    _fields_ = [(n, C.c_int) for n in ("sample_count", "looping", "loop_start", "loop_end", "loop_alignment_multiple",
+                                       "samples_per_seek_table_entry")]
+
+
+class GcChannelLayout(C.Structure):
+    """vgo_gc_channel_layout"""
+    _fields_ = [(n, C.c_int) for n in ("alignment_needed", "loop_start_aligned", "sample_count_aligned",
+                                       "seek_table_entries")]
+
+
+def gc_channel_params(sample_count, looping=False, loop_start=0, loop_end=0, alignment=0, samples_per_entry=0):
+    if not looping:
+        loop_start = loop_end = 0                  # GcAdpcmChannelBuilder.WithLoop(false) (:113-119)
+    return GcChannelParams(sample_count, int(looping), loop_start, loop_end, alignment, samples_per_entry)
+
+
+def gc_channel_layout(p):
+    L = GcChannelLayout()
+    lib().vgo_gc_channel_layout_for.argtypes = [C.POINTER(GcChannelParams), C.POINTER(GcChannelLayout)]
+    lib().vgo_gc_channel_layout_for(C.byref(p), C.byref(L))
+    return L
+
+
+def gc_alignment(multiple, loop_start, loop_end, adpcm, coefs):
+    """GcAdpcmAlignment ctor -> (rc, layout, adpcm_aligned, pcm_aligned)"""
+    adpcm = np.ascontiguousarray(adpcm, dtype=np.uint8)
+    coefs = np.ascontiguousarray(coefs, dtype=np.int16)
+    L = gc_channel_layout(GcChannelParams(loop_end, 1, loop_start, loop_end, multiple, 0))
+    out = np.zeros(max(gc_sample_count_to_byte_count(L.sample_count_aligned), 1), dtype=np.uint8)
+    pcm = np.zeros(max(L.sample_count_aligned, 1), dtype=np.int16)
+    f = lib().vgo_gc_alignment
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.POINTER(GcChannelLayout),
+                  C.POINTER(C.c_uint8), C.POINTER(C.c_int16)]
+    rc = f(multiple, loop_start, loop_end, _u8(adpcm), _i16(coefs), C.byref(L), _u8(out), _i16(pcm))
+    return rc, L, out[:gc_sample_count_to_byte_count(L.sample_count_aligned)], pcm[:L.sample_count_aligned]
+
+
+def gc_loop_context(adpcm, pcm, loop_start):
+    adpcm = np.ascontiguousarray(adpcm, dtype=np.uint8)
+    out = np.zeros(3, dtype=np.int16)
+    f = lib().vgo_gc_loop_context
+    f.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16)]
+    f.restype = None
+    if pcm is None:
+        f(_u8(adpcm), None, loop_start, _i16(out))
+    else:
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        f(_u8(adpcm), _i16(pcm), loop_start, _i16(out))
+    return out
+
+
+def gc_build_channel(adpcm, coefs, p):
+    """GcAdpcmChannel(builder) for a fresh channel -> (rc, layout, adpcm, pcm, seek_table, loop_context)"""
+    adpcm = np.ascontiguousarray(adpcm, dtype=np.uint8)
+    coefs = np.ascontiguousarray(coefs, dtype=np.int16)
+    L = gc_channel_layout(p)
+    a = np.zeros(max(gc_sample_count_to_byte_count(L.sample_count_aligned), 1), dtype=np.uint8)
+    pcm = np.zeros(max(L.sample_count_aligned, 1), dtype=np.int16)
+    seek = np.zeros(max(L.seek_table_entries * 2, 1), dtype=np.int16)
+    ctx = np.zeros(3, dtype=np.int16)
+    f = lib().vgo_gc_build_channel
+    f.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.POINTER(GcChannelParams), C.POINTER(GcChannelLayout),
+                  C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.POINTER(C.c_int16), C.POINTER(C.c_int16)]
+    rc = f(_u8(adpcm), _i16(coefs), C.byref(p), C.byref(L), _u8(a), _i16(pcm), _i16(seek), _i16(ctx))
+    return (rc, L, a[:gc_sample_count_to_byte_count(L.sample_count_aligned)], pcm[:L.sample_count_aligned],
+            seek[:L.seek_table_entries * 2], ctx)
+
+
+
+
 # ---------------- ADX ----------------
 def adx_params(**kw):
     p = AdxParams()
