@@ -129,6 +129,51 @@ int vga_gcadpcm_decode_device(const uint8_t *d_adpcm, int64_t adpcm_pitch, const
                               int nch, int sample_count, const int16_t *d_hist1, const int16_t *d_hist2,
                               int16_t *d_pcm, int64_t pcm_pitch, int *d_status, void *stream);
 
+/* ----------------------------------------------------------------------
+ * GC-ADPCM channel metadata: what the reference derives when a channel is
+ * built after encoding -- GcAdpcmChannel(GcAdpcmChannelBuilder), VGAudio/Formats/GcAdpcm/
+ * GcAdpcmChannel.cs:31-55 -> GcAdpcmChannelBuilder.GetAlignment / GetLoopContext / GetSeekTable
+ * (GcAdpcmChannelBuilder.cs:148-202).  One loop per batch: GcAdpcmFormat applies its loop to every
+ * channel (GcAdpcmFormat.cs:27-40).
+ * -------------------------------------------------------------------- */
+typedef struct {
+    int sample_count;                  /* GcAdpcmChannelBuilder.SampleCount (unaligned) */
+    int looping, loop_start, loop_end; /* WithLoop (:103-120); not looping: pass 0, 0 */
+    int loop_alignment_multiple;       /* WithLoopAlignment (:64-68); 0 = none */
+    int samples_per_seek_table_entry;  /* WithSamplesPerSeekTableEntry (:78-87); 0 = no seek table */
+} vga_gcadpcm_channel_params;
+typedef struct {
+    int alignment_needed;              /* GcAdpcmAlignment.AlignmentNeeded (GcAdpcmAlignment.cs:25) */
+    int loop_start_aligned;            /* LoopStartAligned (:30), or loop_start */
+    int sample_count_aligned;          /* SampleCountAligned (:31), or sample_count: GcAdpcmChannel.SampleCount */
+    int seek_table_entries;            /* GcAdpcmSeekTable.cs:27; the table holds 2 shorts per entry */
+} vga_gcadpcm_channel_layout;
+/* size math only (no device needed); VGA_ERR_OUT_OF_RANGE for negative / inverted loop points */
+int vga_gcadpcm_channel_layout_for(const vga_gcadpcm_channel_params *p, vga_gcadpcm_channel_layout *out);
+/* adpcm[c]: SampleCountToByteCount(sample_count) bytes; coefs: nch*16.  Outputs (each may be NULL):
+ *   adpcm_out[c]       SampleCountToByteCount(sample_count_aligned) bytes = GetAdpcmAudio()
+ *                      (required when the loop needs alignment: GcAdpcmAlignment.cs:20-63 re-encodes the tail
+ *                      from the wrapped loop with the history of the last kept frame);
+ *   pcm_out[c]         sample_count_aligned shorts = the decoded PCM the builder ends up holding;
+ *   seek_table_out[c]  2*seek_table_entries shorts (GcAdpcmSeekTable.cs:25-38);
+ *   loop_context_out   nch*3 shorts: pred/scale byte, hist1, hist2 (GcAdpcmLoopContext.cs:17-26; a loop
+ *                      start of 0 yields the default (0,0,0) like the reference, whose builder considers
+ *                      the unset context valid for LoopContextStart == 0, GcAdpcmChannelBuilder.cs:135-137).
+ * VGA_ERR_INVALID_OP: zero-length loop that needs alignment (the reference never returns);
+ * VGA_ERR_OUT_OF_RANGE: aligned loop start past the ORIGINAL data (the reference indexes b.Adpcm, :179). */
+int vga_gcadpcm_build_channels_batch(const uint8_t *const *adpcm, const int16_t *coefs, int nch,
+                                     const vga_gcadpcm_channel_params *p, uint8_t *const *adpcm_out,
+                                     int16_t *const *pcm_out, int16_t *const *seek_table_out,
+                                     int16_t *loop_context_out);
+/* device-resident variant: layouts as vga_gcadpcm_encode_device / decode_device; seek_pitch in shorts;
+ * d_workspace: 16-byte aligned, vga_gcadpcm_build_channels_workspace_bytes(nch, p) bytes. */
+size_t vga_gcadpcm_build_channels_workspace_bytes(int nch, const vga_gcadpcm_channel_params *p);
+int vga_gcadpcm_build_channels_device(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs, int nch,
+                                      const vga_gcadpcm_channel_params *p, uint8_t *d_adpcm_out, int64_t out_pitch,
+                                      int16_t *d_pcm_out, int64_t pcm_pitch, int16_t *d_seek_out, int64_t seek_pitch,
+                                      int16_t *d_loop_context_out, void *d_workspace, size_t workspace_bytes,
+                                      void *stream);
+
 /* ======================================================================
  * CRI ADX
  * ====================================================================== */

@@ -147,8 +147,8 @@ def test_decode_matches_oracle_random_bitstreams():
 def test_build_seek_table_kats(starts, entries, expected, big_endian):
     # Tests/Formats/GcAdpcmFormatTests.cs:92-158
     pcm = [(np.arange(112) + 1 + s).astype(np.int16) for s in starts]
-    adpcm = GcAdpcmFormat().EncodeFromPcm16(Pcm16Format(pcm, 48000))
-    table = adpcm.BuildSeekTable(entries, 50, big_endian)
+    adpcm = GcAdpcmFormat().EncodeFromPcm16(Pcm16Format(pcm, 48000)).WithSamplesPerSeekTableEntry(50)
+    table = adpcm.BuildSeekTable(entries, big_endian)
     want = np.array(expected, dtype=np.int16).astype(">i2" if big_endian else "<i2").tobytes()
     assert table == want
 
@@ -246,3 +246,74 @@ def test_full_size_channels_sampled_against_oracle():
         wc = po.gc_calculate_coefficients(host)
         assert coefs[c].cpu().numpy().tolist() == wc.tolist()
         assert (adpcm[c, :nb].cpu().numpy() == po.gc_encode(host, wc)).all()
+
+
+# ---- channel metadata: alignment re-encode, loop context, seek table ----
+@pytest.mark.parametrize("n,loop,alignment,spe", [
+    (3000, None, 0, 0),                      # nothing to derive
+    (3000, None, 0, 1000),                   # seek table only (container writers)
+    (3000, (0, 3000), 0, 0x200),             # loop from 0: default loop context (reference quirk)
+    (3000, (100, 2900), 0, 0),               # loop context from the decoded PCM
+    (3000, (100, 2900), 1000, 0x200),        # alignment: loop 100..2900 -> 1000..3800
+    (20000, (2800, 2990), 0x3800, 0x3800),   # short loop wrapped ~60 times, BRSTM-sized alignment
+    (3000, (15, 29), 14, 7),                 # frame-sized pieces
+    (20000, (1, 19999), 2, 0),               # one sample of shift: almost everything is kept
+    (6000, (4999, 5000), 64, 100),           # one-sample loop
+    (14 * 300, (14 * 100, 14 * 300), 14, 14)])  # aligned already
+def test_build_channels_matches_oracle(n, loop, alignment, spe):
+    from vgaudio_amd.gcadpcm import build_channels
+    nch = 5
+    pcm = synth.generate(nch, n)
+    fmt = GcAdpcmFormat().EncodeFromPcm16(Pcm16Format(list(pcm), 48000))
+    looping = loop is not None
+    ls, le = loop if looping else (0, 0)
+    built = build_channels(fmt.Channels, looping, ls, le, alignment, spe, keepPcm=True)
+    p = po.gc_channel_params(n, looping, ls, le, alignment, spe)
+    for c in range(nch):
+        rc, L, want_adpcm, want_pcm, want_seek, want_ctx = po.gc_build_channel(fmt.Channels[c].Adpcm, fmt.Channels[c].Coefs, p)
+        assert rc == 0
+        ch = built[c]
+        assert ch.SampleCount == L.sample_count_aligned and ch.AlignmentNeeded == bool(L.alignment_needed)
+        assert (ch.GetAdpcmAudio() == want_adpcm).all(), c
+        assert (ch.GetPcmAudio() == want_pcm).all(), (c, int(np.argmax(ch.GetPcmAudio() != want_pcm)))
+        assert (ch.GetSeekTable() == want_seek).all(), c
+        assert [ch.LoopContext.PredScale, ch.LoopContext.Hist1, ch.LoopContext.Hist2] == want_ctx.tolist(), c
+
+
+def test_format_loop_alignment_properties_and_errors():
+    from vgaudio_amd import _lib
+    pcm = synth.generate(2, 3000)
+    p16 = Pcm16Format(list(pcm), 48000).WithLoop(True, 100, 2900)
+    fmt = GcAdpcmFormat().EncodeFromPcm16(p16)
+    assert (fmt.Looping, fmt.LoopStart, fmt.LoopEnd, fmt.SampleCount) == (True, 100, 2900, 3000)
+    al = fmt.WithAlignment(1000)                                       # GcAdpcmFormat.cs:19-22, :124-126
+    assert (al.LoopStart, al.LoopEnd, al.SampleCount) == (1000, 3800, 3800)
+    assert all(c.SampleCount == 3800 and len(c.GetAdpcmAudio()) == GcAdpcmMath.SampleCountToByteCount(3800) for c in al.Channels)
+    back = al.ToPcm16()
+    assert (back.Looping, back.LoopStart, back.LoopEnd, back.SampleCount) == (True, 1000, 3800, 3800)
+    # the aligned stream decodes to the aligned PCM (GcAdpcmAlignmentTests.AlignedPcmIsCorrect)
+    want = GcAdpcmDecoder.Decode([c.GetAdpcmAudio() for c in al.Channels], np.stack([c.Coefs for c in al.Channels]),
+                                 GcAdpcmParameters(SampleCount=3800))
+    assert all((a == b).all() for a, b in zip(back.Channels, want))
+    with pytest.raises(_lib.InvalidOperationError):                    # the reference's fill loop never ends
+        fmt.WithLoop(True, 100, 100).WithAlignment(1000)
+    with pytest.raises(_lib.ArgumentOutOfRangeError):                  # pred/scale byte read past the original data
+        fmt.WithLoop(True, 2999, 3000).WithAlignment(0x3800)
+    with pytest.raises(_lib.ArgumentOutOfRangeError):
+        fmt.WithLoop(True, 10, 4000)
+
+
+def test_aligned_sine_kats_on_device():
+    """GcAdpcmAlignmentTests.cs:64-108 through the device path (period-56 sine, +-2)."""
+    from vgaudio_amd.gcadpcm import build_channels
+    for multiple, loop_start, cycles, tol in [(1000, 4524, 100, 2), (1000, 2012, 1, 2), (1000, 60, 1, 2), (1000, 60, 20, 2)]:
+        loop_end = cycles * 56 + loop_start
+        n = -(-loop_end // 14) * 14
+        pcm = synth.sine(n, 1, 56)
+        fmt = GcAdpcmFormat().EncodeFromPcm16(Pcm16Format([pcm], 48000))
+        ch = build_channels(fmt.Channels, True, loop_start, loop_end, multiple, loopContext=False)[0]
+        dec = GcAdpcmDecoder.Decode(ch.GetAdpcmAudio(), ch.Coefs, GcAdpcmParameters(SampleCount=ch.SampleCount))
+        assert (np.asarray(dec).reshape(-1) == ch.GetPcmAudio()).all()
+        want = synth.sine(ch.SampleCount, 1, 56)
+        end = -(-ch.SampleCount // 14) * 14 - 14
+        assert np.abs(want[56:end].astype(int) - ch.GetPcmAudio()[56:end].astype(int)).max() <= tol

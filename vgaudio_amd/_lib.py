@@ -90,6 +90,10 @@ SIGNATURES = {
     "vga_gcadpcm_encode_device": (ci, [vp, i64, ci, ci, vp, vp, vp, vp, i64, vp]),
     "vga_gcadpcm_decode_device": (ci, [vp, i64, vp, ci, ci, vp, vp, vp, i64, vp, vp]),
     "vga_synth_pcm16_device": (ci, [vp, i64, ci, ci, ci, vp, vp]),
+    "vga_gcadpcm_channel_layout_for": (ci, [vp, vp]),
+    "vga_gcadpcm_build_channels_batch": (ci, [u8pp, i16p, ci, vp, u8pp, i16pp, i16pp, i16p]),
+    "vga_gcadpcm_build_channels_workspace_bytes": (C.c_size_t, [ci, vp]),
+    "vga_gcadpcm_build_channels_device": (ci, [vp, i64, vp, ci, vp, vp, i64, vp, i64, vp, i64, vp, vp, C.c_size_t, vp]),
     "vga_adx_default_params": (None, [vp]),
     "vga_adx_calculate_coefficients": (ci, [ci, ci, i16p]),
     "vga_adx_nibble_count_to_sample_count": (ci, [ci, ci]),
@@ -107,6 +111,18 @@ SIGNATURES = {
     "vga_hca_encode_device": (ci, [vp, i64, i64, ci, ci, vp, vp, i64, vp, vp]),
     "vga_hca_decode_device": (ci, [vp, vp, i64, ci, vp, i64, i64, vp, C.c_size_t, vp, vp]),
 }
+
+
+class GcChannelParamsC(C.Structure):
+    """vga_gcadpcm_channel_params (include/vgaudio_hip.h)"""
+    _fields_ = [(n, C.c_int) for n in ("sample_count", "looping", "loop_start", "loop_end", "loop_alignment_multiple",
+                                       "samples_per_seek_table_entry")]
+
+
+class GcChannelLayoutC(C.Structure):
+    """vga_gcadpcm_channel_layout"""
+    _fields_ = [(n, C.c_int) for n in ("alignment_needed", "loop_start_aligned", "sample_count_aligned",
+                                       "seek_table_entries")]
 
 
 class HcaInfoC(C.Structure):

@@ -30,6 +30,7 @@ int require_device()
 
 // ---- GcAdpcmMath.cs:11-47 (host) ----
 static int divide_by2_round_up(int v) { return (v / 2) + (v & 1); }
+static int divide_by_round_up(int v, int d) { return v / d + (v % d != 0 ? 1 : 0); }   // Utilities/Extensions.cs:145
 
 }  // namespace vga
 
@@ -154,6 +155,142 @@ int vga_gcadpcm_decode_device(const uint8_t *d_adpcm, int64_t adpcm_pitch, const
         return rc;
     return gc::launch_decode(d_adpcm, adpcm_pitch, d_coefs, nch, sample_count, d_hist1, d_hist2, d_pcm, pcm_pitch,
                              d_status, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- channel metadata
+static int get_next_multiple(int value, int multiple)          // Utilities/Helpers.cs:71-80
+{
+    if (multiple <= 0) return value;
+    if (value % multiple == 0) return value;
+    return value + multiple - value % multiple;
+}
+
+int vga_gcadpcm_channel_layout_for(const vga_gcadpcm_channel_params *p, vga_gcadpcm_channel_layout *out)
+{
+    if (!p || !out) { set_error("null argument"); return VGA_ERR_ARGUMENT; }
+    if (p->sample_count < 0 || p->loop_start < 0 || p->loop_end < p->loop_start || p->loop_alignment_multiple < 0 ||
+        p->samples_per_seek_table_entry < 0) {
+        set_error("channel parameters out of range (samples %d, loop %d..%d, alignment %d, seek entry %d)", p->sample_count,
+                  p->loop_start, p->loop_end, p->loop_alignment_multiple, p->samples_per_seek_table_entry);
+        return VGA_ERR_OUT_OF_RANGE;
+    }
+    const int multiple = p->loop_alignment_multiple;
+    out->alignment_needed = (multiple != 0 && p->loop_start % multiple != 0) ? 1 : 0;    // Helpers.cs:82-83
+    out->loop_start_aligned = p->loop_start;
+    out->sample_count_aligned = p->sample_count;
+    if (out->alignment_needed) {                                                         // GcAdpcmAlignment.cs:29-31
+        const int64_t aligned = (int64_t)p->loop_start + multiple - p->loop_start % multiple;
+        const int64_t count = (int64_t)p->loop_end + (aligned - p->loop_start);
+        if (count > 0x7FFFFFFF - 16) { set_error("aligned sample count overflows"); return VGA_ERR_OUT_OF_RANGE; }
+        out->loop_start_aligned = get_next_multiple(p->loop_start, multiple);
+        out->sample_count_aligned = (int)count;
+    }
+    out->seek_table_entries = p->samples_per_seek_table_entry != 0                       // GcAdpcmSeekTable.cs:27
+        ? divide_by_round_up(out->sample_count_aligned, p->samples_per_seek_table_entry) : 0;
+    return VGA_OK;
+}
+
+size_t vga_gcadpcm_build_channels_workspace_bytes(int nch, const vga_gcadpcm_channel_params *p)
+{
+    vga_gcadpcm_channel_layout L;
+    if (nch <= 0 || vga_gcadpcm_channel_layout_for(p, &L) != VGA_OK) return 0;
+    // decoded PCM (caller may not want it) + the re-encode input + two history arrays + a status word
+    size_t bytes = (size_t)nch * (size_t)round_up(L.sample_count_aligned > 0 ? L.sample_count_aligned : 1, 8) * 2;
+    if (L.alignment_needed) {
+        const int keep = p->loop_end / 14 * 14;
+        bytes += (size_t)nch * (size_t)round_up(L.sample_count_aligned - keep + 1, 8) * 2;
+    }
+    return bytes + (size_t)round_up(nch * 2, 16) * 2 + 64;
+}
+
+int vga_gcadpcm_build_channels_device(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs, int nch,
+                                      const vga_gcadpcm_channel_params *p, uint8_t *d_adpcm_out, int64_t out_pitch,
+                                      int16_t *d_pcm_out, int64_t pcm_pitch, int16_t *d_seek_out, int64_t seek_pitch,
+                                      int16_t *d_loop_context_out, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    vga_gcadpcm_channel_layout L;
+    if (int rc = vga_gcadpcm_channel_layout_for(p, &L)) return rc;
+    if (nch < 0) { set_error("negative channel count"); return VGA_ERR_ARGUMENT; }
+    if (nch == 0) return VGA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int n_al = L.sample_count_aligned;
+    const int bytes_in = vga_gcadpcm_sample_count_to_byte_count(L.alignment_needed ? p->loop_end : p->sample_count);
+    const int bytes_al = vga_gcadpcm_sample_count_to_byte_count(n_al);
+    if (int rc = check_adpcm_layout(d_adpcm, adpcm_pitch, bytes_in, "vga_gcadpcm_build_channels_device (input)")) return rc;
+    if (L.alignment_needed && !d_adpcm_out) {
+        set_error("the loop needs alignment: adpcm_out is required");
+        return VGA_ERR_ARGUMENT;
+    }
+    if (d_adpcm_out)
+        if (int rc = check_adpcm_layout(d_adpcm_out, out_pitch, bytes_al, "vga_gcadpcm_build_channels_device (output)")) return rc;
+    if (d_pcm_out)
+        if (int rc = check_pcm_layout(d_pcm_out, pcm_pitch, n_al, "vga_gcadpcm_build_channels_device (pcm)")) return rc;
+    if (d_seek_out && seek_pitch < 2 * (int64_t)L.seek_table_entries) { set_error("seek table pitch too small"); return VGA_ERR_ARGUMENT; }
+    if (workspace_bytes < vga_gcadpcm_build_channels_workspace_bytes(nch, p) || !d_workspace || ((uintptr_t)d_workspace & 15)) {
+        set_error("workspace too small or not 16-byte aligned: need %zu bytes", vga_gcadpcm_build_channels_workspace_bytes(nch, p));
+        return VGA_ERR_ARGUMENT;
+    }
+    // the loop context reads the pred/scale byte from the ORIGINAL stream (GcAdpcmChannelBuilder.cs:179)
+    const bool want_ctx = d_loop_context_out != nullptr;
+    if (want_ctx && L.loop_start_aligned != 0 &&
+        L.loop_start_aligned / 14 * 8 >= vga_gcadpcm_sample_count_to_byte_count(p->sample_count)) {
+        set_error("loop context: the aligned loop start (%d) lies past the original ADPCM data (the reference reads "
+                  "Adpcm, not AlignedAdpcm: IndexOutOfRangeException)", L.loop_start_aligned);
+        return VGA_ERR_OUT_OF_RANGE;
+    }
+
+    // workspace carve-up
+    uint8_t *w = static_cast<uint8_t *>(d_workspace);
+    const int64_t ws_pcm_pitch = round_up(n_al > 0 ? n_al : 1, 8);
+    int16_t *pcm = d_pcm_out ? d_pcm_out : reinterpret_cast<int16_t *>(w);
+    const int64_t ppitch = d_pcm_out ? pcm_pitch : ws_pcm_pitch;
+    w += (size_t)nch * ws_pcm_pitch * 2;
+
+    const bool want_seek = d_seek_out && L.seek_table_entries > 0;
+    const bool ctx_needs_pcm = want_ctx && L.loop_start_aligned != 0;
+    if (L.alignment_needed) {                                   // GcAdpcmAlignment.cs:33-62
+        const int loop_start = p->loop_start, loop_end = p->loop_end;
+        const int frames_to_keep = loop_end / 14;
+        const int bytes_to_keep = frames_to_keep * 8, samples_to_keep = frames_to_keep * 14;
+        const int samples_to_encode = n_al - samples_to_keep;
+        if (loop_end - loop_start <= 0 && loop_end - samples_to_keep < samples_to_encode) {
+            set_error("a zero-length loop cannot be aligned (the reference's fill loop never ends, GcAdpcmAlignment.cs:48)");
+            return VGA_ERR_INVALID_OP;
+        }
+        const int64_t new_pitch = round_up(samples_to_encode + 1, 8);
+        int16_t *new_pcm = reinterpret_cast<int16_t *>(w);
+        w += (size_t)nch * new_pitch * 2;
+        int16_t *h1 = reinterpret_cast<int16_t *>(w);
+        int16_t *h2 = h1 + round_up(nch, 8);
+        // :41-43 oldPcm = Decode(adpcm, SampleCount = loopEnd) -> PcmAligned[0, loopEnd)
+        if (int rc = gc::launch_decode(d_adpcm, adpcm_pitch, d_coefs, nch, loop_end, nullptr, nullptr, pcm, ppitch, nullptr, st))
+            return rc;
+        // :44-55 the tail to encode: rest of the last kept-from frame, then the loop, wrapped
+        if (int rc = gc::launch_align_gather(pcm, ppitch, nch, loop_start, loop_end, samples_to_keep, samples_to_encode, new_pcm,
+                                             new_pitch, h1, h2, st))
+            return rc;
+        // :57-59 AdpcmAligned = kept frames + Encode(newPcm, history of the last kept sample)
+        if (bytes_to_keep > 0)
+            VGA_HIP_TRY(hipMemcpy2DAsync(d_adpcm_out, (size_t)out_pitch, d_adpcm, (size_t)adpcm_pitch, (size_t)bytes_to_keep,
+                                         (size_t)nch, hipMemcpyDeviceToDevice, st));
+        if (int rc = gc::launch_encode(new_pcm, new_pitch, nch, samples_to_encode, d_coefs, h1, h2, d_adpcm_out + bytes_to_keep,
+                                       out_pitch, st))
+            return rc;
+        // :61-62 PcmAligned[samplesToKeep..] = Decode(newAdpcm)
+        if (int rc = gc::launch_decode(d_adpcm_out + bytes_to_keep, out_pitch, d_coefs, nch, samples_to_encode, h1, h2,
+                                       pcm + samples_to_keep, ppitch, nullptr, st))
+            return rc;
+    } else {
+        if (d_adpcm_out && bytes_al > 0)
+            VGA_HIP_TRY(hipMemcpy2DAsync(d_adpcm_out, (size_t)out_pitch, d_adpcm, (size_t)adpcm_pitch, (size_t)bytes_al,
+                                         (size_t)nch, hipMemcpyDeviceToDevice, st));
+        if (d_pcm_out || want_seek || ctx_needs_pcm)            // EnsurePcmDecoded (GcAdpcmChannelBuilder.cs:202)
+            if (int rc = gc::launch_decode(d_adpcm, adpcm_pitch, d_coefs, nch, n_al, nullptr, nullptr, pcm, ppitch, nullptr, st))
+                return rc;
+    }
+    return gc::launch_channel_meta(d_adpcm, adpcm_pitch, pcm, ppitch, nch, L.loop_start_aligned, p->samples_per_seek_table_entry,
+                                   want_seek ? L.seek_table_entries : 0, want_seek ? d_seek_out : nullptr, seek_pitch,
+                                   d_loop_context_out, st);
 }
 
 int vga_synth_pcm16_device(int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, int first_channel,
@@ -342,6 +479,68 @@ int vga_gcadpcm_decode_batch(const uint8_t *const *adpcm, const int16_t *coefs, 
     }
     return VGA_OK;
 }
+
+// GcAdpcmChannel(GcAdpcmChannelBuilder) for a batch of freshly encoded channels that share one loop
+// (GcAdpcmFormat.cs:27-40): alignment re-encode, loop context, seek table.  Outputs may be null.
+int vga_gcadpcm_build_channels_batch(const uint8_t *const *adpcm, const int16_t *coefs, int nch,
+                                     const vga_gcadpcm_channel_params *p, uint8_t *const *adpcm_out,
+                                     int16_t *const *pcm_out, int16_t *const *seek_table_out, int16_t *loop_context_out)
+{
+    vga_gcadpcm_channel_layout L;
+    if (int rc = vga_gcadpcm_channel_layout_for(p, &L)) return rc;
+    if (int rc = check_ptrs((const void *const *)adpcm, nch, "adpcm")) return rc;
+    if (nch > 0 && !coefs) { set_error("null coefs"); return VGA_ERR_ARGUMENT; }
+    if (nch == 0) return VGA_OK;
+    if (L.alignment_needed && !adpcm_out) { set_error("the loop needs alignment: adpcm_out is required"); return VGA_ERR_ARGUMENT; }
+    if (adpcm_out) if (int rc = check_ptrs((const void *const *)adpcm_out, nch, "adpcm_out")) return rc;
+    if (pcm_out) if (int rc = check_ptrs((const void *const *)pcm_out, L.sample_count_aligned > 0 ? nch : 0, "pcm_out")) return rc;
+    if (seek_table_out && L.seek_table_entries > 0)
+        if (int rc = check_ptrs((const void *const *)seek_table_out, nch, "seek_table_out")) return rc;
+    if (int rc = require_device()) return rc;
+    GcBatch b;
+    VGA_HIP_TRY(b.st.create());
+    const int bytes_in = vga_gcadpcm_sample_count_to_byte_count(p->sample_count);
+    const int bytes_al = vga_gcadpcm_sample_count_to_byte_count(L.sample_count_aligned);
+    const int64_t in_pitch = round_up(bytes_in > 0 ? bytes_in : 1, 16);
+    b.adpcm_pitch = round_up(bytes_al > 0 ? bytes_al : 1, 16);
+    b.pcm_pitch = round_up(L.sample_count_aligned > 0 ? L.sample_count_aligned : 1, 8);
+    const int64_t seek_pitch = round_up(2 * (L.seek_table_entries > 0 ? L.seek_table_entries : 1), 8);
+    DevBuf in, seek, ctx;
+    VGA_HIP_TRY(in.alloc((size_t)nch * in_pitch));
+    VGA_HIP_TRY(b.adpcm.alloc((size_t)nch * b.adpcm_pitch));
+    VGA_HIP_TRY(b.pcm.alloc((size_t)nch * b.pcm_pitch * 2));
+    VGA_HIP_TRY(b.coefs.alloc((size_t)nch * 32));
+    VGA_HIP_TRY(seek.alloc((size_t)nch * seek_pitch * 2));
+    VGA_HIP_TRY(ctx.alloc((size_t)nch * 6));
+    const size_t wsb = vga_gcadpcm_build_channels_workspace_bytes(nch, p);
+    VGA_HIP_TRY(b.ws.alloc(wsb));
+    for (int c = 0; c < nch; c++)
+        if (bytes_in > 0)
+            VGA_HIP_TRY(hipMemcpyAsync(in.as<uint8_t>() + (int64_t)c * in_pitch, adpcm[c], (size_t)bytes_in,
+                                       hipMemcpyHostToDevice, b.st.s));
+    VGA_HIP_TRY(hipMemcpyAsync(b.coefs.p, coefs, (size_t)nch * 32, hipMemcpyHostToDevice, b.st.s));
+    if (int rc = vga_gcadpcm_build_channels_device(in.as<uint8_t>(), in_pitch, b.coefs.as<int16_t>(), nch, p,
+                                                   (adpcm_out || L.alignment_needed) ? b.adpcm.as<uint8_t>() : nullptr,
+                                                   b.adpcm_pitch, pcm_out ? b.pcm.as<int16_t>() : nullptr, b.pcm_pitch,
+                                                   (seek_table_out && L.seek_table_entries > 0) ? seek.as<int16_t>() : nullptr,
+                                                   seek_pitch, loop_context_out ? ctx.as<int16_t>() : nullptr, b.ws.p, wsb, b.st.s))
+        return rc;
+    if (adpcm_out)
+        if (int rc = download_adpcm(b, adpcm_out, nch, bytes_al)) return rc;
+    for (int c = 0; c < nch; c++) {
+        if (pcm_out && L.sample_count_aligned > 0)
+            VGA_HIP_TRY(hipMemcpyAsync(pcm_out[c], b.pcm.as<int16_t>() + (int64_t)c * b.pcm_pitch,
+                                       (size_t)L.sample_count_aligned * 2, hipMemcpyDeviceToHost, b.st.s));
+        if (seek_table_out && L.seek_table_entries > 0)
+            VGA_HIP_TRY(hipMemcpyAsync(seek_table_out[c], seek.as<int16_t>() + (int64_t)c * seek_pitch,
+                                       (size_t)L.seek_table_entries * 4, hipMemcpyDeviceToHost, b.st.s));
+    }
+    if (loop_context_out)
+        VGA_HIP_TRY(hipMemcpyAsync(loop_context_out, ctx.p, (size_t)nch * 6, hipMemcpyDeviceToHost, b.st.s));
+    VGA_HIP_TRY(hipStreamSynchronize(b.st.s));
+    return VGA_OK;
+}
+
 
 // ---------------------------------------------------------------- dsptool-compatible exports
 // VGAudio.Tools/GcAdpcm/DspToolDll.cs:16-29,94-108.  void-returning like the DLLs:

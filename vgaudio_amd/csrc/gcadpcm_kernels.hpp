@@ -17,6 +17,13 @@ int launch_encode_v1(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sampl
 int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs, int nch, int sample_count,
                   const int16_t *d_hist1, const int16_t *d_hist2, int16_t *d_pcm, int64_t pcm_pitch, int *d_status,
                   hipStream_t stream);
+// gc_channel_kernels.hip (channel metadata)
+int launch_align_gather(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int loop_start, int loop_end,
+                        int samples_to_keep, int samples_to_encode, int16_t *d_new_pcm, int64_t new_pitch,
+                        int16_t *d_hist1, int16_t *d_hist2, hipStream_t stream);
+int launch_channel_meta(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_pcm, int64_t pcm_pitch, int nch,
+                        int loop_start, int samples_per_entry, int entries, int16_t *d_seek, int64_t seek_pitch,
+                        int16_t *d_loop_context, hipStream_t stream);
 int launch_synth(int16_t *d_pcm, int64_t pitch, int nch, int length, int first_channel, const uint32_t *d_params,
                  hipStream_t stream);
 

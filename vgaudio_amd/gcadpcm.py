@@ -186,29 +186,163 @@ class Pcm16Format:
         return self
 
 
-class GcAdpcmChannel:
-    def __init__(self, adpcm, coefs, sampleCount):
-        self.Adpcm, self.Coefs, self.SampleCount = adpcm, coefs, sampleCount
+class GcAdpcmContext:
+    """PredScale / Hist1 / Hist2 (Codecs/GcAdpcm/GcAdpcmContext.cs)."""
 
-    def GetAdpcmAudio(self):
-        return self.Adpcm
+    def __init__(self, predScale=0, hist1=0, hist2=0):
+        self.PredScale, self.Hist1, self.Hist2 = int(predScale), int(hist1), int(hist2)
+
+
+class GcAdpcmChannel:
+    """Formats/GcAdpcm/GcAdpcmChannel.cs.  A channel made by the 3-argument constructor carries only the
+    encoded audio; build_channels() (the batched GcAdpcmChannelBuilder.Build) adds what the reference derives:
+    aligned audio, decoded PCM, loop context and seek table."""
+
+    def __init__(self, adpcm, coefs, sampleCount):
+        self.Adpcm, self.Coefs, self.UnalignedSampleCount = adpcm, coefs, sampleCount
+        self.AlignmentNeeded = False
+        self._aligned_adpcm = None
+        self._aligned_count = sampleCount
+        self._pcm = None
+        self._seek = None
+        self.SamplesPerSeekTableEntry = 0
+        self.LoopContext = GcAdpcmContext()
+        self.LoopContextStart = 0
+        self.StartContext = GcAdpcmContext(adpcm[0] if len(adpcm) else 0, 0, 0)
+
+    @property
+    def SampleCount(self):                       # GcAdpcmChannel.cs:11
+        return self._aligned_count if self.AlignmentNeeded else self.UnalignedSampleCount
+
+    def GetAdpcmAudio(self):                     # :63
+        return self._aligned_adpcm if self.AlignmentNeeded else self.Adpcm
+
+    def GetPcmAudio(self):                       # :57-60
+        if self._pcm is None:
+            self._pcm = GcAdpcmDecoder.Decode(self.GetAdpcmAudio(), self.Coefs, GcAdpcmParameters(SampleCount=self.SampleCount))
+        return self._pcm
+
+    def GetSeekTable(self):                      # :62
+        return self._seek if self._seek is not None else np.zeros(0, dtype=np.int16)
+
+
+def build_channels(channels, looping=False, loopStart=0, loopEnd=0, alignmentMultiple=0, samplesPerSeekTableEntry=0,
+                   keepPcm=False, loopContext=True):
+    """GcAdpcmChannelBuilder.Build for a batch of freshly encoded channels that share one loop
+    (GcAdpcmFormat.cs:27-40) -- ONE GPU call (vga_gcadpcm_build_channels_batch).  Returns new channels.
+    loopContext=False is the bare GcAdpcmAlignment constructor (no GetLoopContext)."""
+    if not channels:
+        return []
+    n = channels[0].UnalignedSampleCount
+    if any(c.UnalignedSampleCount != n for c in channels):
+        raise _lib.ArgumentError("channels of one build must share the sample count")
+    if not looping:
+        loopStart = loopEnd = 0                  # GcAdpcmChannelBuilder.WithLoop(false) (:113-119)
+    p = _lib.GcChannelParamsC(n, int(bool(looping)), loopStart, loopEnd, alignmentMultiple, samplesPerSeekTableEntry)
+    L = _lib.GcChannelLayoutC()
+    check(_lib.lib().vga_gcadpcm_channel_layout_for(C.byref(p), C.byref(L)))
+    nch = len(channels)
+    want_ctx = loopContext and L.loop_start_aligned != 0
+    if not (L.alignment_needed or want_ctx or L.seek_table_entries or keepPcm):
+        out = [GcAdpcmChannel(c.Adpcm, c.Coefs, n) for c in channels]           # nothing to derive
+        for o in out:
+            o.SamplesPerSeekTableEntry = samplesPerSeekTableEntry
+        return out
+    src = [np.ascontiguousarray(c.Adpcm, dtype=np.uint8) for c in channels]
+    coefs = np.ascontiguousarray(np.stack([c.Coefs for c in channels]), dtype=np.int16)
+    nbytes = GcAdpcmMath.SampleCountToByteCount(L.sample_count_aligned)
+    aligned = [np.zeros(nbytes, dtype=np.uint8) for _ in range(nch)] if L.alignment_needed else None
+    pcm = [np.zeros(L.sample_count_aligned, dtype=np.int16) for _ in range(nch)]
+    seek = [np.zeros(L.seek_table_entries * 2, dtype=np.int16) for _ in range(nch)] if L.seek_table_entries else None
+    ctx = np.zeros((nch, 3), dtype=np.int16)
+    check(_lib.lib().vga_gcadpcm_build_channels_batch(
+        _ptr_array(u8p, src), _i16(coefs), nch, C.byref(p), _ptr_array(u8p, aligned) if aligned else None,
+        _ptr_array(i16p, pcm), _ptr_array(i16p, seek) if seek else None, _i16(ctx) if loopContext else None))
+    out = []
+    for i, c in enumerate(channels):
+        o = GcAdpcmChannel(c.Adpcm, c.Coefs, n)
+        o.AlignmentNeeded = bool(L.alignment_needed)
+        o._aligned_adpcm = aligned[i] if aligned else None
+        o._aligned_count = L.sample_count_aligned
+        o._pcm = pcm[i]
+        o._seek = seek[i] if seek else None
+        o.SamplesPerSeekTableEntry = samplesPerSeekTableEntry
+        o.LoopContext = GcAdpcmContext(*ctx[i].tolist())
+        o.LoopContextStart = L.loop_start_aligned
+        out.append(o)
+    return out
 
 
 class GcAdpcmFormat:
-    """IAudioFormat for GC-ADPCM; EncodeFromPcm16/ToPcm16 are each ONE batched GPU call
-    (the reference's Parallel.For over channels, GcAdpcmFormat.cs:65 / :45)."""
+    """IAudioFormat for GC-ADPCM; EncodeFromPcm16/ToPcm16 and the channel build of the constructor are each
+    ONE batched GPU call (the reference's Parallel.For over channels, GcAdpcmFormat.cs:65 / :45 / :32)."""
 
-    def __init__(self, channels=None, sampleRate=48000):
-        self.Channels = list(channels) if channels is not None else []
+    def __init__(self, channels=None, sampleRate=48000, looping=False, loopStart=0, loopEnd=0, alignmentMultiple=0,
+                 samplesPerSeekTableEntry=0):
         self.SampleRate = sampleRate
+        self.Looping = bool(looping)
+        self.UnalignedLoopStart = loopStart if looping else 0
+        self.UnalignedLoopEnd = loopEnd if looping else 0
+        self.AlignmentMultiple = alignmentMultiple
+        self.SamplesPerSeekTableEntry = samplesPerSeekTableEntry
+        chans = list(channels) if channels is not None else []
+        # GcAdpcmFormat(GcAdpcmFormatBuilder) rebuilds every channel with the format's loop (:27-40)
+        self.Channels = build_channels(chans, self.Looping, self.UnalignedLoopStart, self.UnalignedLoopEnd, alignmentMultiple,
+                                       samplesPerSeekTableEntry)
 
     @property
     def ChannelCount(self):
         return len(self.Channels)
 
     @property
-    def SampleCount(self):
-        return self.Channels[0].SampleCount if self.Channels else 0
+    def UnalignedSampleCount(self):
+        return self.Channels[0].UnalignedSampleCount if self.Channels else 0
+
+    @property
+    def _alignment_samples(self):                # GcAdpcmFormat.cs:19
+        m = self.AlignmentMultiple
+        s = self.UnalignedLoopStart
+        return (s + m - s % m if m > 0 and s % m else s) - s
+
+    @property
+    def LoopStart(self):                         # :20
+        return self.UnalignedLoopStart + self._alignment_samples
+
+    @property
+    def LoopEnd(self):                           # :21
+        return self.UnalignedLoopEnd + self._alignment_samples
+
+    @property
+    def SampleCount(self):                       # :22
+        return self.UnalignedSampleCount if self._alignment_samples == 0 else self.LoopEnd
+
+    def _clone(self, **kw):
+        a = dict(sampleRate=self.SampleRate, looping=self.Looping, loopStart=self.UnalignedLoopStart,
+                 loopEnd=self.UnalignedLoopEnd, alignmentMultiple=self.AlignmentMultiple,
+                 samplesPerSeekTableEntry=self.SamplesPerSeekTableEntry)
+        a.update(kw)
+        base = [GcAdpcmChannel(c.Adpcm, c.Coefs, c.UnalignedSampleCount) for c in self.Channels]
+        return GcAdpcmFormat(base, **a)
+
+    def WithLoop(self, loop, loopStart=None, loopEnd=None):          # AudioFormatBase.WithLoop (:61-63)
+        if not loop:
+            return self._clone(looping=False, loopStart=0, loopEnd=0)
+        n = self.UnalignedSampleCount
+        if loopStart is None and loopEnd is None:
+            loopStart, loopEnd = 0, n
+        if loopStart < 0 or loopStart > n or loopEnd < 0 or loopEnd > n:
+            raise _lib.ArgumentOutOfRangeError("Loop points must be less than the number of samples and non-negative.")
+        if loopEnd < loopStart:
+            raise _lib.ArgumentOutOfRangeError("The loop end must be greater than the loop start")
+        return self._clone(looping=True, loopStart=loopStart, loopEnd=loopEnd)
+
+    def WithAlignment(self, loopStartAlignment):                     # GcAdpcmFormat.cs:124-126
+        return self._clone(alignmentMultiple=loopStartAlignment)
+
+    def WithSamplesPerSeekTableEntry(self, samplesPerEntry):
+        """What the container writers do per channel (GetCloneBuilder().WithSamplesPerSeekTableEntry(n).Build(),
+        e.g. the reference's own test helper, Tests/Formats/GcAdpcmFormatTests.cs:149-156), batched."""
+        return self._clone(samplesPerSeekTableEntry=samplesPerEntry)
 
     def EncodeFromPcm16(self, pcm16, config=None):
         nch, n = pcm16.ChannelCount, pcm16.SampleCount
@@ -229,34 +363,33 @@ class GcAdpcmFormat:
             if config is not None and config.Progress is not None:
                 config.Progress.ReportAdd(-(-n // 14) * nch)
         chans = [GcAdpcmChannel(adpcm[i], coefs[i].copy(), n) for i in range(nch)]
-        return GcAdpcmFormat(chans, pcm16.SampleRate)
+        # new GcAdpcmFormatBuilder(channels, rate).WithLoop(pcm16.Looping, LoopStart, LoopEnd).Build() (:70-73)
+        return GcAdpcmFormat(chans, pcm16.SampleRate, pcm16.Looping, pcm16.LoopStart, pcm16.LoopEnd)
 
-    def ToPcm16(self):
+    def ToPcm16(self):                           # GcAdpcmFormat.cs:42-54
         if not self.Channels:
             return Pcm16Format([], self.SampleRate)
-        n = self.SampleCount
-        pcm = GcAdpcmDecoder.Decode([c.Adpcm for c in self.Channels], np.stack([c.Coefs for c in self.Channels]),
-                                    GcAdpcmParameters(SampleCount=n))
-        return Pcm16Format(pcm, self.SampleRate)
+        if all(c._pcm is not None for c in self.Channels):
+            pcm = [c._pcm for c in self.Channels]                    # GetPcmAudio(): already decoded by the build
+        else:
+            n = self.Channels[0].SampleCount
+            pcm = GcAdpcmDecoder.Decode([c.GetAdpcmAudio() for c in self.Channels],
+                                        np.stack([c.Coefs for c in self.Channels]), GcAdpcmParameters(SampleCount=n))
+        out = Pcm16Format(pcm, self.SampleRate)
+        out.Looping, out.LoopStart, out.LoopEnd = self.Looping, self.LoopStart, self.LoopEnd
+        return out
 
-    def BuildSeekTable(self, entryCount, samplesPerEntry, bigEndian=True):
-        """GcAdpcmFormat.BuildSeekTable (GcAdpcmFormat.cs:99-113) on top of ToPcm16():
-        per channel {hist1, hist2} at every samplesPerEntry (GcAdpcmSeekTable.cs:25-38), interleaved by 2."""
-        pcm = self.ToPcm16().Channels
-        tables = []
-        for p in pcm:
-            entries = -(-len(p) // samplesPerEntry)
-            t = np.zeros(entries * 2, dtype=np.int16)
-            for i in range(1, entries):
-                t[2 * i] = p[i * samplesPerEntry - 1]
-                t[2 * i + 1] = p[i * samplesPerEntry - 2]
-            tables.append(t)
-        entries = len(tables[0]) // 2
-        inter = np.zeros(entries * 2 * len(tables), dtype=np.int16)
-        for i in range(entries):
-            for c, t in enumerate(tables):
-                inter[(i * len(tables) + c) * 2:(i * len(tables) + c) * 2 + 2] = t[2 * i:2 * i + 2]
-        out = np.zeros(entryCount * 2 * len(tables), dtype=np.int16)
+    def BuildSeekTable(self, entryCount, bigEndian=True):
+        """GcAdpcmFormat.BuildSeekTable (GcAdpcmFormat.cs:99-113): the channels' seek tables
+        (GcAdpcmSeekTable.cs:25-38, built on the device) interleaved by 2, resized to entryCount."""
+        tables = [c.GetSeekTable() for c in self.Channels]
+        nch = len(tables)
+        entries = max((len(t) // 2 for t in tables), default=0)
+        inter = np.zeros(entries * 2 * nch, dtype=np.int16)
+        for c, t in enumerate(tables):                               # ArrayExtensions.Interleave(2)
+            v = inter.reshape(entries, nch, 2)
+            v[:len(t) // 2, c, :] = t.reshape(-1, 2)
+        out = np.zeros(entryCount * 2 * nch, dtype=np.int16)         # Array.Resize
         m = min(len(out), len(inter))
         out[:m] = inter[:m]
         return out.astype(">i2" if bigEndian else "<i2").tobytes()
