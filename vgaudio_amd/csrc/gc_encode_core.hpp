@@ -30,7 +30,16 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define VGA_MUL24(a, b) __mul24((a), (b))
 #define VGA_OPAQUE(v) asm("" : "+v"(v))
+// acc + e*e as ONE instruction (hipcc otherwise re-associates the 14 sums into mul, mul, add3)
+static __device__ __forceinline__ uint32_t vga_mad24_acc(int e, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_mad_i32_i24 %0, %1, %1, %2" : "=v"(r) : "v"(e), "v"(acc));
+    return r;
+}
+#define VGA_MAD24_ACC(e, acc) vga_mad24_acc((e), (acc))
 #else
+#define VGA_MAD24_ACC(e, acc) ((acc) + (uint32_t)(e) * (uint32_t)(e))
 #define VGA_MUL24(a, b) ((a) * (b))
 #define VGA_OPAQUE(v) ((void)0)
 #endif
@@ -42,6 +51,13 @@ VGA_HD int imin(int a, int b) { return a < b ? a : b; }
 VGA_HD int imax(int a, int b) { return a > b ? a : b; }
 VGA_HD int clamp16i(int v) { return imin(imax(v, -32768), 32767); }
 VGA_HD int clamp4i(int v) { return imin(imax(v, -8), 7); }
+
+// p / 2048 with C#'s truncation toward zero, three ops: sign bit, mad, shift
+VGA_HD int div2048(int p)
+{
+    const int sgn = (int)((unsigned)p >> 31);
+    return (int)((unsigned)p + (unsigned)(sgn * 2047)) >> 11;
+}
 
 VGA_HD int bit_length(unsigned v)
 {
@@ -99,12 +115,17 @@ VGA_HD void prescan_range(const int (&x)[16], int c0, int c1, int s_begin, int s
 // ambiguous (+M and -M both present, M > 0): caller must use prescan_sequential().
 VGA_HD int first_scale_power_from_range(int dmax, int dmin)
 {
+    // straight-line version of halvings() for both signs (|1 keeps clz defined; bit_length(0|1) - 3 < 0 -> 0)
     const int pos = imax(clamp16i(dmax), 0);
     const int neg = imax(-clamp16i(dmin), 0);
-    if (pos == neg && pos != 0) return -100;
-    const int md = pos > neg ? pos : -neg;
-    const int n = halvings(md);
-    return n <= 1 ? 0 : n - 1;                      // (n<=1 ? -1 : n-2) + 1
+    const int hp = imax(bit_length((unsigned)pos | 1u) - 3, 0);
+    const int nn = imax(bit_length((unsigned)neg | 1u) - 4, 0);
+    const int hn = nn + ((((unsigned)neg >> nn) > 8u) ? 1 : 0);
+    // equal magnitudes with different halving counts: the sign of the reference's maxDistance depends on
+    // which of +M / -M came first
+    if (pos == neg && hp != hn) return -100;
+    const int n = pos > neg ? hp : hn;
+    return imax(n - 1, 0);                          // (n<=1 ? -1 : n-2) + 1
 }
 
 VGA_HD int first_scale_power_from_md(int md)
@@ -249,7 +270,7 @@ VGA_HD PassOut pass_fast_core(const int (&x)[16], const int (&in2048v)[14], cons
         const int pr11 = (int)((uint32_t)in2048p[s] - (uint32_t)d) >> 11;
         const int recon = clamp16i(pr11 + (int)((uint32_t)q << km11));
         const int e = x[s + 2] - recon;
-        total += (uint32_t)VGA_MUL24(e, e);
+        total = VGA_MAD24_ACC(e, total);                            // total += e * e, one v_mad_i32_i24
         o0 = o1;
         o1 = recon;
     }

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
                 int dmax = 0, dmin = 0;
 #pragma unroll
                 for (int s = 2; s < 14; s++) {          // x[s] = in[s-2], x[s+1] = in[s-1], x[s+2] = in[s]
-                    const int predicted = (in[s - 2] * c1 + in[s - 1] * c0) / 2048;
+                    const int predicted = div2048(in[s - 2] * c1 + in[s - 1] * c0);
                     const int d = in[s] - predicted;
                     dmax = imax(dmax, d);
                     dmin = imin(dmin, d);
@@ -248,8 +248,8 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
         // ---- pre-scan (:107-124): two history-dependent distances + the helper's range for s = 2..13
         int s1;
         {
-            const int d0 = x[2] - (VGA_MUL24(x[0], c1) + VGA_MUL24(x[1], c0)) / 2048;
-            const int d1 = x[3] - (VGA_MUL24(x[1], c1) + VGA_MUL24(x[2], c0)) / 2048;
+            const int d0 = x[2] - div2048(VGA_MUL24(x[0], c1) + VGA_MUL24(x[1], c0));
+            const int d1 = x[3] - div2048(VGA_MUL24(x[1], c1) + VGA_MUL24(x[2], c0));
             const int dmax = imax(imax((int)(int16_t)(R.pre & 0xFFFF), d0), d1);
             const int dmin = imin(imin((int)R.pre >> 16, d0), d1);
             s1 = first_scale_power_from_range(dmax, dmin);
