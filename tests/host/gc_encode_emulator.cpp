@@ -29,8 +29,12 @@ int emu_compare_pass(const int16_t *x16, int c0, int c1, int scale_power)
     const PassOut f = pass_fast(x, c0, c1, scale_power);
     if (!f.exact) return 2;
     const PassOut l = pass_literal(x, c0, c1, scale_power);
-    const bool same = f.wa == l.wa && f.wb == l.wb && f.total == l.total && f.max_overflow == l.max_overflow &&
-                      f.o12 == l.o12 && f.o13 == l.o13;
+    bool same = f.total == l.total && f.max_overflow == l.max_overflow && f.o12 == l.o12 && f.o13 == l.o13;
+    for (int s = 0; s < 14; s++) same = same && f.q[s] == l.q[s];
+    uint32_t fa, fb, la, lb;
+    frame_words(f, 3, scale_power, fa, fb);
+    frame_words(l, 3, scale_power, la, lb);
+    same = same && fa == la && fb == lb;
     return same ? 0 : 1;
 }
 

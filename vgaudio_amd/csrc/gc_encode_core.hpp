@@ -55,8 +55,9 @@ VGA_HD int clamp4i(int v) { return imin(imax(v, -8), 7); }
 // p / 2048 with C#'s truncation toward zero, three ops: sign bit, mad, shift
 VGA_HD int div2048(int p)
 {
-    const int sgn = (int)((unsigned)p >> 31);
-    return (int)((unsigned)p + (unsigned)(sgn * 2047)) >> 11;
+    int sgn = (int)((unsigned)p >> 31);
+    VGA_OPAQUE(sgn);                                   // keeps it a 0/1 factor: v_lshrrev, v_mad_u32_u24, v_ashrrev
+    return (int)((unsigned)p + (unsigned)VGA_MUL24(sgn, 2047)) >> 11;
 }
 
 VGA_HD int bit_length(unsigned v)
@@ -143,7 +144,7 @@ VGA_HD int apply_bumps(int scale_power, int max_overflow)
 }
 
 struct PassOut {
-    uint32_t wa, wb;     // nibbles 0..5 / 6..13, big-endian nibble order (nibble 0 most significant)
+    int q[14];           // the quantised samples, -8..7 (adpcmOut of GcAdpcmEncoder.cs:155)
     uint64_t total;      // totalDistance
     int max_overflow;
     int o12, o13;        // reconstructed samples 12, 13
@@ -156,12 +157,28 @@ VGA_HD uint32_t bswap32(uint32_t v)
 }
 
 // The 8 frame bytes as two little-endian dwords: byte 0 = header (predictor<<4 | scale),
-// bytes 1..7 = nibbles hi-first (GcAdpcmEncoder.cs:83-93).
+// bytes 1..7 = nibbles hi-first (GcAdpcmEncoder.cs:83-93).  The nibbles are accumulated SIGNED
+// (w = w*16 + q, one shift-add each); adding 0x888..8 turns the sum into the packing of the biased
+// nibbles q+8 and the XOR with 0x888..8 un-biases them.
+VGA_HD void pack_frame(const int (&q)[14], int predictor, int scale_power, uint32_t &d0, uint32_t &d1)
+{
+    uint32_t wa = 0, wb = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int s = 0; s < 14; s++) {
+        if (s < 6) wa = (wa << 4) + (uint32_t)q[s];
+        else       wb = (wb << 4) + (uint32_t)q[s];
+    }
+    wa = ((wa + 0x00888888u) ^ 0x00888888u) & 0x00FFFFFFu;
+    wb = (wb + 0x88888888u) ^ 0x88888888u;
+    const uint32_t header = (uint32_t)((predictor << 4) | (scale_power & 0xF));
+    d0 = bswap32((header << 24) | wa);
+    d1 = bswap32(wb);
+}
 VGA_HD void frame_words(const PassOut &r, int predictor, int scale_power, uint32_t &d0, uint32_t &d1)
 {
-    const uint32_t header = (uint32_t)((predictor << 4) | (scale_power & 0xF));
-    d0 = bswap32((header << 24) | r.wa);
-    d1 = bswap32(r.wb);
+    pack_frame(r.q, predictor, scale_power, d0, d1);
 }
 
 // Literal quantise pass: the reference's own float/double formula (:127-164), 64-bit total.
@@ -172,7 +189,6 @@ VGA_HD PassOut pass_literal(const int (&x)[16], int c0, int c1, int scale_power)
     const int scale = 1 << k;
     union { uint32_t u; float f; } inv;
     inv.u = (uint32_t)(127 - k) << 23;             // exact 2^-k: the f32 divide by 2^k is this multiply
-    uint32_t wa = 0, wb = 0;
     uint64_t total = 0;
     int max_overflow = 0;
     int o0 = x[0], o1 = x[1];
@@ -188,8 +204,7 @@ VGA_HD PassOut pass_literal(const int (&x)[16], int c0, int c1, int scale_power)
         const int q = clamp4i(unclamped);
         const int ov = unclamped - q;
         max_overflow = imax(max_overflow, ov < 0 ? -ov : ov);
-        if (s < 6) wa = (wa << 4) | ((uint32_t)q & 0xFu);
-        else       wb = (wb << 4) | ((uint32_t)q & 0xFu);
+        r.q[s] = q;
         const int corrected = predicted + q * scale;
         const int recon = clamp16i((corrected + 1024) >> 11);
         const int d = x[s + 2] - recon;
@@ -197,7 +212,7 @@ VGA_HD PassOut pass_literal(const int (&x)[16], int c0, int c1, int scale_power)
         o0 = o1;
         o1 = recon;
     }
-    r.wa = wa; r.wb = wb; r.total = total; r.max_overflow = max_overflow; r.o12 = o0; r.o13 = o1;
+    r.total = total; r.max_overflow = max_overflow; r.o12 = o0; r.o13 = o1;
     r.exact = true;
     return r;
 }
@@ -216,15 +231,14 @@ VGA_HD int round_through_f32(int d)
 #endif
 }
 
-// Fast quantise pass: integer-only, 16 VALU ops per sample of which 8 are on the dependent chain
+// Fast quantise pass: integer-only, 15 VALU ops per sample of which 8 are on the dependent chain
 // (mad, cvt, cvt, add3, ashr, med3, lshl_add, med3) instead of the f32/f64 detour.
 //   d      = in*2048 - (o0*c1 + o1*c0)                       (two mads with negated coefs)
 //   r      = (int)(float)d                                   the reference's float rounding
 //   u      = (r + 2^(k-1) - 1 + (d<0)) >> k                  unclamped nibble  (S2)
 //   q      = clamp(u, -8, 7)
 //   recon  = clamp16(((in*2048 + 1024 - d) >> 11) + (q << (k-11)))  (in*2048 + 1024 - d == predicted + 1024)
-// The nibbles are accumulated SIGNED (w = w*16 + q, one shift-add each); adding 0x888..8 turns the sum
-// into the packing of the biased nibbles q+8 and the XOR with 0x888..8 un-biases them (two ops per word).
+// The nibbles leave the pass unpacked (r.q): the kernel's helper wave packs the winner's frame (pack_frame).
 // The overflow is recovered from the running max/min of u (one max3/min3 per two samples).
 // r.exact == false (frame must be redone with pass_literal) when the 32-bit sum of squared
 // errors could overflow (S3): with |c0|+|c1| <= 32767 the predictor cannot wrap, and then
@@ -243,7 +257,6 @@ VGA_HD PassOut pass_fast_core(const int (&x)[16], const int (&in2048v)[14], cons
     VGA_OPAQUE(bias);
     VGA_OPAQUE(nc0);
     VGA_OPAQUE(nc1);
-    uint32_t wa = 0, wb = 0;
     uint32_t total = 0;
     int umax = 0, umin = 0;
     int u_prev = 0;
@@ -263,8 +276,7 @@ VGA_HD PassOut pass_fast_core(const int (&x)[16], const int (&in2048v)[14], cons
             umin = imin(imin(umin, u_prev), u);
         }
         u_prev = u;
-        if (s < 6) wa = (wa << 4) + (uint32_t)q;
-        else       wb = (wb << 4) + (uint32_t)q;
+        r.q[s] = q;
         // (predicted + 1024 + q * 2^k) >> 11 with the shift taken off the dependent chain: q * 2^k is a
         // multiple of 2^11 (k >= 11), so it passes through the floor
         const int pr11 = (int)((uint32_t)in2048p[s] - (uint32_t)d) >> 11;
@@ -277,8 +289,6 @@ VGA_HD PassOut pass_fast_core(const int (&x)[16], const int (&in2048v)[14], cons
     const int ov = imax(imax(umax - 7, -8 - umin), 0);
     const int ac0 = c0 < 0 ? -c0 : c0, ac1 = c1 < 0 ? -c1 : c1;
     r.exact = ac0 + ac1 <= 32767 && ov <= 17497 && (((2 * ov + 1) << (k - 11)) <= 34996);
-    r.wa = ((wa + 0x00888888u) ^ 0x00888888u) & 0x00FFFFFFu;
-    r.wb = (wb + 0x88888888u) ^ 0x88888888u;
     r.total = total;
     r.max_overflow = ov;
     r.o12 = o0; r.o13 = o1;

@@ -83,6 +83,7 @@ struct GcTile {
 #else
 #define VGA_MARK(name)
 #endif
+typedef short short2v __attribute__((ext_vector_type(2)));
 struct X16 { int v[16]; };
 
 #ifdef VGA_ENC_COLD_OUTLINE      // experiment switch: measured 267 ms out of line vs 260 ms inline at configs[1]
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
     const int16_t *__restrict__ hist2, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch)
 {
     __shared__ GcTile s_tile[2];
-    __shared__ uint2 s_out[2][4][TF];
+    // the winner's frame, unpacked: q[0..13], predictor, scale; the helper packs it (pack_frame) when it flushes
+    __shared__ int4 s_out[2][4][TF][4];
     const int tid = threadIdx.x;
     const bool helper = tid >= 64;
     const int lane = tid & 63;
@@ -125,16 +127,17 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
 
     if (helper) {
         // ---------------------------------------------------------------- helper wave
-        int cf[16];
+        uint32_t cpk[8];                               // (c1, c0) of predictor p as a packed pair: low half c1
 #pragma unroll
-        for (int i = 0; i < 16; i++) cf[i] = coefs[ch * 16 + i];
+        for (int p = 0; p < 8; p++)
+            cpk[p] = (uint32_t)(uint16_t)coefs[ch * 16 + 2 * p + 1] | ((uint32_t)(uint16_t)coefs[ch * 16 + 2 * p] << 16);
         auto prepare = [&](int tile) {
             if (l16 >= TF) return;
             const int fr = imin(tile * TF + l16, frames - 1);
             int in[14];
+            uint32_t w[7];                             // the frame as packed pairs (in[2i], in[2i+1])
             if (fr < full_frames) {
                 const uint32_t *p32 = reinterpret_cast<const uint32_t *>(src + (int64_t)fr * 14);
-                uint32_t w[7];
 #pragma unroll
                 for (int i = 0; i < 7; i++) w[i] = p32[i];
 #pragma unroll
@@ -145,6 +148,8 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
             } else {                                   // zero-padded partial last frame (:32-33)
 #pragma unroll
                 for (int s = 0; s < 14; s++) in[s] = (s < tail) ? (int)src[(int64_t)fr * 14 + s] : 0;
+#pragma unroll
+                for (int i = 0; i < 7; i++) w[i] = (uint32_t)(in[2 * i] & 0xFFFF) | ((uint32_t)in[2 * i + 1] << 16);
             }
             GcTile &T = s_tile[tile & 1];
             int4 *xr = reinterpret_cast<int4 *>(&T.x[grp][l16][0]);
@@ -162,15 +167,23 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
             qr[1] = make_int4(in[4] * 2048 + 1024, in[5] * 2048 + 1024, in[6] * 2048 + 1024, in[7] * 2048 + 1024);
             qr[2] = make_int4(in[8] * 2048 + 1024, in[9] * 2048 + 1024, in[10] * 2048 + 1024, in[11] * 2048 + 1024);
             qr[3] = make_int4(in[12] * 2048 + 1024, in[13] * 2048 + 1024, 0, 0);
+            // pre-scan distances of samples 2..13 (:107-115): predicted = (in[k]*c1 + in[k+1]*c0) / 2048 for the
+            // pair starting at k = s - 2.  One v_dot2c_i32_i16 per (predictor, sample): the pairs at even k are
+            // the loaded dwords, the pairs at odd k one v_alignbit each (shared by the 8 predictors); the
+            // wrap of int32 is the reference's (unchecked arithmetic).
+            uint32_t pair[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++)
+                pair[k] = (k & 1) ? __builtin_amdgcn_alignbit(w[(k + 1) / 2], w[(k - 1) / 2], 16) : w[k / 2];
             uint32_t pre[8];
 #pragma unroll
             for (int p = 0; p < 8; p++) {
-                const int c0 = cf[2 * p], c1 = cf[2 * p + 1];
                 int dmax = 0, dmin = 0;
 #pragma unroll
-                for (int s = 2; s < 14; s++) {          // x[s] = in[s-2], x[s+1] = in[s-1], x[s+2] = in[s]
-                    const int predicted = div2048(in[s - 2] * c1 + in[s - 1] * c0);
-                    const int d = in[s] - predicted;
+                for (int k = 0; k < 12; k++) {
+                    const int predicted = div2048(__builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, pair[k]),
+                                                                         __builtin_bit_cast(short2v, cpk[p]), 0, false));
+                    const int d = in[k + 2] - predicted;
                     dmax = imax(dmax, d);
                     dmin = imin(dmin, d);
                 }
@@ -183,7 +196,11 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
         auto flush = [&](int tile) {
             const int fr = tile * TF + l16;
             if (!live || l16 >= TF || fr >= frames) return;
-            const uint2 v = s_out[tile & 1][grp][l16];
+            const int4 *rec = &s_out[tile & 1][grp][l16][0];
+            const int4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+            const int q[14] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y};
+            uint2 v;
+            pack_frame(q, r3.z, r3.w, v.x, v.y);
             if (fr < full_frames) {
                 *reinterpret_cast<uint2 *>(dst + (int64_t)fr * 8) = v;
             } else {
@@ -221,6 +238,8 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
         const int4 *mr = reinterpret_cast<const int4 *>(&T.in2048[grp][j][0]);
         const int4 a0 = xr[0], a1 = xr[1], a2 = xr[2], a3 = xr[3];
         const int4 b0 = mr[0], b1 = mr[1], b2 = mr[2], b3 = mr[3];
+        // keep the padding lanes "used": hipcc otherwise splits the 16-byte row reads into 7 odd-sized ones
+        asm volatile("" ::"v"(a3.z), "v"(a3.w), "v"(b3.z), "v"(b3.w));
         int *x = R.x, *m = R.m;
         x[2] = a0.x; x[3] = a0.y; x[4] = a0.z; x[5] = a0.w; x[6] = a1.x; x[7] = a1.y; x[8] = a1.z; x[9] = a1.w;
         x[10] = a2.x; x[11] = a2.y; x[12] = a2.z; x[13] = a2.w; x[14] = a3.x; x[15] = a3.y;
@@ -228,6 +247,7 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
         m[8] = b2.x; m[9] = b2.y; m[10] = b2.z; m[11] = b2.w; m[12] = b3.x; m[13] = b3.y;
         const int4 *qr = reinterpret_cast<const int4 *>(&T.in2048p[grp][j][0]);
         const int4 e0 = qr[0], e1 = qr[1], e2 = qr[2], e3 = qr[3];
+        asm volatile("" ::"v"(e3.z), "v"(e3.w));
         int *mp = R.mp;
         mp[0] = e0.x; mp[1] = e0.y; mp[2] = e0.z; mp[3] = e0.w; mp[4] = e1.x; mp[5] = e1.y; mp[6] = e1.z; mp[7] = e1.w;
         mp[8] = e2.x; mp[9] = e2.y; mp[10] = e2.z; mp[11] = e2.w; mp[12] = e3.x; mp[13] = e3.y;
@@ -345,10 +365,12 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
 #endif
         const unsigned pay = row16_reduce(won ? ((unsigned)(r.o12 & 0xFFFF) | ((unsigned)r.o13 << 16)) : 0u,
                                           [](unsigned a, unsigned b) { return a | b; });
-        if (won) {
-            uint32_t d0, d1;
-            frame_words(r, p, final_sp, d0, d1);
-            s_out[buf][grp][j] = make_uint2(d0, d1);          // flushed by the helper, 16 frames at a time
+        if (won) {                                           // packed and flushed by the helper, a tile at a time
+            int4 *rec = &s_out[buf][grp][j][0];
+            rec[0] = make_int4(r.q[0], r.q[1], r.q[2], r.q[3]);
+            rec[1] = make_int4(r.q[4], r.q[5], r.q[6], r.q[7]);
+            rec[2] = make_int4(r.q[8], r.q[9], r.q[10], r.q[11]);
+            rec[3] = make_int4(r.q[12], r.q[13], p, final_sp);
         }
 #ifdef VGA_ABL_PAY
 #undef row16_reduce
