@@ -222,6 +222,7 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
     }
 
     // -------------------------------------------------------------------- serial (encoder) wave
+    __builtin_amdgcn_s_setprio(3);                     // its latency is the kernel's run time: win every issue arbitration
     const int p = l16 >> 1;
     const bool cand_b = (l16 & 1) != 0;
     const int c0 = coefs[ch * 16 + 2 * p];
