@@ -101,6 +101,19 @@ VGA_COLD int prescan_sequential_cold(X16 xs, int c0, int c1)
     return prescan_sequential(x, c0, c1);
 }
 
+// The reference's loop as written (bump loop, literal f32/f64 pass): hostile input only.  Out of line ON
+// PURPOSE: inlined, hipcc hoists its loop-invariant set-up (14 shifts, 64-bit mads) into every third trip.
+struct GenericOut { PassOut r; int final_sp; };
+__device__ __noinline__ GenericOut resume_generic(X16 xs, int c0, int c1, int scale_power)
+{
+    int x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = xs.v[i];
+    GenericOut o;
+    o.r = resume_passes(x, c0, c1, scale_power, o.final_sp);
+    return o;
+}
+
 __global__ __launch_bounds__(128) void gc_encode_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int sample_count,
     const int16_t *__restrict__ coefs, const int16_t *__restrict__ hist1,
@@ -315,7 +328,9 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
             if (redo) {
                 fin = false;
                 if (!cand_b) {
-                    r = resume_passes_core(x, R.m, R.mp, c0, c1, s1 - 1, final_sp);
+                    const GenericOut g = resume_generic(pack(x), c0, c1, s1 - 1);
+                    r = g.r;
+                    final_sp = g.final_sp;
                     fin = true;
                 }
             } else if (resume) {
@@ -326,7 +341,9 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
                     r = pass_fast_core(x, R.m, R.mp, c0, c1, sp);
                     const bool cap = sp >= 12;
                     if ((unsigned)r.max_overflow > (cap ? 3u : 248u)) {      // bump loop / inexact sum: generic
-                        r = resume_passes_core(x, R.m, R.mp, c0, c1, sp - 1, final_sp);
+                        const GenericOut g = resume_generic(pack(x), c0, c1, sp - 1);
+                        r = g.r;
+                        final_sp = g.final_sp;
                         break;
                     }
                     final_sp = sp;
