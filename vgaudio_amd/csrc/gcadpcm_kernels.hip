@@ -305,35 +305,78 @@ __device__ __forceinline__ void set3(double (&v)[3], int i, double val)
 // One frame of the analysis loop, GcAdpcmCoefficients.cs:40-61.  x[0..1] are the
 // two samples before the frame (the only part of the 14-sample history the
 // reference reads), x[2..15] the frame (zero padded).
-__device__ __forceinline__ Record frame_record(const int (&x)[16])
-{
-    Record rec;
-    rec.valid = false;
-    rec.r1 = rec.r2 = 0.0;
-
-    // InnerProductMerge :112-120 -- 0.0 - p - p ...: every partial is an exact integer < 2^53
+// the six sums of products a frame needs, as f64 (InnerProductMerge :112-120, OuterProductMerge :122-131)
+struct FrameSums {
     double vec[3];
+    double m11, m12, m22;
+};
+
+__device__ __forceinline__ FrameSums frame_sums(const int (&x)[16])
+{
+    FrameSums f;
+    // 0.0 - p - p ...: every partial is an exact integer < 2^53
 #pragma unroll
     for (int i = 0; i <= 2; i++) {
         long long s = 0;
 #pragma unroll
         for (int t = 0; t < 14; t++) s -= (long long)(x[2 + t - i] * x[2 + t]);
-        vec[i] = (double)s;
+        f.vec[i] = (double)s;
     }
+    long long s11 = 0, s12 = 0, s22 = 0;
+#pragma unroll
+    for (int z = 0; z < 14; z++) {
+        s11 += (long long)(x[2 + z - 1] * x[2 + z - 1]);
+        s12 += (long long)(x[2 + z - 1] * x[2 + z - 2]);
+        s22 += (long long)(x[2 + z - 2] * x[2 + z - 2]);
+    }
+    f.m11 = (double)s11; f.m12 = (double)s12; f.m22 = (double)s22;
+    return f;
+}
+
+// The same six sums from the window as 8 packed pairs w[i] = (x[2i], x[2i+1]): three 7-term dot-product sums
+// with v_dot2_i32_i16 and six edge products instead of 70 multiplies with 64-bit adds.
+//   S0 = sum_{j=2..15} x[j]^2         = -vec[0]      (pairs 1..7 with themselves)
+//   S1 = sum_{j=0..13} x[j] x[j+1]    = m12          (pair i with the pair shifted by one sample)
+//   S2 = sum_{j=0..13} x[j] x[j+2]    = -vec[2]      (pair i with pair i+1)
+//   -vec[1] = S1 - x0 x1 + x14 x15;  m11 = S0 + x1^2 - x15^2;  m22 = m11 + x0^2 - x14^2
+// Every value is an exact integer below 2^53, so the f64 additions are exact in any order.  A pair sum can
+// be +2^31 (two products of -32768 * -32768): the accumulator input -1 keeps it inside int32.
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double dot2_f64(uint32_t a, uint32_t b)
+{
+    return (double)__builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), -1, false) + 1.0;
+}
+__device__ __forceinline__ FrameSums frame_sums_packed(const uint32_t (&w)[8])
+{
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        s0 += dot2_f64(w[i + 1], w[i + 1]);
+        s1 += dot2_f64(w[i], __builtin_amdgcn_alignbit(w[i + 1], w[i], 16));
+        s2 += dot2_f64(w[i], w[i + 1]);
+    }
+    const int x0 = (int)(int16_t)(w[0] & 0xFFFF), x1 = (int)w[0] >> 16;
+    const int x14 = (int)(int16_t)(w[7] & 0xFFFF), x15 = (int)w[7] >> 16;
+    FrameSums f;
+    f.vec[0] = 0.0 - s0;                               // 0.0 - p - p ... (:115-117): +0.0 for an all-zero frame
+    f.vec[1] = 0.0 - ((s1 - (double)(x0 * x1)) + (double)(x14 * x15));
+    f.vec[2] = 0.0 - s2;
+    f.m12 = s1;
+    f.m11 = (s0 + (double)(x1 * x1)) - (double)(x15 * x15);
+    f.m22 = (f.m11 + (double)(x0 * x0)) - (double)(x14 * x14);
+    return f;
+}
+
+__device__ __forceinline__ Record frame_record(const FrameSums &fs)
+{
+    Record rec;
+    rec.valid = false;
+    rec.r1 = rec.r2 = 0.0;
+
+    double vec[3] = {fs.vec[0], fs.vec[1], fs.vec[2]};
     if (!(fabs(vec[0]) > 10.0)) return rec;
 
-    // OuterProductMerge :122-131
-    double m11, m12, m21, m22;
-    {
-        long long s11 = 0, s12 = 0, s22 = 0;
-#pragma unroll
-        for (int z = 0; z < 14; z++) {
-            s11 += (long long)(x[2 + z - 1] * x[2 + z - 1]);
-            s12 += (long long)(x[2 + z - 1] * x[2 + z - 2]);
-            s22 += (long long)(x[2 + z - 2] * x[2 + z - 2]);
-        }
-        m11 = (double)s11; m12 = (double)s12; m21 = (double)s12; m22 = (double)s22;
-    }
+    double m11 = fs.m11, m12 = fs.m12, m21 = fs.m12, m22 = fs.m22;
 
     // AnalyzeRanges :133-208 specialised to the 2x2 block (rows/cols 1..2), same
     // operation order, same comparisons (NaN-false semantics preserved).
@@ -545,7 +588,7 @@ __global__ __launch_bounds__(COEF_BLOCK) void gc_coefs_kernel_v1(
         if (f < frames) {
             int x[16];
             load_frame16(src, f, length, x);
-            const Record r = frame_record(x);
+            const Record r = frame_record(frame_sums(x));
             if (r.valid) {
                 matrix_filter(r.r1, r.r2, d1, d2);
                 idx = 0;
@@ -769,19 +812,23 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
         const int f = base + lane;
         bool valid = false;
         double d1 = 0.0, d2 = 0.0;
-        int x[16];
+        uint32_t wc[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            x[2 * i] = (int)(int16_t)(w[i] & 0xFFFF);
-            x[2 * i + 1] = (int)w[i] >> 16;
-        }
+        for (int i = 0; i < 8; i++) wc[i] = w[i];
         if (have_interior) prefetch(f + 64);           // in flight during this chunk
         if (f < frames) {
-            if (!(have_interior && f >= 1 && f <= f_hi)) load_frame16(src, f, length, x);
+            FrameSums fs;
+            if (have_interior && f >= 1 && f <= f_hi) {
+                fs = frame_sums_packed(wc);
+            } else {                                   // frame 0 / the zero-padded tail
+                int x[16];
+                load_frame16(src, f, length, x);
+                fs = frame_sums(x);
+            }
 #ifdef VGA_CABL_NOREC
-            Record r; r.valid = true; r.r1 = x[2] * 1e-5; r.r2 = x[3] * 1e-5;
+            Record r; r.valid = true; r.r1 = fs.vec[1] * 1e-9; r.r2 = fs.vec[2] * 1e-9;
 #else
-            const Record r = frame_record(x);
+            const Record r = frame_record(fs);
 #endif
             valid = r.valid;
             if (valid) matrix_filter(r.r1, r.r2, d1, d2);
