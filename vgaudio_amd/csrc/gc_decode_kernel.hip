@@ -1,0 +1,177 @@
+// gc_decode_kernel.hip -- GC-ADPCM decoder for gfx950, serial wave + helper waves.
+//
+// Replaces VGAudio/Codecs/GcAdpcm/GcAdpcmDecoder.cs:10-54, bit-exact.
+//
+// The decoder is a second-order IIR with saturation and a truncating shift per sample (:38-45): serial
+// inside a channel, and 4096 channels are only 64 waves -- so time = frames x (instructions per frame on
+// the wave that carries the recurrence).  As in gc_encode_kernel.hip everything that does not depend on the
+// history leaves that wave:
+//   helper waves (3 per workgroup), one tile of frames AHEAD: load the 8-byte frames, split the header
+//     (:25-29), look the coefficient pair up, turn every nibble into scale * nibble + 1024 (:36-37, :41 with
+//     the rounding constant folded in) and lay all of it out in LDS so that the decoder's reads are one
+//     conflict-free b128 per lane; they also write the previous tile's samples to global memory;
+//   decoder wave (lane = channel, 64 channels per workgroup): per sample mad, mad, shift, clamp.
+#include "common.hpp"
+#include "gcadpcm_kernels.hpp"
+
+#include <cstdlib>
+
+namespace vga {
+namespace gc {
+
+constexpr int DTF = 8;                    // frames per tile
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+struct GcDecodeTile {
+    int4 dist[DTF][4][64];                // [frame][quarter][channel]: 14 x (scale*nibble + 1024), 2 padding
+    int2 coef[DTF][64];                   // [frame][channel]: (coef1, coef2) of the frame's predictor
+    int4 out[DTF][2][64];                 // [frame][half][channel]: 14 samples as 7 packed pairs, 1 padding
+};
+
+__global__ __launch_bounds__(256) void gc_decode_kernel_v2(
+    const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
+    int sample_count, const int16_t *__restrict__ hist1, const int16_t *__restrict__ hist2,
+    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    GcDecodeTile *s_tile = reinterpret_cast<GcDecodeTile *>(s_raw);            // [2]
+    int16_t *s_coefs = reinterpret_cast<int16_t *>(s_raw + 2 * sizeof(GcDecodeTile));   // [64][16]
+
+    const int tid = threadIdx.x;
+    const int ch0 = blockIdx.x * 64;
+    const int full_frames = sample_count / 14;
+    const int tail = sample_count - full_frames * 14;
+    const int frames = full_frames + (tail ? 1 : 0);
+    const int tiles = (frames + DTF - 1) / DTF;
+
+    for (int i = tid; i < 64 * 16; i += 256) {
+        const int c = imin(ch0 + (i >> 4), nch - 1);
+        s_coefs[i] = coefs[c * 16 + (i & 15)];
+    }
+    __syncthreads();
+
+    if (tid >= 64) {
+        // ------------------------------------------------------------ helper waves (192 lanes)
+        const int hl = tid - 64;
+        bool bad = false;
+        auto prepare = [&](int tile) {
+            GcDecodeTile &T = s_tile[tile & 1];
+            for (int item = hl; item < 64 * DTF; item += 192) {
+                const int c = item / DTF, j = item - c * DTF;         // consecutive lanes: consecutive frames
+                const int fr = tile * DTF + j;
+                if (fr >= frames) continue;
+                const int ch = imin(ch0 + c, nch - 1);
+                const uint8_t *src = adpcm + (int64_t)ch * adpcm_pitch + (int64_t)fr * 8;
+                uint64_t bits;
+                if (fr < full_frames) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(src);
+                    bits = ((uint64_t)v.y << 32) | v.x;
+                } else {                                               // partial last frame: only its bytes exist
+                    const int nbytes = (tail + 2 + 1) / 2;
+                    bits = 0;
+                    for (int b = 0; b < nbytes; b++) bits |= (uint64_t)src[b] << (8 * b);
+                }
+                const int ps = (int)(bits & 0xFF);
+                const int scale = (1 << (ps & 0xF)) * 2048;            // :26
+                int predictor = (ps >> 4) & 0xF;                       // :27
+                if (predictor > 7) { bad = true; predictor &= 7; }
+                T.coef[j][c] = make_int2(s_coefs[c * 16 + predictor * 2], s_coefs[c * 16 + predictor * 2 + 1]);
+                int d[16];
+#pragma unroll
+                for (int s = 0; s < 14; s++) {
+                    const int byte = (int)((bits >> (8 * (1 + s / 2))) & 0xFF);
+                    const int nib = (s & 1) ? (byte & 0xF) : (byte >> 4);
+                    d[s] = scale * ((nib ^ 8) - 8) + 1024;             // SignedNibbles (Helpers.cs:50), :36, + the 1024 of :41
+                }
+                d[14] = d[15] = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) T.dist[j][q][c] = make_int4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+            }
+        };
+        auto flush = [&](int tile) {
+            const GcDecodeTile &T = s_tile[tile & 1];
+            for (int item = hl; item < 64 * DTF; item += 192) {
+                const int c = item / DTF, j = item - c * DTF;
+                const int fr = tile * DTF + j;
+                if (fr >= frames || ch0 + c >= nch) continue;
+                const int4 a = T.out[j][0][c], b = T.out[j][1][c];
+                const uint32_t w[7] = {(uint32_t)a.x, (uint32_t)a.y, (uint32_t)a.z, (uint32_t)a.w,
+                                       (uint32_t)b.x, (uint32_t)b.y, (uint32_t)b.z};
+                int16_t *dst = pcm + (int64_t)(ch0 + c) * pcm_pitch + (int64_t)fr * 14;
+                if (fr < full_frames) {
+                    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
+#pragma unroll
+                    for (int i = 0; i < 7; i++) d32[i] = w[i];
+                } else {
+                    for (int s = 0; s < tail; s++) dst[s] = (int16_t)(w[s >> 1] >> (16 * (s & 1)));
+                }
+            }
+        };
+        if (tiles > 0) prepare(0);
+        __syncthreads();
+        for (int tile = 0; tile < tiles; tile++) {
+            if (tile + 1 < tiles) prepare(tile + 1);
+            if (tile > 0) flush(tile - 1);
+            __syncthreads();
+        }
+        if (tiles > 0) flush(tiles - 1);
+        if (bad && status) atomicOr(status, 1);
+        return;
+    }
+
+    // ---------------------------------------------------------------- decoder wave: lane = channel
+    __builtin_amdgcn_s_setprio(3);
+    const int ch = imin(ch0 + tid, nch - 1);
+    int h1 = hist1 ? hist1[ch] : 0;
+    int h2 = hist2 ? hist2[ch] : 0;
+    __syncthreads();                                   // tile 0 prepared
+    for (int tile = 0; tile < tiles; tile++) {
+        GcDecodeTile &T = s_tile[tile & 1];
+        const int nf = imin(DTF, frames - tile * DTF);
+#pragma unroll 1
+        for (int j = 0; j < nf; j++) {
+            const int2 cf = T.coef[j][tid];
+            const int4 q0 = T.dist[j][0][tid], q1 = T.dist[j][1][tid], q2 = T.dist[j][2][tid], q3 = T.dist[j][3][tid];
+            const int d[14] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y};
+            int o[14];
+#pragma unroll
+            for (int s = 0; s < 14; s++) {
+                // :38-45: (coef1*hist1 + coef2*hist2 + distance + 1024) >> 11, clamped; int32 wrap like the reference
+                const int t = __mul24(cf.x, h1) + (__mul24(cf.y, h2) + d[s]);
+                const int v = imin(imax(t >> 11, -32768), 32767);
+                h2 = h1;
+                h1 = v;
+                o[s] = v;
+            }
+            // a partial last frame decodes all 14 positions here; the flush writes only the valid ones and the
+            // history is not used afterwards
+            T.out[j][0][tid] = make_int4((o[0] & 0xFFFF) | (o[1] << 16), (o[2] & 0xFFFF) | (o[3] << 16),
+                                         (o[4] & 0xFFFF) | (o[5] << 16), (o[6] & 0xFFFF) | (o[7] << 16));
+            T.out[j][1][tid] = make_int4((o[8] & 0xFFFF) | (o[9] << 16), (o[10] & 0xFFFF) | (o[11] << 16),
+                                         (o[12] & 0xFFFF) | (o[13] << 16), 0);
+        }
+        __syncthreads();
+    }
+}
+
+int launch_decode_v2(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs, int nch, int sample_count,
+                     const int16_t *d_hist1, const int16_t *d_hist2, int16_t *d_pcm, int64_t pcm_pitch, int *d_status,
+                     hipStream_t stream)
+{
+    if (nch <= 0 || sample_count <= 0) return VGA_OK;
+    const size_t lds = 2 * sizeof(GcDecodeTile) + 64 * 16 * sizeof(int16_t);
+    static bool configured = false;
+    if (!configured) {
+        VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gc_decode_kernel_v2),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL(gc_decode_kernel_v2, dim3((nch + 63) / 64), dim3(256), lds, stream, d_adpcm, adpcm_pitch, d_coefs,
+                       nch, sample_count, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
+    VGA_HIP_TRY(hipGetLastError());
+    return VGA_OK;
+}
+
+}  // namespace gc
+}  // namespace vga

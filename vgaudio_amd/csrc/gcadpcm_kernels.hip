@@ -1061,6 +1061,14 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
                   hipStream_t stream)
 {
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
+    // A/B switch for measurements only: VGA_GC_DECODE_IMPL=v1 selects the first (single-wave) kernel
+    static const bool use_v1 = [] {
+        const char *e = getenv("VGA_GC_DECODE_IMPL");
+        return e && e[0] == 'v' && e[1] == '1';
+    }();
+    if (!use_v1)
+        return launch_decode_v2(d_adpcm, adpcm_pitch, d_coefs, nch, sample_count, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status,
+                                stream);
     hipLaunchKernelGGL(gc_decode_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs,
                        nch, sample_count, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
     VGA_HIP_TRY(hipGetLastError());
