@@ -47,6 +47,17 @@ struct Stream {
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// Workgroup barrier for hand-offs that go through LDS only.  __syncthreads() also drains vmcnt, i.e. every
+// global load still in flight (tile prefetches) and every store (tile flushes) -- a full HBM round trip per
+// tile for the helper waves.  Here only the LDS counter is waited for; the "memory" clobber keeps the compiler
+// from moving memory operations across.
+__device__ __forceinline__ void lds_barrier()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 // fails loudly when no gfx950 device is present: there is no CPU fallback.
 int require_device();
 

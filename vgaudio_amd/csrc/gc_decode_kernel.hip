@@ -55,19 +55,34 @@ __global__ __launch_bounds__(256) void gc_decode_kernel_v2(
         // ------------------------------------------------------------ helper waves (192 lanes)
         const int hl = tid - 64;
         bool bad = false;
-        auto prepare = [&](int tile) {
+        // the lane's (up to 3) frames of a tile, loaded a whole tile period before they are unpacked:
+        // unconditional loads with a clamped frame index (a load under a divergent condition is waited for
+        // at once, and the helpers would then pay three HBM round trips per tile)
+        constexpr int ITEMS = (64 * DTF + 191) / 192;
+        auto load_tile = [&](int tile, uint2 (&raw)[ITEMS]) {
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) {
+                const int item = imin(hl + 192 * k, 64 * DTF - 1);
+                const int c = item / DTF, j = item - c * DTF;
+                const int fr = imin(tile * DTF + j, imax(full_frames - 1, 0));
+                const int ch = imin(ch0 + c, nch - 1);
+                // (no full frame at all: frame 0's 8 bytes still lie inside the row -- pitch is a multiple of 8)
+                raw[k] = *reinterpret_cast<const uint2 *>(adpcm + (int64_t)ch * adpcm_pitch + (int64_t)fr * 8);
+            }
+        };
+        auto prepare = [&](int tile, const uint2 (&raw)[ITEMS]) {
             GcDecodeTile &T = s_tile[tile & 1];
-            for (int item = hl; item < 64 * DTF; item += 192) {
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) {
+                const int item = hl + 192 * k;
+                if (item >= 64 * DTF) continue;
                 const int c = item / DTF, j = item - c * DTF;         // consecutive lanes: consecutive frames
                 const int fr = tile * DTF + j;
                 if (fr >= frames) continue;
-                const int ch = imin(ch0 + c, nch - 1);
-                const uint8_t *src = adpcm + (int64_t)ch * adpcm_pitch + (int64_t)fr * 8;
-                uint64_t bits;
-                if (fr < full_frames) {
-                    const uint2 v = *reinterpret_cast<const uint2 *>(src);
-                    bits = ((uint64_t)v.y << 32) | v.x;
-                } else {                                               // partial last frame: only its bytes exist
+                uint64_t bits = ((uint64_t)raw[k].y << 32) | raw[k].x;
+                if (fr >= full_frames) {                               // partial last frame: only its bytes exist
+                    const int ch = imin(ch0 + c, nch - 1);
+                    const uint8_t *src = adpcm + (int64_t)ch * adpcm_pitch + (int64_t)fr * 8;
                     const int nbytes = (tail + 2 + 1) / 2;
                     bits = 0;
                     for (int b = 0; b < nbytes; b++) bits |= (uint64_t)src[b] << (8 * b);
@@ -108,12 +123,22 @@ __global__ __launch_bounds__(256) void gc_decode_kernel_v2(
                 }
             }
         };
-        if (tiles > 0) prepare(0);
-        __syncthreads();
-        for (int tile = 0; tile < tiles; tile++) {
-            if (tile + 1 < tiles) prepare(tile + 1);
+        uint2 ra[ITEMS], rb[ITEMS];                    // ping-pong: tile t+1 being unpacked, tile t+2 in flight
+        load_tile(0, ra);
+        load_tile(1, rb);
+        if (tiles > 0) prepare(0, ra);
+        lds_barrier();
+        for (int tile = 0; tile < tiles; tile += 2) {
+            load_tile(tile + 2, ra);
+            if (tile + 1 < tiles) prepare(tile + 1, rb);
             if (tile > 0) flush(tile - 1);
-            __syncthreads();
+            lds_barrier();
+            if (tile + 1 < tiles) {
+                load_tile(tile + 3, rb);
+                if (tile + 2 < tiles) prepare(tile + 2, ra);
+                flush(tile);
+                lds_barrier();
+            }
         }
         if (tiles > 0) flush(tiles - 1);
         if (bad && status) atomicOr(status, 1);
@@ -125,33 +150,51 @@ __global__ __launch_bounds__(256) void gc_decode_kernel_v2(
     const int ch = imin(ch0 + tid, nch - 1);
     int h1 = hist1 ? hist1[ch] : 0;
     int h2 = hist2 ? hist2[ch] : 0;
-    __syncthreads();                                   // tile 0 prepared
+    lds_barrier();                                   // tile 0 prepared
+    struct Row { int2 cf; int4 q0, q1, q2, q3; };
+    auto read_row = [&](const GcDecodeTile &T, int j, Row &R) {
+        R.cf = T.coef[j][tid];
+        R.q0 = T.dist[j][0][tid]; R.q1 = T.dist[j][1][tid]; R.q2 = T.dist[j][2][tid]; R.q3 = T.dist[j][3][tid];
+    };
+    auto decode_frame = [&](GcDecodeTile &T, int j, const Row &R) {
+        const int d[14] = {R.q0.x, R.q0.y, R.q0.z, R.q0.w, R.q1.x, R.q1.y, R.q1.z, R.q1.w,
+                           R.q2.x, R.q2.y, R.q2.z, R.q2.w, R.q3.x, R.q3.y};
+        int o[14];
+#pragma unroll
+        for (int s = 0; s < 14; s++) {
+            // :38-45: (coef1*hist1 + coef2*hist2 + distance + 1024) >> 11, clamped; int32 wrap like the reference.
+            // Two mads: the hist2 term is ready one sample early, so the dependent chain is mad, shift, clamp.
+            int rest = __mul24(R.cf.y, h2) + d[s];
+            asm("" : "+v"(rest));
+            const int t = __mul24(R.cf.x, h1) + rest;
+            const int v = imin(imax(t >> 11, -32768), 32767);
+            h2 = h1;
+            h1 = v;
+            o[s] = v;
+        }
+        // a partial last frame decodes all 14 positions here; the flush writes only the valid ones and the
+        // history is not used afterwards
+        T.out[j][0][tid] = make_int4((o[0] & 0xFFFF) | (o[1] << 16), (o[2] & 0xFFFF) | (o[3] << 16),
+                                     (o[4] & 0xFFFF) | (o[5] << 16), (o[6] & 0xFFFF) | (o[7] << 16));
+        T.out[j][1][tid] = make_int4((o[8] & 0xFFFF) | (o[9] << 16), (o[10] & 0xFFFF) | (o[11] << 16),
+                                     (o[12] & 0xFFFF) | (o[13] << 16), 0);
+    };
     for (int tile = 0; tile < tiles; tile++) {
         GcDecodeTile &T = s_tile[tile & 1];
         const int nf = imin(DTF, frames - tile * DTF);
+        // two row register sets, ping-pong: the LDS reads of frame j+1 are in flight during frame j
+        Row RA, RB;
+        read_row(T, 0, RA);
 #pragma unroll 1
-        for (int j = 0; j < nf; j++) {
-            const int2 cf = T.coef[j][tid];
-            const int4 q0 = T.dist[j][0][tid], q1 = T.dist[j][1][tid], q2 = T.dist[j][2][tid], q3 = T.dist[j][3][tid];
-            const int d[14] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y};
-            int o[14];
-#pragma unroll
-            for (int s = 0; s < 14; s++) {
-                // :38-45: (coef1*hist1 + coef2*hist2 + distance + 1024) >> 11, clamped; int32 wrap like the reference
-                const int t = __mul24(cf.x, h1) + (__mul24(cf.y, h2) + d[s]);
-                const int v = imin(imax(t >> 11, -32768), 32767);
-                h2 = h1;
-                h1 = v;
-                o[s] = v;
+        for (int j = 0; j < nf; j += 2) {
+            read_row(T, imin(j + 1, DTF - 1), RB);
+            decode_frame(T, j, RA);
+            if (j + 1 < nf) {
+                read_row(T, imin(j + 2, DTF - 1), RA);
+                decode_frame(T, j + 1, RB);
             }
-            // a partial last frame decodes all 14 positions here; the flush writes only the valid ones and the
-            // history is not used afterwards
-            T.out[j][0][tid] = make_int4((o[0] & 0xFFFF) | (o[1] << 16), (o[2] & 0xFFFF) | (o[3] << 16),
-                                         (o[4] & 0xFFFF) | (o[5] << 16), (o[6] & 0xFFFF) | (o[7] << 16));
-            T.out[j][1][tid] = make_int4((o[8] & 0xFFFF) | (o[9] << 16), (o[10] & 0xFFFF) | (o[11] << 16),
-                                         (o[12] & 0xFFFF) | (o[13] << 16), 0);
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
