@@ -10,6 +10,8 @@
 #include "common.hpp"
 #include "adx_kernels.hpp"
 
+#include <cstdlib>
+
 namespace vga {
 namespace adx {
 
@@ -396,6 +398,192 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_kernel(
     if (bad && status) atomicOr(status, 1);
 }
 
+// ---------------------------------------------------------------- 18-byte frames, serial wave + helper waves
+// Same division of labour as gc_decode_kernel.hip: three helper waves load the frames one tile ahead, split
+// the header (CriAdxCodec.cs:23-27), pick the coefficient pair and turn every nibble into scale * nibble
+// (:33-35), laid out in LDS for conflict-free b128 reads; the decoder wave (lane = channel) keeps only the
+// recurrence (:36-45): mad, shift, add, clamp per sample.  The helpers also write the previous tile out.
+constexpr int ATF = 4;                                 // frames (of 32 samples) per tile
+struct AdxDecodeTile {
+    int4 dist[ATF][8][64];                             // [frame][eighth][channel]: 32 x scale*nibble
+    int2 coef[ATF][64];                                // [frame][channel]
+    int4 out[ATF][4][64];                              // [frame][quarter][channel]: 32 samples as 16 packed pairs
+};
+
+template <bool V4>
+__global__ __launch_bounds__(256) void adx_decode_fs18_tiled_kernel(
+    const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int sample_count, AdxDeviceParams p,
+    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    AdxDecodeTile *s_tile = reinterpret_cast<AdxDecodeTile *>(s_raw);          // [2]
+    const int tid = threadIdx.x;
+    const int ch0 = blockIdx.x * 64;
+    const int frame_count = (sample_count + 31) / 32;
+    const int tiles = (frame_count + ATF - 1) / ATF;
+
+    if (tid >= 64) {
+        // ------------------------------------------------------------ helper waves (192 lanes)
+        const int hl = tid - 64;
+        bool bad = false;
+        constexpr int ITEMS = (64 * ATF + 191) / 192;
+        struct Raw { uint32_t w[5]; };
+        auto load_tile = [&](int tile, Raw (&raw)[ITEMS]) {          // unconditional loads, clamped frame index
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) {
+                const int item = min(hl + 192 * k, 64 * ATF - 1);
+                const int c = item / ATF, j = item - c * ATF;
+                const int i = min(tile * ATF + j, frame_count - 1);
+                const int ch = min(ch0 + c, nch - 1);
+                const uint16_t *f = reinterpret_cast<const uint16_t *>(adpcm + (int64_t)ch * in_pitch) + (int64_t)i * 9;
+                // frames are 18 bytes: even frames start on a dword, odd ones two bytes after one
+                const uint32_t *f32 = reinterpret_cast<const uint32_t *>(f - (i & 1));
+                uint32_t t[5];
+#pragma unroll
+                for (int q = 0; q < 5; q++) t[q] = f32[q];
+                if (i & 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) raw[k].w[q] = (t[q] >> 16) | (t[q + 1] << 16);
+                    raw[k].w[4] = t[4] >> 16;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 5; q++) raw[k].w[q] = t[q];
+                }
+            }
+        };
+        auto prepare = [&](int tile, const Raw (&raw)[ITEMS]) {
+            AdxDecodeTile &T = s_tile[tile & 1];
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) {
+                const int item = hl + 192 * k;
+                if (item >= 64 * ATF) continue;
+                const int c = item / ATF, j = item - c * ATF;
+                if (tile * ATF + j >= frame_count) continue;
+                const uint32_t(&w)[5] = raw[k].w;
+                const int hb0 = w[0] & 0xff, hb1 = (w[0] >> 8) & 0xff;
+                int filter_num = ((hb0 >> 4) & 0xF) >> 1;
+                int cf0, cf1;
+                if (p.type == 2) {
+                    if (filter_num > 3) { bad = true; filter_num = 3; }
+                    cf0 = filter_num == 0 ? 0 : (filter_num == 1 ? 0x0F00 : (filter_num == 2 ? 0x1CC0 : 0x1880));
+                    cf1 = filter_num == 0 ? 0 : (filter_num == 1 ? 0 : (filter_num == 2 ? (int)(int16_t)0xF300 : (int)(int16_t)0xF240));
+                } else {
+                    if (filter_num > 0) bad = true;
+                    cf0 = p.coef0;
+                    cf1 = p.coef1;
+                }
+                int scale = (int)(int16_t)(((hb0 << 8) | hb1) & 0x1FFF);
+                scale = (int)(int16_t)(p.type == 4 ? (1 << ((12 - scale) & 31)) : scale + 1);
+                T.coef[j][c] = make_int2(cf0, cf1);
+                int d[32];
+#pragma unroll
+                for (int s = 0; s < 32; s++) {
+                    const int byte_index = 2 + (s >> 1);
+                    const int byte = (w[byte_index >> 2] >> (8 * (byte_index & 3))) & 0xff;
+                    const int nib = (s & 1) ? (byte & 0xF) : (byte >> 4);
+                    d[s] = scale * ((nib ^ 8) - 8);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) T.dist[j][q][c] = make_int4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+            }
+        };
+        auto flush = [&](int tile) {
+            const AdxDecodeTile &T = s_tile[tile & 1];
+            for (int item = hl; item < 64 * ATF; item += 192) {
+                const int c = item / ATF, j = item - c * ATF;
+                const int i = tile * ATF + j;
+                if (i >= frame_count || ch0 + c >= nch) continue;
+                int16_t *dst = pcm + (int64_t)(ch0 + c) * pcm_pitch + (int64_t)i * 32;
+                const int to_read = min(32, sample_count - i * 32);
+                if (to_read == 32) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) reinterpret_cast<int4 *>(dst)[q] = T.out[j][q][c];
+                } else {
+                    for (int s = 0; s < to_read; s++) {
+                        const int4 v = T.out[j][s >> 3][c];
+                        const int pair = (s >> 1) & 3;
+                        const uint32_t wv = (uint32_t)(pair == 0 ? v.x : pair == 1 ? v.y : pair == 2 ? v.z : v.w);
+                        dst[s] = (int16_t)(wv >> (16 * (s & 1)));
+                    }
+                }
+            }
+        };
+        Raw ra[ITEMS], rb[ITEMS];
+        load_tile(0, ra);
+        load_tile(1, rb);
+        if (tiles > 0) prepare(0, ra);
+        lds_barrier();
+        for (int tile = 0; tile < tiles; tile += 2) {
+            load_tile(tile + 2, ra);
+            if (tile + 1 < tiles) prepare(tile + 1, rb);
+            if (tile > 0) flush(tile - 1);
+            lds_barrier();
+            if (tile + 1 < tiles) {
+                load_tile(tile + 3, rb);
+                if (tile + 2 < tiles) prepare(tile + 2, ra);
+                flush(tile);
+                lds_barrier();
+            }
+        }
+        if (tiles > 0) flush(tiles - 1);
+        if (bad && status) atomicOr(status, 1);
+        return;
+    }
+
+    // ---------------------------------------------------------------- decoder wave: lane = channel
+    __builtin_amdgcn_s_setprio(3);
+    int hist1 = p.history, hist2 = p.history;
+    struct Row { int2 cf; int4 q[8]; };
+    auto read_row = [&](const AdxDecodeTile &T, int j, Row &R) {
+        R.cf = T.coef[j][tid];
+#pragma unroll
+        for (int q = 0; q < 8; q++) R.q[q] = T.dist[j][q][tid];
+    };
+    auto decode_frame = [&](AdxDecodeTile &T, int j, const Row &R) {
+        int o[32];
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+            const int4 v4 = R.q[s >> 2];
+            const int dist = (s & 3) == 0 ? v4.x : (s & 3) == 1 ? v4.y : (s & 3) == 2 ? v4.z : v4.w;
+            int sample;
+            if (V4) {                                  // :38-39
+                int rest = __mul24(hist2, R.cf.y);
+                asm("" : "+v"(rest));
+                sample = dist + ((__mul24(hist1, R.cf.x) + rest) >> 12);
+            } else {                                   // :41-42
+                int rest = (__mul24(hist2, R.cf.y) >> 12) + dist;
+                asm("" : "+v"(rest));
+                sample = (__mul24(hist1, R.cf.x) >> 12) + rest;
+            }
+            const int fin = clamp16(sample);
+            hist2 = hist1;                             // a partial last frame runs on: nothing reads the history after it
+            hist1 = fin;
+            o[s] = fin;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            T.out[j][q][tid] = make_int4((o[8 * q] & 0xFFFF) | (o[8 * q + 1] << 16), (o[8 * q + 2] & 0xFFFF) | (o[8 * q + 3] << 16),
+                                         (o[8 * q + 4] & 0xFFFF) | (o[8 * q + 5] << 16), (o[8 * q + 6] & 0xFFFF) | (o[8 * q + 7] << 16));
+    };
+    lds_barrier();                                     // tile 0 prepared
+    for (int tile = 0; tile < tiles; tile++) {
+        AdxDecodeTile &T = s_tile[tile & 1];
+        const int nf = min(ATF, frame_count - tile * ATF);
+        Row RA, RB;
+        read_row(T, 0, RA);
+#pragma unroll 1
+        for (int j = 0; j < nf; j += 2) {
+            read_row(T, min(j + 1, ATF - 1), RB);
+            decode_frame(T, j, RA);
+            if (j + 1 < nf) {
+                read_row(T, min(j + 2, ATF - 1), RA);
+                decode_frame(T, j + 1, RB);
+            }
+        }
+        lds_barrier();
+    }
+}
+
 int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_length, const AdxDeviceParams &p,
                   uint8_t *d_out, int64_t out_pitch, int16_t *d_history_out, hipStream_t stream)
 {
@@ -426,7 +614,28 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
     const bool fast = p.frame_size == 18 && p.padding == 0 && (pcm_pitch % 8) == 0 && ((uintptr_t)d_pcm % 16) == 0 &&
                       (in_pitch % 4) == 0 && ((uintptr_t)d_adpcm % 4) == 0;
-    if (fast && p.version == 4)
+    // A/B switch for measurements only: VGA_ADX_DECODE_IMPL=v1 selects the single-wave kernels
+    static const bool use_v1 = [] {
+        const char *e = getenv("VGA_ADX_DECODE_IMPL");
+        return e && e[0] == 'v' && e[1] == '1';
+    }();
+    if (fast && !use_v1) {
+        const size_t lds = 2 * sizeof(AdxDecodeTile);
+        static bool configured = false;
+        if (!configured) {
+            VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(adx_decode_fs18_tiled_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(adx_decode_fs18_tiled_kernel<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            configured = true;
+        }
+        if (p.version == 4)
+            hipLaunchKernelGGL(adx_decode_fs18_tiled_kernel<true>, dim3((nch + 63) / 64), dim3(256), lds, stream, d_adpcm,
+                               in_pitch, nch, sample_count, p, d_pcm, pcm_pitch, d_status);
+        else
+            hipLaunchKernelGGL(adx_decode_fs18_tiled_kernel<false>, dim3((nch + 63) / 64), dim3(256), lds, stream, d_adpcm,
+                               in_pitch, nch, sample_count, p, d_pcm, pcm_pitch, d_status);
+    } else if (fast && p.version == 4)
         hipLaunchKernelGGL(adx_decode_fs18_kernel<true>, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, in_pitch, nch,
                            sample_count, p, d_pcm, pcm_pitch, d_status);
     else if (fast)
