@@ -33,22 +33,34 @@ __host__ __device__ inline size_t record_channel_offset(int c) { return 16 + (si
 __host__ __device__ inline size_t record_q_offset(int nch) { return 16 + (size_t)nch * 272; }
 size_t unpack_record_bytes(int nch) { return (16 + (size_t)nch * 272 + (size_t)8 * nch * 128 * 2 + 15) / 16 * 16; }
 
+// MSB-first bit reader over the stream's (4-byte aligned) frame data: a 64-bit register window plus the next
+// dword, which is fetched as soon as the position is known -- every symbol's length depends on the previous
+// symbol, so without the look-ahead each peek is two dependent memory round trips.  The fetch is
+// unconditional (same address again when no dword boundary was crossed: an L1 hit).
 struct BitCursor {
     const uint32_t *base;   // 4-byte aligned start of the stream's frame data
     int64_t frame_bit0;     // absolute bit position of this frame inside the stream
+    int64_t last_word;      // highest dword index that may be read (frames_pitch / 4 - 1)
     int frame_bits;
     int pos;                // bit position inside the frame (BitReader.Position)
+    int64_t w;              // dword index of the window's first dword
+    uint32_t hi, lo, nxt;   // base[w], base[w+1], base[w+2], byte-swapped
 
+    __device__ __forceinline__ uint32_t fetch(int64_t i) const { return __builtin_bswap32(base[i < last_word ? i : last_word]); }
+    __device__ __forceinline__ void start()
+    {
+        w = frame_bit0 >> 5;
+        hi = fetch(w);
+        lo = fetch(w + 1);
+        nxt = fetch(w + 2);
+    }
     // BitReader.PeekInt (BitReader.cs:51-92): MSB-first; bits past the end of the frame read as 0
     __device__ __forceinline__ int peek(int bits) const
     {
         if (bits == 0) return 0;
-        const int64_t a = frame_bit0 + pos;
-        const int64_t w = a >> 5;
-        const uint64_t hi = __builtin_bswap32(base[w]);
-        const uint64_t lo = __builtin_bswap32(base[w + 1]);
-        const uint64_t win = (hi << 32) | lo;
-        int v = (int)((win << (a & 31)) >> (64 - bits));
+        const int sh = (int)((frame_bit0 + pos) & 31);
+        const uint64_t win = ((uint64_t)hi << 32) | lo;
+        int v = (int)((win << sh) >> (64 - bits));
         const int avail = frame_bits - pos;
         if (bits > avail) {
             if (avail <= 0) return 0;
@@ -56,10 +68,20 @@ struct BitCursor {
         }
         return v;
     }
+    __device__ __forceinline__ void skip(int bits)     // bits <= 32
+    {
+        pos += bits;
+        const int64_t nw = (frame_bit0 + pos) >> 5;
+        const bool adv = nw != w;
+        hi = adv ? lo : hi;
+        lo = adv ? nxt : lo;
+        w = nw;
+        nxt = fetch(nw + 2);
+    }
     __device__ __forceinline__ int read(int bits)
     {
         const int v = peek(bits);
-        pos += bits;
+        skip(bits);
         return v;
     }
 };
@@ -86,6 +108,8 @@ __global__ __launch_bounds__(64) void hca_unpack_kernel(
     r.frame_bit0 = (int64_t)frame * info.frame_size * 8;
     r.frame_bits = info.frame_size * 8;
     r.pos = 0;
+    r.last_word = stream_pitch / 4 - 1;
+    r.start();
     uint8_t *rec = records + (size_t)id * record_bytes;
 
     int flags = 0;
@@ -101,6 +125,7 @@ __global__ __launch_bounds__(64) void hca_unpack_kernel(
         int prev = 0;
         bool failed = false;
         const int max_delta = delta_bits > 0 ? 1 << (delta_bits - 1) : 0;
+        uint32_t sf_pack[4] = {0, 0, 0, 0}, res_pack[4] = {0, 0, 0, 0};
         for (int i = 0; i < 128; i++) {
             int sf = 0;
             if (i < count && delta_bits != 0) {
@@ -108,7 +133,7 @@ __global__ __launch_bounds__(64) void hca_unpack_kernel(
                     sf = r.read(6);
                 } else if (!failed) {
                     const int delta = r.peek(delta_bits) - (max_delta - 1);   // ReadOffsetBinary, positive bias
-                    r.pos += delta_bits;
+                    r.skip(delta_bits);
                     if (delta < max_delta) {
                         sf = prev + delta;
                         if (sf < 0 || sf > 63) { failed = true; sf = 0; }
@@ -119,14 +144,23 @@ __global__ __launch_bounds__(64) void hca_unpack_kernel(
                 prev = sf;
             }
             // delta_bits == 0: Array.Clear of ALL 128 scale factors (:114-118); >= count stay 0 here
-            if (live) rc[i] = (uint8_t)sf;
             int res = 0;
             if (i < count) {
                 const int noise = info.ath_curve[i] + noise_level - (i < eval_boundary ? 1 : 0);
                 res = calculate_resolution(T, sf, noise);
             }
-            if (live) rc[128 + i] = (uint8_t)res;
             s_res[((size_t)c * 128 + i) * 64 + lane] = (uint8_t)res;
+            // the record's byte arrays leave as 16-byte stores (one per 16 bands instead of 32 byte stores)
+            sf_pack[(i >> 2) & 3] |= (uint32_t)sf << (8 * (i & 3));
+            res_pack[(i >> 2) & 3] |= (uint32_t)res << (8 * (i & 3));
+            if ((i & 15) == 15) {
+                if (live) {
+                    *reinterpret_cast<uint4 *>(rc + (i & ~15)) = make_uint4(sf_pack[0], sf_pack[1], sf_pack[2], sf_pack[3]);
+                    *reinterpret_cast<uint4 *>(rc + 128 + (i & ~15)) = make_uint4(res_pack[0], res_pack[1], res_pack[2], res_pack[3]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) sf_pack[k] = res_pack[k] = 0;
+            }
         }
         if (failed) flags |= 2;
         if (info.channel_type[c] == CH_STEREO_SECONDARY) {
@@ -142,6 +176,7 @@ __global__ __launch_bounds__(64) void hca_unpack_kernel(
         for (int c = 0; c < nch; c++) {
             const int count = info.coded_count[c];
             int16_t *qrow = q + ((size_t)sf * nch + c) * 128;
+            uint32_t qp[4] = {0, 0, 0, 0};
             for (int s = 0; s < count; s++) {
                 const int resolution = s_res[((size_t)c * 128 + s) * 64 + lane];
                 int bits = T.max_bits[resolution];
@@ -154,9 +189,17 @@ __global__ __launch_bounds__(64) void hca_unpack_kernel(
                     value = code / 2 * (1 - (code % 2 * 2));
                     if (value == 0) bits--;
                 }
-                r.pos += bits;
-                if (live) qrow[s] = (int16_t)value;
+                r.skip(bits);
+                // eight int16 values per 16-byte store
+                qp[(s >> 1) & 3] |= (uint32_t)(value & 0xFFFF) << (16 * (s & 1));
+                if ((s & 7) == 7) {
+                    if (live) *reinterpret_cast<uint4 *>(qrow + (s & ~7)) = make_uint4(qp[0], qp[1], qp[2], qp[3]);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) qp[k] = 0;
+                }
             }
+            if (live)                                       // a band count that is not a multiple of 8
+                for (int s = count & ~7; s < count; s++) qrow[s] = (int16_t)(qp[(s >> 1) & 3] >> (16 * (s & 1)));
         }
     }
     if (live) {
