@@ -307,9 +307,9 @@ __global__ __launch_bounds__(256) void hca_imdct_kernel(
     for (int c = 0; c < nch; c++) {
         const double *sp = spec + (size_t)c * 9 * 128;
         // 9 transforms: slots 1..8 on the 8 groups, then slot 0 on group 0
-        dct4_128(T, sp + (size_t)(1 + grp) * 128, tmp + grp * 128, dct + (size_t)(1 + grp) * 128, t, [] { __syncthreads(); });
+        dct4_128(T, sp + (size_t)(1 + grp) * 128, tmp + grp * 128, dct + (size_t)(1 + grp) * 128, t, wave_sync);
         __syncthreads();
-        dct4_128(T, sp, tmp + grp * 128, grp == 0 ? dct : tmp + grp * 128 + 0, t, [] { __syncthreads(); });
+        dct4_128(T, sp, tmp + grp * 128, grp == 0 ? dct : tmp + grp * 128 + 0, t, wave_sync);
         __syncthreads();
         // window + overlap-add: out(slot) needs `previous` produced from slot-1's transform
         int16_t *dst = pcm + (int64_t)stream * stream_pitch + (int64_t)c * ch_pitch;

@@ -115,6 +115,13 @@ __device__ __forceinline__ int calculate_resolution(const LdsTables &t, int scal
     return t.res_curve[curve_position];
 }
 
+// The 32 lanes of one transform live in ONE wave, whose LDS operations execute in program order: between
+// butterfly stages only the LDS counter has to drain (and the compiler must not reorder), no s_barrier.
+struct WaveSync {
+    __device__ __forceinline__ void operator()() const { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+};
+constexpr WaveSync wave_sync{};
+
 // DCT-IV of one 128-vector held in LDS, executed by the 32 lanes `t` = 0..31 of a (sub)group.
 // in != tmp; out may be any 128-double LDS array.  Caller synchronises before (inputs written) and
 // after (outputs read).  group_sync(): barrier among the lanes that cooperate on this transform.

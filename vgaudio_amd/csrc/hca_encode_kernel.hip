@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
             }
         }
         __syncthreads();
-        dct4_128(T, dctin + grp * 128, tmp + grp * 128, spectra + ((size_t)c * 8 + grp) * 128, t, [] { __syncthreads(); });
+        dct4_128(T, dctin + grp * 128, tmp + grp * 128, spectra + ((size_t)c * 8 + grp) * 128, t, wave_sync);
         __syncthreads();
     }
 
