@@ -1,0 +1,27 @@
+"""Times hca_encode on every library under tools/variants/ (ablation builds that stop after a phase)."""
+import glob, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import sys, ctypes as C, torch
+sys.path.insert(0, %r)
+from vgaudio_amd import _lib, device as vdev
+L = _lib.lib(); dev = torch.device("cuda:0"); n = 2880000; ns = 1024
+hp = _lib.HcaParamsC(2, 0, 0, 2, 48000, n, 0, 0, 0); info = _lib.HcaInfoC()
+_lib.check(L.vga_hca_encoder_initialize(C.byref(hp), C.byref(info)))
+spcm = vdev.synth_pcm(ns * 2, n, dev); ch_pitch = spcm.stride(0)
+fpitch = (info.frame_count * info.frame_size + 8 + 15) // 16 * 16
+frames = torch.zeros((ns, fpitch), dtype=torch.uint8, device=dev); status = torch.zeros(1, dtype=torch.int32, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+f = lambda: _lib.check(L.vga_hca_encode_device(spcm.data_ptr(), 2 * ch_pitch, ch_pitch, ns, n, C.byref(info), frames.data_ptr(), fpitch, status.data_ptr(), st))
+f(); torch.cuda.synchronize(); ts = []
+for _ in range(2):
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record(); f(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+print("hca_encode ms %%.1f" %% min(ts))
+''' % ROOT
+for lib in [None] + sorted(glob.glob(os.path.join(ROOT, "tools", "variants", "libvga_*.so"))):
+    env = dict(os.environ)
+    if lib:
+        env["VGAUDIO_HIP_LIBRARY"] = lib
+    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
+    print("%-28s %s" % (os.path.basename(lib) if lib else "product", (r.stdout.strip() or r.stderr.strip()[-300:])), flush=True)

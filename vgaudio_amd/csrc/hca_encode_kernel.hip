@@ -82,14 +82,43 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     const int frame = blockIdx.x % info.frame_count;
     const int fwords = (info.frame_size + 3) / 4 + 2;
 
+    // block-wide sum / exclusive scan: wave-level shuffles, then ONE barrier for the four wave totals (the slot
+    // set alternates, so the next call cannot overwrite totals a slower wave has not read yet)
+    int red_par = 0;
     auto block_sum = [&](int v) -> int {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) red[wave] = v;
+        int *slot = red + 8 * red_par;
+        red_par ^= 1;
+        if (lane == 0) slot[wave] = v;
         __syncthreads();
-        const int total = red[0] + red[1] + red[2] + red[3];
+        return slot[0] + slot[1] + slot[2] + slot[3];
+    };
+    auto wave_inclusive_scan = [&](int v) -> int {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(v, o);
+            if (lane >= o) v += t;
+        }
+        return v;
+    };
+    // exclusive scan over groups of `waves_per_group` consecutive waves (4: the whole block; 2: one channel's
+    // 128 bands); total = the group's sum
+    auto group_exclusive_scan = [&](int v, int waves_per_group, int &total) -> int {
+        const int incl = wave_inclusive_scan(v);
+        int *slot = red + 8 * red_par;
+        red_par ^= 1;
+        if (lane == 63) slot[wave] = incl;
         __syncthreads();
-        return total;
+        const int first = wave / waves_per_group * waves_per_group;
+        int base = 0;
+        total = 0;
+        for (int w = first; w < first + waves_per_group; w++) {
+            const int t = slot[w];
+            if (w < wave) base += t;
+            total += t;
+        }
+        return base + incl - v;
     };
     auto put_bits = [&](int off, unsigned value, int nbits) {
         if (nbits <= 0) return;
@@ -132,6 +161,9 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
         __syncthreads();
     }
 
+#if defined(VGA_HCA_ABL_STOP) && VGA_HCA_ABL_STOP == 1   // ablation builds (timing only)
+    return;
+#endif
     // ---- EncodeIntensityStereo (:711-764)
     if (info.stereo_band_count > 0) {
         if (tid < nch * 8) {
@@ -234,6 +266,9 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
         __syncthreads();
     }
 
+#if defined(VGA_HCA_ABL_STOP) && VGA_HCA_ABL_STOP == 2   // ablation builds (timing only)
+    return;
+#endif
     // ---- CalculateFrameHeaderLength (:599-649)
     auto header_lengths = [&]() {
         if (tid < nch * 5) {
@@ -332,6 +367,9 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
         if (tid == 0 && status) atomicOr(status, 4);
         level = 255;
     }
+#if defined(VGA_HCA_ABL_STOP) && VGA_HCA_ABL_STOP == 3   // ablation builds (timing only)
+    return;
+#endif
     // ---- CalculateEvaluationBoundary (:487-500) / BinarySearchBoundary (:525-552)
     int boundary = 0;
     if (level != 0) {
@@ -353,6 +391,9 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
         }
     }
 
+#if defined(VGA_HCA_ABL_STOP) && VGA_HCA_ABL_STOP == 4   // ablation builds (timing only)
+    return;
+#endif
     // ---- CalculateFrameResolutions (:441-455)
     for (int i = tid; i < nch * 128; i += 256) {
         const int c = i / 128, b = i % 128;
@@ -363,39 +404,43 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     // ---- PackFrame (CriHcaPacking.cs:17-58); a frame the reference refuses ("Bitrate is set too low.")
     // is left zero -- its codes would not fit the frame
     if (tid == 0 && !too_low) fbuf[0] = 0xFFFF0000u | ((unsigned)level << 7) | (unsigned)boundary;
-    if (tid < nch && !too_low) {
-        // WriteScaleFactors (:262-295) + intensity / HFR scales; one lane per channel
-        const int c = tid;
-        int off = 32;
-        for (int k = 0; k < c; k++) off += hlb[k];
-        const int db = dbits[c];
-        const int *sc = sfac + c * 128;
-        put_bits(off, (unsigned)db, 3);
-        off += 3;
-        if (db == 6) {
-            for (int i = 0; i < info.coded_count[c]; i++) { put_bits(off, (unsigned)sc[i], 6); off += 6; }
-        } else if (db != 0) {
-            put_bits(off, (unsigned)sc[0], 6);
-            off += 6;
-            const int max_delta = (1 << (db - 1)) - 1;
-            const unsigned escape = (1u << db) - 1;
-            for (int i = 1; i < info.coded_count[c]; i++) {
-                const int delta = sc[i] - sc[i - 1];
-                if (abs(delta) > max_delta) {
-                    put_bits(off, escape, db);
-                    off += db;
-                    put_bits(off, (unsigned)sc[i], 6);
-                    off += 6;
-                } else {
-                    put_bits(off, (unsigned)(max_delta + delta), db);
-                    off += db;
+    // WriteScaleFactors (:262-295): lane = (channel, band), two channels per pass; the variable-length codes
+    // get their bit offsets from a 128-lane exclusive scan
+    for (int c0 = 0; c0 < nch; c0 += 2) {
+        const int c = c0 + (tid >> 7), band = tid & 127;
+        unsigned code = 0;
+        int nbits = 0;
+        if (c < nch && !too_low) {
+            const int db = dbits[c];
+            const int *sc = sfac + c * 128;
+            if (band == 0) {                           // the 3-bit delta width, then the first scale factor
+                code = (unsigned)db;
+                nbits = 3;
+                if (db != 0) { code = (code << 6) | (unsigned)sc[0]; nbits = 9; }
+            } else if (band < info.coded_count[c] && db != 0) {
+                if (db == 6) { code = (unsigned)sc[band]; nbits = 6; }
+                else {
+                    const int max_delta = (1 << (db - 1)) - 1;
+                    const int delta = sc[band] - sc[band - 1];
+                    if (abs(delta) > max_delta) { code = ((((1u << db) - 1)) << 6) | (unsigned)sc[band]; nbits = db + 6; }
+                    else { code = (unsigned)(max_delta + delta); nbits = db; }
                 }
             }
         }
-        if (info.channel_type[c] == CH_STEREO_SECONDARY) {
-            for (int i = 0; i < 8; i++) { put_bits(off, (unsigned)intensity[c * 8 + i], 4); off += 4; }
-        } else if (info.hfr_group_count > 0) {
-            for (int i = 0; i < info.hfr_group_count; i++) { put_bits(off, (unsigned)hfrs[c * 8 + i], 6); off += 6; }
+        int total;
+        const int rel = group_exclusive_scan(nbits, 2, total);
+        if (c < nch && !too_low) {
+            int off = 32;
+            for (int k = 0; k < c; k++) off += hlb[k];
+            put_bits(off + rel, code, nbits);
+            if (band == 0) {                           // intensity / HFR scales follow the scale factors
+                off += total;
+                if (info.channel_type[c] == CH_STEREO_SECONDARY) {
+                    for (int i = 0; i < 8; i++) { put_bits(off, (unsigned)intensity[c * 8 + i], 4); off += 4; }
+                } else if (info.hfr_group_count > 0) {
+                    for (int i = 0; i < info.hfr_group_count; i++) { put_bits(off, (unsigned)hfrs[c * 8 + i], 6); off += 6; }
+                }
+            }
         }
     }
     // WriteSpectra (:238-260) in (sub-frame, channel, band) order: slot = (sf*nch + c)*128 + band;
@@ -429,15 +474,8 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
             local += nbits;
         }
         // exclusive scan of `local` over the 256 threads
-        scan[tid] = local;
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            const int v = tid >= o ? scan[tid - o] : 0;
-            __syncthreads();
-            scan[tid] += v;
-            __syncthreads();
-        }
-        int off = 32 + scan[tid] - local;
+        int all_bits;
+        int off = 32 + group_exclusive_scan(local, 4, all_bits);
         for (int c = 0; c < nch; c++) off += hlb[c];
         for (int k = 0; k < per_thread && !too_low; k++) {
             unsigned code;
@@ -449,6 +487,9 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     }
     __syncthreads();
 
+#if defined(VGA_HCA_ABL_STOP) && VGA_HCA_ABL_STOP == 5   // ablation builds (timing only)
+    return;
+#endif
     // ---- WriteChecksum (:231-236): CRC-16 (poly 0x8005, init 0) over the first frame_size-2 bytes
     {
         const int nbytes = info.frame_size - 2;
