@@ -191,7 +191,7 @@ def main():
                     "issue": issue}
 
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg runs at N=1 only (rank 0's host cores)
             threads, cpu_note = usable_cpus()
             cch = args.cpu_channels or min(nch, 24 * threads)
             host = pcm[:cch, :n].cpu().numpy()
