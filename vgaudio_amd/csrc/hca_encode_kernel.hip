@@ -47,7 +47,71 @@ __device__ __forceinline__ unsigned gf_mul(unsigned a, unsigned b)
     return r;
 }
 
-__global__ __launch_bounds__(256) void hca_encode_kernel(
+// CalculateUsedBits (:554-597) for one band: the bits its eight scaled coefficients cost at resolution `res`
+__device__ __forceinline__ int band_cost(const LdsTables &T, const double *x, int res)
+{
+    int cost = 0;
+    if (res >= 8) {
+        const int bits = T.max_bits[res] - 1;
+        const double d = T.dead_zone[res];
+#pragma unroll
+        for (int sf = 0; sf < 8; sf++) cost += bits + (fabs(x[sf]) >= d ? 1 : 0);
+    } else {
+        const double inv = T.inv_step[res];
+        const double up = inv + 1;
+        const int down = trunc_i(inv + 0.5 - 8);
+#pragma unroll
+        for (int sf = 0; sf < 8; sf++) {
+            const int q = trunc_i(x[sf] * inv + up) - down;
+            cost += T.enc_bits[res][q];
+        }
+    }
+    return cost;
+}
+
+// 16 costs (each <= 8 * 12 bits) packed into four dwords, plus a "known" bit per resolution
+struct UsedBitsMemo {
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, known = 0;
+};
+
+// this thread's share of the frame's spectrum bits.  Up to two channels a thread owns one band and memoises
+// its costs; with more it owns several bands and recomputes.
+__device__ __forceinline__ int used_bits_partial(const LdsTables &T, int tid, int nch, const int *s_coded, const int *sfac,
+                                                 const double *scaled, int noise_level, int eval_boundary, UsedBitsMemo &m)
+{
+    int partial = 0;
+    if (nch * 128 <= 256) {
+        const int i = min(tid, nch * 128 - 1);
+        const int c = i / 128, b = i % 128;
+        const bool valid = tid < nch * 128 && b < s_coded[c];
+        const int noise = b < eval_boundary ? noise_level - 1 : noise_level;
+        const int res = calculate_resolution(T, sfac[i], noise);
+        const int word = res >> 2, shift = 8 * (res & 3);
+        const bool miss = valid && !((m.known >> res) & 1u);
+        if (__any(miss)) {                             // wave-uniform: all lanes evaluate, the missing ones keep it
+            const uint32_t cost = (uint32_t)band_cost(T, scaled + (size_t)i * 8, res) << shift;
+            m.w0 |= (miss && word == 0) ? cost : 0u;
+            m.w1 |= (miss && word == 1) ? cost : 0u;
+            m.w2 |= (miss && word == 2) ? cost : 0u;
+            m.w3 |= (miss && word == 3) ? cost : 0u;
+            m.known |= miss ? 1u << res : 0u;
+        }
+        const uint32_t wsel = word == 0 ? m.w0 : word == 1 ? m.w1 : word == 2 ? m.w2 : m.w3;
+        partial = valid ? (int)((wsel >> shift) & 0xFFu) : 0;
+    } else {
+        for (int i = tid; i < nch * 128; i += 256) {
+            const int c = i / 128, b = i % 128;
+            if (b >= s_coded[c]) continue;
+            const int noise = b < eval_boundary ? noise_level - 1 : noise_level;
+            partial += band_cost(T, scaled + (size_t)i * 8, calculate_resolution(T, sfac[i], noise));
+        }
+    }
+    return partial;
+}
+
+// LDS limits the kernel to 3-4 workgroups (12-16 waves) per CU; without the occupancy hint hipcc aims for 10
+// waves per SIMD, caps itself at 48 VGPRs and spills pointers to scratch
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void hca_encode_kernel(
     const int16_t *__restrict__ pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, PcmMap map,
     DeviceInfo info, uint8_t *__restrict__ frames, int64_t frames_pitch, const uint16_t *__restrict__ crc_pow,
     int *__restrict__ status)
@@ -85,7 +149,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     // block-wide sum / exclusive scan: wave-level shuffles, then ONE barrier for the four wave totals (the slot
     // set alternates, so the next call cannot overwrite totals a slower wave has not read yet)
     int red_par = 0;
-    auto block_sum = [&](int v) -> int {
+    auto block_sum = [&](int v) __attribute__((always_inline)) -> int {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
         int *slot = red + 8 * red_par;
@@ -94,7 +158,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
         __syncthreads();
         return slot[0] + slot[1] + slot[2] + slot[3];
     };
-    auto wave_inclusive_scan = [&](int v) -> int {
+    auto wave_inclusive_scan = [&](int v) __attribute__((always_inline)) -> int {
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int t = __shfl_up(v, o);
@@ -104,7 +168,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     };
     // exclusive scan over groups of `waves_per_group` consecutive waves (4: the whole block; 2: one channel's
     // 128 bands); total = the group's sum
-    auto group_exclusive_scan = [&](int v, int waves_per_group, int &total) -> int {
+    auto group_exclusive_scan = [&](int v, int waves_per_group, int &total) __attribute__((always_inline)) -> int {
         const int incl = wave_inclusive_scan(v);
         int *slot = red + 8 * red_par;
         red_par ^= 1;
@@ -120,7 +184,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
         }
         return base + incl - v;
     };
-    auto put_bits = [&](int off, unsigned value, int nbits) {
+    auto put_bits = [&](int off, unsigned value, int nbits) __attribute__((always_inline)) {
         if (nbits <= 0) return;
         const uint64_t win = (uint64_t)value << (64 - nbits - (off & 31));
         const unsigned hi = (unsigned)(win >> 32), lo = (unsigned)win;
@@ -128,6 +192,17 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
         if (lo) atomicOr(&fbuf[(off >> 5) + 1], lo);
     };
 
+    // per-channel layout in LDS: indexing the by-value kernel argument with a per-lane channel number makes
+    // hipcc copy the whole struct to scratch
+    __shared__ int s_coded[8], s_ctype[8];
+    if (tid < 8) {
+        int cc = 0, ct = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (tid == k) { cc = info.coded_count[k]; ct = info.channel_type[k]; }
+        s_coded[tid] = cc;
+        s_ctype[tid] = ct;
+    }
     for (int i = tid; i < fwords; i += 256) fbuf[i] = 0;
     load_tables(T, tid, 256);
 
@@ -168,7 +243,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     if (info.stereo_band_count > 0) {
         if (tid < nch * 8) {
             const int c = tid / 8, sf = tid % 8;
-            if (info.channel_type[c] == CH_STEREO_PRIMARY) {
+            if (s_ctype[c] == CH_STEREO_PRIMARY) {
                 const double *l = spectra + ((size_t)c * 8 + sf) * 128;
                 const double *r = spectra + ((size_t)(c + 1) * 8 + sf) * 128;
                 double energy_l = 0, energy_r = 0, energy_total = 0;
@@ -197,7 +272,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
         const int nb = info.total_band_count - info.base_band_count;
         for (int i = tid; i < nch * 8 * nb; i += 256) {
             const int c = i / (8 * nb), sf = (i / nb) % 8, b = info.base_band_count + i % nb;
-            if (info.channel_type[c] != CH_STEREO_PRIMARY) continue;
+            if (s_ctype[c] != CH_STEREO_PRIMARY) continue;
             double *l = spectra + ((size_t)c * 8 + sf) * 128;
             double *r = spectra + ((size_t)(c + 1) * 8 + sf) * 128;
             l[b] = (l[b] + r[b]) * eratio[c * 8 + sf];
@@ -210,7 +285,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     for (int i = tid; i < nch * 128; i += 256) {
         const int c = i / 128, b = i % 128;
         int sfv = 0;
-        if (b < info.coded_count[c]) {
+        if (b < s_coded[c]) {
             double mx = 0;
             for (int sf = 0; sf < 8; sf++) {
                 const double coeff = fabs(spectra[((size_t)c * 8 + sf) * 128 + b]);
@@ -226,7 +301,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
         const int c = i / 1024, b = (i / 8) % 128, sf = i % 8;
         const int sfv = sfac[c * 128 + b];
         double v = 0;
-        if (b < info.coded_count[c] && sfv != 0)
+        if (b < s_coded[c] && sfv != 0)
             v = clampd(spectra[((size_t)c * 8 + sf) * 128 + b] * T.quant_scale[sfv],
                        -0.999999999999, 0.999999999999);
         scaled[i] = v;
@@ -237,7 +312,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     if (info.hfr_group_count > 0) {
         if (tid < nch * 8) {
             const int c = tid / 8, group = tid % 8;
-            if (group < info.hfr_group_count && info.channel_type[c] != CH_STEREO_SECONDARY) {
+            if (group < info.hfr_group_count && s_ctype[c] != CH_STEREO_SECONDARY) {
                 const int hfr_start = info.stereo_band_count + info.base_band_count;
                 double sum = 0.0;
                 int count = 0;
@@ -270,12 +345,12 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     return;
 #endif
     // ---- CalculateFrameHeaderLength (:599-649)
-    auto header_lengths = [&]() {
+    auto header_lengths = [&]() __attribute__((always_inline)) {
         if (tid < nch * 5) {
             const int c = tid / 5, db = 1 + tid % 5;
             const int max_delta = (1 << (db - 1)) - 1;
             int length = 3 + 6;
-            for (int band = 1; band < info.coded_count[c]; band++) {
+            for (int band = 1; band < s_coded[c]; band++) {
                 const int delta = sfac[c * 128 + band] - sfac[c * 128 + band - 1];
                 length += abs(delta) > max_delta ? db + 6 : db;
             }
@@ -283,7 +358,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
         } else if (tid >= 64 && tid < 64 + nch) {
             const int c = tid - 64;
             int e = 1;
-            for (int i = 0; i < info.coded_count[c]; i++)
+            for (int i = 0; i < s_coded[c]; i++)
                 if (sfac[c * 128 + i] != 0) { e = 0; break; }
             empty[c] = e;
         }
@@ -294,11 +369,11 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
             if (empty[c]) { len = 3; db = 0; }
             else {
                 db = 6;
-                len = 3 + 6 * info.coded_count[c];
+                len = 3 + 6 * s_coded[c];
                 for (int k = 1; k < 6; k++)
                     if (cand[c * 8 + k] < len) { len = cand[c * 8 + k]; db = k; }
             }
-            if (info.channel_type[c] == CH_STEREO_SECONDARY) len += 32;
+            if (s_ctype[c] == CH_STEREO_SECONDARY) len += 32;
             else if (info.hfr_group_count > 0) len += 6 * info.hfr_group_count;
             hlb[c] = len;
             dbits[c] = db;
@@ -308,30 +383,13 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     header_lengths();
 
     // ---- CalculateUsedBits (:554-597) as a block reduction
-    auto used_bits = [&](int noise_level, int eval_boundary) -> int {
-        int partial = 0;
-        for (int i = tid; i < nch * 128; i += 256) {
-            const int c = i / 128, b = i % 128;
-            if (b >= info.coded_count[c]) continue;
-            const int noise = b < eval_boundary ? noise_level - 1 : noise_level;
-            const int res = calculate_resolution(T, sfac[i], noise);
-            const double *x = scaled + (size_t)i * 8;
-            if (res >= 8) {
-                const int bits = T.max_bits[res] - 1;
-                const double d = T.dead_zone[res];
-#pragma unroll
-                for (int sf = 0; sf < 8; sf++) partial += bits + (fabs(x[sf]) >= d ? 1 : 0);
-            } else {
-                const double inv = T.inv_step[res];
-                const double up = inv + 1;
-                const int down = trunc_i(inv + 0.5 - 8);
-#pragma unroll
-                for (int sf = 0; sf < 8; sf++) {
-                    const int q = trunc_i(x[sf] * inv + up) - down;
-                    partial += T.enc_bits[res][q];
-                }
-            }
-        }
+    // The bit cost of a band's eight coefficients depends only on its resolution (the scaled spectra are
+    // fixed), and the two binary searches come back to the same few resolutions: every (band, resolution)
+    // cost is computed once and kept in registers (UsedBitsMemo).  used_bits_block() is a free function, not a
+    // lambda: with the memo updated inside a capturing lambda hipcc kept every captured local in scratch.
+    UsedBitsMemo memo;
+    auto used_bits = [&](int noise_level, int eval_boundary) __attribute__((always_inline)) -> int {
+        const int partial = used_bits_partial(T, tid, nch, s_coded, sfac, scaled, noise_level, eval_boundary, memo);
         int total = block_sum(partial) + 16 + 16 + 16;
         for (int c = 0; c < nch; c++) total += hlb[c];
         return total;
@@ -339,7 +397,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
 
     // ---- CalculateNoiseLevel (:457-485) / BinarySearchLevel (:502-523)
     const int available = info.frame_size * 8;
-    auto search_level = [&]() -> int {
+    auto search_level = [&]() __attribute__((always_inline)) -> int {
         int low = 0, high = 255, mid_value = 0;
         while (low != high) {
             const int mid = (low + high) / 2;
@@ -397,7 +455,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     // ---- CalculateFrameResolutions (:441-455)
     for (int i = tid; i < nch * 128; i += 256) {
         const int c = i / 128, b = i % 128;
-        ires[i] = b < info.coded_count[c] ? calculate_resolution(T, sfac[i], b < boundary ? level - 1 : level) : 0;
+        ires[i] = b < s_coded[c] ? calculate_resolution(T, sfac[i], b < boundary ? level - 1 : level) : 0;
     }
     __syncthreads();
 
@@ -417,7 +475,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
                 code = (unsigned)db;
                 nbits = 3;
                 if (db != 0) { code = (code << 6) | (unsigned)sc[0]; nbits = 9; }
-            } else if (band < info.coded_count[c] && db != 0) {
+            } else if (band < s_coded[c] && db != 0) {
                 if (db == 6) { code = (unsigned)sc[band]; nbits = 6; }
                 else {
                     const int max_delta = (1 << (db - 1)) - 1;
@@ -435,7 +493,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
             put_bits(off + rel, code, nbits);
             if (band == 0) {                           // intensity / HFR scales follow the scale factors
                 off += total;
-                if (info.channel_type[c] == CH_STEREO_SECONDARY) {
+                if (s_ctype[c] == CH_STEREO_SECONDARY) {
                     for (int i = 0; i < 8; i++) { put_bits(off, (unsigned)intensity[c * 8 + i], 4); off += 4; }
                 } else if (info.hfr_group_count > 0) {
                     for (int i = 0; i < info.hfr_group_count; i++) { put_bits(off, (unsigned)hfrs[c * 8 + i], 6); off += 6; }
@@ -447,7 +505,7 @@ __global__ __launch_bounds__(256) void hca_encode_kernel(
     // QuantizeSpectra (:420-439) on the fly
     {
         const int per_thread = nch * 4;               // nch*8*128 / 256, divides 128
-        auto code_of = [&](int slot, unsigned &code, int &nbits) {
+        auto code_of = [&](int slot, unsigned &code, int &nbits) __attribute__((always_inline)) {
             const int sf = slot / (nch * 128), c = (slot / 128) % nch, band = slot % 128;
             const int res = ires[c * 128 + band];
             code = 0;
