@@ -317,3 +317,42 @@ def test_aligned_sine_kats_on_device():
         want = synth.sine(ch.SampleCount, 1, 56)
         end = -(-ch.SampleCount // 14) * 14 - 14
         assert np.abs(want[56:end].astype(int) - ch.GetPcmAudio()[56:end].astype(int)).max() <= tol
+
+
+def test_encode_decode_fuzz_mixed_signals():
+    """Random concatenations of signal classes at random levels: level jumps between frames exercise the third and
+    later quantise passes, the cap at scale 12 and the bump loop far more often than stationary signals do."""
+    rng = np.random.default_rng(2024)
+    n = 14 * 1500 + 5
+    chans = []
+    for _ in range(48):
+        parts, total = [], 0
+        while total < n:
+            m = int(rng.integers(7, 400))
+            amp = int(rng.choice([1, 3, 40, 700, 9000, 32767]))
+            kind = rng.integers(0, 6)
+            t = np.arange(m)
+            if kind == 0:
+                seg = np.zeros(m)
+            elif kind == 1:
+                seg = rng.integers(-amp, amp + 1, m)
+            elif kind == 2:
+                seg = amp * np.sin(t * rng.uniform(0.01, 3.1))
+            elif kind == 3:
+                seg = np.where((t // int(rng.integers(1, 9))) % 2 == 0, amp, -amp - 1)
+            elif kind == 4:
+                seg = np.cumsum(rng.integers(-amp // 8 - 1, amp // 8 + 2, m))
+            else:
+                seg = np.full(m, rng.integers(-amp - 1, amp + 1))
+            parts.append(np.clip(seg, -32768, 32767))
+            total += m
+        chans.append(np.concatenate(parts)[:n].astype(np.int16))
+    coefs = GcAdpcmCoefficients.CalculateCoefficients(chans)
+    got = GcAdpcmEncoder.Encode(chans, coefs)
+    dec = GcAdpcmDecoder.Decode(got, coefs, GcAdpcmParameters(SampleCount=n))
+    for c in range(len(chans)):
+        want_coefs = po.gc_calculate_coefficients(chans[c])
+        assert (np.asarray(coefs[c]) == want_coefs).all(), c
+        want = po.gc_encode(chans[c], want_coefs)
+        assert (got[c] == want).all(), (c, int(np.argmax(got[c] != want)))
+        assert (dec[c] == po.gc_decode(want, want_coefs, n)).all(), c
