@@ -832,7 +832,11 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
 #endif
             valid = r.valid;
             if (valid) matrix_filter(r.r1, r.r2, d1, d2);
-            rec[f] = valid ? make_double2(r.r1, r.r2) : make_double2(__builtin_nan(""), 0.0);
+            // The scratch keeps MatrixFilter's output (dst[1], dst[2]), not the record: it is all the later
+            // passes need -- ContrastVectors' `val` (:335-342) is the same expression as mtx[1][1] = dst[1]
+            // (:295-296) and its second term, -r1*val + -r2, the same as dst[2] (sign flips are exact; a
+            // -0.0 / +0.0 difference cannot change a comparison or a sum that started at +0.0).
+            rec[f] = valid ? make_double2(d1, d2) : make_double2(__builtin_nan(""), 0.0);
         }
         const uint64_t mask = __ballot(valid);
         const int n = __popcll(mask);
@@ -896,18 +900,17 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
                 r_next = rec[min(f + 64, frames - 1)];               // in flight during this chunk
                 if (f < frames && r.x == r.x) {
                     valid = true;
-                    // ContrastVectors :335-342 (val) == MatrixFilter :295-296 (mtx[1][1])
-                    const double val = (r.y * r.x + -r.x) / (1.0 - r.y * r.y);
-                    const double bterm = (-r.x * val + -r.y);
-                    const double val_x2 = 2.0 * val, bterm_x2 = 2.0 * bterm;
+                    // r = (dst[1], dst[2]) of MatrixFilter, stored by pass 0 (one f64 divide per frame there,
+                    // none here)
+                    const double val_x2 = 2.0 * r.x, bterm_x2 = 2.0 * r.y;
                     double value = 1.0e30;
 #pragma unroll
                     for (int i = 0; i < EXP; i++) {
                         const double t = cw1[i] + (val_x2 * cw2[i]) + (bterm_x2 * cw3[i]);
                         if (t < value) { value = t; idx = i; }
                     }
-                    d1 = 0.0 + val * 1.0;                       // dst[1] = 0.0 + mtx[1][1]*dst[0]
-                    d2 = (0.0 + (-r.x) * d1) + (-r.y) * 1.0;    // dst[2]
+                    d1 = r.x;
+                    d2 = r.y;
                 }
                 // stable partition by bucket
                 int slot = 0, my_start = 0, my_n = 0, start = 0, max_n = 0;
