@@ -114,6 +114,64 @@ __device__ __noinline__ GenericOut resume_generic(X16 xs, int c0, int c1, int sc
     return o;
 }
 
+// Third and later trips / the generic redo for one frame.  Its mere presence in the frame loop costs the hot
+// path (VGA_X_COLD_NEVER build, block compiled in but never run: 172 ms vs 140 ms without it), which is why the
+// frame's tail is instantiated once per branch below instead of merging the two branches' results.
+#ifdef VGA_X_COUNT          // experiment builds: how often does a wave take the cold block, and why
+__device__ unsigned long long vga_dbg[8];
+extern "C" int vga_debug_counters(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vga_dbg), sizeof(vga_dbg));
+}
+#endif
+struct ColdState {
+    int x[16], m[14], mp[14];
+    int c0, c1, s1;
+    int cand_b, rare, resume;
+};
+struct ColdOut { PassOut r; int final_sp; int fin; };
+#ifdef VGA_ENC_COLD_OUTLINE      // experiment: 370 ms out of line (the by-value state goes through scratch) vs 209 inline
+__device__ __noinline__
+#else
+__device__ __forceinline__
+#endif
+ColdOut encode_frame_cold(ColdState st, PassOut r, int final_sp, int fin)
+{
+    int x[16], m[14], mp[14];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = st.x[i];
+#pragma unroll
+    for (int i = 0; i < 14; i++) { m[i] = st.m[i]; mp[i] = st.mp[i]; }
+    const bool redo = __any(st.rare != 0);         // whole frame again, the reference's loop as written
+    if (redo) {
+        fin = 0;
+        if (!st.cand_b) {
+            r = resume_passes(x, st.c0, st.c1, st.s1 - 1, final_sp);
+            fin = 1;
+        }
+    } else if (st.resume) {
+        // third and later trips of the A lane, same straight-line tests as the first trip
+        int sp = st.s1 + 1;                        // < 12: neither candidate was at the cap
+        for (;;) {
+            sp++;
+            r = pass_fast_core(x, m, mp, st.c0, st.c1, sp);
+            const bool cap = sp >= 12;
+            if ((unsigned)r.max_overflow > (cap ? 3u : 248u)) {      // bump loop / inexact sum: generic
+                r = resume_passes(x, st.c0, st.c1, sp - 1, final_sp);
+                break;
+            }
+            final_sp = sp;
+            if (cap || r.max_overflow <= 1) break;
+        }
+        fin = 1;
+    }
+    ColdOut o;
+    o.r = r;
+    o.final_sp = final_sp;
+    o.fin = fin;
+    return o;
+}
+
 __global__ __launch_bounds__(128) void gc_encode_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int sample_count,
     const int16_t *__restrict__ coefs, const int16_t *__restrict__ hist1,
@@ -298,6 +356,9 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
 #endif
         }
         VGA_MARK("prescan_end");
+#ifdef VGA_X_COUNT
+        if (lane == 0) atomicAdd(&vga_dbg[0], 1ull);
+#endif
         // ---- first trip: candidate A at s1, B at s1+1 (speculation on the loop of :127-170)
         int final_sp = imin(s1 + (cand_b ? 1 : 0), 12);
         const bool at_cap = final_sp >= 12;            // the loop never goes past 12: this pass ends it
@@ -319,84 +380,86 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
         bool fin = eff < 2 && (eff_other | (cand_b ? 0 : 2)) >= 2;
         const bool resume = !cand_b && imin(eff, eff_other) >= 2;     // both overflowed: A carries on at s1+2
         const bool wide = fin && total32 >= (1u << 28);
-        int winner;
-        bool need64 = false;
-#if !defined(VGA_EXPERIMENT_NO_COLD)
-        if (__builtin_expect(__any(rare || resume || wide), 0)) {
-            // ---- cold block (resume: ~40 % of wave-frames on audio; rare: hostile input only)
-            const bool redo = __any(rare);             // whole frame again, the reference's loop as written
-            if (redo) {
-                fin = false;
-                if (!cand_b) {
-                    const GenericOut g = resume_generic(pack(x), c0, c1, s1 - 1);
-                    r = g.r;
-                    final_sp = g.final_sp;
-                    fin = true;
-                }
-            } else if (resume) {
-                // third and later trips of the A lane, same straight-line tests as the first trip
-                int sp = s1 + 1;                       // < 12: neither candidate was at the cap
-                for (;;) {
-                    sp++;
-                    r = pass_fast_core(x, R.m, R.mp, c0, c1, sp);
-                    const bool cap = sp >= 12;
-                    if ((unsigned)r.max_overflow > (cap ? 3u : 248u)) {      // bump loop / inexact sum: generic
-                        const GenericOut g = resume_generic(pack(x), c0, c1, sp - 1);
-                        r = g.r;
-                        final_sp = g.final_sp;
-                        break;
-                    }
-                    final_sp = sp;
-                    if (cap || r.max_overflow <= 1) break;
-                }
-                fin = true;
-            }
-            need64 = __any(fin && (r.total >> 28) != 0);
-        }
-#endif
-        // ---- argmin over the 8 predictors, first index wins ties (:66-76)
-        if (__builtin_expect(need64, 0)) {
-            uint64_t key = fin ? ((r.total << 4) | (uint64_t)l16) : ~0ull;
+        // ---- the frame's tail: argmin over the 8 predictors (first index wins ties, :66-76), winner's history
+        // broadcast, winner's record to LDS.  A lambda so that the hot and the cold branch each get their own
+        // copy: merging the two branches' PassOut registers instead put the copies on the hot path.
+        auto finish = [&](const PassOut &r, int final_sp, bool fin, bool need64) __attribute__((always_inline)) {
+            int winner;
+            if (__builtin_expect(need64, 0)) {
+                uint64_t key = fin ? ((r.total << 4) | (uint64_t)l16) : ~0ull;
 #define VGA_MIN64_STAGE(CTRL)                                                          \
-            {                                                                          \
-                const unsigned olo = (unsigned)dpp<CTRL>((int)(uint32_t)key);          \
-                const unsigned ohi = (unsigned)dpp<CTRL>((int)(uint32_t)(key >> 32));  \
-                const uint64_t okey = ((uint64_t)ohi << 32) | olo;                     \
-                key = okey < key ? okey : key;                                         \
-            }
-            VGA_MIN64_STAGE(DPP_QUAD_XOR1)
-            VGA_MIN64_STAGE(DPP_QUAD_XOR2)
-            VGA_MIN64_STAGE(DPP_ROW_HALF_MIRROR)
-            VGA_MIN64_STAGE(DPP_ROW_MIRROR)
+                {                                                                          \
+                    const unsigned olo = (unsigned)dpp<CTRL>((int)(uint32_t)key);          \
+                    const unsigned ohi = (unsigned)dpp<CTRL>((int)(uint32_t)(key >> 32));  \
+                    const uint64_t okey = ((uint64_t)ohi << 32) | olo;                     \
+                    key = okey < key ? okey : key;                                         \
+                }
+                VGA_MIN64_STAGE(DPP_QUAD_XOR1)
+                VGA_MIN64_STAGE(DPP_QUAD_XOR2)
+                VGA_MIN64_STAGE(DPP_ROW_HALF_MIRROR)
+                VGA_MIN64_STAGE(DPP_ROW_MIRROR)
 #undef VGA_MIN64_STAGE
-            winner = (int)(key & 15u);
-        } else {
-            const unsigned key = fin ? (((unsigned)r.total << 4) | (unsigned)l16) : 0xFFFFFFFFu;
-            const unsigned best = row16_reduce(key, [](unsigned a, unsigned b) { return a < b ? a : b; });
-            winner = (int)(best & 15u);
-        }
-        VGA_MARK("resolve_end");
-        const bool won = l16 == winner;
+                winner = (int)(key & 15u);
+            } else {
+                const unsigned key = fin ? (((unsigned)r.total << 4) | (unsigned)l16) : 0xFFFFFFFFu;
+                const unsigned best = row16_reduce(key, [](unsigned a, unsigned b) { return a < b ? a : b; });
+                winner = (int)(best & 15u);
+            }
+            VGA_MARK("resolve_end");
+            const bool won = l16 == winner;
 #ifdef VGA_ABL_PAY          // ablation (timing only): every lane continues from its own history
-        const unsigned pay_own = (unsigned)(r.o12 & 0xFFFF) | ((unsigned)r.o13 << 16);
+            const unsigned pay_own = (unsigned)(r.o12 & 0xFFFF) | ((unsigned)r.o13 << 16);
 #define row16_reduce(v, f) pay_own
 #endif
-        const unsigned pay = row16_reduce(won ? ((unsigned)(r.o12 & 0xFFFF) | ((unsigned)r.o13 << 16)) : 0u,
-                                          [](unsigned a, unsigned b) { return a | b; });
-        if (won) {                                           // packed and flushed by the helper, a tile at a time
-            int4 *rec = &s_out[buf][grp][j][0];
-            rec[0] = make_int4(r.q[0], r.q[1], r.q[2], r.q[3]);
-            rec[1] = make_int4(r.q[4], r.q[5], r.q[6], r.q[7]);
-            rec[2] = make_int4(r.q[8], r.q[9], r.q[10], r.q[11]);
-            rec[3] = make_int4(r.q[12], r.q[13], p, final_sp);
-        }
+            const unsigned pay = row16_reduce(won ? ((unsigned)(r.o12 & 0xFFFF) | ((unsigned)r.o13 << 16)) : 0u,
+                                              [](unsigned a, unsigned b) { return a | b; });
+            if (won) {                                           // packed and flushed by the helper, a tile at a time
+                int4 *rec = &s_out[buf][grp][j][0];
+                rec[0] = make_int4(r.q[0], r.q[1], r.q[2], r.q[3]);
+                rec[1] = make_int4(r.q[4], r.q[5], r.q[6], r.q[7]);
+                rec[2] = make_int4(r.q[8], r.q[9], r.q[10], r.q[11]);
+                rec[3] = make_int4(r.q[12], r.q[13], p, final_sp);
+            }
 #ifdef VGA_ABL_PAY
 #undef row16_reduce
 #endif
-        h0 = (int)(int16_t)(pay & 0xFFFF);   // pcmBuffer[0] = pcmBuffer[14] (:40)
-        h1 = (int)pay >> 16;                 // pcmBuffer[1] = pcmBuffer[15] (:41)
-        VGA_OPAQUE(h0);                      // hide the 16-bit range: keeps the 24-bit multiplies the next frame
-        VGA_OPAQUE(h1);                      // asks for (the compiler otherwise widens them to 64-bit mads)
+            h0 = (int)(int16_t)(pay & 0xFFFF);   // pcmBuffer[0] = pcmBuffer[14] (:40)
+            h1 = (int)pay >> 16;                 // pcmBuffer[1] = pcmBuffer[15] (:41)
+            VGA_OPAQUE(h0);                      // hide the 16-bit range: keeps the 24-bit multiplies the next frame
+            VGA_OPAQUE(h1);                      // asks for (the compiler otherwise widens them to 64-bit mads)
+        };
+#if !defined(VGA_EXPERIMENT_NO_COLD)
+#ifdef VGA_X_COLD_NEVER     // experiment: cold block compiled in, never executed (nch is never negative)
+        if (__builtin_expect(__any(rare || resume || wide) && nch < 0, 0)) {
+#else
+        if (__builtin_expect(__any(rare || resume || wide), 0)) {
+#endif
+#ifdef VGA_X_COUNT
+            {
+                const bool any_rare = __any(rare), any_wide = __any(wide);
+                const int n_resume = __popcll(__ballot(resume));
+                if (lane == 0) {
+                    atomicAdd(&vga_dbg[1], 1ull);
+                    if (any_rare) atomicAdd(&vga_dbg[2], 1ull);
+                    if (n_resume) atomicAdd(&vga_dbg[3], 1ull);
+                    if (any_wide) atomicAdd(&vga_dbg[4], 1ull);
+                    atomicAdd(&vga_dbg[5], (unsigned long long)n_resume);
+                }
+            }
+#endif
+            // ---- cold block (third trips: ~10 % of wave-frames on audio; rare: hostile input only)
+            ColdState st;
+#pragma unroll
+            for (int i = 0; i < 16; i++) st.x[i] = x[i];
+#pragma unroll
+            for (int i = 0; i < 14; i++) { st.m[i] = R.m[i]; st.mp[i] = R.mp[i]; }
+            st.c0 = c0; st.c1 = c1; st.s1 = s1;
+            st.cand_b = cand_b; st.rare = rare; st.resume = resume;
+            const ColdOut o = encode_frame_cold(st, r, final_sp, fin);
+            finish(o.r, o.final_sp, o.fin != 0, __any(o.fin != 0 && (o.r.total >> 28) != 0));
+        } else
+#endif
+        finish(r, final_sp, fin, false);
         VGA_MARK("frame_end");
     };
 
