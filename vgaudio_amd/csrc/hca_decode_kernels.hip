@@ -213,8 +213,11 @@ __global__ __launch_bounds__(64) void hca_unpack_kernel(
 
 // ---- dequantise + IMDCT ----------------------------------------------------------------------
 // LDS: spec[nch][9][128] f64 (slot 0 = previous frame's sub-frame 7, slots 1..8 = this frame),
-//      tmp[8][128] f64 butterfly scratch, dct[9][128] f64 per channel pass.
-__global__ __launch_bounds__(256) void hca_imdct_kernel(
+//      tmp[9][128] f64 butterfly scratch, dct[9][128] f64 per channel pass.
+// 288 threads = nine 32-lane groups: a channel's nine transforms (eight sub-frames + the previous frame's last
+// one for the overlap) run side by side.
+constexpr int IMDCT_THREADS = 288;
+__global__ __launch_bounds__(IMDCT_THREADS) void hca_imdct_kernel(
     const uint8_t *__restrict__ records, size_t record_bytes, int nstreams, DeviceInfo info,
     int16_t *__restrict__ pcm, int64_t stream_pitch, int64_t ch_pitch)
 {
@@ -222,12 +225,12 @@ __global__ __launch_bounds__(256) void hca_imdct_kernel(
     __shared__ LdsTables T;
     const int nch = info.nch;
     double *spec = s_mem;                               // [nch][9][128]
-    double *tmp = spec + (size_t)nch * 9 * 128;         // [8][128]
-    double *dct = tmp + 8 * 128;                        // [9][128]
+    double *tmp = spec + (size_t)nch * 9 * 128;         // [9][128]
+    double *dct = tmp + 9 * 128;                        // [9][128]
     double *gain = dct + 9 * 128;                       // [2][nch][128]: previous frame, this frame
 
     const int tid = threadIdx.x;
-    load_tables(T, tid, 256);
+    load_tables(T, tid, IMDCT_THREADS);
     __syncthreads();
     const int stream = blockIdx.x / info.frame_count;
     const int frame = blockIdx.x % info.frame_count;
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256) void hca_imdct_kernel(
     const uint8_t *rec_prev = frame > 0 ? rec_cur - record_bytes : nullptr;
 
     // CalculateGain (CriHcaDecoder.cs:108-114)
-    for (int i = tid; i < 2 * nch * 128; i += 256) {
+    for (int i = tid; i < 2 * nch * 128; i += IMDCT_THREADS) {
         const int which = i / (nch * 128), c = (i / 128) % nch, s = i % 128;
         const uint8_t *rec = which == 0 ? rec_prev : rec_cur;
         double g = 0.0;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void hca_imdct_kernel(
     __syncthreads();
 
     // DequantizeFrame (:83-100): spectra = q * gain; bands >= coded count are zero (:180)
-    for (int i = tid; i < nch * 9 * 128; i += 256) {
+    for (int i = tid; i < nch * 9 * 128; i += IMDCT_THREADS) {
         const int c = i / (9 * 128), slot = (i / 128) % 9, s = i % 128;
         const uint8_t *rec = slot == 0 ? rec_prev : rec_cur;
         const int sf = slot == 0 ? 7 : slot - 1;
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256) void hca_imdct_kernel(
         const int total_band_count = min(info.total_band_count, 127);
         const int hfr_start = info.base_band_count + info.stereo_band_count;
         const int hfr_bands = min(info.hfr_band_count, total_band_count - info.hfr_band_count);
-        for (int i = tid; i < nch * 9 * hfr_bands; i += 256) {
+        for (int i = tid; i < nch * 9 * hfr_bands; i += IMDCT_THREADS) {
             const int c = i / (9 * hfr_bands), slot = (i / hfr_bands) % 9, band = i % hfr_bands;
             if (info.channel_type[c] == CH_STEREO_SECONDARY) continue;
             const uint8_t *rec = slot == 0 ? rec_prev : rec_cur;
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256) void hca_imdct_kernel(
     // ApplyIntensityStereo (:147-166)
     if (info.stereo_band_count > 0) {
         const int nb = info.total_band_count - info.base_band_count;
-        for (int i = tid; i < nch * 9 * nb; i += 256) {
+        for (int i = tid; i < nch * 9 * nb; i += IMDCT_THREADS) {
             const int c = i / (9 * nb), slot = (i / nb) % 9, b = info.base_band_count + i % nb;
             if (info.channel_type[c] != CH_STEREO_PRIMARY) continue;
             const uint8_t *rec = slot == 0 ? rec_prev : rec_cur;
@@ -306,14 +309,12 @@ __global__ __launch_bounds__(256) void hca_imdct_kernel(
     const int grp = tid >> 5, t = tid & 31;
     for (int c = 0; c < nch; c++) {
         const double *sp = spec + (size_t)c * 9 * 128;
-        // 9 transforms: slots 1..8 on the 8 groups, then slot 0 on group 0
-        dct4_128(T, sp + (size_t)(1 + grp) * 128, tmp + grp * 128, dct + (size_t)(1 + grp) * 128, t, wave_sync);
-        __syncthreads();
-        dct4_128(T, sp, tmp + grp * 128, grp == 0 ? dct : tmp + grp * 128 + 0, t, wave_sync);
+        // 9 transforms, one per 32-lane group: slot 0 = the previous frame's sub-frame 7, slots 1..8 = this frame
+        dct4_128(T, sp + (size_t)grp * 128, tmp + grp * 128, dct + (size_t)grp * 128, t, wave_sync);
         __syncthreads();
         // window + overlap-add: out(slot) needs `previous` produced from slot-1's transform
         int16_t *dst = pcm + (int64_t)stream * stream_pitch + (int64_t)c * ch_pitch;
-        for (int i = tid; i < 8 * 128; i += 256) {
+        for (int i = tid; i < 8 * 128; i += IMDCT_THREADS) {
             const int slot = 1 + i / 128, j = i % 128;
             const double *dc = dct + (size_t)slot * 128;        // this sub-frame's dctOut
             const double *dp = dct + (size_t)(slot - 1) * 128;  // the one before
@@ -348,11 +349,11 @@ int launch_decode(const uint8_t *d_frames, int64_t frames_pitch, int nstreams, c
     hipLaunchKernelGGL(hca_unpack_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), lds1, stream, d_frames,
                        frames_pitch, nstreams, info, reinterpret_cast<uint8_t *>(d_workspace), rb, d_status);
     VGA_HIP_TRY(hipGetLastError());
-    const size_t lds2 = ((size_t)info.nch * 9 * 128 + 8 * 128 + 9 * 128 + (size_t)2 * info.nch * 128) * sizeof(double);
+    const size_t lds2 = ((size_t)info.nch * 9 * 128 + 9 * 128 + 9 * 128 + (size_t)2 * info.nch * 128) * sizeof(double);
     if (lds2 > 64 * 1024)
         VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hca_imdct_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    hipLaunchKernelGGL(hca_imdct_kernel, dim3((unsigned)total), dim3(256), lds2, stream,
+    hipLaunchKernelGGL(hca_imdct_kernel, dim3((unsigned)total), dim3(IMDCT_THREADS), lds2, stream,
                        reinterpret_cast<const uint8_t *>(d_workspace), rb, nstreams, info, d_pcm, stream_pitch, ch_pitch);
     VGA_HIP_TRY(hipGetLastError());
     return VGA_OK;
