@@ -584,6 +584,207 @@ __global__ __launch_bounds__(256) void adx_decode_fs18_tiled_kernel(
     }
 }
 
+// ---------------------------------------------------------------- 18-byte frames, encoder wave + helper waves
+// CriAdxCodec.EncodeFrame (:107-147) with the same division of labour as the decoders: three helper waves load
+// and unpack the 32 samples of every frame one tile ahead, pre-scan the 30 distances that involve input
+// samples only (:112-118; the first two use the reconstructed history) and pack / store the previous tile's
+// nibbles; the encoder wave (lane = channel) keeps the scale computation and the quantise recurrence
+// (:120-138).  scale_short_to_nibble (:167-171) is done on the magnitude: |q| = ((|v| + 2340) * 114692) >> 29 is
+// floor((|v| + 2340) / 4681) for |v| <= 32768 (2^29 / 4681 = 114691.5.., error term 2340 per unit: exact below
+// 229 432), the result is at most 7 so Clamp4 and the Clamp16 of scale * q (scale <= 4096) cannot bind.
+struct AdxEncodeTile {
+    int4 x[ATF][8][64];                                // [frame][eighth][channel]: the 32 input samples
+    int pmax[ATF][64];                                 // max |Clamp16(distance)| over samples 2..31
+    int4 q[ATF][8][64];                                // encoder output: 32 nibbles (-7..7)
+    int hdr[ATF][64];                                  // encoder output: the 16 header bits (scale, filter)
+};
+
+template <bool V4, bool EXPONENTIAL>
+__global__ __launch_bounds__(256) void adx_encode_fs18_tiled_kernel(
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int pcm_length, AdxDeviceParams p,
+    uint8_t *__restrict__ out, int64_t out_pitch, int16_t *__restrict__ history_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    AdxEncodeTile *s_tile = reinterpret_cast<AdxEncodeTile *>(s_raw);          // [2]
+    const int tid = threadIdx.x;
+    const int ch0 = blockIdx.x * 64;
+    const int frame_count = (pcm_length + 31) / 32;
+    const int tiles = (frame_count + ATF - 1) / ATF;
+    const int c0 = p.coef0, c1 = p.coef1;
+
+    if (tid >= 64) {
+        // ------------------------------------------------------------ helper waves (192 lanes)
+        const int hl = tid - 64;
+        constexpr int ITEMS = (64 * ATF + 191) / 192;
+        struct Raw { uint4 v[4]; };
+        auto load_tile = [&](int tile, Raw (&raw)[ITEMS]) {          // unconditional loads, clamped frame index
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) {
+                const int item = min(hl + 192 * k, 64 * ATF - 1);
+                const int c = item / ATF, j = item - c * ATF;
+                // the last frame may be partial: clamp to the last FULL frame (re-read below if needed)
+                const int i = min(tile * ATF + j, max(pcm_length / 32 - 1, 0));
+                const int ch = min(ch0 + c, nch - 1);
+                const uint4 *src = reinterpret_cast<const uint4 *>(pcm + (int64_t)ch * pcm_pitch + (int64_t)i * 32);
+                if (pcm_length < 32) {                  // no full frame at all: nothing to prefetch (uniform)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) raw[k].v[q] = make_uint4(0, 0, 0, 0);
+                    continue;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) raw[k].v[q] = src[q];
+            }
+        };
+        auto prepare = [&](int tile, const Raw (&raw)[ITEMS]) {
+            AdxEncodeTile &T = s_tile[tile & 1];
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) {
+                const int item = hl + 192 * k;
+                if (item >= 64 * ATF) continue;
+                const int c = item / ATF, j = item - c * ATF;
+                const int i = tile * ATF + j;
+                if (i >= frame_count) continue;
+                uint32_t w[16];
+                if ((int64_t)i * 32 + 32 <= pcm_length) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        w[4 * q] = raw[k].v[q].x; w[4 * q + 1] = raw[k].v[q].y; w[4 * q + 2] = raw[k].v[q].z; w[4 * q + 3] = raw[k].v[q].w;
+                    }
+                } else {                               // zero-padded last frame
+                    const int ch = min(ch0 + c, nch - 1);
+                    adx_load32(pcm + (int64_t)ch * pcm_pitch, (int64_t)i * 32, pcm_length, w);
+                }
+                int x[32];
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    x[2 * q] = (int)(int16_t)(w[q] & 0xFFFF);
+                    x[2 * q + 1] = (int)w[q] >> 16;
+                }
+                int pm = 0;
+#pragma unroll
+                for (int s = 2; s < 32; s++) {         // history = the two input samples before (:112-118)
+                    const int predicted = ((x[s - 1] * c0) >> 12) + ((x[s - 2] * c1) >> 12);
+                    int distance = clamp16(x[s] - predicted);
+                    distance = distance < 0 ? -distance : distance;
+                    pm = max(pm, distance);
+                }
+                T.pmax[j][c] = pm;
+#pragma unroll
+                for (int q = 0; q < 8; q++) T.x[j][q][c] = make_int4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+            }
+        };
+        auto flush = [&](int tile) {
+            const AdxEncodeTile &T = s_tile[tile & 1];
+            for (int item = hl; item < 64 * ATF; item += 192) {
+                const int c = item / ATF, j = item - c * ATF;
+                const int i = tile * ATF + j;
+                if (i >= frame_count || ch0 + c >= nch) continue;
+                uint32_t bytes[5] = {(uint32_t)T.hdr[j][c], 0, 0, 0, 0};       // 18 bytes + 2 spare
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int4 v = T.q[j][q][c];
+                    const int qq[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int s = 4 * q + e;
+                        const int byte_index = 2 + (s >> 1);
+                        bytes[byte_index >> 2] |= (uint32_t)(qq[e] & 0xF) << (8 * (byte_index & 3) + ((s & 1) ? 0 : 4));
+                    }
+                }
+                uint16_t *f = reinterpret_cast<uint16_t *>(out + (int64_t)(ch0 + c) * out_pitch) + (int64_t)i * 9;
+                if ((i & 1) == 0) {                    // 36*k bytes: dword aligned
+                    uint32_t *f32 = reinterpret_cast<uint32_t *>(f);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) f32[q] = bytes[q];
+                    f[8] = (uint16_t)bytes[4];
+                } else {                               // 2 bytes past a dword boundary
+                    f[0] = (uint16_t)bytes[0];
+                    uint32_t *f32 = reinterpret_cast<uint32_t *>(f + 1);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) f32[q] = (bytes[q] >> 16) | (bytes[q + 1] << 16);
+                }
+            }
+        };
+        Raw ra[ITEMS], rb[ITEMS];
+        load_tile(0, ra);
+        load_tile(1, rb);
+        if (tiles > 0) prepare(0, ra);
+        lds_barrier();
+        for (int tile = 0; tile < tiles; tile += 2) {
+            load_tile(tile + 2, ra);
+            if (tile + 1 < tiles) prepare(tile + 1, rb);
+            if (tile > 0) flush(tile - 1);
+            lds_barrier();
+            if (tile + 1 < tiles) {
+                load_tile(tile + 3, rb);
+                if (tile + 2 < tiles) prepare(tile + 2, ra);
+                flush(tile);
+                lds_barrier();
+            }
+        }
+        if (tiles > 0) flush(tiles - 1);
+        return;
+    }
+
+    // ---------------------------------------------------------------- encoder wave: lane = channel
+    __builtin_amdgcn_s_setprio(3);
+    const int ch = min(ch0 + tid, nch - 1);
+    const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
+    int h0 = 0, h1 = 0, hist = p.history;             // h1 = the newer sample
+    if (V4 && pcm_length > 0) { h0 = h1 = pcm[(int64_t)ch * pcm_pitch]; hist = h0; }      // :69-74
+    if (history_out && ch0 + tid < nch) history_out[ch] = (int16_t)hist;
+
+    lds_barrier();                                     // tile 0 prepared
+    for (int tile = 0; tile < tiles; tile++) {
+        AdxEncodeTile &T = s_tile[tile & 1];
+        const int nf = min(ATF, frame_count - tile * ATF);
+#pragma unroll 1
+        for (int j = 0; j < nf; j++) {
+            int x[32];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int4 v = T.x[j][q][tid];
+                x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            }
+            // pre-scan (:112-118): the helpers' maximum + the two distances that see the reconstructed history
+            int max_distance = T.pmax[j][tid];
+            {
+                int d0 = clamp16(x[0] - (((h1 * c0) >> 12) + ((h0 * c1) >> 12)));
+                int d1 = clamp16(x[1] - (((x[0] * c0) >> 12) + ((h1 * c1) >> 12)));
+                d0 = d0 < 0 ? -d0 : d0;
+                d1 = d1 < 0 ? -d1 : d1;
+                max_distance = max(max_distance, max(d0, d1));
+            }
+            double gain;
+            int scale_out;
+            const int scale = calculate_scale(max_distance, EXPONENTIAL, gain, scale_out);
+            T.hdr[j][tid] = (((scale_out >> 8) & 0x1f) | filter_bits) | ((scale_out & 0xff) << 8);     // :140-141, :95
+            int a = h0, b = h1, qv[32];
+#pragma unroll
+            for (int s = 0; s < 32; s++) {             // :122-138
+                const int pb = (__mul24(a, c1)) >> 12;               // older sample: ready a step early
+                const int pa = (__mul24(b, c0)) >> 12;
+                const int raw = (x[s] - pb) - pa;
+                const int scaled = clamp16((int)((double)raw * gain));
+                const int sm = scaled >> 31;                          // scale_short_to_nibble on the magnitude
+                const unsigned mag = (unsigned)((scaled ^ sm) - sm);
+                const int aq = (int)((mag * 114692u + 2340u * 114692u) >> 29);
+                const int q = (aq ^ sm) - sm;
+                const int predicted = V4 ? (__mul24(b, c0) + __mul24(a, c1)) >> 12 : pa + pb;
+                const int rec = clamp16(__mul24(scale, q) + predicted);
+                a = b;
+                b = rec;
+                qv[s] = q;
+            }
+            h0 = a;
+            h1 = b;
+#pragma unroll
+            for (int q = 0; q < 8; q++) T.q[j][q][tid] = make_int4(qv[4 * q], qv[4 * q + 1], qv[4 * q + 2], qv[4 * q + 3]);
+        }
+        lds_barrier();
+    }
+}
+
 int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_length, const AdxDeviceParams &p,
                   uint8_t *d_out, int64_t out_pitch, int16_t *d_history_out, hipStream_t stream)
 {
@@ -592,7 +793,31 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
     // pcm rows must be 16-byte aligned for the vector loads, output rows 4-byte aligned for the dword stores
     const bool fast = p.frame_size == 18 && p.padding == 0 && (pcm_pitch % 8) == 0 && ((uintptr_t)d_pcm % 16) == 0 &&
                       (out_pitch % 4) == 0 && ((uintptr_t)d_out % 4) == 0;
-    if (fast) {
+    // A/B switch for measurements only: VGA_ADX_ENCODE_IMPL=v1 selects the single-wave kernels
+    static const bool use_v1 = [] {
+        const char *e = getenv("VGA_ADX_ENCODE_IMPL");
+        return e && e[0] == 'v' && e[1] == '1';
+    }();
+    if (fast && !use_v1) {
+        const bool v4 = p.version == 4, ex = p.type == 4;
+        const size_t lds = 2 * sizeof(AdxEncodeTile);
+#define VGA_ADX_ENC_T(V, E)                                                                                              \
+        {                                                                                                                \
+            static bool configured = false;                                                                              \
+            if (!configured) {                                                                                           \
+                VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(adx_encode_fs18_tiled_kernel<V, E>),     \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+                configured = true;                                                                                       \
+            }                                                                                                            \
+            hipLaunchKernelGGL((adx_encode_fs18_tiled_kernel<V, E>), grid, dim3(256), lds, stream, d_pcm, pcm_pitch, nch, \
+                               pcm_length, p, d_out, out_pitch, d_history_out);                                         \
+        }
+        if (v4 && ex) VGA_ADX_ENC_T(true, true)
+        else if (v4) VGA_ADX_ENC_T(true, false)
+        else if (ex) VGA_ADX_ENC_T(false, true)
+        else VGA_ADX_ENC_T(false, false)
+#undef VGA_ADX_ENC_T
+    } else if (fast) {
         const bool v4 = p.version == 4, ex = p.type == 4;
 #define VGA_ADX_ENC(V, E) hipLaunchKernelGGL((adx_encode_fs18_kernel<V, E>), grid, block, 0, stream, d_pcm, pcm_pitch, nch, \
                                              pcm_length, p, d_out, out_pitch, d_history_out)
