@@ -11,6 +11,7 @@
 #include "adx_kernels.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace vga {
 namespace adx {
@@ -35,6 +36,15 @@ __device__ __forceinline__ int calculate_scale(int max_distance, bool exponentia
     }
     gain = max_distance == 0 ? 0.0 : 32767.0 / (double)max_distance;
     return scale;
+}
+
+// (int)double the way RyuJIT x64 does it (cvttsd2si): out of range -> int.MinValue.  v_cvt_i32_f64 saturates,
+// which differs for a POSITIVE overflow only (rawDistance * gain >= 2^31: needs max_distance <= 8 and a
+// reconstruction far off the input -- not seen on audio, but the reference's answer is defined).
+__device__ __forceinline__ int trunc_i32_ryujit(double v)
+{
+    const int i = (int)v;
+    return v >= 2147483648.0 ? (int)0x80000000 : i;
 }
 
 // CriAdxCodec.cs:167-171
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(64) void adx_encode_kernel(
             const int x = sample_at(j);
             int predicted = ((b * c0) >> 12) + ((a * c1) >> 12);
             const int raw = x - predicted;
-            const int scaled = clamp16((int)((double)raw * gain));
+            const int scaled = clamp16(trunc_i32_ryujit((double)raw * gain));
             const int q = scale_short_to_nibble(scaled);
             const int decoded_distance = clamp16(scale * q);
             if (p.version == 4) predicted = (b * c0 + a * c1) >> 12;
@@ -247,7 +257,7 @@ __device__ __forceinline__ void adx_encode_frame32(const uint32_t (&w)[16], int 
     for (int j = 0; j < 32; j++) {
         int predicted = ((b * c0) >> 12) + ((a * c1) >> 12);
         const int raw = x[j] - predicted;
-        const int scaled = clamp16((int)((double)raw * gain));
+        const int scaled = clamp16(trunc_i32_ryujit((double)raw * gain));
         const int q = scale_short_to_nibble(scaled);
         const int decoded_distance = clamp16(scale * q);
         if (V4) predicted = (b * c0 + a * c1) >> 12;
@@ -730,6 +740,7 @@ __global__ __launch_bounds__(256) void adx_encode_fs18_tiled_kernel(
     __builtin_amdgcn_s_setprio(3);
     const int ch = min(ch0 + tid, nch - 1);
     const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
+    const double raw_bound = 32770.0 + 8.0 * (double)((c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1));
     int h0 = 0, h1 = 0, hist = p.history;             // h1 = the newer sample
     if (V4 && pcm_length > 0) { h0 = h1 = pcm[(int64_t)ch * pcm_pitch]; hist = h0; }      // :69-74
     if (history_out && ch0 + tid < nch) history_out[ch] = (int16_t)hist;
@@ -760,22 +771,30 @@ __global__ __launch_bounds__(256) void adx_encode_fs18_tiled_kernel(
             const int scale = calculate_scale(max_distance, EXPONENTIAL, gain, scale_out);
             T.hdr[j][tid] = (((scale_out >> 8) & 0x1f) | filter_bits) | ((scale_out & 0xff) << 8);     // :140-141, :95
             int a = h0, b = h1, qv[32];
+            auto quantise = [&](auto guard_c) __attribute__((always_inline)) {
+                constexpr bool GUARD = decltype(guard_c)::value;
 #pragma unroll
-            for (int s = 0; s < 32; s++) {             // :122-138
-                const int pb = (__mul24(a, c1)) >> 12;               // older sample: ready a step early
-                const int pa = (__mul24(b, c0)) >> 12;
-                const int raw = (x[s] - pb) - pa;
-                const int scaled = clamp16((int)((double)raw * gain));
-                const int sm = scaled >> 31;                          // scale_short_to_nibble on the magnitude
-                const unsigned mag = (unsigned)((scaled ^ sm) - sm);
-                const int aq = (int)((mag * 114692u + 2340u * 114692u) >> 29);
-                const int q = (aq ^ sm) - sm;
-                const int predicted = V4 ? (__mul24(b, c0) + __mul24(a, c1)) >> 12 : pa + pb;
-                const int rec = clamp16(__mul24(scale, q) + predicted);
-                a = b;
-                b = rec;
-                qv[s] = q;
-            }
+                for (int s = 0; s < 32; s++) {         // :122-138
+                    const int pb = (__mul24(a, c1)) >> 12;           // older sample: ready a step early
+                    const int pa = (__mul24(b, c0)) >> 12;
+                    const int raw = (x[s] - pb) - pa;
+                    const double prod = (double)raw * gain;
+                    const int scaled = clamp16(GUARD ? trunc_i32_ryujit(prod) : (int)prod);
+                    const int sm = scaled >> 31;                      // scale_short_to_nibble on the magnitude
+                    const unsigned mag = (unsigned)((scaled ^ sm) - sm);
+                    const int aq = (int)((mag * 114692u + 2340u * 114692u) >> 29);
+                    const int q = (aq ^ sm) - sm;
+                    const int predicted = V4 ? (__mul24(b, c0) + __mul24(a, c1)) >> 12 : pa + pb;
+                    const int rec = clamp16(__mul24(scale, q) + predicted);
+                    a = b;
+                    b = rec;
+                    qv[s] = q;
+                }
+            };
+            // |rawDistance| <= 32768 + 8 (|c0| + |c1|): only a frame whose gain can push that past 2^31 needs the
+            // RyuJIT overflow semantics of the cast (a wave-uniform, practically never taken branch)
+            if (__any(gain * raw_bound >= 2147483648.0)) quantise(std::true_type{});
+            else quantise(std::false_type{});
             h0 = a;
             h1 = b;
 #pragma unroll
