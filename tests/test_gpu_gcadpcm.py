@@ -356,3 +356,36 @@ def test_encode_decode_fuzz_mixed_signals():
         want = po.gc_encode(chans[c], want_coefs)
         assert (got[c] == want).all(), (c, int(np.argmax(got[c] != want)))
         assert (dec[c] == po.gc_decode(want, want_coefs, n)).all(), c
+
+
+def test_batch_entry_points_are_reentrant_from_many_threads():
+    """The reference calls the codec from arbitrary TPL threads (GcAdpcmFormat.cs:65, Cli/Batch.cs:24): the
+    host-buffer exports own their stream and device buffers, so concurrent callers must not disturb each other."""
+    import threading
+    n = 14 * 900 + 3
+    jobs = [synth.generate(3, n, first_channel=7 * k) for k in range(6)]
+    want = [po.gc_encode_batch(j, threads=2) for j in jobs]
+    got = [None] * len(jobs)
+    errors = []
+
+    def work(k):
+        try:
+            for _ in range(3):                                   # a few rounds to make overlap likely
+                fmt = GcAdpcmFormat().EncodeFromPcm16(Pcm16Format(list(jobs[k]), 48000))
+                back = fmt.ToPcm16()
+                got[k] = (fmt, back)
+        except Exception as e:                                   # noqa: BLE001 - reported below
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k, (fmt, back) in enumerate(got):
+        coefs, adpcm = want[k]
+        for c in range(3):
+            assert (fmt.Channels[c].Coefs == coefs[c]).all(), (k, c)
+            assert (fmt.Channels[c].Adpcm == adpcm[c]).all(), (k, c)
+            assert (back.Channels[c] == po.gc_decode(adpcm[c], coefs[c], n)).all(), (k, c)
