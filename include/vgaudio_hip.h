@@ -174,6 +174,38 @@ int vga_gcadpcm_build_channels_device(const uint8_t *d_adpcm, int64_t adpcm_pitc
                                       int16_t *d_loop_context_out, void *d_workspace, size_t workspace_bytes,
                                       void *stream);
 
+/* ----------------------------------------------------------------------
+ * DSP container for GC-ADPCM: VGAudio/Containers/Dsp/DspWriter.cs:14-103.
+ * One 0x60-byte big-endian header per channel, then the audio -- one channel verbatim, several channels
+ * interleaved in blocks of SampleCountToByteCount(SamplesPerInterleave) bytes (Utilities/Interleave.cs:43-78).
+ * -------------------------------------------------------------------- */
+typedef struct {
+    int sample_rate;
+    int sample_count;                  /* GcAdpcmFormat.SampleCount */
+    int looping, loop_start, loop_end; /* GcAdpcmFormat.Looping / LoopStart / LoopEnd */
+    int samples_per_interleave;        /* DspConfiguration.SamplesPerInterleave (default 0x3800, divisible by 14) */
+    int loop_point_alignment;          /* DspConfiguration.LoopPointAlignment (default 1) */
+    int trim_file;                     /* Configuration.TrimFile (default true) */
+} vga_dsp_params;
+typedef struct {
+    int sample_count, loop_start, loop_end;            /* as the header carries them (DspWriter.cs:22,29-31) */
+    int start_addr, end_addr, cur_addr;                /* :33-35, nibble addresses */
+    int bytes_per_interleave, frames_per_interleave;   /* :25-27 */
+    int audio_data_size, file_size;                    /* :99-100, :18 */
+} vga_dsp_layout;
+/* size math only; VGA_ERR_OUT_OF_RANGE like DspConfiguration's setters (DspConfiguration.cs:31-46) */
+int vga_dsp_layout_for(const vga_dsp_params *p, int nch, vga_dsp_layout *out);
+/* adpcm[c]: GcAdpcmChannel.GetAdpcmAudio(), adpcm_len bytes each (equal lengths, Interleave.cs:49-50);
+ * coefs nch*16; gain nch or NULL (0); start_context / loop_context nch*3 (pred/scale, hist1, hist2) or NULL
+ * (start: (Adpcm[0], 0, 0) as GcAdpcmChannel.cs:45 builds it; loop: zeros).  file_out: layout.file_size bytes. */
+int vga_dsp_write(const uint8_t *const *adpcm, int adpcm_len, const int16_t *coefs, const int16_t *gain,
+                  const int16_t *start_context, const int16_t *loop_context, int nch, const vga_dsp_params *p,
+                  uint8_t *file_out);
+/* device-resident variant: the image is assembled in HBM (d_file 8-byte aligned, layout.file_size bytes) */
+int vga_dsp_write_device(const uint8_t *d_adpcm, int64_t adpcm_pitch, int adpcm_len, const int16_t *d_coefs,
+                         const int16_t *d_gain, const int16_t *d_start_context, const int16_t *d_loop_context,
+                         int nch, const vga_dsp_params *p, uint8_t *d_file, void *stream);
+
 /* ======================================================================
  * CRI ADX
  * ====================================================================== */

@@ -93,6 +93,34 @@ int vgo_gc_build_channel(const uint8_t *adpcm, const int16_t coefs[16], const vg
                          vgo_gc_channel_layout *layout_out, uint8_t *adpcm_out, int16_t *pcm_out,
                          int16_t *seek_table_out, int16_t loop_context_out[3]);
 
+/* ---- DSP container (Containers/Dsp/DspWriter.cs, DspReader.cs), SURVEY.md 8f rank 2 ---- */
+typedef struct {
+    int sample_rate;
+    int sample_count;                 /* GcAdpcmFormat.SampleCount */
+    int looping, loop_start, loop_end;/* GcAdpcmFormat.Looping / LoopStart / LoopEnd */
+    int samples_per_interleave;       /* DspConfiguration.SamplesPerInterleave, default 0x3800 */
+    int loop_point_alignment;         /* DspConfiguration.LoopPointAlignment, default 1 */
+    int trim_file;                    /* Configuration.TrimFile, default true */
+} vgo_dsp_params;
+typedef struct {
+    int sample_count, loop_start, loop_end;            /* as written to the header (DspWriter.cs:22,29-31) */
+    int start_addr, end_addr, cur_addr;                /* :33-35 */
+    int bytes_per_interleave, frames_per_interleave;   /* :25-27 */
+    int audio_data_size, file_size;                    /* :99-100, :18 */
+} vgo_dsp_layout;
+typedef struct {
+    int sample_count, nibble_count, sample_rate, looping, format, start_addr, end_addr, cur_addr;
+    int channel_count, frames_per_interleave;
+} vgo_dsp_header;
+void vgo_interleave(const uint8_t *const *inputs, int count, int input_size, int interleave, int output_size, uint8_t *out);
+int vgo_deinterleave(const uint8_t *in, int in_len, int interleave, int count, int output_size, uint8_t *const *outs);
+int vgo_dsp_layout_for(const vgo_dsp_params *p, int nch, vgo_dsp_layout *out);
+int vgo_dsp_write(const uint8_t *const *adpcm, int adpcm_len, const int16_t *coefs, const int16_t *gain,
+                  const int16_t *start_context, const int16_t *loop_context, int nch, const vgo_dsp_params *p,
+                  uint8_t *file_out);
+int vgo_dsp_read(const uint8_t *file, int file_len, vgo_dsp_header *hdr, int16_t *coefs_out, int16_t *gain_out,
+                 int16_t *start_context_out, int16_t *loop_context_out, uint8_t *const *adpcm_out);
+
 /* Formats/GcAdpcm/GcAdpcmSeekTable.cs:25-38 (CreateSeekTable).
  * table_out holds 2*ceil(n/samples_per_entry) shorts. */
 void vgo_gc_create_seek_table(const int16_t *pcm, int n, int samples_per_entry, int16_t *table_out);

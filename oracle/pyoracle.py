@@ -128,6 +128,14 @@ def gc_sample_count_to_byte_count(n):
     return lib().vgo_gc_sample_count_to_byte_count(int(n))
 
 
+def gc_sample_to_nibble(n):
+    return lib().vgo_gc_sample_to_nibble(int(n))
+
+
+def gc_sample_count_to_nibble_count(n):
+    return lib().vgo_gc_sample_count_to_nibble_count(int(n))
+
+
 def gc_calculate_coefficients(pcm):
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)
     coefs = np.zeros(16, dtype=np.int16)
@@ -270,6 +278,103 @@ def gc_build_channel(adpcm, coefs, p):
             seek[:L.seek_table_entries * 2], ctx)
 
 
+
+
+# ---------------- DSP container ----------------
+class DspParams(C.Structure):
+    """vgo_dsp_params"""
+    _fields_ = [(n, C.c_int) for n in ("sample_rate", "sample_count", "looping", "loop_start", "loop_end",
+                                       "samples_per_interleave", "loop_point_alignment", "trim_file")]
+
+
+class DspLayout(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("sample_count", "loop_start", "loop_end", "start_addr", "end_addr", "cur_addr",
+                                       "bytes_per_interleave", "frames_per_interleave", "audio_data_size", "file_size")]
+
+
+class DspHeader(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("sample_count", "nibble_count", "sample_rate", "looping", "format", "start_addr",
+                                       "end_addr", "cur_addr", "channel_count", "frames_per_interleave")]
+
+
+def dsp_params(sample_rate, sample_count, looping=False, loop_start=0, loop_end=0, samples_per_interleave=0x3800,
+               loop_point_alignment=1, trim_file=True):
+    return DspParams(sample_rate, sample_count, int(looping), loop_start, loop_end, samples_per_interleave,
+                     loop_point_alignment, int(trim_file))
+
+
+def dsp_layout(p, nch):
+    L = DspLayout()
+    f = lib().vgo_dsp_layout_for
+    f.argtypes = [C.POINTER(DspParams), C.c_int, C.POINTER(DspLayout)]
+    rc = f(C.byref(p), nch, C.byref(L))
+    return rc, L
+
+
+def interleave(inputs, size, output_size=-1):
+    """InterleaveExtensions.Interleave(byte[][]) -> uint8 array of output_size * count bytes."""
+    chans = [np.ascontiguousarray(a, dtype=np.uint8) for a in inputs]
+    n = len(chans)
+    osz = len(chans[0]) if output_size == -1 else output_size
+    out = np.zeros(osz * n, dtype=np.uint8)
+    ptrs = (C.POINTER(C.c_uint8) * n)(*[_u8(a) for a in chans])
+    f = lib().vgo_interleave
+    f.restype = None
+    f.argtypes = [C.POINTER(C.POINTER(C.c_uint8)), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+    f(ptrs, n, len(chans[0]), size, output_size, _u8(out))
+    return out
+
+
+def deinterleave(data, size, count, output_size=-1):
+    """DeInterleave(byte[]) -> (rc, [count arrays of output_size bytes])"""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    osz = len(data) // count if output_size == -1 else output_size
+    outs = [np.zeros(max(osz, 1), dtype=np.uint8) for _ in range(count)]
+    ptrs = (C.POINTER(C.c_uint8) * count)(*[_u8(a) for a in outs])
+    f = lib().vgo_deinterleave
+    f.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8))]
+    rc = f(_u8(data), len(data), size, count, output_size, ptrs)
+    return rc, [o[:osz] for o in outs]
+
+
+def dsp_write(adpcm, coefs, p, gain=None, start_context=None, loop_context=None):
+    """DspWriter -> (rc, file bytes).  adpcm: list of equally long uint8 arrays (GetAdpcmAudio per channel)."""
+    nch = len(adpcm)
+    chans = [np.ascontiguousarray(a, dtype=np.uint8) for a in adpcm]
+    coefs = np.ascontiguousarray(coefs, dtype=np.int16).reshape(nch, 16)
+    gain = np.zeros(nch, np.int16) if gain is None else np.ascontiguousarray(gain, dtype=np.int16)
+    sc = np.zeros((nch, 3), np.int16) if start_context is None else np.ascontiguousarray(start_context, dtype=np.int16)
+    lc = np.zeros((nch, 3), np.int16) if loop_context is None else np.ascontiguousarray(loop_context, dtype=np.int16)
+    rc, L = dsp_layout(p, nch)
+    if rc:
+        return rc, None
+    out = np.zeros(L.file_size, dtype=np.uint8)
+    ptrs = (C.POINTER(C.c_uint8) * nch)(*[_u8(a) for a in chans])
+    f = lib().vgo_dsp_write
+    f.argtypes = [C.POINTER(C.POINTER(C.c_uint8)), C.c_int, C.POINTER(C.c_int16), C.POINTER(C.c_int16),
+                  C.POINTER(C.c_int16), C.POINTER(C.c_int16), C.c_int, C.POINTER(DspParams), C.POINTER(C.c_uint8)]
+    rc = f(ptrs, len(chans[0]), _i16(coefs), _i16(gain), _i16(sc), _i16(lc), nch, C.byref(p), _u8(out))
+    return rc, out
+
+
+def dsp_read(file_bytes):
+    """DspReader -> (rc, header, coefs[nch,16], gain, start ctx, loop ctx, [adpcm per channel])"""
+    data = np.ascontiguousarray(np.frombuffer(bytes(file_bytes), dtype=np.uint8))
+    f = lib().vgo_dsp_read
+    f.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.POINTER(DspHeader), C.POINTER(C.c_int16), C.POINTER(C.c_int16),
+                  C.POINTER(C.c_int16), C.POINTER(C.c_int16), C.POINTER(C.POINTER(C.c_uint8))]
+    h = DspHeader()
+    rc = f(_u8(data), len(data), C.byref(h), None, None, None, None, None)
+    if rc:
+        return rc, h, None, None, None, None, None
+    nch = h.channel_count
+    coefs = np.zeros((nch, 16), np.int16); gain = np.zeros(nch, np.int16)
+    sc = np.zeros((nch, 3), np.int16); lc = np.zeros((nch, 3), np.int16)
+    nb = gc_sample_count_to_byte_count(h.sample_count)
+    chans = [np.zeros(max(nb, 1), np.uint8) for _ in range(nch)]
+    ptrs = (C.POINTER(C.c_uint8) * nch)(*[_u8(a) for a in chans])
+    rc = f(_u8(data), len(data), C.byref(h), _i16(coefs), _i16(gain), _i16(sc), _i16(lc), ptrs)
+    return rc, h, coefs, gain, sc, lc, [c[:nb] for c in chans]
 
 
 # ---------------- ADX ----------------

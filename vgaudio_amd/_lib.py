@@ -90,6 +90,9 @@ SIGNATURES = {
     "vga_gcadpcm_encode_device": (ci, [vp, i64, ci, ci, vp, vp, vp, vp, i64, vp]),
     "vga_gcadpcm_decode_device": (ci, [vp, i64, vp, ci, ci, vp, vp, vp, i64, vp, vp]),
     "vga_synth_pcm16_device": (ci, [vp, i64, ci, ci, ci, vp, vp]),
+    "vga_dsp_layout_for": (ci, [vp, ci, vp]),
+    "vga_dsp_write": (ci, [u8pp, ci, i16p, i16p, i16p, i16p, ci, vp, u8p]),
+    "vga_dsp_write_device": (ci, [vp, i64, ci, vp, vp, vp, vp, ci, vp, vp, vp]),
     "vga_gcadpcm_channel_layout_for": (ci, [vp, vp]),
     "vga_gcadpcm_build_channels_batch": (ci, [u8pp, i16p, ci, vp, u8pp, i16pp, i16pp, i16p]),
     "vga_gcadpcm_build_channels_workspace_bytes": (C.c_size_t, [ci, vp]),
@@ -111,6 +114,18 @@ SIGNATURES = {
     "vga_hca_encode_device": (ci, [vp, i64, i64, ci, ci, vp, vp, i64, vp, vp]),
     "vga_hca_decode_device": (ci, [vp, vp, i64, ci, vp, i64, i64, vp, C.c_size_t, vp, vp]),
 }
+
+
+class DspParamsC(C.Structure):
+    """vga_dsp_params"""
+    _fields_ = [(n, C.c_int) for n in ("sample_rate", "sample_count", "looping", "loop_start", "loop_end",
+                                       "samples_per_interleave", "loop_point_alignment", "trim_file")]
+
+
+class DspLayoutC(C.Structure):
+    """vga_dsp_layout"""
+    _fields_ = [(n, C.c_int) for n in ("sample_count", "loop_start", "loop_end", "start_addr", "end_addr", "cur_addr",
+                                       "bytes_per_interleave", "frames_per_interleave", "audio_data_size", "file_size")]
 
 
 class GcChannelParamsC(C.Structure):

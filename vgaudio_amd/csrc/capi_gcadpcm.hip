@@ -1,5 +1,7 @@
 // capi_gcadpcm.hip -- C-ABI entry points for GC-ADPCM (see include/vgaudio_hip.h).
 #include "common.hpp"
+
+#include <algorithm>
 #include "gcadpcm_kernels.hpp"
 
 #include <cmath>
@@ -293,6 +295,59 @@ int vga_gcadpcm_build_channels_device(const uint8_t *d_adpcm, int64_t adpcm_pitc
                                    d_loop_context_out, st);
 }
 
+// ---------------------------------------------------------------- DSP container
+int vga_dsp_layout_for(const vga_dsp_params *p, int nch, vga_dsp_layout *out)
+{
+    if (!p || !out) { set_error("null argument"); return VGA_ERR_ARGUMENT; }
+    if (nch < 1) { set_error("a DSP file needs at least one channel"); return VGA_ERR_ARGUMENT; }
+    if (p->samples_per_interleave < 1) {                         // DspConfiguration.cs:31-40
+        set_error("Number of samples per interleave must be positive");
+        return VGA_ERR_OUT_OF_RANGE;
+    }
+    if (p->samples_per_interleave % 14 != 0) {
+        set_error("Number of samples per interleave must be divisible by 14");
+        return VGA_ERR_OUT_OF_RANGE;
+    }
+    if (p->sample_count < 0 || p->loop_start < 0 || p->loop_end < 0) { set_error("negative sample count / loop point"); return VGA_ERR_OUT_OF_RANGE; }
+    // DspWriter.cs:22-36
+    const int alignment_samples = get_next_multiple(p->loop_start, p->loop_point_alignment) - p->loop_start;
+    out->loop_start = p->loop_start + alignment_samples;
+    out->loop_end = p->loop_end + alignment_samples;
+    out->sample_count = (p->trim_file && p->looping) ? out->loop_end : std::max(p->sample_count, out->loop_end);
+    out->bytes_per_interleave = vga_gcadpcm_sample_count_to_byte_count(p->samples_per_interleave);
+    out->frames_per_interleave = out->bytes_per_interleave / 8;
+    out->start_addr = vga_gcadpcm_sample_to_nibble(p->looping ? out->loop_start : 0);
+    out->end_addr = vga_gcadpcm_sample_to_nibble(p->looping ? out->loop_end : out->sample_count - 1);
+    out->cur_addr = vga_gcadpcm_sample_to_nibble(0);
+    out->audio_data_size = get_next_multiple(vga_gcadpcm_sample_count_to_byte_count(out->sample_count), nch == 1 ? 1 : 8);   // :99-100
+    const int64_t fs = ((int64_t)0x60 + out->audio_data_size) * nch;                                                          // :18
+    if (fs > 0x7FFFFFFF) { set_error("DSP file would exceed 2 GiB (the reference's FileSize is an int)"); return VGA_ERR_OUT_OF_RANGE; }
+    out->file_size = (int)fs;
+    return VGA_OK;
+}
+
+int vga_dsp_write_device(const uint8_t *d_adpcm, int64_t adpcm_pitch, int adpcm_len, const int16_t *d_coefs,
+                         const int16_t *d_gain, const int16_t *d_start_context, const int16_t *d_loop_context, int nch,
+                         const vga_dsp_params *p, uint8_t *d_file, void *stream)
+{
+    vga_dsp_layout L;
+    if (int rc = vga_dsp_layout_for(p, nch, &L)) return rc;
+    if (adpcm_len < 0 || !d_coefs || !d_file || (adpcm_len > 0 && !d_adpcm)) { set_error("null / negative argument"); return VGA_ERR_ARGUMENT; }
+    if (adpcm_len > 0)
+        if (int rc = check_adpcm_layout(d_adpcm, adpcm_pitch, adpcm_len, "vga_dsp_write_device")) return rc;
+    if (((uintptr_t)d_file & 7) != 0) { set_error("file image must be 8-byte aligned"); return VGA_ERR_ARGUMENT; }
+    const int mono_bytes = vga_gcadpcm_sample_count_to_byte_count(L.sample_count);
+    if (nch == 1 && mono_bytes > adpcm_len) {                   // Stream.Write(buffer, 0, count) past the array
+        set_error("channel audio (%d bytes) is shorter than the %d bytes the header's sample count needs", adpcm_len, mono_bytes);
+        return VGA_ERR_ARGUMENT;
+    }
+    return gc::launch_dsp_image(d_adpcm, adpcm_pitch, adpcm_len, d_coefs, d_gain, d_start_context, d_loop_context, nch,
+                                L.sample_count, vga_gcadpcm_sample_count_to_nibble_count(L.sample_count), p->sample_rate,
+                                p->looping ? 1 : 0, L.start_addr, L.end_addr, L.cur_addr, L.bytes_per_interleave,
+                                L.frames_per_interleave, L.audio_data_size, mono_bytes, d_file, (size_t)L.file_size,
+                                (hipStream_t)stream);
+}
+
 int vga_synth_pcm16_device(int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, int first_channel,
                            const uint32_t *d_params, void *stream)
 {
@@ -477,6 +532,47 @@ int vga_gcadpcm_decode_batch(const uint8_t *const *adpcm, const int16_t *coefs, 
         set_error("a frame header names predictor > 7 (the reference throws IndexOutOfRangeException)");
         return VGA_ERR_ARGUMENT;
     }
+    return VGA_OK;
+}
+
+// DspWriter.GetFile for channels held in host memory: the image is assembled on the device and copied back once.
+int vga_dsp_write(const uint8_t *const *adpcm, int adpcm_len, const int16_t *coefs, const int16_t *gain,
+                  const int16_t *start_context, const int16_t *loop_context, int nch, const vga_dsp_params *p,
+                  uint8_t *file_out)
+{
+    vga_dsp_layout L;
+    if (int rc = vga_dsp_layout_for(p, nch, &L)) return rc;
+    if (adpcm_len < 0) { set_error("negative length"); return VGA_ERR_ARGUMENT; }
+    if (int rc = check_ptrs((const void *const *)adpcm, adpcm_len > 0 ? nch : 0, "adpcm")) return rc;
+    if (!coefs || !file_out) { set_error("null coefs / output"); return VGA_ERR_ARGUMENT; }
+    if (int rc = require_device()) return rc;
+    GcBatch b;
+    VGA_HIP_TRY(b.st.create());
+    b.adpcm_pitch = round_up(adpcm_len > 0 ? adpcm_len : 1, 16);
+    DevBuf file, d_gain, d_sc, d_lc;
+    VGA_HIP_TRY(b.adpcm.alloc((size_t)nch * b.adpcm_pitch));
+    VGA_HIP_TRY(b.coefs.alloc((size_t)nch * 32));
+    VGA_HIP_TRY(file.alloc((size_t)L.file_size));
+    for (int c = 0; c < nch; c++)
+        if (adpcm_len > 0)
+            VGA_HIP_TRY(hipMemcpyAsync(b.adpcm.as<uint8_t>() + (int64_t)c * b.adpcm_pitch, adpcm[c], (size_t)adpcm_len,
+                                       hipMemcpyHostToDevice, b.st.s));
+    VGA_HIP_TRY(hipMemcpyAsync(b.coefs.p, coefs, (size_t)nch * 32, hipMemcpyHostToDevice, b.st.s));
+    auto upload = [&](DevBuf &d, const int16_t *src, size_t shorts) -> int {
+        if (!src) return VGA_OK;
+        VGA_HIP_TRY(d.alloc(shorts * 2));
+        VGA_HIP_TRY(hipMemcpyAsync(d.p, src, shorts * 2, hipMemcpyHostToDevice, b.st.s));
+        return VGA_OK;
+    };
+    if (int rc = upload(d_gain, gain, (size_t)nch)) return rc;
+    if (int rc = upload(d_sc, start_context, (size_t)nch * 3)) return rc;
+    if (int rc = upload(d_lc, loop_context, (size_t)nch * 3)) return rc;
+    if (int rc = vga_dsp_write_device(b.adpcm.as<uint8_t>(), b.adpcm_pitch, adpcm_len, b.coefs.as<int16_t>(),
+                                      gain ? d_gain.as<int16_t>() : nullptr, start_context ? d_sc.as<int16_t>() : nullptr,
+                                      loop_context ? d_lc.as<int16_t>() : nullptr, nch, p, file.as<uint8_t>(), b.st.s))
+        return rc;
+    VGA_HIP_TRY(hipMemcpyAsync(file_out, file.p, (size_t)L.file_size, hipMemcpyDeviceToHost, b.st.s));
+    VGA_HIP_TRY(hipStreamSynchronize(b.st.s));
     return VGA_OK;
 }
 

@@ -88,3 +88,115 @@ int launch_channel_meta(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16
 
 }  // namespace gc
 }  // namespace vga
+
+// ---------------------------------------------------------------- DSP container image
+// Replaces VGAudio/Containers/Dsp/DspWriter.cs:38-97: one 0x60-byte big-endian header per channel, then the
+// audio -- a single channel verbatim, several channels interleaved in blocks of BytesPerInterleave
+// (Utilities/Interleave.cs:43-78).  The image is assembled in HBM next to the encoder's output, so a file
+// leaves the device with one copy.
+namespace vga {
+namespace gc {
+
+struct DspGeometry {
+    int sample_count, nibble_count, sample_rate, looping;
+    int start_addr, end_addr, cur_addr;
+    int bytes_per_interleave, frames_per_interleave, audio_data_size;
+};
+
+__device__ __forceinline__ void put_be16(uint8_t *p, int v) { p[0] = (uint8_t)(v >> 8); p[1] = (uint8_t)v; }
+__device__ __forceinline__ void put_be32(uint8_t *p, int v)
+{
+    p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v;
+}
+
+// WriteHeader (:52-80): one thread per channel (96 bytes each)
+__global__ __launch_bounds__(64) void gc_dsp_header_kernel(
+    const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs,
+    const int16_t *__restrict__ gain, const int16_t *__restrict__ start_context,
+    const int16_t *__restrict__ loop_context, int nch, DspGeometry g, uint8_t *__restrict__ file)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nch) return;
+    uint8_t *h = file + (size_t)0x60 * i;
+    for (int k = 0; k < 0x60; k++) h[k] = 0;
+    put_be32(h + 0x00, g.sample_count);
+    put_be32(h + 0x04, g.nibble_count);
+    put_be32(h + 0x08, g.sample_rate);
+    put_be16(h + 0x0c, g.looping ? 1 : 0);
+    put_be16(h + 0x0e, 0);                                 // Format: 0 for ADPCM (:23)
+    put_be32(h + 0x10, g.start_addr);
+    put_be32(h + 0x14, g.end_addr);
+    put_be32(h + 0x18, g.cur_addr);
+    for (int k = 0; k < 16; k++) put_be16(h + 0x1c + 2 * k, coefs[i * 16 + k]);
+    put_be16(h + 0x3c, gain ? gain[i] : 0);
+    if (start_context) {
+        for (int k = 0; k < 3; k++) put_be16(h + 0x3e + 2 * k, start_context[i * 3 + k]);
+    } else {                                               // GcAdpcmChannel.cs:45: (Adpcm[0], 0, 0) for a fresh channel
+        put_be16(h + 0x3e, (int)adpcm[(int64_t)i * adpcm_pitch]);
+    }
+    if (g.looping && loop_context)
+        for (int k = 0; k < 3; k++) put_be16(h + 0x44 + 2 * k, loop_context[i * 3 + k]);
+    put_be16(h + 0x4a, nch == 1 ? 0 : nch);
+    put_be16(h + 0x4c, nch == 1 ? 0 : g.frames_per_interleave);
+}
+
+// WriteData (:82-94).  Multi-channel: 8-byte words (every offset involved is a multiple of 8: frames are 8 bytes,
+// AudioDataSize is rounded to 8); gaps the reference skips over (Position += ...) stay zero.
+__global__ __launch_bounds__(256) void gc_dsp_interleave_kernel(
+    const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, int input_size, int nch, int interleave, int output_size,
+    uint8_t *__restrict__ data)
+{
+    const int i = blockIdx.y;
+    const int64_t word = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t off = word * 8;                          // byte offset inside the channel's stream
+    if (off >= input_size) return;
+    const int in_blocks = (input_size + interleave - 1) / interleave, out_blocks = (output_size + interleave - 1) / interleave;
+    const int b = (int)(off / interleave);
+    if (b >= (in_blocks < out_blocks ? in_blocks : out_blocks)) return;
+    const int within = (int)(off - (int64_t)b * interleave);
+    const int cur_in = b == in_blocks - 1 ? input_size - (in_blocks - 1) * interleave : interleave;
+    const int cur_out = b == out_blocks - 1 ? output_size - (out_blocks - 1) * interleave : interleave;
+    const int n = cur_in < cur_out ? cur_in : cur_out;    // bytesToCopy
+    if (within >= n) return;
+    const uint8_t *src = adpcm + (int64_t)i * adpcm_pitch + off;
+    uint8_t *dst = data + (int64_t)interleave * b * nch + (int64_t)cur_out * i + within;
+    if (within + 8 <= n) *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(src);
+    else for (int k = 0; within + k < n; k++) dst[k] = src[k];
+}
+
+// single channel: `count` bytes verbatim behind the 0x60-byte header (destination is 8-byte aligned)
+__global__ __launch_bounds__(256) void gc_dsp_copy_kernel(const uint8_t *__restrict__ src, int count, uint8_t *__restrict__ dst)
+{
+    const int64_t off = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (off >= count) return;
+    if (off + 8 <= count) *reinterpret_cast<uint2 *>(dst + off) = *reinterpret_cast<const uint2 *>(src + off);
+    else for (int k = 0; off + k < count; k++) dst[off + k] = src[off + k];
+}
+
+int launch_dsp_image(const uint8_t *d_adpcm, int64_t adpcm_pitch, int adpcm_len, const int16_t *d_coefs,
+                     const int16_t *d_gain, const int16_t *d_start_context, const int16_t *d_loop_context, int nch,
+                     int sample_count, int nibble_count, int sample_rate, int looping, int start_addr, int end_addr,
+                     int cur_addr, int bytes_per_interleave, int frames_per_interleave, int audio_data_size,
+                     int mono_bytes, uint8_t *d_file, size_t file_size, hipStream_t stream)
+{
+    VGA_HIP_TRY(hipMemsetAsync(d_file, 0, file_size, stream));
+    DspGeometry g{sample_count, nibble_count, sample_rate, looping, start_addr, end_addr, cur_addr,
+                  bytes_per_interleave, frames_per_interleave, audio_data_size};
+    hipLaunchKernelGGL(gc_dsp_header_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, d_gain,
+                       d_start_context, d_loop_context, nch, g, d_file);
+    VGA_HIP_TRY(hipGetLastError());
+    uint8_t *data = d_file + (size_t)0x60 * nch;
+    if (nch == 1) {
+        if (mono_bytes > 0)
+            hipLaunchKernelGGL(gc_dsp_copy_kernel, dim3((mono_bytes + 2047) / 2048), dim3(256), 0, stream, d_adpcm, mono_bytes, data);
+    } else if (adpcm_len > 0) {
+        const int64_t words = ((int64_t)adpcm_len + 7) / 8;
+        hipLaunchKernelGGL(gc_dsp_interleave_kernel, dim3((unsigned)((words + 255) / 256), nch), dim3(256), 0, stream, d_adpcm,
+                           adpcm_pitch, adpcm_len, nch, bytes_per_interleave, audio_data_size, data);
+    }
+    VGA_HIP_TRY(hipGetLastError());
+    return VGA_OK;
+}
+
+}  // namespace gc
+}  // namespace vga

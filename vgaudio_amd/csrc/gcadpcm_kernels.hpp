@@ -28,6 +28,11 @@ int launch_align_gather(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int lo
 int launch_channel_meta(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_pcm, int64_t pcm_pitch, int nch,
                         int loop_start, int samples_per_entry, int entries, int16_t *d_seek, int64_t seek_pitch,
                         int16_t *d_loop_context, hipStream_t stream);
+int launch_dsp_image(const uint8_t *d_adpcm, int64_t adpcm_pitch, int adpcm_len, const int16_t *d_coefs,
+                     const int16_t *d_gain, const int16_t *d_start_context, const int16_t *d_loop_context, int nch,
+                     int sample_count, int nibble_count, int sample_rate, int looping, int start_addr, int end_addr,
+                     int cur_addr, int bytes_per_interleave, int frames_per_interleave, int audio_data_size,
+                     int mono_bytes, uint8_t *d_file, size_t file_size, hipStream_t stream);
 int launch_synth(int16_t *d_pcm, int64_t pitch, int nch, int length, int first_channel, const uint32_t *d_params,
                  hipStream_t stream);
 

@@ -209,6 +209,7 @@ class GcAdpcmChannel:
         self.LoopContext = GcAdpcmContext()
         self.LoopContextStart = 0
         self.StartContext = GcAdpcmContext(adpcm[0] if len(adpcm) else 0, 0, 0)
+        self.Gain = 0
 
     @property
     def SampleCount(self):                       # GcAdpcmChannel.cs:11
