@@ -254,6 +254,40 @@ int vga_adx_decode_device(const uint8_t *d_adpcm, int64_t in_pitch, int adpcm_le
                           int sample_count, const vga_adx_params *p, int16_t *d_pcm,
                           int64_t pcm_pitch, int *d_status, void *stream);
 
+/* ----------------------------------------------------------------------
+ * ADX container: VGAudio/Containers/Adx/AdxWriter.cs:14-139.
+ * Header (big-endian; version 4 adds the channel histories), "(c)CRI", the channels' frames interleaved one
+ * frame at a time, footer 0x8001 + padding.  The reference writes the header fields one after the other
+ * whatever HeaderSize is and lets "(c)CRI" and the audio overwrite what ran past it; it puts the footer where
+ * the interleaver left the stream -- both are reproduced.  Encryption (EncryptionKey) is rank 4, not here.
+ * -------------------------------------------------------------------- */
+typedef struct {
+    int sample_rate;
+    int sample_count;                  /* CriAdxFormat.SampleCount (unaligned + AlignmentSamples) */
+    int looping, loop_start, loop_end; /* CriAdxFormat.Looping / LoopStart / LoopEnd (aligned) */
+    int alignment_samples;             /* CriAdxFormat.AlignmentSamples */
+    int frame_size, version, type;     /* CriAdxFormat.FrameSize / Version / Type (2 Fixed, 3 Linear, 4 Exponential) */
+    int highpass_frequency;            /* CriAdxFormat.HighpassFrequency */
+    int encryption_type;               /* AdxConfiguration.EncryptionType: header byte only */
+    int trim_file;                     /* Configuration.TrimFile (default true) */
+} vga_adx_file_params;
+typedef struct {
+    int sample_count, frame_count;                     /* AdxWriter.cs:21,28 */
+    int base_header_size, alignment_bytes, header_size;/* :30-31,58-69 */
+    int audio_offset, audio_size;                      /* :32-33 */
+    int footer_offset, footer_size;                    /* :34-35 */
+    int loop_start_offset, loop_end_offset;            /* :36-37 */
+    int file_size;                                     /* :18 */
+} vga_adx_file_layout;
+int vga_adx_file_layout_for(const vga_adx_file_params *p, int nch, vga_adx_file_layout *out);
+/* audio[c]: CriAdxChannel.Audio (audio_len bytes each); history[c]: CriAdxChannel.History (needed for version 4);
+ * file_out: layout.file_size bytes */
+int vga_adx_write(const uint8_t *const *audio, int audio_len, const int16_t *history, int nch,
+                  const vga_adx_file_params *p, uint8_t *file_out);
+/* device-resident: d_audio rows audio_pitch bytes apart and d_history as vga_adx_encode_device leaves them */
+int vga_adx_write_device(const uint8_t *d_audio, int64_t audio_pitch, int audio_len, const int16_t *d_history, int nch,
+                         const vga_adx_file_params *p, uint8_t *d_file, void *stream);
+
 /* ======================================================================
  * CRI HCA
  * ====================================================================== */
@@ -315,6 +349,23 @@ int vga_hca_decode_device(const vga_hca_info *info, const uint8_t *d_frames, int
  * ====================================================================== */
 int vga_synth_pcm16_device(int16_t *d_pcm, int64_t pcm_pitch, int nch, int length,
                            int first_channel, const uint32_t *d_params, void *stream);
+
+/* ----------------------------------------------------------------------
+ * HCA container: VGAudio/Containers/Hca/HcaWriter.cs:12-185.
+ * Chunks HCA/fmt/comp/[loop]/ciph/[rva]/pad|comm, zero padding to HeaderSize - 2, CRC-16 of the header, then the
+ * frames back to back.  comment: NUL-terminated or NULL (HcaInfo.Comment; info.comment_length must have been its
+ * length when the encoder sized the header); volume: HcaInfo.Volume (1 = no rva chunk); encryption_type:
+ * HcaInfo.EncryptionType (header field only; encryption is rank 4).
+ * -------------------------------------------------------------------- */
+int vga_hca_file_size(const vga_hca_info *info);                              /* HcaWriter.FileSize (:22), < 0 = error */
+int vga_hca_file_header(const vga_hca_info *info, const char *comment, float volume, int encryption_type,
+                        uint8_t *header_out /* info->header_size bytes */);   /* WriteHeader (:57-82); host only */
+int vga_hca_write(const vga_hca_info *info, const uint8_t *frames, const char *comment, float volume,
+                  int encryption_type, uint8_t *file_out);                    /* host memory; header + copy */
+/* nstreams equally shaped streams: image s (file_pitch apart) = header + the frames of stream s (frames_pitch apart) */
+int vga_hca_write_device(const vga_hca_info *info, const uint8_t *d_frames, int64_t frames_pitch, int nstreams,
+                         const char *comment, float volume, int encryption_type, uint8_t *d_files, int64_t file_pitch,
+                         void *stream);
 
 #ifdef __cplusplus
 }

@@ -195,6 +195,36 @@ int vgo_hca_decode_batch(const vgo_hca_info *info, const uint8_t *frames, long f
 /* test hooks */
 int vgo_hca_table(const char *name, double *out, int cap);
 uint16_t vgo_crc16(const uint8_t *data, int size);                       /* Utilities/Crc16.cs:12-18 */
+
+/* ---- ADX / HCA containers (adxhca_container_oracle.c): Containers/Adx/AdxWriter.cs, Containers/Hca/HcaWriter.cs ---- */
+typedef struct {
+    int sample_rate;
+    int sample_count;                  /* CriAdxFormat.SampleCount (= unaligned + AlignmentSamples) */
+    int looping, loop_start, loop_end; /* CriAdxFormat.Looping / LoopStart / LoopEnd (aligned) */
+    int alignment_samples;             /* CriAdxFormat.AlignmentSamples */
+    int frame_size, version, type;     /* type: 2 Fixed, 3 Linear, 4 Exponential */
+    int highpass_frequency;
+    int encryption_type;               /* AdxConfiguration.EncryptionType (header byte only) */
+    int trim_file;
+} vgo_adxfile_params;
+typedef struct {
+    int sample_count, frame_count, base_header_size, alignment_bytes, header_size, audio_offset, audio_size;
+    int footer_offset, footer_size, loop_start_offset, loop_end_offset, file_size;
+} vgo_adxfile_layout;
+typedef struct {
+    int header_size, type, frame_size, bit_depth, channel_count, sample_rate, sample_count, highpass_frequency;
+    int version, revision, inserted_samples, loop_count, looping, loop_type;
+    int loop_start_sample, loop_start_byte, loop_end_sample, loop_end_byte;
+} vgo_adxfile_header;
+int vgo_adxfile_layout_for(const vgo_adxfile_params *p, int nch, vgo_adxfile_layout *out);
+int vgo_adxfile_write(const uint8_t *const *audio, int audio_len, const int16_t *history, int nch,
+                      const vgo_adxfile_params *p, uint8_t *file_out);
+int vgo_adxfile_read(const uint8_t *file, int file_len, vgo_adxfile_header *h, int16_t *history_out, uint8_t *const *audio_out);
+int vgo_hcafile_size(const vgo_hca_info *h);
+int vgo_hcafile_write(const vgo_hca_info *h, const uint8_t *frames, const char *comment, float volume, int encryption_type,
+                      uint8_t *file_out);
+int vgo_hcafile_read(const uint8_t *file, int file_len, vgo_hca_info *h, float *volume_out, int *encryption_type_out,
+                     char *comment_out, int *version_out);
 int vgo_bitwriter_write(uint8_t *buf, int buf_len, int position, int value, int bit_count);  /* BitWriter.cs:26-70 */
 void vgo_mdct_run(const double *in, int blocks, double *out, int inverse);   /* Mdct.cs:63-119, 128-point, HCA scale */
 int vgo_hca_debug_last_frame(const int16_t *pcm, long pitch, const vgo_hca_params *c, int frames,

@@ -377,6 +377,108 @@ def dsp_read(file_bytes):
     return rc, h, coefs, gain, sc, lc, [c[:nb] for c in chans]
 
 
+# ---------------- ADX / HCA containers ----------------
+ADXFILE_PARAM_FIELDS = ("sample_rate", "sample_count", "looping", "loop_start", "loop_end", "alignment_samples", "frame_size",
+                        "version", "type", "highpass_frequency", "encryption_type", "trim_file")
+
+
+class AdxFileParams(C.Structure):
+    """vgo_adxfile_params"""
+    _fields_ = [(n, C.c_int) for n in ADXFILE_PARAM_FIELDS]
+
+
+class AdxFileLayout(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("sample_count", "frame_count", "base_header_size", "alignment_bytes", "header_size",
+                                       "audio_offset", "audio_size", "footer_offset", "footer_size", "loop_start_offset",
+                                       "loop_end_offset", "file_size")]
+
+
+class AdxFileHeader(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("header_size", "type", "frame_size", "bit_depth", "channel_count", "sample_rate",
+                                       "sample_count", "highpass_frequency", "version", "revision", "inserted_samples",
+                                       "loop_count", "looping", "loop_type", "loop_start_sample", "loop_start_byte",
+                                       "loop_end_sample", "loop_end_byte")]
+
+
+def adxfile_params(sample_rate, sample_count, looping=False, loop_start=0, loop_end=0, alignment_samples=0, frame_size=18,
+                   version=4, type=3, highpass_frequency=500, encryption_type=0, trim_file=True):
+    return AdxFileParams(sample_rate, sample_count, int(looping), loop_start, loop_end, alignment_samples, frame_size, version,
+                         type, highpass_frequency, encryption_type, int(trim_file))
+
+
+def adxfile_layout(p, nch):
+    L = AdxFileLayout()
+    f = lib().vgo_adxfile_layout_for
+    f.argtypes = [C.POINTER(AdxFileParams), C.c_int, C.POINTER(AdxFileLayout)]
+    return f(C.byref(p), nch, C.byref(L)), L
+
+
+def adxfile_write(audio, history, p):
+    """AdxWriter -> (rc, file bytes).  audio: equally long uint8 arrays (CriAdxChannel.Audio); history per channel."""
+    nch = len(audio)
+    chans = [np.ascontiguousarray(a, dtype=np.uint8) for a in audio]
+    hist = np.ascontiguousarray(history, dtype=np.int16)
+    rc, L = adxfile_layout(p, nch)
+    if rc:
+        return rc, None
+    out = np.zeros(L.file_size, dtype=np.uint8)
+    ptrs = (C.POINTER(C.c_uint8) * nch)(*[_u8(a) for a in chans])
+    f = lib().vgo_adxfile_write
+    f.argtypes = [C.POINTER(C.POINTER(C.c_uint8)), C.c_int, C.POINTER(C.c_int16), C.c_int, C.POINTER(AdxFileParams),
+                  C.POINTER(C.c_uint8)]
+    rc = f(ptrs, len(chans[0]), _i16(hist), nch, C.byref(p), _u8(out))
+    return rc, out
+
+
+def adxfile_read(file_bytes):
+    """AdxReader -> (rc, header, history, [audio per channel])"""
+    data = np.ascontiguousarray(np.frombuffer(bytes(file_bytes), dtype=np.uint8))
+    f = lib().vgo_adxfile_read
+    f.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.POINTER(AdxFileHeader), C.POINTER(C.c_int16),
+                  C.POINTER(C.POINTER(C.c_uint8))]
+    h = AdxFileHeader()
+    rc = f(_u8(data), len(data), C.byref(h), None, None)
+    if rc:
+        return rc, h, None, None
+    nch = h.channel_count
+    spf = (h.frame_size - 2) * 2
+    nb = h.frame_size * (-(-h.sample_count // spf))
+    hist = np.zeros(nch, np.int16)
+    chans = [np.zeros(max(nb, 1), np.uint8) for _ in range(nch)]
+    ptrs = (C.POINTER(C.c_uint8) * nch)(*[_u8(a) for a in chans])
+    rc = f(_u8(data), len(data), C.byref(h), _i16(hist), ptrs)
+    return rc, h, hist, [c[:nb] for c in chans]
+
+
+def hcafile_size(info):
+    f = lib().vgo_hcafile_size
+    f.argtypes = [C.POINTER(HcaInfo)]
+    return f(C.byref(info))
+
+
+def hcafile_write(info, frames, comment=None, volume=1.0, encryption_type=0):
+    """HcaWriter -> (rc, file bytes).  frames: frame_count * frame_size bytes."""
+    fr = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1)
+    out = np.zeros(hcafile_size(info), dtype=np.uint8)
+    f = lib().vgo_hcafile_write
+    f.argtypes = [C.POINTER(HcaInfo), C.POINTER(C.c_uint8), C.c_char_p, C.c_float, C.c_int, C.POINTER(C.c_uint8)]
+    rc = f(C.byref(info), _u8(fr), None if comment is None else comment.encode("utf-8"), volume, encryption_type, _u8(out))
+    return rc, out
+
+
+def hcafile_read(file_bytes):
+    """HcaReader header -> (rc, info, volume, encryption_type, comment, version)"""
+    data = np.ascontiguousarray(np.frombuffer(bytes(file_bytes), dtype=np.uint8))
+    f = lib().vgo_hcafile_read
+    f.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.POINTER(HcaInfo), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_char_p,
+                  C.POINTER(C.c_int)]
+    h = HcaInfo()
+    vol, enc, ver = C.c_float(), C.c_int(), C.c_int()
+    buf = C.create_string_buffer(max(len(data), 16))
+    rc = f(_u8(data), len(data), C.byref(h), C.byref(vol), C.byref(enc), buf, C.byref(ver))
+    return rc, h, vol.value, enc.value, buf.value.decode("utf-8", "replace"), ver.value
+
+
 # ---------------- ADX ----------------
 def adx_params(**kw):
     p = AdxParams()

@@ -90,6 +90,13 @@ SIGNATURES = {
     "vga_gcadpcm_encode_device": (ci, [vp, i64, ci, ci, vp, vp, vp, vp, i64, vp]),
     "vga_gcadpcm_decode_device": (ci, [vp, i64, vp, ci, ci, vp, vp, vp, i64, vp, vp]),
     "vga_synth_pcm16_device": (ci, [vp, i64, ci, ci, ci, vp, vp]),
+    "vga_adx_file_layout_for": (ci, [vp, ci, vp]),
+    "vga_adx_write": (ci, [u8pp, ci, i16p, ci, vp, u8p]),
+    "vga_adx_write_device": (ci, [vp, i64, ci, vp, ci, vp, vp, vp]),
+    "vga_hca_file_size": (ci, [vp]),
+    "vga_hca_file_header": (ci, [vp, C.c_char_p, C.c_float, ci, u8p]),
+    "vga_hca_write": (ci, [vp, u8p, C.c_char_p, C.c_float, ci, u8p]),
+    "vga_hca_write_device": (ci, [vp, vp, i64, ci, C.c_char_p, C.c_float, ci, vp, i64, vp]),
     "vga_dsp_layout_for": (ci, [vp, ci, vp]),
     "vga_dsp_write": (ci, [u8pp, ci, i16p, i16p, i16p, i16p, ci, vp, u8p]),
     "vga_dsp_write_device": (ci, [vp, i64, ci, vp, vp, vp, vp, ci, vp, vp, vp]),
@@ -114,6 +121,19 @@ SIGNATURES = {
     "vga_hca_encode_device": (ci, [vp, i64, i64, ci, ci, vp, vp, i64, vp, vp]),
     "vga_hca_decode_device": (ci, [vp, vp, i64, ci, vp, i64, i64, vp, C.c_size_t, vp, vp]),
 }
+
+
+class AdxFileParamsC(C.Structure):
+    """vga_adx_file_params"""
+    _fields_ = [(n, C.c_int) for n in ("sample_rate", "sample_count", "looping", "loop_start", "loop_end", "alignment_samples",
+                                       "frame_size", "version", "type", "highpass_frequency", "encryption_type", "trim_file")]
+
+
+class AdxFileLayoutC(C.Structure):
+    """vga_adx_file_layout"""
+    _fields_ = [(n, C.c_int) for n in ("sample_count", "frame_count", "base_header_size", "alignment_bytes", "header_size",
+                                       "audio_offset", "audio_size", "footer_offset", "footer_size", "loop_start_offset",
+                                       "loop_end_offset", "file_size")]
 
 
 class DspParamsC(C.Structure):

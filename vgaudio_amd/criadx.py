@@ -114,7 +114,8 @@ class CriAdxFormat:
         self.UnalignedSampleCount = sampleCount
         self.SampleRate, self.FrameSize, self.HighpassFrequency = sampleRate, frameSize, highpassFrequency
         self.AlignmentSamples, self.Type, self.Version = alignmentSamples, type_, version
-        self.Looping, self.UnalignedLoopStart, self.UnalignedLoopEnd = looping, loopStart, loopEnd
+        self.Looping = bool(looping)                     # AudioFormatBaseBuilder.WithLoop(false) zeroes the points
+        self.UnalignedLoopStart, self.UnalignedLoopEnd = (loopStart, loopEnd) if looping else (0, 0)
 
     @property
     def ChannelCount(self):
@@ -123,6 +124,14 @@ class CriAdxFormat:
     @property
     def SampleCount(self):
         return self.UnalignedSampleCount + self.AlignmentSamples
+
+    @property
+    def LoopStart(self):                             # CriAdxFormat.cs:18
+        return self.UnalignedLoopStart + self.AlignmentSamples
+
+    @property
+    def LoopEnd(self):                               # :19
+        return self.UnalignedLoopEnd + self.AlignmentSamples
 
     def EncodeFromPcm16(self, pcm16, config=None):
         config = config or CriAdxParameters()

@@ -44,14 +44,22 @@ class HcaInfo:
                 LoopStartFrame="loop_start_frame", LoopEndFrame="loop_end_frame", PreLoopSamples="pre_loop_samples",
                 PostLoopSamples="post_loop_samples", UseAthCurve="use_ath_curve", CommentLength="comment_length")
 
+    _HOST = ("Comment", "Volume", "EncryptionType")          # HcaInfo.cs:43-47: container-only fields
+
     def __init__(self, c=None):
         object.__setattr__(self, "c", c if c is not None else _lib.HcaInfoC())
+        object.__setattr__(self, "Comment", None)
+        object.__setattr__(self, "Volume", 1.0)
+        object.__setattr__(self, "EncryptionType", 0)
 
     def __getattr__(self, name):
         return getattr(self.c, HcaInfo._MAP[name])
 
     def __setattr__(self, name, value):
-        setattr(self.c, HcaInfo._MAP[name], int(value))
+        if name in HcaInfo._HOST:
+            object.__setattr__(self, name, value)
+        else:
+            setattr(self.c, HcaInfo._MAP[name], int(value))
 
     @property
     def LoopStartSample(self):

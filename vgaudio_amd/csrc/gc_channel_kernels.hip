@@ -11,6 +11,7 @@
 // channels, GcAdpcmFormat.cs:32-39).
 #include "common.hpp"
 #include "gcadpcm_kernels.hpp"
+#include "container_kernels.hpp"
 
 namespace vga {
 namespace gc {
@@ -140,39 +141,6 @@ __global__ __launch_bounds__(64) void gc_dsp_header_kernel(
     put_be16(h + 0x4c, nch == 1 ? 0 : g.frames_per_interleave);
 }
 
-// WriteData (:82-94).  Multi-channel: 8-byte words (every offset involved is a multiple of 8: frames are 8 bytes,
-// AudioDataSize is rounded to 8); gaps the reference skips over (Position += ...) stay zero.
-__global__ __launch_bounds__(256) void gc_dsp_interleave_kernel(
-    const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, int input_size, int nch, int interleave, int output_size,
-    uint8_t *__restrict__ data)
-{
-    const int i = blockIdx.y;
-    const int64_t word = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t off = word * 8;                          // byte offset inside the channel's stream
-    if (off >= input_size) return;
-    const int in_blocks = (input_size + interleave - 1) / interleave, out_blocks = (output_size + interleave - 1) / interleave;
-    const int b = (int)(off / interleave);
-    if (b >= (in_blocks < out_blocks ? in_blocks : out_blocks)) return;
-    const int within = (int)(off - (int64_t)b * interleave);
-    const int cur_in = b == in_blocks - 1 ? input_size - (in_blocks - 1) * interleave : interleave;
-    const int cur_out = b == out_blocks - 1 ? output_size - (out_blocks - 1) * interleave : interleave;
-    const int n = cur_in < cur_out ? cur_in : cur_out;    // bytesToCopy
-    if (within >= n) return;
-    const uint8_t *src = adpcm + (int64_t)i * adpcm_pitch + off;
-    uint8_t *dst = data + (int64_t)interleave * b * nch + (int64_t)cur_out * i + within;
-    if (within + 8 <= n) *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(src);
-    else for (int k = 0; within + k < n; k++) dst[k] = src[k];
-}
-
-// single channel: `count` bytes verbatim behind the 0x60-byte header (destination is 8-byte aligned)
-__global__ __launch_bounds__(256) void gc_dsp_copy_kernel(const uint8_t *__restrict__ src, int count, uint8_t *__restrict__ dst)
-{
-    const int64_t off = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    if (off >= count) return;
-    if (off + 8 <= count) *reinterpret_cast<uint2 *>(dst + off) = *reinterpret_cast<const uint2 *>(src + off);
-    else for (int k = 0; off + k < count; k++) dst[off + k] = src[off + k];
-}
-
 int launch_dsp_image(const uint8_t *d_adpcm, int64_t adpcm_pitch, int adpcm_len, const int16_t *d_coefs,
                      const int16_t *d_gain, const int16_t *d_start_context, const int16_t *d_loop_context, int nch,
                      int sample_count, int nibble_count, int sample_rate, int looping, int start_addr, int end_addr,
@@ -186,16 +154,9 @@ int launch_dsp_image(const uint8_t *d_adpcm, int64_t adpcm_pitch, int adpcm_len,
                        d_start_context, d_loop_context, nch, g, d_file);
     VGA_HIP_TRY(hipGetLastError());
     uint8_t *data = d_file + (size_t)0x60 * nch;
-    if (nch == 1) {
-        if (mono_bytes > 0)
-            hipLaunchKernelGGL(gc_dsp_copy_kernel, dim3((mono_bytes + 2047) / 2048), dim3(256), 0, stream, d_adpcm, mono_bytes, data);
-    } else if (adpcm_len > 0) {
-        const int64_t words = ((int64_t)adpcm_len + 7) / 8;
-        hipLaunchKernelGGL(gc_dsp_interleave_kernel, dim3((unsigned)((words + 255) / 256), nch), dim3(256), 0, stream, d_adpcm,
-                           adpcm_pitch, adpcm_len, nch, bytes_per_interleave, audio_data_size, data);
-    }
-    VGA_HIP_TRY(hipGetLastError());
-    return VGA_OK;
+    // WriteData (:82-94): one channel verbatim (an "interleave" of one row), several in BytesPerInterleave blocks
+    if (nch == 1) return container::launch_interleave(d_adpcm, adpcm_pitch, mono_bytes, 1, mono_bytes, mono_bytes, data, stream);
+    return container::launch_interleave(d_adpcm, adpcm_pitch, adpcm_len, nch, bytes_per_interleave, audio_data_size, data, stream);
 }
 
 }  // namespace gc
