@@ -367,6 +367,32 @@ int vga_hca_write_device(const vga_hca_info *info, const uint8_t *d_frames, int6
                          const char *comment, float volume, int encryption_type, uint8_t *d_files, int64_t file_pitch,
                          void *stream);
 
+/* ----------------------------------------------------------------------
+ * WAVE, 16-bit PCM: the step before the codec path.
+ * VGAudio/Containers/Wave/WaveReader.cs:13-100 + Utilities/Riff/RiffParser.cs:36-78 (parse: host),
+ * Utilities/Interleave.cs:188-207 InterleavedByteToShort / :168-186 ShortToInterleavedByte (device transposes),
+ * Containers/Wave/WaveWriter.cs:12-165.  8-bit files are parsed but not converted (Pcm8 is outside this path).
+ * -------------------------------------------------------------------- */
+typedef struct {
+    int channel_count, sample_rate, bits_per_sample;
+    int sample_count;            /* per channel, from the data bytes present: the length of Pcm16Format's channels */
+    int sample_count_declared;   /* from the data chunk's declared size (WaveStructure.SampleCount, :27) */
+    int looping, loop_start, loop_end;   /* first smpl loop; Looping = End > Start (:32-37) */
+    int64_t data_offset;         /* of the data chunk's bytes inside the file */
+    int data_size, data_size_declared;
+} vga_wave_info;
+typedef struct { int sample_rate, sample_count, looping, loop_start, loop_end; } vga_wave_params;
+/* VGA_ERR_INVALID_DATA with the reference's message for what ValidateWaveFile rejects (:70-98) and for files that
+ * end inside a chunk; VGA_ERR_OUT_OF_RANGE for loop points Pcm16FormatBuilder.WithLoop rejects */
+int vga_wave_parse(const uint8_t *file, int64_t file_len, vga_wave_info *out);
+int vga_wave_read_pcm16(const uint8_t *file, int64_t file_len, const vga_wave_info *info, int16_t *const *pcm_out);
+int vga_wave_deinterleave_pcm16_device(const uint8_t *d_data, int sample_count, int nch, int16_t *d_pcm,
+                                       int64_t pcm_pitch /* samples */, void *stream);
+int64_t vga_wave_file_size(const vga_wave_params *p, int nch);                 /* WaveWriter.FileSize (:25), < 0 = error */
+int vga_wave_write_pcm16(const int16_t *const *pcm, int nch, const vga_wave_params *p, uint8_t *file_out);
+int vga_wave_write_pcm16_device(const int16_t *d_pcm, int64_t pcm_pitch, int nch, const vga_wave_params *p,
+                                uint8_t *d_file, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -225,6 +225,22 @@ int vgo_hcafile_write(const vgo_hca_info *h, const uint8_t *frames, const char *
                       uint8_t *file_out);
 int vgo_hcafile_read(const uint8_t *file, int file_len, vgo_hca_info *h, float *volume_out, int *encryption_type_out,
                      char *comment_out, int *version_out);
+
+/* ---- WAVE 16-bit PCM (wave_oracle.c): Containers/Wave/WaveReader.cs, WaveWriter.cs, Utilities/Riff ---- */
+typedef struct {
+    int channel_count, sample_rate, bits_per_sample;
+    int sample_count;            /* per channel, from the data bytes actually present (what the Pcm16Format holds) */
+    int sample_count_declared;   /* from the data chunk's declared size (WaveStructure.SampleCount) */
+    int looping, loop_start, loop_end;
+    int smpl_loop_count, smpl_loop_start, smpl_loop_end;
+    long data_offset;
+    int data_size, data_size_declared;
+} vgo_wave_info;
+typedef struct { int sample_rate, sample_count, looping, loop_start, loop_end; } vgo_wave_params;
+int vgo_wave_parse(const uint8_t *file, long file_len, vgo_wave_info *out);
+int vgo_wave_read_pcm16(const uint8_t *file, long file_len, const vgo_wave_info *w, int16_t *const *pcm_out);
+long vgo_wave_file_size(const vgo_wave_params *p, int nch);
+int vgo_wave_write_pcm16(const int16_t *const *pcm, int nch, const vgo_wave_params *p, uint8_t *file_out);
 int vgo_bitwriter_write(uint8_t *buf, int buf_len, int position, int value, int bit_count);  /* BitWriter.cs:26-70 */
 void vgo_mdct_run(const double *in, int blocks, double *out, int inverse);   /* Mdct.cs:63-119, 128-point, HCA scale */
 int vgo_hca_debug_last_frame(const int16_t *pcm, long pitch, const vgo_hca_params *c, int frames,

@@ -479,6 +479,54 @@ def hcafile_read(file_bytes):
     return rc, h, vol.value, enc.value, buf.value.decode("utf-8", "replace"), ver.value
 
 
+# ---------------- WAVE ----------------
+class WaveInfo(C.Structure):
+    _fields_ = ([(n, C.c_int) for n in ("channel_count", "sample_rate", "bits_per_sample", "sample_count", "sample_count_declared",
+                                        "looping", "loop_start", "loop_end", "smpl_loop_count", "smpl_loop_start", "smpl_loop_end")]
+                + [("data_offset", C.c_long), ("data_size", C.c_int), ("data_size_declared", C.c_int)])
+
+
+class WaveParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("sample_rate", "sample_count", "looping", "loop_start", "loop_end")]
+
+
+def wave_parse(file_bytes):
+    data = np.ascontiguousarray(np.frombuffer(bytes(file_bytes), dtype=np.uint8))
+    w = WaveInfo()
+    f = lib().vgo_wave_parse
+    f.argtypes = [C.POINTER(C.c_uint8), C.c_long, C.POINTER(WaveInfo)]
+    return f(_u8(data), len(data), C.byref(w)), w
+
+
+def wave_read(file_bytes):
+    """WaveReader -> (rc, info, [pcm per channel])"""
+    data = np.ascontiguousarray(np.frombuffer(bytes(file_bytes), dtype=np.uint8))
+    rc, w = wave_parse(file_bytes)
+    if rc:
+        return rc, w, None
+    chans = [np.zeros(max(w.sample_count, 1), np.int16) for _ in range(w.channel_count)]
+    ptrs = (C.POINTER(C.c_int16) * w.channel_count)(*[_i16(a) for a in chans])
+    f = lib().vgo_wave_read_pcm16
+    f.argtypes = [C.POINTER(C.c_uint8), C.c_long, C.POINTER(WaveInfo), C.POINTER(C.POINTER(C.c_int16))]
+    rc = f(_u8(data), len(data), C.byref(w), ptrs)
+    return rc, w, [c[:w.sample_count] for c in chans]
+
+
+def wave_write(pcm, sample_rate, looping=False, loop_start=0, loop_end=0):
+    """WaveWriter (16-bit) -> (rc, file bytes)"""
+    chans = [np.ascontiguousarray(a, dtype=np.int16) for a in pcm]
+    nch = len(chans)
+    p = WaveParams(sample_rate, len(chans[0]), int(looping), loop_start, loop_end)
+    fs = lib().vgo_wave_file_size
+    fs.restype, fs.argtypes = C.c_long, [C.POINTER(WaveParams), C.c_int]
+    out = np.zeros(fs(C.byref(p), nch), dtype=np.uint8)
+    ptrs = (C.POINTER(C.c_int16) * nch)(*[_i16(a) for a in chans])
+    f = lib().vgo_wave_write_pcm16
+    f.argtypes = [C.POINTER(C.POINTER(C.c_int16)), C.c_int, C.POINTER(WaveParams), C.POINTER(C.c_uint8)]
+    rc = f(ptrs, nch, C.byref(p), _u8(out))
+    return rc, out
+
+
 # ---------------- ADX ----------------
 def adx_params(**kw):
     p = AdxParams()

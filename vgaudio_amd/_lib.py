@@ -97,6 +97,12 @@ SIGNATURES = {
     "vga_hca_file_header": (ci, [vp, C.c_char_p, C.c_float, ci, u8p]),
     "vga_hca_write": (ci, [vp, u8p, C.c_char_p, C.c_float, ci, u8p]),
     "vga_hca_write_device": (ci, [vp, vp, i64, ci, C.c_char_p, C.c_float, ci, vp, i64, vp]),
+    "vga_wave_parse": (ci, [u8p, i64, vp]),
+    "vga_wave_read_pcm16": (ci, [u8p, i64, vp, i16pp]),
+    "vga_wave_deinterleave_pcm16_device": (ci, [vp, ci, ci, vp, i64, vp]),
+    "vga_wave_file_size": (i64, [vp, ci]),
+    "vga_wave_write_pcm16": (ci, [i16pp, ci, vp, u8p]),
+    "vga_wave_write_pcm16_device": (ci, [vp, i64, ci, vp, vp, vp]),
     "vga_dsp_layout_for": (ci, [vp, ci, vp]),
     "vga_dsp_write": (ci, [u8pp, ci, i16p, i16p, i16p, i16p, ci, vp, u8p]),
     "vga_dsp_write_device": (ci, [vp, i64, ci, vp, vp, vp, vp, ci, vp, vp, vp]),
@@ -134,6 +140,18 @@ class AdxFileLayoutC(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("sample_count", "frame_count", "base_header_size", "alignment_bytes", "header_size",
                                        "audio_offset", "audio_size", "footer_offset", "footer_size", "loop_start_offset",
                                        "loop_end_offset", "file_size")]
+
+
+class WaveInfoC(C.Structure):
+    """vga_wave_info"""
+    _fields_ = ([(n, C.c_int) for n in ("channel_count", "sample_rate", "bits_per_sample", "sample_count", "sample_count_declared",
+                                        "looping", "loop_start", "loop_end")]
+                + [("data_offset", C.c_int64), ("data_size", C.c_int), ("data_size_declared", C.c_int)])
+
+
+class WaveParamsC(C.Structure):
+    """vga_wave_params"""
+    _fields_ = [(n, C.c_int) for n in ("sample_rate", "sample_count", "looping", "loop_start", "loop_end")]
 
 
 class DspParamsC(C.Structure):

@@ -149,5 +149,74 @@ int launch_replicate(const uint8_t *d_header, int header_size, uint8_t *d_files,
     return VGA_OK;
 }
 
+// ---------------------------------------------------------------- WAVE: interleaved 16-bit PCM <-> planar channels
+// A 256-sample x 32-channel tile goes through LDS so that both the interleaved side (runs of nch shorts per sample)
+// and the planar side (runs of samples per channel) are accessed in contiguous runs.  Pure transposition: HBM-bound.
+constexpr int PCM_TS = 256, PCM_TC = 32;
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void pcm16_deinterleave_kernel(const uint8_t *__restrict__ in, int n, int nch,
+                                                                 int16_t *__restrict__ out, int64_t pitch)
+{
+    __shared__ int16_t tile[PCM_TS][PCM_TC + 1];
+    const int i0 = blockIdx.x * PCM_TS, c0 = blockIdx.y * PCM_TC;
+    const int st = min(PCM_TS, n - i0), ct = min(PCM_TC, nch - c0);
+    for (int e = threadIdx.x; e < st * ct; e += 256) {
+        const int s = e / ct, c = e - s * ct;
+        const int64_t off = ((int64_t)(i0 + s) * nch + c0 + c) * 2;
+        tile[s][c] = ALIGNED ? *reinterpret_cast<const int16_t *>(in + off) : (int16_t)(in[off] | (in[off + 1] << 8));
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < st * ct; e += 256) {
+        const int c = e / st, s = e - c * st;
+        out[(int64_t)(c0 + c) * pitch + i0 + s] = tile[s][c];
+    }
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void pcm16_interleave_kernel(const int16_t *__restrict__ in, int64_t pitch, int n, int nch,
+                                                               uint8_t *__restrict__ out)
+{
+    __shared__ int16_t tile[PCM_TS][PCM_TC + 1];
+    const int i0 = blockIdx.x * PCM_TS, c0 = blockIdx.y * PCM_TC;
+    const int st = min(PCM_TS, n - i0), ct = min(PCM_TC, nch - c0);
+    for (int e = threadIdx.x; e < st * ct; e += 256) {
+        const int c = e / st, s = e - c * st;
+        tile[s][c] = in[(int64_t)(c0 + c) * pitch + i0 + s];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < st * ct; e += 256) {
+        const int s = e / ct, c = e - s * ct;
+        const int64_t off = ((int64_t)(i0 + s) * nch + c0 + c) * 2;
+        const int16_t v = tile[s][c];
+        if (ALIGNED) *reinterpret_cast<int16_t *>(out + off) = v;
+        else { out[off] = (uint8_t)v; out[off + 1] = (uint8_t)(v >> 8); }
+    }
+}
+
+int launch_pcm16_deinterleave(const uint8_t *interleaved, int sample_count, int nch, int16_t *pcm, int64_t pitch, hipStream_t stream)
+{
+    if (sample_count <= 0 || nch <= 0) return VGA_OK;
+    const dim3 grid((sample_count + PCM_TS - 1) / PCM_TS, (nch + PCM_TC - 1) / PCM_TC);
+    if (((uintptr_t)interleaved & 1) == 0)
+        hipLaunchKernelGGL(pcm16_deinterleave_kernel<true>, grid, dim3(256), 0, stream, interleaved, sample_count, nch, pcm, pitch);
+    else
+        hipLaunchKernelGGL(pcm16_deinterleave_kernel<false>, grid, dim3(256), 0, stream, interleaved, sample_count, nch, pcm, pitch);
+    VGA_HIP_TRY(hipGetLastError());
+    return VGA_OK;
+}
+
+int launch_pcm16_interleave(const int16_t *pcm, int64_t pitch, int sample_count, int nch, uint8_t *interleaved, hipStream_t stream)
+{
+    if (sample_count <= 0 || nch <= 0) return VGA_OK;
+    const dim3 grid((sample_count + PCM_TS - 1) / PCM_TS, (nch + PCM_TC - 1) / PCM_TC);
+    if (((uintptr_t)interleaved & 1) == 0)
+        hipLaunchKernelGGL(pcm16_interleave_kernel<true>, grid, dim3(256), 0, stream, pcm, pitch, sample_count, nch, interleaved);
+    else
+        hipLaunchKernelGGL(pcm16_interleave_kernel<false>, grid, dim3(256), 0, stream, pcm, pitch, sample_count, nch, interleaved);
+    VGA_HIP_TRY(hipGetLastError());
+    return VGA_OK;
+}
+
 }  // namespace container
 }  // namespace vga

@@ -22,5 +22,11 @@ int launch_adx_footer(const AdxHeaderArgs &a, uint8_t *d_file, hipStream_t strea
 // copies one header_size-byte header (device) to the front of `count` images `pitch` bytes apart
 int launch_replicate(const uint8_t *d_header, int header_size, uint8_t *d_files, int64_t pitch, int count, hipStream_t stream);
 
+// WAVE 16-bit PCM <-> planar channels (Utilities/Interleave.cs:188-207 InterleavedByteToShort, :168-186
+// ShortToInterleavedByte).  `interleaved` is a little-endian byte stream at ANY alignment; planar row c at
+// pcm + c * pitch (in samples).
+int launch_pcm16_deinterleave(const uint8_t *interleaved, int sample_count, int nch, int16_t *pcm, int64_t pitch, hipStream_t stream);
+int launch_pcm16_interleave(const int16_t *pcm, int64_t pitch, int sample_count, int nch, uint8_t *interleaved, hipStream_t stream);
+
 }  // namespace container
 }  // namespace vga
