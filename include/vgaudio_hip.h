@@ -355,17 +355,18 @@ int vga_synth_pcm16_device(int16_t *d_pcm, int64_t pcm_pitch, int nch, int lengt
  * Chunks HCA/fmt/comp/[loop]/ciph/[rva]/pad|comm, zero padding to HeaderSize - 2, CRC-16 of the header, then the
  * frames back to back.  comment: NUL-terminated or NULL (HcaInfo.Comment; info.comment_length must have been its
  * length when the encoder sized the header); volume: HcaInfo.Volume (1 = no rva chunk); encryption_type:
- * HcaInfo.EncryptionType (header field only; encryption is rank 4).
+ * HcaInfo.EncryptionType; encrypted_ids: non-zero when Configuration.EncryptionKey is set -- every
+ * chunk id byte gets its top bit (WriteChunkId :158-171).  The frames are encrypted beforehand with vga_hca_crypt*.
  * -------------------------------------------------------------------- */
 int vga_hca_file_size(const vga_hca_info *info);                              /* HcaWriter.FileSize (:22), < 0 = error */
 int vga_hca_file_header(const vga_hca_info *info, const char *comment, float volume, int encryption_type,
-                        uint8_t *header_out /* info->header_size bytes */);   /* WriteHeader (:57-82); host only */
+                        int encrypted_ids, uint8_t *header_out /* info->header_size bytes */);   /* WriteHeader (:57-82); host only */
 int vga_hca_write(const vga_hca_info *info, const uint8_t *frames, const char *comment, float volume,
-                  int encryption_type, uint8_t *file_out);                    /* host memory; header + copy */
+                  int encryption_type, int encrypted_ids, uint8_t *file_out);   /* host memory; header + copy */
 /* nstreams equally shaped streams: image s (file_pitch apart) = header + the frames of stream s (frames_pitch apart) */
 int vga_hca_write_device(const vga_hca_info *info, const uint8_t *d_frames, int64_t frames_pitch, int nstreams,
-                         const char *comment, float volume, int encryption_type, uint8_t *d_files, int64_t file_pitch,
-                         void *stream);
+                         const char *comment, float volume, int encryption_type, int encrypted_ids, uint8_t *d_files,
+                         int64_t file_pitch, void *stream);
 
 /* ----------------------------------------------------------------------
  * WAVE, 16-bit PCM: the step before the codec path.
@@ -392,6 +393,33 @@ int64_t vga_wave_file_size(const vga_wave_params *p, int nch);                 /
 int vga_wave_write_pcm16(const int16_t *const *pcm, int nch, const vga_wave_params *p, uint8_t *file_out);
 int vga_wave_write_pcm16_device(const int16_t *d_pcm, int64_t pcm_pitch, int nch, const vga_wave_params *p,
                                 uint8_t *d_file, void *stream);
+
+/* ----------------------------------------------------------------------
+ * ADX / HCA encryption passes and key derivations.
+ * VGAudio/Codecs/CriAdx/CriAdxKey.cs:10-66, CriAdxEncryption.cs:8-94;
+ * VGAudio/Codecs/CriHca/CriHcaKey.cs:8-181, CriHcaEncryption.cs:12-33.
+ * The known-key lists (CriAdxEncryptionKeys.cs, CriHcaEncryptionKeys.cs) stay with the caller: find_key takes
+ * the candidates.  The reference has no tests for any of this (parity unpinned by reference vectors).
+ * -------------------------------------------------------------------- */
+typedef struct { int seed, mult, inc; } vga_adx_key;                     /* CriAdxKey.Seed / Mult / Inc */
+int vga_adx_key_from_code(uint64_t key_code, vga_adx_key *out);          /* CriAdxKey(ulong) */
+int vga_adx_key_from_string(const char *key_string, vga_adx_key *out);   /* CriAdxKey(string), ASCII */
+uint64_t vga_adx_key_code(const vga_adx_key *key);                       /* CriAdxKey.KeyCode */
+/* EncryptDecrypt (its own inverse for type 8; type 9 also masks the first header byte), in place.
+ * audio_len must be whole frames. */
+int vga_adx_crypt(uint8_t *const *audio, int audio_len, int nch, const vga_adx_key *key, int encryption_type,
+                  int frame_size);
+int vga_adx_crypt_device(uint8_t *d_audio, int64_t audio_pitch, int audio_len, int nch, const vga_adx_key *key,
+                         int encryption_type, int frame_size, void *stream);
+/* FindKey over `keys` (host array): *index_out = first candidate every frame header agrees with, or -1 */
+int vga_adx_find_key_device(const uint8_t *d_audio, int64_t audio_pitch, int audio_len, int nch, int encryption_type,
+                            int frame_size, const vga_adx_key *keys, int nkeys, int *index_out, void *stream);
+/* CriHcaKey: key_type 56 = CriHcaKey(ulong keyCode), 0 / 1 = CriHcaKey(Type); both tables are 256 bytes */
+int vga_hca_key_tables(int key_type, uint64_t key_code, uint8_t *decryption_table, uint8_t *encryption_table);
+/* Crypt: substitute the first FrameSize - 2 bytes of every frame, refresh its CRC-16; table in host memory */
+int vga_hca_crypt(uint8_t *frames, int frame_count, int frame_size, const uint8_t *table);
+int vga_hca_crypt_device(uint8_t *d_frames, int64_t frames_pitch, int nstreams, int frame_count, int frame_size,
+                         const uint8_t *table, void *stream);
 
 #ifdef __cplusplus
 }

@@ -168,13 +168,19 @@ int vgo_adxfile_read(const uint8_t *file, int file_len, vgo_adxfile_header *h, i
 /* ------------------------------------------------------------------ HCA */
 int vgo_hcafile_size(const vgo_hca_info *h) { return h->header_size + h->frame_size * h->frame_count; }   /* :22 */
 
-static void chunk_id(cursor *c, const char *id, int n) { putn(c, id, n); }   /* WriteChunkId :158-171, no key */
+static int g_mask_ids;                                                  /* WriteChunkId :158-171 */
+static void chunk_id(cursor *c, const char *id, int n)
+{
+    for (int i = 0; i < n; i++) put8(c, (id[i] && g_mask_ids) ? (id[i] | 0x80) : id[i]);
+}
 
 /* frames: frame_count * frame_size bytes (CriHcaFormat.AudioData flattened); comment: NUL-terminated or NULL;
- * volume: HcaInfo.Volume (1 = no rva chunk); file_out: vgo_hcafile_size bytes. */
+ * volume: HcaInfo.Volume (1 = no rva chunk); encrypted_ids: an encryption key is configured (chunk ids get their
+ * top bits); file_out: vgo_hcafile_size bytes. */
 int vgo_hcafile_write(const vgo_hca_info *h, const uint8_t *frames, const char *comment, float volume, int encryption_type,
-                      uint8_t *file_out)
+                      int encrypted_ids, uint8_t *file_out)
 {
+    g_mask_ids = encrypted_ids;                                        /* Configuration.EncryptionKey != null */
     int size = vgo_hcafile_size(h);
     memset(file_out, 0, (size_t)size);
     cursor c = {file_out, size, 0, 0};

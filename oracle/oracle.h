@@ -222,7 +222,7 @@ int vgo_adxfile_write(const uint8_t *const *audio, int audio_len, const int16_t 
 int vgo_adxfile_read(const uint8_t *file, int file_len, vgo_adxfile_header *h, int16_t *history_out, uint8_t *const *audio_out);
 int vgo_hcafile_size(const vgo_hca_info *h);
 int vgo_hcafile_write(const vgo_hca_info *h, const uint8_t *frames, const char *comment, float volume, int encryption_type,
-                      uint8_t *file_out);
+                      int encrypted_ids, uint8_t *file_out);
 int vgo_hcafile_read(const uint8_t *file, int file_len, vgo_hca_info *h, float *volume_out, int *encryption_type_out,
                      char *comment_out, int *version_out);
 
@@ -241,6 +241,18 @@ int vgo_wave_parse(const uint8_t *file, long file_len, vgo_wave_info *out);
 int vgo_wave_read_pcm16(const uint8_t *file, long file_len, const vgo_wave_info *w, int16_t *const *pcm_out);
 long vgo_wave_file_size(const vgo_wave_params *p, int nch);
 int vgo_wave_write_pcm16(const int16_t *const *pcm, int nch, const vgo_wave_params *p, uint8_t *file_out);
+
+/* ---- ADX / HCA encryption (crypt_oracle.c): Codecs/CriAdx/CriAdxKey.cs, CriAdxEncryption.cs, Codecs/CriHca/CriHcaKey.cs,
+ * CriHcaEncryption.cs ---- */
+typedef struct { int seed, mult, inc; } vgo_adx_key;
+void vgo_adx_key_from_code(uint64_t key_code, vgo_adx_key *k);
+void vgo_adx_key_from_string(const char *s, vgo_adx_key *k);
+uint64_t vgo_adx_key_code(const vgo_adx_key *k);
+void vgo_adx_crypt_channel(uint8_t *adpcm, int adpcm_len, const vgo_adx_key *key, int encryption_type, int frame_size,
+                           int channel_num, int channel_count);
+int vgo_adx_test_key(const uint8_t *const *adpcm, int adpcm_len, int nch, const vgo_adx_key *key, int encryption_type, int frame_size);
+int vgo_hca_key_tables(int key_type, uint64_t key_code, uint8_t decryption[256], uint8_t encryption[256]);
+void vgo_hca_crypt(uint8_t *frames, int frame_count, int frame_size, const uint8_t table[256]);
 int vgo_bitwriter_write(uint8_t *buf, int buf_len, int position, int value, int bit_count);  /* BitWriter.cs:26-70 */
 void vgo_mdct_run(const double *in, int blocks, double *out, int inverse);   /* Mdct.cs:63-119, 128-point, HCA scale */
 int vgo_hca_debug_last_frame(const int16_t *pcm, long pitch, const vgo_hca_params *c, int frames,

@@ -456,13 +456,14 @@ def hcafile_size(info):
     return f(C.byref(info))
 
 
-def hcafile_write(info, frames, comment=None, volume=1.0, encryption_type=0):
+def hcafile_write(info, frames, comment=None, volume=1.0, encryption_type=0, encrypted_ids=False):
     """HcaWriter -> (rc, file bytes).  frames: frame_count * frame_size bytes."""
     fr = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1)
     out = np.zeros(hcafile_size(info), dtype=np.uint8)
     f = lib().vgo_hcafile_write
-    f.argtypes = [C.POINTER(HcaInfo), C.POINTER(C.c_uint8), C.c_char_p, C.c_float, C.c_int, C.POINTER(C.c_uint8)]
-    rc = f(C.byref(info), _u8(fr), None if comment is None else comment.encode("utf-8"), volume, encryption_type, _u8(out))
+    f.argtypes = [C.POINTER(HcaInfo), C.POINTER(C.c_uint8), C.c_char_p, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+    rc = f(C.byref(info), _u8(fr), None if comment is None else comment.encode("utf-8"), volume, encryption_type,
+           int(encrypted_ids), _u8(out))
     return rc, out
 
 
@@ -525,6 +526,67 @@ def wave_write(pcm, sample_rate, looping=False, loop_start=0, loop_end=0):
     f.argtypes = [C.POINTER(C.POINTER(C.c_int16)), C.c_int, C.POINTER(WaveParams), C.POINTER(C.c_uint8)]
     rc = f(ptrs, nch, C.byref(p), _u8(out))
     return rc, out
+
+
+# ---------------- ADX / HCA encryption ----------------
+class AdxKey(C.Structure):
+    _fields_ = [("seed", C.c_int), ("mult", C.c_int), ("inc", C.c_int)]
+
+
+def adx_key_from_code(code):
+    k = AdxKey()
+    f = lib().vgo_adx_key_from_code
+    f.restype, f.argtypes = None, [C.c_uint64, C.POINTER(AdxKey)]
+    f(code, C.byref(k))
+    return k
+
+
+def adx_key_from_string(s):
+    k = AdxKey()
+    f = lib().vgo_adx_key_from_string
+    f.restype, f.argtypes = None, [C.c_char_p, C.POINTER(AdxKey)]
+    f(s.encode("ascii"), C.byref(k))
+    return k
+
+
+def adx_key_code(k):
+    f = lib().vgo_adx_key_code
+    f.restype, f.argtypes = C.c_uint64, [C.POINTER(AdxKey)]
+    return f(C.byref(k))
+
+
+def adx_crypt(audio, key, encryption_type, frame_size=18):
+    """CriAdxEncryption.EncryptDecrypt on copies -> list of uint8 arrays"""
+    out = [np.array(a, dtype=np.uint8, copy=True) for a in audio]
+    f = lib().vgo_adx_crypt_channel
+    f.restype, f.argtypes = None, [C.POINTER(C.c_uint8), C.c_int, C.POINTER(AdxKey), C.c_int, C.c_int, C.c_int, C.c_int]
+    for i, a in enumerate(out):
+        f(_u8(a), len(a), C.byref(key), encryption_type, frame_size, i, len(out))
+    return out
+
+
+def adx_test_key(audio, key, encryption_type, frame_size=18):
+    chans = [np.ascontiguousarray(a, dtype=np.uint8) for a in audio]
+    ptrs = (C.POINTER(C.c_uint8) * len(chans))(*[_u8(a) for a in chans])
+    f = lib().vgo_adx_test_key
+    f.argtypes = [C.POINTER(C.POINTER(C.c_uint8)), C.c_int, C.c_int, C.POINTER(AdxKey), C.c_int, C.c_int]
+    return f(ptrs, len(chans[0]), len(chans), C.byref(key), encryption_type, frame_size)
+
+
+def hca_key_tables(key_type, key_code=0):
+    dec, enc = np.zeros(256, np.uint8), np.zeros(256, np.uint8)
+    f = lib().vgo_hca_key_tables
+    f.argtypes = [C.c_int, C.c_uint64, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
+    return f(key_type, key_code, _u8(dec), _u8(enc)), dec, enc
+
+
+def hca_crypt(frames, frame_size, table):
+    out = np.array(frames, dtype=np.uint8, copy=True).reshape(-1)
+    f = lib().vgo_hca_crypt
+    f.restype, f.argtypes = None, [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+    t = np.ascontiguousarray(table, dtype=np.uint8)
+    f(_u8(out), len(out) // frame_size, frame_size, _u8(t))
+    return out
 
 
 # ---------------- ADX ----------------

@@ -88,8 +88,6 @@ def test_adx_errors():
     L = _lib.AdxFileLayoutC()
     assert _lib.lib().vga_adx_file_layout_for(C.byref(p), 0, C.byref(L)) == _lib.ArgumentError.code
     assert _lib.lib().vga_adx_file_layout_for(C.byref(p), 256, C.byref(L)) == _lib.ArgumentError.code
-    with pytest.raises(_lib.ArgumentError):
-        AdxWriter(AdxConfiguration(EncryptionKey=object())).GetFile(Pcm16Format([np.zeros(64, np.int16)], 48000))
 
 
 # ------------------------------------------------------------------ HCA
@@ -124,7 +122,7 @@ def test_hca_device_batch_of_files():
     size = _lib.lib().vga_hca_file_size(C.byref(hca.c))
     pitch = size + 10
     d_files = torch.full((ns, pitch), 0xEE, dtype=torch.uint8, device="cuda")
-    _lib.check(_lib.lib().vga_hca_write_device(C.byref(hca.c), d_frames.data_ptr(), fpitch, ns, None, 1.0, 0, d_files.data_ptr(), pitch,
+    _lib.check(_lib.lib().vga_hca_write_device(C.byref(hca.c), d_frames.data_ptr(), fpitch, ns, None, 1.0, 0, 0, d_files.data_ptr(), pitch,
                                                torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     got = d_files.cpu().numpy()

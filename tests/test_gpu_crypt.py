@@ -1,0 +1,146 @@
+"""GPU parity for the ADX / HCA encryption passes: the device kernels against the oracle's
+literal loops, through the C ABI, including encrypted container files."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pyoracle as po
+from vgaudio_amd import _lib, synth
+from vgaudio_amd.adx import AdxConfiguration, AdxWriter
+from vgaudio_amd.criadx import CriAdxEncryption, CriAdxFormat, CriAdxKey, CriAdxParameters
+from vgaudio_amd.crihca import CriHcaEncryption, CriHcaFormat, CriHcaKey, CriHcaParameters
+from vgaudio_amd.gcadpcm import Pcm16Format
+from vgaudio_amd.hca import HcaConfiguration, HcaWriter
+
+pytestmark = pytest.mark.gpu
+
+
+def okey(k):
+    return po.AdxKey(k.Seed, k.Mult, k.Inc)
+
+
+@pytest.mark.parametrize("nch,frames", [(1, 1), (1, 1000), (2, 257), (3, 4096), (7, 100), (64, 3000)])
+@pytest.mark.parametrize("etype", [8, 9])
+def test_adx_crypt_matches_oracle(nch, frames, etype):
+    rng = np.random.default_rng(nch * 100 + frames)
+    audio = [rng.integers(0, 256, 18 * frames).astype(np.uint8) for _ in range(nch)]
+    for a in audio:                                                            # some empty frames, some with a lone byte
+        for f in rng.integers(0, frames, max(frames // 10, 1)):
+            a[18 * f:18 * f + 18] = 0
+        f = int(rng.integers(0, frames))
+        a[18 * f:18 * f + 18] = 0
+        a[18 * f + 17] = 1
+    key = CriAdxKey("sakakit4649")
+    want = po.adx_crypt(audio, okey(key), etype)
+    got = [a.copy() for a in audio]
+    CriAdxEncryption.EncryptDecrypt(got, key, etype, 18)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+def test_adx_crypt_arbitrary_lcg_parameters():
+    """CriAdxKey(seed, mult, inc) with values outside 15 bits: the first slot uses the raw seed (:18, :31-34)."""
+    rng = np.random.default_rng(5)
+    audio = [rng.integers(1, 256, 18 * 300).astype(np.uint8) for _ in range(2)]
+    for seed, mult, inc in ((0x12345, 0x46b1, 0x62ad), (0x7fff, 0x10001, 3), (0, 1, 0), (0x4d06, 0x663b, 0x7d09), (-5, 77777, -12345)):
+        key = CriAdxKey(seed, mult, inc)
+        want = po.adx_crypt(audio, okey(key), 8)
+        got = [a.copy() for a in audio]
+        CriAdxEncryption.EncryptDecrypt(got, key, 8, 18)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w), (seed, mult, inc)
+
+
+def test_adx_other_frame_sizes_and_errors():
+    rng = np.random.default_rng(6)
+    for fs in (4, 10, 34):
+        audio = [rng.integers(0, 256, fs * 77).astype(np.uint8) for _ in range(2)]
+        key = CriAdxKey(19910623)
+        want = po.adx_crypt(audio, okey(key), 9, fs)
+        got = [a.copy() for a in audio]
+        CriAdxEncryption.EncryptDecrypt(got, key, 9, fs)
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    with pytest.raises(_lib.ArgumentError):
+        CriAdxEncryption.EncryptDecrypt([np.zeros(19, np.uint8)], CriAdxKey(1), 8, 18)      # not whole frames
+
+
+def test_adx_find_key():
+    pcm = synth.generate(2, 32 * 3000)
+    fmt = CriAdxFormat().EncodeFromPcm16(Pcm16Format(list(pcm), 48000))
+    names = ["GHM", "GHMSC", "karaage", "mituba", "morio", "ranatus"]
+    keys = [CriAdxKey(n) for n in names] + [CriAdxKey(0x4133, 0x5a01, 0x5723)]
+    for target in (2, 5, 6):
+        enc = [np.array(c.Audio, dtype=np.uint8, copy=True) for c in fmt.Channels]
+        CriAdxEncryption.EncryptDecrypt(enc, keys[target], 8, 18)
+        found = CriAdxEncryption.FindKey(enc, 8, 18, keys)
+        want = next((k for k in keys if po.adx_test_key(enc, okey(k), 8)), None)
+        assert found is want and found is keys[target]
+    enc = [np.array(c.Audio, dtype=np.uint8, copy=True) for c in fmt.Channels]
+    CriAdxEncryption.EncryptDecrypt(enc, CriAdxKey("CS-GGNX+"), 8, 18)
+    assert CriAdxEncryption.FindKey(enc, 8, 18, keys) is None
+    codes = [CriAdxKey(c) for c in (12160794, 19910623, 416383518)]
+    enc9 = [np.array(c.Audio, dtype=np.uint8, copy=True) for c in fmt.Channels]
+    CriAdxEncryption.EncryptDecrypt(enc9, codes[1], 9, 18)
+    found = CriAdxEncryption.FindKey(enc9, 9, 18, codes)
+    want = next((k for k in codes if po.adx_test_key(enc9, okey(k), 9)), None)
+    assert found is want
+
+
+def test_adx_encrypted_file():
+    pcm = synth.generate(2, 20000)
+    fmt = CriAdxFormat().EncodeFromPcm16(Pcm16Format(list(pcm), 48000))
+    key = CriAdxKey("morio")
+    cfg = AdxConfiguration(EncryptionKey=key, EncryptionType=8)
+    f = AdxWriter(cfg).GetFile(fmt)
+    enc = po.adx_crypt([c.Audio for c in fmt.Channels], okey(key), 8)
+    p = po.adxfile_params(48000, 20000, encryption_type=8)
+    rc, want = po.adxfile_write(enc, [c.History for c in fmt.Channels], p)
+    assert rc == 0 and f == want.tobytes()
+    assert f[19] == 8
+    plain = AdxWriter().GetFile(fmt)                                           # the format's own audio was not touched (:123-127)
+    assert plain != f and po.adxfile_read(plain)[0] == 0
+
+
+@pytest.mark.parametrize("key", [CriHcaKey.Type0, CriHcaKey.Type1, 0xCC55463930DBE1AB, 88888888])
+def test_hca_crypt_matches_oracle(key):
+    pcm = synth.generate(2, 30000)
+    fmt = CriHcaFormat().EncodeFromPcm16(Pcm16Format(list(pcm), 48000), CriHcaParameters())
+    k = CriHcaKey(key)
+    frames = np.ascontiguousarray(fmt.AudioData, dtype=np.uint8).copy()
+    want = po.hca_crypt(frames, fmt.Hca.FrameSize, k.EncryptionTable).reshape(frames.shape)
+    CriHcaEncryption.Crypt(fmt.Hca, frames, k, False)
+    assert np.array_equal(frames, want)
+    CriHcaEncryption.Crypt(fmt.Hca, frames, k, True)
+    assert np.array_equal(frames, np.asarray(fmt.AudioData))
+
+
+def test_hca_crypt_device_batch_and_odd_sizes():
+    rng = np.random.default_rng(9)
+    rc, dec, enc = po.hca_key_tables(56, 123456789)
+    for ns, fc, fs in ((3, 17, 682), (1, 5, 3), (2, 9, 65), (4, 3, 4096), (2, 11, 1023)):
+        pitch = fc * fs + 5
+        host = rng.integers(0, 256, (ns, pitch)).astype(np.uint8)
+        d = torch.from_numpy(host.copy()).cuda()
+        _lib.check(_lib.lib().vga_hca_crypt_device(d.data_ptr(), pitch, ns, fc, fs, enc.ctypes.data_as(_lib.u8p),
+                                                   torch.cuda.current_stream().cuda_stream))
+        got = d.cpu().numpy()
+        for s in range(ns):
+            want = po.hca_crypt(host[s, :fc * fs], fs, enc)
+            assert np.array_equal(got[s, :fc * fs], want)
+            assert np.array_equal(got[s, fc * fs:], host[s, fc * fs:])
+    assert _lib.lib().vga_hca_crypt_device(d.data_ptr(), pitch, 1, 1, 5000, enc.ctypes.data_as(_lib.u8p), None) == _lib.ArgumentError.code
+
+
+def test_hca_encrypted_file():
+    pcm = synth.generate(2, 20000)
+    key = CriHcaKey(0x0123456789ABCDEF)
+    f = HcaWriter(HcaConfiguration(EncryptionKey=key)).GetFile(Pcm16Format(list(pcm), 48000))
+    rc, info, frames = po.hca_encode(pcm, po.hca_params(2, 20000))
+    enc = po.hca_crypt(frames, info.frame_size, key.EncryptionTable)
+    rc, want = po.hcafile_write(info, enc, encryption_type=56, encrypted_ids=True)
+    assert rc == 0 and f == want.tobytes()
+    assert f[:4] == bytes([0xC8, 0xC3, 0xC1, 0x00])
+    rc, r, vol, etype, comment, ver = po.hcafile_read(f)                       # the reader masks the ids off again
+    assert rc == 0 and etype == 56 and r.frame_count == info.frame_count

@@ -186,14 +186,16 @@ def test_hca_comment_chunk():
 def test_host_header_matches_oracle():
     """vga_hca_file_header / vga_hca_write do no device work: compared on the CPU."""
     from vgaudio_amd import _lib
-    for kw, comment, volume, enc in (({}, None, 1.0, 0), (dict(looping=True, loop_start=1200, loop_end=4800), None, 0.25, 1),
-                                     ({}, "a comment", 1.0, 56)):
+    for kw, comment, volume, enc, masked in (({}, None, 1.0, 0, 0), (dict(looping=True, loop_start=1200, loop_end=4800), None, 0.25, 1, 1),
+                                             ({}, "a comment", 1.0, 56, 1)):
         info, frames = hca_stream(**kw)
         if comment:
             info.comment_length = len(comment)
             info.header_size = -(-(96 + len(comment)) // 32) * 32
-        rc, want = po.hcafile_write(info, frames, comment=comment, volume=volume, encryption_type=enc)
+        rc, want = po.hcafile_write(info, frames, comment=comment, volume=volume, encryption_type=enc, encrypted_ids=masked)
         assert rc == 0
+        if masked:
+            assert bytes(want[:4]) == b"\xc8\xc3\xc1\x00" and bytes(want[8:12]) == b"\xe6\xed\xf4\x00"   # "HCA\0", "fmt\0" | 0x80
         ci = _lib.HcaInfoC()
         C.memmove(C.byref(ci), C.byref(info), C.sizeof(ci))
         size = _lib.lib().vga_hca_file_size(C.byref(ci))
@@ -201,14 +203,14 @@ def test_host_header_matches_oracle():
         got = np.zeros(size, np.uint8)
         fr = np.ascontiguousarray(frames).reshape(-1)
         cb = None if comment is None else comment.encode()
-        _lib.check(_lib.lib().vga_hca_write(C.byref(ci), fr.ctypes.data_as(_lib.u8p), cb, volume, enc, got.ctypes.data_as(_lib.u8p)))
+        _lib.check(_lib.lib().vga_hca_write(C.byref(ci), fr.ctypes.data_as(_lib.u8p), cb, volume, enc, masked, got.ctypes.data_as(_lib.u8p)))
         assert got.tobytes() == want.tobytes()
         hdr = np.zeros(info.header_size, np.uint8)
-        _lib.check(_lib.lib().vga_hca_file_header(C.byref(ci), cb, volume, enc, hdr.ctypes.data_as(_lib.u8p)))
+        _lib.check(_lib.lib().vga_hca_file_header(C.byref(ci), cb, volume, enc, masked, hdr.ctypes.data_as(_lib.u8p)))
         assert hdr.tobytes() == want[:info.header_size].tobytes()
     # chunks that do not fit HeaderSize
     ci.header_size = 48
-    assert _lib.lib().vga_hca_file_header(C.byref(ci), b"x" * 40, 1.0, 0, hdr.ctypes.data_as(_lib.u8p)) == _lib.InvalidOperationError.code
+    assert _lib.lib().vga_hca_file_header(C.byref(ci), b"x" * 40, 1.0, 0, 0, hdr.ctypes.data_as(_lib.u8p)) == _lib.InvalidOperationError.code
 
 
 def test_adx_layout_matches_oracle_on_host():

@@ -94,15 +94,24 @@ SIGNATURES = {
     "vga_adx_write": (ci, [u8pp, ci, i16p, ci, vp, u8p]),
     "vga_adx_write_device": (ci, [vp, i64, ci, vp, ci, vp, vp, vp]),
     "vga_hca_file_size": (ci, [vp]),
-    "vga_hca_file_header": (ci, [vp, C.c_char_p, C.c_float, ci, u8p]),
-    "vga_hca_write": (ci, [vp, u8p, C.c_char_p, C.c_float, ci, u8p]),
-    "vga_hca_write_device": (ci, [vp, vp, i64, ci, C.c_char_p, C.c_float, ci, vp, i64, vp]),
+    "vga_hca_file_header": (ci, [vp, C.c_char_p, C.c_float, ci, ci, u8p]),
+    "vga_hca_write": (ci, [vp, u8p, C.c_char_p, C.c_float, ci, ci, u8p]),
+    "vga_hca_write_device": (ci, [vp, vp, i64, ci, C.c_char_p, C.c_float, ci, ci, vp, i64, vp]),
     "vga_wave_parse": (ci, [u8p, i64, vp]),
     "vga_wave_read_pcm16": (ci, [u8p, i64, vp, i16pp]),
     "vga_wave_deinterleave_pcm16_device": (ci, [vp, ci, ci, vp, i64, vp]),
     "vga_wave_file_size": (i64, [vp, ci]),
     "vga_wave_write_pcm16": (ci, [i16pp, ci, vp, u8p]),
     "vga_wave_write_pcm16_device": (ci, [vp, i64, ci, vp, vp, vp]),
+    "vga_adx_key_from_code": (ci, [C.c_uint64, vp]),
+    "vga_adx_key_from_string": (ci, [C.c_char_p, vp]),
+    "vga_adx_key_code": (C.c_uint64, [vp]),
+    "vga_adx_crypt": (ci, [u8pp, ci, ci, vp, ci, ci]),
+    "vga_adx_crypt_device": (ci, [vp, i64, ci, ci, vp, ci, ci, vp]),
+    "vga_adx_find_key_device": (ci, [vp, i64, ci, ci, ci, ci, vp, ci, C.POINTER(ci), vp]),
+    "vga_hca_key_tables": (ci, [ci, C.c_uint64, u8p, u8p]),
+    "vga_hca_crypt": (ci, [u8p, ci, ci, u8p]),
+    "vga_hca_crypt_device": (ci, [vp, i64, ci, ci, ci, u8p, vp]),
     "vga_dsp_layout_for": (ci, [vp, ci, vp]),
     "vga_dsp_write": (ci, [u8pp, ci, i16p, i16p, i16p, i16p, ci, vp, u8p]),
     "vga_dsp_write_device": (ci, [vp, i64, ci, vp, vp, vp, vp, ci, vp, vp, vp]),
@@ -152,6 +161,11 @@ class WaveInfoC(C.Structure):
 class WaveParamsC(C.Structure):
     """vga_wave_params"""
     _fields_ = [(n, C.c_int) for n in ("sample_rate", "sample_count", "looping", "loop_start", "loop_end")]
+
+
+class AdxKeyC(C.Structure):
+    """vga_adx_key"""
+    _fields_ = [("seed", C.c_int), ("mult", C.c_int), ("inc", C.c_int)]
 
 
 class DspParamsC(C.Structure):

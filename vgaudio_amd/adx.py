@@ -1,12 +1,12 @@
 """ADX container writer -- host-side mirror of VGAudio/Containers/Adx/AdxWriter.cs and
-AdxConfiguration.cs.  The image is assembled on the GPU (vga_adx_write); there is no CPU path."""
+AdxConfiguration.cs.  The image is assembled on the GPU (vga_adx_write), encryption included (vga_adx_crypt); there is no CPU path."""
 import ctypes as C
 
 import numpy as np
 
 from . import _lib
 from ._lib import check, u8p
-from .criadx import CriAdxFormat, CriAdxParameters, CriAdxType
+from .criadx import CriAdxEncryption, CriAdxFormat, CriAdxParameters, CriAdxType
 from .gcadpcm import Pcm16Format, _i16, _ptr_array
 
 
@@ -32,8 +32,6 @@ class AdxWriter:
                 Progress=cfg.Progress, Version=cfg.Version, FrameSize=cfg.FrameSize, Filter=cfg.Filter, Type=cfg.Type))
         if not isinstance(audio, CriAdxFormat):
             raise _lib.ArgumentError("AdxWriter takes a CriAdxFormat or a Pcm16Format")
-        if cfg.EncryptionKey is not None:
-            raise _lib.ArgumentError("ADX encryption is not part of this path (SURVEY.md 8f rank 4)")
         return audio
 
     def _params(self, fmt):
@@ -55,6 +53,10 @@ class AdxWriter:
         L = self.Layout(fmt)
         p = self._params(fmt)
         src = [np.ascontiguousarray(ch.Audio, dtype=np.uint8) for ch in fmt.Channels]
+        cfg = self.Configuration
+        if cfg.EncryptionKey is not None:                    # WriteData (:123-128): encrypt copies, not the format's audio
+            src = [a.copy() for a in src]
+            CriAdxEncryption.EncryptDecrypt(src, cfg.EncryptionKey, cfg.EncryptionType, fmt.FrameSize)
         if any(len(a) != len(src[0]) for a in src):
             raise _lib.ArgumentOutOfRangeError("Inputs must be of equal length")            # Interleave.cs:49-50
         hist = np.array([ch.History for ch in fmt.Channels], dtype=np.int16)

@@ -163,3 +163,58 @@ class CriAdxFormat:
         out = Pcm16Format(pcm, self.SampleRate)
         out.Looping, out.LoopStart, out.LoopEnd = self.Looping, self.UnalignedLoopStart, self.UnalignedLoopEnd
         return out
+
+
+class CriAdxKey:
+    """Codecs/CriAdx/CriAdxKey.cs:10-56: CriAdxKey(seed, mult, inc) | CriAdxKey(keyCode) | CriAdxKey(keyString)."""
+
+    def __init__(self, *args):
+        k = _lib.AdxKeyC()
+        self.KeyString = None
+        if len(args) == 3:
+            k.seed, k.mult, k.inc = (int(a) for a in args)
+        elif len(args) == 1 and isinstance(args[0], str):
+            check(_lib.lib().vga_adx_key_from_string(args[0].encode("ascii"), C.byref(k)))
+            self.KeyString = args[0] or None
+        elif len(args) == 1:
+            check(_lib.lib().vga_adx_key_from_code(int(args[0]), C.byref(k)))
+        else:
+            raise _lib.ArgumentError("CriAdxKey(seed, mult, inc) | CriAdxKey(keyCode) | CriAdxKey(keyString)")
+        self.c = k
+
+    Seed = property(lambda self: self.c.seed)
+    Mult = property(lambda self: self.c.mult)
+    Inc = property(lambda self: self.c.inc)
+
+    @property
+    def KeyCode(self):
+        return int(_lib.lib().vga_adx_key_code(C.byref(self.c)))
+
+
+class CriAdxEncryption:
+    """Codecs/CriAdx/CriAdxEncryption.cs: EncryptDecrypt (:8-14) and FindKey (:43-57, over the caller's candidates)."""
+
+    @staticmethod
+    def EncryptDecrypt(adpcm, key, encryptionType, frameSize):
+        """In place on the caller's uint8 arrays, like the reference."""
+        for a in adpcm:
+            if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags.c_contiguous and a.flags.writeable):
+                raise _lib.ArgumentError("EncryptDecrypt works in place on contiguous, writable uint8 arrays")
+        if adpcm:
+            check(_lib.lib().vga_adx_crypt(_ptr_array(u8p, adpcm), len(adpcm[0]), len(adpcm), C.byref(key.c), encryptionType, frameSize))
+
+    @staticmethod
+    def FindKey(adpcm, encryptionType, frameSize, keys):
+        import torch
+        if not keys:
+            return None
+        n = len(adpcm[0]) if adpcm else 0
+        host = np.zeros((max(len(adpcm), 1), max(n, 1)), dtype=np.uint8)
+        for i, a in enumerate(adpcm):
+            host[i, :n] = a
+        d = torch.from_numpy(host).cuda()
+        arr = (_lib.AdxKeyC * len(keys))(*[k.c for k in keys])
+        idx = C.c_int(-1)
+        check(_lib.lib().vga_adx_find_key_device(d.data_ptr(), host.shape[1], n, len(adpcm), encryptionType, frameSize, arr, len(keys),
+                                                 C.byref(idx), torch.cuda.current_stream().cuda_stream))
+        return keys[idx.value] if idx.value >= 0 else None

@@ -151,3 +151,32 @@ class CriHcaFormat:
     def ToPcm16(self, config=None):
         pcm = CriHcaDecoder.Decode(self.Hca, self.AudioData, config)
         return Pcm16Format(pcm, self.Hca.SampleRate)
+
+
+class CriHcaKey:
+    """Codecs/CriHca/CriHcaKey.cs:8-39: CriHcaKey(keyCode) (KeyType 56) | CriHcaKey.Type0 / Type1."""
+    Type0, Type1 = "Type0", "Type1"
+
+    def __init__(self, key):
+        self.DecryptionTable = np.zeros(256, dtype=np.uint8)
+        self.EncryptionTable = np.zeros(256, dtype=np.uint8)
+        if key == CriHcaKey.Type0:
+            self.KeyType, self.KeyCode = 0, 0
+        elif key == CriHcaKey.Type1:
+            self.KeyType, self.KeyCode = 1, 0
+        else:
+            self.KeyType, self.KeyCode = 56, int(key)
+        check(_lib.lib().vga_hca_key_tables(self.KeyType, self.KeyCode, self.DecryptionTable.ctypes.data_as(u8p),
+                                            self.EncryptionTable.ctypes.data_as(u8p)))
+
+
+class CriHcaEncryption:
+    """Codecs/CriHca/CriHcaEncryption.cs:12-33."""
+
+    @staticmethod
+    def Crypt(hca, audio, key, doDecrypt):
+        """In place on `audio` ([FrameCount][FrameSize] uint8, contiguous)."""
+        if not (isinstance(audio, np.ndarray) and audio.dtype == np.uint8 and audio.flags.c_contiguous and audio.flags.writeable):
+            raise _lib.ArgumentError("Crypt works in place on a contiguous, writable uint8 array")
+        table = key.DecryptionTable if doDecrypt else key.EncryptionTable
+        check(_lib.lib().vga_hca_crypt(audio.ctypes.data_as(u8p), hca.FrameCount, hca.FrameSize, table.ctypes.data_as(u8p)))

@@ -156,23 +156,26 @@ int vga_hca_file_size(const vga_hca_info *h)
 }
 
 // WriteHeader (:57-82): the chunks, zero padding, CRC-16 of everything before it.  header_out: h->header_size bytes.
-int vga_hca_file_header(const vga_hca_info *h, const char *comment, float volume, int encryption_type, uint8_t *header_out)
+int vga_hca_file_header(const vga_hca_info *h, const char *comment, float volume, int encryption_type, int encrypted_ids,
+                        uint8_t *header_out)
 {
     if (!h || !header_out) { set_error("null argument"); return VGA_ERR_ARGUMENT; }
     if (h->header_size < 8 || h->header_size > 0x7FFF) { set_error("HCA header size %d out of range", h->header_size); return VGA_ERR_OUT_OF_RANGE; }
     std::memset(header_out, 0, (size_t)h->header_size);
     HostCursor c{header_out, h->header_size - 2, 0};
-    c.putn("HCA\0", 4);                                     // :84-89
+    // WriteChunkId (:158-171): with an encryption key every non-zero id byte gets its top bit set
+    auto chunk = [&](const char *id, int n) { for (int i = 0; i < n; i++) c.put8(id[i] && encrypted_ids ? (id[i] | 0x80) : id[i]); };
+    chunk("HCA\0", 4);                                      // :84-89
     c.put16(0x0200);
     c.put16(h->header_size);
-    c.putn("fmt\0", 4);                                     // :91-103
+    chunk("fmt\0", 4);                                     // :91-103
     c.put8(h->channel_count);
     c.put8(h->sample_rate >> 16);
     c.put16(h->sample_rate);
     c.put32(h->frame_count);
     c.put16(h->inserted_samples);
     c.put16(h->appended_samples);
-    c.putn("comp", 4);                                      // :105-118
+    chunk("comp", 4);                                      // :105-118
     c.put16(h->frame_size);
     c.put8(h->min_resolution);
     c.put8(h->max_resolution);
@@ -184,18 +187,18 @@ int vga_hca_file_header(const vga_hca_info *h, const char *comment, float volume
     c.put8(h->bands_per_hfr_group);
     c.put16(0);
     if (h->looping) {                                       // :120-129
-        c.putn("loop", 4);
+        chunk("loop", 4);
         c.put32(h->loop_start_frame);
         c.put32(h->loop_end_frame);
         c.put16(h->pre_loop_samples);
         c.put16(h->post_loop_samples);
     }
-    c.putn("ciph", 4);                                      // :131-135
+    chunk("ciph", 4);                                      // :131-135
     c.put16(encryption_type);
     if (volume != 1.0f) {                                   // :137-146
         uint32_t bits;
         std::memcpy(&bits, &volume, 4);
-        c.putn("rva\0", 4);
+        chunk("rva\0", 4);
         c.put32((int)bits);
     }
     bool blank = true;                                      // string.IsNullOrWhiteSpace (:66)
@@ -203,9 +206,9 @@ int vga_hca_file_header(const vga_hca_info *h, const char *comment, float volume
         for (const char *s = comment; *s; s++)
             if (!(*s == ' ' || (*s >= 9 && *s <= 13))) blank = false;
     if (blank) {
-        c.putn("pad", 3);                                   // :154-157: three bytes
+        chunk("pad", 3);                                   // :154-157: three bytes
     } else {
-        c.putn("comm\0", 5);                                // :148-152
+        chunk("comm\0", 5);                                // :148-152
         c.putn(comment, (int)std::strlen(comment) + 1);
     }
     if (c.overflow) {
@@ -220,7 +223,7 @@ int vga_hca_file_header(const vga_hca_info *h, const char *comment, float volume
 
 // nstreams equally shaped streams (one HcaInfo): image s = header + stream s's frames, file_pitch bytes apart
 int vga_hca_write_device(const vga_hca_info *h, const uint8_t *d_frames, int64_t frames_pitch, int nstreams, const char *comment,
-                         float volume, int encryption_type, uint8_t *d_files, int64_t file_pitch, void *stream)
+                         float volume, int encryption_type, int encrypted_ids, uint8_t *d_files, int64_t file_pitch, void *stream)
 {
     const int size = vga_hca_file_size(h);
     if (size < 0) return size;
@@ -229,7 +232,7 @@ int vga_hca_write_device(const vga_hca_info *h, const uint8_t *d_frames, int64_t
     if (file_pitch < size || frames_pitch < audio) { set_error("pitch smaller than the data"); return VGA_ERR_ARGUMENT; }
     if (nstreams == 0) return VGA_OK;
     std::vector<uint8_t> header((size_t)h->header_size);
-    if (int rc = vga_hca_file_header(h, comment, volume, encryption_type, header.data())) return rc;
+    if (int rc = vga_hca_file_header(h, comment, volume, encryption_type, encrypted_ids, header.data())) return rc;
     hipStream_t s = (hipStream_t)stream;
     // the header goes into image 0 straight from the host, the other images copy it on the device
     VGA_HIP_TRY(hipMemcpyAsync(d_files, header.data(), header.size(), hipMemcpyHostToDevice, s));
@@ -245,12 +248,12 @@ int vga_hca_write_device(const vga_hca_info *h, const uint8_t *d_frames, int64_t
 // One stream held in host memory (CriHcaFormat.AudioData flattened): header + frames.  No device work is needed
 // for a 96-byte header and a copy, so this form stays on the host.
 int vga_hca_write(const vga_hca_info *h, const uint8_t *frames, const char *comment, float volume, int encryption_type,
-                  uint8_t *file_out)
+                  int encrypted_ids, uint8_t *file_out)
 {
     const int size = vga_hca_file_size(h);
     if (size < 0) return size;
     if (!file_out || (!frames && h->frame_count > 0)) { set_error("null argument"); return VGA_ERR_ARGUMENT; }
-    if (int rc = vga_hca_file_header(h, comment, volume, encryption_type, file_out)) return rc;
+    if (int rc = vga_hca_file_header(h, comment, volume, encryption_type, encrypted_ids, file_out)) return rc;
     std::memcpy(file_out + h->header_size, frames, (size_t)h->frame_size * h->frame_count);
     return VGA_OK;
 }

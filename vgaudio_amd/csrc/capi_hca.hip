@@ -141,7 +141,12 @@ struct CrcPow {
     uint16_t *dev[64] = {};
 } g_crc_pow;
 
-int crc_pow_table(const uint16_t **out)
+}  // namespace
+
+// shared with the encryption pass (capi_crypt.hip)
+namespace vga { namespace hca { int crc_pow_table(const uint16_t **out); } }
+
+int vga::hca::crc_pow_table(const uint16_t **out)
 {
     int device = 0;
     VGA_HIP_TRY(hipGetDevice(&device));
@@ -162,6 +167,10 @@ int crc_pow_table(const uint16_t **out)
     *out = g_crc_pow.dev[device];
     return VGA_OK;
 }
+
+namespace {
+
+using vga::hca::crc_pow_table;
 
 int status_to_error(int status)
 {

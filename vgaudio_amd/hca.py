@@ -6,7 +6,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import check, u8p
-from .crihca import CriHcaFormat, CriHcaParameters, CriHcaQuality
+from .crihca import CriHcaEncryption, CriHcaFormat, CriHcaParameters, CriHcaQuality
 from .gcadpcm import Pcm16Format
 
 
@@ -33,8 +33,10 @@ class HcaWriter:
             audio = CriHcaFormat().EncodeFromPcm16(audio, enc)
         if not isinstance(audio, CriHcaFormat):
             raise _lib.ArgumentError("HcaWriter takes a CriHcaFormat or a Pcm16Format")
-        if cfg.EncryptionKey is not None:
-            raise _lib.ArgumentError("HCA encryption is not part of this path (SURVEY.md 8f rank 4)")
+        if cfg.EncryptionKey is not None:                    # :39-45 -- like the reference, this encrypts the format's frames in place
+            audio.AudioData = np.ascontiguousarray(audio.AudioData, dtype=np.uint8)
+            CriHcaEncryption.Crypt(audio.Hca, audio.AudioData, cfg.EncryptionKey, False)
+            audio.Hca.EncryptionType = cfg.EncryptionKey.KeyType
         return audio
 
     @staticmethod
@@ -45,7 +47,7 @@ class HcaWriter:
         hca = fmt.Hca
         out = np.zeros(hca.HeaderSize, dtype=np.uint8)
         check(_lib.lib().vga_hca_file_header(C.byref(hca.c), self._comment(hca), float(hca.Volume), int(hca.EncryptionType),
-                                             out.ctypes.data_as(u8p)))
+                                             int(self.Configuration.EncryptionKey is not None), out.ctypes.data_as(u8p)))
         return out.tobytes()
 
     def GetFile(self, audio, configuration=None):
@@ -61,5 +63,6 @@ class HcaWriter:
             raise _lib.ArgumentError("AudioData does not hold FrameCount frames of FrameSize bytes")
         out = np.zeros(size, dtype=np.uint8)
         check(_lib.lib().vga_hca_write(C.byref(hca.c), frames.ctypes.data_as(u8p), self._comment(hca), float(hca.Volume),
-                                       int(hca.EncryptionType), out.ctypes.data_as(u8p)))
+                                       int(hca.EncryptionType), int(self.Configuration.EncryptionKey is not None),
+                                       out.ctypes.data_as(u8p)))
         return out.tobytes()
