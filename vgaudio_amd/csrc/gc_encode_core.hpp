@@ -148,6 +148,7 @@ struct PassOut {
     uint64_t total;      // totalDistance
     int max_overflow;
     int o12, o13;        // reconstructed samples 12, 13
+    unsigned hist_pair;  // (o12 & 0xFFFF) | (o13 << 16): the next frame's history, as the kernel hands it on
     bool exact;          // false: the fast pass could not prove itself exact -> redo with pass_literal
 };
 
@@ -213,6 +214,7 @@ VGA_HD PassOut pass_literal(const int (&x)[16], int c0, int c1, int scale_power)
         o1 = recon;
     }
     r.total = total; r.max_overflow = max_overflow; r.o12 = o0; r.o13 = o1;
+    r.hist_pair = (unsigned)(o0 & 0xFFFF) | ((unsigned)o1 << 16);
     r.exact = true;
     return r;
 }
@@ -286,6 +288,7 @@ VGA_HD PassOut pass_fast_core(const int (&x)[16], const int (&in2048v)[14], cons
         o0 = o1;
         o1 = recon;
     }
+    r.hist_pair = (unsigned)(o0 & 0xFFFF) | ((unsigned)o1 << 16);
     const int ov = imax(imax(umax - 7, -8 - umin), 0);
     const int ac0 = c0 < 0 ? -c0 : c0, ac1 = c1 < 0 ? -c1 : c1;
     r.exact = ac0 + ac1 <= 32767 && ov <= 17497 && (((2 * ov + 1) << (k - 11)) <= 34996);

@@ -408,10 +408,10 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
             VGA_MARK("resolve_end");
             const bool won = l16 == winner;
 #ifdef VGA_ABL_PAY          // ablation (timing only): every lane continues from its own history
-            const unsigned pay_own = (unsigned)(r.o12 & 0xFFFF) | ((unsigned)r.o13 << 16);
+            const unsigned pay_own = r.hist_pair;
 #define row16_reduce(v, f) pay_own
 #endif
-            const unsigned pay = row16_reduce(won ? ((unsigned)(r.o12 & 0xFFFF) | ((unsigned)r.o13 << 16)) : 0u,
+            const unsigned pay = row16_reduce(won ? r.hist_pair : 0u,
                                               [](unsigned a, unsigned b) { return a | b; });
             if (won) {                                           // packed and flushed by the helper, a tile at a time
                 int4 *rec = &s_out[buf][grp][j][0];
