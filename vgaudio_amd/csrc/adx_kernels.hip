@@ -201,9 +201,8 @@ __global__ __launch_bounds__(64) void adx_decode_kernel(
     if (bad && status) atomicOr(status, 1);
 }
 
-// ---- fast paths: FrameSize 18 (32 samples), no padding -- BASELINE config 3 and the reference's defaults.
-// Same arithmetic as the generic kernels; the frame lives in registers (16 dword loads, prefetched one
-// frame ahead with ping-pong register sets), loops are fully unrolled, frames are written as dwords.
+// ---- FrameSize 18 (32 samples), no padding -- BASELINE config 3 and the reference's defaults: one frame's
+// 32 samples as 16 dwords (the tiled encoder's loader)
 __device__ __forceinline__ void adx_load32(const int16_t *src, int64_t first, int pcm_length, uint32_t (&w)[16])
 {
     if (first + 32 <= pcm_length) {
@@ -222,190 +221,6 @@ __device__ __forceinline__ void adx_load32(const int16_t *src, int64_t first, in
             w[k] = lo | (hi << 16);
         }
     }
-}
-
-template <bool V4, bool EXPONENTIAL>
-__device__ __forceinline__ void adx_encode_frame32(const uint32_t (&w)[16], int c0, int c1, int filter_bits, int &h0,
-                                                   int &h1, uint32_t (&out)[5])
-{
-    int x[32];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        x[2 * k] = (int)(int16_t)(w[k] & 0xFFFF);
-        x[2 * k + 1] = (int)w[k] >> 16;
-    }
-    int max_distance = 0;
-    {
-        int a = h0, b = h1;
-#pragma unroll
-        for (int j = 0; j < 32; j++) {
-            const int predicted = ((b * c0) >> 12) + ((a * c1) >> 12);
-            int distance = clamp16(x[j] - predicted);
-            distance = distance < 0 ? -distance : distance;
-            max_distance = max(max_distance, distance);
-            a = b;
-            b = x[j];
-        }
-    }
-    double gain;
-    int scale_out;
-    const int scale = calculate_scale(max_distance, EXPONENTIAL, gain, scale_out);
-    const uint32_t b0 = (uint32_t)(((scale_out >> 8) & 0x1f) | filter_bits);
-    uint32_t bytes[5] = {b0 | ((uint32_t)(scale_out & 0xff) << 8), 0, 0, 0, 0};   // 18 bytes + 2 spare
-    int a = h0, b = h1;
-#pragma unroll
-    for (int j = 0; j < 32; j++) {
-        int predicted = ((b * c0) >> 12) + ((a * c1) >> 12);
-        const int raw = x[j] - predicted;
-        const int scaled = clamp16(trunc_i32_ryujit((double)raw * gain));
-        const int q = scale_short_to_nibble(scaled);
-        const int decoded_distance = clamp16(scale * q);
-        if (V4) predicted = (b * c0 + a * c1) >> 12;
-        const int rec = clamp16(decoded_distance + predicted);
-        a = b;
-        b = rec;
-        const int byte_index = 2 + (j >> 1);
-        bytes[byte_index >> 2] |= (uint32_t)(q & 0xF) << (8 * (byte_index & 3) + ((j & 1) ? 0 : 4));
-    }
-    h0 = a;
-    h1 = b;
-#pragma unroll
-    for (int k = 0; k < 5; k++) out[k] = bytes[k];
-}
-
-template <bool V4, bool EXPONENTIAL>
-__global__ __launch_bounds__(64) void adx_encode_fs18_kernel(
-    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int pcm_length, AdxDeviceParams p,
-    uint8_t *__restrict__ out, int64_t out_pitch, int16_t *__restrict__ history_out)
-{
-    const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= nch) return;
-    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
-    uint16_t *dst = reinterpret_cast<uint16_t *>(out + (int64_t)ch * out_pitch);
-    const int frame_count = (pcm_length + 31) / 32;
-    const int c0 = p.coef0, c1 = p.coef1;
-    const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
-    int h0 = 0, h1 = 0, hist = p.history;
-    if (V4 && pcm_length > 0) { h0 = h1 = src[0]; hist = src[0]; }
-    if (history_out) history_out[ch] = (int16_t)hist;
-
-    auto store_frame = [&](int i, const uint32_t (&o)[5]) {
-        uint16_t *f = dst + (int64_t)i * 9;
-        if ((i & 1) == 0) {                                   // 36*k bytes: dword aligned
-            uint32_t *f32 = reinterpret_cast<uint32_t *>(f);
-#pragma unroll
-            for (int k = 0; k < 4; k++) f32[k] = o[k];
-            f[8] = (uint16_t)o[4];
-        } else {                                              // 2 bytes past a dword boundary
-            f[0] = (uint16_t)o[0];
-            uint32_t *f32 = reinterpret_cast<uint32_t *>(f + 1);
-#pragma unroll
-            for (int k = 0; k < 4; k++) f32[k] = (o[k] >> 16) | (o[k + 1] << 16);
-        }
-    };
-    uint32_t wa[16], wb[16], o[5];
-    if (frame_count > 0) adx_load32(src, 0, pcm_length, wa);
-    int i = 0;
-    for (; i + 1 < frame_count; i += 2) {
-        adx_load32(src, (int64_t)(i + 1) * 32, pcm_length, wb);
-        adx_encode_frame32<V4, EXPONENTIAL>(wa, c0, c1, filter_bits, h0, h1, o);
-        store_frame(i, o);
-        adx_load32(src, (int64_t)min(i + 2, frame_count - 1) * 32, pcm_length, wa);
-        adx_encode_frame32<V4, EXPONENTIAL>(wb, c0, c1, filter_bits, h0, h1, o);
-        store_frame(i + 1, o);
-    }
-    if (i < frame_count) {
-        adx_encode_frame32<V4, EXPONENTIAL>(wa, c0, c1, filter_bits, h0, h1, o);
-        store_frame(i, o);
-    }
-}
-
-template <bool V4>
-__global__ __launch_bounds__(64) void adx_decode_fs18_kernel(
-    const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int sample_count, AdxDeviceParams p,
-    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ status)
-{
-    const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= nch) return;
-    const uint16_t *src = reinterpret_cast<const uint16_t *>(adpcm + (int64_t)ch * in_pitch);
-    int16_t *dst = pcm + (int64_t)ch * pcm_pitch;
-    const int frame_count = (sample_count + 31) / 32;
-    int hist1 = p.history, hist2 = p.history;
-    bool bad = false;
-
-    auto load_frame = [&](int i, uint32_t (&w)[5]) {
-        const uint16_t *f = src + (int64_t)i * 9;
-        if ((i & 1) == 0) {
-            const uint32_t *f32 = reinterpret_cast<const uint32_t *>(f);
-#pragma unroll
-            for (int k = 0; k < 4; k++) w[k] = f32[k];
-            w[4] = f[8];
-        } else {
-            const uint32_t first = f[0];
-            const uint32_t *f32 = reinterpret_cast<const uint32_t *>(f + 1);
-            uint32_t t[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) t[k] = f32[k];
-            w[0] = first | (t[0] << 16);
-#pragma unroll
-            for (int k = 1; k < 4; k++) w[k] = (t[k - 1] >> 16) | (t[k] << 16);
-            w[4] = t[3] >> 16;
-        }
-    };
-    auto decode_frame = [&](int i, const uint32_t (&w)[5]) {
-        const int hb0 = w[0] & 0xff, hb1 = (w[0] >> 8) & 0xff;
-        int filter_num = ((hb0 >> 4) & 0xF) >> 1;
-        int cf0, cf1;
-        if (p.type == 2) {
-            if (filter_num > 3) { bad = true; filter_num = 3; }
-            cf0 = filter_num == 0 ? 0 : (filter_num == 1 ? 0x0F00 : (filter_num == 2 ? 0x1CC0 : 0x1880));
-            cf1 = filter_num == 0 ? 0 : (filter_num == 1 ? 0 : (filter_num == 2 ? (int)(int16_t)0xF300 : (int)(int16_t)0xF240));
-        } else {
-            if (filter_num > 0) bad = true;
-            cf0 = p.coef0;
-            cf1 = p.coef1;
-        }
-        int scale = (int)(int16_t)(((hb0 << 8) | hb1) & 0x1FFF);
-        scale = (int)(int16_t)(p.type == 4 ? (1 << ((12 - scale) & 31)) : scale + 1);
-        const int to_read = min(32, sample_count - i * 32);
-        int outv[32];
-#pragma unroll
-        for (int s = 0; s < 32; s++) {
-            const int byte_index = 2 + (s >> 1);
-            const int byte = (w[byte_index >> 2] >> (8 * (byte_index & 3))) & 0xff;
-            int sample = (s & 1) ? (byte & 0xF) : (byte >> 4);
-            sample = (sample ^ 8) - 8;
-            if (V4) sample = scale * sample + ((hist1 * cf0 + hist2 * cf1) >> 12);
-            else sample = scale * sample + ((hist1 * cf0) >> 12) + ((hist2 * cf1) >> 12);
-            const int fin = clamp16(sample);
-            if (s < to_read) { hist2 = hist1; hist1 = fin; }
-            outv[s] = fin;
-        }
-        if (to_read == 32) {
-            uint4 *d = reinterpret_cast<uint4 *>(dst + (int64_t)i * 32);
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                d[k] = make_uint4((uint32_t)(outv[8 * k] & 0xFFFF) | ((uint32_t)outv[8 * k + 1] << 16),
-                                  (uint32_t)(outv[8 * k + 2] & 0xFFFF) | ((uint32_t)outv[8 * k + 3] << 16),
-                                  (uint32_t)(outv[8 * k + 4] & 0xFFFF) | ((uint32_t)outv[8 * k + 5] << 16),
-                                  (uint32_t)(outv[8 * k + 6] & 0xFFFF) | ((uint32_t)outv[8 * k + 7] << 16));
-        } else {
-#pragma unroll
-            for (int s = 0; s < 32; s++)
-                if (s < to_read) dst[(int64_t)i * 32 + s] = (int16_t)outv[s];
-        }
-    };
-    uint32_t wa[5], wb[5];
-    if (frame_count > 0) load_frame(0, wa);
-    int i = 0;
-    for (; i + 1 < frame_count; i += 2) {
-        load_frame(i + 1, wb);
-        decode_frame(i, wa);
-        load_frame(min(i + 2, frame_count - 1), wa);
-        decode_frame(i + 1, wb);
-    }
-    if (i < frame_count) decode_frame(i, wa);
-    if (bad && status) atomicOr(status, 1);
 }
 
 // ---------------------------------------------------------------- 18-byte frames, serial wave + helper waves
@@ -812,12 +627,7 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
     // pcm rows must be 16-byte aligned for the vector loads, output rows 4-byte aligned for the dword stores
     const bool fast = p.frame_size == 18 && p.padding == 0 && (pcm_pitch % 8) == 0 && ((uintptr_t)d_pcm % 16) == 0 &&
                       (out_pitch % 4) == 0 && ((uintptr_t)d_out % 4) == 0;
-    // A/B switch for measurements only: VGA_ADX_ENCODE_IMPL=v1 selects the single-wave kernels
-    static const bool use_v1 = [] {
-        const char *e = getenv("VGA_ADX_ENCODE_IMPL");
-        return e && e[0] == 'v' && e[1] == '1';
-    }();
-    if (fast && !use_v1) {
+    if (fast) {
         const bool v4 = p.version == 4, ex = p.type == 4;
         const size_t lds = 2 * sizeof(AdxEncodeTile);
 #define VGA_ADX_ENC_T(V, E)                                                                                              \
@@ -836,18 +646,10 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
         else if (ex) VGA_ADX_ENC_T(false, true)
         else VGA_ADX_ENC_T(false, false)
 #undef VGA_ADX_ENC_T
-    } else if (fast) {
-        const bool v4 = p.version == 4, ex = p.type == 4;
-#define VGA_ADX_ENC(V, E) hipLaunchKernelGGL((adx_encode_fs18_kernel<V, E>), grid, block, 0, stream, d_pcm, pcm_pitch, nch, \
-                                             pcm_length, p, d_out, out_pitch, d_history_out)
-        if (v4 && ex) VGA_ADX_ENC(true, true);
-        else if (v4) VGA_ADX_ENC(true, false);
-        else if (ex) VGA_ADX_ENC(false, true);
-        else VGA_ADX_ENC(false, false);
-#undef VGA_ADX_ENC
-    } else
-    hipLaunchKernelGGL(adx_encode_kernel, grid, block, 0, stream, d_pcm, pcm_pitch, nch, pcm_length,
-                       p, d_out, out_pitch, d_history_out);
+    } else {                                           // other frame sizes, padded (looping) streams, odd alignments
+        hipLaunchKernelGGL(adx_encode_kernel, grid, block, 0, stream, d_pcm, pcm_pitch, nch, pcm_length, p, d_out, out_pitch,
+                           d_history_out);
+    }
     VGA_HIP_TRY(hipGetLastError());
     return VGA_OK;
 }
@@ -858,12 +660,7 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
     const bool fast = p.frame_size == 18 && p.padding == 0 && (pcm_pitch % 8) == 0 && ((uintptr_t)d_pcm % 16) == 0 &&
                       (in_pitch % 4) == 0 && ((uintptr_t)d_adpcm % 4) == 0;
-    // A/B switch for measurements only: VGA_ADX_DECODE_IMPL=v1 selects the single-wave kernels
-    static const bool use_v1 = [] {
-        const char *e = getenv("VGA_ADX_DECODE_IMPL");
-        return e && e[0] == 'v' && e[1] == '1';
-    }();
-    if (fast && !use_v1) {
+    if (fast) {
         const size_t lds = 2 * sizeof(AdxDecodeTile);
         static bool configured = false;
         if (!configured) {
@@ -879,15 +676,10 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
         else
             hipLaunchKernelGGL(adx_decode_fs18_tiled_kernel<false>, dim3((nch + 63) / 64), dim3(256), lds, stream, d_adpcm,
                                in_pitch, nch, sample_count, p, d_pcm, pcm_pitch, d_status);
-    } else if (fast && p.version == 4)
-        hipLaunchKernelGGL(adx_decode_fs18_kernel<true>, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, in_pitch, nch,
-                           sample_count, p, d_pcm, pcm_pitch, d_status);
-    else if (fast)
-        hipLaunchKernelGGL(adx_decode_fs18_kernel<false>, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, in_pitch,
-                           nch, sample_count, p, d_pcm, pcm_pitch, d_status);
-    else
-    hipLaunchKernelGGL(adx_decode_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, in_pitch, nch,
-                       sample_count, p, d_pcm, pcm_pitch, d_status);
+    } else {
+        hipLaunchKernelGGL(adx_decode_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, in_pitch, nch, sample_count, p,
+                           d_pcm, pcm_pitch, d_status);
+    }
     VGA_HIP_TRY(hipGetLastError());
     return VGA_OK;
 }

@@ -29,7 +29,7 @@ struct GcDecodeTile {
     int4 out[DTF][2][64];                 // [frame][half][channel]: 14 samples as 7 packed pairs, 1 padding
 };
 
-__global__ __launch_bounds__(256) void gc_decode_kernel_v2(
+__global__ __launch_bounds__(256) void gc_decode_kernel(
     const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
     int sample_count, const int16_t *__restrict__ hist1, const int16_t *__restrict__ hist2,
     int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ status)
@@ -198,19 +198,19 @@ __global__ __launch_bounds__(256) void gc_decode_kernel_v2(
     }
 }
 
-int launch_decode_v2(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs, int nch, int sample_count,
-                     const int16_t *d_hist1, const int16_t *d_hist2, int16_t *d_pcm, int64_t pcm_pitch, int *d_status,
-                     hipStream_t stream)
+int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs, int nch, int sample_count,
+                  const int16_t *d_hist1, const int16_t *d_hist2, int16_t *d_pcm, int64_t pcm_pitch, int *d_status,
+                  hipStream_t stream)
 {
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
     const size_t lds = 2 * sizeof(GcDecodeTile) + 64 * 16 * sizeof(int16_t);
     static bool configured = false;
     if (!configured) {
-        VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gc_decode_kernel_v2),
+        VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gc_decode_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    hipLaunchKernelGGL(gc_decode_kernel_v2, dim3((nch + 63) / 64), dim3(256), lds, stream, d_adpcm, adpcm_pitch, d_coefs,
+    hipLaunchKernelGGL(gc_decode_kernel, dim3((nch + 63) / 64), dim3(256), lds, stream, d_adpcm, adpcm_pitch, d_coefs,
                        nch, sample_count, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
     VGA_HIP_TRY(hipGetLastError());
     return VGA_OK;

@@ -498,14 +498,6 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_c
                   hipStream_t stream)
 {
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
-    // A/B switch for measurements only: VGA_GC_ENCODE_IMPL=v1 selects the first (literal) kernel
-    static const bool use_v1 = [] {
-        const char *e = getenv("VGA_GC_ENCODE_IMPL");
-        return e && e[0] == 'v' && e[1] == '1';
-    }();
-    if (use_v1)
-        return launch_encode_v1(d_pcm, pcm_pitch, nch, sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch,
-                                stream);
     hipLaunchKernelGGL(gc_encode_kernel, dim3((nch + 3) / 4), dim3(128), 0, stream, d_pcm, pcm_pitch, nch,
                        sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch);
     VGA_HIP_TRY(hipGetLastError());

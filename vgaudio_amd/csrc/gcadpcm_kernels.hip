@@ -1,25 +1,12 @@
-// gcadpcm_kernels.hip -- hand-written gfx950 kernels for Nintendo GC-ADPCM.
+// gcadpcm_kernels.hip -- GC-ADPCM coefficient search for gfx950 (+ the synthetic PCM generator of the benchmark).
 //
-// Replaces (reference paths relative to /root/reference/src/VGAudio/):
-//   gc_coefs_kernel   Codecs/GcAdpcm/GcAdpcmCoefficients.cs:9-110 (+ helpers :112-396)
-//   gc_encode_kernel  Codecs/GcAdpcm/GcAdpcmEncoder.cs:14-171
-//   gc_decode_kernel  Codecs/GcAdpcm/GcAdpcmDecoder.cs:10-54
+// Replaces VGAudio/Codecs/GcAdpcm/GcAdpcmCoefficients.cs:9-110 (+ helpers :112-396), bit-exact under RyuJIT x64
+// semantics: built with -ffp-contract=off -fwrapv, f64 division/rint are IEEE correctly rounded on gfx950.
+// The encoder lives in gc_encode_kernel.hip / gc_encode_core.hpp, the decoder in gc_decode_kernel.hip.
 //
-// Numeric contract: bit-exact with the reference under RyuJIT x64 semantics.
-// Built with -ffp-contract=off -fwrapv (int32 wraps like unchecked C#), f64
-// division/rint are IEEE correctly rounded on gfx950.
-//
-// Parallel decomposition (ADPCM is a serial recurrence inside a channel,
-// GcAdpcmEncoder.cs:40-41,138,160):
-//   encode: lane = (channel, predictor) -> 8 lanes per channel, 8 channels per
-//           wave64; the 8-predictor argmin is a DPP butterfly (no LDS); the
-//           winner's two reconstructed samples ride along as payload and
-//           become every lane's history for the next frame.
-//   decode: lane = channel (serial IIR per channel).
-//   coefs : one workgroup per channel; frames are lane-parallel for the
-//           per-frame LPC records and per-record cluster terms; the f64
-//           bucket sums are accumulated IN RECORD ORDER by one lane per
-//           (bucket, component) so roundings match the reference's loop.
+// gc_coefs_kernel: one wave per channel.  Frames are lane-parallel for the per-frame LPC records and the
+// per-record cluster terms; the f64 bucket sums are accumulated IN RECORD ORDER (ordered_sum) so that every
+// rounding matches the reference's loop.
 #include "common.hpp"
 #include "gcadpcm_kernels.hpp"
 
@@ -28,267 +15,6 @@
 
 namespace vga {
 namespace gc {
-
-// ---------------------------------------------------------------- helpers
-__device__ __forceinline__ int clamp16(int v) { return min(max(v, -32768), 32767); }
-__device__ __forceinline__ int clamp4(int v) { return min(max(v, -8), 7); }
-
-template <int CTRL>
-__device__ __forceinline__ int dpp_mov(int v)
-{
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
-}
-constexpr int DPP_QUAD_XOR1 = 0xB1;    // quad_perm [1,0,3,2]
-constexpr int DPP_QUAD_XOR2 = 0x4E;    // quad_perm [2,3,0,1]
-constexpr int DPP_ROW_HALF_MIRROR = 0x141;  // lane i <-> 7-i inside each 8-lane half row
-
-// ---------------------------------------------------------------- encode
-// One DspEncodeCoef quantise pass (GcAdpcmEncoder.cs:127-170 loop body) at a
-// given scale power.  x[0..1] history, x[2..15] input samples.
-struct PassResult {
-    uint32_t w0, w1;        // packed nibbles (frame bytes 1..7; byte 0 left clear)
-    uint64_t total;         // totalDistance (exact integer, < 2^36)
-    int max_overflow;
-    int o12, o13;           // reconstructed samples 12, 13 (next frame's history)
-};
-
-__device__ __forceinline__ PassResult quantise_pass(const int (&x)[16], int c0, int c1, int scale_power)
-{
-    PassResult r;
-    const int k = scale_power + 11;
-    const int scale = 1 << k;                               // (1 << scalePower) * 2048
-    const float inv_scale = __builtin_bit_cast(float, (127 - k) << 23);  // exact 2^-k
-    uint32_t w0 = 0, w1 = 0;
-    uint64_t total = 0;
-    int max_overflow = 0;
-    int o0 = x[0], o1 = x[1];
-#pragma unroll
-    for (int s = 0; s < 14; s++) {
-        const int predicted = o0 * c1 + o1 * c0;            // wraps like C# int
-        const int distance = x[s + 2] * 2048 - predicted;
-        // (int)((double)((float)distance / scale) +- 0.4999999f): scale is a power of
-        // two, so the f32 divide is the exact multiply by 2^-k.
-        const float fq = (float)distance * inv_scale;
-        const double half = (distance > 0) ? (double)0.4999999f : -(double)0.4999999f;
-        const int unclamped = (int)((double)fq + half);
-        const int q = clamp4(unclamped);
-        max_overflow = max(max_overflow, abs(unclamped - q));
-        const int nib = q & 0xF;
-        if (s < 6) w0 |= (uint32_t)nib << (8 * (s / 2 + 1) + ((s & 1) ? 0 : 4));
-        else       w1 |= (uint32_t)nib << (8 * ((s - 6) / 2) + ((s & 1) ? 0 : 4));
-        const int corrected = predicted + q * scale;
-        const int recon = clamp16((corrected + 1024) >> 11);
-        const int d = x[s + 2] - recon;
-        total += (uint64_t)(uint32_t)(d * d);
-        o0 = o1;
-        o1 = recon;
-    }
-    r.w0 = w0; r.w1 = w1; r.total = total; r.max_overflow = max_overflow; r.o12 = o0; r.o13 = o1;
-    return r;
-}
-
-// Pre-scan + initial scale power (GcAdpcmEncoder.cs:107-124).  Returns the value
-// scalePower holds when the do-loop is entered (before its first ++).
-__device__ __forceinline__ int initial_scale_power(const int (&x)[16], int c0, int c1)
-{
-    // maxDistance keeps the signed distance of the FIRST sample with the largest
-    // |distance| (strict >).  key = |d|<<5 | (15-s)<<1 | neg: max key == that sample.
-    int key = 0;
-#pragma unroll
-    for (int s = 0; s < 14; s++) {
-        const int predicted = (x[s] * c1 + x[s + 1] * c0) / 2048;
-        const int distance = clamp16(x[s + 2] - predicted);
-        const int ad = abs(distance);
-        const int kk = (ad << 5) | ((15 - s) << 1) | (distance < 0 ? 1 : 0);
-        key = max(key, kk);
-    }
-    int max_distance = key >> 5;
-    if (key & 1) max_distance = -max_distance;
-    int scale_power = 0;
-    while (scale_power <= 12 && (max_distance > 7 || max_distance < -8)) {
-        max_distance /= 2;
-        scale_power++;
-    }
-    return scale_power <= 1 ? -1 : scale_power - 2;
-}
-
-__device__ __forceinline__ void unpack_frame(const uint32_t (&w)[7], int (&x)[16])
-{
-#pragma unroll
-    for (int i = 0; i < 7; i++) {
-        x[2 + 2 * i] = (int)(int16_t)(w[i] & 0xFFFF);
-        x[3 + 2 * i] = (int)w[i] >> 16;
-    }
-}
-
-__global__ __launch_bounds__(64) void gc_encode_kernel_v1(
-    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int sample_count,
-    const int16_t *__restrict__ coefs, const int16_t *__restrict__ hist1,
-    const int16_t *__restrict__ hist2, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch)
-{
-    const int lane = threadIdx.x;
-    const int p = lane & 7;
-    const int ch_raw = blockIdx.x * 8 + (lane >> 3);
-    const bool live = ch_raw < nch;
-    const int ch = live ? ch_raw : nch - 1;
-
-    const int c0 = coefs[ch * 16 + 2 * p];
-    const int c1 = coefs[ch * 16 + 2 * p + 1];
-    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
-    uint8_t *dst = adpcm + (int64_t)ch * adpcm_pitch;
-
-    const int full_frames = sample_count / 14;
-    const int tail = sample_count - full_frames * 14;
-    const int frames = full_frames + (tail ? 1 : 0);
-
-    int x[16];
-    x[0] = hist2 ? hist2[ch] : 0;   // pcmBuffer[0] = History2 (GcAdpcmEncoder.cs:24)
-    x[1] = hist1 ? hist1[ch] : 0;   // pcmBuffer[1] = History1
-
-    uint32_t nxt[7];
-    if (full_frames > 0) {
-        const uint32_t *p32 = reinterpret_cast<const uint32_t *>(src);
-#pragma unroll
-        for (int i = 0; i < 7; i++) nxt[i] = p32[i];
-    }
-
-    for (int f = 0; f < frames; f++) {
-        const bool full = f < full_frames;
-        if (full) {
-            unpack_frame(nxt, x);
-            if (f + 1 < full_frames) {
-                const uint32_t *p32 = reinterpret_cast<const uint32_t *>(src + (int64_t)(f + 1) * 14);
-#pragma unroll
-                for (int i = 0; i < 7; i++) nxt[i] = p32[i];
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 14; s++) x[2 + s] = (s < tail) ? (int)src[(int64_t)f * 14 + s] : 0;
-        }
-
-        int scale_power = initial_scale_power(x, c0, c1);
-        PassResult r;
-        bool at_max;
-        do {
-            scale_power++;
-            at_max = scale_power >= 12;
-            r = quantise_pass(x, c0, c1, scale_power);
-            for (int v = r.max_overflow + 8; v > 256; v >>= 1)
-                if (++scale_power >= 12) scale_power = 11;
-            // TERMINATION GUARD: if the pass at scalePower 12 still overflows by > 248 the
-            // reference resets scalePower to 11 and repeats the identical pass forever
-            // (only reachable when coefs make the int32 predictor wrap; never with
-            // CalculateCoefficients output).  We stop after the first pass at 12.
-        } while (scale_power < 12 && r.max_overflow > 1 && !at_max);
-
-        // argmin over the 8 predictors, first index wins ties (GcAdpcmEncoder.cs:66-76):
-        // key = total<<3 | p is unique per lane; payload = the winner's history pair.
-        uint64_t key = (r.total << 3) | (uint64_t)p;
-        int pay = (r.o12 & 0xFFFF) | (r.o13 << 16);
-#define VGA_ARGMIN_STAGE(CTRL)                                                          \
-        {                                                                               \
-            const int olo = dpp_mov<CTRL>((int)(uint32_t)key);                          \
-            const int ohi = dpp_mov<CTRL>((int)(uint32_t)(key >> 32));                  \
-            const int opay = dpp_mov<CTRL>(pay);                                        \
-            const uint64_t okey = ((uint64_t)(uint32_t)ohi << 32) | (uint32_t)olo;      \
-            const bool take = okey < key;                                               \
-            key = take ? okey : key;                                                    \
-            pay = take ? opay : pay;                                                    \
-        }
-        VGA_ARGMIN_STAGE(DPP_QUAD_XOR1)
-        VGA_ARGMIN_STAGE(DPP_QUAD_XOR2)
-        VGA_ARGMIN_STAGE(DPP_ROW_HALF_MIRROR)
-#undef VGA_ARGMIN_STAGE
-        const int best = (int)(key & 7);
-
-        if (live && p == best) {
-            const uint32_t w0 = r.w0 | (uint32_t)((best << 4) | (scale_power & 0xF));
-            if (full) {
-                *reinterpret_cast<uint2 *>(dst + (int64_t)f * 8) = make_uint2(w0, r.w1);
-            } else {
-                // partial last frame: SampleCountToByteCount(tail) bytes (GcAdpcmEncoder.cs:38)
-                const int nbytes = (tail + 2 + 1) / 2;
-                const uint64_t both = ((uint64_t)r.w1 << 32) | w0;
-                for (int b = 0; b < nbytes; b++) dst[(int64_t)f * 8 + b] = (uint8_t)(both >> (8 * b));
-            }
-        }
-        x[0] = (int)(int16_t)(pay & 0xFFFF);   // pcmBuffer[0] = pcmBuffer[14]
-        x[1] = pay >> 16;                      // pcmBuffer[1] = pcmBuffer[15]
-    }
-}
-
-// ---------------------------------------------------------------- decode
-__global__ __launch_bounds__(64) void gc_decode_kernel(
-    const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
-    int sample_count, const int16_t *__restrict__ hist1, const int16_t *__restrict__ hist2,
-    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ status)
-{
-    const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= nch) return;
-    const uint8_t *src = adpcm + (int64_t)ch * adpcm_pitch;
-    int16_t *dst = pcm + (int64_t)ch * pcm_pitch;
-    int cf[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) cf[i] = coefs[ch * 16 + i];
-    int h1 = hist1 ? hist1[ch] : 0;
-    int h2 = hist2 ? hist2[ch] : 0;
-
-    const int full_frames = sample_count / 14;
-    const int tail = sample_count - full_frames * 14;
-    const int frames = full_frames + (tail ? 1 : 0);
-    bool bad = false;
-
-    uint2 nxt = make_uint2(0, 0);
-    if (full_frames > 0) nxt = *reinterpret_cast<const uint2 *>(src);
-
-    for (int f = 0; f < frames; f++) {
-        uint64_t bits;
-        int count = 14;
-        if (f < full_frames) {
-            bits = ((uint64_t)nxt.y << 32) | nxt.x;
-            if (f + 1 < full_frames) nxt = *reinterpret_cast<const uint2 *>(src + (int64_t)(f + 1) * 8);
-        } else {
-            count = tail;
-            const int nbytes = (tail + 2 + 1) / 2;
-            bits = 0;
-            for (int b = 0; b < nbytes; b++) bits |= (uint64_t)src[(int64_t)f * 8 + b] << (8 * b);
-        }
-        const int ps = (int)(bits & 0xFF);
-        const int scale = (1 << (ps & 0xF)) * 2048;
-        int predictor = (ps >> 4) & 0xF;
-        if (predictor > 7) { bad = true; predictor &= 7; }
-        // coefs[predictor*2], [predictor*2+1] without dynamic register indexing
-        int coef1 = 0, coef2 = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-            if (predictor == i) { coef1 = cf[2 * i]; coef2 = cf[2 * i + 1]; }
-
-        int out[14];
-#pragma unroll
-        for (int s = 0; s < 14; s++) {
-            const int byte = (int)((bits >> (8 * (1 + s / 2))) & 0xFF);
-            const int nib = (s & 1) ? (byte & 0xF) : (byte >> 4);
-            const int adpcm_sample = (nib ^ 8) - 8;               // SignedNibbles LUT, Helpers.cs:50
-            const int distance = scale * adpcm_sample;
-            const int predicted = coef1 * h1 + coef2 * h2;
-            const int corrected = predicted + distance;
-            const int scaled = (corrected + 1024) >> 11;
-            const int clamped = clamp16(scaled);
-            if (s < count) { h2 = h1; h1 = clamped; }
-            out[s] = clamped;
-        }
-        if (count == 14) {
-            uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + (int64_t)f * 14);
-#pragma unroll
-            for (int i = 0; i < 7; i++) d32[i] = (uint32_t)(out[2 * i] & 0xFFFF) | ((uint32_t)out[2 * i + 1] << 16);
-        } else {
-#pragma unroll
-            for (int s = 0; s < 14; s++)
-                if (s < count) dst[(int64_t)f * 14 + s] = (int16_t)out[s];
-        }
-    }
-    if (bad && status) atomicOr(status, 1);
-}
 
 // ---------------------------------------------------------------- coefficients
 struct Record {
@@ -535,8 +261,6 @@ __device__ void merge_finish_record(const double (&src)[3], double (&dst)[3])
     finish_record(tmp, dst);
 }
 
-constexpr int COEF_BLOCK = 256;
-constexpr uint8_t NO_BUCKET = 0xFF;
 
 __device__ __forceinline__ void load_frame16(const int16_t *src, int f, int length, int (&x)[16])
 {
@@ -555,170 +279,6 @@ __device__ __forceinline__ void load_frame16(const int16_t *src, int f, int leng
             const int idx = base + i;
             x[i] = (idx >= 0 && idx < length) ? (int)src[idx] : 0;
         }
-    }
-}
-
-// One workgroup per channel; whole CalculateCoefficients (:9-110).
-// records: [nch][frames] double2 scratch in HBM (NaN r1 marks "no record").
-__global__ __launch_bounds__(COEF_BLOCK) void gc_coefs_kernel_v1(
-    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int length,
-    double2 *__restrict__ records, int16_t *__restrict__ coefs_out)
-{
-    __shared__ double s_d1[COEF_BLOCK];
-    __shared__ double s_d2[COEF_BLOCK];
-    __shared__ uint8_t s_idx[COEF_BLOCK];
-    __shared__ double s_vb[8][3];      // vecBest
-    __shared__ double s_cw[8][3];      // per-codeword val1,val2,val3 of ContrastVectors
-    __shared__ double s_sum[8][3];     // bufferList
-    __shared__ int s_cnt[8];           // buffer1
-
-    const int ch = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
-    const int frames = (length + 13) / 14;
-    double2 *rec = records + (int64_t)ch * frames;
-
-    // ---- pass 0: per-frame records (:40-61) + mean of MatrixFilter outputs (:63-74)
-    double acc = 0.0;   // threads 0,1: vec1[1], vec1[2]
-    int cnt = 0;        // thread 0: recordCount
-    for (int base = 0; base < frames; base += COEF_BLOCK) {
-        const int f = base + tid;
-        uint8_t idx = NO_BUCKET;
-        double d1 = 0.0, d2 = 0.0;
-        if (f < frames) {
-            int x[16];
-            load_frame16(src, f, length, x);
-            const Record r = frame_record(frame_sums(x));
-            if (r.valid) {
-                matrix_filter(r.r1, r.r2, d1, d2);
-                idx = 0;
-                rec[f] = make_double2(r.r1, r.r2);
-            } else {
-                rec[f] = make_double2(__builtin_nan(""), 0.0);
-            }
-        }
-        s_idx[tid] = idx; s_d1[tid] = d1; s_d2[tid] = d2;
-        __syncthreads();
-        if (tid < 2) {
-            const int lim = min(COEF_BLOCK, frames - base);
-            const double *sd = tid == 0 ? s_d1 : s_d2;
-            for (int j = 0; j < lim; j++)
-                if (s_idx[j] == 0) { acc += sd[j]; cnt++; }
-        }
-        __syncthreads();
-    }
-    if (tid < 2) s_sum[0][1 + tid] = acc;
-    if (tid == 0) s_cnt[0] = cnt;
-    __syncthreads();
-
-    if (tid == 0) {
-        double vec1[3];
-        vec1[0] = 1.0;
-        vec1[1] = s_sum[0][1];
-        vec1[2] = s_sum[0][2];
-        const int record_count = s_cnt[0];
-        vec1[1] /= record_count;
-        vec1[2] /= record_count;
-        double vb[3];
-        merge_finish_record(vec1, vb);
-        s_vb[0][0] = vb[0]; s_vb[0][1] = vb[1]; s_vb[0][2] = vb[2];
-    }
-    __syncthreads();
-
-    // ---- 3 splits x 2 Lloyd iterations (:77-91, FilterRecords :344-396)
-    for (int w = 0; w < 3; w++) {
-        const int half = 1 << w;
-        const int exp = 2 << w;
-        if (tid < half) {
-            // vecBest[exp+i][y] = 0.01*vec2[y] + vecBest[i][y], vec2 = {0,-1,0}
-            s_vb[half + tid][0] = (0.01 * 0.0) + s_vb[tid][0];
-            s_vb[half + tid][1] = (0.01 * -1.0) + s_vb[tid][1];
-            s_vb[half + tid][2] = (0.01 * 0.0) + s_vb[tid][2];
-        }
-        __syncthreads();
-
-        for (int iter = 0; iter < 2; iter++) {
-            if (tid < exp) {
-                const double a = s_vb[tid][0], b = s_vb[tid][1], c = s_vb[tid][2];
-                s_cw[tid][0] = (a * a) + (b * b) + (c * c);
-                s_cw[tid][1] = (a * b) + (b * c);
-                s_cw[tid][2] = a * c;
-            }
-            __syncthreads();
-            double cw1[8], cw2[8], cw3[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                cw1[i] = s_cw[i < exp ? i : 0][0];
-                cw2[i] = s_cw[i < exp ? i : 0][1];
-                cw3[i] = s_cw[i < exp ? i : 0][2];
-            }
-
-            acc = 0.0;
-            cnt = 0;
-            const int bucket = tid >> 1;       // accumulator lanes: tid < 2*exp
-            const int comp = tid & 1;
-            for (int base = 0; base < frames; base += COEF_BLOCK) {
-                const int f = base + tid;
-                uint8_t idx = NO_BUCKET;
-                double d1 = 0.0, d2 = 0.0;
-                if (f < frames) {
-                    const double2 r = rec[f];
-                    if (r.x == r.x) {
-                        // ContrastVectors :335-342
-                        const double val = (r.y * r.x + -r.x) / (1.0 - r.y * r.y);
-                        const double bterm = (-r.x * val + -r.y);
-                        int index = 0;
-                        double value = 1.0e30;
-#pragma unroll
-                        for (int i = 0; i < 8; i++) {
-                            if (i < exp) {
-                                const double t = cw1[i] + (2.0 * val * cw2[i]) + (2.0 * bterm * cw3[i]);
-                                if (t < value) { value = t; index = i; }
-                            }
-                        }
-                        idx = (uint8_t)index;
-                        matrix_filter(r.x, r.y, d1, d2);
-                    }
-                }
-                s_idx[tid] = idx; s_d1[tid] = d1; s_d2[tid] = d2;
-                __syncthreads();
-                if (tid < 2 * exp) {
-                    const int lim = min(COEF_BLOCK, frames - base);
-                    const double *sd = comp == 0 ? s_d1 : s_d2;
-                    for (int j = 0; j < lim; j++)
-                        if (s_idx[j] == bucket) { acc += sd[j]; cnt++; }
-                }
-                __syncthreads();
-            }
-            if (tid < 2 * exp) {
-                s_sum[bucket][1 + comp] = acc;
-                if (comp == 0) s_cnt[bucket] = cnt;
-            }
-            __syncthreads();
-            if (tid < exp) {
-                // bufferList[i][0] accumulates 1.0 per record: exactly (double)count
-                double bl[3];
-                const int n = s_cnt[tid];
-                bl[0] = (double)n;
-                bl[1] = s_sum[tid][1];
-                bl[2] = s_sum[tid][2];
-                if (n > 0) { bl[0] /= n; bl[1] /= n; bl[2] /= n; }
-                double vb[3] = {s_vb[tid][0], s_vb[tid][1], s_vb[tid][2]};
-                merge_finish_record(bl, vb);
-                s_vb[tid][0] = vb[0]; s_vb[tid][1] = vb[1]; s_vb[tid][2] = vb[2];
-            }
-            __syncthreads();
-        }
-    }
-
-    // ---- output :94-108
-    if (tid < 16) {
-        const int z = tid >> 1;
-        const double d = -s_vb[z][1 + (tid & 1)] * 2048.0;
-        int out;
-        if (d > 0.0) out = (d > 32767.0) ? 32767 : (int)__builtin_rint(d);
-        else out = (d < -32768.0) ? -32768 : ((d != d) ? 0 : (int)__builtin_rint(d));
-        coefs_out[ch * 16 + tid] = (int16_t)out;
     }
 }
 
@@ -1033,47 +593,8 @@ int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, i
                  void *d_workspace, hipStream_t stream)
 {
     if (nch <= 0) return VGA_OK;
-    // A/B switch for measurements only: VGA_GC_COEFS_IMPL=v1 selects the first kernel
-    static const bool use_v1 = [] {
-        const char *e = getenv("VGA_GC_COEFS_IMPL");
-        return e && e[0] == 'v' && e[1] == '1';
-    }();
-    if (use_v1)
-        hipLaunchKernelGGL(gc_coefs_kernel_v1, dim3(nch), dim3(COEF_BLOCK), 0, stream, d_pcm, pcm_pitch, nch, length,
-                           reinterpret_cast<double2 *>(d_workspace), d_coefs);
-    else
-        hipLaunchKernelGGL(gc_coefs_kernel, dim3(nch), dim3(64), 0, stream, d_pcm, pcm_pitch, nch, length,
-                           reinterpret_cast<double2 *>(d_workspace), d_coefs);
-    VGA_HIP_TRY(hipGetLastError());
-    return VGA_OK;
-}
-
-int launch_encode_v1(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
-                  const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,
-                  hipStream_t stream)
-{
-    if (nch <= 0 || sample_count <= 0) return VGA_OK;
-    hipLaunchKernelGGL(gc_encode_kernel_v1, dim3((nch + 7) / 8), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
-                       sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch);
-    VGA_HIP_TRY(hipGetLastError());
-    return VGA_OK;
-}
-
-int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs, int nch, int sample_count,
-                  const int16_t *d_hist1, const int16_t *d_hist2, int16_t *d_pcm, int64_t pcm_pitch, int *d_status,
-                  hipStream_t stream)
-{
-    if (nch <= 0 || sample_count <= 0) return VGA_OK;
-    // A/B switch for measurements only: VGA_GC_DECODE_IMPL=v1 selects the first (single-wave) kernel
-    static const bool use_v1 = [] {
-        const char *e = getenv("VGA_GC_DECODE_IMPL");
-        return e && e[0] == 'v' && e[1] == '1';
-    }();
-    if (!use_v1)
-        return launch_decode_v2(d_adpcm, adpcm_pitch, d_coefs, nch, sample_count, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status,
-                                stream);
-    hipLaunchKernelGGL(gc_decode_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs,
-                       nch, sample_count, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
+    hipLaunchKernelGGL(gc_coefs_kernel, dim3(nch), dim3(64), 0, stream, d_pcm, pcm_pitch, nch, length,
+                       reinterpret_cast<double2 *>(d_workspace), d_coefs);
     VGA_HIP_TRY(hipGetLastError());
     return VGA_OK;
 }

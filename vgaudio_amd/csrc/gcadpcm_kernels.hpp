@@ -11,16 +11,10 @@ int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, i
 int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
                   const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,
                   hipStream_t stream);
-int launch_encode_v1(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
-                     const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,
-                     hipStream_t stream);
+// gc_decode_kernel.hip (serial wave + helper waves)
 int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs, int nch, int sample_count,
                   const int16_t *d_hist1, const int16_t *d_hist2, int16_t *d_pcm, int64_t pcm_pitch, int *d_status,
                   hipStream_t stream);
-// gc_decode_kernel.hip (serial wave + helper waves); launch_decode dispatches to it
-int launch_decode_v2(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs, int nch, int sample_count,
-                     const int16_t *d_hist1, const int16_t *d_hist2, int16_t *d_pcm, int64_t pcm_pitch, int *d_status,
-                     hipStream_t stream);
 // gc_channel_kernels.hip (channel metadata)
 int launch_align_gather(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int loop_start, int loop_end,
                         int samples_to_keep, int samples_to_encode, int16_t *d_new_pcm, int64_t new_pitch,
