@@ -38,6 +38,13 @@ def main():
     def rec(name, ms, nbytes, **kw):
         out[name] = dict(ms=round(ms, 3), GB_per_s=round(nbytes / ms / 1e6, 1), bytes_moved=int(nbytes), **kw)
 
+    # what a plain device copy reaches on this box (read + write), for scale
+    src = torch.empty(1 << 32, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    ms = timed(lambda: dst.copy_(src))
+    rec("hbm_copy_ceiling", ms, 2 * src.numel(), note="torch copy_ of 4 GiB")
+    del src, dst
+
     n = 60 * 48000
     # DSP image: 1024 channels x 60 s of GC-ADPCM (1.69 GB image)
     nch = 1024
