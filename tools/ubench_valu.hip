@@ -23,6 +23,14 @@ __global__ __launch_bounds__(64) void k(long long *out, int iters, int seed)
                 else if (KIND == 1) a[c] = min(max(a[c] + b, -32768), 32767); // add + med3
                 else if (KIND == 2) a[c] = (int)(float)a[c] + b;            // cvt, cvt, add
                 else if (KIND == 3) a[c] = (a[c] << 3) + b;                 // v_lshl_add_u32
+                else if (KIND == 5) {                                        // the decoders' recurrence: mad, shift, clamp
+                    a[c] = min(max((__mul24(a[c], m) + b) >> 11, -32768), 32767);
+                } else if (KIND == 6) {                                      // the same with dot2 + saturating pack
+                    int t;
+                    asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(t) : "v"(a[c]), "v"(m), "v"(b));
+                    t >>= 11;
+                    asm volatile("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(a[c]) : "v"(b), "v"(t));
+                }
                 else { double d = (double)(float)a[c] + 0.4999999; a[c] = (int)d + b; } // f64 detour
                 asm volatile("" : "+v"(a[c]));
             }
@@ -72,6 +80,10 @@ int main()
     run<1, 2>("cvt+cvt+add dependent", 3);
     run<4, 2>("cvt+cvt+add 4 chains", 3);
     run<1, 3>("lshl_add dependent", 1);
+    run<1, 5>("mad+ashr+med3 dependent", 3);
+    run<2, 5>("mad+ashr+med3 2 chains", 3);
+    run<1, 6>("dot2+ashr+cvt_pk dependent", 3);
+    run<2, 6>("dot2+ashr+cvt_pk 2 chains", 3);
     run<1, 4>("f64 detour dependent", 5);
     run<4, 4>("f64 detour 4 chains", 5);
     return 0;
