@@ -74,6 +74,22 @@ struct UsedBitsMemo {
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, known = 0;
 };
 
+// All sixteen costs of one band at once (the resolution is a compile-time constant in every unrolled step, so each
+// takes one side of band_cost only and the eight coefficients are read from LDS once).  The binary searches touch
+// a new resolution in some lane on nearly every step, which made the lazy variant evaluate band_cost -- both sides,
+// the lanes' resolutions differ -- about fifteen times per frame.
+__device__ __forceinline__ void build_cost_table(const LdsTables &T, const double *xs, bool valid, UsedBitsMemo &m)
+{
+    double x[8];
+#pragma unroll
+    for (int sf = 0; sf < 8; sf++) x[sf] = xs[sf];
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 16; r++) w[r >> 2] |= (uint32_t)band_cost(T, x, r) << (8 * (r & 3));
+    m.w0 = valid ? w[0] : 0u; m.w1 = valid ? w[1] : 0u; m.w2 = valid ? w[2] : 0u; m.w3 = valid ? w[3] : 0u;
+    m.known = 0xFFFFu;
+}
+
 // this thread's share of the frame's spectrum bits.  Up to two channels a thread owns one band and memoises
 // its costs; with more it owns several bands and recomputes.
 __device__ __forceinline__ int used_bits_partial(const LdsTables &T, int tid, int nch, const int *s_coded, const int *sfac,
@@ -87,6 +103,7 @@ __device__ __forceinline__ int used_bits_partial(const LdsTables &T, int tid, in
         const int noise = b < eval_boundary ? noise_level - 1 : noise_level;
         const int res = calculate_resolution(T, sfac[i], noise);
         const int word = res >> 2, shift = 8 * (res & 3);
+#ifdef VGA_HCA_LAZY_COSTS                               // the earlier scheme, kept for A/B timing
         const bool miss = valid && !((m.known >> res) & 1u);
         if (__any(miss)) {                             // wave-uniform: all lanes evaluate, the missing ones keep it
             const uint32_t cost = (uint32_t)band_cost(T, scaled + (size_t)i * 8, res) << shift;
@@ -96,6 +113,7 @@ __device__ __forceinline__ int used_bits_partial(const LdsTables &T, int tid, in
             m.w3 |= (miss && word == 3) ? cost : 0u;
             m.known |= miss ? 1u << res : 0u;
         }
+#endif
         const uint32_t wsel = word == 0 ? m.w0 : word == 1 ? m.w1 : word == 2 ? m.w2 : m.w3;
         partial = valid ? (int)((wsel >> shift) & 0xFFu) : 0;
     } else {
@@ -388,6 +406,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     // cost is computed once and kept in registers (UsedBitsMemo).  used_bits_block() is a free function, not a
     // lambda: with the memo updated inside a capturing lambda hipcc kept every captured local in scratch.
     UsedBitsMemo memo;
+#ifndef VGA_HCA_LAZY_COSTS
+    if (nch * 128 <= 256) {
+        const int i = min(tid, nch * 128 - 1);
+        build_cost_table(T, scaled + (size_t)i * 8, tid < nch * 128, memo);
+    }
+#endif
     auto used_bits = [&](int noise_level, int eval_boundary) __attribute__((always_inline)) -> int {
         const int partial = used_bits_partial(T, tid, nch, s_coded, sfac, scaled, noise_level, eval_boundary, memo);
         int total = block_sum(partial) + 16 + 16 + 16;
@@ -505,16 +529,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     // QuantizeSpectra (:420-439) on the fly
     {
         const int per_thread = nch * 4;               // nch*8*128 / 256, divides 128
-        auto code_of = [&](int slot, unsigned &code, int &nbits) __attribute__((always_inline)) {
-            const int sf = slot / (nch * 128), c = (slot / 128) % nch, band = slot % 128;
-            const int res = ires[c * 128 + band];
+        // per_thread divides 128: a thread's slots share the sub-frame and the channel, the band runs on
+        const int slot0 = tid * per_thread;
+        const int sf = slot0 / (nch * 128), c = (slot0 / 128) % nch, band0 = slot0 % 128;
+        const double *xs = scaled + ((size_t)c * 128 + band0) * 8 + sf;
+        const int *rs = ires + c * 128 + band0;
+        auto code_of = [&](int k, unsigned &code, int &nbits) __attribute__((always_inline)) {
+            const int res = rs[k];
             code = 0;
             nbits = 0;
             if (res == 0) return;
             const double inv = T.inv_step[res];
             const double up = inv + 1;
             const int down = trunc_i(inv + 0.5);
-            const int q = trunc_i(scaled[((size_t)c * 128 + band) * 8 + sf] * inv + up) - down;
+            const int q = trunc_i(xs[(size_t)k * 8] * inv + up) - down;
             if (res < 8) {
                 nbits = T.enc_bits[res][q + 8];
                 code = T.enc_value[res][q + 8];
@@ -524,23 +552,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                 if (q != 0) { code = (code << 1) | (q > 0 ? 0u : 1u); nbits++; }
             }
         };
-        int local = 0;
-        for (int k = 0; k < per_thread; k++) {
-            unsigned code;
-            int nbits;
-            code_of(tid * per_thread + k, code, nbits);
-            local += nbits;
-        }
-        // exclusive scan of `local` over the 256 threads
-        int all_bits;
-        int off = 32 + group_exclusive_scan(local, 4, all_bits);
-        for (int c = 0; c < nch; c++) off += hlb[c];
-        for (int k = 0; k < per_thread && !too_low; k++) {
-            unsigned code;
-            int nbits;
-            code_of(tid * per_thread + k, code, nbits);
-            put_bits(off, code, nbits);
-            off += nbits;
+        // a thread's codes are consecutive in the stream: they are gathered in a 64-bit window and leave as whole
+        // dwords (one LDS atomic per dword instead of up to two per code)
+        struct Emitter {
+            unsigned *buf;
+            uint64_t acc;
+            int word, p;
+            __device__ __forceinline__ void put(unsigned value, int nbits)
+            {
+                acc |= (uint64_t)value << (64 - p - nbits);            // p < 32, nbits <= 13
+                p += nbits;
+                if (p >= 32) {
+                    const unsigned hi = (unsigned)(acc >> 32);
+                    if (hi) atomicOr(&buf[word], hi);
+                    acc <<= 32;
+                    word++;
+                    p -= 32;
+                }
+            }
+            __device__ __forceinline__ void finish()
+            {
+                const unsigned hi = (unsigned)(acc >> 32);
+                if (hi) atomicOr(&buf[word], hi);
+            }
+        };
+        int header_bits = 32;
+        for (int k = 0; k < nch; k++) header_bits += hlb[k];
+        if (per_thread <= 8) {                         // up to two channels: the codes stay in registers
+            unsigned codes[8];
+            int nb[8];
+            int local = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                codes[k] = 0;
+                nb[k] = 0;
+                if (k < per_thread) code_of(k, codes[k], nb[k]);
+                local += nb[k];
+            }
+            int all_bits;
+            const int off = header_bits + group_exclusive_scan(local, 4, all_bits);
+            Emitter e{fbuf, 0, off >> 5, off & 31};
+            if (!too_low) {
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (nb[k] > 0) e.put(codes[k], nb[k]);
+                e.finish();
+            }
+        } else {
+            int local = 0;
+            for (int k = 0; k < per_thread; k++) {
+                unsigned code;
+                int nbits;
+                code_of(k, code, nbits);
+                local += nbits;
+            }
+            int all_bits;
+            const int off = header_bits + group_exclusive_scan(local, 4, all_bits);
+            Emitter e{fbuf, 0, off >> 5, off & 31};
+            for (int k = 0; k < per_thread && !too_low; k++) {
+                unsigned code;
+                int nbits;
+                code_of(k, code, nbits);
+                if (nbits > 0) e.put(code, nbits);
+            }
+            if (!too_low) e.finish();
         }
     }
     __syncthreads();
