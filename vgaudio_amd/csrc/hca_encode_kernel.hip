@@ -168,20 +168,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     // set alternates, so the next call cannot overwrite totals a slower wave has not read yet)
     int red_par = 0;
     auto block_sum = [&](int v) __attribute__((always_inline)) -> int {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        // wave sum with DPP (quad swaps, half-row and row mirrors: every lane then holds its 16-lane row's sum) and
+        // four v_readlane -- the binary searches wait for this fifteen times in a row, and six dependent
+        // ds_bpermute (what __shfl_xor compiles to) cost several hundred cycles each time
+        v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+        v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);     // row_half_mirror
+        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);     // row_mirror
+        const int w = __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+                      __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
         int *slot = red + 8 * red_par;
         red_par ^= 1;
-        if (lane == 0) slot[wave] = v;
+        if (lane == 0) slot[wave] = w;
         __syncthreads();
         return slot[0] + slot[1] + slot[2] + slot[3];
     };
     auto wave_inclusive_scan = [&](int v) __attribute__((always_inline)) -> int {
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(v, o);
-            if (lane >= o) v += t;
-        }
+        // Hillis-Steele inside each 16-lane row with row_shr, then the row totals are handed on with row_bcast
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);     // row_shr:1 (no source lane: + 0)
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);     // row_shr:2
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);     // row_shr:4
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);     // row_shr:8
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1 and 3
+        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
         return v;
     };
     // exclusive scan over groups of `waves_per_group` consecutive waves (4: the whole block; 2: one channel's
@@ -636,8 +645,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
             for (int j = 0; j < 8; j++) crc = ((crc << 1) ^ ((crc & 0x8000u) ? 0x8005u : 0u)) & 0xFFFFu;
         }
         unsigned part = (begin < end) ? gf_mul(crc, crc_pow[nbytes - end]) : 0u;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) part ^= (unsigned)__shfl_xor((int)part, o);
+        {
+            int v = (int)part;
+            v ^= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);  // as block_sum, with xor
+            v ^= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+            v ^= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
+            v ^= __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
+            part = (unsigned)(__builtin_amdgcn_readlane(v, 0) ^ __builtin_amdgcn_readlane(v, 16) ^
+                              __builtin_amdgcn_readlane(v, 32) ^ __builtin_amdgcn_readlane(v, 48));
+        }
         if (lane == 0) red[wave] = (int)part;
         __syncthreads();
         if (tid == 0) {
