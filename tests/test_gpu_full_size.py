@@ -1,0 +1,123 @@
+"""Full BASELINE.json sizes on one GPU, through size-independent properties plus sampled bit-exact units:
+config 2 (4096 channels x 60 s GC-ADPCM), config 3 (the same through CRI ADX), config 4 (1024 stereo HCA streams).
+The oracle cannot run these sizes in seconds, so every unit is checked through decode(encode(x)) ~ x and a few
+units against the oracle bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pyoracle as po
+from vgaudio_amd import _lib, device as vdev
+
+pytestmark = pytest.mark.gpu
+
+N = 2_880_000                                   # 48 kHz x 60 s
+# relative rms error of decode(encode(x)) over a whole channel; calibrated on the synthetic channels (4-bit codes:
+# the quietest, noisiest channels set the maximum) with a factor of two of slack
+GC_BOUND, ADX_BOUND, HCA_BOUND = 0.17, 0.8, 0.12           # measured maxima 0.086, 0.534 (13 kHz tones), 0.060
+
+
+def _rel_rms(dec, pcm, n, chunk=256):
+    out = []
+    for c0 in range(0, pcm.shape[0], chunk):
+        a = dec[c0:c0 + chunk, :n].to(torch.float32)
+        b = pcm[c0:c0 + chunk, :n].to(torch.float32)
+        out.append(((a - b).pow(2).mean(dim=1).sqrt() / b.pow(2).mean(dim=1).sqrt().clamp_min(1.0)).cpu())
+    return torch.cat(out)
+
+
+def test_config2_gcadpcm_4096_channels():
+    d = torch.device("cuda:0")
+    nch = 4096
+    pcm = vdev.synth_pcm(nch, N, d)
+    coefs = vdev.gc_coefs(pcm, N)
+    adpcm = vdev.gc_encode(pcm, N, coefs)
+    dec, status = vdev.gc_decode(adpcm, coefs, N)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    rel = _rel_rms(dec, pcm, N)
+    print("config 2 relative rms: max %.4f mean %.4f" % (float(rel.max()), float(rel.mean())))
+    assert (rel < GC_BOUND).all() and float(rel.mean()) < 0.04, float(rel.max())
+    del dec
+    nb = vdev.gc_byte_count(N)
+    for c in (0, 2047, 4095):                   # first, middle, last: row offsets beyond 4 GiB
+        host = pcm[c, :N].cpu().numpy()
+        wc = po.gc_calculate_coefficients(host)
+        assert coefs[c].cpu().numpy().tolist() == wc.tolist()
+        assert (adpcm[c, :nb].cpu().numpy() == po.gc_encode(host, wc)).all()
+    # every frame header names a predictor 0..7 and a scale 0..12 (GcAdpcmEncoder.cs:83, :118-170)
+    heads = adpcm[:, :nb - nb % 8].reshape(nch, -1, 8)[:, :, 0]
+    assert int((heads >> 4).max()) <= 7 and int((heads & 15).max()) <= 12
+
+
+def test_config3_adx_4096_channels():
+    d = torch.device("cuda:0")
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    nch = 4096
+    pcm = vdev.synth_pcm(nch, N, d)
+    p = _lib.AdxParams()
+    L.vga_adx_default_params(C.byref(p))
+    nb = L.vga_adx_encoded_byte_count(N, C.byref(p))
+    pitch = (nb + 15) // 16 * 16
+    adx = torch.zeros((nch, pitch), dtype=torch.uint8, device=d)
+    hist = torch.zeros(nch, dtype=torch.int16, device=d)
+    status = torch.zeros(1, dtype=torch.int32, device=d)
+    dec = vdev.alloc_pcm(nch, N, d)
+    _lib.check(L.vga_adx_encode_device(pcm.data_ptr(), pcm.stride(0), nch, N, C.byref(p), adx.data_ptr(), pitch, hist.data_ptr(), st))
+    _lib.check(L.vga_adx_decode_device(adx.data_ptr(), pitch, nb, nch, N, C.byref(p), dec.data_ptr(), dec.stride(0),
+                                       status.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    rel = _rel_rms(dec, pcm, N)
+    print("config 3 relative rms: max %.4f mean %.4f" % (float(rel.max()), float(rel.mean())))
+    assert (rel < ADX_BOUND).all() and float(rel.mean()) < 0.08, float(rel.max())
+    for c in (0, 4095):
+        host = pcm[c, :N].cpu().numpy()
+        op = po.adx_params()
+        want = po.adx_encode(host, op)
+        assert (adx[c, :nb].cpu().numpy() == want).all() and int(hist[c]) == op.history
+        assert (dec[c, :N].cpu().numpy() == po.adx_decode(want, N, po.adx_params())).all()
+    # frame scales are 13-bit (CriAdxCodec.cs:140-141)
+    assert int((adx[:, :nb].reshape(nch, -1, 18)[:, :, 0] >> 5).max()) == 0
+
+
+def test_config4_hca_1024_stereo_streams():
+    d = torch.device("cuda:0")
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    ns = 1024
+    hp = _lib.HcaParamsC(2, 0, 0, 2, 48000, N, 0, 0, 0)
+    info = _lib.HcaInfoC()
+    _lib.check(L.vga_hca_encoder_initialize(C.byref(hp), C.byref(info)))
+    assert (info.frame_size, info.frame_count) == (682, 2813)          # config 4's derived parameters
+    spcm = vdev.synth_pcm(ns * 2, N, d)
+    ch_pitch = spcm.stride(0)
+    fbytes = info.frame_count * info.frame_size
+    fpitch = (fbytes + 8 + 15) // 16 * 16
+    frames = torch.zeros((ns, fpitch), dtype=torch.uint8, device=d)
+    status = torch.zeros(1, dtype=torch.int32, device=d)
+    _lib.check(L.vga_hca_encode_device(spcm.data_ptr(), 2 * ch_pitch, ch_pitch, ns, N, C.byref(info), frames.data_ptr(), fpitch,
+                                       status.data_ptr(), st))
+    wsb = L.vga_hca_decode_workspace_bytes(C.byref(info), ns)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=d)
+    dec = torch.zeros_like(spcm)
+    _lib.check(L.vga_hca_decode_device(C.byref(info), frames.data_ptr(), fpitch, ns, dec.data_ptr(), 2 * ch_pitch, ch_pitch,
+                                       ws.data_ptr(), wsb, status.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    rel = _rel_rms(dec, spcm, N)
+    print("config 4 relative rms: max %.4f mean %.4f" % (float(rel.max()), float(rel.mean())))
+    assert (rel < HCA_BOUND).all() and float(rel.mean()) < 0.04, float(rel.max())
+    # every frame starts with the sync word and carries a valid CRC (a CRC over data + CRC is 0); sampled
+    fr = frames[:, :fbytes].reshape(ns, info.frame_count, info.frame_size)
+    assert bool((fr[:, :, 0] == 0xFF).all()) and bool((fr[:, :, 1] == 0xFF).all())
+    sample = fr[::97, ::211].reshape(-1, info.frame_size).cpu().numpy()
+    for f in sample:
+        assert po.lib().vgo_crc16(po._u8(np.ascontiguousarray(f)), info.frame_size) == 0
+    s = 1023                                     # the last stream against the oracle, bit for bit
+    host = spcm[2 * s:2 * s + 2, :N].cpu().numpy()
+    rc, oinfo, want = po.hca_encode(host, po.hca_params(2, N))
+    assert rc == 0 and (fr[s].cpu().numpy() == want).all()
