@@ -122,46 +122,72 @@ struct WaveSync {
 };
 constexpr WaveSync wave_sync{};
 
-// DCT-IV of one 128-vector held in LDS, executed by the 32 lanes `t` = 0..31 of a (sub)group.
-// in != tmp; out may be any 128-double LDS array.  Caller synchronises before (inputs written) and
-// after (outputs read).  group_sync(): barrier among the lanes that cooperate on this transform.
+// DCT-IV of one 128-vector, executed by the 32 lanes `t` = 0..31 of a (sub)group: the staged butterflies of
+// Mdct.cs:126-181 with the six stages held in registers.  Lane t owns the complex pair (t, t + 32) of the
+// pre-rotation and, in stage k, the pair at distance h = 32 >> k inside its block; between stages each lane keeps one
+// of its two results and swaps the other with lane t ^ (h / 2) through ds_swizzle (the crossbar: no LDS memory, no
+// write -> read round trip; staging every stage through LDS was 3 % slower).  Every butterfly is the reference's
+// arithmetic operand for operand, no FMA contraction, so the spectra are bit-identical; LDS is touched once, for
+// the final Gray-code/bit-reverse permutation (:177-180).
+// in: 128 doubles in LDS, written before the caller's last barrier; tmp: 128 doubles of LDS scratch; out: anywhere.
+// group_sync(): makes the 32 lanes' LDS writes visible to each other (they share a wave: wave_sync).
+template <int XOR>
+__device__ __forceinline__ double swizzle_xor(double v)
+{
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_swizzle((int)bits, (XOR << 10) | 0x1F);
+    const int hi = __builtin_amdgcn_ds_swizzle((int)(bits >> 32), (XOR << 10) | 0x1F);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 template <class Sync>
 __device__ __forceinline__ void dct4_128(const LdsTables &T, const double *in, double *tmp, double *out, int t,
-                                         Sync group_sync)
+                                             Sync group_sync)
 {
-    // Mdct.cs:137-147: 64 pre-rotations (2 per lane)
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int i = t + 32 * k;
-        const int i2 = i * 2;
-        const double a = in[i2];
-        const double b = in[127 - i2];
-        const double s = T.sin_t[127 + i], c = T.cos_t[127 + i];
-        tmp[i2] = a * c + b * s;
-        tmp[i2 + 1] = a * s - b * c;
+    // Mdct.cs:137-147: the two pre-rotations of this lane ARE its stage-0 operands
+    double f0, f1, b0, b1;
+    {
+        const double a0 = in[2 * t], c0 = in[127 - 2 * t];
+        const double s0 = T.sin_t[127 + t], k0 = T.cos_t[127 + t];
+        f0 = a0 * k0 + c0 * s0;
+        f1 = a0 * s0 - c0 * k0;
+        const int i = t + 32;
+        const double a1 = in[2 * i], c1 = in[127 - 2 * i];
+        const double s1 = T.sin_t[127 + i], k1 = T.cos_t[127 + i];
+        b0 = a1 * k1 + c1 * s1;
+        b1 = a1 * s1 - c1 * k1;
     }
+    // Mdct.cs:150-175
+#define VGA_DCT_STAGE(H, NEXT)                                                                  \
+    {                                                                                           \
+        const int i = t & ((H) - 1);                                                            \
+        const double s = T.sin_t[(H) - 1 + i], c = T.cos_t[(H) - 1 + i];                        \
+        const double a = f0 - b0, b = f1 - b1;                                                  \
+        const double nf0 = f0 + b0, nf1 = f1 + b1;                                              \
+        const double nb0 = a * c + b * s, nb1 = a * s - b * c;                                  \
+        if ((NEXT) > 0) {                                                                       \
+            const bool upper = (t & (NEXT)) != 0;     /* keeps its back, hands its front over */ \
+            const double r0 = swizzle_xor<(NEXT)>(upper ? nf0 : nb0);                           \
+            const double r1 = swizzle_xor<(NEXT)>(upper ? nf1 : nb1);                           \
+            f0 = upper ? r0 : nf0; f1 = upper ? r1 : nf1;                                       \
+            b0 = upper ? nb0 : r0; b1 = upper ? nb1 : r1;                                       \
+        } else {                                                                                \
+            f0 = nf0; f1 = nf1; b0 = nb0; b1 = nb1;                                             \
+        }                                                                                       \
+    }
+    VGA_DCT_STAGE(32, 16)
+    VGA_DCT_STAGE(16, 8)
+    VGA_DCT_STAGE(8, 4)
+    VGA_DCT_STAGE(4, 2)
+    VGA_DCT_STAGE(2, 1)
+    VGA_DCT_STAGE(1, 0)
+#undef VGA_DCT_STAGE
+    // after the last stage lane t holds the complex values 2t and 2t + 1: four consecutive doubles
+    tmp[4 * t] = f0;
+    tmp[4 * t + 1] = f1;
+    tmp[4 * t + 2] = b0;
+    tmp[4 * t + 3] = b1;
     group_sync();
-    // Mdct.cs:150-175: 6 stages x 32 butterflies (1 per lane)
-#pragma unroll
-    for (int stage = 0; stage < 6; stage++) {
-        const int block_size_bits = 6 - stage;
-        const int half_bits = block_size_bits - 1;
-        const int block_size = 1 << block_size_bits;
-        const int half = 1 << half_bits;
-        const int block = t >> half_bits;
-        const int i = t & (half - 1);
-        const int front = (block * block_size + i) * 2;
-        const int back = front + block_size;
-        const double f0 = tmp[front], f1 = tmp[front + 1], b0 = tmp[back], b1 = tmp[back + 1];
-        const double a = f0 - b0;
-        const double b = f1 - b1;
-        const double s = T.sin_t[half - 1 + i], c = T.cos_t[half - 1 + i];
-        tmp[front] = f0 + b0;
-        tmp[front + 1] = f1 + b1;
-        tmp[back] = a * c + b * s;
-        tmp[back + 1] = a * s - b * c;
-        group_sync();
-    }
     // Mdct.cs:177-180
 #pragma unroll
     for (int k = 0; k < 4; k++) {
