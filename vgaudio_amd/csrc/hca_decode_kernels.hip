@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void hca_unpack_kernel(
     uint8_t *__restrict__ records, size_t record_bytes, int *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_res[];   // [nch][128][64]
-    __shared__ LdsTables T;
+    __shared__ DecTables T;
     const int lane = threadIdx.x;
     load_tables(T, lane, 64);
     __syncthreads();
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(IMDCT_THREADS) void hca_imdct_kernel(
     int16_t *__restrict__ pcm, int64_t stream_pitch, int64_t ch_pitch)
 {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
-    __shared__ LdsTables T;
+    __shared__ DecTables T;
     const int nch = info.nch;
     double *spec = s_mem;                               // [nch][9][128]
     double *tmp = spec + (size_t)nch * 9 * 128;         // [9][128]

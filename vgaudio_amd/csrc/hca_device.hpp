@@ -64,50 +64,68 @@ __device__ __forceinline__ double f64_bits(uint64_t b) { return __longlong_as_do
 constexpr double MDCT_SCALE = 0.125;
 
 // The hot tables, copied into LDS once per workgroup (a table lookup from HBM-backed constant data
-// costs an L1/L2 round trip per dependent access; from LDS ~64 cycles).
-struct LdsTables {
-    double sin_t[192], cos_t[192];      // size 2^b starts at (1<<b)-1; of the size-128 table only i < 64 is used
+// costs an L1/L2 round trip per dependent access; from LDS ~64 cycles).  LDS size sets the occupancy of the HCA
+// kernels, so each side carries only what it reads (ENC / DEC) and the trig tables only the entries the transform
+// uses: [0, 63) = the stage tables of sizes 1..32 (size 2^b starts at 2^b - 1), [63, 127) = the first half of the
+// size-128 table (the pre-rotation).
+template <bool ENC, bool DEC>
+struct LdsTablesT {
+    double sin_t[127], cos_t[127];
     double window[128];
-    double dequant_scale[64];           // DequantizerScalingTable
-    double quant_scale[64];             // QuantizerScalingTable
-    double inv_step[16];                // QuantizerInverseStepSize
-    double step[16];                    // QuantizerStepSize
-    double dead_zone[16];               // QuantizerDeadZone (CriHcaTables.cs:68-78)
+    double dequant_scale[64];                       // DequantizerScalingTable (encoder: FindScaleFactor)
+    double quant_scale[ENC ? 64 : 1];               // QuantizerScalingTable
+    double inv_step[ENC ? 16 : 1];                  // QuantizerInverseStepSize
+    double step[DEC ? 16 : 1];                      // QuantizerStepSize
+    double dead_zone[ENC ? 16 : 1];                 // QuantizerDeadZone (CriHcaTables.cs:68-78)
     uint8_t shuffle[128];
-    uint8_t enc_bits[8][16], enc_value[8][16];   // QuantizeSpectrumBits / Value   (encoder, index q+8)
-    uint8_t dec_bits[8][16];                     // QuantizedSpectrumBits          (decoder, index code)
-    int8_t dec_value[8][16];                     // QuantizedSpectrumValue
+    uint8_t enc_bits[ENC ? 8 : 1][16], enc_value[ENC ? 8 : 1][16];   // QuantizeSpectrumBits / Value   (index q+8)
+    uint8_t dec_bits[DEC ? 8 : 1][16];                               // QuantizedSpectrumBits          (index code)
+    int8_t dec_value[DEC ? 8 : 1][16];                               // QuantizedSpectrumValue
     uint8_t max_bits[16];
-    uint8_t res_curve[64];
+    uint8_t res_curve[64];                          // ScaleToResolutionCurve (both sides: CalculateResolution)
 };
+using EncTables = LdsTablesT<true, false>;
+using DecTables = LdsTablesT<false, true>;
 
-__device__ __forceinline__ void load_tables(LdsTables &t, int tid, int nthreads)
+template <bool ENC, bool DEC>
+__device__ __forceinline__ void load_tables(LdsTablesT<ENC, DEC> &t, int tid, int nthreads)
 {
-    for (int i = tid; i < 191; i += nthreads) { t.sin_t[i] = f64_bits(MDCT_SinBits[i]); t.cos_t[i] = f64_bits(MDCT_CosBits[i]); }
+    for (int i = tid; i < 127; i += nthreads) {
+        const int src = i < 63 ? i : i + 64;        // 63.. -> entries 127.. of the reference's table
+        t.sin_t[i] = f64_bits(MDCT_SinBits[src]);
+        t.cos_t[i] = f64_bits(MDCT_CosBits[src]);
+    }
     for (int i = tid; i < 128; i += nthreads) {
         t.window[i] = (double)__uint_as_float(HCA_MdctWindowF32Bits[i]);
         t.shuffle[i] = MDCT_Shuffle128[i];
-        (&t.enc_bits[0][0])[i] = (&HCA_QuantizeSpectrumBits[0][0])[i];
-        (&t.enc_value[0][0])[i] = (&HCA_QuantizeSpectrumValue[0][0])[i];
-        (&t.dec_bits[0][0])[i] = (&HCA_QuantizedSpectrumBits[0][0])[i];
-        (&t.dec_value[0][0])[i] = (&HCA_QuantizedSpectrumValue[0][0])[i];
+        if constexpr (ENC) {
+            (&t.enc_bits[0][0])[i] = (&HCA_QuantizeSpectrumBits[0][0])[i];
+            (&t.enc_value[0][0])[i] = (&HCA_QuantizeSpectrumValue[0][0])[i];
+        }
+        if constexpr (DEC) {
+            (&t.dec_bits[0][0])[i] = (&HCA_QuantizedSpectrumBits[0][0])[i];
+            (&t.dec_value[0][0])[i] = (&HCA_QuantizedSpectrumValue[0][0])[i];
+        }
     }
     for (int i = tid; i < 64; i += nthreads) {
         t.dequant_scale[i] = f64_bits(HCA_DequantizerScalingTableBits[i]);
-        t.quant_scale[i] = f64_bits(HCA_QuantizerScalingTableBits[i]);
         t.res_curve[i] = i < 59 ? HCA_ScaleToResolutionCurve[i] : 0;
+        if constexpr (ENC) t.quant_scale[i] = f64_bits(HCA_QuantizerScalingTableBits[i]);
     }
     for (int i = tid; i < 16; i += nthreads) {
-        t.inv_step[i] = f64_bits(HCA_QuantizerInverseStepSizeBits[i]);
         const double st = f64_bits(HCA_QuantizerStepSizeBits[i]);
-        t.step[i] = st;
-        t.dead_zone[i] = __longlong_as_double(__double_as_longlong(st / 2) - (long long)(HCA_ResolutionMaxValue[i] + 1));
+        if constexpr (ENC) {
+            t.inv_step[i] = f64_bits(HCA_QuantizerInverseStepSizeBits[i]);
+            t.dead_zone[i] = __longlong_as_double(__double_as_longlong(st / 2) - (long long)(HCA_ResolutionMaxValue[i] + 1));
+        }
+        if constexpr (DEC) t.step[i] = st;
         t.max_bits[i] = HCA_QuantizedSpectrumMaxBits[i];
     }
 }
 
 // CriHcaPacking.cs:60-69
-__device__ __forceinline__ int calculate_resolution(const LdsTables &t, int scale_factor, int noise_level)
+template <class Tables>
+__device__ __forceinline__ int calculate_resolution(const Tables &t, int scale_factor, int noise_level)
 {
     if (scale_factor == 0) return 0;
     int curve_position = noise_level - 5 * scale_factor / 2 + 2;
@@ -129,7 +147,9 @@ constexpr WaveSync wave_sync{};
 // write -> read round trip; staging every stage through LDS was 3 % slower).  Every butterfly is the reference's
 // arithmetic operand for operand, no FMA contraction, so the spectra are bit-identical; LDS is touched once, for
 // the final Gray-code/bit-reverse permutation (:177-180).
-// in: 128 doubles in LDS, written before the caller's last barrier; tmp: 128 doubles of LDS scratch; out: anywhere.
+// in: 128 doubles in LDS, written before the caller's last barrier; tmp: 128 doubles of LDS scratch, which MAY BE
+// `in` itself (a wave's LDS operations execute in order: every lane has read its inputs before any lane writes);
+// out: anywhere.
 // group_sync(): makes the 32 lanes' LDS writes visible to each other (they share a wave: wave_sync).
 template <int XOR>
 __device__ __forceinline__ double swizzle_xor(double v)
@@ -140,20 +160,20 @@ __device__ __forceinline__ double swizzle_xor(double v)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <class Sync>
-__device__ __forceinline__ void dct4_128(const LdsTables &T, const double *in, double *tmp, double *out, int t,
-                                             Sync group_sync)
+template <class Tables, class Sync>
+__device__ __forceinline__ void dct4_128(const Tables &T, const double *in, double *tmp, double *out, int t,
+                                         Sync group_sync)
 {
     // Mdct.cs:137-147: the two pre-rotations of this lane ARE its stage-0 operands
     double f0, f1, b0, b1;
     {
         const double a0 = in[2 * t], c0 = in[127 - 2 * t];
-        const double s0 = T.sin_t[127 + t], k0 = T.cos_t[127 + t];
+        const double s0 = T.sin_t[63 + t], k0 = T.cos_t[63 + t];
         f0 = a0 * k0 + c0 * s0;
         f1 = a0 * s0 - c0 * k0;
         const int i = t + 32;
         const double a1 = in[2 * i], c1 = in[127 - 2 * i];
-        const double s1 = T.sin_t[127 + i], k1 = T.cos_t[127 + i];
+        const double s1 = T.sin_t[63 + i], k1 = T.cos_t[63 + i];
         b0 = a1 * k1 + c1 * s1;
         b1 = a1 * s1 - c1 * k1;
     }

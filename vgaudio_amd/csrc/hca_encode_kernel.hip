@@ -21,7 +21,7 @@ namespace hca {
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // CriHcaEncoder.cs:691-709
-__device__ __forceinline__ int find_scale_factor(const LdsTables &T, double value)
+__device__ __forceinline__ int find_scale_factor(const EncTables &T, double value)
 {
     unsigned low = 0, high = 63;
     while (low < high) {
@@ -48,7 +48,7 @@ __device__ __forceinline__ unsigned gf_mul(unsigned a, unsigned b)
 }
 
 // CalculateUsedBits (:554-597) for one band: the bits its eight scaled coefficients cost at resolution `res`
-__device__ __forceinline__ int band_cost(const LdsTables &T, const double *x, int res)
+__device__ __forceinline__ int band_cost(const EncTables &T, const double *x, int res)
 {
     int cost = 0;
     if (res >= 8) {
@@ -78,7 +78,7 @@ struct UsedBitsMemo {
 // takes one side of band_cost only and the eight coefficients are read from LDS once).  The binary searches touch
 // a new resolution in some lane on nearly every step, which made the lazy variant evaluate band_cost -- both sides,
 // the lanes' resolutions differ -- about fifteen times per frame.
-__device__ __forceinline__ void build_cost_table(const LdsTables &T, const double *xs, bool valid, UsedBitsMemo &m)
+__device__ __forceinline__ void build_cost_table(const EncTables &T, const double *xs, bool valid, UsedBitsMemo &m)
 {
     double x[8];
 #pragma unroll
@@ -92,7 +92,7 @@ __device__ __forceinline__ void build_cost_table(const LdsTables &T, const doubl
 
 // this thread's share of the frame's spectrum bits.  Up to two channels a thread owns one band and memoises
 // its costs; with more it owns several bands and recomputes.
-__device__ __forceinline__ int used_bits_partial(const LdsTables &T, int tid, int nch, const int *s_coded, const int *sfac,
+__device__ __forceinline__ int used_bits_partial(const EncTables &T, int tid, int nch, const int *s_coded, const uint8_t *sfac,
                                                  const double *scaled, int noise_level, int eval_boundary, UsedBitsMemo &m)
 {
     int partial = 0;
@@ -135,34 +135,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     int *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
-    __shared__ LdsTables T;
+    __shared__ EncTables T;
     const int nch = info.nch;
     double *spectra = s_mem;                               // [nch][8][128]
-    // region B is shared: the MDCT staging (xin, tmp, dctin) is dead before `scaled` is written
-    const size_t region_b = (size_t)nch * 1024 > 19 * 128 ? (size_t)nch * 1024 : 19 * 128;
+    // LDS decides the occupancy (4 workgroups per CU need <= 40 KB each): region B is shared -- the MDCT staging
+    // (dctin, which doubles as the transform's scratch, and xin) is dead before `scaled` is written -- and the
+    // small per-band arrays are bytes
+    const size_t region_b = (size_t)nch * 1024 > 11 * 128 ? (size_t)nch * 1024 : 11 * 128;
     double *scaled = spectra + (size_t)nch * 1024;         // [nch][128][8]
-    double *tmp = scaled;                                  // [8][128]
-    double *dctin = tmp + 8 * 128;                         // [8][128]
+    double *dctin = scaled;                                // [8][128]
+    double *tmp = dctin;                                   // the transform permutes in place (hca_device.hpp)
     int16_t *xin = reinterpret_cast<int16_t *>(dctin + 8 * 128);   // [9][128] raw samples (2.3 KB of the 3 x 128 doubles)
     double *hfr_avg = scaled + region_b;                   // [nch][8]
     double *eratio = hfr_avg + nch * 8;                    // [nch][8]
-    int *sfac = reinterpret_cast<int *>(eratio + nch * 8); // [nch][128]
-    int *ires = sfac + nch * 128;                          // [nch][128]
-    int *red = ires + nch * 128;                           // [264]
-    int *hlb = red + 264;                                  // [nch] header length bits
+    int *red = reinterpret_cast<int *>(eratio + nch * 8);  // [32] two alternating slot sets for the block reductions
+    int *hlb = red + 32;                                   // [nch] header length bits
     int *dbits = hlb + 8;                                  // [nch] scale-factor delta bits
     int *cand = dbits + 8;                                 // [nch][8]
     int *empty = cand + 64;                                // [nch]
     int *intensity = empty + 8;                            // [nch][8]
     int *hfrs = intensity + 64;                            // [nch][8]
-    int *scan = hfrs + 64;                                 // [256]
-    uint32_t *fbuf = reinterpret_cast<uint32_t *>(scan + 256);   // frame bits, big-endian words
+    uint32_t *fbuf = reinterpret_cast<uint32_t *>(hfrs + 64);    // frame bits, big-endian words [fwords]
+    const int fwords = (info.frame_size + 3) / 4 + 2;
+    uint8_t *sfac = reinterpret_cast<uint8_t *>(fbuf + fwords);  // [nch][128] scale factors (0..63)
+    uint8_t *ires = sfac + nch * 128;                      // [nch][128] resolutions (0..15)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int stream = blockIdx.x / info.frame_count;
     const int frame = blockIdx.x % info.frame_count;
-    const int fwords = (info.frame_size + 3) / 4 + 2;
 
     // block-wide sum / exclusive scan: wave-level shuffles, then ONE barrier for the four wave totals (the slot
     // set alternates, so the next call cannot overwrite totals a slower wave has not read yet)
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         int nbits = 0;
         if (c < nch && !too_low) {
             const int db = dbits[c];
-            const int *sc = sfac + c * 128;
+            const uint8_t *sc = sfac + c * 128;
             if (band == 0) {                           // the 3-bit delta width, then the first scale factor
                 code = (unsigned)db;
                 nbits = 3;
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         const int slot0 = tid * per_thread;
         const int sf = slot0 / (nch * 128), c = (slot0 / 128) % nch, band0 = slot0 % 128;
         const double *xs = scaled + ((size_t)c * 128 + band0) * 8 + sf;
-        const int *rs = ires + c * 128 + band0;
+        const uint8_t *rs = ires + c * 128 + band0;
         auto code_of = [&](int k, unsigned &code, int &nbits) __attribute__((always_inline)) {
             const int res = rs[k];
             code = 0;
@@ -688,10 +689,10 @@ int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, 
 {
     if (nstreams <= 0 || info.frame_count <= 0) return VGA_OK;
     const int nch = info.nch;
-    const size_t region_b = (size_t)nch * 1024 > 19 * 128 ? (size_t)nch * 1024 : 19 * 128;
+    const size_t region_b = (size_t)nch * 1024 > 11 * 128 ? (size_t)nch * 1024 : 11 * 128;
     const size_t doubles = (size_t)nch * 1024 + region_b + (size_t)nch * 16;
-    const size_t ints = (size_t)nch * 256 + 264 + 8 + 8 + 64 + 8 + 64 + 64 + 256;
-    const size_t lds = doubles * 8 + ints * 4 + ((size_t)(info.frame_size + 3) / 4 + 2) * 4;
+    const size_t ints = 32 + 8 + 8 + 64 + 8 + 64 + 64;
+    const size_t lds = doubles * 8 + ints * 4 + ((size_t)(info.frame_size + 3) / 4 + 2) * 4 + (size_t)nch * 256;
     if (lds > 64 * 1024)
         VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hca_encode_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
