@@ -224,9 +224,9 @@ __global__ __launch_bounds__(IMDCT_THREADS) void hca_imdct_kernel(
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
     __shared__ DecTables T;
     const int nch = info.nch;
+    // LDS decides the occupancy (4 workgroups per CU need <= 40 KB each): the transform permutes in its input
     double *spec = s_mem;                               // [nch][9][128]
-    double *tmp = spec + (size_t)nch * 9 * 128;         // [9][128]
-    double *dct = tmp + 9 * 128;                        // [9][128]
+    double *dct = spec + (size_t)nch * 9 * 128;         // [9][128]
     double *gain = dct + 9 * 128;                       // [2][nch][128]: previous frame, this frame
 
     const int tid = threadIdx.x;
@@ -308,9 +308,9 @@ __global__ __launch_bounds__(IMDCT_THREADS) void hca_imdct_kernel(
     // RunImdct (:168-177 -> Mdct.cs:94-119) + PcmFloatToShort (:179-192) + CopyPcmToOutput (:31-45)
     const int grp = tid >> 5, t = tid & 31;
     for (int c = 0; c < nch; c++) {
-        const double *sp = spec + (size_t)c * 9 * 128;
+        double *sp = spec + (size_t)c * 9 * 128;
         // 9 transforms, one per 32-lane group: slot 0 = the previous frame's sub-frame 7, slots 1..8 = this frame
-        dct4_128(T, sp + (size_t)grp * 128, tmp + grp * 128, dct + (size_t)grp * 128, t, wave_sync);
+        dct4_128(T, sp + (size_t)grp * 128, sp + (size_t)grp * 128, dct + (size_t)grp * 128, t, wave_sync);
         __syncthreads();
         // window + overlap-add: out(slot) needs `previous` produced from slot-1's transform
         int16_t *dst = pcm + (int64_t)stream * stream_pitch + (int64_t)c * ch_pitch;
@@ -349,7 +349,7 @@ int launch_decode(const uint8_t *d_frames, int64_t frames_pitch, int nstreams, c
     hipLaunchKernelGGL(hca_unpack_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), lds1, stream, d_frames,
                        frames_pitch, nstreams, info, reinterpret_cast<uint8_t *>(d_workspace), rb, d_status);
     VGA_HIP_TRY(hipGetLastError());
-    const size_t lds2 = ((size_t)info.nch * 9 * 128 + 9 * 128 + 9 * 128 + (size_t)2 * info.nch * 128) * sizeof(double);
+    const size_t lds2 = ((size_t)info.nch * 9 * 128 + 9 * 128 + (size_t)2 * info.nch * 128) * sizeof(double);
     if (lds2 > 64 * 1024)
         VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hca_imdct_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
