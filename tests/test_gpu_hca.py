@@ -136,3 +136,39 @@ def test_looping_encode_and_decode_match_oracle(nch, quality, n, loop_start, loo
         assert rc == 0
         for c in range(nch):
             assert (d[c] == want[c]).all(), (c, int(np.argmax(d[c] != want[c])))
+
+
+def test_randomised_configurations_match_oracle():
+    """Channel counts, qualities, sample rates and explicit bitrates drawn at random: the derived band layout
+    (base / stereo / HFR bands, frame size) differs in nearly every draw, so every packing path gets input."""
+    rng = np.random.default_rng(2024)
+    kinds = ["synth", "noise", "quiet", "square"]
+    done = 0
+    while done < 24:
+        nch = int(rng.integers(1, 9))
+        quality = ["Highest", "High", "Middle", "Low", "Lowest"][int(rng.integers(0, 5))]
+        rate = int(rng.choice([8000, 16000, 22050, 32000, 44100, 48000, 96000]))
+        n = int(rng.integers(1, 30000))
+        bitrate = int(rng.choice([0, 0, 32000 * nch, 64000 * nch, 100000 * nch]))
+        limit = bool(rng.integers(0, 2))
+        p = po.hca_params(nch, n, sample_rate=rate, quality=quality, bitrate=bitrate, limit_bitrate=limit)
+        rc, info = po.hca_init(p)
+        if rc != 0:
+            continue                                  # a combination the reference refuses as well
+        s = _streams(1, nch, n, kinds[int(rng.integers(0, 4))])[0]
+        rc, info, want = po.hca_encode(s, p)
+        cfg = CriHcaParameters(Quality=Q[quality], Bitrate=bitrate, LimitBitrate=limit)
+        if rc != 0:
+            with pytest.raises(Exception):
+                CriHcaFormat().EncodeFromPcm16(Pcm16Format(list(s), rate), cfg)
+            done += 1
+            continue
+        fmt = CriHcaFormat().EncodeFromPcm16(Pcm16Format(list(s), rate), cfg)
+        bad = np.argwhere(np.asarray(fmt.AudioData) != want)
+        assert bad.size == 0, (nch, quality, rate, n, bitrate, limit, bad[0].tolist(), len(bad))
+        dec = CriHcaDecoder.Decode(fmt.Hca, [fmt.AudioData])[0]
+        rc, wdec = po.hca_decode(info, want)
+        assert rc == 0
+        for c in range(nch):
+            assert (dec[c] == wdec[c]).all(), (nch, quality, rate, n, c)
+        done += 1
