@@ -29,9 +29,12 @@ struct GcDecodeTile {
     int4 out[DTF][2][64];                 // [frame][half][channel]: 14 samples as 7 packed pairs, 1 padding
 };
 
+// Time segments (blockIdx.y): a channel's stream is cut into pieces of `seg_frames` frames that are decoded side by
+// side.  Segment 0 starts from the caller's history; the others start from (0, 0) -- a guess -- and
+// gc_decode_fixup_kernel afterwards re-decodes the head of each until its history meets the guessed run's.
 __global__ __launch_bounds__(256) void gc_decode_kernel(
     const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
-    int sample_count, const int16_t *__restrict__ hist1, const int16_t *__restrict__ hist2,
+    int total_samples, int seg_frames, const int16_t *__restrict__ hist1, const int16_t *__restrict__ hist2,
     int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -40,6 +43,16 @@ __global__ __launch_bounds__(256) void gc_decode_kernel(
 
     const int tid = threadIdx.x;
     const int ch0 = blockIdx.x * 64;
+    // this workgroup's segment, seen as a stream of its own: frames are 8 bytes / 14 samples, so both rows stay
+    // aligned (28-byte sample offsets for the dword stores, 8-byte frame offsets for the loads)
+    const int64_t first_frame = (int64_t)blockIdx.y * seg_frames;
+    const int64_t first_sample = first_frame * 14;
+    if (first_sample >= total_samples) return;
+    const int sample_count = (int)((int64_t)total_samples - first_sample < (int64_t)seg_frames * 14
+                                       ? (int64_t)total_samples - first_sample : (int64_t)seg_frames * 14);
+    adpcm += first_frame * 8;
+    pcm += first_sample;
+    if (blockIdx.y > 0) hist1 = hist2 = nullptr;
     const int full_frames = sample_count / 14;
     const int tail = sample_count - full_frames * 14;
     const int frames = full_frames + (tail ? 1 : 0);
@@ -198,6 +211,53 @@ __global__ __launch_bounds__(256) void gc_decode_kernel(
     }
 }
 
+// Closes the seams between time segments, one lane per channel.  For each segment after the first: decode again from
+// the true history (the two samples before it, final by now) frame by frame, overwriting the guessed run's samples,
+// until the two histories at a frame end coincide -- from there on the guessed run decoded exactly what the serial
+// decoder would have.  If they never coincide the whole segment is redone here: always exact, just slow.
+__global__ __launch_bounds__(64) void gc_decode_fixup_kernel(
+    const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
+    int total_samples, int seg_frames, int segments, int16_t *__restrict__ pcm, int64_t pcm_pitch)
+{
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= nch) return;
+    const uint8_t *src = adpcm + (int64_t)ch * adpcm_pitch;
+    int16_t *dst = pcm + (int64_t)ch * pcm_pitch;
+    int cf[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) cf[i] = coefs[ch * 16 + i];
+    const int full_frames = total_samples / 14;
+    for (int k = 1; k < segments; k++) {
+        const int64_t f0 = (int64_t)k * seg_frames;
+        if (f0 * 14 >= total_samples) break;
+        int h1 = dst[f0 * 14 - 1], h2 = dst[f0 * 14 - 2];
+        const int64_t f_end = f0 + seg_frames;
+        for (int64_t f = f0; f < f_end && f * 14 < total_samples; f++) {
+            const int valid = f < full_frames ? 14 : total_samples - (int)(f * 14);
+            const uint8_t *fr = src + f * 8;
+            const int ps = fr[0];
+            const int scale = (1 << (ps & 0xF)) * 2048;
+            const int predictor = (ps >> 4) & 7;
+            int c1 = 0, c2 = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (predictor == i) { c1 = cf[2 * i]; c2 = cf[2 * i + 1]; }
+            int16_t *o = dst + f * 14;
+            int g1 = 0, g2 = 0;                        // the guessed run's history at this frame's end
+            if (valid == 14) { g1 = o[13]; g2 = o[12]; }
+            for (int s = 0; s < valid; s++) {
+                const int byte = fr[1 + (s >> 1)];
+                const int nib = (s & 1) ? (byte & 0xF) : (byte >> 4);
+                const int v = imin(imax((c1 * h1 + c2 * h2 + scale * ((nib ^ 8) - 8) + 1024) >> 11, -32768), 32767);
+                h2 = h1;
+                h1 = v;
+                o[s] = (int16_t)v;
+            }
+            if (valid == 14 && h1 == g1 && h2 == g2) break;
+        }
+    }
+}
+
 int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs, int nch, int sample_count,
                   const int16_t *d_hist1, const int16_t *d_hist2, int16_t *d_pcm, int64_t pcm_pitch, int *d_status,
                   hipStream_t stream)
@@ -210,9 +270,28 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    hipLaunchKernelGGL(gc_decode_kernel, dim3((nch + 63) / 64), dim3(256), lds, stream, d_adpcm, adpcm_pitch, d_coefs,
-                       nch, sample_count, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
+    // As many time segments as fill the device once (one workgroup of this LDS size per CU, 64 channels each), each
+    // at least 1024 frames long so that the seams stay a small part of the work
+    const int frames = (sample_count + 13) / 14;
+    const int groups = (nch + 63) / 64;
+    int cus = 256;
+    {
+        int device = 0;
+        if (hipGetDevice(&device) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    }
+    int segments = cus / groups;
+    if (segments > frames / 1024) segments = frames / 1024;
+    if (segments < 1) segments = 1;
+    if (segments > 64) segments = 64;
+    const int seg_frames = (frames + segments - 1) / segments;
+    hipLaunchKernelGGL(gc_decode_kernel, dim3(groups, segments), dim3(256), lds, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
+                       sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
     VGA_HIP_TRY(hipGetLastError());
+    if (segments > 1) {
+        hipLaunchKernelGGL(gc_decode_fixup_kernel, dim3(groups), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
+                           sample_count, seg_frames, segments, d_pcm, pcm_pitch);
+        VGA_HIP_TRY(hipGetLastError());
+    }
     return VGA_OK;
 }
 
