@@ -19,20 +19,24 @@
 namespace vga {
 namespace gc {
 
-constexpr int DTF = 8;                    // frames per tile
+constexpr int DTF = 4;                    // frames per tile
+constexpr int DCW = 128;                  // channels per workgroup: TWO decoder waves (they land on different SIMDs of the
+                                          // CU; two 64-channel workgroups would put both of theirs on SIMD 0) + 6 helpers
+constexpr int DTHREADS = DCW * 4;
+constexpr int DHELPERS = DTHREADS - DCW;
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
 struct GcDecodeTile {
-    int4 dist[DTF][4][64];                // [frame][quarter][channel]: 14 x (scale*nibble + 1024), 2 padding
-    int2 coef[DTF][64];                   // [frame][channel]: (coef1, coef2) of the frame's predictor
-    int4 out[DTF][2][64];                 // [frame][half][channel]: 14 samples as 7 packed pairs, 1 padding
+    int4 dist[DTF][4][DCW];                // [frame][quarter][channel]: 14 x (scale*nibble + 1024), 2 padding
+    int2 coef[DTF][DCW];                   // [frame][channel]: (coef1, coef2) of the frame's predictor
+    int4 out[DTF][2][DCW];                 // [frame][half][channel]: 14 samples as 7 packed pairs, 1 padding
 };
 
 // Time segments (blockIdx.y): a channel's stream is cut into pieces of `seg_frames` frames that are decoded side by
 // side.  Segment 0 starts from the caller's history; the others start from (0, 0) -- a guess -- and
 // gc_decode_fixup_kernel afterwards re-decodes the head of each until its history meets the guessed run's.
-__global__ __launch_bounds__(256) void gc_decode_kernel(
+__global__ __launch_bounds__(DTHREADS) void gc_decode_kernel(
     const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
     int total_samples, int seg_frames, const int16_t *__restrict__ hist1, const int16_t *__restrict__ hist2,
     int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ status)
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(256) void gc_decode_kernel(
     int16_t *s_coefs = reinterpret_cast<int16_t *>(s_raw + 2 * sizeof(GcDecodeTile));   // [64][16]
 
     const int tid = threadIdx.x;
-    const int ch0 = blockIdx.x * 64;
+    const int ch0 = blockIdx.x * DCW;
     // this workgroup's segment, seen as a stream of its own: frames are 8 bytes / 14 samples, so both rows stay
     // aligned (28-byte sample offsets for the dword stores, 8-byte frame offsets for the loads)
     const int64_t first_frame = (int64_t)blockIdx.y * seg_frames;
@@ -58,24 +62,24 @@ __global__ __launch_bounds__(256) void gc_decode_kernel(
     const int frames = full_frames + (tail ? 1 : 0);
     const int tiles = (frames + DTF - 1) / DTF;
 
-    for (int i = tid; i < 64 * 16; i += 256) {
+    for (int i = tid; i < DCW * 16; i += DTHREADS) {
         const int c = imin(ch0 + (i >> 4), nch - 1);
         s_coefs[i] = coefs[c * 16 + (i & 15)];
     }
     __syncthreads();
 
-    if (tid >= 64) {
+    if (tid >= DCW) {
         // ------------------------------------------------------------ helper waves (192 lanes)
-        const int hl = tid - 64;
+        const int hl = tid - DCW;
         bool bad = false;
         // the lane's (up to 3) frames of a tile, loaded a whole tile period before they are unpacked:
         // unconditional loads with a clamped frame index (a load under a divergent condition is waited for
         // at once, and the helpers would then pay three HBM round trips per tile)
-        constexpr int ITEMS = (64 * DTF + 191) / 192;
+        constexpr int ITEMS = (DCW * DTF + DHELPERS - 1) / DHELPERS;
         auto load_tile = [&](int tile, uint2 (&raw)[ITEMS]) {
 #pragma unroll
             for (int k = 0; k < ITEMS; k++) {
-                const int item = imin(hl + 192 * k, 64 * DTF - 1);
+                const int item = imin(hl + DHELPERS * k, DCW * DTF - 1);
                 const int c = item / DTF, j = item - c * DTF;
                 const int fr = imin(tile * DTF + j, imax(full_frames - 1, 0));
                 const int ch = imin(ch0 + c, nch - 1);
@@ -87,8 +91,8 @@ __global__ __launch_bounds__(256) void gc_decode_kernel(
             GcDecodeTile &T = s_tile[tile & 1];
 #pragma unroll
             for (int k = 0; k < ITEMS; k++) {
-                const int item = hl + 192 * k;
-                if (item >= 64 * DTF) continue;
+                const int item = hl + DHELPERS * k;
+                if (item >= DCW * DTF) continue;
                 const int c = item / DTF, j = item - c * DTF;         // consecutive lanes: consecutive frames
                 const int fr = tile * DTF + j;
                 if (fr >= frames) continue;
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void gc_decode_kernel(
         };
         auto flush = [&](int tile) {
             const GcDecodeTile &T = s_tile[tile & 1];
-            for (int item = hl; item < 64 * DTF; item += 192) {
+            for (int item = hl; item < DCW * DTF; item += DHELPERS) {
                 const int c = item / DTF, j = item - c * DTF;
                 const int fr = tile * DTF + j;
                 if (fr >= frames || ch0 + c >= nch) continue;
@@ -263,7 +267,7 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
                   hipStream_t stream)
 {
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
-    const size_t lds = 2 * sizeof(GcDecodeTile) + 64 * 16 * sizeof(int16_t);
+    const size_t lds = 2 * sizeof(GcDecodeTile) + DCW * 16 * sizeof(int16_t);
     static bool configured = false;
     if (!configured) {
         VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gc_decode_kernel),
@@ -273,7 +277,7 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
     // As many time segments as fill the device once (one workgroup of this LDS size per CU, 64 channels each), each
     // at least 1024 frames long so that the seams stay a small part of the work
     const int frames = (sample_count + 13) / 14;
-    const int groups = (nch + 63) / 64;
+    const int groups = (nch + DCW - 1) / DCW;
     int cus = 256;
     {
         int device = 0;
@@ -284,11 +288,11 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
     if (segments < 1) segments = 1;
     if (segments > 64) segments = 64;
     const int seg_frames = (frames + segments - 1) / segments;
-    hipLaunchKernelGGL(gc_decode_kernel, dim3(groups, segments), dim3(256), lds, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
+    hipLaunchKernelGGL(gc_decode_kernel, dim3(groups, segments), dim3(DTHREADS), lds, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
                        sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
     VGA_HIP_TRY(hipGetLastError());
     if (segments > 1) {
-        hipLaunchKernelGGL(gc_decode_fixup_kernel, dim3(groups), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
+        hipLaunchKernelGGL(gc_decode_fixup_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
                            sample_count, seg_frames, segments, d_pcm, pcm_pitch);
         VGA_HIP_TRY(hipGetLastError());
     }
