@@ -235,15 +235,25 @@ struct AdxDecodeTile {
     int4 out[ATF][4][64];                              // [frame][quarter][channel]: 32 samples as 16 packed pairs
 };
 
+// Time segments (blockIdx.y), as in gc_decode_kernel.hip: a channel's stream is cut into pieces of `seg_frames`
+// frames (an even number: frame parity decides the load alignment) decoded side by side, every piece but the first
+// from a guessed history (0, 0); adx_decode_fs18_fixup_kernel then closes the seams.
 template <bool V4>
 __global__ __launch_bounds__(256) void adx_decode_fs18_tiled_kernel(
-    const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int sample_count, AdxDeviceParams p,
+    const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, AdxDeviceParams p,
     int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     AdxDecodeTile *s_tile = reinterpret_cast<AdxDecodeTile *>(s_raw);          // [2]
     const int tid = threadIdx.x;
     const int ch0 = blockIdx.x * 64;
+    const int64_t first_frame = (int64_t)blockIdx.y * seg_frames;
+    if (first_frame * 32 >= total_samples) return;
+    const int sample_count = (int)((int64_t)total_samples - first_frame * 32 < (int64_t)seg_frames * 32
+                                       ? (int64_t)total_samples - first_frame * 32 : (int64_t)seg_frames * 32);
+    adpcm += first_frame * 18;
+    pcm += first_frame * 32;
+    if (blockIdx.y > 0) p.history = 0;
     const int frame_count = (sample_count + 31) / 32;
     const int tiles = (frame_count + ATF - 1) / ATF;
 
@@ -406,6 +416,58 @@ __global__ __launch_bounds__(256) void adx_decode_fs18_tiled_kernel(
             }
         }
         lds_barrier();
+    }
+}
+
+// Closes the seams between time segments, one lane per channel: from the true history (the two samples before the
+// segment, final by now) decode again frame by frame over the guessed run's samples until both histories coincide
+// at a frame end -- from there on the guessed run is what the serial decoder produces.  Exact in every case; if the
+// histories never meet, the segment is simply decoded here a second time.
+template <bool V4>
+__global__ __launch_bounds__(64) void adx_decode_fs18_fixup_kernel(
+    const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, int segments,
+    AdxDeviceParams p, int16_t *__restrict__ pcm, int64_t pcm_pitch)
+{
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= nch) return;
+    const uint8_t *src = adpcm + (int64_t)ch * in_pitch;
+    int16_t *dst = pcm + (int64_t)ch * pcm_pitch;
+    for (int k = 1; k < segments; k++) {
+        const int64_t f0 = (int64_t)k * seg_frames;
+        if (f0 * 32 >= total_samples) break;
+        int hist1 = dst[f0 * 32 - 1], hist2 = dst[f0 * 32 - 2];
+        for (int64_t f = f0; f < f0 + seg_frames && f * 32 < total_samples; f++) {
+            const uint8_t *fr = src + f * 18;
+            const int hb0 = fr[0], hb1 = fr[1];
+            int filter_num = ((hb0 >> 4) & 0xF) >> 1;
+            int cf0, cf1;
+            if (p.type == 2) {                          // as the tiled kernel's `prepare`
+                if (filter_num > 3) filter_num = 3;
+                cf0 = filter_num == 0 ? 0 : (filter_num == 1 ? 0x0F00 : (filter_num == 2 ? 0x1CC0 : 0x1880));
+                cf1 = filter_num == 0 ? 0 : (filter_num == 1 ? 0 : (filter_num == 2 ? (int)(int16_t)0xF300 : (int)(int16_t)0xF240));
+            } else {
+                cf0 = p.coef0;
+                cf1 = p.coef1;
+            }
+            int scale = (int)(int16_t)(((hb0 << 8) | hb1) & 0x1FFF);
+            scale = (int)(int16_t)(p.type == 4 ? (1 << ((12 - scale) & 31)) : scale + 1);
+            const int valid = (int)((int64_t)total_samples - f * 32 < 32 ? (int64_t)total_samples - f * 32 : 32);
+            int16_t *o = dst + f * 32;
+            int g1 = 0, g2 = 0;                         // the guessed run's history at this frame's end
+            if (valid == 32) { g1 = o[31]; g2 = o[30]; }
+            for (int s = 0; s < valid; s++) {
+                const int byte = fr[2 + (s >> 1)];
+                int sample = (s & 1) ? (byte & 0xF) : (byte >> 4);
+                sample = (sample ^ 8) - 8;
+                if (V4) sample = scale * sample + ((hist1 * cf0 + hist2 * cf1) >> 12);
+                else sample = scale * sample + ((hist1 * cf0) >> 12) + ((hist2 * cf1) >> 12);
+                const int fin = clamp16(sample);
+                hist2 = hist1;
+                hist1 = fin;
+                o[s] = (int16_t)fin;
+            }
+            if (valid == 32 && hist1 == g1 && hist2 == g2) break;
+        }
     }
 }
 
@@ -670,12 +732,35 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured = true;
         }
-        if (p.version == 4)
-            hipLaunchKernelGGL(adx_decode_fs18_tiled_kernel<true>, dim3((nch + 63) / 64), dim3(256), lds, stream, d_adpcm,
-                               in_pitch, nch, sample_count, p, d_pcm, pcm_pitch, d_status);
-        else
-            hipLaunchKernelGGL(adx_decode_fs18_tiled_kernel<false>, dim3((nch + 63) / 64), dim3(256), lds, stream, d_adpcm,
-                               in_pitch, nch, sample_count, p, d_pcm, pcm_pitch, d_status);
+        // as many time segments as fill the device once (one workgroup of this LDS size per CU), each at least 512
+        // frames long and an even number of frames
+        const int groups = (nch + 63) / 64;
+        int cus = 256;
+        {
+            int device = 0;
+            if (hipGetDevice(&device) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        }
+        const int frames = (sample_count + 31) / 32;
+        const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+        int segments = cus * per_cu / groups;
+        if (segments > frames / 512) segments = frames / 512;
+        if (segments < 1) segments = 1;
+        if (segments > 64) segments = 64;
+        int seg_frames = (frames + segments - 1) / segments;
+        seg_frames += seg_frames & 1;
+        if (p.version == 4) {
+            hipLaunchKernelGGL(adx_decode_fs18_tiled_kernel<true>, dim3(groups, segments), dim3(256), lds, stream, d_adpcm,
+                               in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status);
+            if (segments > 1)
+                hipLaunchKernelGGL(adx_decode_fs18_fixup_kernel<true>, dim3(groups), dim3(64), 0, stream, d_adpcm, in_pitch, nch,
+                                   sample_count, seg_frames, segments, p, d_pcm, pcm_pitch);
+        } else {
+            hipLaunchKernelGGL(adx_decode_fs18_tiled_kernel<false>, dim3(groups, segments), dim3(256), lds, stream, d_adpcm,
+                               in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status);
+            if (segments > 1)
+                hipLaunchKernelGGL(adx_decode_fs18_fixup_kernel<false>, dim3(groups), dim3(64), 0, stream, d_adpcm, in_pitch, nch,
+                                   sample_count, seg_frames, segments, p, d_pcm, pcm_pitch);
+        }
     } else {
         hipLaunchKernelGGL(adx_decode_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, in_pitch, nch, sample_count, p,
                            d_pcm, pcm_pitch, d_status);
