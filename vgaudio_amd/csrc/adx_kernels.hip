@@ -487,14 +487,23 @@ struct AdxEncodeTile {
 };
 
 template <bool V4, bool EXPONENTIAL>
+// Time segments (blockIdx.y): every piece of `seg_frames` frames (an even number) but the first is encoded from a
+// guessed history -- the two INPUT samples before it -- and adx_encode_fs18_fixup_kernel closes the seams afterwards.
+// seg_state[segment][channel] receives each piece's final history (two int16).
 __global__ __launch_bounds__(256) void adx_encode_fs18_tiled_kernel(
-    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int pcm_length, AdxDeviceParams p,
-    uint8_t *__restrict__ out, int64_t out_pitch, int16_t *__restrict__ history_out)
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, AdxDeviceParams p,
+    uint8_t *__restrict__ out, int64_t out_pitch, int16_t *__restrict__ history_out, int16_t *__restrict__ seg_state)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     AdxEncodeTile *s_tile = reinterpret_cast<AdxEncodeTile *>(s_raw);          // [2]
     const int tid = threadIdx.x;
     const int ch0 = blockIdx.x * 64;
+    const int64_t first_frame = (int64_t)blockIdx.y * seg_frames;
+    if (first_frame > 0 && first_frame * 32 >= total_length) return;
+    const int pcm_length = (int)((int64_t)total_length - first_frame * 32 < (int64_t)seg_frames * 32
+                                     ? (int64_t)total_length - first_frame * 32 : (int64_t)seg_frames * 32);
+    pcm += first_frame * 32;
+    out += first_frame * 18;
     const int frame_count = (pcm_length + 31) / 32;
     const int tiles = (frame_count + ATF - 1) / ATF;
     const int c0 = p.coef0, c1 = p.coef1;
@@ -619,8 +628,13 @@ __global__ __launch_bounds__(256) void adx_encode_fs18_tiled_kernel(
     const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
     const double raw_bound = 32770.0 + 8.0 * (double)((c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1));
     int h0 = 0, h1 = 0, hist = p.history;             // h1 = the newer sample
-    if (V4 && pcm_length > 0) { h0 = h1 = pcm[(int64_t)ch * pcm_pitch]; hist = h0; }      // :69-74
-    if (history_out && ch0 + tid < nch) history_out[ch] = (int16_t)hist;
+    if (blockIdx.y > 0) {                              // the guess: the input just before this piece
+        h0 = pcm[(int64_t)ch * pcm_pitch - 2];
+        h1 = pcm[(int64_t)ch * pcm_pitch - 1];
+    } else {
+        if (V4 && pcm_length > 0) { h0 = h1 = pcm[(int64_t)ch * pcm_pitch]; hist = h0; }      // :69-74
+        if (history_out && ch0 + tid < nch) history_out[ch] = (int16_t)hist;
+    }
 
     lds_barrier();                                     // tile 0 prepared
     for (int tile = 0; tile < tiles; tile++) {
@@ -679,6 +693,96 @@ __global__ __launch_bounds__(256) void adx_encode_fs18_tiled_kernel(
         }
         lds_barrier();
     }
+    if (seg_state && ch0 + tid < nch) {
+        int16_t *st = seg_state + ((int64_t)blockIdx.y * nch + ch) * 2;
+        st[0] = (int16_t)h0;
+        st[1] = (int16_t)h1;
+    }
+}
+
+// Closes the seams between the encoder's time segments, one lane per channel.  For every piece after the first it
+// replays the guessed run's reconstruction (decoding that run's frames from the guess, before they are overwritten)
+// next to a true encode from the real history, frame by frame, until the two histories coincide at a frame end:
+// from there on the guessed run wrote exactly what the serial encoder writes, and its final history (seg_state) is the
+// real one.  If they never coincide the piece is simply encoded again here.  Frame maths as adx_encode_kernel.
+template <bool V4, bool EXPONENTIAL>
+__global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, int segments,
+    AdxDeviceParams p, uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state)
+{
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= nch) return;
+    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
+    uint8_t *dst = out + (int64_t)ch * out_pitch;
+    const int c0 = p.coef0, c1 = p.coef1;
+    const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
+    int ta = seg_state[(int64_t)ch * 2], tb = seg_state[(int64_t)ch * 2 + 1];      // piece 0 ends on the real history
+    for (int k = 1; k < segments; k++) {
+        const int64_t f0 = (int64_t)k * seg_frames;
+        if (f0 * 32 >= total_length) break;
+        int sa = src[f0 * 32 - 2], sb = src[f0 * 32 - 1];                         // the guessed run's start
+        bool met = false;
+        for (int64_t f = f0; f < f0 + seg_frames && f * 32 < total_length; f++) {
+            uint8_t *fr = dst + f * 18;
+            int x[32];
+#pragma unroll
+            for (int j = 0; j < 32; j++) x[j] = f * 32 + j < total_length ? (int)src[f * 32 + j] : 0;
+            // the guessed run's reconstruction of this frame (CriAdxCodec.Decode :23-45)
+            {
+                int scale = (int)(int16_t)(((fr[0] << 8) | fr[1]) & 0x1FFF);
+                scale = (int)(int16_t)(EXPONENTIAL ? (1 << ((12 - scale) & 31)) : scale + 1);
+#pragma unroll 4
+                for (int j = 0; j < 32; j++) {
+                    const int byte = fr[2 + (j >> 1)];
+                    int v = (j & 1) ? (byte & 0xF) : (byte >> 4);
+                    v = (v ^ 8) - 8;
+                    if (V4) v = scale * v + ((sb * c0 + sa * c1) >> 12);
+                    else v = scale * v + ((sb * c0) >> 12) + ((sa * c1) >> 12);
+                    sa = sb;
+                    sb = clamp16(v);
+                }
+            }
+            // the real frame (EncodeFrame :107-147)
+            int max_distance = 0;
+            {
+                int a = ta, b = tb;
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    const int predicted = ((b * c0) >> 12) + ((a * c1) >> 12);
+                    int distance = clamp16(x[j] - predicted);
+                    distance = distance < 0 ? -distance : distance;
+                    max_distance = max(max_distance, distance);
+                    a = b;
+                    b = x[j];
+                }
+            }
+            double gain;
+            int scale_out;
+            const int scale = calculate_scale(max_distance, EXPONENTIAL, gain, scale_out);
+            fr[0] = (uint8_t)(((scale_out >> 8) & 0x1f) | filter_bits);
+            fr[1] = (uint8_t)(scale_out & 0xff);
+            int byte = 0;
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                int predicted = ((tb * c0) >> 12) + ((ta * c1) >> 12);
+                const int raw = x[j] - predicted;
+                const int scaled = clamp16(trunc_i32_ryujit((double)raw * gain));
+                const int q = scale_short_to_nibble(scaled);
+                const int decoded_distance = clamp16(scale * q);
+                if (V4) predicted = (tb * c0 + ta * c1) >> 12;
+                const int rec = clamp16(decoded_distance + predicted);
+                ta = tb;
+                tb = rec;
+                if (j & 1) fr[2 + (j >> 1)] = (uint8_t)(byte | (q & 0xF));
+                else byte = (q & 0xF) << 4;
+            }
+            if (ta == sa && tb == sb) { met = true; break; }
+        }
+        if (met) {                                     // the rest of the piece stands: its end is the real history
+            ta = seg_state[((int64_t)k * nch + ch) * 2];
+            tb = seg_state[((int64_t)k * nch + ch) * 2 + 1];
+        }
+    }
 }
 
 int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_length, const AdxDeviceParams &p,
@@ -692,6 +796,24 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
     if (fast) {
         const bool v4 = p.version == 4, ex = p.type == 4;
         const size_t lds = 2 * sizeof(AdxEncodeTile);
+        // as many time segments as fill the device once, each an even number of frames and at least 2048 frames long
+        // (the seams re-encode some hundred frames each)
+        const int groups = (nch + 63) / 64;
+        int cus = 256;
+        {
+            int device = 0;
+            if (hipGetDevice(&device) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        }
+        const int frames = (pcm_length + 31) / 32;
+        const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+        int segments = cus * per_cu / groups;
+        if (segments > frames / 2048) segments = frames / 2048;
+        if (segments < 1) segments = 1;
+        if (segments > 64) segments = 64;
+        int seg_frames = (frames + segments - 1) / segments;
+        seg_frames += seg_frames & 1;
+        int16_t *seg_state = nullptr;
+        if (segments > 1) VGA_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&seg_state), (size_t)segments * nch * 2 * sizeof(int16_t), stream));
 #define VGA_ADX_ENC_T(V, E)                                                                                              \
         {                                                                                                                \
             static bool configured = false;                                                                              \
@@ -700,14 +822,18 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
                 configured = true;                                                                                       \
             }                                                                                                            \
-            hipLaunchKernelGGL((adx_encode_fs18_tiled_kernel<V, E>), grid, dim3(256), lds, stream, d_pcm, pcm_pitch, nch, \
-                               pcm_length, p, d_out, out_pitch, d_history_out);                                         \
+            hipLaunchKernelGGL((adx_encode_fs18_tiled_kernel<V, E>), dim3(groups, segments), dim3(256), lds, stream, d_pcm, \
+                               pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, d_history_out, seg_state);  \
+            if (segments > 1)                                                                                            \
+                hipLaunchKernelGGL((adx_encode_fs18_fixup_kernel<V, E>), dim3(groups), dim3(64), 0, stream, d_pcm,      \
+                                   pcm_pitch, nch, pcm_length, seg_frames, segments, p, d_out, out_pitch, seg_state);   \
         }
         if (v4 && ex) VGA_ADX_ENC_T(true, true)
         else if (v4) VGA_ADX_ENC_T(true, false)
         else if (ex) VGA_ADX_ENC_T(false, true)
         else VGA_ADX_ENC_T(false, false)
 #undef VGA_ADX_ENC_T
+        if (seg_state) VGA_HIP_TRY(hipFreeAsync(seg_state, stream));
     } else {                                           // other frame sizes, padded (looping) streams, odd alignments
         hipLaunchKernelGGL(adx_encode_kernel, grid, block, 0, stream, d_pcm, pcm_pitch, nch, pcm_length, p, d_out, out_pitch,
                            d_history_out);
