@@ -700,88 +700,112 @@ __global__ __launch_bounds__(256) void adx_encode_fs18_tiled_kernel(
     }
 }
 
-// Closes the seams between the encoder's time segments, one lane per channel.  For every piece after the first it
-// replays the guessed run's reconstruction (decoding that run's frames from the guess, before they are overwritten)
-// next to a true encode from the real history, frame by frame, until the two histories coincide at a frame end:
-// from there on the guessed run wrote exactly what the serial encoder writes, and its final history (seg_state) is the
-// real one.  If they never coincide the piece is simply encoded again here.  Frame maths as adx_encode_kernel.
+// One frame of CriAdxCodec.EncodeFrame (:107-147) from the history (a, b); maths as adx_encode_kernel.
+template <bool V4, bool EXPONENTIAL>
+__device__ __forceinline__ void adx_encode_frame_serial(const int (&x)[32], int &a, int &b, int c0, int c1, int filter_bits,
+                                                        uint8_t *fr)
+{
+    int max_distance = 0;
+    {
+        int pa = a, pb = b;
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            const int predicted = ((pb * c0) >> 12) + ((pa * c1) >> 12);
+            int distance = clamp16(x[j] - predicted);
+            distance = distance < 0 ? -distance : distance;
+            max_distance = max(max_distance, distance);
+            pa = pb;
+            pb = x[j];
+        }
+    }
+    double gain;
+    int scale_out;
+    const int scale = calculate_scale(max_distance, EXPONENTIAL, gain, scale_out);
+    fr[0] = (uint8_t)(((scale_out >> 8) & 0x1f) | filter_bits);
+    fr[1] = (uint8_t)(scale_out & 0xff);
+    int byte = 0;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        int predicted = ((b * c0) >> 12) + ((a * c1) >> 12);
+        const int raw = x[j] - predicted;
+        const int scaled = clamp16(trunc_i32_ryujit((double)raw * gain));
+        const int q = scale_short_to_nibble(scaled);
+        const int decoded_distance = clamp16(scale * q);
+        if (V4) predicted = (b * c0 + a * c1) >> 12;
+        const int rec = clamp16(decoded_distance + predicted);
+        a = b;
+        b = rec;
+        if (j & 1) fr[2 + (j >> 1)] = (uint8_t)(byte | (q & 0xF));
+        else byte = (q & 0xF) << 4;
+    }
+}
+
+// Closes the seams between the encoder's time segments: one lane per (channel, seam), all seams at once.  A seam
+// starts from the final history of the piece before it (seg_state) -- the real one provided THAT piece's own seam
+// closes -- and replays the guessed run's reconstruction (decoding that run's frames from the guess, before they are
+// overwritten) next to a true encode, frame by frame, until the two histories coincide at a frame end: from there on
+// the guessed run wrote exactly what the serial encoder writes.  A seam that does not close inside its piece records
+// its index in first_open[channel]; adx_encode_fs18_tail_kernel then encodes that channel serially from there.
 template <bool V4, bool EXPONENTIAL>
 __global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
-    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, int segments,
-    AdxDeviceParams p, uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state)
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, AdxDeviceParams p,
+    uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state, int *__restrict__ first_open)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= nch) return;
+    const int k = blockIdx.y + 1;
+    const int64_t f0 = (int64_t)k * seg_frames;
+    if (ch >= nch || f0 * 32 >= total_length) return;
     const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
     uint8_t *dst = out + (int64_t)ch * out_pitch;
     const int c0 = p.coef0, c1 = p.coef1;
     const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
-    int ta = seg_state[(int64_t)ch * 2], tb = seg_state[(int64_t)ch * 2 + 1];      // piece 0 ends on the real history
-    for (int k = 1; k < segments; k++) {
-        const int64_t f0 = (int64_t)k * seg_frames;
-        if (f0 * 32 >= total_length) break;
-        int sa = src[f0 * 32 - 2], sb = src[f0 * 32 - 1];                         // the guessed run's start
-        bool met = false;
-        for (int64_t f = f0; f < f0 + seg_frames && f * 32 < total_length; f++) {
-            uint8_t *fr = dst + f * 18;
-            int x[32];
+    int ta = seg_state[((int64_t)(k - 1) * nch + ch) * 2], tb = seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1];
+    int sa = src[f0 * 32 - 2], sb = src[f0 * 32 - 1];                             // the guessed run's start
+    for (int64_t f = f0; f < f0 + seg_frames && f * 32 < total_length; f++) {
+        uint8_t *fr = dst + f * 18;
+        int x[32];
 #pragma unroll
-            for (int j = 0; j < 32; j++) x[j] = f * 32 + j < total_length ? (int)src[f * 32 + j] : 0;
-            // the guessed run's reconstruction of this frame (CriAdxCodec.Decode :23-45)
-            {
-                int scale = (int)(int16_t)(((fr[0] << 8) | fr[1]) & 0x1FFF);
-                scale = (int)(int16_t)(EXPONENTIAL ? (1 << ((12 - scale) & 31)) : scale + 1);
+        for (int j = 0; j < 32; j++) x[j] = f * 32 + j < total_length ? (int)src[f * 32 + j] : 0;
+        // the guessed run's reconstruction of this frame (CriAdxCodec.Decode :23-45)
+        int scale = (int)(int16_t)(((fr[0] << 8) | fr[1]) & 0x1FFF);
+        scale = (int)(int16_t)(EXPONENTIAL ? (1 << ((12 - scale) & 31)) : scale + 1);
 #pragma unroll 4
-                for (int j = 0; j < 32; j++) {
-                    const int byte = fr[2 + (j >> 1)];
-                    int v = (j & 1) ? (byte & 0xF) : (byte >> 4);
-                    v = (v ^ 8) - 8;
-                    if (V4) v = scale * v + ((sb * c0 + sa * c1) >> 12);
-                    else v = scale * v + ((sb * c0) >> 12) + ((sa * c1) >> 12);
-                    sa = sb;
-                    sb = clamp16(v);
-                }
-            }
-            // the real frame (EncodeFrame :107-147)
-            int max_distance = 0;
-            {
-                int a = ta, b = tb;
-#pragma unroll
-                for (int j = 0; j < 32; j++) {
-                    const int predicted = ((b * c0) >> 12) + ((a * c1) >> 12);
-                    int distance = clamp16(x[j] - predicted);
-                    distance = distance < 0 ? -distance : distance;
-                    max_distance = max(max_distance, distance);
-                    a = b;
-                    b = x[j];
-                }
-            }
-            double gain;
-            int scale_out;
-            const int scale = calculate_scale(max_distance, EXPONENTIAL, gain, scale_out);
-            fr[0] = (uint8_t)(((scale_out >> 8) & 0x1f) | filter_bits);
-            fr[1] = (uint8_t)(scale_out & 0xff);
-            int byte = 0;
-#pragma unroll
-            for (int j = 0; j < 32; j++) {
-                int predicted = ((tb * c0) >> 12) + ((ta * c1) >> 12);
-                const int raw = x[j] - predicted;
-                const int scaled = clamp16(trunc_i32_ryujit((double)raw * gain));
-                const int q = scale_short_to_nibble(scaled);
-                const int decoded_distance = clamp16(scale * q);
-                if (V4) predicted = (tb * c0 + ta * c1) >> 12;
-                const int rec = clamp16(decoded_distance + predicted);
-                ta = tb;
-                tb = rec;
-                if (j & 1) fr[2 + (j >> 1)] = (uint8_t)(byte | (q & 0xF));
-                else byte = (q & 0xF) << 4;
-            }
-            if (ta == sa && tb == sb) { met = true; break; }
+        for (int j = 0; j < 32; j++) {
+            const int byte = fr[2 + (j >> 1)];
+            int v = (j & 1) ? (byte & 0xF) : (byte >> 4);
+            v = (v ^ 8) - 8;
+            if (V4) v = scale * v + ((sb * c0 + sa * c1) >> 12);
+            else v = scale * v + ((sb * c0) >> 12) + ((sa * c1) >> 12);
+            sa = sb;
+            sb = clamp16(v);
         }
-        if (met) {                                     // the rest of the piece stands: its end is the real history
-            ta = seg_state[((int64_t)k * nch + ch) * 2];
-            tb = seg_state[((int64_t)k * nch + ch) * 2 + 1];
-        }
+        adx_encode_frame_serial<V4, EXPONENTIAL>(x, ta, tb, c0, c1, filter_bits, fr);
+        if (ta == sa && tb == sb) return;              // closed: the rest of the piece stands
+    }
+    atomicMin(&first_open[ch], k);
+}
+
+// Channels with an open seam (practically none): encode serially from that piece to the end of the stream.
+template <bool V4, bool EXPONENTIAL>
+__global__ __launch_bounds__(64) void adx_encode_fs18_tail_kernel(
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, AdxDeviceParams p,
+    uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state, const int *__restrict__ first_open)
+{
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= nch) return;
+    const int k = first_open[ch];
+    if (k <= 0 || k >= 0x7f000000) return;
+    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
+    uint8_t *dst = out + (int64_t)ch * out_pitch;
+    const int c0 = p.coef0, c1 = p.coef1;
+    const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
+    // pieces before k closed their seams, so piece k - 1 ended on the real history
+    int a = seg_state[((int64_t)(k - 1) * nch + ch) * 2], b = seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1];
+    for (int64_t f = (int64_t)k * seg_frames; f * 32 < total_length; f++) {
+        int x[32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) x[j] = f * 32 + j < total_length ? (int)src[f * 32 + j] : 0;
+        adx_encode_frame_serial<V4, EXPONENTIAL>(x, a, b, c0, c1, filter_bits, dst + f * 18);
     }
 }
 
@@ -812,8 +836,14 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
         if (segments > 64) segments = 64;
         int seg_frames = (frames + segments - 1) / segments;
         seg_frames += seg_frames & 1;
-        int16_t *seg_state = nullptr;
-        if (segments > 1) VGA_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&seg_state), (size_t)segments * nch * 2 * sizeof(int16_t), stream));
+        int16_t *seg_state = nullptr;                  // [segments][nch][2] final histories, then [nch] first open seam
+        int *first_open = nullptr;
+        if (segments > 1) {
+            const size_t state_bytes = round_up((size_t)segments * nch * 2 * sizeof(int16_t), 16);
+            VGA_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&seg_state), state_bytes + (size_t)nch * sizeof(int), stream));
+            first_open = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(seg_state) + state_bytes);
+            VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
+        }
 #define VGA_ADX_ENC_T(V, E)                                                                                              \
         {                                                                                                                \
             static bool configured = false;                                                                              \
@@ -824,9 +854,13 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
             }                                                                                                            \
             hipLaunchKernelGGL((adx_encode_fs18_tiled_kernel<V, E>), dim3(groups, segments), dim3(256), lds, stream, d_pcm, \
                                pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, d_history_out, seg_state);  \
-            if (segments > 1)                                                                                            \
-                hipLaunchKernelGGL((adx_encode_fs18_fixup_kernel<V, E>), dim3(groups), dim3(64), 0, stream, d_pcm,      \
-                                   pcm_pitch, nch, pcm_length, seg_frames, segments, p, d_out, out_pitch, seg_state);   \
+            if (segments > 1) {                                                                                          \
+                hipLaunchKernelGGL((adx_encode_fs18_fixup_kernel<V, E>), dim3(groups, segments - 1), dim3(64), 0, stream, \
+                                   d_pcm, pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, seg_state,       \
+                                   first_open);                                                                          \
+                hipLaunchKernelGGL((adx_encode_fs18_tail_kernel<V, E>), dim3(groups), dim3(64), 0, stream, d_pcm,       \
+                                   pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, seg_state, first_open); \
+            }                                                                                                            \
         }
         if (v4 && ex) VGA_ADX_ENC_T(true, true)
         else if (v4) VGA_ADX_ENC_T(true, false)
