@@ -479,25 +479,29 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_fixup_kernel(
 // (:120-138).  scale_short_to_nibble (:167-171) is done on the magnitude: |q| = ((|v| + 2340) * 114692) >> 29 is
 // floor((|v| + 2340) / 4681) for |v| <= 32768 (2^29 / 4681 = 114691.5.., error term 2340 per unit: exact below
 // 229 432), the result is at most 7 so Clamp4 and the Clamp16 of scale * q (scale <= 4096) cannot bind.
+constexpr int EATF = 2;                                // frames per tile
+constexpr int ECW = 128;                               // channels per workgroup: TWO encoder waves (on different SIMDs of the
+                                                       // CU) and six helper waves; the double-buffered tiles fill one CU's LDS
+constexpr int ETHREADS = ECW * 4, EHELPERS = ETHREADS - ECW;
 struct AdxEncodeTile {
-    int4 x[ATF][8][64];                                // [frame][eighth][channel]: the 32 input samples
-    int pmax[ATF][64];                                 // max |Clamp16(distance)| over samples 2..31
-    int4 q[ATF][8][64];                                // encoder output: 32 nibbles (-7..7)
-    int hdr[ATF][64];                                  // encoder output: the 16 header bits (scale, filter)
+    int4 x[EATF][8][ECW];                                // [frame][eighth][channel]: the 32 input samples
+    int pmax[EATF][ECW];                                 // max |Clamp16(distance)| over samples 2..31
+    int4 q[EATF][8][ECW];                                // encoder output: 32 nibbles (-7..7)
+    int hdr[EATF][ECW];                                  // encoder output: the 16 header bits (scale, filter)
 };
 
 template <bool V4, bool EXPONENTIAL>
 // Time segments (blockIdx.y): every piece of `seg_frames` frames (an even number) but the first is encoded from a
 // guessed history -- the two INPUT samples before it -- and adx_encode_fs18_fixup_kernel closes the seams afterwards.
 // seg_state[segment][channel] receives each piece's final history (two int16).
-__global__ __launch_bounds__(256) void adx_encode_fs18_tiled_kernel(
+__global__ __launch_bounds__(ETHREADS) void adx_encode_fs18_tiled_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, AdxDeviceParams p,
     uint8_t *__restrict__ out, int64_t out_pitch, int16_t *__restrict__ history_out, int16_t *__restrict__ seg_state)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     AdxEncodeTile *s_tile = reinterpret_cast<AdxEncodeTile *>(s_raw);          // [2]
     const int tid = threadIdx.x;
-    const int ch0 = blockIdx.x * 64;
+    const int ch0 = blockIdx.x * ECW;
     const int64_t first_frame = (int64_t)blockIdx.y * seg_frames;
     if (first_frame > 0 && first_frame * 32 >= total_length) return;
     const int pcm_length = (int)((int64_t)total_length - first_frame * 32 < (int64_t)seg_frames * 32
@@ -505,21 +509,21 @@ __global__ __launch_bounds__(256) void adx_encode_fs18_tiled_kernel(
     pcm += first_frame * 32;
     out += first_frame * 18;
     const int frame_count = (pcm_length + 31) / 32;
-    const int tiles = (frame_count + ATF - 1) / ATF;
+    const int tiles = (frame_count + EATF - 1) / EATF;
     const int c0 = p.coef0, c1 = p.coef1;
 
-    if (tid >= 64) {
+    if (tid >= ECW) {
         // ------------------------------------------------------------ helper waves (192 lanes)
-        const int hl = tid - 64;
-        constexpr int ITEMS = (64 * ATF + 191) / 192;
+        const int hl = tid - ECW;
+        constexpr int ITEMS = (ECW * EATF + EHELPERS - 1) / EHELPERS;
         struct Raw { uint4 v[4]; };
         auto load_tile = [&](int tile, Raw (&raw)[ITEMS]) {          // unconditional loads, clamped frame index
 #pragma unroll
             for (int k = 0; k < ITEMS; k++) {
-                const int item = min(hl + 192 * k, 64 * ATF - 1);
-                const int c = item / ATF, j = item - c * ATF;
+                const int item = min(hl + EHELPERS * k, ECW * EATF - 1);
+                const int c = item / EATF, j = item - c * EATF;
                 // the last frame may be partial: clamp to the last FULL frame (re-read below if needed)
-                const int i = min(tile * ATF + j, max(pcm_length / 32 - 1, 0));
+                const int i = min(tile * EATF + j, max(pcm_length / 32 - 1, 0));
                 const int ch = min(ch0 + c, nch - 1);
                 const uint4 *src = reinterpret_cast<const uint4 *>(pcm + (int64_t)ch * pcm_pitch + (int64_t)i * 32);
                 if (pcm_length < 32) {                  // no full frame at all: nothing to prefetch (uniform)
@@ -535,10 +539,10 @@ __global__ __launch_bounds__(256) void adx_encode_fs18_tiled_kernel(
             AdxEncodeTile &T = s_tile[tile & 1];
 #pragma unroll
             for (int k = 0; k < ITEMS; k++) {
-                const int item = hl + 192 * k;
-                if (item >= 64 * ATF) continue;
-                const int c = item / ATF, j = item - c * ATF;
-                const int i = tile * ATF + j;
+                const int item = hl + EHELPERS * k;
+                if (item >= ECW * EATF) continue;
+                const int c = item / EATF, j = item - c * EATF;
+                const int i = tile * EATF + j;
                 if (i >= frame_count) continue;
                 uint32_t w[16];
                 if ((int64_t)i * 32 + 32 <= pcm_length) {
@@ -571,9 +575,9 @@ __global__ __launch_bounds__(256) void adx_encode_fs18_tiled_kernel(
         };
         auto flush = [&](int tile) {
             const AdxEncodeTile &T = s_tile[tile & 1];
-            for (int item = hl; item < 64 * ATF; item += 192) {
-                const int c = item / ATF, j = item - c * ATF;
-                const int i = tile * ATF + j;
+            for (int item = hl; item < ECW * EATF; item += EHELPERS) {
+                const int c = item / EATF, j = item - c * EATF;
+                const int i = tile * EATF + j;
                 if (i >= frame_count || ch0 + c >= nch) continue;
                 uint32_t bytes[5] = {(uint32_t)T.hdr[j][c], 0, 0, 0, 0};       // 18 bytes + 2 spare
 #pragma unroll
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(256) void adx_encode_fs18_tiled_kernel(
     lds_barrier();                                     // tile 0 prepared
     for (int tile = 0; tile < tiles; tile++) {
         AdxEncodeTile &T = s_tile[tile & 1];
-        const int nf = min(ATF, frame_count - tile * ATF);
+        const int nf = min(EATF, frame_count - tile * EATF);
 #pragma unroll 1
         for (int j = 0; j < nf; j++) {
             int x[32];
@@ -822,7 +826,7 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
         const size_t lds = 2 * sizeof(AdxEncodeTile);
         // as many time segments as fill the device once, each an even number of frames and at least 2048 frames long
         // (the seams re-encode some hundred frames each)
-        const int groups = (nch + 63) / 64;
+        const int groups = (nch + ECW - 1) / ECW, groups64 = (nch + 63) / 64;
         int cus = 256;
         {
             int device = 0;
@@ -852,13 +856,13 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
                 configured = true;                                                                                       \
             }                                                                                                            \
-            hipLaunchKernelGGL((adx_encode_fs18_tiled_kernel<V, E>), dim3(groups, segments), dim3(256), lds, stream, d_pcm, \
+            hipLaunchKernelGGL((adx_encode_fs18_tiled_kernel<V, E>), dim3(groups, segments), dim3(ETHREADS), lds, stream, d_pcm, \
                                pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, d_history_out, seg_state);  \
             if (segments > 1) {                                                                                          \
-                hipLaunchKernelGGL((adx_encode_fs18_fixup_kernel<V, E>), dim3(groups, segments - 1), dim3(64), 0, stream, \
+                hipLaunchKernelGGL((adx_encode_fs18_fixup_kernel<V, E>), dim3(groups64, segments - 1), dim3(64), 0, stream, \
                                    d_pcm, pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, seg_state,       \
                                    first_open);                                                                          \
-                hipLaunchKernelGGL((adx_encode_fs18_tail_kernel<V, E>), dim3(groups), dim3(64), 0, stream, d_pcm,       \
+                hipLaunchKernelGGL((adx_encode_fs18_tail_kernel<V, E>), dim3(groups64), dim3(64), 0, stream, d_pcm,     \
                                    pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, seg_state, first_open); \
             }                                                                                                            \
         }
