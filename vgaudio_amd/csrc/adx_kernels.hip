@@ -419,55 +419,85 @@ __global__ __launch_bounds__(256) void adx_decode_fs18_tiled_kernel(
     }
 }
 
-// Closes the seams between time segments, one lane per channel: from the true history (the two samples before the
-// segment, final by now) decode again frame by frame over the guessed run's samples until both histories coincide
-// at a frame end -- from there on the guessed run is what the serial decoder produces.  Exact in every case; if the
-// histories never meet, the segment is simply decoded here a second time.
+// One frame of CriAdxCodec.Decode (:23-45) from the history (hist1, hist2) into o[0 .. valid).
+template <bool V4>
+__device__ __forceinline__ void adx_decode_frame_serial(const uint8_t *fr, const AdxDeviceParams &p, int valid, int &hist1,
+                                                        int &hist2, int16_t *o)
+{
+    const int hb0 = fr[0], hb1 = fr[1];
+    int filter_num = ((hb0 >> 4) & 0xF) >> 1;
+    int cf0, cf1;
+    if (p.type == 2) {                                  // as the tiled kernel's `prepare`
+        if (filter_num > 3) filter_num = 3;
+        cf0 = filter_num == 0 ? 0 : (filter_num == 1 ? 0x0F00 : (filter_num == 2 ? 0x1CC0 : 0x1880));
+        cf1 = filter_num == 0 ? 0 : (filter_num == 1 ? 0 : (filter_num == 2 ? (int)(int16_t)0xF300 : (int)(int16_t)0xF240));
+    } else {
+        cf0 = p.coef0;
+        cf1 = p.coef1;
+    }
+    int scale = (int)(int16_t)(((hb0 << 8) | hb1) & 0x1FFF);
+    scale = (int)(int16_t)(p.type == 4 ? (1 << ((12 - scale) & 31)) : scale + 1);
+    for (int s = 0; s < valid; s++) {
+        const int byte = fr[2 + (s >> 1)];
+        int sample = (s & 1) ? (byte & 0xF) : (byte >> 4);
+        sample = (sample ^ 8) - 8;
+        if (V4) sample = scale * sample + ((hist1 * cf0 + hist2 * cf1) >> 12);
+        else sample = scale * sample + ((hist1 * cf0) >> 12) + ((hist2 * cf1) >> 12);
+        const int fin = clamp16(sample);
+        hist2 = hist1;
+        hist1 = fin;
+        o[s] = (int16_t)fin;
+    }
+}
+
+// Closes the seams between time segments: one lane per (channel, seam), all seams at once.  From the history the piece
+// before ended on (its last two samples: final provided THAT piece's own seam closes) decode again frame by frame
+// over the guessed run's samples until both histories coincide at a frame end -- from there on the guessed run is
+// what the serial decoder produces.  A seam that does not close inside its piece records its index in
+// first_open[channel]; adx_decode_fs18_tail_kernel then decodes that channel serially from there.  Exact in every case.
 template <bool V4>
 __global__ __launch_bounds__(64) void adx_decode_fs18_fixup_kernel(
-    const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, int segments,
-    AdxDeviceParams p, int16_t *__restrict__ pcm, int64_t pcm_pitch)
+    const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, AdxDeviceParams p,
+    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ first_open)
+{
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    const int k = blockIdx.y + 1;
+    const int64_t f0 = (int64_t)k * seg_frames;
+    if (ch >= nch || f0 * 32 >= total_samples) return;
+    const uint8_t *src = adpcm + (int64_t)ch * in_pitch;
+    int16_t *dst = pcm + (int64_t)ch * pcm_pitch;
+    int hist1 = dst[f0 * 32 - 1], hist2 = dst[f0 * 32 - 2];
+    for (int64_t f = f0; f < f0 + seg_frames && f * 32 < total_samples; f++) {
+        const int valid = (int)((int64_t)total_samples - f * 32 < 32 ? (int64_t)total_samples - f * 32 : 32);
+        int16_t *o = dst + f * 32;
+        int g1 = 0, g2 = 0;                             // the guessed run's history at this frame's end
+        if (valid == 32) { g1 = o[31]; g2 = o[30]; }
+        adx_decode_frame_serial<V4>(src + f * 18, p, valid, hist1, hist2, o);
+        if (valid == 32 && hist1 == g1 && hist2 == g2) return;
+        if (valid < 32) return;                         // the stream's last, partial frame: nothing follows
+    }
+    if (f0 + seg_frames < ((int64_t)total_samples + 31) / 32) atomicMin(&first_open[ch], k);   // open, and a piece follows
+}
+
+// Channels with an open seam (practically none): decode serially from the piece after it to the end of the stream.
+template <bool V4>
+__global__ __launch_bounds__(64) void adx_decode_fs18_tail_kernel(
+    const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, AdxDeviceParams p,
+    int16_t *__restrict__ pcm, int64_t pcm_pitch, const int *__restrict__ first_open)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= nch) return;
+    const int k = first_open[ch];
+    if (k <= 0 || k >= 0x7f000000) return;
     const uint8_t *src = adpcm + (int64_t)ch * in_pitch;
     int16_t *dst = pcm + (int64_t)ch * pcm_pitch;
-    for (int k = 1; k < segments; k++) {
-        const int64_t f0 = (int64_t)k * seg_frames;
-        if (f0 * 32 >= total_samples) break;
-        int hist1 = dst[f0 * 32 - 1], hist2 = dst[f0 * 32 - 2];
-        for (int64_t f = f0; f < f0 + seg_frames && f * 32 < total_samples; f++) {
-            const uint8_t *fr = src + f * 18;
-            const int hb0 = fr[0], hb1 = fr[1];
-            int filter_num = ((hb0 >> 4) & 0xF) >> 1;
-            int cf0, cf1;
-            if (p.type == 2) {                          // as the tiled kernel's `prepare`
-                if (filter_num > 3) filter_num = 3;
-                cf0 = filter_num == 0 ? 0 : (filter_num == 1 ? 0x0F00 : (filter_num == 2 ? 0x1CC0 : 0x1880));
-                cf1 = filter_num == 0 ? 0 : (filter_num == 1 ? 0 : (filter_num == 2 ? (int)(int16_t)0xF300 : (int)(int16_t)0xF240));
-            } else {
-                cf0 = p.coef0;
-                cf1 = p.coef1;
-            }
-            int scale = (int)(int16_t)(((hb0 << 8) | hb1) & 0x1FFF);
-            scale = (int)(int16_t)(p.type == 4 ? (1 << ((12 - scale) & 31)) : scale + 1);
-            const int valid = (int)((int64_t)total_samples - f * 32 < 32 ? (int64_t)total_samples - f * 32 : 32);
-            int16_t *o = dst + f * 32;
-            int g1 = 0, g2 = 0;                         // the guessed run's history at this frame's end
-            if (valid == 32) { g1 = o[31]; g2 = o[30]; }
-            for (int s = 0; s < valid; s++) {
-                const int byte = fr[2 + (s >> 1)];
-                int sample = (s & 1) ? (byte & 0xF) : (byte >> 4);
-                sample = (sample ^ 8) - 8;
-                if (V4) sample = scale * sample + ((hist1 * cf0 + hist2 * cf1) >> 12);
-                else sample = scale * sample + ((hist1 * cf0) >> 12) + ((hist2 * cf1) >> 12);
-                const int fin = clamp16(sample);
-                hist2 = hist1;
-                hist1 = fin;
-                o[s] = (int16_t)fin;
-            }
-            if (valid == 32 && hist1 == g1 && hist2 == g2) break;
-        }
+    // seam k ran to the end of piece k (so that piece is final now); everything after it was seeded from samples
+    // that have changed since
+    const int64_t f0 = (int64_t)(k + 1) * seg_frames;
+    int hist1 = dst[f0 * 32 - 1], hist2 = dst[f0 * 32 - 2];
+    for (int64_t f = f0; f * 32 < total_samples; f++) {
+        const int valid = (int)((int64_t)total_samples - f * 32 < 32 ? (int64_t)total_samples - f * 32 : 32);
+        adx_decode_frame_serial<V4>(src + f * 18, p, valid, hist1, hist2, dst + f * 32);
     }
 }
 
@@ -912,19 +942,26 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
         if (segments > 64) segments = 64;
         int seg_frames = (frames + segments - 1) / segments;
         seg_frames += seg_frames & 1;
-        if (p.version == 4) {
-            hipLaunchKernelGGL(adx_decode_fs18_tiled_kernel<true>, dim3(groups, segments), dim3(256), lds, stream, d_adpcm,
-                               in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status);
-            if (segments > 1)
-                hipLaunchKernelGGL(adx_decode_fs18_fixup_kernel<true>, dim3(groups), dim3(64), 0, stream, d_adpcm, in_pitch, nch,
-                                   sample_count, seg_frames, segments, p, d_pcm, pcm_pitch);
-        } else {
-            hipLaunchKernelGGL(adx_decode_fs18_tiled_kernel<false>, dim3(groups, segments), dim3(256), lds, stream, d_adpcm,
-                               in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status);
-            if (segments > 1)
-                hipLaunchKernelGGL(adx_decode_fs18_fixup_kernel<false>, dim3(groups), dim3(64), 0, stream, d_adpcm, in_pitch, nch,
-                                   sample_count, seg_frames, segments, p, d_pcm, pcm_pitch);
+        int *first_open = nullptr;
+        if (segments > 1) {
+            VGA_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&first_open), (size_t)nch * sizeof(int), stream));
+            VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
         }
+#define VGA_ADX_DEC_T(V)                                                                                                 \
+        {                                                                                                                \
+            hipLaunchKernelGGL(adx_decode_fs18_tiled_kernel<V>, dim3(groups, segments), dim3(256), lds, stream, d_adpcm, \
+                               in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status);                  \
+            if (segments > 1) {                                                                                          \
+                hipLaunchKernelGGL(adx_decode_fs18_fixup_kernel<V>, dim3(groups, segments - 1), dim3(64), 0, stream,    \
+                                   d_adpcm, in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, first_open);  \
+                hipLaunchKernelGGL(adx_decode_fs18_tail_kernel<V>, dim3(groups), dim3(64), 0, stream, d_adpcm, in_pitch, \
+                                   nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, first_open);                      \
+            }                                                                                                            \
+        }
+        if (p.version == 4) VGA_ADX_DEC_T(true)
+        else VGA_ADX_DEC_T(false)
+#undef VGA_ADX_DEC_T
+        if (first_open) VGA_HIP_TRY(hipFreeAsync(first_open, stream));
     } else {
         hipLaunchKernelGGL(adx_decode_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, in_pitch, nch, sample_count, p,
                            d_pcm, pcm_pitch, d_status);
