@@ -121,3 +121,51 @@ def test_config4_hca_1024_stereo_streams():
     host = spcm[2 * s:2 * s + 2, :N].cpu().numpy()
     rc, oinfo, want = po.hca_encode(host, po.hca_params(2, N))
     assert rc == 0 and (fr[s].cpu().numpy() == want).all()
+
+
+def test_time_segment_fallbacks_are_exact():
+    """GC decode and ADX encode/decode cut long channels into time pieces decoded side by side from a guessed history
+    and close the seams afterwards.  With the test hook no seam is ever accepted as closed, so the
+    fall-back paths (serial redo of the rest of the channel) produce the output: it must not change."""
+    d = torch.device("cuda:0")
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    nch, n = 130, 32 * 14 * 700 + 11           # several pieces, ragged tails, a channel count that fills no workgroup
+    pcm = vdev.synth_pcm(nch, n, d)
+    coefs = vdev.gc_coefs(pcm, n)
+    adpcm = vdev.gc_encode(pcm, n, coefs)
+    p = _lib.AdxParams()
+    L.vga_adx_default_params(C.byref(p))
+    nb = L.vga_adx_encoded_byte_count(n, C.byref(p))
+    pitch = (nb + 15) // 16 * 16
+    status = torch.zeros(1, dtype=torch.int32, device=d)
+
+    def run():
+        dec, _ = vdev.gc_decode(adpcm, coefs, n)
+        adx = torch.zeros((nch, pitch), dtype=torch.uint8, device=d)
+        hist = torch.zeros(nch, dtype=torch.int16, device=d)
+        back = vdev.alloc_pcm(nch, n, d)
+        _lib.check(L.vga_adx_encode_device(pcm.data_ptr(), pcm.stride(0), nch, n, C.byref(p), adx.data_ptr(), pitch,
+                                           hist.data_ptr(), st))
+        _lib.check(L.vga_adx_decode_device(adx.data_ptr(), pitch, nb, nch, n, C.byref(p), back.data_ptr(), back.stride(0),
+                                           status.data_ptr(), st))
+        torch.cuda.synchronize()
+        return dec[:, :n].clone(), adx[:, :nb].clone(), back[:, :n].clone()
+
+    normal = run()
+    old = L.vga_debug_force_open_seams(1)
+    try:
+        forced = run()
+    finally:
+        L.vga_debug_force_open_seams(old)
+    for a, b in zip(normal, forced):
+        assert torch.equal(a, b)
+    # and both equal the oracle on a few channels
+    for c in (0, 64, 129):
+        host = pcm[c, :n].cpu().numpy()
+        assert (normal[0][c].cpu().numpy() == po.gc_decode(adpcm[c, :vdev.gc_byte_count(n)].cpu().numpy(),
+                                                            coefs[c].cpu().numpy(), n)).all()
+        op = po.adx_params()
+        want = po.adx_encode(host, op)
+        assert (normal[1][c].cpu().numpy() == want).all()
+        assert (normal[2][c].cpu().numpy() == po.adx_decode(want, n, po.adx_params())).all()

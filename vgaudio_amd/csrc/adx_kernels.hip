@@ -458,7 +458,7 @@ __device__ __forceinline__ void adx_decode_frame_serial(const uint8_t *fr, const
 template <bool V4>
 __global__ __launch_bounds__(64) void adx_decode_fs18_fixup_kernel(
     const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, AdxDeviceParams p,
-    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ first_open)
+    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ first_open, int force_open)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     const int k = blockIdx.y + 1;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_fixup_kernel(
         int g1 = 0, g2 = 0;                             // the guessed run's history at this frame's end
         if (valid == 32) { g1 = o[31]; g2 = o[30]; }
         adx_decode_frame_serial<V4>(src + f * 18, p, valid, hist1, hist2, o);
-        if (valid == 32 && hist1 == g1 && hist2 == g2) return;
+        if (valid == 32 && hist1 == g1 && hist2 == g2 && !force_open) return;
         if (valid < 32) return;                         // the stream's last, partial frame: nothing follows
     }
     if (f0 + seg_frames < ((int64_t)total_samples + 31) / 32) atomicMin(&first_open[ch], k);   // open, and a piece follows
@@ -783,7 +783,8 @@ __device__ __forceinline__ void adx_encode_frame_serial(const int (&x)[32], int 
 template <bool V4, bool EXPONENTIAL>
 __global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, AdxDeviceParams p,
-    uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state, int *__restrict__ first_open)
+    uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state, int *__restrict__ first_open,
+    int force_open)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     const int k = blockIdx.y + 1;
@@ -814,7 +815,7 @@ __global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
             sb = clamp16(v);
         }
         adx_encode_frame_serial<V4, EXPONENTIAL>(x, ta, tb, c0, c1, filter_bits, fr);
-        if (ta == sa && tb == sb) return;              // closed: the rest of the piece stands
+        if (ta == sa && tb == sb && !force_open) return;   // closed: the rest of the piece stands
     }
     atomicMin(&first_open[ch], k);
 }
@@ -891,7 +892,7 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
             if (segments > 1) {                                                                                          \
                 hipLaunchKernelGGL((adx_encode_fs18_fixup_kernel<V, E>), dim3(groups64, segments - 1), dim3(64), 0, stream, \
                                    d_pcm, pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, seg_state,       \
-                                   first_open);                                                                          \
+                                   first_open, force_open_seams() ? 1 : 0);                                              \
                 hipLaunchKernelGGL((adx_encode_fs18_tail_kernel<V, E>), dim3(groups64), dim3(64), 0, stream, d_pcm,     \
                                    pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, seg_state, first_open); \
             }                                                                                                            \
@@ -953,7 +954,8 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
                                in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status);                  \
             if (segments > 1) {                                                                                          \
                 hipLaunchKernelGGL(adx_decode_fs18_fixup_kernel<V>, dim3(groups, segments - 1), dim3(64), 0, stream,    \
-                                   d_adpcm, in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, first_open);  \
+                                   d_adpcm, in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, first_open,   \
+                                   force_open_seams() ? 1 : 0);                                                          \
                 hipLaunchKernelGGL(adx_decode_fs18_tail_kernel<V>, dim3(groups), dim3(64), 0, stream, d_adpcm, in_pitch, \
                                    nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, first_open);                      \
             }                                                                                                            \

@@ -1,6 +1,8 @@
 // capi_gcadpcm.hip -- C-ABI entry points for GC-ADPCM (see include/vgaudio_hip.h).
 #include "common.hpp"
 
+#include <atomic>
+
 #include <algorithm>
 #include "gcadpcm_kernels.hpp"
 
@@ -17,6 +19,9 @@ void set_error(const char *fmt, ...)
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
 }
+
+static std::atomic<int> g_force_open_seams{0};
+bool force_open_seams() { return g_force_open_seams.load(std::memory_order_relaxed) != 0; }
 
 int require_device()
 {
@@ -41,6 +46,11 @@ using namespace vga;
 extern "C" {
 
 const char *vga_last_error(void) { return g_err; }
+
+int vga_debug_force_open_seams(int enable)
+{
+    return g_force_open_seams.exchange(enable ? 1 : 0);
+}
 const char *vga_version(void) { return "vgaudio_hip 0.1 (gfx950)"; }
 
 int vga_device_count(void)

@@ -61,4 +61,8 @@ __device__ __forceinline__ void lds_barrier()
 // fails loudly when no gfx950 device is present: there is no CPU fallback.
 int require_device();
 
+// test hook (vga_debug_force_open_seams): the seam kernels of the time-segmented codecs then never accept a seam as
+// closed, so that their fall-back (re-computing the rest of the channel serially) is what produces the output
+bool force_open_seams();
+
 }  // namespace vga

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(DTHREADS) void gc_decode_kernel(
 // decoder would have.  If they never coincide the whole segment is redone here: always exact, just slow.
 __global__ __launch_bounds__(64) void gc_decode_fixup_kernel(
     const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
-    int total_samples, int seg_frames, int segments, int16_t *__restrict__ pcm, int64_t pcm_pitch)
+    int total_samples, int seg_frames, int segments, int16_t *__restrict__ pcm, int64_t pcm_pitch, int force_open)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= nch) return;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64) void gc_decode_fixup_kernel(
                 h1 = v;
                 o[s] = (int16_t)v;
             }
-            if (valid == 14 && h1 == g1 && h2 == g2) break;
+            if (valid == 14 && h1 == g1 && h2 == g2 && !force_open) break;
         }
     }
 }
@@ -293,7 +293,7 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
     VGA_HIP_TRY(hipGetLastError());
     if (segments > 1) {
         hipLaunchKernelGGL(gc_decode_fixup_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
-                           sample_count, seg_frames, segments, d_pcm, pcm_pitch);
+                           sample_count, seg_frames, segments, d_pcm, pcm_pitch, force_open_seams() ? 1 : 0);
         VGA_HIP_TRY(hipGetLastError());
     }
     return VGA_OK;
