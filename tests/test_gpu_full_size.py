@@ -141,6 +141,7 @@ def test_time_segment_fallbacks_are_exact():
     status = torch.zeros(1, dtype=torch.int32, device=d)
 
     def run():
+        enc = vdev.gc_encode(pcm, n, coefs)
         dec, _ = vdev.gc_decode(adpcm, coefs, n)
         adx = torch.zeros((nch, pitch), dtype=torch.uint8, device=d)
         hist = torch.zeros(nch, dtype=torch.int16, device=d)
@@ -150,7 +151,7 @@ def test_time_segment_fallbacks_are_exact():
         _lib.check(L.vga_adx_decode_device(adx.data_ptr(), pitch, nb, nch, n, C.byref(p), back.data_ptr(), back.stride(0),
                                            status.data_ptr(), st))
         torch.cuda.synchronize()
-        return dec[:, :n].clone(), adx[:, :nb].clone(), back[:, :n].clone()
+        return dec[:, :n].clone(), adx[:, :nb].clone(), back[:, :n].clone(), enc[:, :vdev.gc_byte_count(n)].clone()
 
     normal = run()
     old = L.vga_debug_force_open_seams(1)
@@ -163,6 +164,7 @@ def test_time_segment_fallbacks_are_exact():
     # and both equal the oracle on a few channels
     for c in (0, 64, 129):
         host = pcm[c, :n].cpu().numpy()
+        assert (normal[3][c].cpu().numpy() == po.gc_encode(host, coefs[c].cpu().numpy())).all()
         assert (normal[0][c].cpu().numpy() == po.gc_decode(adpcm[c, :vdev.gc_byte_count(n)].cpu().numpy(),
                                                             coefs[c].cpu().numpy(), n)).all()
         op = po.adx_params()

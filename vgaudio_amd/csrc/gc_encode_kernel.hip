@@ -172,11 +172,39 @@ ColdOut encode_frame_cold(ColdState st, PassOut r, int final_sp, int fin)
     return o;
 }
 
+// Time segments (blockIdx.y): with fewer channels than fill the chip, a channel's stream is cut into
+// pieces of `seg_frames` frames encoded side by side.  Piece 0 starts from the caller's history, the others from a
+// guess -- the two INPUT samples before the piece -- and gc_encode_seam_kernel closes the seams afterwards.
+// seg_state[piece][channel] receives every piece's final history.  At BASELINE configs[1] there is one piece.
 __global__ __launch_bounds__(128) void gc_encode_kernel(
-    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int sample_count,
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, int seg_frames,
     const int16_t *__restrict__ coefs, const int16_t *__restrict__ hist1,
-    const int16_t *__restrict__ hist2, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch)
+    const int16_t *__restrict__ hist2, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, int16_t *__restrict__ seg_state,
+    const int *__restrict__ first_open)
 {
+    // Repair launch (first_open != nullptr, one workgroup row): channels with a seam that would not close are encoded
+    // again, serially, from the earliest such seam among the workgroup's four channels to the end of the stream --
+    // starting from seg_state of the piece before, which is the real history for all four (every seam before it
+    // closed).  Workgroups without such a channel leave at once.
+    const bool repair = first_open != nullptr;
+    int64_t first_frame = (int64_t)blockIdx.y * seg_frames;
+    int repair_piece = 0;
+    if (repair) {
+        int k = 0x7f000000;
+        for (int g = 0; g < 4; g++) {
+            const int c = blockIdx.x * 4 + g;
+            if (c < nch) k = first_open[c] < k ? first_open[c] : k;
+        }
+        if (k <= 0 || k >= 0x7f000000) return;
+        repair_piece = k;
+        first_frame = (int64_t)k * seg_frames;
+    }
+    if (first_frame * 14 >= total_samples) return;
+    const int64_t piece_samples = repair ? (int64_t)total_samples : (int64_t)seg_frames * 14;
+    const int sample_count = (int)((int64_t)total_samples - first_frame * 14 < piece_samples
+                                       ? (int64_t)total_samples - first_frame * 14 : piece_samples);
+    pcm += first_frame * 14;
+    adpcm += first_frame * 8;
     __shared__ GcTile s_tile[2];
     // the winner's frame, unpacked: q[0..13], predictor, scale; the helper packs it (pack_frame) when it flushes
     __shared__ int4 s_out[2][4][TF][4];
@@ -301,6 +329,13 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
     const bool coef_ok = (c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1) <= 32767;   // predictor cannot wrap int32
     int h0 = hist2 ? hist2[ch] : 0;   // pcmBuffer[0] = History2 (GcAdpcmEncoder.cs:24)
     int h1 = hist1 ? hist1[ch] : 0;   // pcmBuffer[1] = History1 (:25)
+    if (repair) {
+        h0 = seg_state[((int64_t)(repair_piece - 1) * nch + ch) * 2];
+        h1 = seg_state[((int64_t)(repair_piece - 1) * nch + ch) * 2 + 1];
+    } else if (blockIdx.y > 0) {                       // a later piece: the guess
+        h0 = src[-2];
+        h1 = src[-1];
+    }
     VGA_OPAQUE(h0);
     VGA_OPAQUE(h1);
 
@@ -491,6 +526,86 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
 #endif
         __syncthreads();                               // tile done: helper may flush it and refill this buffer later
     }
+    if (seg_state && !repair && live && l16 == 0) {
+        int16_t *st = seg_state + ((int64_t)blockIdx.y * nch + ch) * 2;
+        st[0] = (int16_t)h0;
+        st[1] = (int16_t)h1;
+    }
+}
+
+// ---------------------------------------------------------------- seams of the time segments
+// DspEncodeFrame (:48-94) for one frame on ONE lane, the reference's loops as written (gc_encode_core.hpp):
+// x[0], x[1] = history, x[2..15] = the frame's samples (zero padded); returns the packed frame and moves the history on.
+__device__ __noinline__ void encode_frame_serial(int (&x)[16], const int16_t *__restrict__ cf, uint32_t &d0, uint32_t &d1)
+{
+    PassOut best;
+    int best_p = 0, best_sp = 0;
+    for (int pr = 0; pr < 8; pr++) {
+        const int c0 = cf[2 * pr], c1 = cf[2 * pr + 1];
+        const int s1 = first_scale_power_from_md(prescan_sequential(x, c0, c1));
+        int final_sp;
+        const PassOut r = resume_passes(x, c0, c1, s1 - 1, final_sp);
+        if (pr == 0 || r.total < best.total) { best = r; best_p = pr; best_sp = final_sp; }   // strict <, first wins (:66-76)
+    }
+    pack_frame(best.q, best_p, best_sp, d0, d1);
+    x[0] = best.o12;                                   // :40-41
+    x[1] = best.o13;
+}
+
+__device__ __forceinline__ void store_frame_bytes(uint8_t *dst, uint32_t d0, uint32_t d1, int nbytes)
+{
+    const uint64_t bits = ((uint64_t)d1 << 32) | d0;
+    for (int b = 0; b < nbytes; b++) dst[b] = (uint8_t)(bits >> (8 * b));
+}
+
+// One lane per (channel, seam), all seams at once.  From the history the piece before ended on (seg_state: the real one
+// provided THAT piece's own seam closes) encode again frame by frame, next to a replay of the guessed run's
+// reconstruction (decoding that run's frames from the guess, before they are overwritten), until both histories
+// coincide at a frame end: from there on the guessed run wrote what the serial encoder writes.  A seam still open
+// after max_frames records its index in first_open[channel] for the repair launch of gc_encode_kernel.
+__global__ __launch_bounds__(64) void gc_encode_seam_kernel(
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, int seg_frames,
+    const int16_t *__restrict__ coefs, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch,
+    const int16_t *__restrict__ seg_state, int *__restrict__ first_open, int max_frames, int force_open)
+{
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    const int k = blockIdx.y + 1;
+    const int64_t f0 = (int64_t)k * seg_frames;
+    if (ch >= nch || f0 * 14 >= total_samples) return;
+    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
+    uint8_t *dst = adpcm + (int64_t)ch * adpcm_pitch;
+    const int16_t *cf = coefs + ch * 16;
+    const int full_frames = total_samples / 14;
+    int x[16];
+    x[0] = seg_state[((int64_t)(k - 1) * nch + ch) * 2];
+    x[1] = seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1];
+    int g2 = src[f0 * 14 - 2], g1 = src[f0 * 14 - 1];                 // the guessed run's history (g1 = newest)
+    for (int64_t f = f0; f < f0 + seg_frames && f < f0 + max_frames && f < full_frames; f++) {
+        const uint8_t *old = dst + f * 8;
+        // the guessed run's reconstruction of this frame (GcAdpcmDecoder.cs:25-45)
+        {
+            const int ps = old[0];
+            const int scale = (1 << (ps & 0xF)) * 2048;
+            const int c1 = cf[((ps >> 4) & 7) * 2], c2 = cf[((ps >> 4) & 7) * 2 + 1];
+            for (int s = 0; s < 14; s++) {
+                const int byte = old[1 + (s >> 1)];
+                const int nib = (s & 1) ? (byte & 0xF) : (byte >> 4);
+                const int v = clamp16i((c1 * g1 + c2 * g2 + scale * ((nib ^ 8) - 8) + 1024) >> 11);
+                g2 = g1;
+                g1 = v;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 14; s++) x[2 + s] = src[f * 14 + s];
+        uint32_t d0, d1;
+        encode_frame_serial(x, cf, d0, d1);
+        store_frame_bytes(dst + f * 8, d0, d1, 8);
+        if (x[0] == g2 && x[1] == g1 && !force_open) return;          // closed
+    }
+    // still open after max_frames (the launcher passes the piece length: half the seams close within nine frames, one in
+    // a hundred needs more than 400, a few channels never meet): the repair launch encodes this channel serially from
+    // this piece on.  A smaller cap sends too many channels there -- one open seam makes the whole channel serial.
+    atomicMin(&first_open[ch], k);
 }
 
 int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
@@ -498,9 +613,43 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_c
                   hipStream_t stream)
 {
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
-    hipLaunchKernelGGL(gc_encode_kernel, dim3((nch + 3) / 4), dim3(128), 0, stream, d_pcm, pcm_pitch, nch,
-                       sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch);
+    // one encoder wave per SIMD fills the chip (4 channels each): fewer channels than that are cut into time pieces
+    // (each at least 512 frames: a seam re-encodes a few dozen)
+    const int groups = (nch + 3) / 4;
+    int cus = 256;
+    {
+        int device = 0;
+        if (hipGetDevice(&device) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    }
+    const int frames = (sample_count + 13) / 14;
+    int segments = cus * 4 / groups;
+    if (segments > frames / 512) segments = frames / 512;
+    if (segments < 1) segments = 1;
+    if (segments > 1024) segments = 1024;
+    const int seg_frames = (frames + segments - 1) / segments;
+    int16_t *seg_state = nullptr;
+    int *first_open = nullptr;
+    if (segments > 1) {
+        const size_t state_bytes = (size_t)round_up((int64_t)segments * nch * 2 * (int64_t)sizeof(int16_t), 16);
+        VGA_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&seg_state), state_bytes + (size_t)nch * sizeof(int), stream));
+        first_open = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(seg_state) + state_bytes);
+        VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
+    }
+    hipLaunchKernelGGL(gc_encode_kernel, dim3(groups, segments), dim3(128), 0, stream, d_pcm, pcm_pitch, nch,
+                       sample_count, seg_frames, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state,
+                       (const int *)nullptr);
     VGA_HIP_TRY(hipGetLastError());
+    if (segments > 1) {
+        const int groups64 = (nch + 63) / 64;
+        hipLaunchKernelGGL(gc_encode_seam_kernel, dim3(groups64, segments - 1), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
+                           sample_count, seg_frames, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seg_frames,
+                           force_open_seams() ? 1 : 0);
+        // repair: the same encoder, serially, for the channels whose seams stayed open (none: every workgroup returns)
+        hipLaunchKernelGGL(gc_encode_kernel, dim3(groups, 1), dim3(128), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
+                           seg_frames, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state, (const int *)first_open);
+        VGA_HIP_TRY(hipGetLastError());
+        VGA_HIP_TRY(hipFreeAsync(seg_state, stream));
+    }
     return VGA_OK;
 }
 
