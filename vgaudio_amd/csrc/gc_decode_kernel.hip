@@ -215,50 +215,81 @@ __global__ __launch_bounds__(DTHREADS) void gc_decode_kernel(
     }
 }
 
-// Closes the seams between time segments, one lane per channel.  For each segment after the first: decode again from
-// the true history (the two samples before it, final by now) frame by frame, overwriting the guessed run's samples,
-// until the two histories at a frame end coincide -- from there on the guessed run decoded exactly what the serial
-// decoder would have.  If they never coincide the whole segment is redone here: always exact, just slow.
+// One frame of GcAdpcmDecoder.Decode (:25-45) from the history (h1, h2) into o[0 .. valid).
+__device__ __forceinline__ void gc_decode_frame_serial(const uint8_t *fr, const int (&cf)[16], int valid, int &h1, int &h2,
+                                                       int16_t *o)
+{
+    const int ps = fr[0];
+    const int scale = (1 << (ps & 0xF)) * 2048;
+    const int predictor = (ps >> 4) & 7;
+    int c1 = 0, c2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (predictor == i) { c1 = cf[2 * i]; c2 = cf[2 * i + 1]; }
+    for (int s = 0; s < valid; s++) {
+        const int byte = fr[1 + (s >> 1)];
+        const int nib = (s & 1) ? (byte & 0xF) : (byte >> 4);
+        const int v = imin(imax((c1 * h1 + c2 * h2 + scale * ((nib ^ 8) - 8) + 1024) >> 11, -32768), 32767);
+        h2 = h1;
+        h1 = v;
+        o[s] = (int16_t)v;
+    }
+}
+
+// Closes the seams between time segments: one lane per (channel, seam), all seams at once.  From the history the piece
+// before ended on (its last two samples: final provided THAT piece's own seam closes) decode again frame by frame over
+// the guessed run's samples until both histories coincide at a frame end -- from there on the guessed run decoded
+// exactly what the serial decoder would have.  A seam that does not close inside its piece records its index in
+// first_open[channel]; gc_decode_tail_kernel then decodes that channel serially from the next piece on.  Always exact.
 __global__ __launch_bounds__(64) void gc_decode_fixup_kernel(
     const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
-    int total_samples, int seg_frames, int segments, int16_t *__restrict__ pcm, int64_t pcm_pitch, int force_open)
+    int total_samples, int seg_frames, int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ first_open,
+    int force_open)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= nch) return;
+    const int k = blockIdx.y + 1;
+    const int64_t f0 = (int64_t)k * seg_frames;
+    if (ch >= nch || f0 * 14 >= total_samples) return;
     const uint8_t *src = adpcm + (int64_t)ch * adpcm_pitch;
     int16_t *dst = pcm + (int64_t)ch * pcm_pitch;
     int cf[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) cf[i] = coefs[ch * 16 + i];
     const int full_frames = total_samples / 14;
-    for (int k = 1; k < segments; k++) {
-        const int64_t f0 = (int64_t)k * seg_frames;
-        if (f0 * 14 >= total_samples) break;
-        int h1 = dst[f0 * 14 - 1], h2 = dst[f0 * 14 - 2];
-        const int64_t f_end = f0 + seg_frames;
-        for (int64_t f = f0; f < f_end && f * 14 < total_samples; f++) {
-            const int valid = f < full_frames ? 14 : total_samples - (int)(f * 14);
-            const uint8_t *fr = src + f * 8;
-            const int ps = fr[0];
-            const int scale = (1 << (ps & 0xF)) * 2048;
-            const int predictor = (ps >> 4) & 7;
-            int c1 = 0, c2 = 0;
+    int h1 = dst[f0 * 14 - 1], h2 = dst[f0 * 14 - 2];
+    for (int64_t f = f0; f < f0 + seg_frames && f * 14 < total_samples; f++) {
+        const int valid = f < full_frames ? 14 : total_samples - (int)(f * 14);
+        int16_t *o = dst + f * 14;
+        int g1 = 0, g2 = 0;                            // the guessed run's history at this frame's end
+        if (valid == 14) { g1 = o[13]; g2 = o[12]; }
+        gc_decode_frame_serial(src + f * 8, cf, valid, h1, h2, o);
+        if (valid == 14 && h1 == g1 && h2 == g2 && !force_open) return;
+        if (valid < 14) return;                        // the stream's last, partial frame: nothing follows
+    }
+    if ((f0 + seg_frames) * 14 < total_samples) atomicMin(&first_open[ch], k);   // open, and a piece follows
+}
+
+// Channels with an open seam (practically none): seam k re-decoded all of piece k, so that piece is final; everything
+// after it was seeded from samples that have changed since and is decoded again here, serially.
+__global__ __launch_bounds__(64) void gc_decode_tail_kernel(
+    const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
+    int total_samples, int seg_frames, int16_t *__restrict__ pcm, int64_t pcm_pitch, const int *__restrict__ first_open)
+{
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= nch) return;
+    const int k = first_open[ch];
+    if (k <= 0 || k >= 0x7f000000) return;
+    const uint8_t *src = adpcm + (int64_t)ch * adpcm_pitch;
+    int16_t *dst = pcm + (int64_t)ch * pcm_pitch;
+    int cf[16];
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (predictor == i) { c1 = cf[2 * i]; c2 = cf[2 * i + 1]; }
-            int16_t *o = dst + f * 14;
-            int g1 = 0, g2 = 0;                        // the guessed run's history at this frame's end
-            if (valid == 14) { g1 = o[13]; g2 = o[12]; }
-            for (int s = 0; s < valid; s++) {
-                const int byte = fr[1 + (s >> 1)];
-                const int nib = (s & 1) ? (byte & 0xF) : (byte >> 4);
-                const int v = imin(imax((c1 * h1 + c2 * h2 + scale * ((nib ^ 8) - 8) + 1024) >> 11, -32768), 32767);
-                h2 = h1;
-                h1 = v;
-                o[s] = (int16_t)v;
-            }
-            if (valid == 14 && h1 == g1 && h2 == g2 && !force_open) break;
-        }
+    for (int i = 0; i < 16; i++) cf[i] = coefs[ch * 16 + i];
+    const int full_frames = total_samples / 14;
+    const int64_t f0 = (int64_t)(k + 1) * seg_frames;
+    int h1 = dst[f0 * 14 - 1], h2 = dst[f0 * 14 - 2];
+    for (int64_t f = f0; f * 14 < total_samples; f++) {
+        const int valid = f < full_frames ? 14 : total_samples - (int)(f * 14);
+        gc_decode_frame_serial(src + f * 8, cf, valid, h1, h2, dst + f * 14);
     }
 }
 
@@ -292,9 +323,15 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
                        sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
     VGA_HIP_TRY(hipGetLastError());
     if (segments > 1) {
-        hipLaunchKernelGGL(gc_decode_fixup_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
-                           sample_count, seg_frames, segments, d_pcm, pcm_pitch, force_open_seams() ? 1 : 0);
+        int *first_open = nullptr;
+        VGA_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&first_open), (size_t)nch * sizeof(int), stream));
+        VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
+        hipLaunchKernelGGL(gc_decode_fixup_kernel, dim3((nch + 63) / 64, segments - 1), dim3(64), 0, stream, d_adpcm, adpcm_pitch,
+                           d_coefs, nch, sample_count, seg_frames, d_pcm, pcm_pitch, first_open, force_open_seams() ? 1 : 0);
+        hipLaunchKernelGGL(gc_decode_tail_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
+                           sample_count, seg_frames, d_pcm, pcm_pitch, first_open);
         VGA_HIP_TRY(hipGetLastError());
+        VGA_HIP_TRY(hipFreeAsync(first_open, stream));
     }
     return VGA_OK;
 }
