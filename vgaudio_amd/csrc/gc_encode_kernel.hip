@@ -52,7 +52,7 @@ __device__ __forceinline__ unsigned row16_reduce(unsigned v, Op op)
 
 
 // =====================================================================================================
-// gc_encode_kernel -- serial wave + helper wave per workgroup (128 threads, 4 channels).
+// gc_encode_kernel -- SW encoder (serial) waves + one helper wave per workgroup (4 channels per encoder wave).
 // Everything that does not depend on the reconstructed history is taken off the serial wave:
 //   helper wave (wave 1), one 16-frame tile AHEAD of the encoder:
 //     * coalesced global loads of the tile (lane = frame j of channel g: 28 contiguous bytes),
@@ -68,15 +68,18 @@ __device__ __forceinline__ unsigned row16_reduce(unsigned v, Op op)
 // compiling the rare paths inline cost 80 ms of 257 ms (code size, register pressure, branches).
 // The SIMDs have idle issue slots next to a lone latency-bound wave (tools/ubench_valu.hip: two waves
 // per SIMD do not slow each other's dependent chains), so the helper costs the encoder nothing.
-#ifndef VGA_ENC_TILE
-#define VGA_ENC_TILE 16
+#ifndef VGA_ENC_SW
+#define VGA_ENC_SW 2               // measured at configs[1]: 1 -> 209.5 ms, 2 -> 200.1 ms (two pieces per channel)
 #endif
-constexpr int TF = VGA_ENC_TILE;   // frames per tile (<= 16: one helper lane per frame and channel)
+constexpr int SW = VGA_ENC_SW;     // encoder (serial) waves per workgroup, 4 channels each; one helper wave serves them all
+constexpr int CS = 4 * SW;         // channel slots per workgroup
+constexpr int TF = 64 / CS;        // frames per tile: one helper lane per (channel slot, frame)
+constexpr int ENC_THREADS = 64 * (SW + 1);
 struct GcTile {
-    int x[4][TF][16];          // [channel group][frame][sample]  (14 used)
-    int in2048[4][TF][16];     // x * 2048
-    int in2048p[4][TF][16];    // x * 2048 + 1024
-    uint32_t pre[4][TF][8];    // per predictor: clamp16(max d) & 0xFFFF | clamp16(min d) << 16, over s = 2..13
+    int x[CS][TF][16];         // [channel slot][frame][sample]  (14 used)
+    int in2048[CS][TF][16];    // x * 2048
+    int in2048p[CS][TF][16];   // x * 2048 + 1024
+    uint32_t pre[CS][TF][8];   // per predictor: clamp16(max d) & 0xFFFF | clamp16(min d) << 16, over s = 2..13
 };
 #ifdef VGA_ENC_MARKS   // analysis builds: region markers in the assembly listing
 #define VGA_MARK(name) asm volatile("; MARK " name)
@@ -176,7 +179,11 @@ ColdOut encode_frame_cold(ColdState st, PassOut r, int final_sp, int fin)
 // pieces of `seg_frames` frames encoded side by side.  Piece 0 starts from the caller's history, the others from a
 // guess -- the two INPUT samples before the piece -- and gc_encode_seam_kernel closes the seams afterwards.
 // seg_state[piece][channel] receives every piece's final history.  At BASELINE configs[1] there is one piece.
-__global__ __launch_bounds__(128) void gc_encode_kernel(
+#if VGA_ENC_SW > 1
+__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void gc_encode_kernel(
+#else
+__global__ __launch_bounds__(ENC_THREADS) void gc_encode_kernel(
+#endif
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, int seg_frames,
     const int16_t *__restrict__ coefs, const int16_t *__restrict__ hist1,
     const int16_t *__restrict__ hist2, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, int16_t *__restrict__ seg_state,
@@ -191,8 +198,8 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
     int repair_piece = 0;
     if (repair) {
         int k = 0x7f000000;
-        for (int g = 0; g < 4; g++) {
-            const int c = blockIdx.x * 4 + g;
+        for (int g = 0; g < CS; g++) {
+            const int c = blockIdx.x * CS + g;
             if (c < nch) k = first_open[c] < k ? first_open[c] : k;
         }
         if (k <= 0 || k >= 0x7f000000) return;
@@ -207,13 +214,16 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
     adpcm += first_frame * 8;
     __shared__ GcTile s_tile[2];
     // the winner's frame, unpacked: q[0..13], predictor, scale; the helper packs it (pack_frame) when it flushes
-    __shared__ int4 s_out[2][4][TF][4];
+    __shared__ int4 s_out[2][CS][TF][4];
     const int tid = threadIdx.x;
-    const bool helper = tid >= 64;
+    const int wave = tid >> 6;
+    const bool helper = wave == SW;
     const int lane = tid & 63;
-    const int grp = lane >> 4;
+    // encoder wave: 4 channels x (8 predictors x 2 candidates); helper wave: CS channel slots x TF frames
+    const int grp = helper ? lane / TF : wave * 4 + (lane >> 4);   // channel slot of this lane
     const int l16 = lane & 15;
-    const int ch_raw = blockIdx.x * 4 + grp;
+    const int hfr = lane % TF;                         // helper lanes: the frame inside the tile
+    const int ch_raw = blockIdx.x * CS + grp;
     const bool live = ch_raw < nch;
     const int ch = live ? ch_raw : nch - 1;
     const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
@@ -231,8 +241,7 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
         for (int p = 0; p < 8; p++)
             cpk[p] = (uint32_t)(uint16_t)coefs[ch * 16 + 2 * p + 1] | ((uint32_t)(uint16_t)coefs[ch * 16 + 2 * p] << 16);
         auto prepare = [&](int tile) {
-            if (l16 >= TF) return;
-            const int fr = imin(tile * TF + l16, frames - 1);
+            const int fr = imin(tile * TF + hfr, frames - 1);
             int in[14];
             uint32_t w[7];                             // the frame as packed pairs (in[2i], in[2i+1])
             if (fr < full_frames) {
@@ -251,8 +260,8 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
                 for (int i = 0; i < 7; i++) w[i] = (uint32_t)(in[2 * i] & 0xFFFF) | ((uint32_t)in[2 * i + 1] << 16);
             }
             GcTile &T = s_tile[tile & 1];
-            int4 *xr = reinterpret_cast<int4 *>(&T.x[grp][l16][0]);
-            int4 *mr = reinterpret_cast<int4 *>(&T.in2048[grp][l16][0]);
+            int4 *xr = reinterpret_cast<int4 *>(&T.x[grp][hfr][0]);
+            int4 *mr = reinterpret_cast<int4 *>(&T.in2048[grp][hfr][0]);
             xr[0] = make_int4(in[0], in[1], in[2], in[3]);
             xr[1] = make_int4(in[4], in[5], in[6], in[7]);
             xr[2] = make_int4(in[8], in[9], in[10], in[11]);
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
             mr[1] = make_int4(in[4] * 2048, in[5] * 2048, in[6] * 2048, in[7] * 2048);
             mr[2] = make_int4(in[8] * 2048, in[9] * 2048, in[10] * 2048, in[11] * 2048);
             mr[3] = make_int4(in[12] * 2048, in[13] * 2048, 0, 0);
-            int4 *qr = reinterpret_cast<int4 *>(&T.in2048p[grp][l16][0]);
+            int4 *qr = reinterpret_cast<int4 *>(&T.in2048p[grp][hfr][0]);
             qr[0] = make_int4(in[0] * 2048 + 1024, in[1] * 2048 + 1024, in[2] * 2048 + 1024, in[3] * 2048 + 1024);
             qr[1] = make_int4(in[4] * 2048 + 1024, in[5] * 2048 + 1024, in[6] * 2048 + 1024, in[7] * 2048 + 1024);
             qr[2] = make_int4(in[8] * 2048 + 1024, in[9] * 2048 + 1024, in[10] * 2048 + 1024, in[11] * 2048 + 1024);
@@ -288,14 +297,14 @@ __global__ __launch_bounds__(128) void gc_encode_kernel(
                 }
                 pre[p] = (uint32_t)(clamp16i(dmax) & 0xFFFF) | ((uint32_t)clamp16i(dmin) << 16);
             }
-            uint4 *pr = reinterpret_cast<uint4 *>(&T.pre[grp][l16][0]);
+            uint4 *pr = reinterpret_cast<uint4 *>(&T.pre[grp][hfr][0]);
             pr[0] = make_uint4(pre[0], pre[1], pre[2], pre[3]);
             pr[1] = make_uint4(pre[4], pre[5], pre[6], pre[7]);
         };
         auto flush = [&](int tile) {
-            const int fr = tile * TF + l16;
-            if (!live || l16 >= TF || fr >= frames) return;
-            const int4 *rec = &s_out[tile & 1][grp][l16][0];
+            const int fr = tile * TF + hfr;
+            if (!live || fr >= frames) return;
+            const int4 *rec = &s_out[tile & 1][grp][hfr][0];
             const int4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
             const int q[14] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y};
             uint2 v;
@@ -615,14 +624,14 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_c
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
     // one encoder wave per SIMD fills the chip (4 channels each): fewer channels than that are cut into time pieces
     // (each at least 512 frames: a seam re-encodes a few dozen)
-    const int groups = (nch + 3) / 4;
+    const int groups = (nch + CS - 1) / CS;
     int cus = 256;
     {
         int device = 0;
         if (hipGetDevice(&device) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     }
     const int frames = (sample_count + 13) / 14;
-    int segments = cus * 4 / groups;
+    int segments = cus * 4 / groups;                   // = SW encoder waves on every SIMD
     if (segments > frames / 512) segments = frames / 512;
     if (segments < 1) segments = 1;
     if (segments > 1024) segments = 1024;
@@ -635,7 +644,7 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_c
         first_open = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(seg_state) + state_bytes);
         VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
     }
-    hipLaunchKernelGGL(gc_encode_kernel, dim3(groups, segments), dim3(128), 0, stream, d_pcm, pcm_pitch, nch,
+    hipLaunchKernelGGL(gc_encode_kernel, dim3(groups, segments), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch,
                        sample_count, seg_frames, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state,
                        (const int *)nullptr);
     VGA_HIP_TRY(hipGetLastError());
@@ -645,7 +654,7 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_c
                            sample_count, seg_frames, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seg_frames,
                            force_open_seams() ? 1 : 0);
         // repair: the same encoder, serially, for the channels whose seams stayed open (none: every workgroup returns)
-        hipLaunchKernelGGL(gc_encode_kernel, dim3(groups, 1), dim3(128), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
+        hipLaunchKernelGGL(gc_encode_kernel, dim3(groups, 1), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
                            seg_frames, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state, (const int *)first_open);
         VGA_HIP_TRY(hipGetLastError());
         VGA_HIP_TRY(hipFreeAsync(seg_state, stream));
