@@ -543,78 +543,97 @@ __global__ __launch_bounds__(ENC_THREADS) void gc_encode_kernel(
 }
 
 // ---------------------------------------------------------------- seams of the time segments
-// DspEncodeFrame (:48-94) for one frame on ONE lane, the reference's loops as written (gc_encode_core.hpp):
-// x[0], x[1] = history, x[2..15] = the frame's samples (zero padded); returns the packed frame and moves the history on.
-__device__ __noinline__ void encode_frame_serial(int (&x)[16], const int16_t *__restrict__ cf, uint32_t &d0, uint32_t &d1)
-{
-    PassOut best;
-    int best_p = 0, best_sp = 0;
-    for (int pr = 0; pr < 8; pr++) {
-        const int c0 = cf[2 * pr], c1 = cf[2 * pr + 1];
-        const int s1 = first_scale_power_from_md(prescan_sequential(x, c0, c1));
-        int final_sp;
-        const PassOut r = resume_passes(x, c0, c1, s1 - 1, final_sp);
-        if (pr == 0 || r.total < best.total) { best = r; best_p = pr; best_sp = final_sp; }   // strict <, first wins (:66-76)
-    }
-    pack_frame(best.q, best_p, best_sp, d0, d1);
-    x[0] = best.o12;                                   // :40-41
-    x[1] = best.o13;
-}
-
 __device__ __forceinline__ void store_frame_bytes(uint8_t *dst, uint32_t d0, uint32_t d1, int nbytes)
 {
     const uint64_t bits = ((uint64_t)d1 << 32) | d0;
     for (int b = 0; b < nbytes; b++) dst[b] = (uint8_t)(bits >> (8 * b));
 }
 
-// One lane per (channel, seam), all seams at once.  From the history the piece before ended on (seg_state: the real one
-// provided THAT piece's own seam closes) encode again frame by frame, next to a replay of the guessed run's
-// reconstruction (decoding that run's frames from the guess, before they are overwritten), until both histories
-// coincide at a frame end: from there on the guessed run wrote what the serial encoder writes.  A seam still open
-// after max_frames records its index in first_open[channel] for the repair launch of gc_encode_kernel.
+// Eight lanes per (channel, seam) -- one per predictor, as DspEncodeFrame's loop (:58-77) -- all seams at once.  From the
+// history the piece before ended on (seg_state: the real one provided THAT piece's own seam closes) encode again frame
+// by frame, next to a replay of the guessed run's reconstruction (decoding that run's frames from the guess, before
+// they are overwritten), until both histories coincide at a frame end: from there on the guessed run wrote what the
+// serial encoder writes.  A seam still open after max_frames records its index in first_open[channel] for the repair
+// launch of gc_encode_kernel.
 __global__ __launch_bounds__(64) void gc_encode_seam_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, int seg_frames,
     const int16_t *__restrict__ coefs, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch,
     const int16_t *__restrict__ seg_state, int *__restrict__ first_open, int max_frames, int force_open)
 {
-    const int ch = blockIdx.x * 64 + threadIdx.x;
+    const int lane = threadIdx.x;
+    const int pr = lane & 7;                            // this lane's predictor
+    const int ch_raw = blockIdx.x * 8 + (lane >> 3);
     const int k = blockIdx.y + 1;
     const int64_t f0 = (int64_t)k * seg_frames;
-    if (ch >= nch || f0 * 14 >= total_samples) return;
+    const bool valid = ch_raw < nch && f0 * 14 < total_samples;
+    const int ch = ch_raw < nch ? ch_raw : nch - 1;
     const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
     uint8_t *dst = adpcm + (int64_t)ch * adpcm_pitch;
     const int16_t *cf = coefs + ch * 16;
+    const int c0 = cf[2 * pr], c1 = cf[2 * pr + 1];
     const int full_frames = total_samples / 14;
     int x[16];
-    x[0] = seg_state[((int64_t)(k - 1) * nch + ch) * 2];
-    x[1] = seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1];
-    int g2 = src[f0 * 14 - 2], g1 = src[f0 * 14 - 1];                 // the guessed run's history (g1 = newest)
-    for (int64_t f = f0; f < f0 + seg_frames && f < f0 + max_frames && f < full_frames; f++) {
-        const uint8_t *old = dst + f * 8;
-        // the guessed run's reconstruction of this frame (GcAdpcmDecoder.cs:25-45)
-        {
-            const int ps = old[0];
-            const int scale = (1 << (ps & 0xF)) * 2048;
-            const int c1 = cf[((ps >> 4) & 7) * 2], c2 = cf[((ps >> 4) & 7) * 2 + 1];
-            for (int s = 0; s < 14; s++) {
-                const int byte = old[1 + (s >> 1)];
-                const int nib = (s & 1) ? (byte & 0xF) : (byte >> 4);
-                const int v = clamp16i((c1 * g1 + c2 * g2 + scale * ((nib ^ 8) - 8) + 1024) >> 11);
-                g2 = g1;
-                g1 = v;
+    x[0] = valid ? seg_state[((int64_t)(k - 1) * nch + ch) * 2] : 0;
+    x[1] = valid ? seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1] : 0;
+    int g2 = valid ? src[f0 * 14 - 2] : 0, g1 = valid ? src[f0 * 14 - 1] : 0;   // the guessed run's history (g1 = newest)
+    bool open = valid;                                  // uniform inside a group of eight
+    int64_t f = f0;
+    for (; ; f++) {
+        const bool in_range = f < f0 + seg_frames && f < f0 + max_frames && f < full_frames;
+        if (!__any(open && in_range)) break;
+        const bool act = open && in_range;
+        uint64_t key = ~0ull;                           // (total distance, predictor): smallest wins, first on ties
+        uint32_t d0 = 0, d1 = 0;
+        int n0 = 0, n1 = 0;
+        if (act) {
+            const uint8_t *old = dst + f * 8;
+            {                                           // the guessed run's reconstruction (GcAdpcmDecoder.cs:25-45)
+                const int ps = old[0];
+                const int scale = (1 << (ps & 0xF)) * 2048;
+                const int k1 = cf[((ps >> 4) & 7) * 2], k2 = cf[((ps >> 4) & 7) * 2 + 1];
+                for (int s2 = 0; s2 < 14; s2++) {
+                    const int byte = old[1 + (s2 >> 1)];
+                    const int nib = (s2 & 1) ? (byte & 0xF) : (byte >> 4);
+                    const int v = clamp16i((k1 * g1 + k2 * g2 + scale * ((nib ^ 8) - 8) + 1024) >> 11);
+                    g2 = g1;
+                    g1 = v;
+                }
             }
-        }
 #pragma unroll
-        for (int s = 0; s < 14; s++) x[2 + s] = src[f * 14 + s];
-        uint32_t d0, d1;
-        encode_frame_serial(x, cf, d0, d1);
-        store_frame_bytes(dst + f * 8, d0, d1, 8);
-        if (x[0] == g2 && x[1] == g1 && !force_open) return;          // closed
+            for (int s2 = 0; s2 < 14; s2++) x[2 + s2] = src[f * 14 + s2];
+            const int s1 = first_scale_power_from_md(prescan_sequential(x, c0, c1));
+            int final_sp;
+            const PassOut r = resume_passes(x, c0, c1, s1 - 1, final_sp);
+            // totals are below 2^60 (14 squares of 17-bit errors): the predictor rides in the low bits
+            key = (r.total << 3) | (uint64_t)pr;
+            pack_frame(r.q, pr, final_sp, d0, d1);
+            n0 = r.o12;
+            n1 = r.o13;
+        }
+        uint64_t best = key;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best, o, 8);
+            const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), o, 8);
+            const uint64_t other = ((uint64_t)hi << 32) | lo;
+            best = other < best ? other : best;
+        }
+        const int winner = (int)(best & 7u);
+        d0 = (uint32_t)__shfl((int)d0, winner, 8);
+        d1 = (uint32_t)__shfl((int)d1, winner, 8);
+        n0 = __shfl(n0, winner, 8);
+        n1 = __shfl(n1, winner, 8);
+        if (act) {
+            if (pr == 0) store_frame_bytes(dst + f * 8, d0, d1, 8);
+            x[0] = n0;                                  // :40-41
+            x[1] = n1;
+            if (x[0] == g2 && x[1] == g1 && !force_open) open = false;   // closed
+        }
     }
-    // still open after max_frames (the launcher passes the piece length: half the seams close within nine frames, one in
-    // a hundred needs more than 400, a few channels never meet): the repair launch encodes this channel serially from
-    // this piece on.  A smaller cap sends too many channels there -- one open seam makes the whole channel serial.
-    atomicMin(&first_open[ch], k);
+    // still open (the launcher's max_frames is the piece length: half the seams close within nine frames, one in a
+    // hundred needs more than 400, a few channels never meet): the repair launch encodes this channel serially from this
+    // piece on.  A smaller cap sends too many channels there -- one open seam makes the whole channel serial.
+    if (valid && open && pr == 0) atomicMin(&first_open[ch], k);
 }
 
 int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
@@ -649,8 +668,7 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_c
                        (const int *)nullptr);
     VGA_HIP_TRY(hipGetLastError());
     if (segments > 1) {
-        const int groups64 = (nch + 63) / 64;
-        hipLaunchKernelGGL(gc_encode_seam_kernel, dim3(groups64, segments - 1), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
+        hipLaunchKernelGGL(gc_encode_seam_kernel, dim3((nch + 7) / 8, segments - 1), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
                            sample_count, seg_frames, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seg_frames,
                            force_open_seams() ? 1 : 0);
         // repair: the same encoder, serially, for the channels whose seams stayed open (none: every workgroup returns)
