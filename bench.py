@@ -157,10 +157,10 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         # What actually binds the kernel: wave-instruction issue.  From the committed SQ
-        # counter pass (profiles/r01_d_sq_counters.json): VALU-active quad-cycles / (SIMDs x kernel quad-cycles).
+        # counter pass (profiles/r01_l_sq_counters.json): VALU-active quad-cycles / (SIMDs x kernel quad-cycles).
         issue = None
         try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r01_d_sq_counters.json")))["gc_encode_kernel"]
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r01_l_sq_counters.json")))["gc_encode_kernel"]
             if nch == 4096 and n == 2880000:
                 clk_quads = sq["SQ_WAVE_CYCLES"] / sq["SQ_WAVES"]          # every wave lives the whole launch
                 issue = {"valu_wave_instructions_per_launch": round(sq["SQ_INSTS_VALU"]),
