@@ -858,11 +858,7 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
         // as many time segments as fill the device once, each an even number of frames and at least 2048 frames long
         // (the seams re-encode some hundred frames each)
         const int groups = (nch + ECW - 1) / ECW, groups64 = (nch + 63) / 64;
-        int cus = 256;
-        {
-            int device = 0;
-            if (hipGetDevice(&device) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-        }
+        const int cus = device_cu_count();
         const int frames = (pcm_length + 31) / 32;
         const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
         int segments = cus * per_cu / groups;
@@ -930,11 +926,7 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
         // as many time segments as fill the device once (one workgroup of this LDS size per CU), each at least 512
         // frames long and an even number of frames
         const int groups = (nch + 63) / 64;
-        int cus = 256;
-        {
-            int device = 0;
-            if (hipGetDevice(&device) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-        }
+        const int cus = device_cu_count();
         const int frames = (sample_count + 31) / 32;
         const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
         int segments = cus * per_cu / groups;

@@ -61,6 +61,14 @@ __device__ __forceinline__ void lds_barrier()
 // fails loudly when no gfx950 device is present: there is no CPU fallback.
 int require_device();
 
+// compute units of the current device (256 on an MI355X): how many time pieces fill the chip
+inline int device_cu_count()
+{
+    int device = 0, cus = 256;
+    if (hipGetDevice(&device) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    return cus > 0 ? cus : 256;
+}
+
 // test hook (vga_debug_force_open_seams): the seam kernels of the time-segmented codecs then never accept a seam as
 // closed, so that their fall-back (re-computing the rest of the channel serially) is what produces the output
 bool force_open_seams();

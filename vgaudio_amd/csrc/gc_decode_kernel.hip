@@ -309,11 +309,7 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
     // at least 1024 frames long so that the seams stay a small part of the work
     const int frames = (sample_count + 13) / 14;
     const int groups = (nch + DCW - 1) / DCW;
-    int cus = 256;
-    {
-        int device = 0;
-        if (hipGetDevice(&device) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-    }
+    const int cus = device_cu_count();
     int segments = cus / groups;
     if (segments > frames / 1024) segments = frames / 1024;
     if (segments < 1) segments = 1;

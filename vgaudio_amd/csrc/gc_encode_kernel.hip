@@ -647,11 +647,7 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_c
     // one encoder wave per SIMD fills the chip (4 channels each): fewer channels than that are cut into time pieces
     // (each at least 512 frames: a seam re-encodes a few dozen)
     const int groups = (nch + CS - 1) / CS;
-    int cus = 256;
-    {
-        int device = 0;
-        if (hipGetDevice(&device) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-    }
+    const int cus = device_cu_count();
     const int frames = (sample_count + 13) / 14;
     int segments = cus * 4 / groups;                   // = SW encoder waves on every SIMD
     if (segments > frames / 512) segments = frames / 512;
