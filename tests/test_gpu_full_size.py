@@ -154,13 +154,14 @@ def test_time_segment_fallbacks_are_exact():
         return dec[:, :n].clone(), adx[:, :nb].clone(), back[:, :n].clone(), enc[:, :vdev.gc_byte_count(n)].clone()
 
     normal = run()
-    old = L.vga_debug_force_open_seams(1)
-    try:
-        forced = run()
-    finally:
-        L.vga_debug_force_open_seams(old)
-    for a, b in zip(normal, forced):
-        assert torch.equal(a, b)
+    for mode in (1, 2):                          # every seam open / open and closed seams mixed inside a workgroup
+        old = L.vga_debug_force_open_seams(mode)
+        try:
+            forced = run()
+        finally:
+            L.vga_debug_force_open_seams(old)
+        for a, b in zip(normal, forced):
+            assert torch.equal(a, b), mode
     # and both equal the oracle on a few channels
     for c in (0, 64, 129):
         host = pcm[c, :n].cpu().numpy()

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_fixup_kernel(
         int g1 = 0, g2 = 0;                             // the guessed run's history at this frame's end
         if (valid == 32) { g1 = o[31]; g2 = o[30]; }
         adx_decode_frame_serial<V4>(src + f * 18, p, valid, hist1, hist2, o);
-        if (valid == 32 && hist1 == g1 && hist2 == g2 && !force_open) return;
+        if (valid == 32 && hist1 == g1 && hist2 == g2 && !seam_forced_open(force_open, ch, k)) return;
         if (valid < 32) return;                         // the stream's last, partial frame: nothing follows
     }
     if (f0 + seg_frames < ((int64_t)total_samples + 31) / 32) atomicMin(&first_open[ch], k);   // open, and a piece follows
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
             sb = clamp16(v);
         }
         adx_encode_frame_serial<V4, EXPONENTIAL>(x, ta, tb, c0, c1, filter_bits, fr);
-        if (ta == sa && tb == sb && !force_open) return;   // closed: the rest of the piece stands
+        if (ta == sa && tb == sb && !seam_forced_open(force_open, ch, k)) return;   // closed: the rest of the piece stands
     }
     atomicMin(&first_open[ch], k);
 }
@@ -888,7 +888,7 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
             if (segments > 1) {                                                                                          \
                 hipLaunchKernelGGL((adx_encode_fs18_fixup_kernel<V, E>), dim3(groups64, segments - 1), dim3(64), 0, stream, \
                                    d_pcm, pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, seg_state,       \
-                                   first_open, force_open_seams() ? 1 : 0);                                              \
+                                   first_open, force_open_seams());                                              \
                 hipLaunchKernelGGL((adx_encode_fs18_tail_kernel<V, E>), dim3(groups64), dim3(64), 0, stream, d_pcm,     \
                                    pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, seg_state, first_open); \
             }                                                                                                            \
@@ -947,7 +947,7 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
             if (segments > 1) {                                                                                          \
                 hipLaunchKernelGGL(adx_decode_fs18_fixup_kernel<V>, dim3(groups, segments - 1), dim3(64), 0, stream,    \
                                    d_adpcm, in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, first_open,   \
-                                   force_open_seams() ? 1 : 0);                                                          \
+                                   force_open_seams());                                                          \
                 hipLaunchKernelGGL(adx_decode_fs18_tail_kernel<V>, dim3(groups), dim3(64), 0, stream, d_adpcm, in_pitch, \
                                    nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, first_open);                      \
             }                                                                                                            \

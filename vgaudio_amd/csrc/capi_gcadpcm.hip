@@ -21,7 +21,7 @@ void set_error(const char *fmt, ...)
 }
 
 static std::atomic<int> g_force_open_seams{0};
-bool force_open_seams() { return g_force_open_seams.load(std::memory_order_relaxed) != 0; }
+int force_open_seams() { return g_force_open_seams.load(std::memory_order_relaxed); }
 
 int require_device()
 {
@@ -49,7 +49,7 @@ const char *vga_last_error(void) { return g_err; }
 
 int vga_debug_force_open_seams(int enable)
 {
-    return g_force_open_seams.exchange(enable ? 1 : 0);
+    return g_force_open_seams.exchange(enable);
 }
 const char *vga_version(void) { return "vgaudio_hip 0.1 (gfx950)"; }
 

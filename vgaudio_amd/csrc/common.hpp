@@ -71,6 +71,12 @@ inline int device_cu_count()
 
 // test hook (vga_debug_force_open_seams): the seam kernels of the time-segmented codecs then never accept a seam as
 // closed, so that their fall-back (re-computing the rest of the channel serially) is what produces the output
-bool force_open_seams();
+int force_open_seams();          // 0 = off, 1 = every seam, 2 = seams with an even index of every third channel
+
+// the per-(channel, seam) reading of that mode inside the seam kernels
+__host__ __device__ inline bool seam_forced_open(int mode, int channel, int seam)
+{
+    return mode == 1 || (mode == 2 && channel % 3 == 0 && seam % 2 == 0);
+}
 
 }  // namespace vga

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64) void gc_decode_fixup_kernel(
         int g1 = 0, g2 = 0;                            // the guessed run's history at this frame's end
         if (valid == 14) { g1 = o[13]; g2 = o[12]; }
         gc_decode_frame_serial(src + f * 8, cf, valid, h1, h2, o);
-        if (valid == 14 && h1 == g1 && h2 == g2 && !force_open) return;
+        if (valid == 14 && h1 == g1 && h2 == g2 && !seam_forced_open(force_open, ch, k)) return;
         if (valid < 14) return;                        // the stream's last, partial frame: nothing follows
     }
     if ((f0 + seg_frames) * 14 < total_samples) atomicMin(&first_open[ch], k);   // open, and a piece follows
@@ -323,7 +323,7 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
         VGA_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&first_open), (size_t)nch * sizeof(int), stream));
         VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
         hipLaunchKernelGGL(gc_decode_fixup_kernel, dim3((nch + 63) / 64, segments - 1), dim3(64), 0, stream, d_adpcm, adpcm_pitch,
-                           d_coefs, nch, sample_count, seg_frames, d_pcm, pcm_pitch, first_open, force_open_seams() ? 1 : 0);
+                           d_coefs, nch, sample_count, seg_frames, d_pcm, pcm_pitch, first_open, force_open_seams());
         hipLaunchKernelGGL(gc_decode_tail_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
                            sample_count, seg_frames, d_pcm, pcm_pitch, first_open);
         VGA_HIP_TRY(hipGetLastError());

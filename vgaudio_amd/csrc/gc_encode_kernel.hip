@@ -630,7 +630,7 @@ __global__ __launch_bounds__(64) void gc_encode_seam_kernel(
             if (pr == 0) store_frame_bytes(dst + f * 8, d0, d1, 8);
             x[0] = n0;                                  // :40-41
             x[1] = n1;
-            if (x[0] == g2 && x[1] == g1 && !force_open) open = false;   // closed
+            if (x[0] == g2 && x[1] == g1 && !seam_forced_open(force_open, ch, k)) open = false;   // closed
         }
     }
     // still open (the launcher's max_frames is the piece length: half the seams close within nine frames, one in a
@@ -669,7 +669,7 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_c
     if (segments > 1) {
         hipLaunchKernelGGL(gc_encode_seam_kernel, dim3((nch + 7) / 8, segments - 1), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
                            sample_count, seg_frames, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seg_frames,
-                           force_open_seams() ? 1 : 0);
+                           force_open_seams());
         // repair: the same encoder, serially, for the channels whose seams stayed open (none: every workgroup returns)
         hipLaunchKernelGGL(gc_encode_kernel<true>, dim3(groups, 1), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
                            seg_frames, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state, (const int *)first_open);
