@@ -37,11 +37,6 @@ extern "C" {
 #define VGA_ERR_DEVICE (-5)
 
 const char *vga_last_error(void);
-/* Test hook, not part of the drop-in surface: GC-ADPCM decode and ADX encode/decode cut long channels into time
- * segments that run side by side and close the seams afterwards.  enable = 1: no seam is ever
- * accepted as closed; 2: only the even seams of every third channel are kept open (a mix of open and closed seams
- * inside one workgroup).  The serial fall-backs then produce the output, which must not change.  Returns the old value. */
-int vga_debug_force_open_seams(int enable);
 /* number of visible HIP devices (0 when none; never fails) */
 int vga_device_count(void);
 /* selects the device for the calling thread (one process per GPU: LOCAL_RANK) */

@@ -14,6 +14,13 @@
 #include <pthread.h>
 
 static inline int16_t clamp16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : (int16_t)v); }
+/* (int)double as RyuJIT x64 does it (cvttsd2si): NaN and values outside int32 give 0x80000000.  The plain C cast is
+ * undefined there; rawDistance * gain reaches +-2^32 on hostile input (|rawDistance| <= 2^17, gain <= 32767). */
+static inline int double_to_int(double d)
+{
+    if (!(d > -2147483649.0 && d < 2147483648.0)) return (int)0x80000000;
+    return (int)d;
+}
 static inline int clamp4(int v) { return v > 7 ? 7 : (v < -8 ? -8 : v); }
 static inline int divide_by_round_up(int value, int divisor) { return (int)ceil((double)value / divisor); }
 static inline int divide_by2_round_up(int value) { return (value / 2) + (value & 1); }
@@ -58,8 +65,8 @@ void vgo_adx_calculate_coefficients(int highpass_freq, int sample_rate, int16_t 
     double b = sqrt2 - 1;
     double c = (a - sqrt((a + b) * (a - b))) / b;
 
-    coefs[0] = (int16_t)(int)(c * 8192);
-    coefs[1] = (int16_t)(int)(c * c * -4096);
+    coefs[0] = (int16_t)double_to_int(c * 8192);
+    coefs[1] = (int16_t)double_to_int(c * c * -4096);
 }
 
 /* Formats/CriAdx/CriAdxHelpers.cs:7-31 */
@@ -133,7 +140,7 @@ static void encode_frame(int16_t *pcm, uint8_t *adpcm_out, const int16_t coefs[2
     for (int i = 0; i < samples_per_frame; i++) {
         int predicted_sample = (pcm[i + 1] * coefs[0] >> 12) + (pcm[i] * coefs[1] >> 12);
         int raw_distance = pcm[i + 2] - predicted_sample;
-        int scaled_distance = clamp16((int)(raw_distance * gain));
+        int scaled_distance = clamp16(double_to_int(raw_distance * gain));
 
         int adpcm_sample = scale_short_to_nibble(scaled_distance);
         adpcm[i] = adpcm_sample;

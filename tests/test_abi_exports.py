@@ -1,5 +1,5 @@
 """The C-ABI library loads on a CPU-only box and exports every symbol that
-include/vgaudio_hip.h declares (no compute calls without a GPU)."""
+include/*.h declare (no compute calls without a GPU)."""
 import ctypes
 import os
 import re
@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "vgaudio_hip.h")).read()
+    inc = os.path.join(ROOT, "include")
+    text = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//.*", "", text)
     text = re.sub(r"^\s*#.*$", "", text, flags=re.M)
@@ -27,6 +28,11 @@ def test_header_symbols_exported():
     assert not missing, f"not exported: {missing}"
     # and the ctypes table covers the header
     assert not [n for n in names if n not in _lib.SIGNATURES], "ctypes SIGNATURES missing entries"
+
+
+def test_test_hooks_are_not_in_the_drop_in_header():
+    text = open(os.path.join(ROOT, "include", "vgaudio_hip.h")).read()
+    assert "debug" not in text.lower() and "testing" not in text.lower()
 
 
 def test_host_side_size_math_needs_no_gpu():

@@ -1,8 +1,9 @@
 """Full BASELINE.json sizes on one GPU, through size-independent properties plus sampled bit-exact units:
 config 2 (4096 channels x 60 s GC-ADPCM), config 3 (the same through CRI ADX), config 4 (1024 stereo HCA streams).
-The oracle cannot run these sizes in seconds, so every unit is checked through decode(encode(x)) ~ x and a few
-units against the oracle bit for bit."""
+The oracle cannot run these sizes in seconds, so every unit is checked through decode(encode(x)) ~ x and 64 units
+per configuration (spread over the batch, first and last included) against the oracle bit for bit."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -14,6 +15,7 @@ from vgaudio_amd import _lib, device as vdev
 pytestmark = pytest.mark.gpu
 
 N = 2_880_000                                   # 48 kHz x 60 s
+THREADS = max(1, min(16, len(os.sched_getaffinity(0))))
 # relative rms error of decode(encode(x)) over a whole channel; calibrated on the synthetic channels (4-bit codes:
 # the quietest, noisiest channels set the maximum) with a factor of two of slack
 GC_BOUND, ADX_BOUND, HCA_BOUND = 0.17, 0.8, 0.12           # measured maxima 0.086, 0.534 (13 kHz tones), 0.060
@@ -42,11 +44,18 @@ def test_config2_gcadpcm_4096_channels():
     assert (rel < GC_BOUND).all() and float(rel.mean()) < 0.04, float(rel.max())
     del dec
     nb = vdev.gc_byte_count(N)
-    for c in (0, 2047, 4095):                   # first, middle, last: row offsets beyond 4 GiB
-        host = pcm[c, :N].cpu().numpy()
-        wc = po.gc_calculate_coefficients(host)
-        assert coefs[c].cpu().numpy().tolist() == wc.tolist()
-        assert (adpcm[c, :nb].cpu().numpy() == po.gc_encode(host, wc)).all()
+    # 64 channels spread over the batch (first and last included: row offsets beyond 4 GiB), bit for bit against
+    # the oracle with the reference's scheduling (one task per channel)
+    idx = torch.arange(0, nch, 65, device=d)
+    assert idx.numel() == 64 and int(idx[-1]) == nch - 1
+    host = pcm[idx, :N].cpu().numpy()
+    wc, wa = po.gc_encode_batch(host, threads=THREADS)
+    assert np.array_equal(coefs[idx].cpu().numpy().reshape(64, 16), np.asarray(wc).reshape(64, 16))
+    assert np.array_equal(adpcm[idx, :nb].cpu().numpy(), np.asarray(wa)[:, :nb])
+    wd = po.gc_decode_batch(np.asarray(wa)[:, :nb], np.asarray(wc).reshape(64, 16), N, threads=THREADS)
+    dec, status = vdev.gc_decode(adpcm[idx].contiguous(), coefs[idx].contiguous(), N)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0 and np.array_equal(dec[:, :N].cpu().numpy(), wd)
     # every frame header names a predictor 0..7 and a scale 0..12 (GcAdpcmEncoder.cs:83, :118-170)
     heads = adpcm[:, :nb - nb % 8].reshape(nch, -1, 8)[:, :, 0]
     assert int((heads >> 4).max()) <= 7 and int((heads & 15).max()) <= 12
@@ -74,12 +83,11 @@ def test_config3_adx_4096_channels():
     rel = _rel_rms(dec, pcm, N)
     print("config 3 relative rms: max %.4f mean %.4f" % (float(rel.max()), float(rel.mean())))
     assert (rel < ADX_BOUND).all() and float(rel.mean()) < 0.08, float(rel.max())
-    for c in (0, 4095):
-        host = pcm[c, :N].cpu().numpy()
-        op = po.adx_params()
-        want = po.adx_encode(host, op)
-        assert (adx[c, :nb].cpu().numpy() == want).all() and int(hist[c]) == op.history
-        assert (dec[c, :N].cpu().numpy() == po.adx_decode(want, N, po.adx_params())).all()
+    idx = torch.arange(0, nch, 65, device=d)      # 64 channels, first and last included, bit for bit
+    host = pcm[idx, :N].cpu().numpy()
+    want, whist = po.adx_encode_batch(host, po.adx_params(), threads=THREADS)
+    assert np.array_equal(adx[idx, :nb].cpu().numpy(), want) and np.array_equal(hist[idx].cpu().numpy(), whist)
+    assert np.array_equal(dec[idx, :N].cpu().numpy(), po.adx_decode_batch(want, N, po.adx_params(), threads=THREADS))
     # frame scales are 13-bit (CriAdxCodec.cs:140-141)
     assert int((adx[:, :nb].reshape(nch, -1, 18)[:, :, 0] >> 5).max()) == 0
 
@@ -117,10 +125,17 @@ def test_config4_hca_1024_stereo_streams():
     sample = fr[::97, ::211].reshape(-1, info.frame_size).cpu().numpy()
     for f in sample:
         assert po.lib().vgo_crc16(po._u8(np.ascontiguousarray(f)), info.frame_size) == 0
-    s = 1023                                     # the last stream against the oracle, bit for bit
-    host = spcm[2 * s:2 * s + 2, :N].cpu().numpy()
-    rc, oinfo, want = po.hca_encode(host, po.hca_params(2, N))
-    assert rc == 0 and (fr[s].cpu().numpy() == want).all()
+    # 64 streams spread over the batch (the last one included) against the oracle, bit for bit: frames and decoded PCM
+    sidx = list(range(0, ns, 16))[:63] + [ns - 1]
+    host = np.stack([spcm[2 * s:2 * s + 2, :N].cpu().numpy() for s in sidx])
+    rc, oinfo, want = po.hca_encode_batch(host, po.hca_params(2, N), threads=THREADS)
+    assert rc == 0
+    got = fr[torch.tensor(sidx, device=d)].cpu().numpy().reshape(len(sidx), -1)
+    assert np.array_equal(got, want)
+    rc, wdec = po.hca_decode_batch(oinfo, want, threads=THREADS)
+    assert rc == 0
+    for k, s in enumerate(sidx):
+        assert np.array_equal(dec[2 * s:2 * s + 2, :N].cpu().numpy(), wdec[k]), s
 
 
 def test_time_segment_fallbacks_are_exact():
@@ -155,11 +170,11 @@ def test_time_segment_fallbacks_are_exact():
 
     normal = run()
     for mode in (1, 2):                          # every seam open / open and closed seams mixed inside a workgroup
-        old = L.vga_debug_force_open_seams(mode)
+        old = L.vga_testing_force_open_seams_this_thread(mode)
         try:
             forced = run()
         finally:
-            L.vga_debug_force_open_seams(old)
+            L.vga_testing_force_open_seams_this_thread(old)
         for a, b in zip(normal, forced):
             assert torch.equal(a, b), mode
     # and both equal the oracle on a few channels

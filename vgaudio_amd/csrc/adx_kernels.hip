@@ -466,6 +466,9 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_fixup_kernel(
     if (ch >= nch || f0 * 32 >= total_samples) return;
     const uint8_t *src = adpcm + (int64_t)ch * in_pitch;
     int16_t *dst = pcm + (int64_t)ch * pcm_pitch;
+    // Seed read concurrently with seam k-1's lane rewriting piece k-1 -- same invariant as gc_decode_fixup_kernel
+    // (gc_decode_kernel.hip): a seam that closes leaves the piece's last samples with the values they already hold,
+    // one that stays open hands pieces k.. to the tail kernel, which redoes them from the final samples.
     int hist1 = dst[f0 * 32 - 1], hist2 = dst[f0 * 32 - 2];
     for (int64_t f = f0; f < f0 + seg_frames && f * 32 < total_samples; f++) {
         const int valid = (int)((int64_t)total_samples - f * 32 < 32 ? (int64_t)total_samples - f * 32 : 32);
@@ -867,28 +870,27 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
         if (segments > 64) segments = 64;
         int seg_frames = (frames + segments - 1) / segments;
         seg_frames += seg_frames & 1;
+        AsyncBuf scratch;                              // freed (stream-ordered) on every exit path
         int16_t *seg_state = nullptr;                  // [segments][nch][2] final histories, then [nch] first open seam
         int *first_open = nullptr;
         if (segments > 1) {
             const size_t state_bytes = round_up((size_t)segments * nch * 2 * sizeof(int16_t), 16);
-            VGA_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&seg_state), state_bytes + (size_t)nch * sizeof(int), stream));
-            first_open = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(seg_state) + state_bytes);
+            VGA_HIP_TRY(scratch.alloc(state_bytes + (size_t)nch * sizeof(int), stream));
+            seg_state = scratch.as<int16_t>();
+            first_open = reinterpret_cast<int *>(scratch.as<unsigned char>() + state_bytes);
             VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
         }
 #define VGA_ADX_ENC_T(V, E)                                                                                              \
         {                                                                                                                \
-            static bool configured = false;                                                                              \
-            if (!configured) {                                                                                           \
-                VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(adx_encode_fs18_tiled_kernel<V, E>),     \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
-                configured = true;                                                                                       \
-            }                                                                                                            \
+            VGA_HIP_TRY(allow_dynamic_lds(adx_encode_fs18_tiled_kernel<V, E>, lds));                                     \
             hipLaunchKernelGGL((adx_encode_fs18_tiled_kernel<V, E>), dim3(groups, segments), dim3(ETHREADS), lds, stream, d_pcm, \
                                pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, d_history_out, seg_state);  \
+            VGA_HIP_TRY(hipGetLastError());                                                                              \
             if (segments > 1) {                                                                                          \
                 hipLaunchKernelGGL((adx_encode_fs18_fixup_kernel<V, E>), dim3(groups64, segments - 1), dim3(64), 0, stream, \
                                    d_pcm, pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, seg_state,       \
                                    first_open, force_open_seams());                                              \
+                VGA_HIP_TRY(hipGetLastError());                                                                          \
                 hipLaunchKernelGGL((adx_encode_fs18_tail_kernel<V, E>), dim3(groups64), dim3(64), 0, stream, d_pcm,     \
                                    pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, seg_state, first_open); \
             }                                                                                                            \
@@ -898,7 +900,6 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
         else if (ex) VGA_ADX_ENC_T(false, true)
         else VGA_ADX_ENC_T(false, false)
 #undef VGA_ADX_ENC_T
-        if (seg_state) VGA_HIP_TRY(hipFreeAsync(seg_state, stream));
     } else {                                           // other frame sizes, padded (looping) streams, odd alignments
         hipLaunchKernelGGL(adx_encode_kernel, grid, block, 0, stream, d_pcm, pcm_pitch, nch, pcm_length, p, d_out, out_pitch,
                            d_history_out);
@@ -915,14 +916,8 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
                       (in_pitch % 4) == 0 && ((uintptr_t)d_adpcm % 4) == 0;
     if (fast) {
         const size_t lds = 2 * sizeof(AdxDecodeTile);
-        static bool configured = false;
-        if (!configured) {
-            VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(adx_decode_fs18_tiled_kernel<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(adx_decode_fs18_tiled_kernel<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            configured = true;
-        }
+        if (p.version == 4) VGA_HIP_TRY(allow_dynamic_lds(adx_decode_fs18_tiled_kernel<true>, lds));
+        else VGA_HIP_TRY(allow_dynamic_lds(adx_decode_fs18_tiled_kernel<false>, lds));
         // as many time segments as fill the device once (one workgroup of this LDS size per CU), each at least 512
         // frames long and an even number of frames
         const int groups = (nch + 63) / 64;
@@ -935,19 +930,23 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
         if (segments > 64) segments = 64;
         int seg_frames = (frames + segments - 1) / segments;
         seg_frames += seg_frames & 1;
+        AsyncBuf scratch;                              // freed (stream-ordered) on every exit path
         int *first_open = nullptr;
         if (segments > 1) {
-            VGA_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&first_open), (size_t)nch * sizeof(int), stream));
+            VGA_HIP_TRY(scratch.alloc((size_t)nch * sizeof(int), stream));
+            first_open = scratch.as<int>();
             VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
         }
 #define VGA_ADX_DEC_T(V)                                                                                                 \
         {                                                                                                                \
             hipLaunchKernelGGL(adx_decode_fs18_tiled_kernel<V>, dim3(groups, segments), dim3(256), lds, stream, d_adpcm, \
                                in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status);                  \
+            VGA_HIP_TRY(hipGetLastError());                                                                              \
             if (segments > 1) {                                                                                          \
                 hipLaunchKernelGGL(adx_decode_fs18_fixup_kernel<V>, dim3(groups, segments - 1), dim3(64), 0, stream,    \
                                    d_adpcm, in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, first_open,   \
                                    force_open_seams());                                                          \
+                VGA_HIP_TRY(hipGetLastError());                                                                          \
                 hipLaunchKernelGGL(adx_decode_fs18_tail_kernel<V>, dim3(groups), dim3(64), 0, stream, d_adpcm, in_pitch, \
                                    nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, first_open);                      \
             }                                                                                                            \
@@ -955,7 +954,6 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
         if (p.version == 4) VGA_ADX_DEC_T(true)
         else VGA_ADX_DEC_T(false)
 #undef VGA_ADX_DEC_T
-        if (first_open) VGA_HIP_TRY(hipFreeAsync(first_open, stream));
     } else {
         hipLaunchKernelGGL(adx_decode_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, in_pitch, nch, sample_count, p,
                            d_pcm, pcm_pitch, d_status);

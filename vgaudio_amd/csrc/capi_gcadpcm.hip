@@ -1,7 +1,6 @@
 // capi_gcadpcm.hip -- C-ABI entry points for GC-ADPCM (see include/vgaudio_hip.h).
 #include "common.hpp"
-
-#include <atomic>
+#include "../../include/vgaudio_hip_testing.h"
 
 #include <algorithm>
 #include "gcadpcm_kernels.hpp"
@@ -20,8 +19,9 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
-static std::atomic<int> g_force_open_seams{0};
-int force_open_seams() { return g_force_open_seams.load(std::memory_order_relaxed); }
+// test hook (include/vgaudio_hip_testing.h): per calling thread, so that no call on another thread is affected
+static thread_local int g_force_open_seams = 0;
+int force_open_seams() { return g_force_open_seams; }
 
 int require_device()
 {
@@ -47,9 +47,11 @@ extern "C" {
 
 const char *vga_last_error(void) { return g_err; }
 
-int vga_debug_force_open_seams(int enable)
+int vga_testing_force_open_seams_this_thread(int mode)
 {
-    return g_force_open_seams.exchange(enable);
+    const int old = g_force_open_seams;
+    g_force_open_seams = mode;
+    return old;
 }
 const char *vga_version(void) { return "vgaudio_hip 0.1 (gfx950)"; }
 

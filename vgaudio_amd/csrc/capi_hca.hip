@@ -238,6 +238,12 @@ int vga_hca_encoder_initialize(const vga_hca_params *c, vga_hca_info *h)
     {                                                           // CalculateHeaderSize :400-418
         h->header_size = get_next_multiple(96 + h->comment_length, 32);
         if (h->looping) {
+            if (h->frame_size <= 0) {
+                // the reference divides by FrameSize here (CriHcaEncoder.cs:411: a catchable DivideByZeroException);
+                // the non-looping path reports the same condition from the encoder ("Bitrate is set too low.")
+                set_error("Bitrate is set too low.");
+                return VGA_ERR_INVALID_DATA;
+            }
             const int off = h->header_size + h->frame_size * h->loop_start_frame;
             const int padding_bytes = get_next_multiple(off, 2048) - off;
             const int padding_frames = padding_bytes / h->frame_size;

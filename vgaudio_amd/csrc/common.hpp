@@ -39,6 +39,30 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// stream-ordered scratch of the segmented launchers: freed on every exit path (hipFreeAsync on the same stream)
+struct AsyncBuf {
+    void *p = nullptr;
+    hipStream_t stream = nullptr;
+    AsyncBuf() = default;
+    AsyncBuf(const AsyncBuf &) = delete;
+    AsyncBuf &operator=(const AsyncBuf &) = delete;
+    ~AsyncBuf() { if (p) (void)hipFreeAsync(p, stream); }
+    hipError_t alloc(size_t n, hipStream_t s) {
+        stream = s;
+        return hipMallocAsync(&p, n ? n : 1, s);
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of the function: set it on every launch (a
+// host-side table update, microseconds) instead of caching a process-wide "done" flag, which would be wrong after
+// vga_set_device() picks another GPU and racy between threads.
+template <class F>
+inline hipError_t allow_dynamic_lds(F *kernel, size_t bytes)
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 struct Stream {
     hipStream_t s = nullptr;
     ~Stream() { if (s) (void)hipStreamDestroy(s); }
@@ -69,7 +93,7 @@ inline int device_cu_count()
     return cus > 0 ? cus : 256;
 }
 
-// test hook (vga_debug_force_open_seams): the seam kernels of the time-segmented codecs then never accept a seam as
+// test hook (vga_testing_force_open_seams_this_thread, include/vgaudio_hip_testing.h): the seam kernels of the time-segmented codecs then never accept a seam as
 // closed, so that their fall-back (re-computing the rest of the channel serially) is what produces the output
 int force_open_seams();          // 0 = off, 1 = every seam, 2 = seams with an even index of every third channel
 

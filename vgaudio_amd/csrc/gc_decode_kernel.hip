@@ -43,7 +43,7 @@ __global__ __launch_bounds__(DTHREADS) void gc_decode_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     GcDecodeTile *s_tile = reinterpret_cast<GcDecodeTile *>(s_raw);            // [2]
-    int16_t *s_coefs = reinterpret_cast<int16_t *>(s_raw + 2 * sizeof(GcDecodeTile));   // [64][16]
+    int16_t *s_coefs = reinterpret_cast<int16_t *>(s_raw + 2 * sizeof(GcDecodeTile));   // [DCW][16]: the coefficient sets of the workgroup's DCW (= 128) channels
 
     const int tid = threadIdx.x;
     const int ch0 = blockIdx.x * DCW;
@@ -256,6 +256,13 @@ __global__ __launch_bounds__(64) void gc_decode_fixup_kernel(
 #pragma unroll
     for (int i = 0; i < 16; i++) cf[i] = coefs[ch * 16 + i];
     const int full_frames = total_samples / 14;
+    // Seed = the last two samples of piece k-1, read while seam k-1's lane (another thread, all seams run at once) may
+    // still be rewriting that piece.  Invariant that makes this safe: if seam k-1 CLOSES, the samples it rewrites past
+    // its closing frame are untouched and the ones before it get the values of the serial run -- the tail of piece
+    // k-1, which is what is read here, is identical before and after (a closing seam never reaches the last frame
+    // without having matched the guessed run there, i.e. it rewrites those two samples with the values they hold);
+    // if seam k-1 stays OPEN, first_open[ch] <= k-1 and gc_decode_tail_kernel decodes pieces k.. again from the final
+    // samples, overwriting whatever this lane produced from a possibly stale seed.  Either way the output is exact.
     int h1 = dst[f0 * 14 - 1], h2 = dst[f0 * 14 - 2];
     for (int64_t f = f0; f < f0 + seg_frames && f * 14 < total_samples; f++) {
         const int valid = f < full_frames ? 14 : total_samples - (int)(f * 14);
@@ -299,12 +306,7 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
 {
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
     const size_t lds = 2 * sizeof(GcDecodeTile) + DCW * 16 * sizeof(int16_t);
-    static bool configured = false;
-    if (!configured) {
-        VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gc_decode_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
-    }
+    VGA_HIP_TRY(allow_dynamic_lds(gc_decode_kernel, lds));
     // As many time segments as fill the device once (one workgroup of this LDS size per CU, 64 channels each), each
     // at least 1024 frames long so that the seams stay a small part of the work
     const int frames = (sample_count + 13) / 14;
@@ -319,15 +321,16 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
                        sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
     VGA_HIP_TRY(hipGetLastError());
     if (segments > 1) {
-        int *first_open = nullptr;
-        VGA_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&first_open), (size_t)nch * sizeof(int), stream));
+        AsyncBuf scratch;                              // freed (stream-ordered) on every exit path
+        VGA_HIP_TRY(scratch.alloc((size_t)nch * sizeof(int), stream));
+        int *first_open = scratch.as<int>();
         VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
         hipLaunchKernelGGL(gc_decode_fixup_kernel, dim3((nch + 63) / 64, segments - 1), dim3(64), 0, stream, d_adpcm, adpcm_pitch,
                            d_coefs, nch, sample_count, seg_frames, d_pcm, pcm_pitch, first_open, force_open_seams());
+        VGA_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(gc_decode_tail_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
                            sample_count, seg_frames, d_pcm, pcm_pitch, first_open);
         VGA_HIP_TRY(hipGetLastError());
-        VGA_HIP_TRY(hipFreeAsync(first_open, stream));
     }
     return VGA_OK;
 }

@@ -68,10 +68,8 @@ __device__ __forceinline__ unsigned row16_reduce(unsigned v, Op op)
 // compiling the rare paths inline cost 80 ms of 257 ms (code size, register pressure, branches).
 // The SIMDs have idle issue slots next to a lone latency-bound wave (tools/ubench_valu.hip: two waves
 // per SIMD do not slow each other's dependent chains), so the helper costs the encoder nothing.
-#ifndef VGA_ENC_SW
-#define VGA_ENC_SW 2               // measured at configs[1]: 1 -> 209.5 ms, 2 -> 200.1 ms (two pieces per channel)
-#endif
-constexpr int SW = VGA_ENC_SW;     // encoder (serial) waves per workgroup, 4 channels each; one helper wave serves them all
+// measured at configs[1]: 1 encoder wave -> 209.5 ms, 2 -> 200.1 ms (two pieces per channel)
+constexpr int SW = 2;              // encoder (serial) waves per workgroup, 4 channels each; one helper wave serves them all
 constexpr int CS = 4 * SW;         // channel slots per workgroup
 constexpr int TF = 64 / CS;        // frames per tile: one helper lane per (channel slot, frame)
 constexpr int ENC_THREADS = 64 * (SW + 1);
@@ -81,19 +79,11 @@ struct GcTile {
     int in2048p[CS][TF][16];   // x * 2048 + 1024
     uint32_t pre[CS][TF][8];   // per predictor: clamp16(max d) & 0xFFFF | clamp16(min d) << 16, over s = 2..13
 };
-#ifdef VGA_ENC_MARKS   // analysis builds: region markers in the assembly listing
-#define VGA_MARK(name) asm volatile("; MARK " name)
-#else
-#define VGA_MARK(name)
-#endif
 typedef short short2v __attribute__((ext_vector_type(2)));
 struct X16 { int v[16]; };
 
-#ifdef VGA_ENC_COLD_OUTLINE      // experiment switch: measured 267 ms out of line vs 260 ms inline at configs[1]
-#define VGA_COLD __device__ __noinline__
-#else
+// inline: measured 267 ms out of line vs 260 ms inline at configs[1] (round 1)
 #define VGA_COLD __device__ __forceinline__
-#endif
 
 // Rare +M/-M tie of the pre-scan (argument by value: the hot copy of the frame stays in registers).
 VGA_COLD int prescan_sequential_cold(X16 xs, int c0, int c1)
@@ -118,26 +108,16 @@ __device__ __noinline__ GenericOut resume_generic(X16 xs, int c0, int c1, int sc
 }
 
 // Third and later trips / the generic redo for one frame.  Its mere presence in the frame loop costs the hot
-// path (VGA_X_COLD_NEVER build, block compiled in but never run: 172 ms vs 140 ms without it), which is why the
+// path (a build with the block compiled in but never run: 172 ms vs 140 ms without it), which is why the
 // frame's tail is instantiated once per branch below instead of merging the two branches' results.
-#ifdef VGA_X_COUNT          // experiment builds: how often does a wave take the cold block, and why
-__device__ unsigned long long vga_dbg[8];
-extern "C" int vga_debug_counters(unsigned long long *out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vga_dbg), sizeof(vga_dbg));
-}
-#endif
 struct ColdState {
     int x[16], m[14], mp[14];
     int c0, c1, s1;
     int cand_b, rare, resume;
 };
 struct ColdOut { PassOut r; int final_sp; int fin; };
-#ifdef VGA_ENC_COLD_OUTLINE      // experiment: 370 ms out of line (the by-value state goes through scratch) vs 209 inline
-__device__ __noinline__
-#else
+// inline: 370 ms out of line (the by-value state goes through scratch) vs 209 inline (round 1)
 __device__ __forceinline__
-#endif
 ColdOut encode_frame_cold(ColdState st, PassOut r, int final_sp, int fin)
 {
     int x[16], m[14], mp[14];
@@ -182,11 +162,7 @@ ColdOut encode_frame_cold(ColdState st, PassOut r, int final_sp, int fin)
 // REPAIR is a template parameter only so that the two launches carry different names in profiles (the repair launch
 // normally returns at once and would halve the kernel's average duration).
 template <bool REPAIR>
-#if VGA_ENC_SW > 1
 __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void gc_encode_kernel(
-#else
-__global__ __launch_bounds__(ENC_THREADS) void gc_encode_kernel(
-#endif
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, int seg_frames,
     const int16_t *__restrict__ coefs, const int16_t *__restrict__ hist1,
     const int16_t *__restrict__ hist2, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, int16_t *__restrict__ seg_state,
@@ -381,7 +357,6 @@ __global__ __launch_bounds__(ENC_THREADS) void gc_encode_kernel(
 
     auto encode_frame = [&](Row &R, int buf, int j) {
         int (&x)[16] = R.x;
-        VGA_MARK("frame_begin");
         x[0] = h0;
         x[1] = h1;
         // ---- pre-scan (:107-124): two history-dependent distances + the helper's range for s = 2..13
@@ -392,26 +367,15 @@ __global__ __launch_bounds__(ENC_THREADS) void gc_encode_kernel(
             const int dmax = imax(imax((int)(int16_t)(R.pre & 0xFFFF), d0), d1);
             const int dmin = imin(imin((int)R.pre >> 16, d0), d1);
             s1 = first_scale_power_from_range(dmax, dmin);
-#ifdef VGA_ABL_PRESCAN      // ablation (timing only): scale from the helper's range alone
-            s1 = first_scale_power_from_range((int)(int16_t)(R.pre & 0xFFFF), (int)R.pre >> 16);
-            if (s1 == -100) s1 = 3;
-#endif
-#if !defined(VGA_EXPERIMENT_NO_COLD) && !defined(VGA_X_NO_TIE)
             if (__any(s1 == -100)) {                   // +M and -M both present: first occurrence decides
                 if (s1 == -100) s1 = first_scale_power_from_md(prescan_sequential_cold(pack(x), c0, c1));
             }
-#endif
         }
-        VGA_MARK("prescan_end");
-#ifdef VGA_X_COUNT
-        if (lane == 0) atomicAdd(&vga_dbg[0], 1ull);
-#endif
         // ---- first trip: candidate A at s1, B at s1+1 (speculation on the loop of :127-170)
         int final_sp = imin(s1 + (cand_b ? 1 : 0), 12);
         const bool at_cap = final_sp >= 12;            // the loop never goes past 12: this pass ends it
         const unsigned ov_limit = at_cap ? 3u : 248u;  // see `rare` below
         PassOut r = pass_fast_core(x, R.m, R.mp, c0, c1, final_sp);
-        VGA_MARK("pass_end");
         // Straight-line resolution, valid when no lane is `rare`:
         //   * no overflow can start the bump loop (:166-168 needs max_overflow + 8 > 256),
         //   * the 32-bit error sum of every lane that can become final is exact (gc_encode_core.hpp S3:
@@ -452,12 +416,7 @@ __global__ __launch_bounds__(ENC_THREADS) void gc_encode_kernel(
                 const unsigned best = row16_reduce(key, [](unsigned a, unsigned b) { return a < b ? a : b; });
                 winner = (int)(best & 15u);
             }
-            VGA_MARK("resolve_end");
             const bool won = l16 == winner;
-#ifdef VGA_ABL_PAY          // ablation (timing only): every lane continues from its own history
-            const unsigned pay_own = r.hist_pair;
-#define row16_reduce(v, f) pay_own
-#endif
             const unsigned pay = row16_reduce(won ? r.hist_pair : 0u,
                                               [](unsigned a, unsigned b) { return a | b; });
             if (won) {                                           // packed and flushed by the helper, a tile at a time
@@ -467,33 +426,12 @@ __global__ __launch_bounds__(ENC_THREADS) void gc_encode_kernel(
                 rec[2] = make_int4(r.q[8], r.q[9], r.q[10], r.q[11]);
                 rec[3] = make_int4(r.q[12], r.q[13], p, final_sp);
             }
-#ifdef VGA_ABL_PAY
-#undef row16_reduce
-#endif
             h0 = (int)(int16_t)(pay & 0xFFFF);   // pcmBuffer[0] = pcmBuffer[14] (:40)
             h1 = (int)pay >> 16;                 // pcmBuffer[1] = pcmBuffer[15] (:41)
             VGA_OPAQUE(h0);                      // hide the 16-bit range: keeps the 24-bit multiplies the next frame
             VGA_OPAQUE(h1);                      // asks for (the compiler otherwise widens them to 64-bit mads)
         };
-#if !defined(VGA_EXPERIMENT_NO_COLD)
-#ifdef VGA_X_COLD_NEVER     // experiment: cold block compiled in, never executed (nch is never negative)
-        if (__builtin_expect(__any(rare || resume || wide) && nch < 0, 0)) {
-#else
         if (__builtin_expect(__any(rare || resume || wide), 0)) {
-#endif
-#ifdef VGA_X_COUNT
-            {
-                const bool any_rare = __any(rare), any_wide = __any(wide);
-                const int n_resume = __popcll(__ballot(resume));
-                if (lane == 0) {
-                    atomicAdd(&vga_dbg[1], 1ull);
-                    if (any_rare) atomicAdd(&vga_dbg[2], 1ull);
-                    if (n_resume) atomicAdd(&vga_dbg[3], 1ull);
-                    if (any_wide) atomicAdd(&vga_dbg[4], 1ull);
-                    atomicAdd(&vga_dbg[5], (unsigned long long)n_resume);
-                }
-            }
-#endif
             // ---- cold block (third trips: ~10 % of wave-frames on audio; rare: hostile input only)
             ColdState st;
 #pragma unroll
@@ -505,9 +443,7 @@ __global__ __launch_bounds__(ENC_THREADS) void gc_encode_kernel(
             const ColdOut o = encode_frame_cold(st, r, final_sp, fin);
             finish(o.r, o.final_sp, o.fin != 0, __any(o.fin != 0 && (o.r.total >> 28) != 0));
         } else
-#endif
-        finish(r, final_sp, fin, false);
-        VGA_MARK("frame_end");
+            finish(r, final_sp, fin, false);
     };
 
     __syncthreads();                                   // tile 0 prepared
@@ -515,14 +451,6 @@ __global__ __launch_bounds__(ENC_THREADS) void gc_encode_kernel(
         const int buf = tile & 1;
         const int nf = imin(TF, frames - tile * TF);
         const GcTile &T = s_tile[buf];
-#ifdef VGA_ENC_SINGLE
-#pragma unroll 1
-        for (int j = 0; j < nf; j++) {
-            Row R;
-            read_row(T, j, R);
-            encode_frame(R, buf, j);
-        }
-#else
         // two row register sets, ping-pong: the LDS reads of frame j+1 are in flight during frame j
         Row RA, RB;
         read_row(T, 0, RA);
@@ -535,7 +463,6 @@ __global__ __launch_bounds__(ENC_THREADS) void gc_encode_kernel(
                 encode_frame(RB, buf, j + 1);
             }
         }
-#endif
         __syncthreads();                               // tile done: helper may flush it and refill this buffer later
     }
     if (seg_state && !repair && live && l16 == 0) {
@@ -654,12 +581,14 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_c
     if (segments < 1) segments = 1;
     if (segments > 1024) segments = 1024;
     const int seg_frames = (frames + segments - 1) / segments;
+    AsyncBuf scratch;                                  // freed (stream-ordered) on every exit path
     int16_t *seg_state = nullptr;
     int *first_open = nullptr;
     if (segments > 1) {
         const size_t state_bytes = (size_t)round_up((int64_t)segments * nch * 2 * (int64_t)sizeof(int16_t), 16);
-        VGA_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&seg_state), state_bytes + (size_t)nch * sizeof(int), stream));
-        first_open = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(seg_state) + state_bytes);
+        VGA_HIP_TRY(scratch.alloc(state_bytes + (size_t)nch * sizeof(int), stream));
+        seg_state = scratch.as<int16_t>();
+        first_open = reinterpret_cast<int *>(scratch.as<unsigned char>() + state_bytes);
         VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
     }
     hipLaunchKernelGGL(gc_encode_kernel<false>, dim3(groups, segments), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch,
@@ -670,11 +599,11 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_c
         hipLaunchKernelGGL(gc_encode_seam_kernel, dim3((nch + 7) / 8, segments - 1), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
                            sample_count, seg_frames, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seg_frames,
                            force_open_seams());
+        VGA_HIP_TRY(hipGetLastError());
         // repair: the same encoder, serially, for the channels whose seams stayed open (none: every workgroup returns)
         hipLaunchKernelGGL(gc_encode_kernel<true>, dim3(groups, 1), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
                            seg_frames, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state, (const int *)first_open);
         VGA_HIP_TRY(hipGetLastError());
-        VGA_HIP_TRY(hipFreeAsync(seg_state, stream));
     }
     return VGA_OK;
 }
