@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: GC-ADPCM batch encode (coefficient search + encode),
-BASELINE.json configs[1]: 4096 independent mono channels x 48 kHz x 60 s per GPU.
+"""bench.py -- the driver's benchmark contract, one JSON line per run.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                  (headline: --codec gc)
+    python bench.py --codec adx|hca ...                            (BASELINE configs[2] / configs[3], same contract)
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over the batch, inputs resident in HBM:
-  gc_coefs_kernel  (GcAdpcmCoefficients.CalculateCoefficients for every channel)
-  gc_encode_kernel (GcAdpcmEncoder.Encode for every channel)
-Channels shard across GPUs with no data-path collective (weak scaling: every rank owns
-its own 4096 channels; BASELINE configs[4] = 8 x configs[1]).  Rank 0 prints ONE JSON line.
+--codec gc  (default; BASELINE.json's metric): configs[1], 4096 independent mono channels x 48 kHz x 60 s per GPU.
+            A step = gc_coefs_kernel (GcAdpcmCoefficients.CalculateCoefficients for every channel) +
+            gc_encode_kernel (GcAdpcmEncoder.Encode), inputs resident in HBM.
+--codec adx: configs[2], 4096 channels CRI ADX encode + decode round trip.  A step = encode + decode.
+--codec hca: configs[3], 1024 stereo streams CRI HCA encode, quality High.  A step = encode (decode is timed beside it).
 
-roofline  : dominant kernel gc_encode_kernel, algorithmic bytes = 2 B/sample read +
-            8/14 B/sample written (SURVEY.md 8d "encode-only"), / mean HIP-event duration.
-cpu_baseline: the oracle (C restatement of the reference, "port") run with the reference's
-            scheduling (one task per channel on all host cores) on a bounded channel subset; the
-            same leg compares its output with this run's GPU output for those channels, bit for bit
-            (config.bit_exact_channels_checked; 0 when the leg does not run).  The oracle is touched
-            nowhere else.
+Channels/streams shard across GPUs with no data-path collective (weak scaling: every rank owns its own units);
+with N > 1 the gc line also reports the step with the final RCCL gather of the bitstream to rank 0.
+Rank 0 prints ONE JSON line.
+
+roofline    : the dominant kernel; achieved = algorithmic bytes per launch (GC encode 2 + 8/14 B/sample,
+              ADX 2.5625 B/sample, HCA 2 + 682/2048 B/channel-sample) / mean HIP-event duration of that launch;
+              traffic = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), valid for the
+              profiled shape only.
+cpu_baseline: the oracle (C restatement of the reference, "port") run with the reference's scheduling -- one task per
+              channel (Parallel.For, GcAdpcmFormat.cs:65; CriAdxFormat.cs:67) or per stream (HCA has no intra-file
+              parallelism, CriHcaFormat.cs:53-81; Cli/Batch.cs:24-25) -- on a bounded sample; the same leg compares its
+              output with this run's GPU output for those units, bit for bit.  The oracle is touched nowhere else.
+e2e         : (gc, N = 1) one vga_gcadpcm_encode_batch call through the host-pointer C ABI -- what a P/Invoke caller
+              gets, pageable host arrays in and out -- next to the PCIe-bound time for the same bytes.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -33,6 +41,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ENC_BYTES_PER_SAMPLE = 2.0 + 8.0 / 14.0
 COEF_BYTES_PER_SAMPLE = 2.0
 PIPE_BYTES_PER_SAMPLE = 4.0 + 8.0 / 14.0
+ADX_BYTES_PER_SAMPLE = 2.0 + 18.0 / 32.0
+HCA_BYTES_PER_CHANNEL_SAMPLE = 2.0 + 682.0 / 2048.0
 
 
 def parse():
@@ -40,10 +50,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--channels", type=int, default=4096, help="channels per GPU")
+    ap.add_argument("--codec", choices=["gc", "adx", "hca"], default="gc")
+    ap.add_argument("--channels", type=int, default=4096, help="channels per GPU (gc, adx)")
+    ap.add_argument("--streams", type=int, default=1024, help="stereo streams per GPU (hca)")
     ap.add_argument("--seconds", type=float, default=60.0, help="audio seconds per channel @48 kHz")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-channels", type=int, default=0, help="channels in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--cpu-channels", type=int, default=0, help="units in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-pointer ABI measurement (gc)")
+    ap.add_argument("--e2e-channels", type=int, default=0, help="channels of the e2e call (0 = as many of --channels as host memory allows)")
     return ap.parse_args()
 
 
@@ -64,163 +78,502 @@ def usable_cpus():
     return n, note
 
 
-def main():
-    args = parse()
-    import numpy as np
+def host_memory_available():
+    """bytes this process can still allocate: min(MemAvailable, cgroup headroom)."""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    try:
+        mx = open("/sys/fs/cgroup/memory.max").read().strip()
+        cur = int(open("/sys/fs/cgroup/memory.current").read().strip())
+        if mx != "max":
+            head = int(mx) - cur
+            avail = head if avail is None else min(avail, head)
+    except (OSError, ValueError):
+        pass
+    return avail
+
+
+def load_profile_json(*names):
+    for name in names:
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+class Ctx:
+    pass
+
+
+def setup(args):
     import torch
     import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    cx = Ctx()
+    cx.torch, cx.dist = torch, dist
+    cx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    cx.rank = int(os.environ.get("RANK", "0"))
+    cx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and cx.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={cx.world})")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
+    torch.cuda.set_device(cx.local_rank)
+    cx.dev = torch.device("cuda", cx.local_rank)
     from vgaudio_amd import _lib, device as vdev, distributed as vdist
-    _lib.check(_lib.lib().vga_set_device(local_rank))
-    if world > 1:
-        vdist.init("nccl", dev)
+    cx.lib, cx.vdev, cx.vdist = _lib, vdev, vdist
+    cx.L = _lib.lib()
+    _lib.check(cx.L.vga_set_device(cx.local_rank))
+    if cx.world > 1:
+        vdist.init("nccl", cx.dev)
+    cx.st = lambda: torch.cuda.current_stream().cuda_stream
+    return cx
 
-    nch = args.channels
-    n = int(round(args.seconds * 48000))
-    first_channel = rank * nch                     # contiguous channel block per GPU
 
-    # ---- inputs resident in HBM before the timed region
-    pcm = vdev.synth_pcm(nch, n, dev, first_channel=first_channel)
-    adpcm = vdev.alloc_adpcm(nch, n, dev)
-    L = _lib.lib()
-    ws = torch.empty(max(L.vga_gcadpcm_coefs_workspace_bytes(nch, n), 16), dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()
-
-    def step(events=None):
-        if events is not None:
-            events[0].record()
-        coefs = vdev.gc_coefs(pcm, n, workspace=ws)
-        if events is not None:
-            events[1].record()
-        vdev.gc_encode(pcm, n, coefs, out=adpcm)
-        if events is not None:
-            events[2].record()
-        return coefs
-
-    # device wake-up (part of set-up, not of the W warm-up steps the contract asks for): the first two
-    # launches after allocation run ~45 % slow (clock ramp + first-touch TLB fills of the 24 GB input,
-    # profiles/r01_c_kernel_trace.csv: 339, 341, then 234 ms), whatever W the caller picks
+def timed_steps(cx, args, step, n_events):
+    """W warm-up steps (after a two-step device wake-up), then exactly K steps between barrier + synchronize;
+    returns (seconds over K steps, max over ranks; per-step event lists)."""
+    torch, dist = cx.torch, cx.dist
+    # device wake-up (part of set-up, not of the W warm-up steps the contract asks for): the first two launches after
+    # allocation run ~45 % slow (clock ramp + first-touch TLB fills of the 24 GB input, profiles/r01_c_kernel_trace.csv)
     for _ in range(2):
-        step()
+        step(None)
     for _ in range(args.warmup):
-        step()
+        step(None)
     torch.cuda.synchronize()
-    if world > 1:
+    if cx.world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(n_events)] for _ in range(args.steps)]
     t0 = time.perf_counter()
-    coefs = None
     for k in range(args.steps):
-        coefs = step(evs[k])
+        step(evs[k])
     torch.cuda.synchronize()
-    if world > 1:
+    if cx.world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if cx.world > 1:
+        elapsed = cx.vdist.max_over_ranks(elapsed, cx.dev)
+    return elapsed, evs
 
-    coef_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs])) if args.steps else 0.0
-    enc_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs])) if args.steps else 0.0
 
-    if world > 1:
-        elapsed = vdist.max_over_ranks(elapsed, dev)
-        # the only exchange: 32 B/channel of coefficients gathered for the caller (RCCL over xGMI)
-        all_coefs = vdist.gather_channel_metadata(coefs, [nch] * world)
-        assert all_coefs.shape[0] == nch * world
+def mean_ms(evs, a, b):
+    import numpy as np
+    return float(np.mean([e[a].elapsed_time(e[b]) for e in evs])) if evs else 0.0
 
-    samples_per_step = nch * n * world
+
+def base_line(args, cx, metric, value, ms_per_step, dtype, workload, config, roofline, cpu):
+    out = {"metric": metric, "value": round(value, 2), "unit": "Msamples/s", "n_gpus": cx.world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+           "config": dict({"workload": workload, "parallelism": f"units sharded x{cx.world}"}, **config),
+           "roofline": roofline, "cpu_baseline": cpu}
+    if cpu:
+        out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 2)
+    return out
+
+
+# ====================================================================================================== GC-ADPCM
+def encode_benchmarks_single_thread(po, np):
+    """The reference's own micro-benchmark shapes (VGAudio.Benchmark/AdpcmBenchmarks/EncodeBenchmarks.cs:8-24: 1 s of a
+    48 kHz 440 Hz sine; GenerateCoefs, EncodeAdpcm, both), single thread, on the C restatement."""
+    from vgaudio_amd import synth
+    x = synth.sine(48000)
+    coefs = po.gc_calculate_coefficients(x)
+
+    def per_call(fn):
+        fn()
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 0.4:
+            fn()
+            k += 1
+        return (time.perf_counter() - t0) / max(k, 1)
+
+    t_coefs = per_call(lambda: po.gc_calculate_coefficients(x))
+    t_enc = per_call(lambda: po.gc_encode(x, coefs))
+    t_both = per_call(lambda: po.gc_encode(x, po.gc_calculate_coefficients(x)))
+    return {"shape": "1 s, 48 kHz, 440 Hz sine (EncodeBenchmarks.cs:8-24), 1 thread, C restatement",
+            "GenerateCoefs_ms": round(t_coefs * 1e3, 3), "EncodeAdpcm_ms": round(t_enc * 1e3, 3),
+            "GenerateCoefsAndEncode_ms": round(t_both * 1e3, 3),
+            "GenerateCoefsAndEncode_Msamples_per_s": round(48000 / t_both / 1e6, 3)}
+
+
+def measure_e2e(cx, args, pcm, n, coefs_dev, adpcm_dev):
+    """One vga_gcadpcm_encode_batch call through the host-pointer ABI (pageable numpy rows in and out)."""
+    import numpy as np
+    torch, L, lib = cx.torch, cx.L, cx.lib
+    nch = pcm.shape[0]
+    nb = cx.vdev.gc_byte_count(n)
+    want = args.e2e_channels or nch
+    avail = host_memory_available()
+    per_ch = 2 * n + nb
+    note = None
+    if avail is not None and want * per_ch > 0.7 * avail:
+        fit = max(64, int(0.7 * avail / per_ch) // 64 * 64)
+        note = f"host memory allows {fit} of {want} channels ({avail / 2**30:.0f} GiB available)"
+        want = min(want, fit)
+    want = min(want, nch)
+    # PCIe rate of this box from page-locked memory (what the pipeline's rings see), 1 GiB each way
+    pin = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
+    dbuf = torch.empty(1 << 30, dtype=torch.uint8, device=cx.dev)
+    rates = {}
+    for name, (a, b) in (("h2d", (dbuf, pin)), ("d2h", (pin, dbuf))):
+        a.copy_(b, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        a.copy_(b, non_blocking=True)
+        torch.cuda.synchronize()
+        rates[name] = (1 << 30) / (time.perf_counter() - t0) / 1e9
+    del pin, dbuf
+    host = np.empty((want, n), dtype=np.int16)                       # pageable, like a managed short[][]
+    for c0 in range(0, want, 256):
+        host[c0:c0 + 256] = pcm[c0:c0 + 256, :n].cpu().numpy()
+    outs = np.zeros((want, nb), dtype=np.uint8)
+    cf = np.zeros(want * 16, dtype=np.int16)
+    pp = (lib.i16p * want)(*[host[c].ctypes.data_as(lib.i16p) for c in range(want)])
+    op = (lib.u8p * want)(*[outs[c].ctypes.data_as(lib.u8p) for c in range(want)])
+    warm = min(want, 64)                                             # first call: pinned rings, code objects
+    lib.check(L.vga_gcadpcm_encode_batch(pp, warm, n, 0, 0, cf.ctypes.data_as(lib.i16p), op))
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        lib.check(L.vga_gcadpcm_encode_batch(pp, want, n, 0, 0, cf.ctypes.data_as(lib.i16p), op))
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    same = bool(np.array_equal(outs, adpcm_dev[:want, :nb].cpu().numpy()) and
+                np.array_equal(cf.reshape(want, 16), coefs_dev[:want].cpu().numpy().reshape(want, 16)))
+    if not same:
+        raise SystemExit("PARITY FAILURE: the host-pointer ABI and the device-resident path disagree")
+    in_bytes, out_bytes = want * 2 * n, want * nb
+    pcie_ms = max(in_bytes / rates["h2d"], out_bytes / rates["d2h"]) / 1e6      # full duplex: the larger direction
+    e2e = {"entry_point": "vga_gcadpcm_encode_batch (pageable host arrays in and out)", "channels": want,
+           "samples_per_channel": n, "ms": round(best * 1e3, 1), "value": round(want * n / best / 1e6, 1), "unit": "Msamples/s",
+           "host_bytes_in": in_bytes, "host_bytes_out": out_bytes,
+           "pcie_pinned_GBps": {k: round(v, 1) for k, v in rates.items()}, "pcie_bound_ms": round(pcie_ms, 1),
+           "ratio_to_pcie_bound": round(best * 1e3 / pcie_ms, 2), "identical_to_device_path": same,
+           "host_threads": "8 feeders + 4 drainers + caller (host_pipeline.hpp)"}
+    if note:
+        e2e["note"] = note
+    return e2e
+
+
+def run_gc(args, cx):
+    import numpy as np
+    torch, vdev, L = cx.torch, cx.vdev, cx.L
+    nch = args.channels
+    n = int(round(args.seconds * 48000))
+    first_channel = cx.rank * nch                     # contiguous channel block per GPU
+    pcm = vdev.synth_pcm(nch, n, cx.dev, first_channel=first_channel)
+    adpcm = vdev.alloc_adpcm(nch, n, cx.dev)
+    ws = torch.empty(max(L.vga_gcadpcm_coefs_workspace_bytes(nch, n), 16), dtype=torch.uint8, device=cx.dev)
+    torch.cuda.synchronize()
+    state = {}
+
+    def step(events):
+        if events is not None:
+            events[0].record()
+        state["coefs"] = vdev.gc_coefs(pcm, n, workspace=ws)
+        if events is not None:
+            events[1].record()
+        vdev.gc_encode(pcm, n, state["coefs"], out=adpcm)
+        if events is not None:
+            events[2].record()
+
+    elapsed, evs = timed_steps(cx, args, step, 3)
+    coefs = state["coefs"]
+    coef_ms, enc_ms = mean_ms(evs, 0, 1), mean_ms(evs, 1, 2)
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
+    samples_per_step = nch * n * cx.world
     value = samples_per_step / (ms_per_step * 1e-3) / 1e6
 
-    out = None
-    if rank == 0:
-        verified = 0
+    gather = None
+    if cx.world > 1:
+        # SURVEY.md 8e: the results of all channels end up in one place (GcAdpcmFormat.cs:65-74): ADPCM rows + coefs of
+        # every rank gathered to rank 0 over RCCL/xGMI, in channel chunks; timed as steps that include it.
+        nb = vdev.gc_byte_count(n)
+        g = cx.vdist.BitstreamGather(nch, adpcm.stride(0), cx.dev)
+        g.gather(adpcm, coefs)                              # warm-up: communicators, buffers
+        torch.cuda.synchronize()
+        cx.dist.barrier()
+        # double-buffered outputs: the gather of step k runs on the process group's stream beside the kernels of
+        # step k+1 (a caller converting batch after batch); the last gather is waited for inside the timed region
+        bufs = [adpcm, torch.empty_like(adpcm)]
+        keep, pending = [], []
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            cur = bufs[k % 2]
+            ck = vdev.gc_coefs(pcm, n, workspace=ws)
+            vdev.gc_encode(pcm, n, ck, out=cur)
+            for w in pending:
+                w.wait()
+            pending = g.gather(cur, ck, async_op=True)
+            keep = [keep[-1], ck] if keep else [ck]         # coefficient rows stay alive until their gather is done
+        for w in pending:
+            w.wait()
+        torch.cuda.synchronize()
+        cx.dist.barrier()
+        torch.cuda.synchronize()
+        el = cx.vdist.max_over_ranks(time.perf_counter() - t0, cx.dev)
+        ms_g = el / max(args.steps, 1) * 1e3
+        adpcm, coefs = bufs[(args.steps - 1) % 2] if args.steps else adpcm, (keep[-1] if keep else coefs)
+        gather = {"what": "all ranks' ADPCM rows + coefficients to rank 0 (grouped send/recv in 512-channel chunks; the gather "
+                          "of step k overlaps the kernels of step k+1)",
+                  "bytes_per_peer": nch * nb + nch * 32, "ms_per_step_with_gather": round(ms_g, 3),
+                  "value_with_gather": round(samples_per_step / (ms_g * 1e-3) / 1e6, 2),
+                  "verified": g.verify(adpcm, coefs, nb) if cx.rank == 0 else None}
 
-        enc_bytes = ENC_BYTES_PER_SAMPLE * nch * n
-        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
-        # correction, + WRITE_SIZE; profiles/r01_pmc_traffic.json).  Only valid for the profiled shape.
-        traffic = None
+    if cx.rank != 0:
+        return None
+    verified = 0
+    enc_bytes = ENC_BYTES_PER_SAMPLE * nch * n
+    full = nch == 4096 and n == 2880000
+    pmc = load_profile_json("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+    traffic = None
+    if pmc and full:
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if nch == 4096 and n == 2880000:
-                traffic = round(pmc["gc_encode_kernel"]["traffic_bytes_per_launch"])
-        except (OSError, KeyError, ValueError):
+            traffic = round(pmc["gc_encode_kernel"]["traffic_bytes_per_launch"])
+        except KeyError:
             pass
-        # What actually binds the kernel: wave-instruction issue.  From the committed SQ
-        # counter pass (profiles/r01_l_sq_counters.json): VALU-active quad-cycles / (SIMDs x kernel quad-cycles).
-        issue = None
+    # What actually binds the kernel (DESIGN.md 4.1): wave-instruction issue.  From the committed SQ counter pass.
+    issue = None
+    sqj = load_profile_json("r02_sq_counters.json", "r01_l_sq_counters.json")
+    if sqj and full:
         try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r01_l_sq_counters.json")))["gc_encode_kernel"]
-            if nch == 4096 and n == 2880000:
-                clk_quads = sq["SQ_WAVE_CYCLES"] / sq["SQ_WAVES"]          # every wave lives the whole launch
-                issue = {"valu_wave_instructions_per_launch": round(sq["SQ_INSTS_VALU"]),
-                         "valu_issue_frac": round(sq["SQ_ACTIVE_INST_VALU"] / (1024 * clk_quads), 3),
-                         "profiled_launch_ms": round(sq["_dur_ms"], 1),
-                         "note": "1024 SIMDs x one wave-instruction per 4 cycles; profiled launch, not this run"}
-        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            sq = sqj["gc_encode_kernel"]
+            clk_quads = sq["SQ_WAVE_CYCLES"] / sq["SQ_WAVES"]          # every wave lives the whole launch
+            issue = {"valu_wave_instructions_per_launch": round(sq["SQ_INSTS_VALU"]),
+                     "valu_issue_frac": round(sq["SQ_ACTIVE_INST_VALU"] / (1024 * clk_quads), 3),
+                     "profiled_launch_ms": round(sq["_dur_ms"], 1),
+                     "note": "1024 SIMDs x one wave-instruction per 4 cycles; profiled launch, not this run"}
+        except (KeyError, ZeroDivisionError):
             pass
-        achieved = enc_bytes / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
-        # one encode = gc_encode_kernel<false> (all time pieces at once) + gc_encode_seam_kernel + gc_encode_kernel<true>
-        # (the repair launch: returns at once unless a seam stayed open); launch_ms spans the three, the rocprofv3
-        # kernel stats under profiles/ list them separately (their averages add up to it)
-        roofline = {"bound": "hbm", "kernel": "gc_encode_kernel", "achieved": round(achieved, 2),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "algorithmic_bytes_per_launch": enc_bytes, "launch_ms": round(enc_ms, 3),
-                    "launch_parts": ["gc_encode_kernel<false>", "gc_encode_seam_kernel", "gc_encode_kernel<true>"],
-                    "other_kernels": {"gc_coefs_kernel": {
-                        "launch_ms": round(coef_ms, 3),
-                        "achieved": round(COEF_BYTES_PER_SAMPLE * nch * n / (coef_ms * 1e-3) / 1e9, 2) if coef_ms > 0 else 0.0}},
-                    "pipeline_achieved": round(PIPE_BYTES_PER_SAMPLE * nch * n / ((coef_ms + enc_ms) * 1e-3) / 1e9, 2)
-                    if coef_ms + enc_ms > 0 else 0.0,
-                    "issue": issue}
+    achieved = enc_bytes / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
+    # one encode = gc_encode_kernel<false> (all time pieces at once) + gc_encode_seam_kernel + gc_encode_kernel<true>
+    # (the repair launch: returns at once unless a seam stayed open); launch_ms spans the three, the rocprofv3
+    # kernel stats under profiles/ list them separately (their averages add up to it)
+    roofline = {"bound": "hbm", "kernel": "gc_encode_kernel", "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": traffic, "algorithmic_bytes_per_launch": enc_bytes, "launch_ms": round(enc_ms, 3),
+                "launch_parts": ["gc_encode_kernel<false>", "gc_encode_seam_kernel", "gc_encode_kernel<true>"],
+                "other_kernels": {"gc_coefs_kernel": {
+                    "launch_ms": round(coef_ms, 3),
+                    "achieved": round(COEF_BYTES_PER_SAMPLE * nch * n / (coef_ms * 1e-3) / 1e9, 2) if coef_ms > 0 else 0.0}},
+                "pipeline_achieved": round(PIPE_BYTES_PER_SAMPLE * nch * n / ((coef_ms + enc_ms) * 1e-3) / 1e9, 2)
+                if coef_ms + enc_ms > 0 else 0.0,
+                "issue": issue}
 
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:          # the CPU leg runs at N=1 only (rank 0's host cores)
-            threads, cpu_note = usable_cpus()
-            cch = args.cpu_channels or min(nch, 24 * threads)
-            host = pcm[:cch, :n].cpu().numpy()
-            from oracle import pyoracle as po                 # the oracle appears in this leg only
-            po.lib()
-            t1 = time.perf_counter()
-            ref_coefs, ref_adpcm = po.gc_encode_batch(host, threads=threads)
-            dt = time.perf_counter() - t1
-            # the baseline's output doubles as the checker of this run's: every sampled channel, bit for bit
-            nb = vdev.gc_byte_count(n)
-            if not (np.array_equal(coefs[:cch].cpu().numpy().reshape(cch, 16), np.asarray(ref_coefs).reshape(cch, 16)) and
-                    np.array_equal(adpcm[:cch, :nb].cpu().numpy(), np.asarray(ref_adpcm)[:, :nb])):
-                raise SystemExit("PARITY FAILURE: GPU output differs from the CPU restatement")
-            verified = cch
-            cpu = {"value": round(cch * n / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
-                   "sample": f"{cch} of the same channels x {n} samples, one task per channel on {threads} threads "
-                             f"({cpu_note}); C restatement of GcAdpcmFormat.EncodeFromPcm16 (the C# reference cannot "
-                             f"be built here), {dt:.1f} s wall"}
+    cpu = None
+    if not args.no_cpu_baseline and cx.world == 1:          # the CPU leg runs at N=1 only (rank 0's host cores)
+        threads, cpu_note = usable_cpus()
+        cch = args.cpu_channels or min(nch, 24 * threads)
+        host = pcm[:cch, :n].cpu().numpy()
+        from oracle import pyoracle as po                 # the oracle appears in this leg only
+        po.lib()
+        t1 = time.perf_counter()
+        ref_coefs, ref_adpcm = po.gc_encode_batch(host, threads=threads)
+        dt = time.perf_counter() - t1
+        # the baseline's output doubles as the checker of this run's: every sampled channel, bit for bit
+        nb = vdev.gc_byte_count(n)
+        if not (np.array_equal(coefs[:cch].cpu().numpy().reshape(cch, 16), np.asarray(ref_coefs).reshape(cch, 16)) and
+                np.array_equal(adpcm[:cch, :nb].cpu().numpy(), np.asarray(ref_adpcm)[:, :nb])):
+            raise SystemExit("PARITY FAILURE: GPU output differs from the CPU restatement")
+        verified = cch
+        cpu = {"value": round(cch * n / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
+               "sample": f"{cch} of the same channels x {n} samples, one task per channel on {threads} threads "
+                         f"({cpu_note}); C restatement of GcAdpcmFormat.EncodeFromPcm16 (the C# reference cannot "
+                         f"be built here), {dt:.1f} s wall",
+               "encode_benchmarks_single_thread": encode_benchmarks_single_thread(po, np)}
+        del host, ref_adpcm
 
-        out = {"metric": "Msamples/s encoded (GC-ADPCM, 4096 ch) at 1/2/4/8 GPUs; % HBM roofline",
-               "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-               "config": {"workload": f"BASELINE configs[1]: {nch} mono channels x 48 kHz x {args.seconds:g} s "
-                                      f"GC-ADPCM coefficient search + encode per GPU",
-                          "channels_per_gpu": nch, "samples_per_channel": n, "parallelism": f"channels sharded x{world}",
-                          "bit_exact_channels_checked": verified},
-               "roofline": roofline, "cpu_baseline": cpu}
-        if cpu:
-            out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 2)
+    out = base_line(args, cx, "Msamples/s encoded (GC-ADPCM, 4096 ch) at 1/2/4/8 GPUs; % HBM roofline", value, ms_per_step,
+                    "int32", f"BASELINE configs[1]: {nch} mono channels x 48 kHz x {args.seconds:g} s GC-ADPCM coefficient "
+                             f"search + encode per GPU",
+                    {"channels_per_gpu": nch, "samples_per_channel": n, "bit_exact_channels_checked": verified}, roofline, cpu)
+    if gather:
+        out["gather"] = gather
+    if not args.no_e2e and cx.world == 1:
+        out["e2e"] = measure_e2e(cx, args, pcm, n, coefs, adpcm)
+    return out
+
+
+# ====================================================================================================== CRI ADX
+def run_adx(args, cx):
+    import numpy as np
+    torch, vdev, L, lib = cx.torch, cx.vdev, cx.L, cx.lib
+    nch = args.channels
+    n = int(round(args.seconds * 48000))
+    pcm = vdev.synth_pcm(nch, n, cx.dev, first_channel=cx.rank * nch)
+    p = lib.AdxParams()
+    L.vga_adx_default_params(C.byref(p))
+    nb = L.vga_adx_encoded_byte_count(n, C.byref(p))
+    pitch = (nb + 15) // 16 * 16
+    adx = torch.zeros((nch, pitch), dtype=torch.uint8, device=cx.dev)
+    hist = torch.zeros(nch, dtype=torch.int16, device=cx.dev)
+    status = torch.zeros(1, dtype=torch.int32, device=cx.dev)
+    dec = vdev.alloc_pcm(nch, n, cx.dev)
+    torch.cuda.synchronize()
+
+    def step(events):
+        if events is not None:
+            events[0].record()
+        lib.check(L.vga_adx_encode_device(pcm.data_ptr(), pcm.stride(0), nch, n, C.byref(p), adx.data_ptr(), pitch,
+                                          hist.data_ptr(), cx.st()))
+        if events is not None:
+            events[1].record()
+        lib.check(L.vga_adx_decode_device(adx.data_ptr(), pitch, nb, nch, n, C.byref(p), dec.data_ptr(), dec.stride(0),
+                                          status.data_ptr(), cx.st()))
+        if events is not None:
+            events[2].record()
+
+    elapsed, evs = timed_steps(cx, args, step, 3)
+    if int(status.item()) != 0:
+        raise SystemExit("ADX decode reported a bad frame")
+    enc_ms, dec_ms = mean_ms(evs, 0, 1), mean_ms(evs, 1, 2)
+    ms_per_step = elapsed / max(args.steps, 1) * 1e3
+    value = nch * n * cx.world / (ms_per_step * 1e-3) / 1e6
+    if cx.rank != 0:
+        return None
+    bytes_launch = ADX_BYTES_PER_SAMPLE * nch * n
+    achieved = bytes_launch / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
+    pmc = load_profile_json("r02_pmc_traffic.json")
+    traffic = None
+    if pmc and nch == 4096 and n == 2880000:
+        traffic = (pmc.get("adx_encode_fs18_tiled_kernel") or {}).get("traffic_bytes_per_launch")
+    roofline = {"bound": "hbm", "kernel": "adx_encode_fs18_tiled_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": bytes_launch, "launch_ms": round(enc_ms, 3),
+                "launch_parts": ["adx_encode_fs18_tiled_kernel", "adx_encode_fs18_fixup_kernel", "adx_encode_fs18_tail_kernel"],
+                "other_kernels": {"adx_decode_fs18_tiled_kernel (+fixup, tail)": {
+                    "launch_ms": round(dec_ms, 3),
+                    "achieved": round(bytes_launch / (dec_ms * 1e-3) / 1e9, 2) if dec_ms > 0 else 0.0}},
+                "pipeline_achieved": round(2 * bytes_launch / ((enc_ms + dec_ms) * 1e-3) / 1e9, 2) if enc_ms + dec_ms > 0 else 0.0}
+    cpu, verified = None, 0
+    if not args.no_cpu_baseline and cx.world == 1:
+        threads, cpu_note = usable_cpus()
+        cch = args.cpu_channels or min(nch, 64 * threads)
+        host = pcm[:cch, :n].cpu().numpy()
+        from oracle import pyoracle as po
+        po.lib()
+        t1 = time.perf_counter()
+        want, whist = po.adx_encode_batch(host, po.adx_params(), threads=threads)
+        wdec = po.adx_decode_batch(want, n, po.adx_params(), threads=threads)
+        dt = time.perf_counter() - t1
+        if not (np.array_equal(adx[:cch, :nb].cpu().numpy(), want) and np.array_equal(hist[:cch].cpu().numpy(), whist) and
+                np.array_equal(dec[:cch, :n].cpu().numpy(), wdec)):
+            raise SystemExit("PARITY FAILURE: GPU ADX output differs from the CPU restatement")
+        verified = cch
+        cpu = {"value": round(cch * n / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
+               "sample": f"{cch} of the same channels x {n} samples, encode + decode, one task per channel on {threads} threads "
+                         f"({cpu_note}); C restatement of CriAdxFormat.EncodeFromPcm16 / ToPcm16, {dt:.1f} s wall"}
+    return base_line(args, cx, "Msamples/s (CRI ADX encode+decode round trip, 4096 ch)", value, ms_per_step, "int32",
+                     f"BASELINE configs[2]: {nch} mono channels x 48 kHz x {args.seconds:g} s CRI ADX (18-byte frames, v4, "
+                     f"linear) encode + decode round trip per GPU",
+                     {"channels_per_gpu": nch, "samples_per_channel": n, "bit_exact_channels_checked": verified}, roofline, cpu)
+
+
+# ====================================================================================================== CRI HCA
+def run_hca(args, cx):
+    import numpy as np
+    torch, vdev, L, lib = cx.torch, cx.vdev, cx.L, cx.lib
+    ns = args.streams
+    n = int(round(args.seconds * 48000))
+    hp = lib.HcaParamsC(2, 0, 0, 2, 48000, n, 0, 0, 0)            # quality High, stereo
+    info = lib.HcaInfoC()
+    lib.check(L.vga_hca_encoder_initialize(C.byref(hp), C.byref(info)))
+    spcm = vdev.synth_pcm(ns * 2, n, cx.dev, first_channel=cx.rank * ns * 2)     # [ns*2, pitch]: stream-major planar
+    ch_pitch = spcm.stride(0)
+    fbytes = info.frame_count * info.frame_size
+    fpitch = (fbytes + 8 + 15) // 16 * 16
+    frames = torch.zeros((ns, fpitch), dtype=torch.uint8, device=cx.dev)
+    status = torch.zeros(1, dtype=torch.int32, device=cx.dev)
+    wsb = L.vga_hca_decode_workspace_bytes(C.byref(info), ns)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=cx.dev)
+    dec = torch.zeros_like(spcm)
+    torch.cuda.synchronize()
+
+    def step(events):
+        if events is not None:
+            events[0].record()
+        lib.check(L.vga_hca_encode_device(spcm.data_ptr(), 2 * ch_pitch, ch_pitch, ns, n, C.byref(info), frames.data_ptr(), fpitch,
+                                          status.data_ptr(), cx.st()))
+        if events is not None:
+            events[1].record()
+
+    elapsed, evs = timed_steps(cx, args, step, 2)
+    enc_ms = mean_ms(evs, 0, 1)
+    # decode beside it (not part of the step)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for _ in range(2):
+        e[0].record()
+        lib.check(L.vga_hca_decode_device(C.byref(info), frames.data_ptr(), fpitch, ns, dec.data_ptr(), 2 * ch_pitch, ch_pitch,
+                                          ws.data_ptr(), wsb, status.data_ptr(), cx.st()))
+        e[1].record()
+        torch.cuda.synchronize()
+    dec_ms = e[0].elapsed_time(e[1])
+    if int(status.item()) != 0:
+        raise SystemExit("HCA kernels reported an error status")
+    ms_per_step = elapsed / max(args.steps, 1) * 1e3
+    chs = ns * 2 * n
+    value = chs * cx.world / (ms_per_step * 1e-3) / 1e6
+    if cx.rank != 0:
+        return None
+    bytes_launch = (2.0 + info.frame_size * info.frame_count / (2.0 * n)) * chs if n else 0.0
+    achieved = bytes_launch / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
+    pmc = load_profile_json("r02_pmc_traffic.json")
+    traffic = None
+    if pmc and ns == 1024 and n == 2880000:
+        traffic = (pmc.get("hca_encode_kernel") or {}).get("traffic_bytes_per_launch")
+    roofline = {"bound": "hbm", "kernel": "hca_encode_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes_per_launch": bytes_launch,
+                "launch_ms": round(enc_ms, 3),
+                "other_kernels": {"hca_unpack_kernel + hca_imdct_kernel (decode)": {
+                    "launch_ms": round(dec_ms, 3),
+                    "achieved": round(bytes_launch / (dec_ms * 1e-3) / 1e9, 2) if dec_ms > 0 else 0.0}},
+                "mfma": "the exact path uses no MFMA: a dense 128x128 DCT-IV reassociates the f64 sums (DESIGN.md 4.4; "
+                        "measured variant: tools/bench_hca_mfma.py, profiles/)"}
+    cpu, verified = None, 0
+    if not args.no_cpu_baseline and cx.world == 1:
+        threads, cpu_note = usable_cpus()
+        workers = max(1, threads - 1)                          # Cli/Batch.cs:25: ProcessorCount - 1 workers, one file each
+        cs = args.cpu_channels or min(ns, 16 * workers)
+        host = np.stack([spcm[2 * s:2 * s + 2, :n].cpu().numpy() for s in range(cs)])
+        from oracle import pyoracle as po
+        po.lib()
+        t1 = time.perf_counter()
+        rc, oinfo, want = po.hca_encode_batch(host, po.hca_params(2, n), threads=workers)
+        dt = time.perf_counter() - t1
+        if rc != 0 or not np.array_equal(frames[:cs, :fbytes].cpu().numpy(), want):
+            raise SystemExit("PARITY FAILURE: GPU HCA frames differ from the CPU restatement")
+        rc, wdec = po.hca_decode_batch(oinfo, want, threads=workers)
+        got = dec[:2 * cs, :n].cpu().numpy().reshape(cs, 2, n)
+        if rc != 0 or not np.array_equal(got, wdec):
+            raise SystemExit("PARITY FAILURE: GPU HCA decode differs from the CPU restatement")
+        verified = cs
+        cpu = {"value": round(cs * 2 * n / dt / 1e6, 3), "unit": "Msamples/s", "cores": workers, "kind": "port",
+               "sample": f"{cs} of the same stereo streams x {n} samples, encode only, one task per STREAM on {workers} workers "
+                         f"(the reference has no intra-file parallelism, CriHcaFormat.cs:53-81; Cli/Batch.cs:24-25 runs "
+                         f"ProcessorCount-1 files at a time; {cpu_note}); C restatement of CriHcaFormat.EncodeFromPcm16, {dt:.1f} s wall"}
+    return base_line(args, cx, "Msamples/s encoded (CRI HCA, 1024 stereo streams, quality High; channel-samples)", value, ms_per_step,
+                     "f64", f"BASELINE configs[3]: {ns} stereo streams x 48 kHz x {args.seconds:g} s CRI HCA encode, quality High "
+                            f"({info.frame_size}-byte frames, {info.frame_count} frames per stream) per GPU",
+                     {"streams_per_gpu": ns, "channels_per_stream": 2, "samples_per_channel": n, "bit_exact_streams_checked": verified},
+                     roofline, cpu)
+
+
+def main():
+    args = parse()
+    cx = setup(args)
+    out = {"gc": run_gc, "adx": run_adx, "hca": run_hca}[args.codec](args, cx)
+    if cx.rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
-
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if cx.world > 1:
+        cx.dist.barrier()
+        cx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

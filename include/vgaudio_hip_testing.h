@@ -17,6 +17,12 @@ extern "C" {
  * Returns the calling thread's previous mode. */
 int vga_testing_force_open_seams_this_thread(int mode);
 
+/* The host-pointer entry points (vga_*_batch) move data through a pipeline of feeder threads, pinned rings, per-chunk
+ * kernel launches and drainer threads (vgaudio_amd/csrc/host_pipeline.hpp); its shape normally follows the volume of
+ * the call.  Non-zero arguments override it for calls made FROM THE CALLING THREAD (0 = automatic): feeder / drainer
+ * thread counts, units (channels, streams) per chunk, bytes per ring slot.  Results must not depend on any of them. */
+void vga_testing_host_pipeline_this_thread(int feeders, int drainers, int chunk_units, int slot_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,98 @@
+// Drives vgaudio_amd/csrc/host_pipeline.hpp against tests/host/mockhip (asynchronous mock streams) on the CPU:
+// data integrity over ragged shapes, error propagation without hangs, pinned-pool reuse.  Built with
+// -fsanitize=thread by tests/test_host_pipeline.py.
+#include "../../vgaudio_amd/csrc/host_pipeline.hpp"
+
+#include <cstdio>
+#include <random>
+
+using namespace vga::pipe;
+
+static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t out_bytes, int chunk, int feeders, int drainers,
+                    size_t slot_bytes, int delay_us, int fail_after, bool compute_fails)
+{
+    const size_t in_pitch = (in_bytes + 15) / 16 * 16, out_pitch = (out_bytes + 15) / 16 * 16;
+    const int in_rows = units * in_rpu, out_rows = units * out_rpu;
+    std::vector<std::vector<unsigned char>> in(in_rows, std::vector<unsigned char>(in_bytes)), out(out_rows, std::vector<unsigned char>(out_bytes, 0xEE));
+    std::mt19937 rng(units * 131 + chunk);
+    for (auto &r : in) for (auto &b : r) b = (unsigned char)rng();
+    std::vector<const void *> in_ptrs(in_rows);
+    std::vector<void *> out_ptrs(out_rows);
+    for (int r = 0; r < in_rows; r++) in_ptrs[r] = in[r].data();
+    for (int r = 0; r < out_rows; r++) out_ptrs[r] = out[r].data();
+    std::vector<char> d_in((size_t)in_rows * in_pitch + 64, 0x11), d_out((size_t)out_rows * out_pitch + 64, 0x22);
+
+    Job job;
+    job.units = units;
+    job.chunk_units = chunk;
+    job.in_rows_per_unit = in_rpu;
+    job.in_rows = in_ptrs.data();
+    job.in_row_bytes = in_bytes;
+    job.d_in = d_in.data();
+    job.d_in_pitch = in_pitch;
+    job.out_rows_per_unit = out_rpu;
+    job.out_rows = out_ptrs.data();
+    job.out_row_bytes = out_bytes;
+    job.d_out = d_out.data();
+    job.d_out_pitch = out_pitch;
+    job.feeders = feeders;
+    job.drainers = drainers;
+    job.slot_bytes = slot_bytes;
+    int launches = 0;
+    // "kernel": output row (u, j) byte i = sum over the unit's input rows of byte (i mod in_bytes), plus j and i
+    job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
+        launches++;
+        if (compute_fails && first > 0) {
+            why = "compute refused";
+            return -3;
+        }
+        mockLaunch(s, [&, first, count] {
+            for (int u = first; u < first + count; u++)
+                for (int j = 0; j < out_rpu; j++)
+                    for (size_t i = 0; i < out_bytes; i++) {
+                        unsigned v = (unsigned)j + (unsigned)i;
+                        for (int k = 0; k < in_rpu; k++) v += (unsigned char)d_in[(size_t)(u * in_rpu + k) * in_pitch + i % in_bytes];
+                        d_out[(size_t)(u * out_rpu + j) * out_pitch + i] = (char)v;
+                    }
+        });
+        return 0;
+    };
+    mock_copy_delay_us() = delay_us;
+    mock_fail_memcpy_after() = fail_after;
+    const Result r = run(job);
+    mock_fail_memcpy_after() = -1;
+    mock_copy_delay_us() = 0;
+    if (fail_after >= 0 || compute_fails) {
+        if (r.code == 0) { std::printf("expected a failure (units %d)\n", units); return 1; }
+        return 0;
+    }
+    if (r.code != 0) { std::printf("unexpected failure %d: %s\n", r.code, r.why.c_str()); return 1; }
+    for (int u = 0; u < units; u++)
+        for (int j = 0; j < out_rpu; j++)
+            for (size_t i = 0; i < out_bytes; i++) {
+                unsigned v = (unsigned)j + (unsigned)i;
+                for (int k = 0; k < in_rpu; k++) v += in[u * in_rpu + k][i % in_bytes];
+                if (out[u * out_rpu + j][i] != (unsigned char)v) {
+                    std::printf("mismatch: units %d chunk %d unit %d row %d byte %zu\n", units, chunk, u, j, i);
+                    return 1;
+                }
+            }
+    return 0;
+}
+
+int main()
+{
+    int bad = 0;
+    // units, in_rpu, out_rpu, in_bytes, out_bytes, chunk, feeders, drainers, slot_bytes, delay, fail_after, compute_fails
+    bad += run_case(1, 1, 1, 100, 40, 0, 8, 4, 1 << 20, 0, -1, false);
+    bad += run_case(37, 1, 1, 1000, 300, 8, 8, 4, 2048, 20, -1, false);           // ragged last chunk, several rows per slot
+    bad += run_case(64, 2, 1, 513, 77, 16, 3, 2, 512, 50, -1, false);             // stream-like units, one row per slot
+    bad += run_case(5, 1, 3, 64, 64, 1, 8, 8, 1 << 20, 10, -1, false);            // more workers than rows
+    bad += run_case(200, 1, 1, 4096, 1200, 50, 8, 4, 16384, 5, -1, false);
+    bad += run_case(33, 1, 1, 256, 64, 4, 4, 2, 1024, 30, 7, false);              // a copy fails mid-way: error, no hang
+    bad += run_case(33, 1, 1, 256, 64, 4, 4, 2, 1024, 30, 0, false);
+    bad += run_case(40, 1, 1, 256, 64, 8, 4, 2, 1024, 10, -1, true);              // the compute callback refuses the 2nd chunk
+    PinnedPool::get().trim();
+    std::printf(bad ? "FAILED %d\n" : "ok\n", bad);
+    return bad ? 1 : 0;
+}

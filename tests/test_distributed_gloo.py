@@ -1,5 +1,6 @@
 """world_size-2 gloo test of the N>1 path on CPU: contiguous channel sharding, no data-path
-collective, one all_gather of the per-channel coefficients, max-over-ranks timing.  Each rank's
+collective, the final gather of every rank's bitstream and coefficients to rank 0 (BitstreamGather,
+SURVEY.md 8e), max-over-ranks timing.  Each rank's
 "device work" is stood in for by the oracle (checker) so the gathered result can be compared
 with a single-process run over all channels."""
 import os
@@ -45,8 +46,20 @@ WORKER = textwrap.dedent("""
     tmax = vd.max_over_ranks(dt, torch.device("cpu"))
     assert tmax >= dt
     np.save(os.path.join({out!r}, f"adpcm_{{rank}}.npy"), adpcm)
+    # SURVEY.md 8e: the final gather of the BITSTREAM (and coefficients) to rank 0, in channel chunks
+    pitch = (adpcm.shape[1] + 15) // 16 * 16
+    rows = torch.zeros((count, pitch), dtype=torch.uint8)
+    rows[:, :adpcm.shape[1]] = torch.from_numpy(np.ascontiguousarray(adpcm))
+    g = vd.BitstreamGather(counts, pitch, torch.device("cpu"), chunk_channels=2)
+    g.gather(rows, torch.from_numpy(coefs).reshape(count, 16))
+    works = g.gather(rows, torch.from_numpy(coefs).reshape(count, 16), async_op=True)      # and the asynchronous form
+    for w in works:
+        w.wait()
     if rank == 0:
         np.save(os.path.join({out!r}, "coefs_all.npy"), allc.numpy())
+        np.save(os.path.join({out!r}, "gathered_adpcm.npy"), g.all_adpcm[:, :adpcm.shape[1]].numpy())
+        np.save(os.path.join({out!r}, "gathered_coefs.npy"), g.all_coefs.numpy())
+        assert g.verify(rows, torch.from_numpy(coefs).reshape(count, 16), adpcm.shape[1]).startswith("own rows identical")
     dist.barrier()
     dist.destroy_process_group()
 """)
@@ -68,3 +81,6 @@ def test_two_rank_gloo_sharded_encode(tmp_path):
     assert (got == coefs).all()
     parts = np.concatenate([np.load(tmp_path / f"adpcm_{r}.npy") for r in range(2)])
     assert (parts == adpcm).all()
+    # the gathered bitstream on rank 0 is the single-process result, channel for channel
+    assert (np.load(tmp_path / "gathered_adpcm.npy") == adpcm).all()
+    assert (np.load(tmp_path / "gathered_coefs.npy").reshape(7, 16) == np.asarray(coefs).reshape(7, 16)).all()

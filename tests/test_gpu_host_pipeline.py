@@ -1,0 +1,64 @@
+"""The host-pointer entry points run a pipeline (feeders -> pinned rings -> per-chunk kernels -> drainers,
+vgaudio_amd/csrc/host_pipeline.hpp).  Its shape normally follows the volume of the call; here the test hook forces
+many workers, tiny ring slots and small chunks on small inputs, and the results must equal the default shape's and
+the oracle's, byte for byte."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from vgaudio_amd import _lib, synth
+from vgaudio_amd.criadx import CriAdxCodec, CriAdxParameters
+from vgaudio_amd.crihca import CriHcaDecoder, CriHcaFormat, CriHcaParameters
+from vgaudio_amd.gcadpcm import GcAdpcmDecoder, GcAdpcmFormat, GcAdpcmParameters, Pcm16Format
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(0, 0, 0, 0), (5, 3, 7, 4096), (8, 4, 1, 1), (1, 1, 1000, 1 << 20), (3, 8, 13, 30000)]
+
+
+@pytest.fixture(params=SHAPES, ids=[str(s) for s in SHAPES])
+def shape(request):
+    L = _lib.lib()
+    L.vga_testing_host_pipeline_this_thread(*request.param)
+    yield request.param
+    L.vga_testing_host_pipeline_this_thread(0, 0, 0, 0)
+
+
+def test_gc_encode_and_decode_through_every_pipeline_shape(shape):
+    nch, n = 37, 14 * 900 + 5
+    pcm = synth.generate(nch, n)
+    fmt = GcAdpcmFormat().EncodeFromPcm16(Pcm16Format(list(pcm), 48000))
+    wc, wa = po.gc_encode_batch(pcm, threads=4)
+    for c in range(nch):
+        assert fmt.Channels[c].Coefs.tolist() == np.asarray(wc).reshape(nch, 16)[c].tolist(), c
+        assert np.array_equal(fmt.Channels[c].GetAdpcmAudio(), np.asarray(wa)[c][:len(fmt.Channels[c].GetAdpcmAudio())]), c
+    dec = GcAdpcmDecoder.Decode([ch.GetAdpcmAudio() for ch in fmt.Channels], np.stack([ch.Coefs for ch in fmt.Channels]),
+                                GcAdpcmParameters(SampleCount=n))
+    want = po.gc_decode_batch(np.stack([ch.GetAdpcmAudio() for ch in fmt.Channels]), np.asarray(wc).reshape(nch, 16), n, threads=4)
+    assert np.array_equal(np.stack(dec), want)
+
+
+def test_adx_through_every_pipeline_shape(shape):
+    nch, n = 29, 32 * 300 + 13
+    pcm = synth.generate(nch, n)
+    cfg = CriAdxParameters()
+    enc = CriAdxCodec.Encode(list(pcm), cfg)
+    want, hist = po.adx_encode_batch(pcm, po.adx_params(), threads=4)
+    assert np.array_equal(np.stack(enc), want) and np.array_equal(np.asarray(cfg.History), hist)
+    dec = CriAdxCodec.Decode(enc, n, CriAdxParameters())
+    assert np.array_equal(np.stack(dec), po.adx_decode_batch(want, n, po.adx_params(), threads=4))
+
+
+def test_hca_through_every_pipeline_shape(shape):
+    ns, n = 11, 6000
+    streams = [synth.generate(2, n, first_channel=2 * s) for s in range(ns)]
+    fmts = CriHcaFormat.EncodeBatchFromPcm16([Pcm16Format(list(s), 48000) for s in streams], CriHcaParameters())
+    rc, info, want = po.hca_encode_batch(np.stack(streams), po.hca_params(2, n), threads=4)
+    assert rc == 0
+    for s in range(ns):
+        assert np.array_equal(fmts[s].AudioData.reshape(-1), want[s]), s
+    dec = CriHcaDecoder.Decode(fmts[0].Hca, [f.AudioData for f in fmts])
+    rc, wdec = po.hca_decode_batch(info, want, threads=4)
+    assert rc == 0
+    for s in range(ns):
+        assert np.array_equal(np.stack(dec[s]), wdec[s]), s

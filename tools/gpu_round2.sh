@@ -1,0 +1,50 @@
+#!/bin/bash
+# One GPU-box visit (round 2).  Stages are chosen with STAGES="smoke tests bench prof pmc sq"; everything under timeouts,
+# everything written to gpurun_out/r02/.
+STAGES=${STAGES:-"smoke tests bench prof"}
+O=$GRAFT_REPO_ROOT/gpurun_out/r02
+mkdir -p $O
+cd $GRAFT_REPO_ROOT
+has() { [[ " $STAGES " == *" $1 "* ]]; }
+if has smoke; then
+  timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
+fi
+if has tests; then
+  timeout ${TEST_TIMEOUT:-1500} python -m pytest tests -m gpu -x -q --timeout=600 ${TEST_ARGS:-} > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -5 $O/pytest_gpu.log
+fi
+if has bench; then
+  for c in gc adx hca; do
+    timeout 900 python bench.py --codec $c --steps ${BENCH_STEPS:-5} --warmup 2 > $O/bench_$c.json.log 2> $O/bench_$c.err; echo "bench $c rc=$?"; tail -c 1500 $O/bench_$c.json.log
+  done
+fi
+if has prof; then
+  cd /tmp && export TMPDIR=/tmp
+  for c in gc adx hca; do
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$c -o r02 -- python $GRAFT_REPO_ROOT/bench.py --codec $c --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > $O/prof_$c.log 2>&1; echo "rocprof $c rc=$?"
+    f=$(find $O/prof_$c -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && head -8 $f | cut -c1-220
+  done
+  cd $GRAFT_REPO_ROOT
+fi
+if has pmc; then
+  cd /tmp && export TMPDIR=/tmp
+  for c in ${PMC_CODECS:-gc adx hca}; do
+    for k in FETCH_SIZE WRITE_SIZE; do
+      timeout 600 rocprofv3 --pmc $k --kernel-trace --output-format csv -d $O/pmc_${c}_$k -o pmc -- python $GRAFT_REPO_ROOT/bench.py --codec $c --steps 2 --warmup 0 --no-cpu-baseline --no-e2e > $O/pmc_${c}_$k.log 2>&1; echo "pmc $c $k rc=$?"
+    done
+  done
+  cd $GRAFT_REPO_ROOT
+  python tools/summarize_pmc.py traffic $O/r02_pmc_traffic.json $O/pmc_gc_FETCH_SIZE $O/pmc_gc_WRITE_SIZE $O/pmc_adx_FETCH_SIZE $O/pmc_adx_WRITE_SIZE $O/pmc_hca_FETCH_SIZE $O/pmc_hca_WRITE_SIZE | tail -60
+  # the raw per-dispatch CSVs are tens of MB: keep the summaries only
+  find $O -name "pmc_*" -type d -exec rm -rf {} + 2>/dev/null
+fi
+if has sq; then
+  cd /tmp && export TMPDIR=/tmp
+  for c in ${SQ_CODECS:-gc adx hca}; do
+    timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/sq_${c}_a -o pmc -- python $GRAFT_REPO_ROOT/bench.py --codec $c --steps 1 --warmup 0 --no-cpu-baseline --no-e2e > $O/sq_${c}_a.log 2>&1; echo "sq $c a rc=$?"
+    timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_F64 --kernel-trace --output-format csv -d $O/sq_${c}_b -o pmc -- python $GRAFT_REPO_ROOT/bench.py --codec $c --steps 1 --warmup 0 --no-cpu-baseline --no-e2e > $O/sq_${c}_b.log 2>&1; echo "sq $c b rc=$?"
+  done
+  cd $GRAFT_REPO_ROOT
+  python tools/summarize_pmc.py sq $O/r02_sq_counters.json $O/sq_gc_a $O/sq_gc_b $O/sq_adx_a $O/sq_adx_b $O/sq_hca_a $O/sq_hca_b | tail -80
+  find $O -name "sq_*" -type d -exec rm -rf {} + 2>/dev/null
+fi
+ls $O | head -40

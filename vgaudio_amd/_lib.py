@@ -113,6 +113,7 @@ SIGNATURES = {
     "vga_hca_crypt": (ci, [u8p, ci, ci, u8p]),
     "vga_hca_crypt_device": (ci, [vp, i64, ci, ci, ci, u8p, vp]),
     "vga_testing_force_open_seams_this_thread": (ci, [ci]),
+    "vga_testing_host_pipeline_this_thread": (None, [ci, ci, ci, ci]),
     "vga_dsp_layout_for": (ci, [vp, ci, vp]),
     "vga_dsp_write": (ci, [u8pp, ci, i16p, i16p, i16p, i16p, ci, vp, u8p]),
     "vga_dsp_write_device": (ci, [vp, i64, ci, vp, vp, vp, vp, ci, vp, vp, vp]),

@@ -1,5 +1,6 @@
 // capi_adx.hip -- C-ABI entry points for CRI ADX (see include/vgaudio_hip.h).
 #include "common.hpp"
+#include "host_batch.hpp"
 #include "adx_kernels.hpp"
 
 #include <cmath>
@@ -59,6 +60,9 @@ adx::AdxDeviceParams device_params(const vga_adx_params *p, bool encode)
 }
 
 }  // namespace
+
+// channels per chunk of the host pipeline (host_pipeline.hpp): the tiled kernels fill the chip from 1024 channels on
+static constexpr int ADX_CHUNK_CHANNELS = 1024;
 
 extern "C" {
 
@@ -153,8 +157,6 @@ int vga_adx_encode_batch(const int16_t *const *pcm, int nch, int pcm_length, con
         return VGA_ERR_ARGUMENT;
     }
     if (int rc = require_device()) return rc;
-    Stream st;
-    VGA_HIP_TRY(st.create());
     DevBuf d_pcm, d_out, d_hist;
     const int64_t pcm_pitch = round_up(pcm_length > 0 ? pcm_length : 1, 8);
     const int nbytes = vga_adx_encoded_byte_count(pcm_length, p);
@@ -162,19 +164,29 @@ int vga_adx_encode_batch(const int16_t *const *pcm, int nch, int pcm_length, con
     VGA_HIP_TRY(d_pcm.alloc((size_t)nch * pcm_pitch * 2));
     VGA_HIP_TRY(d_out.alloc((size_t)nch * out_pitch));
     VGA_HIP_TRY(d_hist.alloc((size_t)nch * 2));
-    for (int c = 0; c < nch; c++)
-        if (pcm_length > 0)
-            VGA_HIP_TRY(hipMemcpyAsync(d_pcm.as<int16_t>() + (int64_t)c * pcm_pitch, pcm[c], (size_t)pcm_length * 2,
-                                       hipMemcpyHostToDevice, st.s));
-    if (int rc = adx::launch_encode(d_pcm.as<int16_t>(), pcm_pitch, nch, pcm_length, device_params(p, true),
-                                    d_out.as<uint8_t>(), out_pitch, d_hist.as<int16_t>(), st.s))
+    const adx::AdxDeviceParams dp = device_params(p, true);
+    pipe::Job job;
+    job.units = nch;
+    if (pcm_length > 0) {
+        job.in_rows = (const void *const *)pcm;
+        job.in_row_bytes = (size_t)pcm_length * 2;
+        job.d_in = d_pcm.as<char>();
+        job.d_in_pitch = (size_t)pcm_pitch * 2;
+    }
+    if (nbytes > 0) {
+        job.out_rows = (void *const *)out;
+        job.out_row_bytes = (size_t)nbytes;
+        job.d_out = d_out.as<char>();
+        job.d_out_pitch = (size_t)out_pitch;
+    }
+    job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
+        const int rc = adx::launch_encode(d_pcm.as<int16_t>() + (int64_t)first * pcm_pitch, pcm_pitch, count, pcm_length, dp,
+                                          d_out.as<uint8_t>() + (int64_t)first * out_pitch, out_pitch, d_hist.as<int16_t>() + first, s);
+        if (rc) why = vga_last_error();
         return rc;
-    for (int c = 0; c < nch; c++)
-        if (nbytes > 0)
-            VGA_HIP_TRY(hipMemcpyAsync(out[c], d_out.as<uint8_t>() + (int64_t)c * out_pitch, (size_t)nbytes,
-                                       hipMemcpyDeviceToHost, st.s));
-    if (history_out) VGA_HIP_TRY(hipMemcpyAsync(history_out, d_hist.p, (size_t)nch * 2, hipMemcpyDeviceToHost, st.s));
-    VGA_HIP_TRY(hipStreamSynchronize(st.s));
+    };
+    if (int rc = run_batch_pipeline(job, ADX_CHUNK_CHANNELS)) return rc;
+    if (history_out) VGA_HIP_TRY(hipMemcpy(history_out, d_hist.p, (size_t)nch * 2, hipMemcpyDeviceToHost));
     return VGA_OK;
 }
 
@@ -195,27 +207,33 @@ int vga_adx_decode_batch(const uint8_t *const *adpcm, int adpcm_length, int nch,
         return VGA_ERR_ARGUMENT;
     }
     if (int rc = require_device()) return rc;
-    Stream st;
-    VGA_HIP_TRY(st.create());
     DevBuf d_in, d_pcm, d_status;
     const int64_t in_pitch = round_up(adpcm_length, 16);
     const int64_t pcm_pitch = round_up(sample_count, 8);
     VGA_HIP_TRY(d_in.alloc((size_t)nch * in_pitch));
     VGA_HIP_TRY(d_pcm.alloc((size_t)nch * pcm_pitch * 2));
     VGA_HIP_TRY(d_status.alloc(sizeof(int)));
-    VGA_HIP_TRY(hipMemsetAsync(d_status.p, 0, sizeof(int), st.s));
-    for (int c = 0; c < nch; c++)
-        VGA_HIP_TRY(hipMemcpyAsync(d_in.as<uint8_t>() + (int64_t)c * in_pitch, adpcm[c], (size_t)adpcm_length,
-                                   hipMemcpyHostToDevice, st.s));
-    if (int rc = adx::launch_decode(d_in.as<uint8_t>(), in_pitch, nch, sample_count, device_params(p, false),
-                                    d_pcm.as<int16_t>(), pcm_pitch, d_status.as<int>(), st.s))
+    VGA_HIP_TRY(hipMemset(d_status.p, 0, sizeof(int)));
+    const adx::AdxDeviceParams dp = device_params(p, false);
+    pipe::Job job;
+    job.units = nch;
+    job.in_rows = (const void *const *)adpcm;
+    job.in_row_bytes = (size_t)adpcm_length;
+    job.d_in = d_in.as<char>();
+    job.d_in_pitch = (size_t)in_pitch;
+    job.out_rows = (void *const *)pcm_out;
+    job.out_row_bytes = (size_t)sample_count * 2;
+    job.d_out = d_pcm.as<char>();
+    job.d_out_pitch = (size_t)pcm_pitch * 2;
+    job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
+        const int rc = adx::launch_decode(d_in.as<uint8_t>() + (int64_t)first * in_pitch, in_pitch, count, sample_count, dp,
+                                          d_pcm.as<int16_t>() + (int64_t)first * pcm_pitch, pcm_pitch, d_status.as<int>(), s);
+        if (rc) why = vga_last_error();
         return rc;
+    };
+    if (int rc = run_batch_pipeline(job, ADX_CHUNK_CHANNELS)) return rc;
     int status = 0;
-    VGA_HIP_TRY(hipMemcpyAsync(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost, st.s));
-    for (int c = 0; c < nch; c++)
-        VGA_HIP_TRY(hipMemcpyAsync(pcm_out[c], d_pcm.as<int16_t>() + (int64_t)c * pcm_pitch, (size_t)sample_count * 2,
-                                   hipMemcpyDeviceToHost, st.s));
-    VGA_HIP_TRY(hipStreamSynchronize(st.s));
+    VGA_HIP_TRY(hipMemcpy(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost));
     if (status != 0) {
         set_error("a frame names a filter the coefficient table lacks (IndexOutOfRangeException in the reference)");
         return VGA_ERR_ARGUMENT;

@@ -1,5 +1,6 @@
 // capi_gcadpcm.hip -- C-ABI entry points for GC-ADPCM (see include/vgaudio_hip.h).
 #include "common.hpp"
+#include "host_batch.hpp"
 #include "../../include/vgaudio_hip_testing.h"
 
 #include <algorithm>
@@ -22,6 +23,9 @@ void set_error(const char *fmt, ...)
 // test hook (include/vgaudio_hip_testing.h): per calling thread, so that no call on another thread is affected
 static thread_local int g_force_open_seams = 0;
 int force_open_seams() { return g_force_open_seams; }
+
+static thread_local PipeOverride g_pipe_override;
+PipeOverride &pipe_override() { return g_pipe_override; }
 
 int require_device()
 {
@@ -52,6 +56,13 @@ int vga_testing_force_open_seams_this_thread(int mode)
     const int old = g_force_open_seams;
     g_force_open_seams = mode;
     return old;
+}
+void vga_testing_host_pipeline_this_thread(int feeders, int drainers, int chunk_units, int slot_bytes)
+{
+    g_pipe_override.feeders = feeders;
+    g_pipe_override.drainers = drainers;
+    g_pipe_override.chunk_units = chunk_units;
+    g_pipe_override.slot_bytes = slot_bytes;
 }
 const char *vga_version(void) { return "vgaudio_hip 0.1 (gfx950)"; }
 
@@ -376,18 +387,6 @@ struct GcBatch {
     int64_t pcm_pitch = 0, adpcm_pitch = 0;
 };
 
-int upload_pcm(GcBatch &b, const int16_t *const *pcm, int nch, int n)
-{
-    b.pcm_pitch = round_up(n > 0 ? n : 1, 8);
-    VGA_HIP_TRY(b.pcm.alloc((size_t)nch * b.pcm_pitch * sizeof(int16_t)));
-    for (int c = 0; c < nch; c++) {
-        if (n > 0)
-            VGA_HIP_TRY(hipMemcpyAsync(b.pcm.as<int16_t>() + (int64_t)c * b.pcm_pitch, pcm[c],
-                                       (size_t)n * sizeof(int16_t), hipMemcpyHostToDevice, b.st.s));
-    }
-    return VGA_OK;
-}
-
 int upload_hist(GcBatch &b, int nch, const int16_t *h1, const int16_t *h2)
 {
     if (h1) {
@@ -421,6 +420,10 @@ int download_adpcm(GcBatch &b, uint8_t *const *adpcm_out, int nch, int nbytes)
 
 }  // namespace
 
+// Channels per pipeline chunk (host path): small enough that the first kernels start after a quarter
+// of configs[1] has arrived, large enough that the coefficient kernel (one wave per channel) still has a wave per SIMD.
+static constexpr int GC_CHUNK_CHANNELS = 1024;
+
 int vga_gcadpcm_calculate_coefficients_batch(const int16_t *const *pcm, int nch, int length, int16_t *coefs_out)
 {
     if (length < 0) { set_error("negative length"); return VGA_ERR_ARGUMENT; }
@@ -429,14 +432,27 @@ int vga_gcadpcm_calculate_coefficients_batch(const int16_t *const *pcm, int nch,
     if (nch == 0) return VGA_OK;
     if (int rc = require_device()) return rc;
     GcBatch b;
-    VGA_HIP_TRY(b.st.create());
-    if (int rc = upload_pcm(b, pcm, nch, length)) return rc;
+    b.pcm_pitch = round_up(length > 0 ? length : 1, 8);
+    VGA_HIP_TRY(b.pcm.alloc((size_t)nch * b.pcm_pitch * sizeof(int16_t)));
     VGA_HIP_TRY(b.coefs.alloc((size_t)nch * 32));
-    VGA_HIP_TRY(b.ws.alloc(vga_gcadpcm_coefs_workspace_bytes(nch, length)));
-    if (int rc = gc::launch_coefs(b.pcm.as<int16_t>(), b.pcm_pitch, nch, length, b.coefs.as<int16_t>(), b.ws.p, b.st.s))
+    pipe::Job job;
+    job.units = nch;
+    if (length > 0) {
+        job.in_rows = (const void *const *)pcm;
+        job.in_row_bytes = (size_t)length * sizeof(int16_t);
+        job.d_in = b.pcm.as<char>();
+        job.d_in_pitch = (size_t)b.pcm_pitch * sizeof(int16_t);
+    }
+    job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
+        const int rc = gc::launch_coefs(b.pcm.as<int16_t>() + (int64_t)first * b.pcm_pitch, b.pcm_pitch, count, length,
+                                        b.coefs.as<int16_t>() + (int64_t)first * 16, b.ws.p, s);
+        if (rc) why = vga_last_error();
         return rc;
-    VGA_HIP_TRY(hipMemcpyAsync(coefs_out, b.coefs.p, (size_t)nch * 32, hipMemcpyDeviceToHost, b.st.s));
-    VGA_HIP_TRY(hipStreamSynchronize(b.st.s));
+    };
+    // one chunk's workspace: the chunks' kernels run one after the other on the compute stream
+    VGA_HIP_TRY(b.ws.alloc(vga_gcadpcm_coefs_workspace_bytes(planned_chunk_units(job, GC_CHUNK_CHANNELS), length)));
+    if (int rc = run_batch_pipeline(job, GC_CHUNK_CHANNELS)) return rc;
+    VGA_HIP_TRY(hipMemcpy(coefs_out, b.coefs.p, (size_t)nch * 32, hipMemcpyDeviceToHost));
     return VGA_OK;
 }
 
@@ -457,19 +473,34 @@ int vga_gcadpcm_encode_with_coefs_batch(const int16_t *const *pcm, int nch, int 
     if (int rc = require_device()) return rc;
     GcBatch b;
     VGA_HIP_TRY(b.st.create());
-    if (int rc = upload_pcm(b, pcm, nch, sample_count)) return rc;
+    b.pcm_pitch = round_up(sample_count, 8);
+    VGA_HIP_TRY(b.pcm.alloc((size_t)nch * b.pcm_pitch * sizeof(int16_t)));
     if (int rc = upload_hist(b, nch, hist1, hist2)) return rc;
     VGA_HIP_TRY(b.coefs.alloc((size_t)nch * 32));
     VGA_HIP_TRY(hipMemcpyAsync(b.coefs.p, coefs, (size_t)nch * 32, hipMemcpyHostToDevice, b.st.s));
+    VGA_HIP_TRY(hipStreamSynchronize(b.st.s));
     const int nbytes = vga_gcadpcm_sample_count_to_byte_count(sample_count);
     b.adpcm_pitch = round_up(nbytes, 16);
     VGA_HIP_TRY(b.adpcm.alloc((size_t)nch * b.adpcm_pitch));
-    if (int rc = gc::launch_encode(b.pcm.as<int16_t>(), b.pcm_pitch, nch, sample_count, b.coefs.as<int16_t>(),
-                                   b.h1.as<int16_t>(), b.h2.as<int16_t>(), b.adpcm.as<uint8_t>(), b.adpcm_pitch, b.st.s))
+    pipe::Job job;
+    job.units = nch;
+    job.in_rows = (const void *const *)pcm;
+    job.in_row_bytes = (size_t)sample_count * sizeof(int16_t);
+    job.d_in = b.pcm.as<char>();
+    job.d_in_pitch = (size_t)b.pcm_pitch * sizeof(int16_t);
+    job.out_rows = (void *const *)adpcm_out;
+    job.out_row_bytes = (size_t)nbytes;
+    job.d_out = b.adpcm.as<char>();
+    job.d_out_pitch = (size_t)b.adpcm_pitch;
+    job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
+        const int rc = gc::launch_encode(b.pcm.as<int16_t>() + (int64_t)first * b.pcm_pitch, b.pcm_pitch, count, sample_count,
+                                         b.coefs.as<int16_t>() + (int64_t)first * 16,
+                                         b.h1.p ? b.h1.as<int16_t>() + first : nullptr, b.h2.p ? b.h2.as<int16_t>() + first : nullptr,
+                                         b.adpcm.as<uint8_t>() + (int64_t)first * b.adpcm_pitch, b.adpcm_pitch, s);
+        if (rc) why = vga_last_error();
         return rc;
-    if (int rc = download_adpcm(b, adpcm_out, nch, nbytes)) return rc;
-    VGA_HIP_TRY(hipStreamSynchronize(b.st.s));
-    return VGA_OK;
+    };
+    return run_batch_pipeline(job, GC_CHUNK_CHANNELS);
 }
 
 int vga_gcadpcm_encode_batch(const int16_t *const *pcm, int nch, int sample_count, int16_t hist1, int16_t hist2,
@@ -483,26 +514,46 @@ int vga_gcadpcm_encode_batch(const int16_t *const *pcm, int nch, int sample_coun
     if (int rc = require_device()) return rc;
     GcBatch b;
     VGA_HIP_TRY(b.st.create());
-    if (int rc = upload_pcm(b, pcm, nch, sample_count)) return rc;
+    b.pcm_pitch = round_up(sample_count > 0 ? sample_count : 1, 8);
+    VGA_HIP_TRY(b.pcm.alloc((size_t)nch * b.pcm_pitch * sizeof(int16_t)));
     std::vector<int16_t> h1v((size_t)nch, hist1), h2v((size_t)nch, hist2);
     const bool use_hist = hist1 != 0 || hist2 != 0;
     if (use_hist)
         if (int rc = upload_hist(b, nch, h1v.data(), h2v.data())) return rc;
+    VGA_HIP_TRY(hipStreamSynchronize(b.st.s));
     VGA_HIP_TRY(b.coefs.alloc((size_t)nch * 32));
-    VGA_HIP_TRY(b.ws.alloc(vga_gcadpcm_coefs_workspace_bytes(nch, sample_count)));
     const int nbytes = vga_gcadpcm_sample_count_to_byte_count(sample_count);
     b.adpcm_pitch = round_up(nbytes > 0 ? nbytes : 1, 16);
     VGA_HIP_TRY(b.adpcm.alloc((size_t)nch * b.adpcm_pitch));
-    // EncodeChannel (GcAdpcmFormat.cs:129-135): coefficients, then encode
-    if (int rc = gc::launch_coefs(b.pcm.as<int16_t>(), b.pcm_pitch, nch, sample_count, b.coefs.as<int16_t>(), b.ws.p,
-                                  b.st.s))
+    pipe::Job job;
+    job.units = nch;
+    if (sample_count > 0) {
+        job.in_rows = (const void *const *)pcm;
+        job.in_row_bytes = (size_t)sample_count * sizeof(int16_t);
+        job.d_in = b.pcm.as<char>();
+        job.d_in_pitch = (size_t)b.pcm_pitch * sizeof(int16_t);
+        job.out_rows = (void *const *)adpcm_out;
+        job.out_row_bytes = (size_t)nbytes;
+        job.d_out = b.adpcm.as<char>();
+        job.d_out_pitch = (size_t)b.adpcm_pitch;
+    }
+    // EncodeChannel (GcAdpcmFormat.cs:129-135): coefficients, then encode -- per chunk of channels, so that the next
+    // chunk's upload and the previous chunk's download overlap these kernels
+    job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
+        int rc = gc::launch_coefs(b.pcm.as<int16_t>() + (int64_t)first * b.pcm_pitch, b.pcm_pitch, count, sample_count,
+                                  b.coefs.as<int16_t>() + (int64_t)first * 16, b.ws.p, s);
+        if (!rc)
+            rc = gc::launch_encode(b.pcm.as<int16_t>() + (int64_t)first * b.pcm_pitch, b.pcm_pitch, count, sample_count,
+                                   b.coefs.as<int16_t>() + (int64_t)first * 16,
+                                   b.h1.p ? b.h1.as<int16_t>() + first : nullptr, b.h2.p ? b.h2.as<int16_t>() + first : nullptr,
+                                   b.adpcm.as<uint8_t>() + (int64_t)first * b.adpcm_pitch, b.adpcm_pitch, s);
+        if (rc) why = vga_last_error();
         return rc;
-    if (int rc = gc::launch_encode(b.pcm.as<int16_t>(), b.pcm_pitch, nch, sample_count, b.coefs.as<int16_t>(),
-                                   b.h1.as<int16_t>(), b.h2.as<int16_t>(), b.adpcm.as<uint8_t>(), b.adpcm_pitch, b.st.s))
-        return rc;
-    VGA_HIP_TRY(hipMemcpyAsync(coefs_out, b.coefs.p, (size_t)nch * 32, hipMemcpyDeviceToHost, b.st.s));
-    if (int rc = download_adpcm(b, adpcm_out, nch, nbytes)) return rc;
-    VGA_HIP_TRY(hipStreamSynchronize(b.st.s));
+    };
+    // one chunk's workspace: the chunks' kernels run one after the other on the compute stream
+    VGA_HIP_TRY(b.ws.alloc(vga_gcadpcm_coefs_workspace_bytes(planned_chunk_units(job, GC_CHUNK_CHANNELS), sample_count)));
+    if (int rc = run_batch_pipeline(job, GC_CHUNK_CHANNELS)) return rc;
+    VGA_HIP_TRY(hipMemcpy(coefs_out, b.coefs.p, (size_t)nch * 32, hipMemcpyDeviceToHost));
     return VGA_OK;
 }
 
@@ -525,21 +576,30 @@ int vga_gcadpcm_decode_batch(const uint8_t *const *adpcm, const int16_t *coefs, 
     VGA_HIP_TRY(b.coefs.alloc((size_t)nch * 32));
     VGA_HIP_TRY(b.status.alloc(sizeof(int)));
     VGA_HIP_TRY(hipMemsetAsync(b.status.p, 0, sizeof(int), b.st.s));
-    for (int c = 0; c < nch; c++)
-        VGA_HIP_TRY(hipMemcpyAsync(b.adpcm.as<uint8_t>() + (int64_t)c * b.adpcm_pitch, adpcm[c], (size_t)nbytes,
-                                   hipMemcpyHostToDevice, b.st.s));
     VGA_HIP_TRY(hipMemcpyAsync(b.coefs.p, coefs, (size_t)nch * 32, hipMemcpyHostToDevice, b.st.s));
     if (int rc = upload_hist(b, nch, hist1, hist2)) return rc;
-    if (int rc = gc::launch_decode(b.adpcm.as<uint8_t>(), b.adpcm_pitch, b.coefs.as<int16_t>(), nch, sample_count,
-                                   b.h1.as<int16_t>(), b.h2.as<int16_t>(), b.pcm.as<int16_t>(), b.pcm_pitch,
-                                   b.status.as<int>(), b.st.s))
-        return rc;
-    int status = 0;
-    VGA_HIP_TRY(hipMemcpyAsync(&status, b.status.p, sizeof(int), hipMemcpyDeviceToHost, b.st.s));
-    for (int c = 0; c < nch; c++)
-        VGA_HIP_TRY(hipMemcpyAsync(pcm_out[c], b.pcm.as<int16_t>() + (int64_t)c * b.pcm_pitch, (size_t)sample_count * 2,
-                                   hipMemcpyDeviceToHost, b.st.s));
     VGA_HIP_TRY(hipStreamSynchronize(b.st.s));
+    pipe::Job job;
+    job.units = nch;
+    job.in_rows = (const void *const *)adpcm;
+    job.in_row_bytes = (size_t)nbytes;
+    job.d_in = b.adpcm.as<char>();
+    job.d_in_pitch = (size_t)b.adpcm_pitch;
+    job.out_rows = (void *const *)pcm_out;
+    job.out_row_bytes = (size_t)sample_count * 2;
+    job.d_out = b.pcm.as<char>();
+    job.d_out_pitch = (size_t)b.pcm_pitch * 2;
+    job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
+        const int rc = gc::launch_decode(b.adpcm.as<uint8_t>() + (int64_t)first * b.adpcm_pitch, b.adpcm_pitch,
+                                         b.coefs.as<int16_t>() + (int64_t)first * 16, count, sample_count,
+                                         b.h1.p ? b.h1.as<int16_t>() + first : nullptr, b.h2.p ? b.h2.as<int16_t>() + first : nullptr,
+                                         b.pcm.as<int16_t>() + (int64_t)first * b.pcm_pitch, b.pcm_pitch, b.status.as<int>(), s);
+        if (rc) why = vga_last_error();
+        return rc;
+    };
+    if (int rc = run_batch_pipeline(job, 2 * GC_CHUNK_CHANNELS)) return rc;
+    int status = 0;
+    VGA_HIP_TRY(hipMemcpy(&status, b.status.p, sizeof(int), hipMemcpyDeviceToHost));
     if (status != 0) {
         set_error("a frame header names predictor > 7 (the reference throws IndexOutOfRangeException)");
         return VGA_ERR_ARGUMENT;

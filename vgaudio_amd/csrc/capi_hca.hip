@@ -2,6 +2,7 @@
 // Host side: CriHcaEncoder.Initialize (stream parameters), channel typing, ATH curve; the per-frame
 // work is entirely in hca_encode_kernel.hip / hca_decode_kernels.hip.
 #include "common.hpp"
+#include "host_batch.hpp"
 #include "hca_kernels.hpp"
 
 #include <cmath>
@@ -321,6 +322,9 @@ int vga_hca_decode_device(const vga_hca_info *h, const uint8_t *d_frames, int64_
                               (hipStream_t)stream);
 }
 
+// streams per chunk of the host pipeline (host_pipeline.hpp): 256 stereo streams x 2813 frames = 720 k workgroups
+static constexpr int HCA_CHUNK_STREAMS = 256;
+
 // CriHcaFormat.EncodeFromPcm16 (Formats/CriHca/CriHcaFormat.cs:34-84) for a batch of equally shaped streams.
 // pcm: nstreams*channel_count planar pointers (stream-major); frames_out[s]: frame_count*frame_size bytes.
 int vga_hca_encode_batch(const int16_t *const *pcm, int nstreams, const vga_hca_params *p, vga_hca_info *info_out,
@@ -338,8 +342,6 @@ int vga_hca_encode_batch(const int16_t *const *pcm, int nstreams, const vga_hca_
     for (int i = 0; i < nstreams; i++)
         if (!frames_out[i]) { set_error("frames_out[%d] is null", i); return VGA_ERR_ARGUMENT; }
     if (int rc = require_device()) return rc;
-    Stream st;
-    VGA_HIP_TRY(st.create());
     DevBuf d_pcm, d_frames, d_status;
     const int64_t ch_pitch = round_up(n > 0 ? n : 1, 8);
     const int64_t stream_pitch = ch_pitch * nch;
@@ -348,20 +350,33 @@ int vga_hca_encode_batch(const int16_t *const *pcm, int nstreams, const vga_hca_
     VGA_HIP_TRY(d_pcm.alloc((size_t)nstreams * stream_pitch * 2));
     VGA_HIP_TRY(d_frames.alloc((size_t)nstreams * frames_pitch));
     VGA_HIP_TRY(d_status.alloc(sizeof(int)));
-    VGA_HIP_TRY(hipMemsetAsync(d_status.p, 0, sizeof(int), st.s));
-    for (int i = 0; i < nstreams * nch; i++)
-        if (n > 0)
-            VGA_HIP_TRY(hipMemcpyAsync(d_pcm.as<int16_t>() + (int64_t)i * ch_pitch, pcm[i], (size_t)n * 2,
-                                       hipMemcpyHostToDevice, st.s));
-    if (int rc = vga_hca_encode_device(d_pcm.as<int16_t>(), stream_pitch, ch_pitch, nstreams, n, &h, d_frames.as<uint8_t>(),
-                                       frames_pitch, d_status.as<int>(), st.s))
+    VGA_HIP_TRY(hipMemset(d_status.p, 0, sizeof(int)));
+    // a unit of the pipeline is a stream: channel_count input rows, one row of frames out (the reference encodes one
+    // stream per task, CriHcaFormat.cs:53-81 under Cli/Batch.cs:24-25)
+    pipe::Job job;
+    job.units = nstreams;
+    if (n > 0) {
+        job.in_rows_per_unit = nch;
+        job.in_rows = (const void *const *)pcm;
+        job.in_row_bytes = (size_t)n * 2;
+        job.d_in = d_pcm.as<char>();
+        job.d_in_pitch = (size_t)ch_pitch * 2;
+    }
+    if (fbytes > 0) {
+        job.out_rows = (void *const *)frames_out;
+        job.out_row_bytes = (size_t)fbytes;
+        job.d_out = d_frames.as<char>();
+        job.d_out_pitch = (size_t)frames_pitch;
+    }
+    job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
+        const int rc = vga_hca_encode_device(d_pcm.as<int16_t>() + (int64_t)first * stream_pitch, stream_pitch, ch_pitch, count, n, &h,
+                                             d_frames.as<uint8_t>() + (int64_t)first * frames_pitch, frames_pitch, d_status.as<int>(), s);
+        if (rc) why = vga_last_error();
         return rc;
+    };
+    if (int rc = run_batch_pipeline(job, HCA_CHUNK_STREAMS)) return rc;
     int status = 0;
-    VGA_HIP_TRY(hipMemcpyAsync(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost, st.s));
-    for (int i = 0; i < nstreams; i++)
-        VGA_HIP_TRY(hipMemcpyAsync(frames_out[i], d_frames.as<uint8_t>() + (int64_t)i * frames_pitch, (size_t)fbytes,
-                                   hipMemcpyDeviceToHost, st.s));
-    VGA_HIP_TRY(hipStreamSynchronize(st.s));
+    VGA_HIP_TRY(hipMemcpy(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost));
     return status_to_error(status);
 }
 
@@ -380,8 +395,6 @@ int vga_hca_decode_batch(const vga_hca_info *h, const uint8_t *const *frames, in
     for (int i = 0; i < nstreams * nch; i++)
         if (!pcm_out[i] && h->sample_count > 0) { set_error("pcm_out[%d] is null", i); return VGA_ERR_ARGUMENT; }
     if (int rc = require_device()) return rc;
-    Stream st;
-    VGA_HIP_TRY(st.create());
     DevBuf d_pcm, d_frames, d_status, d_ws;
     const int n = h->sample_count;
     const int64_t ch_pitch = round_up(n > 0 ? n : 1, 8);
@@ -389,27 +402,40 @@ int vga_hca_decode_batch(const vga_hca_info *h, const uint8_t *const *frames, in
     const int64_t fbytes = (int64_t)h->frame_count * h->frame_size;
     const int64_t frames_pitch = round_up(fbytes + 8, 16);
     VGA_HIP_TRY(d_pcm.alloc((size_t)nstreams * stream_pitch * 2));
-    VGA_HIP_TRY(hipMemsetAsync(d_pcm.p, 0, (size_t)nstreams * stream_pitch * 2, st.s));
+    VGA_HIP_TRY(hipMemset(d_pcm.p, 0, (size_t)nstreams * stream_pitch * 2));
     VGA_HIP_TRY(d_frames.alloc((size_t)nstreams * frames_pitch));
-    VGA_HIP_TRY(hipMemsetAsync(d_frames.p, 0, (size_t)nstreams * frames_pitch, st.s));
+    VGA_HIP_TRY(hipMemset(d_frames.p, 0, (size_t)nstreams * frames_pitch));     // the 8 bytes of slack behind every stream
     VGA_HIP_TRY(d_status.alloc(sizeof(int)));
-    VGA_HIP_TRY(hipMemsetAsync(d_status.p, 0, sizeof(int), st.s));
+    VGA_HIP_TRY(hipMemset(d_status.p, 0, sizeof(int)));
     const size_t wsb = vga_hca_decode_workspace_bytes(h, nstreams);
     VGA_HIP_TRY(d_ws.alloc(wsb));
-    for (int i = 0; i < nstreams; i++)
-        if (fbytes > 0)
-            VGA_HIP_TRY(hipMemcpyAsync(d_frames.as<uint8_t>() + (int64_t)i * frames_pitch, frames[i], (size_t)fbytes,
-                                       hipMemcpyHostToDevice, st.s));
-    if (int rc = vga_hca_decode_device(h, d_frames.as<uint8_t>(), frames_pitch, nstreams, d_pcm.as<int16_t>(), stream_pitch,
-                                       ch_pitch, d_ws.p, wsb, d_status.as<int>(), st.s))
+    const size_t ws_per_stream = nstreams > 0 ? wsb / (size_t)nstreams : 0;
+    pipe::Job job;
+    job.units = nstreams;
+    if (fbytes > 0) {
+        job.in_rows = (const void *const *)frames;
+        job.in_row_bytes = (size_t)fbytes;
+        job.d_in = d_frames.as<char>();
+        job.d_in_pitch = (size_t)frames_pitch;
+    }
+    if (n > 0) {
+        job.out_rows_per_unit = nch;
+        job.out_rows = (void *const *)pcm_out;
+        job.out_row_bytes = (size_t)n * 2;
+        job.d_out = d_pcm.as<char>();
+        job.d_out_pitch = (size_t)ch_pitch * 2;
+    }
+    job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
+        const int rc = vga_hca_decode_device(h, d_frames.as<uint8_t>() + (int64_t)first * frames_pitch, frames_pitch, count,
+                                             d_pcm.as<int16_t>() + (int64_t)first * stream_pitch, stream_pitch, ch_pitch,
+                                             d_ws.as<char>() + (size_t)first * ws_per_stream, (size_t)count * ws_per_stream,
+                                             d_status.as<int>(), s);
+        if (rc) why = vga_last_error();
         return rc;
+    };
+    if (int rc = run_batch_pipeline(job, HCA_CHUNK_STREAMS)) return rc;
     int status = 0;
-    VGA_HIP_TRY(hipMemcpyAsync(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost, st.s));
-    for (int i = 0; i < nstreams * nch; i++)
-        if (n > 0)
-            VGA_HIP_TRY(hipMemcpyAsync(pcm_out[i], d_pcm.as<int16_t>() + (int64_t)i * ch_pitch, (size_t)n * 2,
-                                       hipMemcpyDeviceToHost, st.s));
-    VGA_HIP_TRY(hipStreamSynchronize(st.s));
+    VGA_HIP_TRY(hipMemcpy(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost));
     return status_to_error(status);
 }
 

@@ -1,0 +1,50 @@
+// host_batch.hpp -- glue between the host-pointer entry points of the C ABI and host_pipeline.hpp.
+#pragma once
+#include "common.hpp"
+#include "host_pipeline.hpp"
+
+namespace vga {
+
+// Per-thread overrides of the pipeline's shape (vga_testing_host_pipeline_this_thread): the tests force many feeders,
+// one-row slots and small chunks on small inputs so that every hand-off of the pipeline is exercised on the GPU box.
+struct PipeOverride { int feeders = 0, drainers = 0, chunk_units = 0, slot_bytes = 0; };
+PipeOverride &pipe_override();                       // capi_gcadpcm.hip
+
+// Units per chunk run_batch_pipeline() will use for this job (callers size per-chunk scratch with it).
+inline int planned_chunk_units(const pipe::Job &job, int default_chunk_units)
+{
+    const PipeOverride &o = pipe_override();
+    const size_t in_total = job.in_rows ? (size_t)job.units * job.in_rows_per_unit * job.in_row_bytes : 0;
+    const size_t out_total = job.out_rows ? (size_t)job.units * job.out_rows_per_unit * job.out_row_bytes : 0;
+    int chunk = o.chunk_units > 0 ? o.chunk_units : default_chunk_units;
+    // small batches: one chunk (a chunk boundary only pays when the upload of the next chunk is worth hiding)
+    if (o.chunk_units <= 0 && in_total + out_total < ((size_t)256 << 20)) chunk = job.units;
+    return std::max(1, std::min(chunk, job.units));
+}
+
+// Shapes the job (workers by volume, chunk size) and runs it; a failure becomes set_error() + its status code.
+inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
+{
+    const PipeOverride &o = pipe_override();
+    // set-up done on the legacy stream (hipMemset of status words, slack bytes) must have run: the pipeline's streams
+    // are non-blocking and do not order themselves behind it
+    VGA_HIP_TRY(hipStreamSynchronize(nullptr));
+    int device = 0;
+    VGA_HIP_TRY(hipGetDevice(&device));
+    job.device = device;
+    const size_t in_total = job.in_rows ? (size_t)job.units * job.in_rows_per_unit * job.in_row_bytes : 0;
+    const size_t out_total = job.out_rows ? (size_t)job.units * job.out_rows_per_unit * job.out_row_bytes : 0;
+    const size_t per_worker = (size_t)16 << 20;      // a worker thread is worth starting for every 16 MB it moves
+    job.feeders = o.feeders > 0 ? o.feeders : (int)std::min<size_t>(8, std::max<size_t>(1, in_total / per_worker));
+    job.drainers = o.drainers > 0 ? o.drainers : (int)std::min<size_t>(4, std::max<size_t>(1, out_total / per_worker));
+    job.slot_bytes = o.slot_bytes > 0 ? (size_t)o.slot_bytes : (size_t)8 << 20;
+    job.chunk_units = planned_chunk_units(job, default_chunk_units);
+    const pipe::Result r = pipe::run(job);
+    if (r.code) {
+        set_error("%s", r.why.c_str());
+        return r.code;
+    }
+    return VGA_OK;
+}
+
+}  // namespace vga

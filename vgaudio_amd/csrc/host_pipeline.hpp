@@ -1,0 +1,353 @@
+// host_pipeline.hpp -- what a P/Invoke caller actually gets: the host-pointer entry points of the C ABI as a
+// three-stage pipeline (caller memory -> pinned ring -> HBM -> kernels -> HBM -> pinned ring -> caller memory).
+//
+// The reference fans channels out with Parallel.For over managed arrays (Formats/GcAdpcm/GcAdpcmFormat.cs:65-68,
+// Formats/CriAdx/CriAdxFormat.cs:67-81) -- arrays that are pinned for the garbage collector but PAGEABLE for a DMA engine.
+// One hipMemcpyAsync per channel from such memory goes through the runtime's single staging thread (round 1:
+// 8-11 Gsamples/s through the ABI against 52 Gsamples/s in HBM).  Here:
+//   * F feeder threads copy the caller's rows into their own ring of page-locked slots (a row = one channel's PCM; the slot
+//     has the DEVICE pitch, so a slot goes to HBM with one contiguous hipMemcpyAsync on the feeder's own stream) -- the
+//     CPU fills slot i+1 while the DMA engine moves slot i;
+//   * the calling thread launches the kernels of a CHUNK of units (channels / streams) on the compute stream as soon as
+//     every feeder has recorded that chunk's event -- chunk k computes while chunk k+1 uploads;
+//   * D drainer threads wait for the chunk's compute event, pull its output rows through their own pinned rings on their
+//     own streams and copy them out to the caller's arrays -- chunk k-1 downloads while chunk k computes.
+// Page-locked memory comes from a process-wide pool (hipHostMalloc costs ~0.3 s per GB; the rings are a few hundred MB
+// and are reused by later calls).  No caller pointer is retained past return.
+//
+// Host-only code (no kernels): tests/host/test_host_pipeline.cpp compiles this header against a mock of the few HIP
+// entry points it uses and runs it under ThreadSanitizer on the CPU.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace vga {
+namespace pipe {
+
+// ---------------------------------------------------------------- page-locked staging pool (process-wide)
+class PinnedPool {
+public:
+    static PinnedPool &get()
+    {
+        static PinnedPool pool;
+        return pool;
+    }
+    // a page-locked block of at least `bytes` (nullptr on failure)
+    void *acquire(size_t bytes)
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            int best = -1;
+            for (int i = 0; i < (int)blocks_.size(); i++)
+                if (!blocks_[i].busy && blocks_[i].bytes >= bytes && (best < 0 || blocks_[i].bytes < blocks_[best].bytes)) best = i;
+            if (best >= 0) {
+                blocks_[best].busy = true;
+                return blocks_[best].p;
+            }
+        }
+        void *p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
+        std::lock_guard<std::mutex> g(m_);
+        blocks_.push_back({p, bytes, true});
+        return p;
+    }
+    void release(void *p)
+    {
+        std::lock_guard<std::mutex> g(m_);
+        size_t idle = 0;
+        for (auto &b : blocks_) {
+            if (b.p == p) b.busy = false;
+            if (!b.busy) idle += b.bytes;
+        }
+        // keep at most ~1 GiB parked: drop the largest idle blocks beyond that
+        while (idle > kKeepBytes) {
+            int big = -1;
+            for (int i = 0; i < (int)blocks_.size(); i++)
+                if (!blocks_[i].busy && (big < 0 || blocks_[i].bytes > blocks_[big].bytes)) big = i;
+            if (big < 0) break;
+            idle -= blocks_[big].bytes;
+            (void)hipHostFree(blocks_[big].p);
+            blocks_.erase(blocks_.begin() + big);
+        }
+    }
+    void trim()                                            // frees every idle block (tests; library unload)
+    {
+        std::lock_guard<std::mutex> g(m_);
+        for (int i = (int)blocks_.size() - 1; i >= 0; i--)
+            if (!blocks_[i].busy) {
+                (void)hipHostFree(blocks_[i].p);
+                blocks_.erase(blocks_.begin() + i);
+            }
+    }
+
+private:
+    static constexpr size_t kKeepBytes = (size_t)1 << 30;
+    struct Block { void *p; size_t bytes; bool busy; };
+    std::mutex m_;
+    std::vector<Block> blocks_;
+};
+
+struct PinnedBlock {
+    void *p = nullptr;
+    ~PinnedBlock() { if (p) PinnedPool::get().release(p); }
+    bool alloc(size_t bytes) { p = PinnedPool::get().acquire(bytes ? bytes : 1); return p != nullptr; }
+};
+
+// ---------------------------------------------------------------- the job
+// A "unit" is what the reference hands to one task: a channel (GC-ADPCM, ADX) or a stream (HCA).  Unit u owns the
+// input rows [u * in_rows_per_unit, (u + 1) * in_rows_per_unit) and the output rows [u * out_rows_per_unit, ...).
+struct Job {
+    int units = 0;
+    int chunk_units = 0;                 // kernels are launched per chunk of this many units
+    // input side (rows of in_row_bytes bytes at host pointers in_rows[r]; device row r at d_in + r * d_in_pitch)
+    int in_rows_per_unit = 1;
+    const void *const *in_rows = nullptr;
+    size_t in_row_bytes = 0;
+    char *d_in = nullptr;
+    size_t d_in_pitch = 0;
+    // output side
+    int out_rows_per_unit = 1;
+    void *const *out_rows = nullptr;
+    size_t out_row_bytes = 0;
+    const char *d_out = nullptr;
+    size_t d_out_pitch = 0;
+    // enqueues the kernels for units [first, first + count) on `stream`; returns 0 or an error code (message via `why`)
+    std::function<int(int first, int count, hipStream_t stream, std::string &why)> compute;
+    int feeders = 8, drainers = 4;
+    size_t slot_bytes = (size_t)8 << 20;   // target size of one ring slot (whole rows; at least one row)
+    int ring = 3;                          // slots per feeder / drainer
+    int device = 0;
+};
+
+struct Result {
+    int code = 0;                          // 0 = ok; otherwise the first failure
+    std::string why;
+};
+
+namespace detail {
+
+struct Shared {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<int> uploaded;             // per chunk: feeders that have recorded its event
+    std::vector<char> launched;            // per chunk: compute event recorded
+    std::atomic<int> err{0};
+    std::string why;
+
+    void fail(int code, const std::string &msg)
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (!err.load()) {
+            why = msg;
+            err.store(code ? code : -5);
+        }
+        cv.notify_all();
+    }
+};
+
+inline std::string hip_msg(const char *what, hipError_t e)
+{
+    return std::string(what) + " failed: " + hipGetErrorString(e);
+}
+
+#define VGA_PIPE_TRY(expr)                                                   \
+    do {                                                                     \
+        hipError_t _e = (expr);                                              \
+        if (_e != hipSuccess) {                                              \
+            sh.fail(-5, detail::hip_msg(#expr, _e));                         \
+            return;                                                          \
+        }                                                                    \
+    } while (0)
+
+// rows [begin, end) of the chunk's row range, split evenly over `parts` workers: worker `i` gets [lo, hi)
+inline void split(int begin, int end, int parts, int i, int &lo, int &hi)
+{
+    const int64_t n = end - begin;
+    lo = begin + (int)(n * i / parts);
+    hi = begin + (int)(n * (i + 1) / parts);
+}
+
+}  // namespace detail
+
+inline Result run(const Job &job)
+{
+    using namespace detail;
+    Result res;
+    if (job.units <= 0) return res;
+    const int chunk_units = std::max(1, std::min(job.chunk_units > 0 ? job.chunk_units : job.units, job.units));
+    const int chunks = (job.units + chunk_units - 1) / chunk_units;
+    const bool has_in = job.in_rows && job.in_row_bytes > 0 && job.in_rows_per_unit > 0;
+    const bool has_out = job.out_rows && job.out_row_bytes > 0 && job.out_rows_per_unit > 0;
+    const int F = has_in ? std::max(1, job.feeders) : 0;
+    const int D = has_out ? std::max(1, job.drainers) : 0;
+    const int R = std::max(2, job.ring);
+    const int in_slot_rows = has_in ? (int)std::max<size_t>(1, job.slot_bytes / std::max<size_t>(1, job.d_in_pitch)) : 0;
+    const int out_slot_rows = has_out ? (int)std::max<size_t>(1, job.slot_bytes / std::max<size_t>(1, job.d_out_pitch)) : 0;
+
+    Shared sh;
+    sh.uploaded.assign(chunks, 0);
+    sh.launched.assign(chunks, 0);
+
+    // everything HIP-side is created up front on the calling thread, destroyed after every thread has joined
+    std::vector<hipStream_t> fstream(F, nullptr), dstream(D, nullptr);
+    std::vector<hipEvent_t> fslot(F * R, nullptr), dslot(D * R, nullptr), upl(F * chunks, nullptr), comp(chunks, nullptr);
+    hipStream_t cstream = nullptr;
+    PinnedBlock in_ring, out_ring;
+    bool ok = true;
+    auto check = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && ok) {
+            ok = false;
+            res.code = -5;
+            res.why = hip_msg(what, e);
+        }
+    };
+    check(hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking), "hipStreamCreate");
+    for (auto &s : fstream) check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    for (auto &s : dstream) check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    for (auto *v : {&fslot, &dslot, &upl, &comp})
+        for (auto &e : *v) check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    if (ok && has_in && !in_ring.alloc((size_t)F * R * in_slot_rows * job.d_in_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (input ring)");
+    if (ok && has_out && !out_ring.alloc((size_t)D * R * out_slot_rows * job.d_out_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (output ring)");
+
+    auto chunk_units_of = [&](int k) { return std::min(chunk_units, job.units - k * chunk_units); };
+
+    // ---------------------------------------------------------------- feeder t
+    auto feeder = [&](int t) {
+        VGA_PIPE_TRY(hipSetDevice(job.device));
+        char *ring = static_cast<char *>(in_ring.p) + (size_t)t * R * in_slot_rows * job.d_in_pitch;
+        int64_t used = 0;                                  // slots handed to the DMA engine so far
+        for (int k = 0; k < chunks && !sh.err.load(); k++) {
+            const int row0 = k * chunk_units * job.in_rows_per_unit;
+            const int row1 = row0 + chunk_units_of(k) * job.in_rows_per_unit;
+            int lo, hi;
+            split(row0, row1, F, t, lo, hi);
+            for (int r = lo; r < hi && !sh.err.load(); r += in_slot_rows) {
+                const int n = std::min(in_slot_rows, hi - r);
+                const int s = (int)(used % R);
+                if (used >= R) VGA_PIPE_TRY(hipEventSynchronize(fslot[t * R + s]));      // the slot's previous upload is done
+                char *slot = ring + (size_t)s * in_slot_rows * job.d_in_pitch;
+                for (int i = 0; i < n; i++) std::memcpy(slot + (size_t)i * job.d_in_pitch, job.in_rows[r + i], job.in_row_bytes);
+                const size_t bytes = (size_t)(n - 1) * job.d_in_pitch + job.in_row_bytes;
+                VGA_PIPE_TRY(hipMemcpyAsync(job.d_in + (size_t)r * job.d_in_pitch, slot, bytes, hipMemcpyHostToDevice, fstream[t]));
+                VGA_PIPE_TRY(hipEventRecord(fslot[t * R + s], fstream[t]));
+                used++;
+            }
+            VGA_PIPE_TRY(hipEventRecord(upl[t * chunks + k], fstream[t]));
+            {
+                std::lock_guard<std::mutex> g(sh.m);
+                sh.uploaded[k]++;
+            }
+            sh.cv.notify_all();
+        }
+        if (!sh.err.load()) VGA_PIPE_TRY(hipStreamSynchronize(fstream[t]));             // nothing in flight reads the ring after this
+    };
+
+    // ---------------------------------------------------------------- drainer u
+    auto drainer = [&](int u) {
+        VGA_PIPE_TRY(hipSetDevice(job.device));
+        char *ring = static_cast<char *>(out_ring.p) + (size_t)u * R * out_slot_rows * job.d_out_pitch;
+        struct Pending { int row = -1, n = 0; };
+        std::vector<Pending> pend(R);
+        int64_t used = 0;
+        auto flush = [&](int s) -> bool {                  // slot s: wait for its download, hand the rows to the caller
+            if (pend[s].row < 0) return true;
+            hipError_t e = hipEventSynchronize(dslot[u * R + s]);
+            if (e != hipSuccess) {
+                sh.fail(-5, hip_msg("hipEventSynchronize", e));
+                return false;
+            }
+            const char *slot = ring + (size_t)s * out_slot_rows * job.d_out_pitch;
+            for (int i = 0; i < pend[s].n; i++)
+                std::memcpy(job.out_rows[pend[s].row + i], slot + (size_t)i * job.d_out_pitch, job.out_row_bytes);
+            pend[s].row = -1;
+            return true;
+        };
+        for (int k = 0; k < chunks; k++) {
+            {
+                std::unique_lock<std::mutex> g(sh.m);
+                sh.cv.wait(g, [&] { return sh.launched[k] || sh.err.load(); });
+            }
+            if (sh.err.load()) break;
+            VGA_PIPE_TRY(hipStreamWaitEvent(dstream[u], comp[k], 0));
+            const int row0 = k * chunk_units * job.out_rows_per_unit;
+            const int row1 = row0 + chunk_units_of(k) * job.out_rows_per_unit;
+            int lo, hi;
+            split(row0, row1, D, u, lo, hi);
+            for (int r = lo; r < hi && !sh.err.load(); r += out_slot_rows) {
+                const int n = std::min(out_slot_rows, hi - r);
+                const int s = (int)(used % R);
+                if (!flush(s)) return;
+                char *slot = ring + (size_t)s * out_slot_rows * job.d_out_pitch;
+                const size_t bytes = (size_t)(n - 1) * job.d_out_pitch + job.out_row_bytes;
+                VGA_PIPE_TRY(hipMemcpyAsync(slot, job.d_out + (size_t)r * job.d_out_pitch, bytes, hipMemcpyDeviceToHost, dstream[u]));
+                VGA_PIPE_TRY(hipEventRecord(dslot[u * R + s], dstream[u]));
+                pend[s].row = r;
+                pend[s].n = n;
+                used++;
+            }
+        }
+        if (!sh.err.load())
+            for (int s = 0; s < R; s++)
+                if (!flush((int)((used + s) % R))) return;  // oldest first
+    };
+
+    std::vector<std::thread> threads;
+    if (ok) {
+        for (int t = 0; t < F; t++) threads.emplace_back(feeder, t);
+        for (int u = 0; u < D; u++) threads.emplace_back(drainer, u);
+        // ---------------------------------------------------------------- the calling thread: kernels, chunk by chunk
+        [&] {
+            for (int k = 0; k < chunks; k++) {
+                if (F > 0) {
+                    std::unique_lock<std::mutex> g(sh.m);
+                    sh.cv.wait(g, [&] { return sh.uploaded[k] == F || sh.err.load(); });
+                }
+                if (sh.err.load()) return;
+                for (int t = 0; t < F; t++) VGA_PIPE_TRY(hipStreamWaitEvent(cstream, upl[t * chunks + k], 0));
+                std::string why;
+                const int rc = job.compute(k * chunk_units, chunk_units_of(k), cstream, why);
+                if (rc) {
+                    sh.fail(rc, why);
+                    return;
+                }
+                VGA_PIPE_TRY(hipEventRecord(comp[k], cstream));
+                {
+                    std::lock_guard<std::mutex> g(sh.m);
+                    sh.launched[k] = 1;
+                }
+                sh.cv.notify_all();
+            }
+            VGA_PIPE_TRY(hipStreamSynchronize(cstream));
+        }();
+        for (auto &th : threads) th.join();
+        if (sh.err.load()) {
+            res.code = sh.err.load();
+            res.why = sh.why;
+        }
+    }
+    // after a failure, operations may still be in flight on the rings: drain every stream before anything is released
+    if (cstream) (void)hipStreamSynchronize(cstream);
+    for (auto s : fstream) if (s) (void)hipStreamSynchronize(s);
+    for (auto s : dstream) if (s) (void)hipStreamSynchronize(s);
+    for (auto *v : {&fslot, &dslot, &upl, &comp})
+        for (auto e : *v) if (e) (void)hipEventDestroy(e);
+    for (auto s : fstream) if (s) (void)hipStreamDestroy(s);
+    for (auto s : dstream) if (s) (void)hipStreamDestroy(s);
+    if (cstream) (void)hipStreamDestroy(cstream);
+    return res;
+}
+
+#undef VGA_PIPE_TRY
+
+}  // namespace pipe
+}  // namespace vga
