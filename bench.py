@@ -229,7 +229,20 @@ def measure_e2e(cx, args, pcm, n, coefs_dev, adpcm_dev):
         a.copy_(b, non_blocking=True)
         torch.cuda.synchronize()
         rates[name] = (1 << 30) / (time.perf_counter() - t0) / 1e9
-    del pin, dbuf
+    # both directions at once (two streams): the DMA engines' aggregate, which is what a pipelined call is bound by
+    pin2 = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
+    dbuf2 = torch.empty(1 << 30, dtype=torch.uint8, device=cx.dev)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        with torch.cuda.stream(s1):
+            dbuf.copy_(pin, non_blocking=True)
+        with torch.cuda.stream(s2):
+            pin2.copy_(dbuf2, non_blocking=True)
+    torch.cuda.synchronize()
+    rates["both_directions_aggregate"] = 4 * (1 << 30) / (time.perf_counter() - t0) / 1e9
+    del pin, dbuf, pin2, dbuf2
     host = np.empty((want, n), dtype=np.int16)                       # pageable, like a managed short[][]
     for c0 in range(0, want, 256):
         host[c0:c0 + 256] = pcm[c0:c0 + 256, :n].cpu().numpy()
@@ -245,18 +258,25 @@ def measure_e2e(cx, args, pcm, n, coefs_dev, adpcm_dev):
         lib.check(L.vga_gcadpcm_encode_batch(pp, want, n, 0, 0, cf.ctypes.data_as(lib.i16p), op))
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
+    st = (C.c_double * 32)()
+    nf = L.vga_testing_last_pipeline_stats(st, 32)
+    names = ["total", "setup", "feeders_memcpy_sum", "feeders_wait_slot_sum", "feeders_issue_sum", "slowest_feeder", "caller_wait_upload",
+             "caller_launch", "caller_tail_sync", "drainers_wait_compute_sum", "drainers_wait_download_sum", "drainers_memcpy_sum",
+             "slowest_drainer", "feeders", "drainers", "chunks", "units_per_chunk", "device_alloc", "entry_point"]
+    breakdown = {k: (int(st[i]) if 13 <= i <= 16 else round(st[i] * 1e3, 1)) for i, k in enumerate(names[:nf])}
     same = bool(np.array_equal(outs, adpcm_dev[:want, :nb].cpu().numpy()) and
                 np.array_equal(cf.reshape(want, 16), coefs_dev[:want].cpu().numpy().reshape(want, 16)))
     if not same:
         raise SystemExit("PARITY FAILURE: the host-pointer ABI and the device-resident path disagree")
     in_bytes, out_bytes = want * 2 * n, want * nb
-    pcie_ms = max(in_bytes / rates["h2d"], out_bytes / rates["d2h"]) / 1e6      # full duplex: the larger direction
+    # bound: the larger direction alone, or all bytes at the measured two-way aggregate, whichever is longer
+    pcie_ms = max(in_bytes / rates["h2d"], out_bytes / rates["d2h"], (in_bytes + out_bytes) / rates["both_directions_aggregate"]) / 1e6
     e2e = {"entry_point": "vga_gcadpcm_encode_batch (pageable host arrays in and out)", "channels": want,
            "samples_per_channel": n, "ms": round(best * 1e3, 1), "value": round(want * n / best / 1e6, 1), "unit": "Msamples/s",
            "host_bytes_in": in_bytes, "host_bytes_out": out_bytes,
            "pcie_pinned_GBps": {k: round(v, 1) for k, v in rates.items()}, "pcie_bound_ms": round(pcie_ms, 1),
            "ratio_to_pcie_bound": round(best * 1e3 / pcie_ms, 2), "identical_to_device_path": same,
-           "host_threads": "8 feeders + 4 drainers + caller (host_pipeline.hpp)"}
+           "host_threads": "4 feeders + 2 drainers + caller (host_pipeline.hpp)", "breakdown_ms": breakdown}
     if note:
         e2e["note"] = note
     return e2e

@@ -41,6 +41,10 @@ const char *vga_last_error(void);
 int vga_device_count(void);
 /* selects the device for the calling thread (one process per GPU: LOCAL_RANK) */
 int vga_set_device(int device);
+/* The host-buffer entry points keep the device buffers and the page-locked staging rings of their last calls for the
+ * next one (allocation costs more than a call's transfers and kernels: ~1.4 s for the 44 GB of BASELINE configs[1]); at
+ * most 64 GiB of device memory and 1 GiB of pinned host memory stay parked.  This returns all of it to the system. */
+void vga_release_cached_memory(void);
 /* library version string */
 const char *vga_version(void);
 

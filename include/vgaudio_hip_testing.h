@@ -23,6 +23,14 @@ int vga_testing_force_open_seams_this_thread(int mode);
  * thread counts, units (channels, streams) per chunk, bytes per ring slot.  Results must not depend on any of them. */
 void vga_testing_host_pipeline_this_thread(int feeders, int drainers, int chunk_units, int slot_bytes);
 
+/* Where the wall time of the calling thread's last pipelined call went, in seconds (diagnostics for bench.py's e2e
+ * block): [0] total [1] set-up [2] feeders' memcpy (sum over threads) [3] feeders waiting for a ring slot [4] feeders
+ * inside hipMemcpyAsync/hipEventRecord [5] slowest feeder [6] caller waiting for uploads [7] caller launching kernels
+ * [8] caller's final stream sync [9] drainers waiting for compute [10] drainers waiting for downloads [11] drainers'
+ * memcpy [12] slowest drainer [13] feeders [14] drainers [15] chunks [16] units per chunk [17] device allocation
+ * before the pipeline [18] the whole entry point up to its return value.  Returns the number of fields. */
+int vga_testing_last_pipeline_stats(double *out, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,7 @@
 
 using namespace vga::pipe;
 
+static int g_taper = 0;
 static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t out_bytes, int chunk, int feeders, int drainers,
                     size_t slot_bytes, int delay_us, int fail_after, bool compute_fails)
 {
@@ -38,10 +39,13 @@ static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t 
     job.feeders = feeders;
     job.drainers = drainers;
     job.slot_bytes = slot_bytes;
+    job.taper_min_units = g_taper;
     int launches = 0;
+    std::vector<int> seen(units, 0);
     // "kernel": output row (u, j) byte i = sum over the unit's input rows of byte (i mod in_bytes), plus j and i
     job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
         launches++;
+        for (int u = first; u < first + count; u++) seen[u]++;
         if (compute_fails && first > 0) {
             why = "compute refused";
             return -3;
@@ -68,6 +72,8 @@ static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t 
     }
     if (r.code != 0) { std::printf("unexpected failure %d: %s\n", r.code, r.why.c_str()); return 1; }
     for (int u = 0; u < units; u++)
+        if (seen[u] != 1) { std::printf("unit %d computed %d times\n", u, seen[u]); return 1; }
+    for (int u = 0; u < units; u++)
         for (int j = 0; j < out_rpu; j++)
             for (size_t i = 0; i < out_bytes; i++) {
                 unsigned v = (unsigned)j + (unsigned)i;
@@ -92,6 +98,12 @@ int main()
     bad += run_case(33, 1, 1, 256, 64, 4, 4, 2, 1024, 30, 7, false);              // a copy fails mid-way: error, no hang
     bad += run_case(33, 1, 1, 256, 64, 4, 4, 2, 1024, 30, 0, false);
     bad += run_case(40, 1, 1, 256, 64, 8, 4, 2, 1024, 10, -1, true);              // the compute callback refuses the 2nd chunk
+    g_taper = 3;                                                                  // tapered last chunk
+    bad += run_case(37, 1, 1, 1000, 300, 8, 8, 4, 2048, 20, -1, false);
+    bad += run_case(64, 2, 1, 513, 77, 32, 3, 2, 512, 10, -1, false);
+    bad += run_case(100, 1, 1, 128, 32, 40, 4, 2, 4096, 5, -1, false);
+    bad += run_case(9, 1, 1, 128, 32, 100, 4, 2, 4096, 5, -1, false);             // one chunk: nothing to taper
+    g_taper = 0;
     PinnedPool::get().trim();
     std::printf(bad ? "FAILED %d\n" : "ok\n", bad);
     return bad ? 1 : 0;

@@ -47,4 +47,26 @@ if has sq; then
   python tools/summarize_pmc.py sq $O/r02_sq_counters.json $O/sq_gc_a $O/sq_gc_b $O/sq_adx_a $O/sq_adx_b $O/sq_hca_a $O/sq_hca_b | tail -80
   find $O -name "sq_*" -type d -exec rm -rf {} + 2>/dev/null
 fi
+if has mfma; then
+  timeout 300 tools/variants/bench_hca_mfma 2097152 5 > $O/hca_mfma.json.log 2> $O/hca_mfma.err; echo "mfma rc=$?"; cat $O/hca_mfma.json.log
+  cd /tmp && export TMPDIR=/tmp
+  timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/sq_mfma -o pmc -- $GRAFT_REPO_ROOT/tools/variants/bench_hca_mfma 2097152 2 > $O/sq_mfma.log 2>&1; echo "mfma pmc rc=$?"
+  cd $GRAFT_REPO_ROOT
+  python - <<'PY'
+import csv, glob, json, collections
+rows = []
+for f in glob.glob("gpurun_out/r02/sq_mfma/**/*counter_collection*.csv", recursive=True):
+    rows += list(csv.DictReader(open(f, newline="")))
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    k = "mfma" if "mfma" in r["Kernel_Name"] else ("staged" if "staged" in r["Kernel_Name"] else None)
+    if k:
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[k]["_dur_ms"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+json.dump(out, open("gpurun_out/r02/hca_mfma_counters.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
+  rm -rf $O/sq_mfma
+fi
 ls $O | head -40

@@ -112,8 +112,10 @@ SIGNATURES = {
     "vga_hca_key_tables": (ci, [ci, C.c_uint64, u8p, u8p]),
     "vga_hca_crypt": (ci, [u8p, ci, ci, u8p]),
     "vga_hca_crypt_device": (ci, [vp, i64, ci, ci, ci, u8p, vp]),
+    "vga_release_cached_memory": (None, []),
     "vga_testing_force_open_seams_this_thread": (ci, [ci]),
     "vga_testing_host_pipeline_this_thread": (None, [ci, ci, ci, ci]),
+    "vga_testing_last_pipeline_stats": (ci, [vp, ci]),
     "vga_dsp_layout_for": (ci, [vp, ci, vp]),
     "vga_dsp_write": (ci, [u8pp, ci, i16p, i16p, i16p, i16p, ci, vp, u8p]),
     "vga_dsp_write_device": (ci, [vp, i64, ci, vp, vp, vp, vp, ci, vp, vp, vp]),

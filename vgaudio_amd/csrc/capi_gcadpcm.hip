@@ -26,6 +26,8 @@ int force_open_seams() { return g_force_open_seams; }
 
 static thread_local PipeOverride g_pipe_override;
 PipeOverride &pipe_override() { return g_pipe_override; }
+static thread_local PipeReport g_pipe_report;
+PipeReport &pipe_report() { return g_pipe_report; }
 
 int require_device()
 {
@@ -64,7 +66,23 @@ void vga_testing_host_pipeline_this_thread(int feeders, int drainers, int chunk_
     g_pipe_override.chunk_units = chunk_units;
     g_pipe_override.slot_bytes = slot_bytes;
 }
-const char *vga_version(void) { return "vgaudio_hip 0.1 (gfx950)"; }
+int vga_testing_last_pipeline_stats(double *out, int n)
+{
+    const PipeReport &r = g_pipe_report;
+    const double v[] = {r.stats.total, r.stats.setup, r.stats.feed_copy, r.stats.feed_wait_slot, r.stats.feed_issue, r.stats.feed_max,
+                        r.stats.main_wait_upload, r.stats.main_launch, r.stats.main_tail_sync, r.stats.drain_wait_compute,
+                        r.stats.drain_wait_copy, r.stats.drain_copy, r.stats.drain_max, (double)r.stats.feeders, (double)r.stats.drainers,
+                        (double)r.stats.chunks, (double)r.stats.chunk_units, r.t_alloc, r.t_entry};
+    const int m = (int)(sizeof v / sizeof v[0]);
+    for (int i = 0; i < n && i < m; i++) out[i] = v[i];
+    return m;
+}
+void vga_release_cached_memory(void)
+{
+    DevicePool::get().trim();
+    pipe::PinnedPool::get().trim();
+}
+const char *vga_version(void) { return "vgaudio_hip 0.2 (gfx950)"; }
 
 int vga_device_count(void)
 {
@@ -512,6 +530,7 @@ int vga_gcadpcm_encode_batch(const int16_t *const *pcm, int nch, int sample_coun
     if (nch < 0 || (nch > 0 && !coefs_out)) { set_error("bad coefs_out/nch"); return VGA_ERR_ARGUMENT; }
     if (nch == 0) return VGA_OK;
     if (int rc = require_device()) return rc;
+    const double t_entry = pipe::detail::now();
     GcBatch b;
     VGA_HIP_TRY(b.st.create());
     b.pcm_pitch = round_up(sample_count > 0 ? sample_count : 1, 8);
@@ -552,8 +571,10 @@ int vga_gcadpcm_encode_batch(const int16_t *const *pcm, int nch, int sample_coun
     };
     // one chunk's workspace: the chunks' kernels run one after the other on the compute stream
     VGA_HIP_TRY(b.ws.alloc(vga_gcadpcm_coefs_workspace_bytes(planned_chunk_units(job, GC_CHUNK_CHANNELS), sample_count)));
+    pipe_report().t_alloc = pipe::detail::now() - t_entry;
     if (int rc = run_batch_pipeline(job, GC_CHUNK_CHANNELS)) return rc;
     VGA_HIP_TRY(hipMemcpy(coefs_out, b.coefs.p, (size_t)nch * 32, hipMemcpyDeviceToHost));
+    pipe_report().t_entry = pipe::detail::now() - t_entry;      // without the buffers' release (the destructors below)
     return VGA_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/vgaudio_hip.h"
@@ -24,6 +25,94 @@ void set_error(const char *fmt, ...);
         }                                                                              \
     } while (0)
 
+// Process-wide cache of the host-buffer entry points' device allocations.  hipMalloc maps memory at ~25 GB/s (1.4 s for
+// the 44 GB of a configs[1] call: more than the call's transfers and kernels together); a caller converting batch after
+// batch gets the previous call's buffers back instead.  Blocks of at least 1 MiB are parked on release (up to 64 GiB,
+// largest dropped first) and handed to the next request they fit without wasting more than half; smaller ones go
+// straight to hipMalloc / hipFree.  vga_release_cached_memory() empties the cache.
+class DevicePool {
+public:
+    static DevicePool &get()
+    {
+        static DevicePool pool;
+        return pool;
+    }
+    hipError_t acquire(void **out, size_t bytes)
+    {
+        if (bytes < kMinPooled) return hipMalloc(out, bytes ? bytes : 1);
+        int device = 0;
+        (void)hipGetDevice(&device);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            int best = -1;
+            for (int i = 0; i < (int)blocks_.size(); i++) {
+                const Block &b = blocks_[i];
+                if (!b.busy && b.device == device && b.bytes >= bytes && b.bytes / 2 <= bytes &&
+                    (best < 0 || b.bytes < blocks_[best].bytes))
+                    best = i;
+            }
+            if (best >= 0) {
+                blocks_[best].busy = true;
+                *out = blocks_[best].p;
+                return hipSuccess;
+            }
+        }
+        hipError_t e = hipMalloc(out, bytes);
+        if (e != hipSuccess) {                             // out of memory with blocks parked: drop them and retry once
+            trim();
+            e = hipMalloc(out, bytes);
+        }
+        if (e == hipSuccess) {
+            std::lock_guard<std::mutex> g(m_);
+            blocks_.push_back({*out, bytes, device, true});
+        }
+        return e;
+    }
+    void release(void *p)
+    {
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            bool pooled = false;
+            size_t idle = 0;
+            for (auto &b : blocks_) {
+                if (b.p == p) { b.busy = false; pooled = true; }
+                if (!b.busy) idle += b.bytes;
+            }
+            if (!pooled) drop.push_back(p);
+            while (idle > kKeepBytes) {
+                int big = -1;
+                for (int i = 0; i < (int)blocks_.size(); i++)
+                    if (!blocks_[i].busy && (big < 0 || blocks_[i].bytes > blocks_[big].bytes)) big = i;
+                if (big < 0) break;
+                idle -= blocks_[big].bytes;
+                drop.push_back(blocks_[big].p);
+                blocks_.erase(blocks_.begin() + big);
+            }
+        }
+        for (void *q : drop) (void)hipFree(q);
+    }
+    void trim()
+    {
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            for (int i = (int)blocks_.size() - 1; i >= 0; i--)
+                if (!blocks_[i].busy) {
+                    drop.push_back(blocks_[i].p);
+                    blocks_.erase(blocks_.begin() + i);
+                }
+        }
+        for (void *q : drop) (void)hipFree(q);
+    }
+
+private:
+    static constexpr size_t kMinPooled = (size_t)1 << 20, kKeepBytes = (size_t)64 << 30;
+    struct Block { void *p; size_t bytes; int device; bool busy; };
+    std::mutex m_;
+    std::vector<Block> blocks_;
+};
+
 // RAII device buffer (host-buffer entry points only)
 struct DevBuf {
     void *p = nullptr;
@@ -31,10 +120,11 @@ struct DevBuf {
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p) DevicePool::get().release(p); }
     hipError_t alloc(size_t n) {
+        if (p) { DevicePool::get().release(p); p = nullptr; }
         bytes = n;
-        return hipMalloc(&p, n ? n : 1);
+        return DevicePool::get().acquire(&p, n ? n : 1);
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };

@@ -9,6 +9,9 @@ namespace vga {
 // one-row slots and small chunks on small inputs so that every hand-off of the pipeline is exercised on the GPU box.
 struct PipeOverride { int feeders = 0, drainers = 0, chunk_units = 0, slot_bytes = 0; };
 PipeOverride &pipe_override();                       // capi_gcadpcm.hip
+// the calling thread's last pipeline run, plus what the entry point spent around it (device allocation, small copies)
+struct PipeReport { pipe::Stats stats; double t_alloc = 0, t_entry = 0; };
+PipeReport &pipe_report();                           // capi_gcadpcm.hip
 
 // Units per chunk run_batch_pipeline() will use for this job (callers size per-chunk scratch with it).
 inline int planned_chunk_units(const pipe::Job &job, int default_chunk_units)
@@ -34,12 +37,17 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     job.device = device;
     const size_t in_total = job.in_rows ? (size_t)job.units * job.in_rows_per_unit * job.in_row_bytes : 0;
     const size_t out_total = job.out_rows ? (size_t)job.units * job.out_rows_per_unit * job.out_row_bytes : 0;
-    const size_t per_worker = (size_t)16 << 20;      // a worker thread is worth starting for every 16 MB it moves
-    job.feeders = o.feeders > 0 ? o.feeders : (int)std::min<size_t>(8, std::max<size_t>(1, in_total / per_worker));
-    job.drainers = o.drainers > 0 ? o.drainers : (int)std::min<size_t>(4, std::max<size_t>(1, out_total / per_worker));
-    job.slot_bytes = o.slot_bytes > 0 ? (size_t)o.slot_bytes : (size_t)8 << 20;
+    // Measured at configs[1] (tools/sweep_host_pipeline.py, profiles/r02_sweep_pipeline.log): one feeder thread copies
+    // ~23 GB/s into its ring, the DMA engines take ~57 GB/s in total (both directions together), so 4 feeders and 2
+    // drainers with 32 MB slots keep them busy; 8 + 4 threads with 8 MB slots were 25 % slower (more, smaller DMAs).
+    const size_t per_worker = (size_t)64 << 20;      // a worker thread is worth starting for every 64 MB it moves
+    job.feeders = o.feeders > 0 ? o.feeders : (int)std::min<size_t>(4, std::max<size_t>(1, in_total / per_worker));
+    job.drainers = o.drainers > 0 ? o.drainers : (int)std::min<size_t>(2, std::max<size_t>(1, out_total / per_worker));
+    job.slot_bytes = o.slot_bytes > 0 ? (size_t)o.slot_bytes : (size_t)32 << 20;
     job.chunk_units = planned_chunk_units(job, default_chunk_units);
+    job.taper_min_units = std::max(1, job.chunk_units / 4);       // ..., chunk, chunk/2, chunk/4, chunk/4
     const pipe::Result r = pipe::run(job);
+    pipe_report().stats = r.stats;
     if (r.code) {
         set_error("%s", r.why.c_str());
         return r.code;

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
@@ -109,6 +110,8 @@ struct PinnedBlock {
 struct Job {
     int units = 0;
     int chunk_units = 0;                 // kernels are launched per chunk of this many units
+    int taper_min_units = 0;             // > 0: the LAST chunk is split into halves down to this size (chunk, ..., chunk/2,
+                                         // chunk/4, chunk/4): what runs after the last upload is a small chunk's kernels
     // input side (rows of in_row_bytes bytes at host pointers in_rows[r]; device row r at d_in + r * d_in_pitch)
     int in_rows_per_unit = 1;
     const void *const *in_rows = nullptr;
@@ -129,15 +132,31 @@ struct Job {
     int device = 0;
 };
 
+// Where the wall time of one run() went (seconds): per-thread sums, and the slowest thread of each kind.
+struct Stats {
+    double setup = 0, total = 0;
+    double feed_copy = 0, feed_wait_slot = 0, feed_issue = 0, feed_max = 0;       // feeders: memcpy into the ring, waiting for a slot, hipMemcpyAsync calls
+    double main_wait_upload = 0, main_launch = 0, main_tail_sync = 0;               // calling thread
+    double drain_wait_compute = 0, drain_wait_copy = 0, drain_copy = 0, drain_max = 0;
+    int feeders = 0, drainers = 0, chunks = 0, chunk_units = 0;
+};
+
 struct Result {
     int code = 0;                          // 0 = ok; otherwise the first failure
     std::string why;
+    Stats stats;
 };
 
 namespace detail {
 
+inline double now()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 struct Shared {
     std::mutex m;
+    Stats st;                              // guarded by m
     std::condition_variable cv;
     std::vector<int> uploaded;             // per chunk: feeders that have recorded its event
     std::vector<char> launched;            // per chunk: compute event recorded
@@ -184,8 +203,25 @@ inline Result run(const Job &job)
     using namespace detail;
     Result res;
     if (job.units <= 0) return res;
+    const double t_begin = now();
     const int chunk_units = std::max(1, std::min(job.chunk_units > 0 ? job.chunk_units : job.units, job.units));
-    const int chunks = (job.units + chunk_units - 1) / chunk_units;
+    // chunk k covers units [cbegin[k], cbegin[k + 1])
+    std::vector<int> cbegin;
+    for (int u = 0; u < job.units; u += chunk_units) cbegin.push_back(u);
+    cbegin.push_back(job.units);
+    if (job.taper_min_units > 0 && cbegin.size() >= 3) {   // at least two chunks: taper the last one
+        int lo = cbegin[cbegin.size() - 2];
+        const int hi = job.units;
+        cbegin.pop_back();
+        int len = hi - lo;
+        while (len >= 2 * job.taper_min_units) {
+            lo += len / 2;
+            cbegin.push_back(lo);
+            len = hi - lo;
+        }
+        cbegin.push_back(hi);
+    }
+    const int chunks = (int)cbegin.size() - 1;
     const bool has_in = job.in_rows && job.in_row_bytes > 0 && job.in_rows_per_unit > 0;
     const bool has_out = job.out_rows && job.out_row_bytes > 0 && job.out_rows_per_unit > 0;
     const int F = has_in ? std::max(1, job.feeders) : 0;
@@ -219,27 +255,40 @@ inline Result run(const Job &job)
     if (ok && has_in && !in_ring.alloc((size_t)F * R * in_slot_rows * job.d_in_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (input ring)");
     if (ok && has_out && !out_ring.alloc((size_t)D * R * out_slot_rows * job.d_out_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (output ring)");
 
-    auto chunk_units_of = [&](int k) { return std::min(chunk_units, job.units - k * chunk_units); };
+    auto chunk_units_of = [&](int k) { return cbegin[k + 1] - cbegin[k]; };
 
     // ---------------------------------------------------------------- feeder t
     auto feeder = [&](int t) {
         VGA_PIPE_TRY(hipSetDevice(job.device));
         char *ring = static_cast<char *>(in_ring.p) + (size_t)t * R * in_slot_rows * job.d_in_pitch;
         int64_t used = 0;                                  // slots handed to the DMA engine so far
+        double t_copy = 0, t_wait = 0, t_issue = 0;
+        const double t_start = now();
+        struct Report {
+            Shared &sh; double &c, &w, &i; const double &t0;
+            ~Report() { std::lock_guard<std::mutex> g(sh.m); sh.st.feed_copy += c; sh.st.feed_wait_slot += w; sh.st.feed_issue += i;
+                        sh.st.feed_max = std::max(sh.st.feed_max, now() - t0); }
+        } report{sh, t_copy, t_wait, t_issue, t_start};
         for (int k = 0; k < chunks && !sh.err.load(); k++) {
-            const int row0 = k * chunk_units * job.in_rows_per_unit;
-            const int row1 = row0 + chunk_units_of(k) * job.in_rows_per_unit;
+            const int row0 = cbegin[k] * job.in_rows_per_unit;
+            const int row1 = cbegin[k + 1] * job.in_rows_per_unit;
             int lo, hi;
             split(row0, row1, F, t, lo, hi);
             for (int r = lo; r < hi && !sh.err.load(); r += in_slot_rows) {
                 const int n = std::min(in_slot_rows, hi - r);
                 const int s = (int)(used % R);
+                double ta = now();
                 if (used >= R) VGA_PIPE_TRY(hipEventSynchronize(fslot[t * R + s]));      // the slot's previous upload is done
+                double tb = now();
+                t_wait += tb - ta;
                 char *slot = ring + (size_t)s * in_slot_rows * job.d_in_pitch;
                 for (int i = 0; i < n; i++) std::memcpy(slot + (size_t)i * job.d_in_pitch, job.in_rows[r + i], job.in_row_bytes);
+                ta = now();
+                t_copy += ta - tb;
                 const size_t bytes = (size_t)(n - 1) * job.d_in_pitch + job.in_row_bytes;
                 VGA_PIPE_TRY(hipMemcpyAsync(job.d_in + (size_t)r * job.d_in_pitch, slot, bytes, hipMemcpyHostToDevice, fstream[t]));
                 VGA_PIPE_TRY(hipEventRecord(fslot[t * R + s], fstream[t]));
+                t_issue += now() - ta;
                 used++;
             }
             VGA_PIPE_TRY(hipEventRecord(upl[t * chunks + k], fstream[t]));
@@ -259,28 +308,46 @@ inline Result run(const Job &job)
         struct Pending { int row = -1, n = 0; };
         std::vector<Pending> pend(R);
         int64_t used = 0;
+        double t_wait_comp = 0, t_wait_copy = 0, t_copy = 0;
+        const double t_start = now();
+        struct Report {
+            Shared &sh; double &a, &b, &c; const double &t0;
+            ~Report() { std::lock_guard<std::mutex> g(sh.m); sh.st.drain_wait_compute += a; sh.st.drain_wait_copy += b; sh.st.drain_copy += c;
+                        sh.st.drain_max = std::max(sh.st.drain_max, now() - t0); }
+        } report{sh, t_wait_comp, t_wait_copy, t_copy, t_start};
         auto flush = [&](int s) -> bool {                  // slot s: wait for its download, hand the rows to the caller
             if (pend[s].row < 0) return true;
+            const double ta = now();
             hipError_t e = hipEventSynchronize(dslot[u * R + s]);
             if (e != hipSuccess) {
                 sh.fail(-5, hip_msg("hipEventSynchronize", e));
                 return false;
             }
+            const double tb = now();
+            t_wait_copy += tb - ta;
             const char *slot = ring + (size_t)s * out_slot_rows * job.d_out_pitch;
             for (int i = 0; i < pend[s].n; i++)
                 std::memcpy(job.out_rows[pend[s].row + i], slot + (size_t)i * job.d_out_pitch, job.out_row_bytes);
+            t_copy += now() - tb;
             pend[s].row = -1;
             return true;
         };
         for (int k = 0; k < chunks; k++) {
             {
+                const double ta = now();
                 std::unique_lock<std::mutex> g(sh.m);
                 sh.cv.wait(g, [&] { return sh.launched[k] || sh.err.load(); });
+                t_wait_comp += now() - ta;
             }
             if (sh.err.load()) break;
             VGA_PIPE_TRY(hipStreamWaitEvent(dstream[u], comp[k], 0));
-            const int row0 = k * chunk_units * job.out_rows_per_unit;
-            const int row1 = row0 + chunk_units_of(k) * job.out_rows_per_unit;
+            {                                              // not needed for ordering (the copies are stream-ordered behind the
+                const double ta = now();                   // event); it only attributes the wait to "compute" in the stats
+                VGA_PIPE_TRY(hipEventSynchronize(comp[k]));
+                t_wait_comp += now() - ta;
+            }
+            const int row0 = cbegin[k] * job.out_rows_per_unit;
+            const int row1 = cbegin[k + 1] * job.out_rows_per_unit;
             int lo, hi;
             split(row0, row1, D, u, lo, hi);
             for (int r = lo; r < hi && !sh.err.load(); r += out_slot_rows) {
@@ -302,32 +369,47 @@ inline Result run(const Job &job)
     };
 
     std::vector<std::thread> threads;
+    const double t_setup_done = now();
     if (ok) {
         for (int t = 0; t < F; t++) threads.emplace_back(feeder, t);
         for (int u = 0; u < D; u++) threads.emplace_back(drainer, u);
         // ---------------------------------------------------------------- the calling thread: kernels, chunk by chunk
         [&] {
+            double t_wait = 0, t_launch = 0;
+            struct Report {
+                Shared &sh; double &a, &b;
+                ~Report() { std::lock_guard<std::mutex> g(sh.m); sh.st.main_wait_upload = a; sh.st.main_launch = b; }
+            } report{sh, t_wait, t_launch};
             for (int k = 0; k < chunks; k++) {
+                double ta = now();
                 if (F > 0) {
                     std::unique_lock<std::mutex> g(sh.m);
                     sh.cv.wait(g, [&] { return sh.uploaded[k] == F || sh.err.load(); });
                 }
                 if (sh.err.load()) return;
+                double tb = now();
+                t_wait += tb - ta;
                 for (int t = 0; t < F; t++) VGA_PIPE_TRY(hipStreamWaitEvent(cstream, upl[t * chunks + k], 0));
                 std::string why;
-                const int rc = job.compute(k * chunk_units, chunk_units_of(k), cstream, why);
+                const int rc = job.compute(cbegin[k], chunk_units_of(k), cstream, why);
                 if (rc) {
                     sh.fail(rc, why);
                     return;
                 }
                 VGA_PIPE_TRY(hipEventRecord(comp[k], cstream));
+                t_launch += now() - tb;
                 {
                     std::lock_guard<std::mutex> g(sh.m);
                     sh.launched[k] = 1;
                 }
                 sh.cv.notify_all();
             }
+            const double tc = now();
             VGA_PIPE_TRY(hipStreamSynchronize(cstream));
+            {
+                std::lock_guard<std::mutex> g(sh.m);
+                sh.st.main_tail_sync = now() - tc;
+            }
         }();
         for (auto &th : threads) th.join();
         if (sh.err.load()) {
@@ -344,6 +426,13 @@ inline Result run(const Job &job)
     for (auto s : fstream) if (s) (void)hipStreamDestroy(s);
     for (auto s : dstream) if (s) (void)hipStreamDestroy(s);
     if (cstream) (void)hipStreamDestroy(cstream);
+    res.stats = sh.st;
+    res.stats.setup = t_setup_done - t_begin;
+    res.stats.total = now() - t_begin;
+    res.stats.feeders = F;
+    res.stats.drainers = D;
+    res.stats.chunks = chunks;
+    res.stats.chunk_units = chunk_units;
     return res;
 }
 
