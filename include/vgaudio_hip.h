@@ -418,12 +418,35 @@ int vga_adx_crypt_device(uint8_t *d_audio, int64_t audio_pitch, int audio_len, i
 /* FindKey over `keys` (host array): *index_out = first candidate every frame header agrees with, or -1 */
 int vga_adx_find_key_device(const uint8_t *d_audio, int64_t audio_pitch, int audio_len, int nch, int encryption_type,
                             int frame_size, const vga_adx_key *keys, int nkeys, int *index_out, void *stream);
+/* The brute-force key search of the reference's `crackadx` tool for one file (VGAudio.Tools/CrackAdx/GuessAdx.cs:118-218:
+ * Run / TryScale / FindStartingKey / KeyIsValid).  scales = the file's big-endian 16-bit frame headers in stream order
+ * (AdxFile.Scales), start_frame = the frame holding the file's first non-zero byte (AdxFile.StartFrame).  mults / incs:
+ * candidate lists, NULL = the reference's sets for the type (vga_adx_guess_default_candidates: 0x400 primes each for
+ * type 8; 2048 / 4096 values for type 9).  keys_out receives the keys every scale agrees with, sorted by
+ * (seed, mult, inc), without duplicates; the confidence report (re-encode and diff) is the caller's
+ * (vga_adx_decode_batch + vga_adx_encode_batch). */
+int vga_adx_guess_default_candidates(int encryption_type, int *mults, int *nmult, int *incs, int *ninc);
+int vga_adx_guess_keys(const uint16_t *scales, int nscales, int start_frame, int encryption_type, const int *mults, int nmult,
+                       const int *incs, int ninc, vga_adx_key *keys_out, int max_keys, int *nkeys_out);
 /* CriHcaKey: key_type 56 = CriHcaKey(ulong keyCode), 0 / 1 = CriHcaKey(Type); both tables are 256 bytes */
 int vga_hca_key_tables(int key_type, uint64_t key_code, uint8_t *decryption_table, uint8_t *encryption_table);
 /* Crypt: substitute the first FrameSize - 2 bytes of every frame, refresh its CRC-16; table in host memory */
 int vga_hca_crypt(uint8_t *frames, int frame_count, int frame_size, const uint8_t *table);
 int vga_hca_crypt_device(uint8_t *d_frames, int64_t frames_pitch, int nstreams, int frame_count, int frame_size,
                          const uint8_t *table, void *stream);
+/* CriHcaEncryption.FindKey / TestKey (CriHcaEncryption.cs:34-88) over caller-supplied candidates: decryption_tables =
+ * nkeys x 256 bytes (host memory).  *index_out = the first key under which the first ten non-empty frames unpack
+ * (CriHcaPacking.UnpackFrame), or -1.  VGA_ERR_INVALID_DATA: a frame's sync word is wrong (InvalidDataException). */
+int vga_hca_find_key(const vga_hca_info *info, const uint8_t *frames, int frame_count, const uint8_t *decryption_tables,
+                     int nkeys, int *index_out);
+int vga_hca_find_key_device(const vga_hca_info *info, const uint8_t *d_frames, int frame_count,
+                            const uint8_t *decryption_tables, int nkeys, int *index_out, void *stream);
+/* The statistics the reference's `crackhca` analysis starts from (VGAudio.Tools/CrackHca/Crack.cs:43-80): how often each
+ * byte value occurs at each of the first `positions` (<= 64; the tool uses 30) bytes of the frames.  counts_out:
+ * positions x 256 uint32 in host memory.  The table solver that follows (Solver.cs, Table.cs) is interactive analysis
+ * on those 30 x 256 numbers and stays with the tool. */
+int vga_hca_byte_position_counts_device(const uint8_t *d_frames, int64_t frames_pitch, int nstreams, int frame_count,
+                                        int frame_size, int positions, uint32_t *counts_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,124 @@ int vgo_adx_test_key(const uint8_t *const *adpcm, int adpcm_len, int nch, const 
     return 1;
 }
 
+/* ------------------------------------------------------------------ VGAudio.Tools/CrackAdx/GuessAdx.cs
+ * The key search of the reference's `crackadx` tool for ONE file's frame scales: Run/TryScale (:118-179),
+ * FindStartingKey (:181-204), AddKey's validity filter KeyIsValid (:129-147, :206-218).  The confidence report
+ * (re-encode and diff, :220-262) and the key-string lookup are reporting, not search, and are not restated.
+ * mults / incs: candidate lists (NULL, 0 = the reference's sets for the encryption type, :47-69).  Writes the keys that
+ * survive KeyIsValid, without duplicates, sorted by (seed, mult, inc); returns their count or -1 when more than
+ * max_keys were found. */
+static int adx_key_cmp(const void *a, const void *b)
+{
+    const vgo_adx_key *x = (const vgo_adx_key *)a, *y = (const vgo_adx_key *)b;
+    if (x->seed != y->seed) return x->seed < y->seed ? -1 : 1;
+    if (x->mult != y->mult) return x->mult < y->mult ? -1 : 1;
+    if (x->inc != y->inc) return x->inc < y->inc ? -1 : 1;
+    return 0;
+}
+
+int vgo_adx_default_candidates(int encryption_type, int *mults, int *nmult, int *incs, int *ninc)
+{
+    int nm = 0, ni = 0;
+    if (encryption_type == 8) {
+        build_primes();
+        for (int i = 0; i < 0x400; i++) { if (mults) mults[nm] = g_primes[i]; nm++; if (incs) incs[ni] = g_primes[i]; ni++; }
+    } else if (encryption_type == 9) {
+        for (int x = 0; x < 0x2000; x++) {
+            if ((x & 3) == 1) { if (mults) mults[nm] = x; nm++; }
+            if ((x & 1) == 1) { if (incs) incs[ni] = x; ni++; }
+        }
+    } else {
+        return -1;
+    }
+    *nmult = nm;
+    *ninc = ni;
+    return 0;
+}
+
+int vgo_adx_guess_keys(const uint16_t *scales, int nscales, int start_frame, int encryption_type, const int *mults_in,
+                       int nmult, const int *incs_in, int ninc, vgo_adx_key *out, int max_keys)
+{
+    if (encryption_type != 8 && encryption_type != 9) return -2;
+    if (nscales <= 0 || start_frame < 0 || start_frame >= nscales) return 0;
+    const int validation_mask = encryption_type == 8 ? 0xE000 : 0x1000;
+    const int max_seed = encryption_type == 8 ? 0x8000 : 0x2000;
+    const int xor_mask = 0x7fff;
+    int *mults = NULL, *incs = NULL;
+    if (!mults_in || !incs_in) {
+        mults = (int *)malloc(0x2000 * sizeof(int));
+        incs = (int *)malloc(0x2000 * sizeof(int));
+        vgo_adx_default_candidates(encryption_type, mults, &nmult, incs, &ninc);
+        mults_in = mults;
+        incs_in = incs;
+    }
+    /* PossibleSeeds: type 8 = the 0x400 primes after 0x4000, type 9 = 0 .. 0x1FFF (ascending enumeration) */
+    unsigned char *seed_ok = (unsigned char *)calloc(0x8000, 1);
+    int *seed_list = (int *)malloc(0x2000 * sizeof(int));
+    int nseeds = 0;
+    if (encryption_type == 8) {
+        build_primes();
+        for (int i = 0; i < 0x400; i++) { seed_ok[g_primes[i]] = 1; seed_list[nseeds++] = g_primes[i]; }
+    } else {
+        for (int x = 0; x < 0x2000; x++) { seed_ok[x] = 1; seed_list[nseeds++] = x; }
+    }
+    int count = 0, overflow = 0;
+    for (int index = 0; index < 0x1000 && !overflow; index++) {                 /* Run (:118-128) */
+        const int seed = (scales[start_frame] ^ index) & (max_seed - 1);        /* TryScale (:150-179) */
+        if (start_frame == 0 && !seed_ok[seed]) continue;
+        for (int m = 0; m < nmult && !overflow; m++)
+            for (int n = 0; n < ninc && !overflow; n++) {
+                const int mult = mults_in[m], inc = incs_in[n];
+                int xor = seed, match = 1;
+                for (int i = start_frame; i < nscales; i++) {
+                    const int scale = scales[i];
+                    if (((scale ^ xor) & validation_mask) != 0 && scale != 0) { match = 0; break; }
+                    xor = (xor * mult + inc) & xor_mask;
+                }
+                if (!match) continue;
+                vgo_adx_key key = {seed, mult, inc};                            /* FindStartingKey (:181-204) */
+                int have = start_frame == 0;
+                for (int k = 0; k < nseeds && !have; k++) {
+                    int x = seed_list[k];
+                    for (int i = 0; i < start_frame; i++) x = (x * mult + inc) & xor_mask;
+                    if ((x & (max_seed - 1)) == seed) { key.seed = seed_list[k]; have = 1; }
+                }
+                if (!have) continue;
+                int dup = 0;                                                    /* AddKey: TriedKeys (:131) */
+                for (int k = 0; k < count && !dup; k++) dup = adx_key_cmp(&out[k], &key) == 0;
+                if (dup) continue;
+                int x = key.seed, valid = 1;                                    /* KeyIsValid (:206-218) */
+                for (int i = 0; i < nscales && valid; i++) {
+                    if (((scales[i] ^ x) & validation_mask) != 0 && scales[i] != 0) valid = 0;
+                    x = (x * key.mult + key.inc) & xor_mask;
+                }
+                if (!valid) continue;
+                if (count >= max_keys) { overflow = 1; break; }
+                out[count++] = key;
+            }
+    }
+    free(seed_ok);
+    free(seed_list);
+    free(mults);
+    free(incs);
+    if (overflow) return -1;
+    qsort(out, (size_t)count, sizeof *out, adx_key_cmp);
+    return count;
+}
+
+/* ------------------------------------------------------------------ VGAudio.Tools/CrackHca/Crack.cs:43-80
+ * LoadFrequencies' counting step: how often each byte value occurs at each of the first `positions` bytes of the
+ * frames (the statistics the HCA key analysis starts from).  counts: positions x 256. */
+void vgo_hca_byte_position_counts(const uint8_t *frames, long frames_pitch, int nstreams, int frame_count, int frame_size,
+                                  int positions, uint32_t *counts)
+{
+    memset(counts, 0, (size_t)positions * 256 * sizeof(uint32_t));
+    for (int s = 0; s < nstreams; s++)
+        for (int f = 0; f < frame_count; f++)
+            for (int p = 0; p < positions && p < frame_size; p++)
+                counts[(size_t)p * 256 + frames[(size_t)s * frames_pitch + (size_t)f * frame_size + p]]++;
+}
+
 /* ------------------------------------------------------------------ HCA */
 static void random_row(uint8_t seed, uint8_t row[16])                   /* CreateRandomRow (:116-131) */
 {

@@ -1169,6 +1169,52 @@ static int unpack_frame(hca_frame *f, bit_reader *r)
     return 0;
 }
 
+/* CriHcaPacking.UnpackingWasSuccessful / FrameEmpty (CriHcaPacking.cs:213-237) */
+static int unpacking_was_successful(const hca_frame *f, const bit_reader *r)
+{
+    int remaining = r->length_bits - r->position;
+    int empty = f->acceptable_noise_level <= 0;
+    for (int c = 0; c < f->nch && empty; c++)
+        if (f->ch[c].sf_delta_bits > 0) empty = 0;
+    return (remaining >= 16 && remaining <= 128) || empty || (f->acceptable_noise_level == 0 && remaining >= 16);
+}
+
+/* CriHcaEncryption.FindKey / TestKey / FindFirstNonEmptyFrame / FrameEmpty (CriHcaEncryption.cs:34-88) over a
+ * caller-supplied list of 256-byte DECRYPTION tables.  Returns the index of the first key under which the first ten
+ * non-empty frames unpack, -1 when none does, -3 when a frame's sync word is wrong (InvalidDataException). */
+int vgo_hca_find_key(const vgo_hca_info *h, const uint8_t *frames, int frame_count, const uint8_t *tables, int nkeys)
+{
+    ensure_tables();
+    const int fs = h->frame_size;
+    int start = 0;
+    for (int i = 0; i < frame_count; i++) {
+        int empty = 1;
+        for (int b = 2; b < fs - 2; b++)
+            if (frames[(size_t)i * fs + b]) { empty = 0; break; }
+        if (!empty) { start = i; break; }
+    }
+    int end = frame_count < start + 10 ? frame_count : start + 10;
+    hca_frame *f = frame_new(h);
+    uint8_t *buffer = (uint8_t *)malloc((size_t)fs);
+    int found = -1;
+    for (int k = 0; k < nkeys && found == -1; k++) {
+        const uint8_t *table = tables + (size_t)k * 256;
+        int ok = 1;
+        for (int i = start; i < end && ok; i++) {
+            memcpy(buffer, frames + (size_t)i * fs, (size_t)fs);
+            vgo_hca_crypt(buffer, 1, fs, table);                          /* CryptFrame(.., doDecrypt: true) */
+            bit_reader r = {buffer, fs * 8, 0};
+            int rc = unpack_frame(f, &r);
+            if (rc == -3) { found = -3; ok = 0; break; }
+            if (rc == 1 || !unpacking_was_successful(f, &r)) ok = 0;
+        }
+        if (ok && found == -1) found = k;
+    }
+    free(buffer);
+    frame_free(f);
+    return found;
+}
+
 /* CriHcaDecoder.DecodeFrame :72-192 */
 static int decode_frame(hca_frame *f, const uint8_t *audio, int16_t *const *pcm_out)
 {

@@ -253,6 +253,15 @@ void vgo_adx_crypt_channel(uint8_t *adpcm, int adpcm_len, const vgo_adx_key *key
 int vgo_adx_test_key(const uint8_t *const *adpcm, int adpcm_len, int nch, const vgo_adx_key *key, int encryption_type, int frame_size);
 int vgo_hca_key_tables(int key_type, uint64_t key_code, uint8_t decryption[256], uint8_t encryption[256]);
 void vgo_hca_crypt(uint8_t *frames, int frame_count, int frame_size, const uint8_t table[256]);
+/* CriHcaEncryption.FindKey over caller-supplied decryption tables (hca_oracle.c); -1 none, -3 bad sync word */
+int vgo_hca_find_key(const vgo_hca_info *h, const uint8_t *frames, int frame_count, const uint8_t *tables, int nkeys);
+/* VGAudio.Tools/CrackAdx/GuessAdx.cs: the brute-force key search for one file's frame scales */
+int vgo_adx_default_candidates(int encryption_type, int *mults, int *nmult, int *incs, int *ninc);
+int vgo_adx_guess_keys(const uint16_t *scales, int nscales, int start_frame, int encryption_type, const int *mults,
+                       int nmult, const int *incs, int ninc, vgo_adx_key *out, int max_keys);
+/* VGAudio.Tools/CrackHca/Crack.cs:43-80: byte-value counts at the first `positions` bytes of every frame */
+void vgo_hca_byte_position_counts(const uint8_t *frames, long frames_pitch, int nstreams, int frame_count, int frame_size,
+                                  int positions, uint32_t *counts);
 int vgo_bitwriter_write(uint8_t *buf, int buf_len, int position, int value, int bit_count);  /* BitWriter.cs:26-70 */
 void vgo_mdct_run(const double *in, int blocks, double *out, int inverse);   /* Mdct.cs:63-119, 128-point, HCA scale */
 int vgo_hca_debug_last_frame(const int16_t *pcm, long pitch, const vgo_hca_params *c, int frames,

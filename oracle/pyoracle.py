@@ -589,6 +589,53 @@ def hca_crypt(frames, frame_size, table):
     return out
 
 
+def hca_find_key(info, frames, tables):
+    """CriHcaEncryption.FindKey over `tables` ([nkeys, 256] decryption tables): index, -1 (none) or -3 (bad sync word)"""
+    frames = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1)
+    tables = np.ascontiguousarray(tables, dtype=np.uint8).reshape(-1, 256)
+    f = lib().vgo_hca_find_key
+    f.restype, f.argtypes = C.c_int, [C.POINTER(HcaInfo), C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8), C.c_int]
+    return f(C.byref(info), _u8(frames), len(frames) // info.frame_size, _u8(tables), tables.shape[0])
+
+
+def adx_guess_default_candidates(encryption_type):
+    m, n = np.zeros(0x2000, np.int32), np.zeros(0x2000, np.int32)
+    nm, nn = C.c_int(), C.c_int()
+    f = lib().vgo_adx_default_candidates
+    f.restype, f.argtypes = C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int)]
+    assert f(encryption_type, m.ctypes.data, C.byref(nm), n.ctypes.data, C.byref(nn)) == 0
+    return m[:nm.value].copy(), n[:nn.value].copy()
+
+
+def adx_guess_keys(scales, start_frame, encryption_type, mults=None, incs=None, max_keys=4096):
+    """GuessAdx's search for one file's scales -> sorted list of (seed, mult, inc); None when more than max_keys"""
+    scales = np.ascontiguousarray(scales, dtype=np.uint16)
+    out = (AdxKey * max_keys)()
+    f = lib().vgo_adx_guess_keys
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(AdxKey), C.c_int]
+    if mults is None or incs is None:
+        n = f(scales.ctypes.data, len(scales), start_frame, encryption_type, None, 0, None, 0, out, max_keys)
+    else:
+        m = np.ascontiguousarray(mults, dtype=np.int32)
+        i = np.ascontiguousarray(incs, dtype=np.int32)
+        n = f(scales.ctypes.data, len(scales), start_frame, encryption_type, m.ctypes.data, len(m), i.ctypes.data, len(i), out, max_keys)
+    if n < 0:
+        return None
+    return [(out[k].seed, out[k].mult, out[k].inc) for k in range(n)]
+
+
+def hca_byte_position_counts(frames2d, frame_size, positions=30):
+    frames2d = np.ascontiguousarray(frames2d, dtype=np.uint8)
+    ns, pitch = frames2d.shape
+    counts = np.zeros((positions, 256), dtype=np.uint32)
+    f = lib().vgo_hca_byte_position_counts
+    f.restype = None
+    f.argtypes = [C.POINTER(C.c_uint8), C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    f(_u8(frames2d), pitch, ns, pitch // frame_size, frame_size, positions, counts.ctypes.data)
+    return counts
+
+
 # ---------------- ADX ----------------
 def adx_params(**kw):
     p = AdxParams()

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import pyoracle as po
+import vgaudio_amd
 from vgaudio_amd import _lib, synth
 from vgaudio_amd.adx import AdxConfiguration, AdxWriter
 from vgaudio_amd.criadx import CriAdxEncryption, CriAdxFormat, CriAdxKey, CriAdxParameters
@@ -144,3 +145,103 @@ def test_hca_encrypted_file():
     assert f[:4] == bytes([0xC8, 0xC3, 0xC1, 0x00])
     rc, r, vol, etype, comment, ver = po.hcafile_read(f)                       # the reader masks the ids off again
     assert rc == 0 and etype == 56 and r.frame_count == info.frame_count
+
+
+# ---------------------------------------------------------------- key searches (remainder)
+def test_hca_find_key_matches_oracle():
+    """CriHcaEncryption.FindKey / TestKey (CriHcaEncryption.cs:34-88) over candidate lists, against the oracle's literal loop."""
+    from vgaudio_amd.crihca import CriHcaEncryption, CriHcaFormat, CriHcaKey, CriHcaParameters
+    from vgaudio_amd.gcadpcm import Pcm16Format
+    rng = np.random.default_rng(77)
+    for nch, quality, n, silence in ((2, 2, 1024 * 14, 3000), (1, 5, 1024 * 12, 0), (2, 4, 1024 * 6, 1024 * 3), (2, 2, 1024 * 3, 0)):
+        x = synth.generate(nch, n)
+        x[:, :silence] = 0
+        fmt = CriHcaFormat().EncodeFromPcm16(Pcm16Format(list(x), 48000), CriHcaParameters(Quality=quality))
+        q = {1: "Highest", 2: "High", 3: "Middle", 4: "Low", 5: "Lowest"}[quality]
+        rc, info, frames = po.hca_encode(x, po.hca_params(nch, n, quality=q))
+        assert rc == 0 and np.array_equal(frames, fmt.AudioData)
+        codes = [int(c) for c in rng.integers(1, 2 ** 56, 12)]
+        keys = [CriHcaKey(c) for c in codes]
+        true = 7
+        enc = fmt.AudioData.copy()
+        CriHcaEncryption.Crypt(fmt.Hca, enc, keys[true], False)
+        tables = np.stack([k.DecryptionTable for k in keys])
+        want = po.hca_find_key(info, enc, tables)
+        assert want == true
+        got = CriHcaEncryption.FindKey(fmt.Hca, enc, keys)
+        assert got is keys[true]
+        # without the right key: whatever the literal loop says (normally none)
+        others = keys[:true] + keys[true + 1:]
+        want = po.hca_find_key(info, enc, np.stack([k.DecryptionTable for k in others]))
+        got = CriHcaEncryption.FindKey(fmt.Hca, enc, others)
+        assert (got is None and want == -1) or (want >= 0 and got is others[want])
+        # unencrypted audio and the type-0 key
+        ident = CriHcaKey(CriHcaKey.Type0)
+        assert CriHcaEncryption.FindKey(fmt.Hca, fmt.AudioData, [keys[0], ident]) is ident
+    bad = enc.copy()
+    bad[1, 0] = 0x12
+    with pytest.raises(vgaudio_amd.InvalidDataError):
+        CriHcaEncryption.FindKey(fmt.Hca, bad, keys)
+
+
+def test_hca_find_key_random_frames_agree_with_oracle():
+    """Random bytes behind a valid sync word: validity is decided by the bit walk alone; every key must get the oracle's verdict."""
+    from vgaudio_amd.crihca import CriHcaEncoder, CriHcaEncryption, CriHcaKey, CriHcaParameters
+    rng = np.random.default_rng(5)
+    enc = CriHcaEncoder.InitializeNew(CriHcaParameters(ChannelCount=2, SampleRate=48000, SampleCount=1024 * 8, Quality=4))
+    hca = enc.Hca
+    rc, info = po.hca_init(po.hca_params(2, 1024 * 8, quality="Low"))
+    frames = rng.integers(0, 256, (hca.FrameCount, hca.FrameSize)).astype(np.uint8)
+    frames[:, :2] = 0xFF
+    frames[:, 2] &= 0x0F                                        # small noise levels: more frames survive
+    keys = [CriHcaKey(int(c)) for c in rng.integers(1, 2 ** 56, 40)] + [CriHcaKey(CriHcaKey.Type0), CriHcaKey(CriHcaKey.Type1)]
+    for k in range(len(keys)):                                  # one candidate at a time: the verdict for every key
+        want = po.hca_find_key(info, frames, keys[k].DecryptionTable[None, :])
+        got = CriHcaEncryption.FindKey(hca, frames, [keys[k]])
+        assert (want == 0) == (got is keys[k]), k
+
+
+def test_adx_guess_keys_matches_oracle_and_finds_the_key():
+    """GuessAdx (VGAudio.Tools/CrackAdx/GuessAdx.cs:118-218): reduced candidate lists against the oracle's literal loops,
+    then the reference's full candidate sets (4096 x 1024 x 1024 triples for type 8) on the GPU alone."""
+    from vgaudio_amd.criadx import AdxFile, CriAdxKey, GuessAdx
+    rng = np.random.default_rng(21)
+    pcm = synth.generate(1, 32 * 600)[0]
+    audio = po.adx_encode(pcm, po.adx_params())
+    for etype, key in ((8, CriAdxKey("crack me")), (9, CriAdxKey(0x123456789))):
+        mults, incs = po.adx_guess_default_candidates(etype)
+        gm, gi = GuessAdx.DefaultCandidates(etype)
+        assert np.array_equal(mults, gm) and np.array_equal(incs, gi)
+        for start_silence in (0, 4):
+            a = audio.copy()
+            a[:18 * start_silence] = 0
+            enc = po.adx_crypt([a], po.AdxKey(key.Seed, key.Mult, key.Inc), etype)[0]
+            f = AdxFile(enc, 18)
+            assert f.StartFrame == start_silence
+            sub_m = np.unique(np.concatenate([rng.choice(mults, 24, replace=False), [key.Mult]])).astype(np.int32)
+            sub_i = np.unique(np.concatenate([rng.choice(incs, 24, replace=False), [key.Inc]])).astype(np.int32)
+            want = po.adx_guess_keys(f.Scales, f.StartFrame, etype, sub_m, sub_i)
+            got = [(k.Seed, k.Mult, k.Inc) for k in GuessAdx.Run(f, etype, sub_m, sub_i)]
+            assert got == want and (key.Seed & (0x7fff if etype == 8 else 0x1fff), key.Mult, key.Inc) in [(s & (0x7fff if etype == 8 else 0x1fff), m, i) for s, m, i in got]
+    # the full search, type 8
+    key = CriAdxKey("crack me")
+    enc = po.adx_crypt([audio], po.AdxKey(key.Seed, key.Mult, key.Inc), 8)[0]
+    found = [(k.Seed, k.Mult, k.Inc) for k in GuessAdx.Run(AdxFile(enc, 18), 8)]
+    assert (key.Seed, key.Mult, key.Inc) in found and len(found) < 50
+    for s, m, i in found:
+        assert po.adx_test_key([enc], po.AdxKey(s, m, i), 8) == 1
+
+
+def test_hca_byte_position_counts_match_oracle():
+    import ctypes as C
+    import torch
+    from vgaudio_amd import _lib
+    rng = np.random.default_rng(2)
+    ns, fc, fs = 5, 37, 100
+    frames = rng.integers(0, 256, (ns, fc * fs + 12)).astype(np.uint8)
+    d = torch.from_numpy(frames).cuda()
+    counts = np.zeros((30, 256), dtype=np.uint32)
+    _lib.check(_lib.lib().vga_hca_byte_position_counts_device(d.data_ptr(), frames.shape[1], ns, fc, fs, 30, counts.ctypes.data,
+                                                              torch.cuda.current_stream().cuda_stream))
+    want = po.hca_byte_position_counts(frames[:, :fc * fs], fs, 30)
+    assert np.array_equal(counts, want)

@@ -123,3 +123,68 @@ def test_hca_crypt_round_trip_and_crc():
     d = po.hca_crypt(e, info.frame_size, dec).reshape(info.frame_count, info.frame_size)
     assert np.array_equal(d, frames)
     assert np.array_equal(e[:, :-2], enc[frames[:, :-2]])
+
+
+# ---------------------------------------------------------------- key searches (remainder)
+def test_hca_find_key_finds_the_key_that_encrypted_the_stream():
+    """CriHcaEncryption.FindKey (CriHcaEncryption.cs:34-88): encrypt a real stream, offer the right key among wrong ones."""
+    from vgaudio_amd import synth
+    n = 1024 * 14
+    x = synth.generate(2, n)
+    x[:, :3000] = 0                                            # leading silence: FindFirstNonEmptyFrame has work to do
+    rc, info, frames = po.hca_encode(x, po.hca_params(2, n))
+    assert rc == 0
+    codes = [0x1234, 12345678901234, 0xCC55463930DBE1AB, 765765765765765, 2]
+    tables = [po.hca_key_tables(56, c)[1] for c in codes]
+    enc_table = po.hca_key_tables(56, codes[2])[2]
+    enc = po.hca_crypt(frames, info.frame_size, enc_table).reshape(frames.shape)
+    assert po.hca_find_key(info, enc, np.stack(tables)) == 2
+    assert po.hca_find_key(info, enc, np.stack(tables[:2] + tables[3:])) == -1
+    assert po.hca_find_key(info, enc, np.stack([tables[2]])) == 0
+    # an unencrypted stream is explained by the identity (type 0) table
+    ident = po.hca_key_tables(0)[1]
+    assert po.hca_find_key(info, frames, np.stack([tables[0], ident])) == 1
+    # a wrong sync word is the reference's InvalidDataException
+    bad = enc.copy()
+    bad[4, 0] = 0x12
+    assert po.hca_find_key(info, bad, np.stack(tables)) == -3
+
+
+def test_adx_guess_keys_recovers_the_key_from_scales():
+    """GuessAdx (VGAudio.Tools/CrackAdx/GuessAdx.cs:118-218) on reduced candidate lists: the true key is found, every
+    key returned explains every scale, and a start frame > 0 is traced back to the starting seed."""
+    from vgaudio_amd import synth
+    rng = np.random.default_rng(8)
+    pcm = synth.generate(1, 32 * 400)[0]
+    audio = po.adx_encode(pcm, po.adx_params())
+    mults, incs = po.adx_guess_default_candidates(8)
+    assert len(mults) == 0x400 and len(incs) == 0x400 and mults[0] == 16411 and (mults == incs).all()   # the first prime after 0x4000
+    m9, i9 = po.adx_guess_default_candidates(9)
+    assert len(m9) == 2048 and len(i9) == 4096 and m9[0] == 1 and m9[1] == 5 and i9[1] == 3
+    for start_silence in (0, 5):
+        a = audio.copy()
+        if start_silence:
+            a[:18 * start_silence] = 0
+        key = po.adx_key_from_string("crack me")
+        enc = po.adx_crypt([a], key, 8)[0]
+        scales = (enc.reshape(-1, 18)[:, 0].astype(np.uint16) << 8) | enc.reshape(-1, 18)[:, 1]
+        start = int(np.flatnonzero(enc)[0]) // 18
+        assert start == start_silence
+        sub_m = np.unique(np.concatenate([rng.choice(mults, 40, replace=False), [key.mult]])).astype(np.int32)
+        sub_i = np.unique(np.concatenate([rng.choice(incs, 40, replace=False), [key.inc]])).astype(np.int32)
+        keys = po.adx_guess_keys(scales, start, 8, sub_m, sub_i)
+        assert (key.seed, key.mult, key.inc) in keys, (start_silence, keys[:5])
+        assert keys == sorted(set(keys))
+        for seed, mult, inc in keys:                            # KeyIsValid: every key explains every scale
+            k = po.AdxKey(seed, mult, inc)
+            assert po.adx_test_key([enc], k, 8) == 1
+
+
+def test_hca_byte_position_counts():
+    rng = np.random.default_rng(1)
+    frames = rng.integers(0, 256, (3, 7 * 100)).astype(np.uint8)
+    counts = po.hca_byte_position_counts(frames, 100, positions=30)
+    assert counts.sum() == 30 * 21
+    f = frames.reshape(3, 7, 100)
+    for p in (0, 13, 29):
+        assert (counts[p] == np.bincount(f[:, :, p].reshape(-1), minlength=256)).all()

@@ -111,6 +111,11 @@ SIGNATURES = {
     "vga_adx_find_key_device": (ci, [vp, i64, ci, ci, ci, ci, vp, ci, C.POINTER(ci), vp]),
     "vga_hca_key_tables": (ci, [ci, C.c_uint64, u8p, u8p]),
     "vga_hca_crypt": (ci, [u8p, ci, ci, u8p]),
+    "vga_hca_find_key": (ci, [vp, u8p, ci, u8p, ci, vp]),
+    "vga_hca_find_key_device": (ci, [vp, vp, ci, u8p, ci, vp, vp]),
+    "vga_hca_byte_position_counts_device": (ci, [vp, i64, ci, ci, ci, ci, vp, vp]),
+    "vga_adx_guess_default_candidates": (ci, [vp, vp, vp, vp]),
+    "vga_adx_guess_keys": (ci, [vp, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp]),
     "vga_hca_crypt_device": (ci, [vp, i64, ci, ci, ci, u8p, vp]),
     "vga_release_cached_memory": (None, []),
     "vga_testing_force_open_seams_this_thread": (ci, [ci]),

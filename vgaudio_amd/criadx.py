@@ -218,3 +218,45 @@ class CriAdxEncryption:
         check(_lib.lib().vga_adx_find_key_device(d.data_ptr(), host.shape[1], n, len(adpcm), encryptionType, frameSize, arr, len(keys),
                                                  C.byref(idx), torch.cuda.current_stream().cuda_stream))
         return keys[idx.value] if idx.value >= 0 else None
+
+
+class AdxFile:
+    """VGAudio.Tools/CrackAdx/GuessAdx.cs:272-303: what the key search needs of one file -- the big-endian 16-bit frame
+    headers in stream order and the frame that holds the first non-zero byte."""
+
+    def __init__(self, audio, frameSize):
+        audio = np.ascontiguousarray(audio, dtype=np.uint8).reshape(-1)
+        self.FrameSize = frameSize
+        self.FrameCount = len(audio) // frameSize
+        a = audio[:self.FrameCount * frameSize].reshape(self.FrameCount, frameSize)
+        self.Scales = ((a[:, 0].astype(np.uint16) << 8) | a[:, 1]).astype(np.uint16)
+        nz = np.flatnonzero(audio)
+        self.StartFrame = int(nz[0]) // frameSize if len(nz) else 0
+
+
+class GuessAdx:
+    """The search of the reference's `crackadx` tool (GuessAdx.Run / TryScale / FindStartingKey / KeyIsValid,
+    GuessAdx.cs:118-218) for one file: every (scale index, multiplier, increment) on the GPU in one call."""
+
+    @staticmethod
+    def DefaultCandidates(encryptionType):
+        m, n = np.zeros(0x2000, np.int32), np.zeros(0x2000, np.int32)
+        nm, nn = C.c_int(), C.c_int()
+        check(_lib.lib().vga_adx_guess_default_candidates(encryptionType, m.ctypes.data, C.byref(nm), n.ctypes.data, C.byref(nn)))
+        return m[:nm.value].copy(), n[:nn.value].copy()
+
+    @staticmethod
+    def Run(adxFile, encryptionType, mults=None, incs=None, maxKeys=4096):
+        scales = np.ascontiguousarray(adxFile.Scales, dtype=np.uint16)
+        out = (_lib.AdxKeyC * maxKeys)()
+        n = C.c_int(0)
+        if mults is None or incs is None:
+            mp = ip = None
+            nm = ni = 0
+        else:
+            m = np.ascontiguousarray(mults, dtype=np.int32)
+            i = np.ascontiguousarray(incs, dtype=np.int32)
+            mp, ip, nm, ni = m.ctypes.data, i.ctypes.data, len(m), len(i)
+        check(_lib.lib().vga_adx_guess_keys(scales.ctypes.data, len(scales), adxFile.StartFrame, encryptionType, mp, nm, ip, ni,
+                                            out, maxKeys, C.byref(n)))
+        return [CriAdxKey(out[k].seed, out[k].mult, out[k].inc) for k in range(n.value)]

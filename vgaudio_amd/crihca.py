@@ -180,3 +180,17 @@ class CriHcaEncryption:
             raise _lib.ArgumentError("Crypt works in place on a contiguous, writable uint8 array")
         table = key.DecryptionTable if doDecrypt else key.EncryptionTable
         check(_lib.lib().vga_hca_crypt(audio.ctypes.data_as(u8p), hca.FrameCount, hca.FrameSize, table.ctypes.data_as(u8p)))
+
+    @staticmethod
+    def FindKey(hca, audio, keys):
+        """CriHcaKey FindKey(HcaInfo hca, byte[][] audio) (CriHcaEncryption.cs:34-46) over the caller's candidate keys
+        (the reference's own list, CriHcaEncryptionKeys.cs, is data and stays with the caller): the first key under
+        which the first ten non-empty frames unpack, or None."""
+        if not keys:
+            return None
+        frames = np.ascontiguousarray(audio, dtype=np.uint8).reshape(-1)
+        tables = np.ascontiguousarray(np.stack([k.DecryptionTable for k in keys]), dtype=np.uint8)
+        idx = C.c_int(-1)
+        check(_lib.lib().vga_hca_find_key(C.byref(hca.c), frames.ctypes.data_as(u8p), len(frames) // hca.FrameSize,
+                                          tables.ctypes.data_as(u8p), len(keys), C.byref(idx)))
+        return keys[idx.value] if idx.value >= 0 else None

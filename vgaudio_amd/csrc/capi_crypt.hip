@@ -2,13 +2,15 @@
 #include "common.hpp"
 #include "crypt_kernels.hpp"
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 using namespace vga;
 
-namespace vga { namespace hca { int crc_pow_table(const uint16_t **out); } }
+namespace vga { namespace hca { int crc_pow_table(const uint16_t **out); int device_info_from(const vga_hca_info &h, DeviceInfo &d); } }
 
 namespace {
 
@@ -145,6 +147,119 @@ int vga_adx_find_key_device(const uint8_t *d_audio, int64_t audio_pitch, int aud
     return VGA_OK;
 }
 
+
+// ---------------------------------------------------------------- VGAudio.Tools/CrackAdx/GuessAdx.cs
+// GuessAdx's candidate sets (:47-69): type 8 = the 0x400 primes after 0x4000 for seed, multiplier and increment;
+// type 9 = seeds 0..0x1FFF, multipliers = 1 mod 4, increments odd, all below 0x2000.
+int vga_adx_guess_default_candidates(int encryption_type, int *mults, int *nmult, int *incs, int *ninc)
+{
+    if (!nmult || !ninc) { set_error("null count pointer"); return VGA_ERR_ARGUMENT; }
+    int nm = 0, ni = 0;
+    if (encryption_type == 8) {
+        const int *pr = adx_primes();
+        for (int i = 0; i < 0x400; i++) { if (mults) mults[nm] = pr[i]; nm++; if (incs) incs[ni] = pr[i]; ni++; }
+    } else if (encryption_type == 9) {
+        for (int x = 0; x < 0x2000; x++) {
+            if ((x & 3) == 1) { if (mults) mults[nm] = x; nm++; }
+            if ((x & 1) == 1) { if (incs) incs[ni] = x; ni++; }
+        }
+    } else {
+        set_error("encryption type %d: the key search knows types 8 and 9", encryption_type);
+        return VGA_ERR_ARGUMENT;
+    }
+    *nmult = nm;
+    *ninc = ni;
+    return VGA_OK;
+}
+
+// GuessAdx.Run / TryScale / FindStartingKey / AddKey's KeyIsValid filter (:118-218) for one file's frame scales
+// (AdxFile.Scales :283-291: big-endian 16-bit frame headers; start_frame = AdxFile.StartFrame, the frame holding the
+// first non-zero byte).  The (index, multiplier, increment) sweep runs on the device; FindStartingKey, the duplicate
+// filter and KeyIsValid run here over the survivors.  Keys come back sorted by (seed, mult, inc).
+int vga_adx_guess_keys(const uint16_t *scales, int nscales, int start_frame, int encryption_type, const int *mults, int nmult,
+                       const int *incs, int ninc, vga_adx_key *keys_out, int max_keys, int *nkeys_out)
+{
+    if (!nkeys_out || max_keys < 0 || (max_keys > 0 && !keys_out)) { set_error("null / negative output arguments"); return VGA_ERR_ARGUMENT; }
+    *nkeys_out = 0;
+    if (encryption_type != 8 && encryption_type != 9) {
+        set_error("encryption type %d: the key search knows types 8 and 9", encryption_type);
+        return VGA_ERR_ARGUMENT;
+    }
+    if (nscales < 0 || start_frame < 0 || (nscales > 0 && !scales)) { set_error("bad scales"); return VGA_ERR_ARGUMENT; }
+    if (nscales == 0 || start_frame >= nscales) return VGA_OK;
+    std::vector<int> dm, di;
+    if (!mults || !incs) {
+        int nm = 0, ni = 0;
+        dm.resize(0x2000);
+        di.resize(0x2000);
+        if (int rc = vga_adx_guess_default_candidates(encryption_type, dm.data(), &nm, di.data(), &ni)) return rc;
+        mults = dm.data(); nmult = nm; incs = di.data(); ninc = ni;
+    }
+    if (nmult <= 0 || ninc <= 0) return VGA_OK;
+    if (int rc = require_device()) return rc;
+    const int max_seed = encryption_type == 8 ? 0x8000 : 0x2000, mask = encryption_type == 8 ? 0xE000 : 0x1000;
+    // PossibleSeeds (:57, :62), in the order the reference enumerates them
+    std::vector<int> seeds;
+    std::vector<uint32_t> bitmap(0x8000 / 32, 0u);
+    if (encryption_type == 8) { const int *pr = adx_primes(); seeds.assign(pr, pr + 0x400); }
+    else for (int x = 0; x < 0x2000; x++) seeds.push_back(x);
+    for (int v : seeds) bitmap[v >> 5] |= 1u << (v & 31);
+    Stream st;
+    VGA_HIP_TRY(st.create());
+    const int cap = 1 << 20;                                         // raw survivors (short files have many)
+    DevBuf d_scales, d_bitmap, d_mults, d_incs, d_out, d_count;
+    VGA_HIP_TRY(d_scales.alloc((size_t)nscales * 2));
+    VGA_HIP_TRY(d_bitmap.alloc(bitmap.size() * 4));
+    VGA_HIP_TRY(d_mults.alloc((size_t)nmult * 4));
+    VGA_HIP_TRY(d_incs.alloc((size_t)ninc * 4));
+    VGA_HIP_TRY(d_out.alloc((size_t)cap * 12));
+    VGA_HIP_TRY(d_count.alloc(4));
+    VGA_HIP_TRY(hipMemcpyAsync(d_scales.p, scales, (size_t)nscales * 2, hipMemcpyHostToDevice, st.s));
+    VGA_HIP_TRY(hipMemcpyAsync(d_bitmap.p, bitmap.data(), bitmap.size() * 4, hipMemcpyHostToDevice, st.s));
+    VGA_HIP_TRY(hipMemcpyAsync(d_mults.p, mults, (size_t)nmult * 4, hipMemcpyHostToDevice, st.s));
+    VGA_HIP_TRY(hipMemcpyAsync(d_incs.p, incs, (size_t)ninc * 4, hipMemcpyHostToDevice, st.s));
+    VGA_HIP_TRY(hipMemsetAsync(d_count.p, 0, 4, st.s));
+    if (int rc = crypt::launch_adx_guess_keys(d_scales.as<uint16_t>(), nscales, start_frame, encryption_type,
+                                              start_frame == 0 ? d_bitmap.as<uint32_t>() : nullptr, d_mults.as<int>(), nmult,
+                                              d_incs.as<int>(), ninc, d_out.as<int>(), cap, d_count.as<int>(), st.s))
+        return rc;
+    int count = 0;
+    VGA_HIP_TRY(hipMemcpyAsync(&count, d_count.p, 4, hipMemcpyDeviceToHost, st.s));
+    VGA_HIP_TRY(hipStreamSynchronize(st.s));
+    if (count > cap) { set_error("%d candidate keys survive the scales: too few frames to search", count); return VGA_ERR_INVALID_OP; }
+    std::vector<int> raw((size_t)count * 3);
+    if (count > 0) VGA_HIP_TRY(hipMemcpy(raw.data(), d_out.p, (size_t)count * 12, hipMemcpyDeviceToHost));
+    std::vector<std::tuple<int, int, int>> found;
+    for (int i = 0; i < count; i++) {
+        const int seed = raw[3 * i], mult = raw[3 * i + 1], inc = raw[3 * i + 2];
+        int real = seed;
+        bool have = start_frame == 0;
+        for (size_t k = 0; k < seeds.size() && !have; k++) {        // FindStartingKey (:181-204)
+            int x = seeds[k];
+            for (int j = 0; j < start_frame; j++) x = (x * mult + inc) & 0x7fff;
+            if ((x & (max_seed - 1)) == seed) { real = seeds[k]; have = true; }
+        }
+        if (!have) continue;
+        int x = real;                                                // KeyIsValid (:206-218)
+        bool valid = true;
+        for (int j = 0; j < nscales && valid; j++) {
+            if (((scales[j] ^ x) & mask) != 0 && scales[j] != 0) valid = false;
+            x = (x * mult + inc) & 0x7fff;
+        }
+        if (valid) found.emplace_back(real, mult, inc);
+    }
+    std::sort(found.begin(), found.end());
+    found.erase(std::unique(found.begin(), found.end()), found.end());
+    if ((int)found.size() > max_keys) {
+        set_error("%d keys found, room for %d", (int)found.size(), max_keys);
+        *nkeys_out = (int)found.size();
+        return VGA_ERR_ARGUMENT;
+    }
+    for (size_t i = 0; i < found.size(); i++) keys_out[i] = vga_adx_key{std::get<0>(found[i]), std::get<1>(found[i]), std::get<2>(found[i])};
+    *nkeys_out = (int)found.size();
+    return VGA_OK;
+}
+
 // ---------------------------------------------------------------- HCA (Codecs/CriHca/CriHcaKey.cs, CriHcaEncryption.cs)
 // key_type 56: CriHcaKey(ulong keyCode); 0 / 1: CriHcaKey(Type).  Tables of 256 bytes each.
 int vga_hca_key_tables(int key_type, uint64_t key_code, uint8_t *decryption_table, uint8_t *encryption_table)
@@ -235,6 +350,90 @@ int vga_hca_crypt(uint8_t *frames, int frame_count, int frame_size, const uint8_
     if (int rc = vga_hca_crypt_device(d.as<uint8_t>(), (int64_t)bytes, 1, frame_count, frame_size, table, st.s)) return rc;
     VGA_HIP_TRY(hipMemcpyAsync(frames, d.p, bytes, hipMemcpyDeviceToHost, st.s));
     VGA_HIP_TRY(hipStreamSynchronize(st.s));
+    return VGA_OK;
+}
+
+// CriHcaEncryption.FindKey (CriHcaEncryption.cs:34-46) over caller-supplied candidates: decryption_tables = nkeys x 256
+// bytes (CriHcaKey.DecryptionTable, vga_hca_key_tables) in host memory; *index_out = the first key under which the first
+// ten non-empty frames of the stream unpack (TestKey :48-63), or -1.  A frame whose sync word is wrong is the
+// reference's InvalidDataException.
+int vga_hca_find_key_device(const vga_hca_info *h, const uint8_t *d_frames, int frame_count, const uint8_t *decryption_tables,
+                            int nkeys, int *index_out, void *stream)
+{
+    if (!h || !index_out || nkeys < 0 || frame_count < 0 || (nkeys > 0 && !decryption_tables)) { set_error("null / negative argument"); return VGA_ERR_ARGUMENT; }
+    *index_out = -1;
+    hca::DeviceInfo d;
+    if (int rc = hca::device_info_from(*h, d)) return rc;
+    if (nkeys == 0) return VGA_OK;
+    if (frame_count == 0) { *index_out = 0; return VGA_OK; }            // no frame to refute the first key
+    if (!d_frames) { set_error("null frames"); return VGA_ERR_ARGUMENT; }
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf d_tables, d_valid, d_small;
+    VGA_HIP_TRY(d_tables.alloc((size_t)nkeys * 256));
+    VGA_HIP_TRY(d_valid.alloc((size_t)nkeys * sizeof(int)));
+    VGA_HIP_TRY(d_small.alloc(2 * sizeof(int)));
+    VGA_HIP_TRY(hipMemcpyAsync(d_tables.p, decryption_tables, (size_t)nkeys * 256, hipMemcpyHostToDevice, s));
+    if (int rc = crypt::launch_hca_find_key(d_frames, frame_count, d, d_tables.as<uint8_t>(), nkeys, d_small.as<int>(), d_valid.as<int>(),
+                                            d_small.as<int>() + 1, s))
+        return rc;
+    std::vector<int> valid((size_t)nkeys);
+    int flags = 0;
+    VGA_HIP_TRY(hipMemcpyAsync(valid.data(), d_valid.p, (size_t)nkeys * sizeof(int), hipMemcpyDeviceToHost, s));
+    VGA_HIP_TRY(hipMemcpyAsync(&flags, d_small.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    VGA_HIP_TRY(hipStreamSynchronize(s));
+    if (flags & 1) { set_error("Invalid frame header"); return VGA_ERR_INVALID_DATA; }
+    for (int i = 0; i < nkeys; i++)
+        if (valid[i]) { *index_out = i; break; }
+    return VGA_OK;
+}
+
+int vga_hca_find_key(const vga_hca_info *h, const uint8_t *frames, int frame_count, const uint8_t *decryption_tables, int nkeys,
+                     int *index_out)
+{
+    if (!h || !index_out || frame_count < 0) { set_error("null / negative argument"); return VGA_ERR_ARGUMENT; }
+    *index_out = -1;
+    if (frame_count > 0 && !frames) { set_error("null frames"); return VGA_ERR_ARGUMENT; }
+    if (nkeys <= 0 || frame_count == 0)
+        return vga_hca_find_key_device(h, nullptr, frame_count, decryption_tables, nkeys, index_out, nullptr);
+    if (int rc = require_device()) return rc;
+    Stream st;
+    VGA_HIP_TRY(st.create());
+    // FindFirstNonEmptyFrame on the host copy: only the ten frames TestKey reads travel
+    const int fs = h->frame_size;
+    if (fs < 8) { set_error("frame size %d", fs); return VGA_ERR_ARGUMENT; }
+    int first = 0;
+    for (int i = 0; i < frame_count; i++) {
+        bool empty = true;
+        for (int b = 2; b < fs - 2 && empty; b++) empty = frames[(size_t)i * fs + b] == 0;
+        if (!empty) { first = i; break; }
+    }
+    const int n = std::min(10, frame_count - first);
+    DevBuf d;
+    VGA_HIP_TRY(d.alloc((size_t)n * fs));
+    VGA_HIP_TRY(hipMemcpyAsync(d.p, frames + (size_t)first * fs, (size_t)n * fs, hipMemcpyHostToDevice, st.s));
+    // the copied window starts at the first non-empty frame (or at frame 0 when all are empty): the device search
+    // finds it at index 0 again
+    return vga_hca_find_key_device(h, d.as<uint8_t>(), n, decryption_tables, nkeys, index_out, st.s);
+}
+
+// VGAudio.Tools/CrackHca/Crack.cs:43-80 (LoadFrequencies): counts[p * 256 + v] = frames whose byte p equals v, for the
+// first `positions` bytes (the reference uses 30); counts_out in host memory, frames on the device.
+int vga_hca_byte_position_counts_device(const uint8_t *d_frames, int64_t frames_pitch, int nstreams, int frame_count,
+                                        int frame_size, int positions, uint32_t *counts_out, void *stream)
+{
+    if (!counts_out || positions < 1 || positions > 64 || nstreams < 0 || frame_count < 0 || frame_size < 1) {
+        set_error("bad arguments (positions 1..64)");
+        return VGA_ERR_ARGUMENT;
+    }
+    if (nstreams > 0 && frame_count > 0 && (!d_frames || frames_pitch < (int64_t)frame_count * frame_size)) { set_error("null pointer / pitch too small"); return VGA_ERR_ARGUMENT; }
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf d_counts;
+    VGA_HIP_TRY(d_counts.alloc((size_t)positions * 256 * sizeof(unsigned)));
+    if (int rc = crypt::launch_hca_byte_position_counts(d_frames, frames_pitch, nstreams, frame_count, frame_size, positions,
+                                                        d_counts.as<unsigned>(), s))
+        return rc;
+    VGA_HIP_TRY(hipMemcpyAsync(counts_out, d_counts.p, (size_t)positions * 256 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    VGA_HIP_TRY(hipStreamSynchronize(s));
     return VGA_OK;
 }
 

@@ -146,6 +146,8 @@ struct CrcPow {
 
 // shared with the encryption pass (capi_crypt.hip)
 namespace vga { namespace hca { int crc_pow_table(const uint16_t **out); } }
+// used by capi_crypt.hip (vga_hca_find_key)
+namespace vga { namespace hca { int device_info_from(const vga_hca_info &h, DeviceInfo &d) { return make_device_info(h, d); } } }
 
 int vga::hca::crc_pow_table(const uint16_t **out)
 {
