@@ -48,6 +48,8 @@ __device__ __forceinline__ unsigned gf_mul(unsigned a, unsigned b)
 }
 
 // CalculateUsedBits (:554-597) for one band: the bits its eight scaled coefficients cost at resolution `res`
+// x: the band's eight coefficients, one per sub-frame, XS doubles apart
+template <int XS>
 __device__ __forceinline__ int band_cost(const EncTables &T, const double *x, int res)
 {
     int cost = 0;
@@ -55,14 +57,14 @@ __device__ __forceinline__ int band_cost(const EncTables &T, const double *x, in
         const int bits = T.max_bits[res] - 1;
         const double d = T.dead_zone[res];
 #pragma unroll
-        for (int sf = 0; sf < 8; sf++) cost += bits + (fabs(x[sf]) >= d ? 1 : 0);
+        for (int sf = 0; sf < 8; sf++) cost += bits + (fabs(x[sf * XS]) >= d ? 1 : 0);
     } else {
         const double inv = T.inv_step[res];
         const double up = inv + 1;
         const int down = trunc_i(inv + 0.5 - 8);
 #pragma unroll
         for (int sf = 0; sf < 8; sf++) {
-            const int q = trunc_i(x[sf] * inv + up) - down;
+            const int q = trunc_i(x[sf * XS] * inv + up) - down;
             cost += T.enc_bits[res][q];
         }
     }
@@ -82,10 +84,10 @@ __device__ __forceinline__ void build_cost_table(const EncTables &T, const doubl
 {
     double x[8];
 #pragma unroll
-    for (int sf = 0; sf < 8; sf++) x[sf] = xs[sf];
+    for (int sf = 0; sf < 8; sf++) x[sf] = xs[sf * 128];               // scaled spectra: [channel][sub-frame][band]
     uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int r = 0; r < 16; r++) w[r >> 2] |= (uint32_t)band_cost(T, x, r) << (8 * (r & 3));
+    for (int r = 0; r < 16; r++) w[r >> 2] |= (uint32_t)band_cost<1>(T, x, r) << (8 * (r & 3));
     m.w0 = valid ? w[0] : 0u; m.w1 = valid ? w[1] : 0u; m.w2 = valid ? w[2] : 0u; m.w3 = valid ? w[3] : 0u;
     m.known = 0xFFFFu;
 }
@@ -103,17 +105,6 @@ __device__ __forceinline__ int used_bits_partial(const EncTables &T, int tid, in
         const int noise = b < eval_boundary ? noise_level - 1 : noise_level;
         const int res = calculate_resolution(T, sfac[i], noise);
         const int word = res >> 2, shift = 8 * (res & 3);
-#ifdef VGA_HCA_LAZY_COSTS                               // the earlier scheme, kept for A/B timing
-        const bool miss = valid && !((m.known >> res) & 1u);
-        if (__any(miss)) {                             // wave-uniform: all lanes evaluate, the missing ones keep it
-            const uint32_t cost = (uint32_t)band_cost(T, scaled + (size_t)i * 8, res) << shift;
-            m.w0 |= (miss && word == 0) ? cost : 0u;
-            m.w1 |= (miss && word == 1) ? cost : 0u;
-            m.w2 |= (miss && word == 2) ? cost : 0u;
-            m.w3 |= (miss && word == 3) ? cost : 0u;
-            m.known |= miss ? 1u << res : 0u;
-        }
-#endif
         const uint32_t wsel = word == 0 ? m.w0 : word == 1 ? m.w1 : word == 2 ? m.w2 : m.w3;
         partial = valid ? (int)((wsel >> shift) & 0xFFu) : 0;
     } else {
@@ -121,15 +112,34 @@ __device__ __forceinline__ int used_bits_partial(const EncTables &T, int tid, in
             const int c = i / 128, b = i % 128;
             if (b >= s_coded[c]) continue;
             const int noise = b < eval_boundary ? noise_level - 1 : noise_level;
-            partial += band_cost(T, scaled + (size_t)i * 8, calculate_resolution(T, sfac[i], noise));
+            partial += band_cost<128>(T, scaled + (size_t)c * 1024 + b, calculate_resolution(T, sfac[i], noise));
         }
+    }
+    return partial;
+}
+
+// One probe of CalculateUsedBits for the four bands a lane of the searching wave owns: resolution from the noise level
+// (CriHcaPacking.CalculateResolution), cost from the band's table.
+// The sixteen byte costs of a band sit in two 64-bit halves (resolutions 0-7, 8-15): one select and one 64-bit shift
+// (a four-way select over a uint4 makes hipcc spill the table to scratch and index it).
+__device__ __forceinline__ int probe_partial(const EncTables &T, const uint64_t (&clo)[4], const uint64_t (&chi)[4],
+                                             const int (&off)[4], const int (&bnd)[4], const bool (&on)[4], int noise_level,
+                                             int eval_boundary)
+{
+    int partial = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int noise = bnd[k] < eval_boundary ? noise_level - 1 : noise_level;
+        const int res = T.res_curve[min(max(noise + off[k], 0), 58)];
+        const uint64_t half = res >= 8 ? chi[k] : clo[k];
+        partial += on[k] ? (int)((half >> (8 * (res & 7))) & 0xFFu) : 0;
     }
     return partial;
 }
 
 // LDS limits the kernel to 3-4 workgroups (12-16 waves) per CU; without the occupancy hint hipcc aims for 10
 // waves per SIMD, caps itself at 48 VGPRs and spills pointers to scratch
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void hca_encode_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void hca_encode_kernel(
     const int16_t *__restrict__ pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, PcmMap map,
     DeviceInfo info, uint8_t *__restrict__ frames, int64_t frames_pitch, const uint16_t *__restrict__ crc_pow,
     int *__restrict__ status)
@@ -138,15 +148,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     __shared__ EncTables T;
     const int nch = info.nch;
     double *spectra = s_mem;                               // [nch][8][128]
-    // LDS decides the occupancy (4 workgroups per CU need <= 40 KB each): region B is shared -- the MDCT staging
-    // (dctin, which doubles as the transform's scratch, and xin) is dead before `scaled` is written -- and the
-    // small per-band arrays are bytes
-    const size_t region_b = (size_t)nch * 1024 > 11 * 128 ? (size_t)nch * 1024 : 11 * 128;
-    double *scaled = spectra + (size_t)nch * 1024;         // [nch][128][8]
-    double *dctin = scaled;                                // [8][128]
+    // LDS decides the occupancy (5 workgroups per CU need <= 32 KB each): ScaleSpectra works IN PLACE -- the scaled
+    // spectra keep the [channel][sub-frame][band] layout of the MDCT output (bands of one sub-frame are contiguous,
+    // which is also what the cost tables and WriteSpectra read conflict-free); only the MDCT staging needs a second
+    // region (dctin, which doubles as the transform's scratch, and xin; later the searching wave's cost tables)
+    const size_t region_b = 11 * 128;
+    double *scaled = spectra;                              // [nch][8][128], bands < coded count (the rest stays unscaled)
+    double *dctin = spectra + (size_t)nch * 1024;          // [8][128]
     double *tmp = dctin;                                   // the transform permutes in place (hca_device.hpp)
     int16_t *xin = reinterpret_cast<int16_t *>(dctin + 8 * 128);   // [9][128] raw samples (2.3 KB of the 3 x 128 doubles)
-    double *hfr_avg = scaled + region_b;                   // [nch][8]
+    double *hfr_avg = dctin + region_b;                    // [nch][8]
     double *eratio = hfr_avg + nch * 8;                    // [nch][8]
     int *red = reinterpret_cast<int *>(eratio + nch * 8);  // [32] two alternating slot sets for the block reductions
     int *hlb = red + 32;                                   // [nch] header length bits
@@ -264,9 +275,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         __syncthreads();
     }
 
-#if defined(VGA_HCA_ABL_STOP) && VGA_HCA_ABL_STOP == 1   // ablation builds (timing only)
-    return;
-#endif
     // ---- EncodeIntensityStereo (:711-764)
     if (info.stereo_band_count > 0) {
         if (tid < nch * 8) {
@@ -324,15 +332,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         sfac[i] = sfv;
     }
     __syncthreads();
-    // ---- ScaleSpectra (:651-671)
+    // ---- ScaleSpectra (:651-671), in place: bands >= the coded count keep their unscaled values (the HFR group
+    // averages below read exactly those), nothing reads a scaled value there
     for (int i = tid; i < nch * 1024; i += 256) {
-        const int c = i / 1024, b = (i / 8) % 128, sf = i % 8;
+        const int c = i / 1024, b = i % 128;
         const int sfv = sfac[c * 128 + b];
-        double v = 0;
-        if (b < s_coded[c] && sfv != 0)
-            v = clampd(spectra[((size_t)c * 8 + sf) * 128 + b] * T.quant_scale[sfv],
-                       -0.999999999999, 0.999999999999);
-        scaled[i] = v;
+        if (b < s_coded[c])
+            spectra[i] = sfv != 0 ? clampd(spectra[i] * T.quant_scale[sfv], -0.999999999999, 0.999999999999) : 0.0;
     }
     __syncthreads();
 
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
                 count = 0;
                 band = group * info.bands_per_hfr_group;
                 for (int i = 0; i < info.bands_per_hfr_group && band < lim; band++, i++) {
-                    for (int sf = 0; sf < 8; sf++) sum += fabs(scaled[((size_t)c * 128 + (hfr_start - band - 1)) * 8 + sf]);
+                    for (int sf = 0; sf < 8; sf++) sum += fabs(scaled[((size_t)c * 8 + sf) * 128 + (hfr_start - band - 1)]);
                     count += 8;
                 }
                 const double average = sum / count;
@@ -369,10 +375,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         __syncthreads();
     }
 
-#if defined(VGA_HCA_ABL_STOP) && VGA_HCA_ABL_STOP == 2   // ablation builds (timing only)
-    return;
-#endif
     // ---- CalculateFrameHeaderLength (:599-649)
+    // Up to two channels (every BASELINE shape): lane = (channel, band).  The five candidate delta widths' lengths are
+    // 11-bit sums packed three to a register and reduced with DPP -- the serial form below walks 128 bands on ten lanes
+    // while the other 246 wait at the barrier (~13 k cycles of a 66 k-cycle frame).
+    const bool small = nch * 128 <= 256;
+    auto wave_sum = [&](int v) __attribute__((always_inline)) -> int {
+        v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+        v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);     // row_half_mirror
+        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);     // row_mirror
+        return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+               __builtin_amdgcn_readlane(v, 48);
+    };
+    auto header_lengths_fast = [&]() __attribute__((always_inline)) {
+        const int c = tid >> 7, band = tid & 127;
+        const bool in = c < nch && band < s_coded[min(c, nch - 1)];
+        const int sf = in ? sfac[c * 128 + band] : 0;
+        const int delta = (in && band >= 1) ? abs(sf - (int)sfac[c * 128 + band - 1]) : 0;
+        const bool counted = in && band >= 1;
+        // per-lane costs <= 11, at most 127 lanes: 16-bit fields cannot carry into each other
+        int a = 0, b = 0, e = 0;
+        if (counted) {
+            a = (delta > 0 ? 7 : 1) | ((delta > 1 ? 8 : 2) << 16);
+            b = (delta > 3 ? 9 : 3) | ((delta > 7 ? 10 : 4) << 16);
+            e = delta > 15 ? 11 : 5;
+        }
+        e |= (in && sf != 0) ? 1 << 16 : 0;                               // non-zero scale factors: "empty channel" test
+        a = wave_sum(a);
+        b = wave_sum(b);
+        e = wave_sum(e);
+        int *slot = red + 16;                                             // [3][4]: red[16..27]; red[28..29] hold the search result
+        if (lane == 0) { slot[wave] = a; slot[4 + wave] = b; slot[8 + wave] = e; }
+        __syncthreads();
+        if (tid < nch) {
+            const int cc = tid;
+            const int sa = slot[2 * cc] + slot[2 * cc + 1], sb = slot[4 + 2 * cc] + slot[4 + 2 * cc + 1],
+                      se = slot[8 + 2 * cc] + slot[8 + 2 * cc + 1];
+            const int cand_len[6] = {0, 9 + (sa & 0xFFFF), 9 + (sa >> 16), 9 + (sb & 0xFFFF), 9 + (sb >> 16), 9 + (se & 0xFFFF)};
+            int len, db;
+            if ((se >> 16) == 0) { len = 3; db = 0; }
+            else {
+                db = 6;
+                len = 3 + 6 * s_coded[cc];
+#pragma unroll
+                for (int k = 1; k < 6; k++)
+                    if (cand_len[k] < len) { len = cand_len[k]; db = k; }
+            }
+            if (s_ctype[cc] == CH_STEREO_SECONDARY) len += 32;
+            else if (info.hfr_group_count > 0) len += 6 * info.hfr_group_count;
+            hlb[cc] = len;
+            dbits[cc] = db;
+        }
+        __syncthreads();
+    };
     auto header_lengths = [&]() __attribute__((always_inline)) {
         if (tid < nch * 5) {
             const int c = tid / 5, db = 1 + tid % 5;
@@ -408,20 +464,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         }
         __syncthreads();
     };
-    header_lengths();
+    if (small) header_lengths_fast();
+    else header_lengths();
 
-    // ---- CalculateUsedBits (:554-597) as a block reduction
-    // The bit cost of a band's eight coefficients depends only on its resolution (the scaled spectra are
-    // fixed), and the two binary searches come back to the same few resolutions: every (band, resolution)
-    // cost is computed once and kept in registers (UsedBitsMemo).  used_bits_block() is a free function, not a
-    // lambda: with the memo updated inside a capturing lambda hipcc kept every captured local in scratch.
+    // ---- CalculateUsedBits (:554-597)
+    // The bit cost of a band's eight coefficients depends only on its resolution (the scaled spectra are fixed): every
+    // (band, resolution) cost is computed once (build_cost_table: 16 costs of <= 96 bits in four dwords per band).
     UsedBitsMemo memo;
-#ifndef VGA_HCA_LAZY_COSTS
-    if (nch * 128 <= 256) {
+    if (small) {
         const int i = min(tid, nch * 128 - 1);
-        build_cost_table(T, scaled + (size_t)i * 8, tid < nch * 128, memo);
+        build_cost_table(T, scaled + (size_t)(i >> 7) * 1024 + (i & 127), tid < nch * 128 && (i & 127) < s_coded[i >> 7], memo);
     }
-#endif
     auto used_bits = [&](int noise_level, int eval_boundary) __attribute__((always_inline)) -> int {
         const int partial = used_bits_partial(T, tid, nch, s_coded, sfac, scaled, noise_level, eval_boundary, memo);
         int total = block_sum(partial) + 16 + 16 + 16;
@@ -429,63 +482,116 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         return total;
     };
 
-    // ---- CalculateNoiseLevel (:457-485) / BinarySearchLevel (:502-523)
+    // ---- CalculateNoiseLevel (:457-485) / BinarySearchLevel (:502-523) and CalculateEvaluationBoundary (:487-500) /
+    // BinarySearchBoundary (:525-552).
     const int available = info.frame_size * 8;
-    auto search_level = [&]() __attribute__((always_inline)) -> int {
-        int low = 0, high = 255, mid_value = 0;
-        while (low != high) {
-            const int mid = (low + high) / 2;
-            mid_value = used_bits(mid, 0);
-            if (mid_value > available) low = mid + 1;
-            else high = mid;
-        }
-        return (low == 255 && mid_value > available) ? -1 : low;
-    };
-    int level = search_level();
-    int highest_band = info.base_band_count + info.stereo_band_count - 1;
+    int level = 0, boundary = 0;
     bool too_low = false;
-    while (level < 0) {
-        highest_band -= 2;
-        if (highest_band < 0) { too_low = true; break; }
-        if (tid < nch) {
-            sfac[tid * 128 + highest_band + 1] = 0;
-            sfac[tid * 128 + highest_band + 2] = 0;
+    bool searched = false;
+    if (small) {
+        // ONE wave runs both binary searches: the cost tables of all bands travel to it through LDS (4 KB, in the dead
+        // MDCT staging region), each of its lanes then owns four bands and every probe is ~45 instructions and a DPP
+        // reduction -- no LDS round trip, no barrier -- where the block-wide form issued the same ~45 instructions on
+        // four waves and met at a barrier sixteen times per frame.  The other three waves wait once.
+        uint4 *costs = reinterpret_cast<uint4 *>(dctin);
+        costs[tid] = make_uint4(memo.w0, memo.w1, memo.w2, memo.w3);
+        __syncthreads();
+        if (wave == 0) {
+            uint64_t clo[4], chi[4];
+            int off[4], bnd[4];
+            bool on[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int slot = lane + 64 * k;
+                const int sf = slot < nch * 128 ? sfac[slot] : 0;
+                on[k] = slot < nch * 128 && sf != 0 && (slot & 127) < s_coded[min(slot >> 7, nch - 1)];
+                off[k] = 2 - 5 * sf / 2;
+                bnd[k] = slot & 127;
+                const uint4 cw = costs[slot];
+                clo[k] = ((uint64_t)cw.y << 32) | cw.x;
+                chi[k] = ((uint64_t)cw.w << 32) | cw.z;
+            }
+            int hsum = 48;
+            for (int c = 0; c < nch; c++) hsum += hlb[c];
+            // (a free function, not a lambda: hipcc keeps by-reference captures of register arrays in scratch)
+#define probe(NL, EB) (wave_sum(probe_partial(T, clo, chi, off, bnd, on, (NL), (EB))) + hsum)
+            int low = 0, high = 255, mid_value = 0;
+            while (low != high) {
+                const int mid = (low + high) / 2;
+                mid_value = probe(mid, 0);
+                if (mid_value > available) low = mid + 1;
+                else high = mid;
+            }
+            int lv = (low == 255 && mid_value > available) ? -1 : low;
+            int bd = 0;
+            if (lv > 0) {
+                int lo2 = 0, hi2 = 127;
+                while (abs(hi2 - lo2) > 1) {
+                    const int mid = (lo2 + hi2) / 2;
+                    const int mid_value2 = probe(lv, mid);
+                    if (available < mid_value2) hi2 = mid - 1;
+                    else lo2 = mid;
+                }
+                if (lo2 == hi2) bd = lo2 < 127 ? lo2 : -1;
+                else bd = probe(lv, hi2) > available ? lo2 : hi2;
+            }
+#undef probe
+            if (lane == 0) { red[28] = lv; red[29] = bd; }
         }
         __syncthreads();
-        header_lengths();
-        level = search_level();
+        level = red[28];
+        boundary = red[29];
+        searched = level >= 0;                         // level < 0 (bands must be dropped): the block-wide form below
     }
-    if (too_low) {                       // InvalidDataException("Bitrate is set too low.")
-        if (tid == 0 && status) atomicOr(status, 4);
-        level = 255;
+    if (!searched) {
+        auto search_level = [&]() __attribute__((always_inline)) -> int {
+            int low = 0, high = 255, mid_value = 0;
+            while (low != high) {
+                const int mid = (low + high) / 2;
+                mid_value = used_bits(mid, 0);
+                if (mid_value > available) low = mid + 1;
+                else high = mid;
+            }
+            return (low == 255 && mid_value > available) ? -1 : low;
+        };
+        level = small ? -1 : search_level();
+        int highest_band = info.base_band_count + info.stereo_band_count - 1;
+        while (level < 0) {
+            highest_band -= 2;
+            if (highest_band < 0) { too_low = true; break; }
+            if (tid < nch) {
+                sfac[tid * 128 + highest_band + 1] = 0;
+                sfac[tid * 128 + highest_band + 2] = 0;
+            }
+            __syncthreads();
+            header_lengths();
+            level = search_level();
+        }
+        if (too_low) {                       // InvalidDataException("Bitrate is set too low.")
+            if (tid == 0 && status) atomicOr(status, 4);
+            level = 255;
+        }
+        boundary = 0;
+        if (level != 0) {
+            int low = 0, high = 127;
+            while (abs(high - low) > 1) {
+                const int mid = (low + high) / 2;
+                const int mid_value = used_bits(level, mid);
+                if (available < mid_value) high = mid - 1;
+                else low = mid;
+            }
+            if (low == high) boundary = low < 127 ? low : -1;
+            else {
+                const int hi_value = used_bits(level, high);
+                boundary = hi_value > available ? low : high;
+            }
+        }
     }
-#if defined(VGA_HCA_ABL_STOP) && VGA_HCA_ABL_STOP == 3   // ablation builds (timing only)
-    return;
-#endif
-    // ---- CalculateEvaluationBoundary (:487-500) / BinarySearchBoundary (:525-552)
-    int boundary = 0;
-    if (level != 0) {
-        int low = 0, high = 127;
-        while (abs(high - low) > 1) {
-            const int mid = (low + high) / 2;
-            const int mid_value = used_bits(level, mid);
-            if (available < mid_value) high = mid - 1;
-            else low = mid;
-        }
-        if (low == high) boundary = low < 127 ? low : -1;
-        else {
-            const int hi_value = used_bits(level, high);
-            boundary = hi_value > available ? low : high;
-        }
-        if (boundary < 0) {               // NotImplementedException in the reference
-            if (tid == 0 && status) atomicOr(status, 8);
-            boundary = 0;
-        }
+    if (boundary < 0) {                       // NotImplementedException in the reference
+        if (tid == 0 && status) atomicOr(status, 8);
+        boundary = 0;
     }
 
-#if defined(VGA_HCA_ABL_STOP) && VGA_HCA_ABL_STOP == 4   // ablation builds (timing only)
-    return;
-#endif
     // ---- CalculateFrameResolutions (:441-455)
     for (int i = tid; i < nch * 128; i += 256) {
         const int c = i / 128, b = i % 128;
@@ -542,7 +648,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         // per_thread divides 128: a thread's slots share the sub-frame and the channel, the band runs on
         const int slot0 = tid * per_thread;
         const int sf = slot0 / (nch * 128), c = (slot0 / 128) % nch, band0 = slot0 % 128;
-        const double *xs = scaled + ((size_t)c * 128 + band0) * 8 + sf;
+        const double *xs = scaled + ((size_t)c * 8 + sf) * 128 + band0;
         const uint8_t *rs = ires + c * 128 + band0;
         auto code_of = [&](int k, unsigned &code, int &nbits) __attribute__((always_inline)) {
             const int res = rs[k];
@@ -552,7 +658,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
             const double inv = T.inv_step[res];
             const double up = inv + 1;
             const int down = trunc_i(inv + 0.5);
-            const int q = trunc_i(xs[(size_t)k * 8] * inv + up) - down;
+            // a thread's slots run on across a channel boundary when 4 * nch does not divide 128 (3, 5, 6, 7 channels):
+            // the sub-frame stays, the band wraps into the next channel
+            const int bk = band0 + k;
+            const int q = trunc_i(xs[(size_t)(bk >> 7) * 1024 + (bk & 127) - band0] * inv + up) - down;
             if (res < 8) {
                 nbits = T.enc_bits[res][q + 8];
                 code = T.enc_value[res][q + 8];
@@ -630,9 +739,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     }
     __syncthreads();
 
-#if defined(VGA_HCA_ABL_STOP) && VGA_HCA_ABL_STOP == 5   // ablation builds (timing only)
-    return;
-#endif
     // ---- WriteChecksum (:231-236): CRC-16 (poly 0x8005, init 0) over the first frame_size-2 bytes
     {
         const int nbytes = info.frame_size - 2;
@@ -689,7 +795,7 @@ int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, 
 {
     if (nstreams <= 0 || info.frame_count <= 0) return VGA_OK;
     const int nch = info.nch;
-    const size_t region_b = (size_t)nch * 1024 > 11 * 128 ? (size_t)nch * 1024 : 11 * 128;
+    const size_t region_b = 11 * 128;
     const size_t doubles = (size_t)nch * 1024 + region_b + (size_t)nch * 16;
     const size_t ints = 32 + 8 + 8 + 64 + 8 + 64 + 64;
     const size_t lds = doubles * 8 + ints * 4 + ((size_t)(info.frame_size + 3) / 4 + 2) * 4 + (size_t)nch * 256;
