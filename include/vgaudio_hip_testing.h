@@ -17,6 +17,14 @@ extern "C" {
  * Returns the calling thread's previous mode. */
 int vga_testing_force_open_seams_this_thread(int mode);
 
+/* GC-ADPCM encoder wave layout for calls made FROM THE CALLING THREAD: 8 = lane per (channel, predictor), the product's
+ * choice; 4 = lane per (channel, predictor, scale candidate), the round-1 layout kept for A/B measurements.  Both produce
+ * the same bytes.  Returns the previous value; other arguments leave it unchanged. */
+int vga_testing_gc_encoder_layout_this_thread(int channels_per_wave);
+/* Forces the number of time pieces a channel is cut into by the GC-ADPCM encoder (0 = the launcher's own choice: what
+ * fills the chip), for calls made from the calling thread.  Results must not depend on it.  Returns the previous value. */
+int vga_testing_gc_encoder_segments_this_thread(int segments);
+
 /* The host-pointer entry points (vga_*_batch) move data through a pipeline of feeder threads, pinned rings, per-chunk
  * kernel launches and drainer threads (vgaudio_amd/csrc/host_pipeline.hpp); its shape normally follows the volume of
  * the call.  Non-zero arguments override it for calls made FROM THE CALLING THREAD (0 = automatic): feeder / drainer

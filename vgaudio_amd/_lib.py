@@ -120,6 +120,8 @@ SIGNATURES = {
     "vga_release_cached_memory": (None, []),
     "vga_testing_force_open_seams_this_thread": (ci, [ci]),
     "vga_testing_host_pipeline_this_thread": (None, [ci, ci, ci, ci]),
+    "vga_testing_gc_encoder_layout_this_thread": (ci, [ci]),
+    "vga_testing_gc_encoder_segments_this_thread": (ci, [ci]),
     "vga_testing_last_pipeline_stats": (ci, [vp, ci]),
     "vga_dsp_layout_for": (ci, [vp, ci, vp]),
     "vga_dsp_write": (ci, [u8pp, ci, i16p, i16p, i16p, i16p, ci, vp, u8p]),

@@ -24,6 +24,10 @@ void set_error(const char *fmt, ...)
 static thread_local int g_force_open_seams = 0;
 int force_open_seams() { return g_force_open_seams; }
 
+static thread_local int g_encoder_layout = 8;
+int encoder_layout() { return g_encoder_layout; }
+static thread_local int g_encoder_segments = 0;
+int encoder_segments_override() { return g_encoder_segments; }
 static thread_local PipeOverride g_pipe_override;
 PipeOverride &pipe_override() { return g_pipe_override; }
 static thread_local PipeReport g_pipe_report;
@@ -57,6 +61,18 @@ int vga_testing_force_open_seams_this_thread(int mode)
 {
     const int old = g_force_open_seams;
     g_force_open_seams = mode;
+    return old;
+}
+int vga_testing_gc_encoder_layout_this_thread(int channels_per_wave)
+{
+    const int old = g_encoder_layout;
+    if (channels_per_wave == 4 || channels_per_wave == 8) g_encoder_layout = channels_per_wave;
+    return old;
+}
+int vga_testing_gc_encoder_segments_this_thread(int segments)
+{
+    const int old = g_encoder_segments;
+    g_encoder_segments = segments > 0 ? segments : 0;
     return old;
 }
 void vga_testing_host_pipeline_this_thread(int feeders, int drainers, int chunk_units, int slot_bytes)

@@ -39,6 +39,8 @@ __device__ __forceinline__ int dpp(int v)
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 
+__device__ __forceinline__ unsigned umin32(unsigned a, unsigned b) { return a < b ? a : b; }
+
 // all-reduce over each 16-lane row
 template <class Op>
 __device__ __forceinline__ unsigned row16_reduce(unsigned v, Op op)
@@ -69,11 +71,20 @@ __device__ __forceinline__ unsigned row16_reduce(unsigned v, Op op)
 // The SIMDs have idle issue slots next to a lone latency-bound wave (tools/ubench_valu.hip: two waves
 // per SIMD do not slow each other's dependent chains), so the helper costs the encoder nothing.
 // measured at configs[1]: 1 encoder wave -> 209.5 ms, 2 -> 200.1 ms (two pieces per channel)
-constexpr int SW = 2;              // encoder (serial) waves per workgroup, 4 channels each; one helper wave serves them all
-constexpr int CS = 4 * SW;         // channel slots per workgroup
-constexpr int TF = 64 / CS;        // frames per tile: one helper lane per (channel slot, frame)
+constexpr int SW = 2;              // encoder (serial) waves per workgroup; one helper wave serves them all
 constexpr int ENC_THREADS = 64 * (SW + 1);
-struct GcTile {
+// Two lane layouts of the encoder wave (template parameter CPW = channels per encoder wave):
+//   CPW = 4: lane = (channel, predictor, scale candidate A/B) -- the candidates of the retry loop run side by side;
+//   CPW = 8: lane = (channel, predictor) -- candidate B (s1 + 1) and candidate A (s1) run one after the other in the
+//            same lane.  Twice the channels share every per-frame fixed cost (row reads, pre-scan, resolution,
+//            argmin, the cold block's pass), which is worth more than the second pass costs: DESIGN.md 4.1.
+template <int CPW>
+struct Lay {
+    static constexpr int CS = CPW * SW;    // channel slots per workgroup
+    static constexpr int TF = 64 / CS;     // frames per tile: one helper lane per (channel slot, frame)
+};
+template <int CS, int TF>
+struct GcTileT {
     int x[CS][TF][16];         // [channel slot][frame][sample]  (14 used)
     int in2048[CS][TF][16];    // x * 2048
     int in2048p[CS][TF][16];   // x * 2048 + 1024
@@ -161,7 +172,7 @@ ColdOut encode_frame_cold(ColdState st, PassOut r, int final_sp, int fin)
 // seg_state[piece][channel] receives every piece's final history.  At BASELINE configs[1] there is one piece.
 // REPAIR is a template parameter only so that the two launches carry different names in profiles (the repair launch
 // normally returns at once and would halve the kernel's average duration).
-template <bool REPAIR>
+template <bool REPAIR, int CPW>
 __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void gc_encode_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, int seg_frames,
     const int16_t *__restrict__ coefs, const int16_t *__restrict__ hist1,
@@ -173,6 +184,8 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     // starting from seg_state of the piece before, which is the real history for all four (every seam before it
     // closed).  Workgroups without such a channel leave at once.
     constexpr bool repair = REPAIR;
+    constexpr int CS = Lay<CPW>::CS, TF = Lay<CPW>::TF;
+    using GcTile = GcTileT<CS, TF>;
     int64_t first_frame = (int64_t)blockIdx.y * seg_frames;
     int repair_piece = 0;
     if (repair) {
@@ -198,9 +211,10 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     const int wave = tid >> 6;
     const bool helper = wave == SW;
     const int lane = tid & 63;
-    // encoder wave: 4 channels x (8 predictors x 2 candidates); helper wave: CS channel slots x TF frames
-    const int grp = helper ? lane / TF : wave * 4 + (lane >> 4);   // channel slot of this lane
-    const int l16 = lane & 15;
+    // encoder wave: CPW channels x 8 predictors (x 2 candidates when CPW = 4); helper wave: CS channel slots x TF frames
+    constexpr int LPC = 64 / CPW;                          // lanes per channel: 16 or 8
+    const int grp = helper ? lane / TF : wave * CPW + lane / LPC;  // channel slot of this lane
+    const int l16 = lane & (LPC - 1);
     const int hfr = lane % TF;                         // helper lanes: the frame inside the tile
     const int ch_raw = blockIdx.x * CS + grp;
     const bool live = ch_raw < nch;
@@ -310,8 +324,8 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
 
     // -------------------------------------------------------------------- serial (encoder) wave
     __builtin_amdgcn_s_setprio(3);                     // its latency is the kernel's run time: win every issue arbitration
-    const int p = l16 >> 1;
-    const bool cand_b = (l16 & 1) != 0;
+    const int p = CPW == 4 ? l16 >> 1 : l16;
+    const bool cand_b = CPW == 4 && (l16 & 1) != 0;
     const int c0 = coefs[ch * 16 + 2 * p];
     const int c1 = coefs[ch * 16 + 2 * p + 1];
     const bool coef_ok = (c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1) <= 32767;   // predictor cannot wrap int32
@@ -446,6 +460,100 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
             finish(r, final_sp, fin, false);
     };
 
+    // ---- CPW = 8: lane = (channel, predictor); candidate B (s1 + 1) and candidate A (s1) are two passes of the SAME lane,
+    // inlined back to back (two independent dependent chains: the wave has instructions to issue while one waits).
+    auto encode_frame8 = [&](Row &R, int buf, int j) {
+        int (&x)[16] = R.x;
+        x[0] = h0;
+        x[1] = h1;
+        int s1;
+        {
+            const int d0 = x[2] - div2048(VGA_MUL24(x[0], c1) + VGA_MUL24(x[1], c0));
+            const int d1 = x[3] - div2048(VGA_MUL24(x[1], c1) + VGA_MUL24(x[2], c0));
+            const int dmax = imax(imax((int)(int16_t)(R.pre & 0xFFFF), d0), d1);
+            const int dmin = imin(imin((int)R.pre >> 16, d0), d1);
+            s1 = first_scale_power_from_range(dmax, dmin);
+            if (__any(s1 == -100)) {                   // +M and -M both present: first occurrence decides
+                if (s1 == -100) s1 = first_scale_power_from_md(prescan_sequential_cold(pack(x), c0, c1));
+            }
+        }
+        const int sp_a = imin(s1, 12), sp_b = imin(s1 + 1, 12);
+        const PassOut rb = pass_fast_core(x, R.m, R.mp, c0, c1, sp_b);
+        const PassOut ra = pass_fast_core(x, R.m, R.mp, c0, c1, sp_a);
+        const bool cap_a = sp_a >= 12, cap_b = sp_b >= 12;         // a pass at the cap ends the loop whatever it overflowed
+        // `rare` as in the four-channel layout (see there): either pass could start the bump loop or has an inexact sum
+        const bool rare = !coef_ok || (unsigned)ra.max_overflow > (cap_a ? 3u : 248u) || (unsigned)rb.max_overflow > (cap_b ? 3u : 248u);
+        const int eff_a = cap_a ? 0 : ra.max_overflow, eff_b = cap_b ? 0 : rb.max_overflow;
+        const bool fin_a = eff_a < 2;                              // the reference stops after the pass at s1
+        const bool resume = !fin_a && eff_b >= 2;                  // both overflowed: on to s1 + 2 in the cold block
+        PassOut r;
+#pragma unroll
+        for (int i = 0; i < 14; i++) r.q[i] = fin_a ? ra.q[i] : rb.q[i];
+        r.total = fin_a ? ra.total : rb.total;
+        r.hist_pair = fin_a ? ra.hist_pair : rb.hist_pair;
+        r.max_overflow = fin_a ? ra.max_overflow : rb.max_overflow;
+        r.o12 = r.o13 = 0;
+        r.exact = true;
+        const int final_sp = fin_a ? sp_a : sp_b;
+        const bool wide = !resume && (unsigned)r.total >= (1u << 28);
+        auto finish = [&](const PassOut &r, int final_sp, bool fin, bool need64) __attribute__((always_inline)) {
+            int winner;
+            if (__builtin_expect(need64, 0)) {
+                uint64_t key = fin ? ((r.total << 3) | (uint64_t)p) : ~0ull;
+#define VGA_MIN64_STAGE(CTRL)                                                          \
+                {                                                                          \
+                    const unsigned olo = (unsigned)dpp<CTRL>((int)(uint32_t)key);          \
+                    const unsigned ohi = (unsigned)dpp<CTRL>((int)(uint32_t)(key >> 32));  \
+                    const uint64_t okey = ((uint64_t)ohi << 32) | olo;                     \
+                    key = okey < key ? okey : key;                                         \
+                }
+                VGA_MIN64_STAGE(DPP_QUAD_XOR1)
+                VGA_MIN64_STAGE(DPP_QUAD_XOR2)
+                VGA_MIN64_STAGE(DPP_ROW_HALF_MIRROR)
+#undef VGA_MIN64_STAGE
+                winner = (int)(key & 7u);
+            } else {
+                unsigned key = fin ? (((unsigned)r.total << 3) | (unsigned)p) : 0xFFFFFFFFu;
+                key = umin32(key, (unsigned)dpp<DPP_QUAD_XOR1>((int)key));
+                key = umin32(key, (unsigned)dpp<DPP_QUAD_XOR2>((int)key));
+                key = umin32(key, (unsigned)dpp<DPP_ROW_HALF_MIRROR>((int)key));
+                winner = (int)(key & 7u);
+            }
+            const bool won = p == winner;
+            unsigned pay = won ? r.hist_pair : 0u;
+            pay |= (unsigned)dpp<DPP_QUAD_XOR1>((int)pay);
+            pay |= (unsigned)dpp<DPP_QUAD_XOR2>((int)pay);
+            pay |= (unsigned)dpp<DPP_ROW_HALF_MIRROR>((int)pay);
+            if (won) {
+                int4 *rec = &s_out[buf][grp][j][0];
+                rec[0] = make_int4(r.q[0], r.q[1], r.q[2], r.q[3]);
+                rec[1] = make_int4(r.q[4], r.q[5], r.q[6], r.q[7]);
+                rec[2] = make_int4(r.q[8], r.q[9], r.q[10], r.q[11]);
+                rec[3] = make_int4(r.q[12], r.q[13], p, final_sp);
+            }
+            h0 = (int)(int16_t)(pay & 0xFFFF);
+            h1 = (int)pay >> 16;
+            VGA_OPAQUE(h0);
+            VGA_OPAQUE(h1);
+        };
+        if (__builtin_expect(__any(rare || resume || wide), 0)) {
+            ColdState st;
+#pragma unroll
+            for (int i = 0; i < 16; i++) st.x[i] = x[i];
+#pragma unroll
+            for (int i = 0; i < 14; i++) { st.m[i] = R.m[i]; st.mp[i] = R.mp[i]; }
+            st.c0 = c0; st.c1 = c1; st.s1 = s1;
+            st.cand_b = 0; st.rare = rare; st.resume = resume;
+            const ColdOut o = encode_frame_cold(st, r, final_sp, resume ? 0 : 1);
+            finish(o.r, o.final_sp, o.fin != 0, __any(o.fin != 0 && (o.r.total >> 28) != 0));
+        } else
+            finish(r, final_sp, true, false);
+    };
+    auto encode_one = [&](Row &R, int buf, int j) __attribute__((always_inline)) {
+        if constexpr (CPW == 4) encode_frame(R, buf, j);
+        else encode_frame8(R, buf, j);
+    };
+
     __syncthreads();                                   // tile 0 prepared
     for (int tile = 0; tile < tiles; tile++) {
         const int buf = tile & 1;
@@ -457,15 +565,15 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
 #pragma unroll 1
         for (int j = 0; j < nf; j += 2) {
             read_row(T, imin(j + 1, TF - 1), RB);
-            encode_frame(RA, buf, j);
+            encode_one(RA, buf, j);
             if (j + 1 < nf) {
                 read_row(T, imin(j + 2, TF - 1), RA);
-                encode_frame(RB, buf, j + 1);
+                encode_one(RB, buf, j + 1);
             }
         }
         __syncthreads();                               // tile done: helper may flush it and refill this buffer later
     }
-    if (seg_state && !repair && live && l16 == 0) {
+    if (seg_state && !repair && live && l16 == 0) {   // one lane per channel
         int16_t *st = seg_state + ((int64_t)blockIdx.y * nch + ch) * 2;
         st[0] = (int16_t)h0;
         st[1] = (int16_t)h1;
@@ -501,64 +609,124 @@ __global__ __launch_bounds__(64) void gc_encode_seam_kernel(
     uint8_t *dst = adpcm + (int64_t)ch * adpcm_pitch;
     const int16_t *cf = coefs + ch * 16;
     const int c0 = cf[2 * pr], c1 = cf[2 * pr + 1];
+    const bool coef_ok = (c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1) <= 32767;
     const int full_frames = total_samples / 14;
-    int x[16];
-    x[0] = valid ? seg_state[((int64_t)(k - 1) * nch + ch) * 2] : 0;
-    x[1] = valid ? seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1] : 0;
+    // The frame loop is one wave's dependent chain (nothing else runs on its SIMD for long: the slowest seam IS the
+    // kernel's run time), so it is the encoder's fast path -- range pre-scan, the two speculative passes of the
+    // (channel, predictor) layout, DPP argmin -- with the next frame's PCM and old bytes already in flight; the
+    // reference's loop as written (resume_passes) only behind the same `rare` / `resume` conditions as there.
+    int h0 = valid ? seg_state[((int64_t)(k - 1) * nch + ch) * 2] : 0;            // true history (x[0], x[1])
+    int h1 = valid ? seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1] : 0;
     int g2 = valid ? src[f0 * 14 - 2] : 0, g1 = valid ? src[f0 * 14 - 1] : 0;   // the guessed run's history (g1 = newest)
     bool open = valid;                                  // uniform inside a group of eight
-    int64_t f = f0;
-    for (; ; f++) {
-        const bool in_range = f < f0 + seg_frames && f < f0 + max_frames && f < full_frames;
+    const int64_t f_end = imin((int)imin((int)(f0 + seg_frames), (int)(f0 + max_frames)), full_frames);   // frames [f0, f_end)
+    const int64_t f_last = full_frames > 0 ? full_frames - 1 : 0;
+    auto fetch = [&](int64_t f, uint32_t (&w)[7], uint2 &old) {
+        const int64_t fc = f < f_last ? f : f_last;     // clamped: always a valid full frame (unconditional loads)
+        const uint32_t *p32 = reinterpret_cast<const uint32_t *>(src + fc * 14);
+#pragma unroll
+        for (int i = 0; i < 7; i++) w[i] = p32[i];
+        old = *reinterpret_cast<const uint2 *>(dst + fc * 8);
+    };
+    uint32_t w[7], wn[7];
+    uint2 old, oldn;
+    fetch(f0, w, old);
+    for (int64_t f = f0; ; f++) {
+        const bool in_range = f < f_end;
         if (!__any(open && in_range)) break;
         const bool act = open && in_range;
-        uint64_t key = ~0ull;                           // (total distance, predictor): smallest wins, first on ties
-        uint32_t d0 = 0, d1 = 0;
-        int n0 = 0, n1 = 0;
-        if (act) {
-            const uint8_t *old = dst + f * 8;
-            {                                           // the guessed run's reconstruction (GcAdpcmDecoder.cs:25-45)
-                const int ps = old[0];
-                const int scale = (1 << (ps & 0xF)) * 2048;
-                const int k1 = cf[((ps >> 4) & 7) * 2], k2 = cf[((ps >> 4) & 7) * 2 + 1];
-                for (int s2 = 0; s2 < 14; s2++) {
-                    const int byte = old[1 + (s2 >> 1)];
-                    const int nib = (s2 & 1) ? (byte & 0xF) : (byte >> 4);
-                    const int v = clamp16i((k1 * g1 + k2 * g2 + scale * ((nib ^ 8) - 8) + 1024) >> 11);
-                    g2 = g1;
-                    g1 = v;
-                }
+        fetch(f + 1, wn, oldn);                         // in flight during this frame
+        int x[16], m[14], mp[14];
+        x[0] = h0;
+        x[1] = h1;
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            x[2 + 2 * i] = (int)(int16_t)(w[i] & 0xFFFF);
+            x[3 + 2 * i] = (int)w[i] >> 16;
+        }
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            m[i] = x[2 + i] * 2048;
+            mp[i] = m[i] + 1024;
+        }
+        // the guessed run's reconstruction of this frame (GcAdpcmDecoder.cs:25-45), from its bytes before they change
+        {
+            const int ps = (int)(old.x & 0xFFu);
+            const int scale = (1 << (ps & 0xF)) * 2048;
+            const int pred = (ps >> 4) & 7;
+            const int k1 = __shfl(c0, pred, 8), k2 = __shfl(c1, pred, 8);     // that predictor's pair sits in lane `pred` of the group
+            const uint64_t bits = ((uint64_t)old.y << 32) | old.x;            // byte b of the frame = bits >> 8b
+#pragma unroll
+            for (int s2 = 0; s2 < 14; s2++) {
+                const int byte = (int)((bits >> (8 * (1 + (s2 >> 1)))) & 0xFFu);
+                const int nib = (s2 & 1) ? (byte & 0xF) : (byte >> 4);
+                const int v = clamp16i((k1 * g1 + k2 * g2 + scale * ((nib ^ 8) - 8) + 1024) >> 11);
+                g2 = g1;
+                g1 = v;
             }
+        }
+        // the true frame: pre-scan (:107-124), candidates A and B (:127-170), see encode_frame8
+        int s1;
+        {
+            int dmax = 0, dmin = 0;
+            prescan_range(x, c0, c1, 0, 14, dmax, dmin);
+            s1 = first_scale_power_from_range(dmax, dmin);
+            if (s1 == -100) s1 = first_scale_power_from_md(prescan_sequential(x, c0, c1));
+        }
+        const int sp_a = imin(s1, 12), sp_b = imin(s1 + 1, 12);
+        const PassOut rb = pass_fast_core(x, m, mp, c0, c1, sp_b);
+        const PassOut ra = pass_fast_core(x, m, mp, c0, c1, sp_a);
+        const bool cap_a = sp_a >= 12, cap_b = sp_b >= 12;
+        const bool rare = !coef_ok || (unsigned)ra.max_overflow > (cap_a ? 3u : 248u) || (unsigned)rb.max_overflow > (cap_b ? 3u : 248u);
+        const int eff_a = cap_a ? 0 : ra.max_overflow, eff_b = cap_b ? 0 : rb.max_overflow;
+        const bool fin_a = eff_a < 2;
+        const bool resume = !fin_a && eff_b >= 2;
+        PassOut r;
 #pragma unroll
-            for (int s2 = 0; s2 < 14; s2++) x[2 + s2] = src[f * 14 + s2];
-            const int s1 = first_scale_power_from_md(prescan_sequential(x, c0, c1));
-            int final_sp;
-            const PassOut r = resume_passes(x, c0, c1, s1 - 1, final_sp);
-            // totals are below 2^60 (14 squares of 17-bit errors): the predictor rides in the low bits
-            key = (r.total << 3) | (uint64_t)pr;
+        for (int i = 0; i < 14; i++) r.q[i] = fin_a ? ra.q[i] : rb.q[i];
+        r.total = fin_a ? ra.total : rb.total;
+        r.hist_pair = fin_a ? ra.hist_pair : rb.hist_pair;
+        int final_sp = fin_a ? sp_a : sp_b;
+        if (__any(rare || resume)) {
+            if (rare || resume) {
+                const PassOut rc = resume_passes(x, c0, c1, rare ? s1 - 1 : s1 + 1, final_sp);
+#pragma unroll
+                for (int i = 0; i < 14; i++) r.q[i] = rc.q[i];
+                r.total = rc.total;
+                r.hist_pair = rc.hist_pair;
+            }
+        }
+        // totals are below 2^60 (14 squares of 17-bit errors): the predictor rides in the low bits
+        uint64_t key = act ? ((r.total << 3) | (uint64_t)pr) : ~0ull;
+#define VGA_MIN64_STAGE(CTRL)                                                          \
+        {                                                                              \
+            const unsigned olo = (unsigned)dpp<CTRL>((int)(uint32_t)key);              \
+            const unsigned ohi = (unsigned)dpp<CTRL>((int)(uint32_t)(key >> 32));      \
+            const uint64_t okey = ((uint64_t)ohi << 32) | olo;                         \
+            key = okey < key ? okey : key;                                             \
+        }
+        VGA_MIN64_STAGE(DPP_QUAD_XOR1)
+        VGA_MIN64_STAGE(DPP_QUAD_XOR2)
+        VGA_MIN64_STAGE(DPP_ROW_HALF_MIRROR)
+#undef VGA_MIN64_STAGE
+        const bool won = act && pr == (int)(key & 7u);
+        unsigned pay = won ? r.hist_pair : 0u;
+        pay |= (unsigned)dpp<DPP_QUAD_XOR1>((int)pay);
+        pay |= (unsigned)dpp<DPP_QUAD_XOR2>((int)pay);
+        pay |= (unsigned)dpp<DPP_ROW_HALF_MIRROR>((int)pay);
+        if (won) {
+            uint32_t d0, d1;
             pack_frame(r.q, pr, final_sp, d0, d1);
-            n0 = r.o12;
-            n1 = r.o13;
+            *reinterpret_cast<uint2 *>(dst + f * 8) = make_uint2(d0, d1);
         }
-        uint64_t best = key;
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best, o, 8);
-            const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), o, 8);
-            const uint64_t other = ((uint64_t)hi << 32) | lo;
-            best = other < best ? other : best;
-        }
-        const int winner = (int)(best & 7u);
-        d0 = (uint32_t)__shfl((int)d0, winner, 8);
-        d1 = (uint32_t)__shfl((int)d1, winner, 8);
-        n0 = __shfl(n0, winner, 8);
-        n1 = __shfl(n1, winner, 8);
         if (act) {
-            if (pr == 0) store_frame_bytes(dst + f * 8, d0, d1, 8);
-            x[0] = n0;                                  // :40-41
-            x[1] = n1;
-            if (x[0] == g2 && x[1] == g1 && !seam_forced_open(force_open, ch, k)) open = false;   // closed
+            h0 = (int)(int16_t)(pay & 0xFFFF);          // :40-41
+            h1 = (int)pay >> 16;
+            if (h0 == g2 && h1 == g1 && !seam_forced_open(force_open, ch, k)) open = false;   // closed
         }
+#pragma unroll
+        for (int i = 0; i < 7; i++) w[i] = wn[i];
+        old = oldn;
     }
     // still open (the launcher's max_frames is the piece length: half the seams close within nine frames, one in a
     // hundred needs more than 400, a few channels never meet): the repair launch encodes this channel serially from this
@@ -566,10 +734,12 @@ __global__ __launch_bounds__(64) void gc_encode_seam_kernel(
     if (valid && open && pr == 0) atomicMin(&first_open[ch], k);
 }
 
-int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
-                  const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,
-                  hipStream_t stream)
+template <int CPW>
+static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
+                                const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,
+                                hipStream_t stream)
 {
+    constexpr int CS = Lay<CPW>::CS;
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
     // one encoder wave per SIMD fills the chip (4 channels each): fewer channels than that are cut into time pieces
     // (each at least 512 frames: a seam re-encodes a few dozen)
@@ -580,6 +750,7 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_c
     if (segments > frames / 512) segments = frames / 512;
     if (segments < 1) segments = 1;
     if (segments > 1024) segments = 1024;
+    if (encoder_segments_override() > 0) segments = imin(imax(frames / 64, 1), encoder_segments_override());   // test hook
     const int seg_frames = (frames + segments - 1) / segments;
     AsyncBuf scratch;                                  // freed (stream-ordered) on every exit path
     int16_t *seg_state = nullptr;
@@ -591,7 +762,7 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_c
         first_open = reinterpret_cast<int *>(scratch.as<unsigned char>() + state_bytes);
         VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
     }
-    hipLaunchKernelGGL(gc_encode_kernel<false>, dim3(groups, segments), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch,
+    hipLaunchKernelGGL((gc_encode_kernel<false, CPW>), dim3(groups, segments), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch,
                        sample_count, seg_frames, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state,
                        (const int *)nullptr);
     VGA_HIP_TRY(hipGetLastError());
@@ -601,11 +772,20 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_c
                            force_open_seams());
         VGA_HIP_TRY(hipGetLastError());
         // repair: the same encoder, serially, for the channels whose seams stayed open (none: every workgroup returns)
-        hipLaunchKernelGGL(gc_encode_kernel<true>, dim3(groups, 1), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
+        hipLaunchKernelGGL((gc_encode_kernel<true, CPW>), dim3(groups, 1), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
                            seg_frames, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state, (const int *)first_open);
         VGA_HIP_TRY(hipGetLastError());
     }
     return VGA_OK;
+}
+
+int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
+                  const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,
+                  hipStream_t stream)
+{
+    if (encoder_layout() == 4)
+        return launch_encode_layout<4>(d_pcm, pcm_pitch, nch, sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, stream);
+    return launch_encode_layout<8>(d_pcm, pcm_pitch, nch, sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, stream);
 }
 
 }  // namespace gc
