@@ -262,7 +262,8 @@ def measure_e2e(cx, args, pcm, n, coefs_dev, adpcm_dev):
     nf = L.vga_testing_last_pipeline_stats(st, 32)
     names = ["total", "setup", "feeders_memcpy_sum", "feeders_wait_slot_sum", "feeders_issue_sum", "slowest_feeder", "caller_wait_upload",
              "caller_launch", "caller_tail_sync", "drainers_wait_compute_sum", "drainers_wait_download_sum", "drainers_memcpy_sum",
-             "slowest_drainer", "feeders", "drainers", "chunks", "units_per_chunk", "device_alloc", "entry_point"]
+             "slowest_drainer", "feeders", "drainers", "chunks", "units_per_chunk", "device_alloc", "entry_point",
+             "feeders_chunk_boundary_sum", "feeders_final_sync_sum"]
     breakdown = {k: (int(st[i]) if 13 <= i <= 16 else round(st[i] * 1e3, 1)) for i, k in enumerate(names[:nf])}
     same = bool(np.array_equal(outs, adpcm_dev[:want, :nb].cpu().numpy()) and
                 np.array_equal(cf.reshape(want, 16), coefs_dev[:want].cpu().numpy().reshape(want, 16)))

@@ -15,7 +15,7 @@
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
-static const unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocPortable = 1;
+static const unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipEventDefault = 0, hipHostMallocPortable = 1;
 
 struct MockStream {
     std::mutex m;
@@ -81,6 +81,19 @@ inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "o
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
+static const unsigned hipHostRegisterDefault = 0;
+inline int &mock_registered() { static int n = 0; return n; }
+// every third registration "fails" (already registered / shared page): the caller must fall back to a plain copy
+inline hipError_t hipHostRegister(void *, size_t, unsigned)
+{
+    std::lock_guard<std::mutex> g(mock_mutex());
+    static int calls = 0;
+    if (++calls % 3 == 0) return hipErrorInvalidValue;
+    mock_registered()++;
+    return hipSuccess;
+}
+inline hipError_t hipHostUnregister(void *) { std::lock_guard<std::mutex> g(mock_mutex()); mock_registered()--; return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new MockStream; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t s) { s->sync(); return hipSuccess; }
@@ -109,6 +122,7 @@ inline hipError_t hipEventSynchronize(hipEvent_t e)
     e->cv.wait(g, [&] { return e->done >= gen; });
     return hipSuccess;
 }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return hipSuccess; }     // the mock keeps no clock
 inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
 {
     long gen;

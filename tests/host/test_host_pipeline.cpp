@@ -9,6 +9,7 @@
 using namespace vga::pipe;
 
 static int g_taper = 0;
+static bool g_direct = false, g_shared = false;
 static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t out_bytes, int chunk, int feeders, int drainers,
                     size_t slot_bytes, int delay_us, int fail_after, bool compute_fails)
 {
@@ -40,6 +41,10 @@ static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t 
     job.drainers = drainers;
     job.slot_bytes = slot_bytes;
     job.taper_min_units = g_taper;
+    job.direct = g_direct;
+    job.shared_streams = g_shared;
+    if (in_rows == 0) job.in_rows = nullptr;                 // a job with nothing to upload / nothing to download
+    if (out_rows == 0) job.out_rows = nullptr;
     int launches = 0;
     std::vector<int> seen(units, 0);
     // "kernel": output row (u, j) byte i = sum over the unit's input rows of byte (i mod in_bytes), plus j and i
@@ -86,7 +91,22 @@ static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t 
     return 0;
 }
 
+static int all_cases();
 int main()
+{
+    int bad = 0;
+    for (int mode = 0; mode < 4; mode++) {
+        g_direct = mode & 1;
+        g_shared = mode & 2;
+        bad += all_cases();
+    }
+    PinnedPool::get().trim();
+    if (mock_registered() != 0) { std::printf("%d rows left registered\n", mock_registered()); bad++; }
+    std::printf(bad ? "FAILED %d\n" : "ok\n", bad);
+    return bad ? 1 : 0;
+}
+
+static int all_cases()
 {
     int bad = 0;
     // units, in_rpu, out_rpu, in_bytes, out_bytes, chunk, feeders, drainers, slot_bytes, delay, fail_after, compute_fails
@@ -98,13 +118,13 @@ int main()
     bad += run_case(33, 1, 1, 256, 64, 4, 4, 2, 1024, 30, 7, false);              // a copy fails mid-way: error, no hang
     bad += run_case(33, 1, 1, 256, 64, 4, 4, 2, 1024, 30, 0, false);
     bad += run_case(40, 1, 1, 256, 64, 8, 4, 2, 1024, 10, -1, true);              // the compute callback refuses the 2nd chunk
+    bad += run_case(21, 1, 0, 300, 16, 4, 3, 2, 1024, 10, -1, false);             // upload only (coefficient search)
+    bad += run_case(21, 0, 2, 16, 300, 4, 3, 2, 1024, 10, -1, false);             // download only
     g_taper = 3;                                                                  // tapered last chunk
     bad += run_case(37, 1, 1, 1000, 300, 8, 8, 4, 2048, 20, -1, false);
     bad += run_case(64, 2, 1, 513, 77, 32, 3, 2, 512, 10, -1, false);
     bad += run_case(100, 1, 1, 128, 32, 40, 4, 2, 4096, 5, -1, false);
     bad += run_case(9, 1, 1, 128, 32, 100, 4, 2, 4096, 5, -1, false);             // one chunk: nothing to taper
     g_taper = 0;
-    PinnedPool::get().trim();
-    std::printf(bad ? "FAILED %d\n" : "ok\n", bad);
-    return bad ? 1 : 0;
+    return bad;
 }

@@ -168,15 +168,20 @@ def test_time_segment_fallbacks_are_exact():
         torch.cuda.synchronize()
         return dec[:, :n].clone(), adx[:, :nb].clone(), back[:, :n].clone(), enc[:, :vdev.gc_byte_count(n)].clone()
 
-    normal = run()
-    for mode in (1, 2):                          # every seam open / open and closed seams mixed inside a workgroup
-        old = L.vga_testing_force_open_seams_this_thread(mode)
-        try:
-            forced = run()
-        finally:
-            L.vga_testing_force_open_seams_this_thread(old)
-        for a, b in zip(normal, forced):
-            assert torch.equal(a, b), mode
+    # the GC encoder only cuts pieces of 12 288 frames or more on its own: ask for 12 pieces of this shorter stream
+    L.vga_testing_gc_encoder_segments_this_thread(12)
+    try:
+        normal = run()
+        for mode in (1, 2):                      # every seam open / open and closed seams mixed inside a workgroup
+            old = L.vga_testing_force_open_seams_this_thread(mode)
+            try:
+                forced = run()
+            finally:
+                L.vga_testing_force_open_seams_this_thread(old)
+            for a, b in zip(normal, forced):
+                assert torch.equal(a, b), mode
+    finally:
+        L.vga_testing_gc_encoder_segments_this_thread(0)
     # and both equal the oracle on a few channels
     for c in (0, 64, 129):
         host = pcm[c, :n].cpu().numpy()

@@ -389,3 +389,30 @@ def test_batch_entry_points_are_reentrant_from_many_threads():
             assert (fmt.Channels[c].Coefs == coefs[c]).all(), (k, c)
             assert (fmt.Channels[c].Adpcm == adpcm[c]).all(), (k, c)
             assert (back.Channels[c] == po.gc_decode(adpcm[c], coefs[c], n)).all(), (k, c)
+
+
+def test_encoder_layouts_and_piece_counts_give_the_same_bytes():
+    """The encoder's lane layout (8 = (channel, predictor), the product's; 4 = (channel, predictor, candidate)) and the
+    number of time pieces a channel is cut into are performance choices: every combination must produce the oracle's bytes."""
+    import torch
+    from vgaudio_amd import _lib, device as vdev
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    nch, n = 37, 14 * 9000 + 5
+    pcm = vdev.synth_pcm(nch, n, d)
+    coefs = vdev.gc_coefs(pcm, n)
+    host = pcm[:, :n].cpu().numpy()
+    wc, wa = po.gc_encode_batch(host, threads=4)
+    nb = vdev.gc_byte_count(n)
+    assert np.array_equal(coefs.cpu().numpy().reshape(nch, 16), np.asarray(wc).reshape(nch, 16))
+    try:
+        for layout in (4, 8):
+            for segments in (0, 1, 2, 5, 16):
+                L.vga_testing_gc_encoder_layout_this_thread(layout)
+                L.vga_testing_gc_encoder_segments_this_thread(segments)
+                out = vdev.gc_encode(pcm, n, coefs)
+                torch.cuda.synchronize()
+                assert np.array_equal(out[:, :nb].cpu().numpy(), np.asarray(wa)[:, :nb]), (layout, segments)
+    finally:
+        L.vga_testing_gc_encoder_layout_this_thread(8)
+        L.vga_testing_gc_encoder_segments_this_thread(0)

@@ -13,7 +13,7 @@ from vgaudio_amd.gcadpcm import GcAdpcmDecoder, GcAdpcmFormat, GcAdpcmParameters
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(0, 0, 0, 0), (5, 3, 7, 4096), (8, 4, 1, 1), (1, 1, 1000, 1 << 20), (3, 8, 13, 30000)]
+SHAPES = [(0, 0, 0, 0), (5, 3, 7, 4096), (8, 4, 1, 1), (1, 1, 1000, 1 << 20), (3, 8, 13, 30000), (3, 2, 5, -4096), (1, 1, 0, -1)]
 
 
 @pytest.fixture(params=SHAPES, ids=[str(s) for s in SHAPES])

@@ -868,6 +868,7 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
         if (segments > frames / 2048) segments = frames / 2048;
         if (segments < 1) segments = 1;
         if (segments > 64) segments = 64;
+        if (encoder_segments_override() > 0) segments = std::min(std::max(frames / 64, 1), encoder_segments_override());   // test hook
         int seg_frames = (frames + segments - 1) / segments;
         seg_frames += seg_frames & 1;
         AsyncBuf scratch;                              // freed (stream-ordered) on every exit path

@@ -88,7 +88,7 @@ int vga_testing_last_pipeline_stats(double *out, int n)
     const double v[] = {r.stats.total, r.stats.setup, r.stats.feed_copy, r.stats.feed_wait_slot, r.stats.feed_issue, r.stats.feed_max,
                         r.stats.main_wait_upload, r.stats.main_launch, r.stats.main_tail_sync, r.stats.drain_wait_compute,
                         r.stats.drain_wait_copy, r.stats.drain_copy, r.stats.drain_max, (double)r.stats.feeders, (double)r.stats.drainers,
-                        (double)r.stats.chunks, (double)r.stats.chunk_units, r.t_alloc, r.t_entry};
+                        (double)r.stats.chunks, (double)r.stats.chunk_units, r.t_alloc, r.t_entry, r.stats.feed_boundary, r.stats.feed_final};
     const int m = (int)(sizeof v / sizeof v[0]);
     for (int i = 0; i < n && i < m; i++) out[i] = v[i];
     return m;
@@ -516,6 +516,7 @@ int vga_gcadpcm_encode_with_coefs_batch(const int16_t *const *pcm, int nch, int 
     const int nbytes = vga_gcadpcm_sample_count_to_byte_count(sample_count);
     b.adpcm_pitch = round_up(nbytes, 16);
     VGA_HIP_TRY(b.adpcm.alloc((size_t)nch * b.adpcm_pitch));
+    DevBuf scratch;                                       // the encoder's piece states: one chunk at a time uses it
     pipe::Job job;
     job.units = nch;
     job.in_rows = (const void *const *)pcm;
@@ -530,10 +531,11 @@ int vga_gcadpcm_encode_with_coefs_batch(const int16_t *const *pcm, int nch, int 
         const int rc = gc::launch_encode(b.pcm.as<int16_t>() + (int64_t)first * b.pcm_pitch, b.pcm_pitch, count, sample_count,
                                          b.coefs.as<int16_t>() + (int64_t)first * 16,
                                          b.h1.p ? b.h1.as<int16_t>() + first : nullptr, b.h2.p ? b.h2.as<int16_t>() + first : nullptr,
-                                         b.adpcm.as<uint8_t>() + (int64_t)first * b.adpcm_pitch, b.adpcm_pitch, s);
+                                         b.adpcm.as<uint8_t>() + (int64_t)first * b.adpcm_pitch, b.adpcm_pitch, s, scratch.p, scratch.bytes);
         if (rc) why = vga_last_error();
         return rc;
     };
+    VGA_HIP_TRY(scratch.alloc(gc::encode_scratch_bytes(planned_chunk_units(job, GC_CHUNK_CHANNELS))));
     return run_batch_pipeline(job, GC_CHUNK_CHANNELS);
 }
 
@@ -560,6 +562,7 @@ int vga_gcadpcm_encode_batch(const int16_t *const *pcm, int nch, int sample_coun
     const int nbytes = vga_gcadpcm_sample_count_to_byte_count(sample_count);
     b.adpcm_pitch = round_up(nbytes > 0 ? nbytes : 1, 16);
     VGA_HIP_TRY(b.adpcm.alloc((size_t)nch * b.adpcm_pitch));
+    DevBuf scratch;                                       // the encoder's piece states: one chunk at a time uses it
     pipe::Job job;
     job.units = nch;
     if (sample_count > 0) {
@@ -581,10 +584,11 @@ int vga_gcadpcm_encode_batch(const int16_t *const *pcm, int nch, int sample_coun
             rc = gc::launch_encode(b.pcm.as<int16_t>() + (int64_t)first * b.pcm_pitch, b.pcm_pitch, count, sample_count,
                                    b.coefs.as<int16_t>() + (int64_t)first * 16,
                                    b.h1.p ? b.h1.as<int16_t>() + first : nullptr, b.h2.p ? b.h2.as<int16_t>() + first : nullptr,
-                                   b.adpcm.as<uint8_t>() + (int64_t)first * b.adpcm_pitch, b.adpcm_pitch, s);
+                                   b.adpcm.as<uint8_t>() + (int64_t)first * b.adpcm_pitch, b.adpcm_pitch, s, scratch.p, scratch.bytes);
         if (rc) why = vga_last_error();
         return rc;
     };
+    VGA_HIP_TRY(scratch.alloc(gc::encode_scratch_bytes(planned_chunk_units(job, GC_CHUNK_CHANNELS))));
     // one chunk's workspace: the chunks' kernels run one after the other on the compute stream
     VGA_HIP_TRY(b.ws.alloc(vga_gcadpcm_coefs_workspace_bytes(planned_chunk_units(job, GC_CHUNK_CHANNELS), sample_count)));
     pipe_report().t_alloc = pipe::detail::now() - t_entry;

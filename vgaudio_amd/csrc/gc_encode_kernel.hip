@@ -734,20 +734,25 @@ __global__ __launch_bounds__(64) void gc_encode_seam_kernel(
     if (valid && open && pr == 0) atomicMin(&first_open[ch], k);
 }
 
+constexpr int MIN_PIECE_FRAMES = 12288;
+
 template <int CPW>
 static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
                                 const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,
-                                hipStream_t stream)
+                                hipStream_t stream, void *d_scratch, size_t scratch_bytes)
 {
     constexpr int CS = Lay<CPW>::CS;
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
-    // one encoder wave per SIMD fills the chip (4 channels each): fewer channels than that are cut into time pieces
-    // (each at least 512 frames: a seam re-encodes a few dozen)
+    // one encoder wave per SIMD fills the chip: fewer channels than that are cut into time pieces.  A seam re-encodes a
+    // few dozen frames as a rule, but the tail is long -- with 6 400-frame pieces a 512-channel launch (16 000 seams) had
+    // seams still open at the end of their piece, and one such channel is then encoded serially from there on (300 ms
+    // on a 75 s stream, tools/sweep_host_pipeline.py's timeline); no seam of three 1024-channel launches stayed open
+    // over 12 800 frames, so that is the shortest piece the launcher cuts when it has the choice.
     const int groups = (nch + CS - 1) / CS;
     const int cus = device_cu_count();
     const int frames = (sample_count + 13) / 14;
     int segments = cus * 4 / groups;                   // = SW encoder waves on every SIMD
-    if (segments > frames / 512) segments = frames / 512;
+    if (segments > frames / MIN_PIECE_FRAMES) segments = frames / MIN_PIECE_FRAMES;
     if (segments < 1) segments = 1;
     if (segments > 1024) segments = 1024;
     if (encoder_segments_override() > 0) segments = imin(imax(frames / 64, 1), encoder_segments_override());   // test hook
@@ -757,9 +762,15 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
     int *first_open = nullptr;
     if (segments > 1) {
         const size_t state_bytes = (size_t)round_up((int64_t)segments * nch * 2 * (int64_t)sizeof(int16_t), 16);
-        VGA_HIP_TRY(scratch.alloc(state_bytes + (size_t)nch * sizeof(int), stream));
-        seg_state = scratch.as<int16_t>();
-        first_open = reinterpret_cast<int *>(scratch.as<unsigned char>() + state_bytes);
+        // the caller's scratch when it brought one (the host pipeline: hipMallocAsync next to busy copy streams stalled
+        // its launching thread for up to 300 ms per call), a stream-ordered allocation otherwise
+        unsigned char *base = static_cast<unsigned char *>(d_scratch);
+        if (!base || scratch_bytes < state_bytes + (size_t)nch * sizeof(int)) {
+            VGA_HIP_TRY(scratch.alloc(state_bytes + (size_t)nch * sizeof(int), stream));
+            base = scratch.as<unsigned char>();
+        }
+        seg_state = reinterpret_cast<int16_t *>(base);
+        first_open = reinterpret_cast<int *>(base + state_bytes);
         VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
     }
     hipLaunchKernelGGL((gc_encode_kernel<false, CPW>), dim3(groups, segments), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch,
@@ -779,13 +790,18 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
     return VGA_OK;
 }
 
+// upper bound of what launch_encode wants as scratch for nch channels (1024 pieces x 4 B + 4 B per channel, + alignment)
+size_t encode_scratch_bytes(int nch) { return (size_t)(nch > 0 ? nch : 0) * (1024 * 4 + 4) + 64; }
+
 int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
                   const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,
-                  hipStream_t stream)
+                  hipStream_t stream, void *d_scratch, size_t scratch_bytes)
 {
     if (encoder_layout() == 4)
-        return launch_encode_layout<4>(d_pcm, pcm_pitch, nch, sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, stream);
-    return launch_encode_layout<8>(d_pcm, pcm_pitch, nch, sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, stream);
+        return launch_encode_layout<4>(d_pcm, pcm_pitch, nch, sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, stream,
+                                       d_scratch, scratch_bytes);
+    return launch_encode_layout<8>(d_pcm, pcm_pitch, nch, sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, stream,
+                                   d_scratch, scratch_bytes);
 }
 
 }  // namespace gc

@@ -8,9 +8,11 @@ namespace gc {
 
 int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, int16_t *d_coefs,
                  void *d_workspace, hipStream_t stream);
+// d_scratch (optional, encode_scratch_bytes(nch) bytes): where the time pieces' states go; allocated stream-ordered when null
 int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
                   const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,
-                  hipStream_t stream);
+                  hipStream_t stream, void *d_scratch = nullptr, size_t scratch_bytes = 0);
+size_t encode_scratch_bytes(int nch);
 // gc_decode_kernel.hip (serial wave + helper waves)
 int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs, int nch, int sample_count,
                   const int16_t *d_hist1, const int16_t *d_hist2, int16_t *d_pcm, int64_t pcm_pitch, int *d_status,

@@ -1,5 +1,6 @@
 // host_batch.hpp -- glue between the host-pointer entry points of the C ABI and host_pipeline.hpp.
 #pragma once
+#include <cstdlib>
 #include "common.hpp"
 #include "host_pipeline.hpp"
 
@@ -7,7 +8,7 @@ namespace vga {
 
 // Per-thread overrides of the pipeline's shape (vga_testing_host_pipeline_this_thread): the tests force many feeders,
 // one-row slots and small chunks on small inputs so that every hand-off of the pipeline is exercised on the GPU box.
-struct PipeOverride { int feeders = 0, drainers = 0, chunk_units = 0, slot_bytes = 0; };
+struct PipeOverride { int feeders = 0, drainers = 0, chunk_units = 0, slot_bytes = 0; };   // slot_bytes < 0: direct copies (no staging ring); > 0: staged
 PipeOverride &pipe_override();                       // capi_gcadpcm.hip
 // the calling thread's last pipeline run, plus what the entry point spent around it (device allocation, small copies)
 struct PipeReport { pipe::Stats stats; double t_alloc = 0, t_entry = 0; };
@@ -37,15 +38,20 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     job.device = device;
     const size_t in_total = job.in_rows ? (size_t)job.units * job.in_rows_per_unit * job.in_row_bytes : 0;
     const size_t out_total = job.out_rows ? (size_t)job.units * job.out_rows_per_unit * job.out_row_bytes : 0;
-    // Measured at configs[1] (tools/sweep_host_pipeline.py, profiles/r02_sweep_pipeline.log): one feeder thread copies
-    // ~23 GB/s into its ring, the DMA engines take ~57 GB/s in total (both directions together), so 4 feeders and 2
-    // drainers with 32 MB slots keep them busy; 8 + 4 threads with 8 MB slots were 25 % slower (more, smaller DMAs).
-    const size_t per_worker = (size_t)64 << 20;      // a worker thread is worth starting for every 64 MB it moves
-    job.feeders = o.feeders > 0 ? o.feeders : (int)std::min<size_t>(4, std::max<size_t>(1, in_total / per_worker));
-    job.drainers = o.drainers > 0 ? o.drainers : (int)std::min<size_t>(2, std::max<size_t>(1, out_total / per_worker));
-    job.slot_bytes = o.slot_bytes > 0 ? (size_t)o.slot_bytes : (size_t)32 << 20;
+    // Measured on the MI355X box (tools/bench_h2d_modes.hip, tools/bench_overlap.hip, tools/sweep_host_pipeline.py;
+    // profiles/r02_*): page-locking the caller's rows for the call (hipHostRegister) lets ONE stream of direct copies
+    // run at the link's rate (~56 GB/s) on the DMA engines next to the kernels; copies issued on several streams at once
+    // were held back until the kernels ended, and a ring filled by memcpy threads was no faster than its four threads.
+    // So: one feeder and one drainer, direct copies, all uploads on one stream and all downloads on another (a slot = the
+    // rows a worker takes at a time); the staged mode stays selectable.
+    (void)in_total; (void)out_total;
+    job.feeders = o.feeders > 0 ? o.feeders : 1;
+    job.drainers = o.drainers > 0 ? o.drainers : 1;
+    job.direct = o.slot_bytes <= 0;
+    job.shared_streams = true;
+    job.slot_bytes = o.slot_bytes > 0 ? (size_t)o.slot_bytes : (o.slot_bytes < -1 ? (size_t)(-o.slot_bytes) : (size_t)32 << 20);
     job.chunk_units = planned_chunk_units(job, default_chunk_units);
-    job.taper_min_units = std::max(1, job.chunk_units / 4);       // ..., chunk, chunk/2, chunk/4, chunk/4
+    job.taper_min_units = std::max(1, job.chunk_units / 2);       // ..., chunk, chunk/2, chunk/2: what runs after the last upload is short
     const pipe::Result r = pipe::run(job);
     pipe_report().stats = r.stats;
     if (r.code) {

@@ -18,6 +18,8 @@
 // Host-only code (no kernels): tests/host/test_host_pipeline.cpp compiles this header against a mock of the few HIP
 // entry points it uses and runs it under ThreadSanitizer on the CPU.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -129,6 +131,12 @@ struct Job {
     int feeders = 8, drainers = 4;
     size_t slot_bytes = (size_t)8 << 20;   // target size of one ring slot (whole rows; at least one row)
     int ring = 3;                          // slots per feeder / drainer
+    // true: no staging -- the workers hand the caller's rows straight to hipMemcpyAsync (the runtime moves pageable
+    // memory at ~51 GB/s on an MI355X host, tools/bench_h2d_modes.hip; CPU-side copies into a pinned ring only compete
+    // with the DMA engines for the host's memory bandwidth).  false: stage through the page-locked rings.
+    bool direct = true;
+    bool register_rows = true;             // direct mode: hipHostRegister each row for the duration of the call
+    bool shared_streams = false;           // every feeder issues on one stream, every drainer on another (3 streams in all)
     int device = 0;
 };
 
@@ -136,6 +144,7 @@ struct Job {
 struct Stats {
     double setup = 0, total = 0;
     double feed_copy = 0, feed_wait_slot = 0, feed_issue = 0, feed_max = 0;       // feeders: memcpy into the ring, waiting for a slot, hipMemcpyAsync calls
+    double feed_boundary = 0, feed_final = 0;                                       // feeders: chunk events + notifications, the final stream sync
     double main_wait_upload = 0, main_launch = 0, main_tail_sync = 0;               // calling thread
     double drain_wait_compute = 0, drain_wait_copy = 0, drain_copy = 0, drain_max = 0;
     int feeders = 0, drainers = 0, chunks = 0, chunk_units = 0;
@@ -188,14 +197,6 @@ inline std::string hip_msg(const char *what, hipError_t e)
         }                                                                    \
     } while (0)
 
-// rows [begin, end) of the chunk's row range, split evenly over `parts` workers: worker `i` gets [lo, hi)
-inline void split(int begin, int end, int parts, int i, int &lo, int &hi)
-{
-    const int64_t n = end - begin;
-    lo = begin + (int)(n * i / parts);
-    hi = begin + (int)(n * (i + 1) / parts);
-}
-
 }  // namespace detail
 
 inline Result run(const Job &job)
@@ -230,6 +231,9 @@ inline Result run(const Job &job)
     const int in_slot_rows = has_in ? (int)std::max<size_t>(1, job.slot_bytes / std::max<size_t>(1, job.d_in_pitch)) : 0;
     const int out_slot_rows = has_out ? (int)std::max<size_t>(1, job.slot_bytes / std::max<size_t>(1, job.d_out_pitch)) : 0;
 
+    std::vector<std::atomic<int>> next_in(chunks), next_out(chunks);   // per chunk: first row not yet taken by a worker
+    for (auto &a : next_in) a.store(0);
+    for (auto &a : next_out) a.store(0);
     Shared sh;
     sh.uploaded.assign(chunks, 0);
     sh.launched.assign(chunks, 0);
@@ -248,12 +252,25 @@ inline Result run(const Job &job)
         }
     };
     check(hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking), "hipStreamCreate");
-    for (auto &s : fstream) check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
-    for (auto &s : dstream) check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
-    for (auto *v : {&fslot, &dslot, &upl, &comp})
+    const bool shared_streams = job.shared_streams;
+    if (shared_streams) {
+        if (F > 0) check(hipStreamCreateWithFlags(&fstream[0], hipStreamNonBlocking), "hipStreamCreate");
+        if (D > 0) check(hipStreamCreateWithFlags(&dstream[0], hipStreamNonBlocking), "hipStreamCreate");
+        for (auto &s : fstream) s = fstream[0];
+        for (auto &s : dstream) s = dstream[0];
+    } else {
+        for (auto &s : fstream) check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+        for (auto &s : dstream) check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    }
+    const bool timeline = std::getenv("VGA_HIP_PIPELINE_TIMELINE") != nullptr;
+    std::vector<hipEvent_t> cstart(chunks + 1, nullptr);
+    for (auto *v : {&fslot, &dslot})
         for (auto &e : *v) check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
-    if (ok && has_in && !in_ring.alloc((size_t)F * R * in_slot_rows * job.d_in_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (input ring)");
-    if (ok && has_out && !out_ring.alloc((size_t)D * R * out_slot_rows * job.d_out_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (output ring)");
+    for (auto *v : {&upl, &comp, &cstart})
+        for (auto &e : *v) check(hipEventCreateWithFlags(&e, timeline ? hipEventDefault : hipEventDisableTiming), "hipEventCreate");
+    if (timeline) check(hipEventRecord(cstart[chunks], cstream), "hipEventRecord");
+    if (ok && has_in && !job.direct && !in_ring.alloc((size_t)F * R * in_slot_rows * job.d_in_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (input ring)");
+    if (ok && has_out && !job.direct && !out_ring.alloc((size_t)D * R * out_slot_rows * job.d_out_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (output ring)");
 
     auto chunk_units_of = [&](int k) { return cbegin[k + 1] - cbegin[k]; };
 
@@ -262,20 +279,46 @@ inline Result run(const Job &job)
         VGA_PIPE_TRY(hipSetDevice(job.device));
         char *ring = static_cast<char *>(in_ring.p) + (size_t)t * R * in_slot_rows * job.d_in_pitch;
         int64_t used = 0;                                  // slots handed to the DMA engine so far
-        double t_copy = 0, t_wait = 0, t_issue = 0;
+        std::vector<void *> registered;                    // direct mode: rows this thread page-locked for the call
+        struct Unregister {
+            std::vector<void *> &v; hipStream_t s;
+            ~Unregister() { if (!v.empty()) { (void)hipStreamSynchronize(s); for (void *p : v) (void)hipHostUnregister(p); } }
+        } unregister{registered, fstream[t]};
+        double t_copy = 0, t_wait = 0, t_issue = 0, t_boundary = 0, t_final = 0;
         const double t_start = now();
         struct Report {
-            Shared &sh; double &c, &w, &i; const double &t0;
+            Shared &sh; double &c, &w, &i, &b, &f; const double &t0;
             ~Report() { std::lock_guard<std::mutex> g(sh.m); sh.st.feed_copy += c; sh.st.feed_wait_slot += w; sh.st.feed_issue += i;
+                        sh.st.feed_boundary += b; sh.st.feed_final += f;
                         sh.st.feed_max = std::max(sh.st.feed_max, now() - t0); }
-        } report{sh, t_copy, t_wait, t_issue, t_start};
+        } report{sh, t_copy, t_wait, t_issue, t_boundary, t_final, t_start};
         for (int k = 0; k < chunks && !sh.err.load(); k++) {
             const int row0 = cbegin[k] * job.in_rows_per_unit;
             const int row1 = cbegin[k + 1] * job.in_rows_per_unit;
-            int lo, hi;
-            split(row0, row1, F, t, lo, hi);
-            for (int r = lo; r < hi && !sh.err.load(); r += in_slot_rows) {
-                const int n = std::min(in_slot_rows, hi - r);
+            // row groups are handed out on demand: a feeder that runs on a core far from the caller's pages (or shares
+            // its core) simply takes fewer of them -- with a fixed split the slowest thread set the upload time
+            for (;;) {
+                if (sh.err.load()) break;
+                const int r = row0 + next_in[k].fetch_add(in_slot_rows);
+                if (r >= row1) break;
+                const int n = std::min(in_slot_rows, row1 - r);
+                if (job.direct) {
+                    const double ta = now();
+                    for (int i = 0; i < n; i++) {
+                        // registered rows go through the DMA engines asynchronously (and next to running kernels); a row
+                        // that cannot be registered (already registered by the caller, shares a page with its neighbour,
+                        // ...) is copied by the runtime's pageable path, which is correct but blocks this thread
+                        void *row = const_cast<void *>(job.in_rows[r + i]);
+                        if (job.register_rows && hipHostRegister(row, job.in_row_bytes, hipHostRegisterDefault) == hipSuccess)
+                            registered.push_back(row);
+                        else
+                            (void)hipGetLastError();
+                        VGA_PIPE_TRY(hipMemcpyAsync(job.d_in + (size_t)(r + i) * job.d_in_pitch, row, job.in_row_bytes,
+                                                    hipMemcpyHostToDevice, fstream[t]));
+                    }
+                    t_issue += now() - ta;
+                    continue;
+                }
                 const int s = (int)(used % R);
                 double ta = now();
                 if (used >= R) VGA_PIPE_TRY(hipEventSynchronize(fslot[t * R + s]));      // the slot's previous upload is done
@@ -291,14 +334,18 @@ inline Result run(const Job &job)
                 t_issue += now() - ta;
                 used++;
             }
+            const double tb0 = now();
             VGA_PIPE_TRY(hipEventRecord(upl[t * chunks + k], fstream[t]));
             {
                 std::lock_guard<std::mutex> g(sh.m);
                 sh.uploaded[k]++;
             }
             sh.cv.notify_all();
+            t_boundary += now() - tb0;
         }
+        const double tf0 = now();
         if (!sh.err.load()) VGA_PIPE_TRY(hipStreamSynchronize(fstream[t]));             // nothing in flight reads the ring after this
+        t_final = now() - tf0;
     };
 
     // ---------------------------------------------------------------- drainer u
@@ -308,6 +355,11 @@ inline Result run(const Job &job)
         struct Pending { int row = -1, n = 0; };
         std::vector<Pending> pend(R);
         int64_t used = 0;
+        std::vector<void *> registered;
+        struct Unregister {
+            std::vector<void *> &v; hipStream_t s;
+            ~Unregister() { if (!v.empty()) { (void)hipStreamSynchronize(s); for (void *p : v) (void)hipHostUnregister(p); } }
+        } unregister{registered, dstream[u]};
         double t_wait_comp = 0, t_wait_copy = 0, t_copy = 0;
         const double t_start = now();
         struct Report {
@@ -348,10 +400,25 @@ inline Result run(const Job &job)
             }
             const int row0 = cbegin[k] * job.out_rows_per_unit;
             const int row1 = cbegin[k + 1] * job.out_rows_per_unit;
-            int lo, hi;
-            split(row0, row1, D, u, lo, hi);
-            for (int r = lo; r < hi && !sh.err.load(); r += out_slot_rows) {
-                const int n = std::min(out_slot_rows, hi - r);
+            for (;;) {
+                if (sh.err.load()) break;
+                const int r = row0 + next_out[k].fetch_add(out_slot_rows);
+                if (r >= row1) break;
+                const int n = std::min(out_slot_rows, row1 - r);
+                if (job.direct) {
+                    const double ta = now();
+                    for (int i = 0; i < n; i++) {
+                        void *row = job.out_rows[r + i];
+                        if (job.register_rows && hipHostRegister(row, job.out_row_bytes, hipHostRegisterDefault) == hipSuccess)
+                            registered.push_back(row);
+                        else
+                            (void)hipGetLastError();
+                        VGA_PIPE_TRY(hipMemcpyAsync(row, job.d_out + (size_t)(r + i) * job.d_out_pitch, job.out_row_bytes,
+                                                    hipMemcpyDeviceToHost, dstream[u]));
+                    }
+                    t_copy += now() - ta;
+                    continue;
+                }
                 const int s = (int)(used % R);
                 if (!flush(s)) return;
                 char *slot = ring + (size_t)s * out_slot_rows * job.d_out_pitch;
@@ -366,6 +433,11 @@ inline Result run(const Job &job)
         if (!sh.err.load())
             for (int s = 0; s < R; s++)
                 if (!flush((int)((used + s) % R))) return;  // oldest first
+        if (!sh.err.load() && job.direct) {
+            const double ta = now();
+            VGA_PIPE_TRY(hipStreamSynchronize(dstream[u]));   // the caller's rows are complete when run() returns
+            t_wait_copy += now() - ta;
+        }
     };
 
     std::vector<std::thread> threads;
@@ -390,6 +462,7 @@ inline Result run(const Job &job)
                 double tb = now();
                 t_wait += tb - ta;
                 for (int t = 0; t < F; t++) VGA_PIPE_TRY(hipStreamWaitEvent(cstream, upl[t * chunks + k], 0));
+                if (timeline) VGA_PIPE_TRY(hipEventRecord(cstart[k], cstream));
                 std::string why;
                 const int rc = job.compute(cbegin[k], chunk_units_of(k), cstream, why);
                 if (rc) {
@@ -421,8 +494,17 @@ inline Result run(const Job &job)
     if (cstream) (void)hipStreamSynchronize(cstream);
     for (auto s : fstream) if (s) (void)hipStreamSynchronize(s);
     for (auto s : dstream) if (s) (void)hipStreamSynchronize(s);
-    for (auto *v : {&fslot, &dslot, &upl, &comp})
+    if (timeline && ok && !sh.err.load()) {
+        auto at = [&](hipEvent_t e) { float ms = -1; (void)hipEventElapsedTime(&ms, cstart[chunks], e); return ms; };
+        for (int k = 0; k < chunks; k++) {
+            std::fprintf(stderr, "timeline chunk %d: uploaded", k);
+            for (int t = 0; t < F; t++) std::fprintf(stderr, " %.1f", at(upl[t * chunks + k]));
+            std::fprintf(stderr, "  compute %.1f .. %.1f ms\n", at(cstart[k]), at(comp[k]));
+        }
+    }
+    for (auto *v : {&fslot, &dslot, &upl, &comp, &cstart})
         for (auto e : *v) if (e) (void)hipEventDestroy(e);
+    if (shared_streams) { fstream.resize(F > 0 ? 1 : 0); dstream.resize(D > 0 ? 1 : 0); }
     for (auto s : fstream) if (s) (void)hipStreamDestroy(s);
     for (auto s : dstream) if (s) (void)hipStreamDestroy(s);
     if (cstream) (void)hipStreamDestroy(cstream);
