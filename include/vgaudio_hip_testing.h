@@ -37,7 +37,7 @@ void vga_testing_host_pipeline_this_thread(int feeders, int drainers, int chunk_
  * [8] caller's final stream sync [9] drainers waiting for compute [10] drainers waiting for downloads [11] drainers'
  * memcpy [12] slowest drainer [13] feeders [14] drainers [15] chunks [16] units per chunk [17] device allocation
  * before the pipeline [18] the whole entry point up to its return value [19] feeders at chunk boundaries [20] feeders' final
- * stream synchronisation.  Returns the number of fields. */
+ * stream synchronisation [21] drainers page-locking the output rows.  Returns the number of fields. */
 int vga_testing_last_pipeline_stats(double *out, int n);
 
 #ifdef __cplusplus

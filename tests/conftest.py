@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# read by the HIP runtime when it initialises (see vgaudio_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

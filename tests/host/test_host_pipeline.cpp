@@ -9,7 +9,8 @@
 using namespace vga::pipe;
 
 static int g_taper = 0;
-static bool g_direct = false, g_shared = false;
+static bool g_direct = false, g_direct_out = false, g_shared = false;
+static int g_lanes = 1;
 static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t out_bytes, int chunk, int feeders, int drainers,
                     size_t slot_bytes, int delay_us, int fail_after, bool compute_fails)
 {
@@ -42,7 +43,9 @@ static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t 
     job.slot_bytes = slot_bytes;
     job.taper_min_units = g_taper;
     job.direct = g_direct;
+    job.direct_out = g_direct_out;
     job.shared_streams = g_shared;
+    job.compute_lanes = g_lanes;
     if (in_rows == 0) job.in_rows = nullptr;                 // a job with nothing to upload / nothing to download
     if (out_rows == 0) job.out_rows = nullptr;
     int launches = 0;
@@ -95,9 +98,13 @@ static int all_cases();
 int main()
 {
     int bad = 0;
-    for (int mode = 0; mode < 4; mode++) {
-        g_direct = mode & 1;
-        g_shared = mode & 2;
+    // direct uploads, direct downloads, shared copy streams, compute lanes
+    const int modes[][4] = {{0, 0, 0, 1}, {1, 1, 0, 1}, {0, 0, 1, 1}, {1, 1, 1, 3}, {1, 0, 1, 2}, {0, 1, 0, 3}};
+    for (const auto &m : modes) {
+        g_direct = m[0];
+        g_direct_out = m[1];
+        g_shared = m[2];
+        g_lanes = m[3];
         bad += all_cases();
     }
     PinnedPool::get().trim();

@@ -168,7 +168,7 @@ def test_time_segment_fallbacks_are_exact():
         torch.cuda.synchronize()
         return dec[:, :n].clone(), adx[:, :nb].clone(), back[:, :n].clone(), enc[:, :vdev.gc_byte_count(n)].clone()
 
-    # the GC encoder only cuts pieces of 12 288 frames or more on its own: ask for 12 pieces of this shorter stream
+    # 12 pieces (ADX encode included)
     L.vga_testing_gc_encoder_segments_this_thread(12)
     try:
         normal = run()

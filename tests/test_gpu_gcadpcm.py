@@ -416,3 +416,33 @@ def test_encoder_layouts_and_piece_counts_give_the_same_bytes():
     finally:
         L.vga_testing_gc_encoder_layout_this_thread(8)
         L.vga_testing_gc_encoder_segments_this_thread(0)
+
+
+@pytest.mark.parametrize("n", [14 * 40000, 14 * 40000 + 9])
+def test_short_pieces_leave_seams_open_and_the_chain_closes_them(n):
+    """Pieces of ~130 frames: a few percent of the seams are still open when their piece ends (often several in a row in
+    one channel), so the chain launch -- and, with a partial last frame, the last-piece repair -- produce part of the
+    output.  It is the oracle's, byte for byte."""
+    import torch
+    from vgaudio_amd import _lib, device as vdev
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    nch = 45
+    pcm = vdev.synth_pcm(nch, n, d)
+    coefs = vdev.gc_coefs(pcm, n)
+    host = pcm[:, :n].cpu().numpy()
+    wc, wa = po.gc_encode_batch(host, threads=4)
+    nb = vdev.gc_byte_count(n)
+    try:
+        for segments in (64, 300, 625):
+            L.vga_testing_gc_encoder_segments_this_thread(segments)
+            for mode in (0, 2):                              # 2: some seams are never accepted as closed
+                old = L.vga_testing_force_open_seams_this_thread(mode)
+                try:
+                    out = vdev.gc_encode(pcm, n, coefs)
+                    torch.cuda.synchronize()
+                finally:
+                    L.vga_testing_force_open_seams_this_thread(old)
+                assert np.array_equal(out[:, :nb].cpu().numpy(), np.asarray(wa)[:, :nb]), (segments, mode)
+    finally:
+        L.vga_testing_gc_encoder_segments_this_thread(0)

@@ -138,5 +138,37 @@ int main()
         }
         CHECK(hipStreamSynchronize(sc)); tc = now() - a;
         CHECK(hipStreamSynchronize(sk)); tkk = now() - a; });
+    // downloads next to uploads and kernels: when are the downloads done?  (2 GiB in 8 MB pieces, no dependencies)
+    int lo = 0, hi = 0;
+    CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));            // lo = least, hi = greatest priority (numerically lower)
+    hipStream_t sd_hi, sk_lo;
+    CHECK(hipStreamCreateWithPriority(&sd_hi, hipStreamNonBlocking, hi));
+    CHECK(hipStreamCreateWithPriority(&sk_lo, hipStreamNonBlocking, lo));
+    const size_t dpiece = (size_t)8 << 20;
+    const int dpieces = (int)(total / 4 / dpiece);
+    auto d2h_case = [&](const char *name, bool with_h2d, hipStream_t ks, hipStream_t ds) {
+        double best = 1e9, best_d = 0, best_c = 0;
+        for (int rep = 0; rep < 3; rep++) {
+            sync_all();
+            const double a = now();
+            if (with_h2d)
+                for (int i = 0; i < pieces; i++) CHECK(hipMemcpyAsync(d + i * piece, h + i * piece, piece, hipMemcpyHostToDevice, sc));
+            kernels(ks, groups);
+            for (int i = 0; i < dpieces; i++) CHECK(hipMemcpyAsync(hout + i * dpiece, d2 + i * dpiece, dpiece, hipMemcpyDeviceToHost, ds));
+            CHECK(hipStreamSynchronize(ds));
+            const double td = now() - a;
+            CHECK(hipStreamSynchronize(sc));
+            const double tc = now() - a;
+            sync_all();
+            const double t = now() - a;
+            if (t < best) { best = t; best_d = td; best_c = tc; }
+        }
+        std::printf("{\"case\": \"%s\", \"total_ms\": %.1f, \"downloads_done_ms\": %.1f, \"uploads_done_ms\": %.1f}\n", name, best * 1e3, best_d * 1e3, best_c * 1e3);
+        std::fflush(stdout);
+    };
+    d2h_case("d2h_with_kernels", false, sk, sd);
+    d2h_case("d2h_with_kernels_and_h2d", true, sk, sd);
+    d2h_case("d2h_high_priority_stream_with_kernels_and_h2d", true, sk, sd_hi);
+    d2h_case("d2h_with_low_priority_kernels_and_h2d", true, sk_lo, sd);
     return 0;
 }

@@ -39,7 +39,7 @@ def main():
     names = ["total", "setup", "feeders_memcpy_sum", "feeders_wait_slot_sum", "feeders_issue_sum", "slowest_feeder", "caller_wait_upload",
              "caller_launch", "caller_tail_sync", "drainers_wait_compute_sum", "drainers_wait_download_sum", "drainers_memcpy_sum",
              "slowest_drainer", "feeders", "drainers", "chunks", "units_per_chunk", "device_alloc", "entry_point",
-             "feeders_chunk_boundary_sum", "feeders_final_sync_sum"]
+             "feeders_chunk_boundary_sum", "feeders_final_sync_sum", "drainers_register_sum"]
     ref = None
     for shape in args.shapes.split(";"):
         f, d, ch, sl = (int(v) for v in shape.split(","))

@@ -28,6 +28,26 @@ static thread_local int g_encoder_layout = 8;
 int encoder_layout() { return g_encoder_layout; }
 static thread_local int g_encoder_segments = 0;
 int encoder_segments_override() { return g_encoder_segments; }
+
+// The host pipeline runs an upload stream, a download stream and two lanes of kernels next to whatever streams the host
+// has; the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless told otherwise), and a copy
+// stream that shares a queue with a kernel stream waits behind that stream's kernels (measured: every download of a
+// 4096-channel encode ended only when the last kernel had, 660 ms instead of 533 ms).  The variable is read when the
+// runtime initialises, so it is set when this library is loaded -- only if the host has not set it; a host that
+// initialises HIP before loading the library sets it itself.
+__attribute__((constructor)) static void ask_for_hardware_queues()
+{
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+}
+
+int hardware_queues_requested()
+{
+    static const int n = [] {
+        const char *e = std::getenv("GPU_MAX_HW_QUEUES");
+        return e ? std::atoi(e) : 4;
+    }();
+    return n;
+}
 static thread_local PipeOverride g_pipe_override;
 PipeOverride &pipe_override() { return g_pipe_override; }
 static thread_local PipeReport g_pipe_report;
@@ -88,7 +108,7 @@ int vga_testing_last_pipeline_stats(double *out, int n)
     const double v[] = {r.stats.total, r.stats.setup, r.stats.feed_copy, r.stats.feed_wait_slot, r.stats.feed_issue, r.stats.feed_max,
                         r.stats.main_wait_upload, r.stats.main_launch, r.stats.main_tail_sync, r.stats.drain_wait_compute,
                         r.stats.drain_wait_copy, r.stats.drain_copy, r.stats.drain_max, (double)r.stats.feeders, (double)r.stats.drainers,
-                        (double)r.stats.chunks, (double)r.stats.chunk_units, r.t_alloc, r.t_entry, r.stats.feed_boundary, r.stats.feed_final};
+                        (double)r.stats.chunks, (double)r.stats.chunk_units, r.t_alloc, r.t_entry, r.stats.feed_boundary, r.stats.feed_final, r.stats.drain_register};
     const int m = (int)(sizeof v / sizeof v[0]);
     for (int i = 0; i < n && i < m; i++) out[i] = v[i];
     return m;
@@ -562,9 +582,14 @@ int vga_gcadpcm_encode_batch(const int16_t *const *pcm, int nch, int sample_coun
     const int nbytes = vga_gcadpcm_sample_count_to_byte_count(sample_count);
     b.adpcm_pitch = round_up(nbytes > 0 ? nbytes : 1, 16);
     VGA_HIP_TRY(b.adpcm.alloc((size_t)nch * b.adpcm_pitch));
-    DevBuf scratch;                                       // the encoder's piece states: one chunk at a time uses it
+    // two compute lanes: a chunk's kernels need not wait for the chunk before (the short chunks at the end of the upload
+    // are bound by the latency of one channel's coefficient search, ~25 ms, not by the chip); each lane has its own
+    // piece states and workspace
+    constexpr int LANES = 2;
+    DevBuf scratch[LANES], ws[LANES];
     pipe::Job job;
     job.units = nch;
+    job.compute_lanes = hardware_queues_requested() >= 6 ? LANES : 1;   // a lane more than the queues hold would stall the copies
     if (sample_count > 0) {
         job.in_rows = (const void *const *)pcm;
         job.in_row_bytes = (size_t)sample_count * sizeof(int16_t);
@@ -578,19 +603,24 @@ int vga_gcadpcm_encode_batch(const int16_t *const *pcm, int nch, int sample_coun
     // EncodeChannel (GcAdpcmFormat.cs:129-135): coefficients, then encode -- per chunk of channels, so that the next
     // chunk's upload and the previous chunk's download overlap these kernels
     job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
+        const int lane = pipe::compute_lane();
         int rc = gc::launch_coefs(b.pcm.as<int16_t>() + (int64_t)first * b.pcm_pitch, b.pcm_pitch, count, sample_count,
-                                  b.coefs.as<int16_t>() + (int64_t)first * 16, b.ws.p, s);
+                                  b.coefs.as<int16_t>() + (int64_t)first * 16, ws[lane].p, s);
         if (!rc)
             rc = gc::launch_encode(b.pcm.as<int16_t>() + (int64_t)first * b.pcm_pitch, b.pcm_pitch, count, sample_count,
                                    b.coefs.as<int16_t>() + (int64_t)first * 16,
                                    b.h1.p ? b.h1.as<int16_t>() + first : nullptr, b.h2.p ? b.h2.as<int16_t>() + first : nullptr,
-                                   b.adpcm.as<uint8_t>() + (int64_t)first * b.adpcm_pitch, b.adpcm_pitch, s, scratch.p, scratch.bytes);
+                                   b.adpcm.as<uint8_t>() + (int64_t)first * b.adpcm_pitch, b.adpcm_pitch, s, scratch[lane].p,
+                                   scratch[lane].bytes);
         if (rc) why = vga_last_error();
         return rc;
     };
-    VGA_HIP_TRY(scratch.alloc(gc::encode_scratch_bytes(planned_chunk_units(job, GC_CHUNK_CHANNELS))));
-    // one chunk's workspace: the chunks' kernels run one after the other on the compute stream
-    VGA_HIP_TRY(b.ws.alloc(vga_gcadpcm_coefs_workspace_bytes(planned_chunk_units(job, GC_CHUNK_CHANNELS), sample_count)));
+    const int chunk = planned_chunk_units(job, GC_CHUNK_CHANNELS);
+    const int lanes_used = chunk < nch ? job.compute_lanes : 1;       // one chunk: one lane
+    for (int l = 0; l < lanes_used; l++) {
+        VGA_HIP_TRY(scratch[l].alloc(gc::encode_scratch_bytes(chunk)));
+        VGA_HIP_TRY(ws[l].alloc(vga_gcadpcm_coefs_workspace_bytes(chunk, sample_count)));
+    }
     pipe_report().t_alloc = pipe::detail::now() - t_entry;
     if (int rc = run_batch_pipeline(job, GC_CHUNK_CHANNELS)) return rc;
     VGA_HIP_TRY(hipMemcpy(coefs_out, b.coefs.p, (size_t)nch * 32, hipMemcpyDeviceToHost));

@@ -587,38 +587,21 @@ __device__ __forceinline__ void store_frame_bytes(uint8_t *dst, uint32_t d0, uin
     for (int b = 0; b < nbytes; b++) dst[b] = (uint8_t)(bits >> (8 * b));
 }
 
-// Eight lanes per (channel, seam) -- one per predictor, as DspEncodeFrame's loop (:58-77) -- all seams at once.  From the
-// history the piece before ended on (seg_state: the real one provided THAT piece's own seam closes) encode again frame
-// by frame, next to a replay of the guessed run's reconstruction (decoding that run's frames from the guess, before
-// they are overwritten), until both histories coincide at a frame end: from there on the guessed run wrote what the
-// serial encoder writes.  A seam still open after max_frames records its index in first_open[channel] for the repair
-// launch of gc_encode_kernel.
-__global__ __launch_bounds__(64) void gc_encode_seam_kernel(
-    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, int seg_frames,
-    const int16_t *__restrict__ coefs, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch,
-    const int16_t *__restrict__ seg_state, int *__restrict__ first_open, int max_frames, int force_open)
+// Eight lanes per (channel, seam) -- one per predictor, as DspEncodeFrame's loop (:58-77).  seam_run: from the TRUE history
+// (h0, h1) at the start of piece k encode again frame by frame, next to a replay of the reconstruction of the run whose
+// bytes the piece holds (decoding its frames from ITS start history (g2, g1), before they are overwritten), until both
+// histories coincide at a frame end: from there on the piece holds what the serial encoder writes.  Returns with
+// open == true when the piece ended first; (h0, h1) is then the true history at the piece's end.
+__device__ __forceinline__ void seam_run(const int16_t *__restrict__ src, uint8_t *__restrict__ dst, int c0, int c1, bool coef_ok,
+                                         int pr, int ch, int k, int total_samples, int seg_frames, int max_frames, int force_open,
+                                         int &h0, int &h1, int g2, int g1, bool &open)
 {
-    const int lane = threadIdx.x;
-    const int pr = lane & 7;                            // this lane's predictor
-    const int ch_raw = blockIdx.x * 8 + (lane >> 3);
-    const int k = blockIdx.y + 1;
     const int64_t f0 = (int64_t)k * seg_frames;
-    const bool valid = ch_raw < nch && f0 * 14 < total_samples;
-    const int ch = ch_raw < nch ? ch_raw : nch - 1;
-    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
-    uint8_t *dst = adpcm + (int64_t)ch * adpcm_pitch;
-    const int16_t *cf = coefs + ch * 16;
-    const int c0 = cf[2 * pr], c1 = cf[2 * pr + 1];
-    const bool coef_ok = (c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1) <= 32767;
     const int full_frames = total_samples / 14;
     // The frame loop is one wave's dependent chain (nothing else runs on its SIMD for long: the slowest seam IS the
     // kernel's run time), so it is the encoder's fast path -- range pre-scan, the two speculative passes of the
     // (channel, predictor) layout, DPP argmin -- with the next frame's PCM and old bytes already in flight; the
     // reference's loop as written (resume_passes) only behind the same `rare` / `resume` conditions as there.
-    int h0 = valid ? seg_state[((int64_t)(k - 1) * nch + ch) * 2] : 0;            // true history (x[0], x[1])
-    int h1 = valid ? seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1] : 0;
-    int g2 = valid ? src[f0 * 14 - 2] : 0, g1 = valid ? src[f0 * 14 - 1] : 0;   // the guessed run's history (g1 = newest)
-    bool open = valid;                                  // uniform inside a group of eight
     const int64_t f_end = imin((int)imin((int)(f0 + seg_frames), (int)(f0 + max_frames)), full_frames);   // frames [f0, f_end)
     const int64_t f_last = full_frames > 0 ? full_frames - 1 : 0;
     auto fetch = [&](int64_t f, uint32_t (&w)[7], uint2 &old) {
@@ -728,13 +711,109 @@ __global__ __launch_bounds__(64) void gc_encode_seam_kernel(
         for (int i = 0; i < 7; i++) w[i] = wn[i];
         old = oldn;
     }
-    // still open (the launcher's max_frames is the piece length: half the seams close within nine frames, one in a
-    // hundred needs more than 400, a few channels never meet): the repair launch encodes this channel serially from this
-    // piece on.  A smaller cap sends too many channels there -- one open seam makes the whole channel serial.
-    if (valid && open && pr == 0) atomicMin(&first_open[ch], k);
 }
 
-constexpr int MIN_PIECE_FRAMES = 12288;
+// All seams at once, each from the history the piece before ended on (seg_state: the real one provided THAT piece's own
+// seam closes).  A seam still open at the end of its piece leaves a flag and the true history it arrived at
+// (seam_flag / seam_end) and its index in first_open[channel]: gc_encode_chain_kernel carries on from there.
+__global__ __launch_bounds__(64) void gc_encode_seam_kernel(
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, int seg_frames,
+    const int16_t *__restrict__ coefs, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch,
+    const int16_t *__restrict__ seg_state, int *__restrict__ first_open, int *__restrict__ seam_flag,
+    int *__restrict__ seam_end, int max_frames, int force_open)
+{
+    const int lane = threadIdx.x;
+    const int pr = lane & 7;                            // this lane's predictor
+    const int ch_raw = blockIdx.x * 8 + (lane >> 3);
+    const int k = blockIdx.y + 1;
+    const int64_t f0 = (int64_t)k * seg_frames;
+    const bool valid = ch_raw < nch && f0 * 14 < total_samples;
+    const int ch = ch_raw < nch ? ch_raw : nch - 1;
+    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
+    uint8_t *dst = adpcm + (int64_t)ch * adpcm_pitch;
+    const int16_t *cf = coefs + ch * 16;
+    const int c0 = cf[2 * pr], c1 = cf[2 * pr + 1];
+    const bool coef_ok = (c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1) <= 32767;
+    int h0 = valid ? seg_state[((int64_t)(k - 1) * nch + ch) * 2] : 0;            // true history (x[0], x[1])
+    int h1 = valid ? seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1] : 0;
+    const int g2 = valid ? src[f0 * 14 - 2] : 0, g1 = valid ? src[f0 * 14 - 1] : 0;   // the guessed run's history (g1 = newest)
+    bool open = valid;                                  // uniform inside a group of eight
+    seam_run(src, dst, c0, c1, coef_ok, pr, ch, k, total_samples, seg_frames, max_frames, force_open, h0, h1, g2, g1, open);
+    // still open at the piece's end (half the seams close within nine frames, one in a hundred needs more than 400, a
+    // few channels never meet)
+    if (valid && pr == 0) {
+        seam_flag[(int64_t)(k - 1) * nch + ch] = open ? 1 : 0;
+        if (open) {
+            seam_end[(int64_t)(k - 1) * nch + ch] = (int)(((unsigned)h1 << 16) | ((unsigned)h0 & 0xFFFFu));
+            atomicMin(&first_open[ch], k);
+        }
+    }
+}
+
+// The channels with an open seam, piece after piece: where the true history V at the start of piece k is not the one the
+// seam launch assumed there (T = seg_state[k - 1]), the piece's bytes are the run from T, so the same seam_run from V next
+// to a replay from T finds where the two meet -- as a rule a few frames in, and the chain ends unless a later seam of the
+// channel was left open too (then V is that seam's recorded end).  Only a run that is still apart at the very end of a
+// stream with a partial last frame goes to the serial repair launch (first_open[channel] = last piece; seg_state gets
+// that piece's true start), which also remains the fall-back when the scratch cannot hold the flags.
+__global__ __launch_bounds__(64) void gc_encode_chain_kernel(
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, int seg_frames, int segments,
+    const int16_t *__restrict__ coefs, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch,
+    int16_t *__restrict__ seg_state, int *__restrict__ first_open, const int *__restrict__ seam_flag,
+    const int *__restrict__ seam_end, int force_open)
+{
+    const int lane = threadIdx.x;
+    const int pr = lane & 7;
+    const int ch_raw = blockIdx.x * 8 + (lane >> 3);
+    const bool live = ch_raw < nch;
+    const int ch = live ? ch_raw : nch - 1;
+    const int mine = live ? first_open[ch] : 0x7f7f7f7f;
+    int kmin = mine;
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) kmin = imin(kmin, __shfl_xor(kmin, o));
+    if (kmin >= segments) return;                       // no open seam among these eight channels
+    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
+    uint8_t *dst = adpcm + (int64_t)ch * adpcm_pitch;
+    const int16_t *cf = coefs + ch * 16;
+    const int c0 = cf[2 * pr], c1 = cf[2 * pr + 1];
+    const bool coef_ok = (c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1) <= 32767;
+    bool have = false;                                  // V differs from what the seam launch assumed at this piece
+    int v0 = 0, v1 = 0;                                 // V (x[0], x[1])
+    int last_k = 0;
+    for (int k = kmin; k < segments; k++) {
+        const int64_t f0 = (int64_t)k * seg_frames;
+        if (f0 * 14 >= total_samples) break;            // uniform: pieces past the end do not exist
+        last_k = k;
+        const bool is_last = (int64_t)(k + 1) * seg_frames * 14 >= total_samples || k == segments - 1;
+        const int64_t idx = (int64_t)(k - 1) * nch + ch;
+        const bool flagged = live && seam_flag[idx] != 0;
+        const int ended = seam_end[idx];
+        const bool ran = live && have;
+        bool open = ran;
+        int h0 = v0, h1 = v1;
+        if (__any(ran)) {
+            const int g2 = seg_state[idx * 2], g1 = seg_state[idx * 2 + 1];      // T: what the piece's bytes were encoded from
+            if (ran && pr == 0 && is_last) {                                     // the repair launch would start here
+                seg_state[idx * 2] = (int16_t)v0;
+                seg_state[idx * 2 + 1] = (int16_t)v1;
+            }
+            seam_run(src, dst, c0, c1, coef_ok, pr, ch, k, total_samples, seg_frames, seg_frames, force_open, h0, h1, g2, g1, open);
+        }
+        if (ran && open) {                              // still apart at the piece's end: carry on into the next one
+            v0 = h0;
+            v1 = h1;
+        } else if (flagged) {                           // met the run from T, whose own seam ran out of frames: its end is the truth
+            have = true;
+            v0 = (int)(int16_t)(ended & 0xFFFF);
+            v1 = ended >> 16;
+        } else
+            have = false;
+    }
+    // apart to the very end: only a partial last frame is left to encode from V
+    if (live && pr == 0) first_open[ch] = (have && total_samples % 14 != 0) ? last_k : 0x7f7f7f7f;
+}
+
+constexpr int MIN_PIECE_FRAMES = 512;
 
 template <int CPW>
 static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
@@ -743,11 +822,8 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
 {
     constexpr int CS = Lay<CPW>::CS;
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
-    // one encoder wave per SIMD fills the chip: fewer channels than that are cut into time pieces.  A seam re-encodes a
-    // few dozen frames as a rule, but the tail is long -- with 6 400-frame pieces a 512-channel launch (16 000 seams) had
-    // seams still open at the end of their piece, and one such channel is then encoded serially from there on (300 ms
-    // on a 75 s stream, tools/sweep_host_pipeline.py's timeline); no seam of three 1024-channel launches stayed open
-    // over 12 800 frames, so that is the shortest piece the launcher cuts when it has the choice.
+    // one encoder wave per SIMD fills the chip: fewer channels than that are cut into time pieces (each at least 512
+    // frames: a seam re-encodes a few dozen as a rule; the ones that take longer than their piece go to the chain launch)
     const int groups = (nch + CS - 1) / CS;
     const int cus = device_cu_count();
     const int frames = (sample_count + 13) / 14;
@@ -759,18 +835,21 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
     const int seg_frames = (frames + segments - 1) / segments;
     AsyncBuf scratch;                                  // freed (stream-ordered) on every exit path
     int16_t *seg_state = nullptr;
-    int *first_open = nullptr;
+    int *first_open = nullptr, *seam_flag = nullptr, *seam_end = nullptr;
     if (segments > 1) {
         const size_t state_bytes = (size_t)round_up((int64_t)segments * nch * 2 * (int64_t)sizeof(int16_t), 16);
+        const size_t need = 3 * state_bytes + (size_t)nch * sizeof(int);
         // the caller's scratch when it brought one (the host pipeline: hipMallocAsync next to busy copy streams stalled
         // its launching thread for up to 300 ms per call), a stream-ordered allocation otherwise
         unsigned char *base = static_cast<unsigned char *>(d_scratch);
-        if (!base || scratch_bytes < state_bytes + (size_t)nch * sizeof(int)) {
-            VGA_HIP_TRY(scratch.alloc(state_bytes + (size_t)nch * sizeof(int), stream));
+        if (!base || scratch_bytes < need) {
+            VGA_HIP_TRY(scratch.alloc(need, stream));
             base = scratch.as<unsigned char>();
         }
         seg_state = reinterpret_cast<int16_t *>(base);
-        first_open = reinterpret_cast<int *>(base + state_bytes);
+        seam_flag = reinterpret_cast<int *>(base + state_bytes);
+        seam_end = reinterpret_cast<int *>(base + 2 * state_bytes);
+        first_open = reinterpret_cast<int *>(base + 3 * state_bytes);
         VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
     }
     hipLaunchKernelGGL((gc_encode_kernel<false, CPW>), dim3(groups, segments), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch,
@@ -779,10 +858,16 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
     VGA_HIP_TRY(hipGetLastError());
     if (segments > 1) {
         hipLaunchKernelGGL(gc_encode_seam_kernel, dim3((nch + 7) / 8, segments - 1), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
-                           sample_count, seg_frames, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seg_frames,
+                           sample_count, seg_frames, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
+                           seg_frames, force_open_seams());
+        VGA_HIP_TRY(hipGetLastError());
+        // the seams that were still open at the end of their piece, chained piece after piece (none: every wave returns)
+        hipLaunchKernelGGL(gc_encode_chain_kernel, dim3((nch + 7) / 8), dim3(64), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
+                           seg_frames, segments, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
                            force_open_seams());
         VGA_HIP_TRY(hipGetLastError());
-        // repair: the same encoder, serially, for the channels whose seams stayed open (none: every workgroup returns)
+        // repair: the same encoder, serially over the last piece, for a channel the chain could not finish (a partial
+        // last frame after a run that never met; none: every workgroup returns)
         hipLaunchKernelGGL((gc_encode_kernel<true, CPW>), dim3(groups, 1), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
                            seg_frames, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state, (const int *)first_open);
         VGA_HIP_TRY(hipGetLastError());
@@ -790,8 +875,8 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
     return VGA_OK;
 }
 
-// upper bound of what launch_encode wants as scratch for nch channels (1024 pieces x 4 B + 4 B per channel, + alignment)
-size_t encode_scratch_bytes(int nch) { return (size_t)(nch > 0 ? nch : 0) * (1024 * 4 + 4) + 64; }
+// upper bound of what launch_encode wants as scratch for nch channels (1024 pieces x (state, flag, end) + 4 B per channel, + alignment)
+size_t encode_scratch_bytes(int nch) { return (size_t)(nch > 0 ? nch : 0) * (1024 * 12 + 4) + 64; }
 
 int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
                   const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,

@@ -13,6 +13,7 @@ PipeOverride &pipe_override();                       // capi_gcadpcm.hip
 // the calling thread's last pipeline run, plus what the entry point spent around it (device allocation, small copies)
 struct PipeReport { pipe::Stats stats; double t_alloc = 0, t_entry = 0; };
 PipeReport &pipe_report();                           // capi_gcadpcm.hip
+int hardware_queues_requested();                     // capi_gcadpcm.hip: GPU_MAX_HW_QUEUES as this process will see it (4 when unset)
 
 // Units per chunk run_batch_pipeline() will use for this job (callers size per-chunk scratch with it).
 inline int planned_chunk_units(const pipe::Job &job, int default_chunk_units)
@@ -42,16 +43,21 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     // profiles/r02_*): page-locking the caller's rows for the call (hipHostRegister) lets ONE stream of direct copies
     // run at the link's rate (~56 GB/s) on the DMA engines next to the kernels; copies issued on several streams at once
     // were held back until the kernels ended, and a ring filled by memcpy threads was no faster than its four threads.
-    // So: one feeder and one drainer, direct copies, all uploads on one stream and all downloads on another (a slot = the
-    // rows a worker takes at a time); the staged mode stays selectable.
-    (void)in_total; (void)out_total;
+    // Downloads are rows of a megabyte or two; issued one by one next to two lanes of kernels they were left waiting
+    // until the kernels ended (118 ms after the last kernel), so they go through the page-locked ring in 32 MB copies and
+    // two drainer threads hand the rows out.  So: one feeder with direct uploads, two drainers behind a ring, all
+    // uploads on one stream and all downloads on another (a slot = the rows a worker takes at a time); slot_bytes < 0
+    // (testing hook) makes both directions direct, > 0 both staged.
+    (void)in_total;
     job.feeders = o.feeders > 0 ? o.feeders : 1;
-    job.drainers = o.drainers > 0 ? o.drainers : 1;
-    job.direct = o.slot_bytes <= 0;
+    job.drainers = o.drainers > 0 ? o.drainers : (out_total >= ((size_t)256 << 20) ? 2 : 1);
+    // rows worth page-locking one by one: from 256 KB on (smaller rows are cheap to copy into the ring)
+    job.direct = o.slot_bytes < 0 || (o.slot_bytes == 0 && job.in_row_bytes >= ((size_t)256 << 10));
+    job.direct_out = o.slot_bytes < 0;
     job.shared_streams = true;
     job.slot_bytes = o.slot_bytes > 0 ? (size_t)o.slot_bytes : (o.slot_bytes < -1 ? (size_t)(-o.slot_bytes) : (size_t)32 << 20);
     job.chunk_units = planned_chunk_units(job, default_chunk_units);
-    job.taper_min_units = std::max(1, job.chunk_units / 2);       // ..., chunk, chunk/2, chunk/2: what runs after the last upload is short
+    job.taper_min_units = std::max(1, job.chunk_units / 8);       // ..., chunk, chunk/2, chunk/4, chunk/8, chunk/8: what runs after the last upload is short
     const pipe::Result r = pipe::run(job);
     pipe_report().stats = r.stats;
     if (r.code) {

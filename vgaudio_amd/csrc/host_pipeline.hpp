@@ -109,6 +109,9 @@ struct PinnedBlock {
 // ---------------------------------------------------------------- the job
 // A "unit" is what the reference hands to one task: a channel (GC-ADPCM, ADX) or a stream (HCA).  Unit u owns the
 // input rows [u * in_rows_per_unit, (u + 1) * in_rows_per_unit) and the output rows [u * out_rows_per_unit, ...).
+// the compute lane of the chunk whose callback is running on this thread (0 when compute_lanes == 1)
+inline int &compute_lane() { static thread_local int lane = 0; return lane; }
+
 struct Job {
     int units = 0;
     int chunk_units = 0;                 // kernels are launched per chunk of this many units
@@ -128,13 +131,18 @@ struct Job {
     size_t d_out_pitch = 0;
     // enqueues the kernels for units [first, first + count) on `stream`; returns 0 or an error code (message via `why`)
     std::function<int(int first, int count, hipStream_t stream, std::string &why)> compute;
+    // compute_lanes > 1: chunk k's kernels go to compute stream k % compute_lanes, so that a chunk need not wait for the one
+    // before it (the short chunks at the end are bound by their kernels' latency, not by the chip).  The callback learns
+    // the lane through compute_lane() and must keep per-lane scratch; chunks of one lane still run in order.
+    int compute_lanes = 1;
     int feeders = 8, drainers = 4;
     size_t slot_bytes = (size_t)8 << 20;   // target size of one ring slot (whole rows; at least one row)
     int ring = 3;                          // slots per feeder / drainer
     // true: no staging -- the workers hand the caller's rows straight to hipMemcpyAsync (the runtime moves pageable
     // memory at ~51 GB/s on an MI355X host, tools/bench_h2d_modes.hip; CPU-side copies into a pinned ring only compete
     // with the DMA engines for the host's memory bandwidth).  false: stage through the page-locked rings.
-    bool direct = true;
+    bool direct = true;                    // uploads
+    bool direct_out = true;                // downloads (false: through the page-locked ring, whatever `direct` says)
     bool register_rows = true;             // direct mode: hipHostRegister each row for the duration of the call
     bool shared_streams = false;           // every feeder issues on one stream, every drainer on another (3 streams in all)
     int device = 0;
@@ -144,6 +152,7 @@ struct Job {
 struct Stats {
     double setup = 0, total = 0;
     double feed_copy = 0, feed_wait_slot = 0, feed_issue = 0, feed_max = 0;       // feeders: memcpy into the ring, waiting for a slot, hipMemcpyAsync calls
+    double drain_register = 0;                                                      // drainers: page-locking the caller's output rows (direct mode)
     double feed_boundary = 0, feed_final = 0;                                       // feeders: chunk events + notifications, the final stream sync
     double main_wait_upload = 0, main_launch = 0, main_tail_sync = 0;               // calling thread
     double drain_wait_compute = 0, drain_wait_copy = 0, drain_copy = 0, drain_max = 0;
@@ -241,7 +250,8 @@ inline Result run(const Job &job)
     // everything HIP-side is created up front on the calling thread, destroyed after every thread has joined
     std::vector<hipStream_t> fstream(F, nullptr), dstream(D, nullptr);
     std::vector<hipEvent_t> fslot(F * R, nullptr), dslot(D * R, nullptr), upl(F * chunks, nullptr), comp(chunks, nullptr);
-    hipStream_t cstream = nullptr;
+    const int CL = std::max(1, std::min(job.compute_lanes, 4));
+    std::vector<hipStream_t> cstreams(CL, nullptr);
     PinnedBlock in_ring, out_ring;
     bool ok = true;
     auto check = [&](hipError_t e, const char *what) {
@@ -251,7 +261,7 @@ inline Result run(const Job &job)
             res.why = hip_msg(what, e);
         }
     };
-    check(hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking), "hipStreamCreate");
+    for (auto &c : cstreams) check(hipStreamCreateWithFlags(&c, hipStreamNonBlocking), "hipStreamCreate");
     const bool shared_streams = job.shared_streams;
     if (shared_streams) {
         if (F > 0) check(hipStreamCreateWithFlags(&fstream[0], hipStreamNonBlocking), "hipStreamCreate");
@@ -263,14 +273,14 @@ inline Result run(const Job &job)
         for (auto &s : dstream) check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
     }
     const bool timeline = std::getenv("VGA_HIP_PIPELINE_TIMELINE") != nullptr;
-    std::vector<hipEvent_t> cstart(chunks + 1, nullptr);
+    std::vector<hipEvent_t> cstart(chunks + 1, nullptr), dlev(timeline ? D * chunks : 0, nullptr);
     for (auto *v : {&fslot, &dslot})
         for (auto &e : *v) check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
-    for (auto *v : {&upl, &comp, &cstart})
+    for (auto *v : {&upl, &comp, &cstart, &dlev})
         for (auto &e : *v) check(hipEventCreateWithFlags(&e, timeline ? hipEventDefault : hipEventDisableTiming), "hipEventCreate");
-    if (timeline) check(hipEventRecord(cstart[chunks], cstream), "hipEventRecord");
+    if (timeline) check(hipEventRecord(cstart[chunks], cstreams[0]), "hipEventRecord");
     if (ok && has_in && !job.direct && !in_ring.alloc((size_t)F * R * in_slot_rows * job.d_in_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (input ring)");
-    if (ok && has_out && !job.direct && !out_ring.alloc((size_t)D * R * out_slot_rows * job.d_out_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (output ring)");
+    if (ok && has_out && !job.direct_out && !out_ring.alloc((size_t)D * R * out_slot_rows * job.d_out_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (output ring)");
 
     auto chunk_units_of = [&](int k) { return cbegin[k + 1] - cbegin[k]; };
 
@@ -360,13 +370,28 @@ inline Result run(const Job &job)
             std::vector<void *> &v; hipStream_t s;
             ~Unregister() { if (!v.empty()) { (void)hipStreamSynchronize(s); for (void *p : v) (void)hipHostUnregister(p); } }
         } unregister{registered, dstream[u]};
-        double t_wait_comp = 0, t_wait_copy = 0, t_copy = 0;
+        double t_wait_comp = 0, t_wait_copy = 0, t_copy = 0, t_register = 0;
         const double t_start = now();
         struct Report {
-            Shared &sh; double &a, &b, &c; const double &t0;
+            Shared &sh; double &a, &b, &c, &r; const double &t0;
             ~Report() { std::lock_guard<std::mutex> g(sh.m); sh.st.drain_wait_compute += a; sh.st.drain_wait_copy += b; sh.st.drain_copy += c;
+                        sh.st.drain_register += r;
                         sh.st.drain_max = std::max(sh.st.drain_max, now() - t0); }
-        } report{sh, t_wait_comp, t_wait_copy, t_copy, t_start};
+        } report{sh, t_wait_comp, t_wait_copy, t_copy, t_register, t_start};
+        // direct mode: page-lock this drainer's share of the output rows now, while it has nothing else to do (rows it
+        // cannot lock are copied by the runtime's pageable path later, which is correct but blocks)
+        if (job.direct_out && job.register_rows) {
+            const double ta = now();
+            const int total_rows = job.units * job.out_rows_per_unit;
+            for (int r = u; r < total_rows; r += D) {
+                void *row = job.out_rows[r];
+                if (hipHostRegister(row, job.out_row_bytes, hipHostRegisterDefault) == hipSuccess)
+                    registered.push_back(row);
+                else
+                    (void)hipGetLastError();
+            }
+            t_register = now() - ta;
+        }
         auto flush = [&](int s) -> bool {                  // slot s: wait for its download, hand the rows to the caller
             if (pend[s].row < 0) return true;
             const double ta = now();
@@ -405,14 +430,10 @@ inline Result run(const Job &job)
                 const int r = row0 + next_out[k].fetch_add(out_slot_rows);
                 if (r >= row1) break;
                 const int n = std::min(out_slot_rows, row1 - r);
-                if (job.direct) {
+                if (job.direct_out) {
                     const double ta = now();
                     for (int i = 0; i < n; i++) {
                         void *row = job.out_rows[r + i];
-                        if (job.register_rows && hipHostRegister(row, job.out_row_bytes, hipHostRegisterDefault) == hipSuccess)
-                            registered.push_back(row);
-                        else
-                            (void)hipGetLastError();
                         VGA_PIPE_TRY(hipMemcpyAsync(row, job.d_out + (size_t)(r + i) * job.d_out_pitch, job.out_row_bytes,
                                                     hipMemcpyDeviceToHost, dstream[u]));
                     }
@@ -429,11 +450,12 @@ inline Result run(const Job &job)
                 pend[s].n = n;
                 used++;
             }
+            if (timeline) VGA_PIPE_TRY(hipEventRecord(dlev[u * chunks + k], dstream[u]));
         }
         if (!sh.err.load())
             for (int s = 0; s < R; s++)
                 if (!flush((int)((used + s) % R))) return;  // oldest first
-        if (!sh.err.load() && job.direct) {
+        if (!sh.err.load() && job.direct_out) {
             const double ta = now();
             VGA_PIPE_TRY(hipStreamSynchronize(dstream[u]));   // the caller's rows are complete when run() returns
             t_wait_copy += now() - ta;
@@ -461,6 +483,8 @@ inline Result run(const Job &job)
                 if (sh.err.load()) return;
                 double tb = now();
                 t_wait += tb - ta;
+                hipStream_t cstream = cstreams[k % CL];
+                compute_lane() = k % CL;
                 for (int t = 0; t < F; t++) VGA_PIPE_TRY(hipStreamWaitEvent(cstream, upl[t * chunks + k], 0));
                 if (timeline) VGA_PIPE_TRY(hipEventRecord(cstart[k], cstream));
                 std::string why;
@@ -478,7 +502,7 @@ inline Result run(const Job &job)
                 sh.cv.notify_all();
             }
             const double tc = now();
-            VGA_PIPE_TRY(hipStreamSynchronize(cstream));
+            for (auto c : cstreams) VGA_PIPE_TRY(hipStreamSynchronize(c));
             {
                 std::lock_guard<std::mutex> g(sh.m);
                 sh.st.main_tail_sync = now() - tc;
@@ -491,7 +515,7 @@ inline Result run(const Job &job)
         }
     }
     // after a failure, operations may still be in flight on the rings: drain every stream before anything is released
-    if (cstream) (void)hipStreamSynchronize(cstream);
+    for (auto c : cstreams) if (c) (void)hipStreamSynchronize(c);
     for (auto s : fstream) if (s) (void)hipStreamSynchronize(s);
     for (auto s : dstream) if (s) (void)hipStreamSynchronize(s);
     if (timeline && ok && !sh.err.load()) {
@@ -499,15 +523,17 @@ inline Result run(const Job &job)
         for (int k = 0; k < chunks; k++) {
             std::fprintf(stderr, "timeline chunk %d: uploaded", k);
             for (int t = 0; t < F; t++) std::fprintf(stderr, " %.1f", at(upl[t * chunks + k]));
-            std::fprintf(stderr, "  compute %.1f .. %.1f ms\n", at(cstart[k]), at(comp[k]));
+            std::fprintf(stderr, "  compute %.1f .. %.1f  downloaded", at(cstart[k]), at(comp[k]));
+            for (int u = 0; u < D; u++) std::fprintf(stderr, " %.1f", at(dlev[u * chunks + k]));
+            std::fprintf(stderr, " ms\n");
         }
     }
-    for (auto *v : {&fslot, &dslot, &upl, &comp, &cstart})
+    for (auto *v : {&fslot, &dslot, &upl, &comp, &cstart, &dlev})
         for (auto e : *v) if (e) (void)hipEventDestroy(e);
     if (shared_streams) { fstream.resize(F > 0 ? 1 : 0); dstream.resize(D > 0 ? 1 : 0); }
     for (auto s : fstream) if (s) (void)hipStreamDestroy(s);
     for (auto s : dstream) if (s) (void)hipStreamDestroy(s);
-    if (cstream) (void)hipStreamDestroy(cstream);
+    for (auto c : cstreams) if (c) (void)hipStreamDestroy(c);
     res.stats = sh.st;
     res.stats.setup = t_setup_done - t_begin;
     res.stats.total = now() - t_begin;
