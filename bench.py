@@ -360,7 +360,7 @@ def run_gc(args, cx):
     verified = 0
     enc_bytes = ENC_BYTES_PER_SAMPLE * nch * n
     full = nch == 4096 and n == 2880000
-    pmc = load_profile_json("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+    pmc = load_profile_json("r02_b_pmc_traffic.json", "r01_pmc_traffic.json")
     traffic = None
     if pmc and full:
         try:
@@ -369,7 +369,7 @@ def run_gc(args, cx):
             pass
     # What actually binds the kernel: wave-instruction issue.  From the committed SQ counter pass.
     issue = None
-    sqj = load_profile_json("r02_sq_counters.json", "r01_l_sq_counters.json")
+    sqj = load_profile_json("r02_b_sq_counters.json", "r01_l_sq_counters.json")
     if sqj and full:
         try:
             sq = sqj["gc_encode_kernel"]
@@ -381,8 +381,8 @@ def run_gc(args, cx):
         except (KeyError, ZeroDivisionError):
             pass
     achieved = enc_bytes / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
-    # one encode = gc_encode_kernel<false> (all time pieces at once) + gc_encode_seam_kernel + gc_encode_kernel<true>
-    # (the repair launch: returns at once unless a seam stayed open); launch_ms spans the three, the rocprofv3
+    # one encode = gc_encode_kernel<false> (all time pieces at once) + gc_encode_seam_kernel + gc_encode_chain_kernel +
+    # gc_encode_kernel<true> (chain and repair return at once unless a seam stayed open); launch_ms spans the four, the rocprofv3
     # kernel stats under profiles/ list them separately (their averages add up to it)
     roofline = {"bound": "hbm", "kernel": "gc_encode_kernel", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -468,7 +468,7 @@ def run_adx(args, cx):
         return None
     bytes_launch = ADX_BYTES_PER_SAMPLE * nch * n
     achieved = bytes_launch / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
-    pmc = load_profile_json("r02_pmc_traffic.json")
+    pmc = load_profile_json("r02_b_pmc_traffic.json")
     traffic = None
     if pmc and nch == 4096 and n == 2880000:
         traffic = (pmc.get("adx_encode_fs18_tiled_kernel") or {}).get("traffic_bytes_per_launch")
@@ -552,7 +552,7 @@ def run_hca(args, cx):
         return None
     bytes_launch = (2.0 + info.frame_size * info.frame_count / (2.0 * n)) * chs if n else 0.0
     achieved = bytes_launch / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
-    pmc = load_profile_json("r02_pmc_traffic.json")
+    pmc = load_profile_json("r02_b_pmc_traffic.json")
     traffic = None
     if pmc and ns == 1024 and n == 2880000:
         traffic = (pmc.get("hca_encode_kernel") or {}).get("traffic_bytes_per_launch")
