@@ -357,6 +357,19 @@ def run_gc(args, cx):
 
     if cx.rank != 0:
         return None
+    # the other direction (GcAdpcmDecoder.Decode), outside the timed steps: three launches between HIP events
+    dec_ms = 0.0
+    if cx.world == 1:
+        back = vdev.alloc_pcm(nch, n, cx.dev)
+        vdev.gc_decode(adpcm, coefs, n, out=back)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            vdev.gc_decode(adpcm, coefs, n, out=back)
+        e1.record()
+        torch.cuda.synchronize()
+        dec_ms = e0.elapsed_time(e1) / 3
+        del back
     verified = 0
     enc_bytes = ENC_BYTES_PER_SAMPLE * nch * n
     full = nch == 4096 and n == 2880000
@@ -377,7 +390,8 @@ def run_gc(args, cx):
             issue = {"valu_wave_instructions_per_launch": round(sq["SQ_INSTS_VALU"]),
                      "valu_issue_frac": round(sq["SQ_ACTIVE_INST_VALU"] / (1024 * clk_quads), 3),
                      "profiled_launch_ms": round(sq["_dur_ms"], 1),
-                     "note": "1024 SIMDs x one wave-instruction per 4 cycles; profiled launch, not this run"}
+                     "clock_GHz_seen_by_the_waves": round(4 * clk_quads / (sq["_dur_ms"] * 1e6), 2),
+                     "note": "1024 SIMDs x one wave-instruction per 4 cycles at that clock; profiled launch, not this run"}
         except (KeyError, ZeroDivisionError):
             pass
     achieved = enc_bytes / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
@@ -390,7 +404,10 @@ def run_gc(args, cx):
                 "launch_parts": ["gc_encode_kernel<false>", "gc_encode_seam_kernel", "gc_encode_chain_kernel", "gc_encode_kernel<true>"],
                 "other_kernels": {"gc_coefs_kernel": {
                     "launch_ms": round(coef_ms, 3),
-                    "achieved": round(COEF_BYTES_PER_SAMPLE * nch * n / (coef_ms * 1e-3) / 1e9, 2) if coef_ms > 0 else 0.0}},
+                    "achieved": round(COEF_BYTES_PER_SAMPLE * nch * n / (coef_ms * 1e-3) / 1e9, 2) if coef_ms > 0 else 0.0},
+                    "gc_decode_kernel (+fixup, tail; not part of the step)": {
+                        "launch_ms": round(dec_ms, 3),
+                        "achieved": round(ENC_BYTES_PER_SAMPLE * nch * n / (dec_ms * 1e-3) / 1e9, 2) if dec_ms > 0 else 0.0}},
                 "pipeline_achieved": round(PIPE_BYTES_PER_SAMPLE * nch * n / ((coef_ms + enc_ms) * 1e-3) / 1e9, 2)
                 if coef_ms + enc_ms > 0 else 0.0,
                 "issue": issue}

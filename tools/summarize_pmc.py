@@ -38,18 +38,21 @@ def read(dirname):
     out = {}
     for k, counters in per.items():
         out[k] = {}
+        # the launches that count: near-empty ones (e.g. the repair launch that returns at once, which shares the
+        # kernel's name) are dropped from every mean -- chosen once, by duration, so that all counters (SQ_WAVES
+        # included) average over the same dispatches
+        dmax = max(dur[k].values()) if dur[k] else 0.0
+        keep = {d for d, t in dur[k].items() if t >= 0.05 * dmax}
         for c, vals in counters.items():
             by = defaultdict(float)
             for d, v in vals:                              # a counter may come in several rows (XCDs): sum per dispatch
-                by[d] += v
-            # drop near-empty launches (e.g. the repair launch that returns at once) from the mean
-            vs = sorted(by.values())
-            big = [v for v in vs if v >= 0.05 * vs[-1]] if vs and vs[-1] > 0 else vs
-            out[k][c] = sum(big) / max(len(big), 1)
-        ds = sorted(dur[k].values())
-        bigd = [d for d in ds if d >= 0.05 * ds[-1]] if ds else ds
-        out[k]["_dur_ms"] = sum(bigd) / max(len(bigd), 1)
-        out[k]["_launches"] = len(ds)
+                if d in keep:
+                    by[d] += v
+            out[k][c] = sum(by.values()) / max(len(by), 1)
+        kept = [dur[k][d] for d in keep]
+        out[k]["_dur_ms"] = sum(kept) / max(len(kept), 1)
+        out[k]["_launches"] = len(kept)
+        out[k]["_launches_dropped"] = len(dur[k]) - len(kept)
     return out
 
 

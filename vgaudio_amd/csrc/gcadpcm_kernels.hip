@@ -385,11 +385,7 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
                 load_frame16(src, f, length, x);
                 fs = frame_sums(x);
             }
-#ifdef VGA_CABL_NOREC
-            Record r; r.valid = true; r.r1 = fs.vec[1] * 1e-9; r.r2 = fs.vec[2] * 1e-9;
-#else
             const Record r = frame_record(fs);
-#endif
             valid = r.valid;
             if (valid) matrix_filter(r.r1, r.r2, d1, d2);
             // The scratch keeps MatrixFilter's output (dst[1], dst[2]), not the record: it is all the later
@@ -407,9 +403,7 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
             s_d[par][1][slot] = d2;
         }
         wave_lds_sync();
-#ifndef VGA_CABL_NOACC
         if (lane < 2) acc = ordered_sum(acc, &s_d[par][lane][0], n, n);
-#endif
         cnt += n;
     }
     __syncthreads();
@@ -491,9 +485,7 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
                 }
                 wave_lds_sync();
                 if (lane < 2 * EXP) {
-#ifndef VGA_CABL_NOACC
                     acc = ordered_sum(acc, &s_d[par][my_comp][my_start], my_n, max_n);
-#endif
                     cnt += my_n;
                 }
             }
@@ -519,11 +511,7 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     };
 
     // ---- 3 splits x 2 Lloyd iterations (:77-91, FilterRecords :344-396)
-#ifdef VGA_CABL_NOLLOYD
-    for (int w = 0; w < 0; w++) {
-#else
     for (int w = 0; w < 3; w++) {
-#endif
         const int half = 1 << w;
         if (lane < half) {
             s_vb[half + lane][0] = (0.01 * 0.0) + s_vb[lane][0];

@@ -30,8 +30,10 @@ namespace hca {
 // [0] noise level (u16) [2] evaluation boundary (u8) [3] flags (u8); then per channel 272 bytes:
 // scale factors[128], resolutions[128], intensity[8], hfr scales[8]; then int16 q[8][nch][128].
 __host__ __device__ inline size_t record_channel_offset(int c) { return 16 + (size_t)c * 272; }
-__host__ __device__ inline size_t record_q_offset(int nch) { return 16 + (size_t)nch * 272; }
-size_t unpack_record_bytes(int nch) { return (16 + (size_t)nch * 272 + (size_t)8 * nch * 128 * 2 + 15) / 16 * 16; }
+// the quantised spectra start on a 128-byte boundary of a record whose size is a multiple of 128: the unpacker hands
+// them over in whole 128-byte runs (see flush_spectra)
+__host__ __device__ inline size_t record_q_offset(int nch) { return (16 + (size_t)nch * 272 + 127) / 128 * 128; }
+size_t unpack_record_bytes(int nch) { return record_q_offset(nch) + (size_t)8 * nch * 128 * 2; }
 
 // MSB-first bit reader over the stream's (4-byte aligned) frame data: a 64-bit register window plus the next
 // dword, which is fetched as soon as the position is known -- every symbol's length depends on the previous
@@ -86,15 +88,19 @@ struct BitCursor {
     }
 };
 
+// Tried and dropped (round 2): copying the wave's 64 frames into LDS first, so that the bit readers walk LDS instead of
+// issuing a vector load per symbol whose 64 lanes sit in 64 different cache lines.  The 44 KB of frames leave two waves
+// per CU instead of six, and the chain per symbol (window shift, table look-up, advance) is long enough that the lost
+// latency hiding costs more than the loads did: 67.6 ms instead of 39.3 at config 4.
 __global__ __launch_bounds__(64) void hca_unpack_kernel(
     const uint8_t *__restrict__ frames, int64_t stream_pitch, int nstreams, DeviceInfo info,
     uint8_t *__restrict__ records, size_t record_bytes, int *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_res[];   // [nch][128][64]
     __shared__ DecTables T;
+    __shared__ uint4 s_stage[64][9];                                  // [lane][piece], 144-byte rows (bank spread)
     const int lane = threadIdx.x;
     load_tables(T, lane, 64);
-    __syncthreads();
     const int64_t gid = (int64_t)blockIdx.x * 64 + lane;
     const int64_t total = (int64_t)nstreams * info.frame_count;
     const bool live = gid < total;
@@ -106,9 +112,10 @@ __global__ __launch_bounds__(64) void hca_unpack_kernel(
     BitCursor r;
     r.base = reinterpret_cast<const uint32_t *>(frames + (int64_t)stream * stream_pitch);
     r.frame_bit0 = (int64_t)frame * info.frame_size * 8;
+    r.last_word = stream_pitch / 4 - 1;
+    __syncthreads();
     r.frame_bits = info.frame_size * 8;
     r.pos = 0;
-    r.last_word = stream_pitch / 4 - 1;
     r.start();
     uint8_t *rec = records + (size_t)id * record_bytes;
 
@@ -170,12 +177,32 @@ __global__ __launch_bounds__(64) void hca_unpack_kernel(
         }
     }
 
-    // ReadSpectralCoefficients (:148-183)
-    int16_t *q = reinterpret_cast<int16_t *>(rec + record_q_offset(nch));
+    // ReadSpectralCoefficients (:148-183).  A lane's eight int16 values are one 16-byte piece; written straight to its
+    // record, the 64 lanes of a store hit 64 different records 4.7 KB apart (measured: 48 GB of HBM writes for 7.5 GB of
+    // records).  The pieces go through LDS instead: after eight of them (64 coefficients) the wave writes 128 contiguous
+    // bytes per record, eight lanes per record.
+    const size_t q_off = record_q_offset(nch);
+    const int64_t first = (int64_t)blockIdx.x * 64;
+    auto flush_spectra = [&](size_t row_off, int s0, int pieces) {
+        // the workgroup is one wave, whose LDS operations execute in program order: the hand-over needs the LDS counter
+        // and a compiler ordering point, not s_barrier (and not __syncthreads(), which would also wait for the
+        // bit reader's prefetched dword)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int rr = k * 8 + (lane >> 3), piece = lane & 7;
+            if (piece < pieces && first + rr < total) {
+                const uint4 v = s_stage[rr][piece];
+                *reinterpret_cast<uint4 *>(records + (size_t)(first + rr) * record_bytes + q_off + row_off + (size_t)s0 * 2 +
+                                           (size_t)piece * 16) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the pieces are in registers before the next ones overwrite them
+    };
     for (int sf = 0; sf < SUBFRAMES; sf++) {
         for (int c = 0; c < nch; c++) {
             const int count = info.coded_count[c];
-            int16_t *qrow = q + ((size_t)sf * nch + c) * 128;
+            const size_t row_off = ((size_t)sf * nch + c) * 128 * 2;
             uint32_t qp[4] = {0, 0, 0, 0};
             for (int s = 0; s < count; s++) {
                 const int resolution = s_res[((size_t)c * 128 + s) * 64 + lane];
@@ -190,16 +217,15 @@ __global__ __launch_bounds__(64) void hca_unpack_kernel(
                     if (value == 0) bits--;
                 }
                 r.skip(bits);
-                // eight int16 values per 16-byte store
                 qp[(s >> 1) & 3] |= (uint32_t)(value & 0xFFFF) << (16 * (s & 1));
-                if ((s & 7) == 7) {
-                    if (live) *reinterpret_cast<uint4 *>(qrow + (s & ~7)) = make_uint4(qp[0], qp[1], qp[2], qp[3]);
+                const bool last = s == count - 1;
+                if ((s & 7) == 7 || last) {                 // a piece is complete (the row's last one may be partly zeros)
+                    s_stage[lane][(s >> 3) & 7] = make_uint4(qp[0], qp[1], qp[2], qp[3]);
 #pragma unroll
                     for (int k = 0; k < 4; k++) qp[k] = 0;
+                    if ((s & 63) == 63 || last) flush_spectra(row_off, s & ~63, ((s & 63) >> 3) + 1);
                 }
             }
-            if (live)                                       // a band count that is not a multiple of 8
-                for (int s = count & ~7; s < count; s++) qrow[s] = (int16_t)(qp[(s >> 1) & 3] >> (16 * (s & 1)));
         }
     }
     if (live) {
@@ -346,9 +372,9 @@ int launch_decode(const uint8_t *d_frames, int64_t frames_pitch, int nstreams, c
     const size_t rb = unpack_record_bytes(info.nch);
     const int64_t total = (int64_t)nstreams * info.frame_count;
     const size_t lds1 = (size_t)info.nch * 128 * 64;
+    if (lds1 > 48 * 1024) VGA_HIP_TRY(allow_dynamic_lds(hca_unpack_kernel, lds1));
     hipLaunchKernelGGL(hca_unpack_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), lds1, stream, d_frames,
                        frames_pitch, nstreams, info, reinterpret_cast<uint8_t *>(d_workspace), rb, d_status);
-    VGA_HIP_TRY(hipGetLastError());
     const size_t lds2 = ((size_t)info.nch * 9 * 128 + 9 * 128 + (size_t)2 * info.nch * 128) * sizeof(double);
     if (lds2 > 64 * 1024)
         VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hca_imdct_kernel),
