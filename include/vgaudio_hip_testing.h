@@ -21,6 +21,10 @@ int vga_testing_force_open_seams_this_thread(int mode);
  * choice; 4 = lane per (channel, predictor, scale candidate), the round-1 layout kept for A/B measurements.  Both produce
  * the same bytes.  Returns the previous value; other arguments leave it unchanged. */
 int vga_testing_gc_encoder_layout_this_thread(int channels_per_wave);
+/* GC-ADPCM coefficient-search kernel for calls made from the calling thread: 0 = the launcher's choice by channel count
+ * (the product), 1 = one wave per channel, 2 = workgroups of four channels and a summing wave.  Same coefficients.
+ * Returns the previous value; other arguments leave it unchanged. */
+int vga_testing_gc_coefs_variant_this_thread(int variant);
 /* Forces the number of time pieces a channel is cut into by the GC-ADPCM encoder (0 = the launcher's own choice: what
  * fills the chip), for calls made from the calling thread.  Results must not depend on it.  Returns the previous value. */
 int vga_testing_gc_encoder_segments_this_thread(int segments);

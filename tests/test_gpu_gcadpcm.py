@@ -418,6 +418,28 @@ def test_encoder_layouts_and_piece_counts_give_the_same_bytes():
         L.vga_testing_gc_encoder_segments_this_thread(0)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_all_coefficient_kernels_match_the_oracle(variant):
+    """0 = the launcher's choice, 1 = one wave per channel, 2 = four channels + a summing wave per workgroup: the ordered
+    f64 sums must come out the same in all, on channel counts that fill no workgroup and on the edge inputs."""
+    from vgaudio_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    old = L.vga_testing_gc_coefs_variant_this_thread(variant)
+    try:
+        for nch, n in ((1, 14 * 700 + 3), (5, 14 * 3000 + 5), (7, 64 * 14), (9, 64 * 14 + 1), (3, 13), (2, 0)):
+            pcm = synth.generate(nch, n) if n else np.zeros((nch, 0), dtype=np.int16)
+            got = GcAdpcmCoefficients.CalculateCoefficients(list(pcm))
+            for c in range(nch):
+                assert got[c].tolist() == po.gc_calculate_coefficients(pcm[c]).tolist(), (variant, nch, n, c)
+        chans = _edge_channels(14 * 700 + 9, rng)
+        got = GcAdpcmCoefficients.CalculateCoefficients(list(chans.values()))
+        for i, (name, pcm) in enumerate(chans.items()):
+            assert got[i].tolist() == po.gc_calculate_coefficients(pcm).tolist(), (variant, name)
+    finally:
+        L.vga_testing_gc_coefs_variant_this_thread(old)
+
+
 @pytest.mark.parametrize("n", [14 * 40000, 14 * 40000 + 9])
 def test_short_pieces_leave_seams_open_and_the_chain_closes_them(n):
     """Pieces of ~130 frames: a few percent of the seams are still open when their piece ends (often several in a row in

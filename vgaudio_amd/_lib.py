@@ -121,6 +121,7 @@ SIGNATURES = {
     "vga_testing_force_open_seams_this_thread": (ci, [ci]),
     "vga_testing_host_pipeline_this_thread": (None, [ci, ci, ci, ci]),
     "vga_testing_gc_encoder_layout_this_thread": (ci, [ci]),
+    "vga_testing_gc_coefs_variant_this_thread": (ci, [ci]),
     "vga_testing_gc_encoder_segments_this_thread": (ci, [ci]),
     "vga_testing_last_pipeline_stats": (ci, [vp, ci]),
     "vga_dsp_layout_for": (ci, [vp, ci, vp]),

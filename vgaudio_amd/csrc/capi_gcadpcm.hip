@@ -26,6 +26,8 @@ int force_open_seams() { return g_force_open_seams; }
 
 static thread_local int g_encoder_layout = 8;
 int encoder_layout() { return g_encoder_layout; }
+static thread_local int g_coefs_variant = 0;
+int coefs_kernel_variant() { return g_coefs_variant; }
 static thread_local int g_encoder_segments = 0;
 int encoder_segments_override() { return g_encoder_segments; }
 
@@ -87,6 +89,12 @@ int vga_testing_gc_encoder_layout_this_thread(int channels_per_wave)
 {
     const int old = g_encoder_layout;
     if (channels_per_wave == 4 || channels_per_wave == 8) g_encoder_layout = channels_per_wave;
+    return old;
+}
+int vga_testing_gc_coefs_variant_this_thread(int variant)
+{
+    const int old = g_coefs_variant;
+    if (variant >= 0 && variant <= 2) g_coefs_variant = variant;
     return old;
 }
 int vga_testing_gc_encoder_segments_this_thread(int segments)

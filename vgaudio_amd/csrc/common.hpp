@@ -190,6 +190,7 @@ int force_open_seams();          // 0 = off, 1 = every seam, 2 = seams with an e
 // lane layout of the GC-ADPCM encoder wave (gc_encode_kernel.hip): 8 = (channel, predictor), the default; 4 = (channel,
 // predictor, candidate).  Thread-local test hook vga_testing_gc_encoder_layout_this_thread: both must give the same bytes.
 int encoder_layout();
+int coefs_kernel_variant();               // 0: four channels + summing wave per workgroup (product); 1: one wave per channel
 int encoder_segments_override();   // > 0: time pieces per channel forced by the test hook
 
 // the per-(channel, seam) reading of that mode inside the seam kernels

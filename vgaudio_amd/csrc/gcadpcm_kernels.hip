@@ -537,6 +537,234 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     }
 }
 
+// ---------------------------------------------------------------- coefficients, v3: four channels + a summing wave
+// (used below ~3600 channels, see launch_coefs)
+// The ordered bucket sums are a chain of dependent f64 adds per (bucket, component): in the one-wave-per-channel kernel
+// above they occupy a whole wave-instruction for 2..16 active lanes, a quarter of that kernel's instructions.  Here a
+// workgroup is four RECORD waves (one channel each: records, nearest codeword, stable partition into LDS, as above) and
+// one SUMMING wave whose lanes are (channel, bucket, component) -- 4 x 8 x 2 = 64 -- so that one add instruction carries
+// the chains of all four channels.  The summing wave works on chunk c - 1 while the record waves prepare chunk c
+// (double-buffered LDS, one LDS-only barrier per chunk); it also owns the per-pass codebook updates.  Measured at
+// 4096 x 60 s: 14.0 G VALU wave-instructions instead of 16.3 G, but the five waves of a workgroup move in lockstep and
+// wait more (SQ_WAIT_ANY 40 % of the wave-cycles instead of 31 %): 43.0 ms against 41.6.
+constexpr int COEF_CW = 4;                                  // channels per workgroup
+constexpr int COEF_THREADS = (COEF_CW + 1) * 64;
+
+__global__ __launch_bounds__(COEF_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void gc_coefs_kernel4(
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int length,
+    double2 *__restrict__ records, int16_t *__restrict__ coefs_out)
+{
+    __shared__ __align__(64) double s_d[COEF_CW][2][2][128];       // [channel][chunk parity][component][compacted slot]
+    __shared__ int s_meta[2][COEF_CW][8];                          // (start << 8) | n of every bucket
+    __shared__ int s_maxn[2][COEF_CW];                             // max_b n_b: the summing loop's trip bound
+    __shared__ double s_vb[COEF_CW][8][3];                         // vecBest
+    __shared__ double s_cw[COEF_CW][8][3];                         // ContrastVectors terms per codeword
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool summer = wave == COEF_CW;
+    const int cs = summer ? 0 : wave;                              // this record wave's channel slot
+    const int ch_raw = blockIdx.x * COEF_CW + cs;
+    const bool live = !summer && ch_raw < nch;
+    const int ch = ch_raw < nch ? ch_raw : nch - 1;
+    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
+    const int frames = (length + 13) / 14;
+    const int chunks = (frames + 63) / 64;
+    double2 *rec = records + (int64_t)ch * frames;
+    // summing-wave lane = (channel slot, bucket, component)
+    const int sc = lane >> 4, sb = (lane >> 1) & 7, sk = lane & 1;
+
+    auto zero_fill = [&](int par) {
+        reinterpret_cast<double2 *>(&s_d[cs][par][0][0])[lane] = make_double2(0.0, 0.0);
+        reinterpret_cast<double2 *>(&s_d[cs][par][1][0])[lane] = make_double2(0.0, 0.0);
+    };
+    double acc = 0.0;                                              // summing wave: this lane's chain
+    int cnt = 0;
+    // the summing wave's share of one chunk: buckets < nb take part
+    auto sum_chunk = [&](int par, int nb) {
+        const int meta = s_meta[par][sc][sb];
+        const int trip = max(max(s_maxn[par][0], s_maxn[par][1]), max(s_maxn[par][2], s_maxn[par][3]));
+        const int n = sb < nb ? (meta & 0xFF) : 0;
+        acc = ordered_sum(acc, &s_d[sc][par][sk][meta >> 8], n, trip);
+        cnt += n;
+    };
+
+    // ---- pass 0: per-frame records (:40-61) + ordered mean of MatrixFilter outputs (:63-74)
+    const int f_hi = (length - 14) / 14;
+    const bool have_interior = f_hi >= 1;
+    uint32_t w[8];
+    auto prefetch = [&](int f) {
+        const int fp = min(max(f, 1), max(f_hi, 1));
+        const uint32_t *p32 = reinterpret_cast<const uint32_t *>(src + (int64_t)fp * 14 - 2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = p32[i];
+    };
+    if (!summer && have_interior) prefetch(lane);
+    for (int c = 0; c < chunks; c++) {
+        const int par = c & 1;
+        if (!summer) {
+            const int f = c * 64 + lane;
+            bool valid = false;
+            double d1 = 0.0, d2 = 0.0;
+            uint32_t wc[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) wc[i] = w[i];
+            if (have_interior) prefetch(f + 64);
+            if (f < frames) {
+                FrameSums fs;
+                if (have_interior && f >= 1 && f <= f_hi) {
+                    fs = frame_sums_packed(wc);
+                } else {
+                    int x[16];
+                    load_frame16(src, f, length, x);
+                    fs = frame_sums(x);
+                }
+                const Record r = frame_record(fs);
+                valid = r.valid && live;
+                if (valid) matrix_filter(r.r1, r.r2, d1, d2);
+                if (live) rec[f] = valid ? make_double2(d1, d2) : make_double2(__builtin_nan(""), 0.0);
+            }
+            const uint64_t mask = __ballot(valid);
+            const int n = __popcll(mask);
+            zero_fill(par);
+            if (valid) {
+                const int slot = lane_rank(mask);
+                s_d[cs][par][0][slot] = d1;
+                s_d[cs][par][1][slot] = d2;
+            }
+            if (lane < 8) s_meta[par][cs][lane] = lane == 0 ? n : 0;
+            if (lane == 8) s_maxn[par][cs] = n;
+        } else if (c > 0) {
+            sum_chunk(par ^ 1, 1);
+        }
+        lds_barrier();
+    }
+    if (summer) {
+        if (chunks > 0) sum_chunk((chunks - 1) & 1, 1);
+        const double other = __shfl_xor(acc, 1);
+        if (sb == 0 && sk == 0) {
+            double vec1[3];
+            vec1[0] = 1.0;
+            vec1[1] = acc;
+            vec1[2] = other;
+            vec1[1] /= cnt;
+            vec1[2] /= cnt;
+            double vb[3];
+            merge_finish_record(vec1, vb);
+            s_vb[sc][0][0] = vb[0]; s_vb[sc][0][1] = vb[1]; s_vb[sc][0][2] = vb[2];
+        }
+    }
+    lds_barrier();
+
+    auto lloyd_iterations = [&](auto exp_c) {
+        constexpr int EXP = decltype(exp_c)::value;
+        for (int iter = 0; iter < 2; iter++) {
+            if (!summer && lane < EXP) {
+                const double a = s_vb[cs][lane][0], b = s_vb[cs][lane][1], c3 = s_vb[cs][lane][2];
+                s_cw[cs][lane][0] = (a * a) + (b * b) + (c3 * c3);
+                s_cw[cs][lane][1] = (a * b) + (b * c3);
+                s_cw[cs][lane][2] = a * c3;
+            }
+            lds_barrier();
+            double cw1[EXP], cw2[EXP], cw3[EXP];
+#pragma unroll
+            for (int i = 0; i < EXP; i++) {
+                cw1[i] = s_cw[cs][i][0];
+                cw2[i] = s_cw[cs][i][1];
+                cw3[i] = s_cw[cs][i][2];
+            }
+            acc = 0.0;
+            cnt = 0;
+            double2 r_next = make_double2(0.0, 0.0);
+            if (!summer && frames > 0) r_next = rec[min(lane, frames - 1)];
+            for (int c = 0; c < chunks; c++) {
+                const int par = c & 1;
+                if (!summer) {
+                    const int f = c * 64 + lane;
+                    bool valid = false;
+                    int idx = 0;
+                    double d1 = 0.0, d2 = 0.0;
+                    const double2 r = r_next;
+                    r_next = rec[min(f + 64, frames - 1)];           // in flight during this chunk
+                    if (live && f < frames && r.x == r.x) {
+                        valid = true;
+                        const double val_x2 = 2.0 * r.x, bterm_x2 = 2.0 * r.y;
+                        double value = 1.0e30;
+#pragma unroll
+                        for (int i = 0; i < EXP; i++) {
+                            const double t = cw1[i] + (val_x2 * cw2[i]) + (bterm_x2 * cw3[i]);
+                            if (t < value) { value = t; idx = i; }
+                        }
+                        d1 = r.x;
+                        d2 = r.y;
+                    }
+                    // stable partition by bucket; lane b keeps bucket b's (start, n) for the summing wave
+                    int slot = 0, my_meta = 0, start = 0, max_n = 0;
+#pragma unroll
+                    for (int b = 0; b < EXP; b++) {
+                        const bool mine = valid && idx == b;
+                        const uint64_t m = __ballot(mine);
+                        const int n_b = __popcll(m);
+                        if (mine) slot = start + lane_rank(m);
+                        if (lane == b) my_meta = (start << 8) | n_b;
+                        start += (n_b + 7) & ~7;
+                        max_n = max(max_n, n_b);
+                    }
+                    zero_fill(par);
+                    if (valid) {
+                        s_d[cs][par][0][slot] = d1;
+                        s_d[cs][par][1][slot] = d2;
+                    }
+                    if (lane < 8) s_meta[par][cs][lane] = my_meta;
+                    if (lane == 8) s_maxn[par][cs] = max_n;
+                } else if (c > 0) {
+                    sum_chunk(par ^ 1, EXP);
+                }
+                lds_barrier();
+            }
+            if (summer) {
+                if (chunks > 0) sum_chunk((chunks - 1) & 1, EXP);
+                const double other = __shfl_xor(acc, 1);
+                if (sb < EXP && sk == 0) {
+                    double bl[3];
+                    const int n = cnt;
+                    bl[0] = (double)n;                  // bufferList[i][0] sums 1.0 per record
+                    bl[1] = acc;
+                    bl[2] = other;
+                    if (n > 0) { bl[0] /= n; bl[1] /= n; bl[2] /= n; }
+                    double vb[3] = {s_vb[sc][sb][0], s_vb[sc][sb][1], s_vb[sc][sb][2]};
+                    merge_finish_record(bl, vb);
+                    s_vb[sc][sb][0] = vb[0]; s_vb[sc][sb][1] = vb[1]; s_vb[sc][sb][2] = vb[2];
+                }
+            }
+            lds_barrier();
+        }
+    };
+
+    // ---- 3 splits x 2 Lloyd iterations (:77-91, FilterRecords :344-396)
+    for (int wsplit = 0; wsplit < 3; wsplit++) {
+        const int half = 1 << wsplit;
+        if (!summer && lane < half) {
+            s_vb[cs][half + lane][0] = (0.01 * 0.0) + s_vb[cs][lane][0];
+            s_vb[cs][half + lane][1] = (0.01 * -1.0) + s_vb[cs][lane][1];
+            s_vb[cs][half + lane][2] = (0.01 * 0.0) + s_vb[cs][lane][2];
+        }
+        lds_barrier();
+        if (wsplit == 0) lloyd_iterations(std::integral_constant<int, 2>{});
+        else if (wsplit == 1) lloyd_iterations(std::integral_constant<int, 4>{});
+        else lloyd_iterations(std::integral_constant<int, 8>{});
+    }
+
+    // ---- output :94-108
+    if (live && lane < 16) {
+        const int z = lane >> 1;
+        const double d = -s_vb[cs][z][1 + (lane & 1)] * 2048.0;
+        int out;
+        if (d > 0.0) out = (d > 32767.0) ? 32767 : (int)__builtin_rint(d);
+        else out = (d < -32768.0) ? -32768 : ((d != d) ? 0 : (int)__builtin_rint(d));
+        coefs_out[ch * 16 + lane] = (int16_t)out;
+    }
+}
+
 // ---------------------------------------------------------------- synthetic PCM (synth.py)
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 {
@@ -581,8 +809,21 @@ int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, i
                  void *d_workspace, hipStream_t stream)
 {
     if (nch <= 0) return VGA_OK;
-    hipLaunchKernelGGL(gc_coefs_kernel, dim3(nch), dim3(64), 0, stream, d_pcm, pcm_pitch, nch, length,
-                       reinterpret_cast<double2 *>(d_workspace), d_coefs);
+    // One wave per channel is the faster kernel only when it fills the chip (4 waves per SIMD at 4096 channels: 41.7 vs
+    // 43.1 ms for 60 s channels); with fewer channels the workgroups of four channels + summing wave win, because a chunk
+    // costs max(records, sums) instead of their sum: 3072 channels 31.1 vs 34.4 ms, 2048: 24.7 vs 28.3, 1024: 19.1 vs
+    // 23.9, one channel: 15.7 vs 18.6 (tools/time_coefs_variants.py, profiles/r02_c_coefs_variants.log).  A third variant
+    // -- the same roles with the chunks handed over through a ring of LDS slots and producer / consumer counters instead
+    // of a workgroup barrier per chunk -- was measured at 70 ms (polling LDS counters costs more than the barriers) and
+    // dropped.
+    const int variant = coefs_kernel_variant();
+    const bool per_channel = variant == 1 || (variant == 0 && nch > device_cu_count() * 14);
+    if (per_channel)
+        hipLaunchKernelGGL(gc_coefs_kernel, dim3(nch), dim3(64), 0, stream, d_pcm, pcm_pitch, nch, length,
+                           reinterpret_cast<double2 *>(d_workspace), d_coefs);
+    else
+        hipLaunchKernelGGL(gc_coefs_kernel4, dim3((nch + COEF_CW - 1) / COEF_CW), dim3(COEF_THREADS), 0, stream, d_pcm, pcm_pitch,
+                           nch, length, reinterpret_cast<double2 *>(d_workspace), d_coefs);
     VGA_HIP_TRY(hipGetLastError());
     return VGA_OK;
 }
