@@ -738,9 +738,10 @@ __global__ __launch_bounds__(ETHREADS) void adx_encode_fs18_tiled_kernel(
 }
 
 // One frame of CriAdxCodec.EncodeFrame (:107-147) from the history (a, b); maths as adx_encode_kernel.
+// The frame leaves as nine 16-bit words (low byte = the earlier byte of the frame).
 template <bool V4, bool EXPONENTIAL>
-__device__ __forceinline__ void adx_encode_frame_serial(const int (&x)[32], int &a, int &b, int c0, int c1, int filter_bits,
-                                                        uint8_t *fr)
+__device__ __forceinline__ void adx_encode_frame_words(const int (&x)[32], int &a, int &b, int c0, int c1, int filter_bits,
+                                                       uint32_t (&fw)[9])
 {
     int max_distance = 0;
     {
@@ -758,8 +759,7 @@ __device__ __forceinline__ void adx_encode_frame_serial(const int (&x)[32], int 
     double gain;
     int scale_out;
     const int scale = calculate_scale(max_distance, EXPONENTIAL, gain, scale_out);
-    fr[0] = (uint8_t)(((scale_out >> 8) & 0x1f) | filter_bits);
-    fr[1] = (uint8_t)(scale_out & 0xff);
+    fw[0] = (uint32_t)((((scale_out >> 8) & 0x1f) | filter_bits) & 0xff) | ((uint32_t)(scale_out & 0xff) << 8);
     int byte = 0;
 #pragma unroll
     for (int j = 0; j < 32; j++) {
@@ -772,17 +772,29 @@ __device__ __forceinline__ void adx_encode_frame_serial(const int (&x)[32], int 
         const int rec = clamp16(decoded_distance + predicted);
         a = b;
         b = rec;
-        if (j & 1) fr[2 + (j >> 1)] = (uint8_t)(byte | (q & 0xF));
-        else byte = (q & 0xF) << 4;
+        if (j & 1) {
+            const uint32_t full = (uint32_t)(byte | (q & 0xF));
+            // frame byte 2 + (j >> 1): even frame bytes are the low half of word (2 + (j >> 1)) / 2
+            if (((j >> 1) & 1) == 0) fw[1 + (j >> 2)] = full;
+            else fw[1 + (j >> 2)] |= full << 8;
+        } else
+            byte = (q & 0xF) << 4;
     }
 }
 
-// Closes the seams between the encoder's time segments: one lane per (channel, seam), all seams at once.  A seam
-// starts from the final history of the piece before it (seg_state) -- the real one provided THAT piece's own seam
-// closes -- and replays the guessed run's reconstruction (decoding that run's frames from the guess, before they are
-// overwritten) next to a true encode, frame by frame, until the two histories coincide at a frame end: from there on
-// the guessed run wrote exactly what the serial encoder writes.  A seam that does not close inside its piece records
-// its index in first_open[channel]; adx_encode_fs18_tail_kernel then encodes that channel serially from there.
+template <bool V4, bool EXPONENTIAL>
+__device__ __forceinline__ void adx_encode_frame_serial(const int (&x)[32], int &a, int &b, int c0, int c1, int filter_bits,
+                                                        uint8_t *fr)
+{
+    uint32_t fw[9];
+    adx_encode_frame_words<V4, EXPONENTIAL>(x, a, b, c0, c1, filter_bits, fw);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        fr[2 * i] = (uint8_t)(fw[i] & 0xff);
+        fr[2 * i + 1] = (uint8_t)(fw[i] >> 8);
+    }
+}
+
 template <bool V4, bool EXPONENTIAL>
 __global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, AdxDeviceParams p,
@@ -799,17 +811,49 @@ __global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
     const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
     int ta = seg_state[((int64_t)(k - 1) * nch + ch) * 2], tb = seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1];
     int sa = src[f0 * 32 - 2], sb = src[f0 * 32 - 1];                             // the guessed run's start
-    for (int64_t f = f0; f < f0 + seg_frames && f * 32 < total_length; f++) {
-        uint8_t *fr = dst + f * 18;
-        int x[32];
+    // lane = channel, so every load of the wave touches 64 different rows: a frame is fetched as four 16-byte loads of PCM
+    // and nine 16-bit loads of the old frame (instead of 32 + 18 scalar loads), one frame ahead of its use (clamped,
+    // unconditional), and leaves as nine 16-bit stores.  All lanes of a wave are at the same frame (same seam index).
+    const int64_t full_frames = total_length / 32;     // frames with all 32 samples (>= 64 here: pieces are that long at least)
+    auto fetch = [&](int64_t f, uint4 (&px)[4], uint32_t (&fw)[9]) {
+        const int64_t fc = f < full_frames ? f : full_frames - 1;
+        const uint4 *p = reinterpret_cast<const uint4 *>(src + fc * 32);
 #pragma unroll
-        for (int j = 0; j < 32; j++) x[j] = f * 32 + j < total_length ? (int)src[f * 32 + j] : 0;
+        for (int i = 0; i < 4; i++) px[i] = p[i];
+        const uint16_t *q = reinterpret_cast<const uint16_t *>(dst + fc * 18);
+#pragma unroll
+        for (int i = 0; i < 9; i++) fw[i] = q[i];
+    };
+    uint4 px[4], nx[4];
+    uint32_t ow[9], nw[9];
+    fetch(f0, px, ow);
+    for (int64_t f = f0; f < f0 + seg_frames && f * 32 < total_length; f++) {
+        fetch(f + 1, nx, nw);                           // in flight during this frame
+        int x[32];
+        if (f < full_frames) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t wv[4] = {px[i].x, px[i].y, px[i].z, px[i].w};
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    x[8 * i + 2 * t] = (int)(int16_t)(wv[t] & 0xFFFF);
+                    x[8 * i + 2 * t + 1] = (int)wv[t] >> 16;
+                }
+            }
+        } else {                                        // the zero-padded last frame: its own loads
+#pragma unroll
+            for (int j = 0; j < 32; j++) x[j] = f * 32 + j < total_length ? (int)src[f * 32 + j] : 0;
+            const uint16_t *q = reinterpret_cast<const uint16_t *>(dst + f * 18);
+#pragma unroll
+            for (int i = 0; i < 9; i++) ow[i] = q[i];
+        }
         // the guessed run's reconstruction of this frame (CriAdxCodec.Decode :23-45)
-        int scale = (int)(int16_t)(((fr[0] << 8) | fr[1]) & 0x1FFF);
+        int scale = (int)(int16_t)((((ow[0] & 0xff) << 8) | (ow[0] >> 8)) & 0x1FFF);
         scale = (int)(int16_t)(EXPONENTIAL ? (1 << ((12 - scale) & 31)) : scale + 1);
-#pragma unroll 4
+#pragma unroll
         for (int j = 0; j < 32; j++) {
-            const int byte = fr[2 + (j >> 1)];
+            const int bi = 2 + (j >> 1);                // frame byte
+            const int byte = (int)((ow[bi >> 1] >> (8 * (bi & 1))) & 0xff);
             int v = (j & 1) ? (byte & 0xF) : (byte >> 4);
             v = (v ^ 8) - 8;
             if (V4) v = scale * v + ((sb * c0 + sa * c1) >> 12);
@@ -817,8 +861,16 @@ __global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
             sa = sb;
             sb = clamp16(v);
         }
-        adx_encode_frame_serial<V4, EXPONENTIAL>(x, ta, tb, c0, c1, filter_bits, fr);
+        uint32_t fw[9];
+        adx_encode_frame_words<V4, EXPONENTIAL>(x, ta, tb, c0, c1, filter_bits, fw);
+        uint16_t *o = reinterpret_cast<uint16_t *>(dst + f * 18);
+#pragma unroll
+        for (int i = 0; i < 9; i++) o[i] = (uint16_t)fw[i];
         if (ta == sa && tb == sb && !seam_forced_open(force_open, ch, k)) return;   // closed: the rest of the piece stands
+#pragma unroll
+        for (int i = 0; i < 4; i++) px[i] = nx[i];
+#pragma unroll
+        for (int i = 0; i < 9; i++) ow[i] = nw[i];
     }
     atomicMin(&first_open[ch], k);
 }
