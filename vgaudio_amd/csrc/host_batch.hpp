@@ -57,7 +57,11 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     job.shared_streams = true;
     job.slot_bytes = o.slot_bytes > 0 ? (size_t)o.slot_bytes : (o.slot_bytes < -1 ? (size_t)(-o.slot_bytes) : (size_t)32 << 20);
     job.chunk_units = planned_chunk_units(job, default_chunk_units);
-    job.taper_min_units = std::max(1, job.chunk_units / 8);       // ..., chunk, chunk/2, chunk/4, chunk/8, chunk/8: what runs after the last upload is short
+    // the last chunk is split once, into (5/8, 3/8) of a chunk: the first part's kernels end about when the second part's
+    // upload does, so the tail of the call is one short chunk's kernels running alone (measured at 4096 x 60 s, tail =
+    // 192 / 256 / 320 / 384 / 448 / 512 of 1024: 555 / 545 / 539 / 519 / 528 / 529 ms; halving down to 1/8: 533 ms --
+    // short chunks that overlap slow each other down)
+    job.tail_units = std::max(1, job.chunk_units * 3 / 8);
     const pipe::Result r = pipe::run(job);
     pipe_report().stats = r.stats;
     if (r.code) {

@@ -117,6 +117,7 @@ struct Job {
     int chunk_units = 0;                 // kernels are launched per chunk of this many units
     int taper_min_units = 0;             // > 0: the LAST chunk is split into halves down to this size (chunk, ..., chunk/2,
                                          // chunk/4, chunk/4): what runs after the last upload is a small chunk's kernels
+    int tail_units = 0;                  // > 0 (takes precedence): the last chunk is split once, into (rest, tail_units)
     // input side (rows of in_row_bytes bytes at host pointers in_rows[r]; device row r at d_in + r * d_in_pitch)
     int in_rows_per_unit = 1;
     const void *const *in_rows = nullptr;
@@ -219,7 +220,11 @@ inline Result run(const Job &job)
     std::vector<int> cbegin;
     for (int u = 0; u < job.units; u += chunk_units) cbegin.push_back(u);
     cbegin.push_back(job.units);
-    if (job.taper_min_units > 0 && cbegin.size() >= 3) {   // at least two chunks: taper the last one
+    if (job.tail_units > 0 && cbegin.size() >= 3 && job.units - cbegin[cbegin.size() - 2] > job.tail_units) {
+        // two kernel lanes: the last chunk as (rest, tail) -- both run side by side, the short one last
+        cbegin.back() = job.units - job.tail_units;
+        cbegin.push_back(job.units);
+    } else if (job.taper_min_units > 0 && cbegin.size() >= 3) {   // at least two chunks: taper the last one
         int lo = cbegin[cbegin.size() - 2];
         const int hi = job.units;
         cbegin.pop_back();
