@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--seconds", type=float, default=60.0, help="audio seconds per channel @48 kHz")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-channels", type=int, default=0, help="units in the CPU baseline sample (0 = auto)")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the host-pointer ABI measurement (gc)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-pointer ABI measurement")
     ap.add_argument("--e2e-channels", type=int, default=0, help="channels of the e2e call (0 = as many of --channels as host memory allows)")
     return ap.parse_args()
 
@@ -207,21 +207,9 @@ def encode_benchmarks_single_thread(po, np):
             "GenerateCoefsAndEncode_Msamples_per_s": round(48000 / t_both / 1e6, 3)}
 
 
-def measure_e2e(cx, args, pcm, n, coefs_dev, adpcm_dev):
-    """One vga_gcadpcm_encode_batch call through the host-pointer ABI (pageable numpy rows in and out)."""
-    import numpy as np
-    torch, L, lib = cx.torch, cx.L, cx.lib
-    nch = pcm.shape[0]
-    nb = cx.vdev.gc_byte_count(n)
-    want = args.e2e_channels or nch
-    avail = host_memory_available()
-    per_ch = 2 * n + nb
-    note = None
-    if avail is not None and want * per_ch > 0.7 * avail:
-        fit = max(64, int(0.7 * avail / per_ch) // 64 * 64)
-        note = f"host memory allows {fit} of {want} channels ({avail / 2**30:.0f} GiB available)"
-        want = min(want, fit)
-    want = min(want, nch)
+def pcie_rates(cx):
+    """Page-locked copy rates of this box, GB/s: each direction alone (1 GiB) and both at once on two streams."""
+    torch = cx.torch
     # PCIe rate of this box from page-locked memory (what the pipeline's rings see), 1 GiB each way
     pin = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
     dbuf = torch.empty(1 << 30, dtype=torch.uint8, device=cx.dev)
@@ -248,6 +236,49 @@ def measure_e2e(cx, args, pcm, n, coefs_dev, adpcm_dev):
         torch.cuda.synchronize()
         rates["both_directions_aggregate"] = 4 * (1 << 30) / (time.perf_counter() - t0) / 1e9
     del pin, dbuf, pin2, dbuf2
+    return rates
+
+
+def pcie_bound_ms(rates, in_bytes, out_bytes):
+    """the larger direction alone, or all bytes at the measured two-way aggregate, whichever is longer"""
+    return max(in_bytes / rates["h2d"], out_bytes / rates["d2h"], (in_bytes + out_bytes) / rates["both_directions_aggregate"]) / 1e6
+
+
+def host_call_e2e(cx, entry_point, call, in_bytes, out_bytes, units, total_samples, identical):
+    """Times one host-pointer batch call (best of two after a warm-up call made by the caller) against the PCIe bound."""
+    rates = pcie_rates(cx)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        call()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    same = bool(identical())
+    if not same:
+        raise SystemExit(f"PARITY FAILURE: {entry_point} and the device-resident path disagree")
+    bound = pcie_bound_ms(rates, in_bytes, out_bytes)
+    return {"entry_point": entry_point + " (pageable host arrays in and out)", "units": units, "ms": round(best * 1e3, 1),
+            "value": round(total_samples / best / 1e6, 1), "unit": "Msamples/s", "host_bytes_in": in_bytes, "host_bytes_out": out_bytes,
+            "pcie_pinned_GBps": {k: round(v, 1) for k, v in rates.items()}, "pcie_bound_ms": round(bound, 1),
+            "ratio_to_pcie_bound": round(best * 1e3 / bound, 2), "identical_to_device_path": same}
+
+
+def measure_e2e(cx, args, pcm, n, coefs_dev, adpcm_dev):
+    """One vga_gcadpcm_encode_batch call through the host-pointer ABI (pageable numpy rows in and out)."""
+    import numpy as np
+    torch, L, lib = cx.torch, cx.L, cx.lib
+    nch = pcm.shape[0]
+    nb = cx.vdev.gc_byte_count(n)
+    want = args.e2e_channels or nch
+    avail = host_memory_available()
+    per_ch = 2 * n + nb
+    note = None
+    if avail is not None and want * per_ch > 0.7 * avail:
+        fit = max(64, int(0.7 * avail / per_ch) // 64 * 64)
+        note = f"host memory allows {fit} of {want} channels ({avail / 2**30:.0f} GiB available)"
+        want = min(want, fit)
+    want = min(want, nch)
+    rates = pcie_rates(cx)
     host = np.empty((want, n), dtype=np.int16)                       # pageable, like a managed short[][]
     for c0 in range(0, want, 256):
         host[c0:c0 + 256] = pcm[c0:c0 + 256, :n].cpu().numpy()
@@ -275,8 +306,7 @@ def measure_e2e(cx, args, pcm, n, coefs_dev, adpcm_dev):
     if not same:
         raise SystemExit("PARITY FAILURE: the host-pointer ABI and the device-resident path disagree")
     in_bytes, out_bytes = want * 2 * n, want * nb
-    # bound: the larger direction alone, or all bytes at the measured two-way aggregate, whichever is longer
-    pcie_ms = max(in_bytes / rates["h2d"], out_bytes / rates["d2h"], (in_bytes + out_bytes) / rates["both_directions_aggregate"]) / 1e6
+    pcie_ms = pcie_bound_ms(rates, in_bytes, out_bytes)
     e2e = {"entry_point": "vga_gcadpcm_encode_batch (pageable host arrays in and out)", "channels": want,
            "samples_per_channel": n, "ms": round(best * 1e3, 1), "value": round(want * n / best / 1e6, 1), "unit": "Msamples/s",
            "host_bytes_in": in_bytes, "host_bytes_out": out_bytes,
@@ -515,10 +545,34 @@ def run_adx(args, cx):
         cpu = {"value": round(cch * n / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
                "sample": f"{cch} of the same channels x {n} samples, encode + decode, one task per channel on {threads} threads "
                          f"({cpu_note}); C restatement of CriAdxFormat.EncodeFromPcm16 / ToPcm16, {dt:.1f} s wall"}
-    return base_line(args, cx, "Msamples/s (CRI ADX encode+decode round trip, 4096 ch)", value, ms_per_step, "int32",
+    e2e = None
+    if not args.no_e2e and cx.world == 1:
+        avail = host_memory_available()
+        want_ch = nch
+        if avail is not None and want_ch * (2 * n + nb) > 0.7 * avail:
+            want_ch = max(64, int(0.7 * avail / (2 * n + nb)) // 64 * 64)
+        want_ch = min(want_ch, nch)
+        host = np.empty((want_ch, n), dtype=np.int16)
+        for c0 in range(0, want_ch, 256):
+            host[c0:c0 + 256] = pcm[c0:c0 + 256, :n].cpu().numpy()
+        outs = np.zeros((want_ch, nb), dtype=np.uint8)
+        hh = np.zeros(want_ch, dtype=np.int16)
+        pp = (lib.i16p * want_ch)(*[host[c].ctypes.data_as(lib.i16p) for c in range(want_ch)])
+        op = (lib.u8p * want_ch)(*[outs[c].ctypes.data_as(lib.u8p) for c in range(want_ch)])
+        lib.check(L.vga_adx_encode_batch(pp, min(want_ch, 64), n, C.byref(p), op, hh.ctypes.data_as(lib.i16p)))     # warm-up
+        e2e = host_call_e2e(cx, "vga_adx_encode_batch",
+                            lambda: lib.check(L.vga_adx_encode_batch(pp, want_ch, n, C.byref(p), op, hh.ctypes.data_as(lib.i16p))),
+                            want_ch * 2 * n, want_ch * nb, want_ch, want_ch * n,
+                            lambda: np.array_equal(outs, adx[:want_ch, :nb].cpu().numpy()) and
+                            np.array_equal(hh, hist[:want_ch].cpu().numpy()))
+        del host, outs
+    out = base_line(args, cx, "Msamples/s (CRI ADX encode+decode round trip, 4096 ch)", value, ms_per_step, "int32",
                      f"BASELINE configs[2]: {nch} mono channels x 48 kHz x {args.seconds:g} s CRI ADX (18-byte frames, v4, "
                      f"linear) encode + decode round trip per GPU",
                      {"channels_per_gpu": nch, "samples_per_channel": n, "bit_exact_channels_checked": verified}, roofline, cpu)
+    if e2e:
+        out["e2e"] = e2e
+    return out
 
 
 # ====================================================================================================== CRI HCA
@@ -603,11 +657,35 @@ def run_hca(args, cx):
                "sample": f"{cs} of the same stereo streams x {n} samples, encode only, one task per STREAM on {workers} workers "
                          f"(the reference has no intra-file parallelism, CriHcaFormat.cs:53-81; Cli/Batch.cs:24-25 runs "
                          f"ProcessorCount-1 files at a time; {cpu_note}); C restatement of CriHcaFormat.EncodeFromPcm16, {dt:.1f} s wall"}
-    return base_line(args, cx, "Msamples/s encoded (CRI HCA, 1024 stereo streams, quality High; channel-samples)", value, ms_per_step,
+    e2e = None
+    if not args.no_e2e and cx.world == 1:
+        avail = host_memory_available()
+        want_s = ns
+        per_stream = 2 * 2 * n + fbytes
+        if avail is not None and want_s * per_stream > 0.7 * avail:
+            want_s = max(16, int(0.7 * avail / per_stream) // 16 * 16)
+        want_s = min(want_s, ns)
+        host = np.empty((want_s * 2, n), dtype=np.int16)
+        for c0 in range(0, want_s * 2, 256):
+            host[c0:c0 + 256] = spcm[c0:c0 + 256, :n].cpu().numpy()
+        outs = np.zeros((want_s, fbytes), dtype=np.uint8)
+        pp = (lib.i16p * (want_s * 2))(*[host[c].ctypes.data_as(lib.i16p) for c in range(want_s * 2)])
+        op = (lib.u8p * want_s)(*[outs[k].ctypes.data_as(lib.u8p) for k in range(want_s)])
+        info2 = lib.HcaInfoC()
+        lib.check(L.vga_hca_encode_batch(pp, min(want_s, 16), C.byref(hp), C.byref(info2), op))                     # warm-up
+        e2e = host_call_e2e(cx, "vga_hca_encode_batch",
+                            lambda: lib.check(L.vga_hca_encode_batch(pp, want_s, C.byref(hp), C.byref(info2), op)),
+                            want_s * 2 * 2 * n, want_s * fbytes, want_s, want_s * 2 * n,
+                            lambda: np.array_equal(outs, frames[:want_s, :fbytes].cpu().numpy()))
+        del host, outs
+    out = base_line(args, cx, "Msamples/s encoded (CRI HCA, 1024 stereo streams, quality High; channel-samples)", value, ms_per_step,
                      "f64", f"BASELINE configs[3]: {ns} stereo streams x 48 kHz x {args.seconds:g} s CRI HCA encode, quality High "
                             f"({info.frame_size}-byte frames, {info.frame_count} frames per stream) per GPU",
                      {"streams_per_gpu": ns, "channels_per_stream": 2, "samples_per_channel": n, "bit_exact_streams_checked": verified},
                      roofline, cpu)
+    if e2e:
+        out["e2e"] = e2e
+    return out
 
 
 def main():

@@ -910,14 +910,17 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
     if (fast) {
         const bool v4 = p.version == 4, ex = p.type == 4;
         const size_t lds = 2 * sizeof(AdxEncodeTile);
-        // as many time segments as fill the device once, each an even number of frames and at least 2048 frames long
+        // as many time segments as fill the device once, each an even number of frames and at least 8192 frames long: a
+        // seam still open at the end of its piece sends its channel to the serial tail kernel (0.7 s for a 60 s
+        // channel), and with 2048-frame pieces a 1024-channel launch (44 pieces, 44 000 seams) had such seams -- the host
+        // pipeline's chunks took 250 ms each instead of 10.  The longest seam seen at configs[2] is ~1100 frames.
         // (the seams re-encode some hundred frames each)
         const int groups = (nch + ECW - 1) / ECW, groups64 = (nch + 63) / 64;
         const int cus = device_cu_count();
         const int frames = (pcm_length + 31) / 32;
         const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
         int segments = cus * per_cu / groups;
-        if (segments > frames / 2048) segments = frames / 2048;
+        if (segments > frames / 8192) segments = frames / 8192;
         if (segments < 1) segments = 1;
         if (segments > 64) segments = 64;
         if (encoder_segments_override() > 0) segments = std::min(std::max(frames / 64, 1), encoder_segments_override());   // test hook
