@@ -983,7 +983,11 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
         int segments = cus * per_cu / groups;
         if (segments > frames / 512) segments = frames / 512;
         if (segments < 1) segments = 1;
-        if (segments > 64) segments = 64;
+        // at most 16 pieces: a seam that is still open at the end of its piece (an integer IIR can keep two runs one LSB
+        // apart for good) sends its channel to the serial tail kernel -- up to 220 ms for a 60 s channel -- and every
+        // piece boundary is one more chance of that: 256-channel chunks cut into 64 pieces hit it twice in 4096 channels
+        // (profiles/r02_c_adx_decode_timeline_open_seams.log)
+        if (segments > 16) segments = 16;
         int seg_frames = (frames + segments - 1) / segments;
         seg_frames += seg_frames & 1;
         AsyncBuf scratch;                              // freed (stream-ordered) on every exit path

@@ -22,6 +22,9 @@ inline int planned_chunk_units(const pipe::Job &job, int default_chunk_units)
     const size_t in_total = job.in_rows ? (size_t)job.units * job.in_rows_per_unit * job.in_row_bytes : 0;
     const size_t out_total = job.out_rows ? (size_t)job.units * job.out_rows_per_unit * job.out_row_bytes : 0;
     int chunk = o.chunk_units > 0 ? o.chunk_units : default_chunk_units;
+    // a call that downloads more than it uploads (a decode) is bound by the download, which cannot start before the first
+    // chunk's kernels have run: quarter chunks there (GC decode, 4096 x 60 s: the first download started at 87 ms)
+    if (o.chunk_units <= 0 && out_total > in_total) chunk = std::max(1, chunk / 4);
     // small batches: one chunk (a chunk boundary only pays when the upload of the next chunk is worth hiding)
     if (o.chunk_units <= 0 && in_total + out_total < ((size_t)256 << 20)) chunk = job.units;
     return std::max(1, std::min(chunk, job.units));
@@ -48,12 +51,14 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     // two drainer threads hand the rows out.  So: one feeder with direct uploads, two drainers behind a ring, all
     // uploads on one stream and all downloads on another (a slot = the rows a worker takes at a time); slot_bytes < 0
     // (testing hook) makes both directions direct, > 0 both staged.
-    (void)in_total;
     job.feeders = o.feeders > 0 ? o.feeders : 1;
     job.drainers = o.drainers > 0 ? o.drainers : (out_total >= ((size_t)256 << 20) ? 2 : 1);
     // rows worth page-locking one by one: from 256 KB on (smaller rows are cheap to copy into the ring)
     job.direct = o.slot_bytes < 0 || (o.slot_bytes == 0 && job.in_row_bytes >= ((size_t)256 << 10));
-    job.direct_out = o.slot_bytes < 0;
+    // downloads: through the ring when they are the smaller direction (an encode), direct into page-locked caller rows
+    // when they are the larger one (a decode: 23.6 GB of PCM through two memcpy threads would be the bottleneck;
+    // tools/time_decode_batches.py: ADX 582 -> 527 ms, HCA 323 -> 271 ms)
+    job.direct_out = o.slot_bytes < 0 || (o.slot_bytes == 0 && job.out_row_bytes >= ((size_t)256 << 10) && out_total > in_total);
     job.shared_streams = true;
     job.slot_bytes = o.slot_bytes > 0 ? (size_t)o.slot_bytes : (o.slot_bytes < -1 ? (size_t)(-o.slot_bytes) : (size_t)32 << 20);
     job.chunk_units = planned_chunk_units(job, default_chunk_units);
