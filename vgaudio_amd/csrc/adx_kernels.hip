@@ -987,7 +987,9 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
         // apart for good) sends its channel to the serial tail kernel -- up to 220 ms for a 60 s channel -- and every
         // piece boundary is one more chance of that: 256-channel chunks cut into 64 pieces hit it twice in 4096 channels
         // (profiles/r02_c_adx_decode_timeline_open_seams.log)
-        if (segments > 16) segments = 16;
+        // (a few channels may have more: the seams of a launch stay below ~4000 there)
+        if (segments > std::max(16, 4096 / nch)) segments = std::max(16, 4096 / nch);
+        if (segments > 64) segments = 64;
         int seg_frames = (frames + segments - 1) / segments;
         seg_frames += seg_frames & 1;
         AsyncBuf scratch;                              // freed (stream-ordered) on every exit path

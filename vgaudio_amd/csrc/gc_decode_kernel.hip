@@ -315,7 +315,9 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
     int segments = cus / groups;
     if (segments > frames / 1024) segments = frames / 1024;
     if (segments < 1) segments = 1;
-    if (segments > 16) segments = 16;                  // every seam is a chance of a run that never meets: see adx_kernels.hip
+    // every seam is a chance of a run that never meets (see adx_kernels.hip): at most 16 pieces, or ~4000 seams per launch
+    const int piece_cap = 4096 / nch > 16 ? (4096 / nch > 64 ? 64 : 4096 / nch) : 16;
+    if (segments > piece_cap) segments = piece_cap;
     const int seg_frames = (frames + segments - 1) / segments;
     hipLaunchKernelGGL(gc_decode_kernel, dim3(groups, segments), dim3(DTHREADS), lds, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
                        sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
