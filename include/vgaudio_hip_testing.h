@@ -25,8 +25,9 @@ int vga_testing_gc_encoder_layout_this_thread(int channels_per_wave);
  * (the product), 1 = one wave per channel, 2 = workgroups of four channels and a summing wave.  Same coefficients.
  * Returns the previous value; other arguments leave it unchanged. */
 int vga_testing_gc_coefs_variant_this_thread(int variant);
-/* Forces the number of time pieces a channel is cut into by the GC-ADPCM encoder (0 = the launcher's own choice: what
- * fills the chip), for calls made from the calling thread.  Results must not depend on it.  Returns the previous value. */
+/* Forces the number of time pieces a channel is cut into by the kernels that speculate over time -- the GC-ADPCM and ADX
+ * encoders (pieces of 64 frames or more) and decoders (8 frames or more) -- for calls made from the calling thread (0 = the
+ * launcher's own choice).  Results must not depend on it.  Returns the previous value. */
 int vga_testing_gc_encoder_segments_this_thread(int segments);
 
 /* The host-pointer entry points (vga_*_batch) move data through a pipeline of feeder threads, pinned rings, per-chunk

@@ -192,3 +192,46 @@ def test_time_segment_fallbacks_are_exact():
         want = po.adx_encode(host, op)
         assert (normal[1][c].cpu().numpy() == want).all()
         assert (normal[2][c].cpu().numpy() == po.adx_decode(want, n, po.adx_params())).all()
+
+
+@pytest.mark.parametrize("pieces", [40, 700, 3000])
+def test_decoders_with_short_pieces_chain_their_open_seams(pieces):
+    """Pieces of a few frames: many seams are still open when their piece ends, several in a row, so the chained tail
+    kernels produce much of the output (with mode 2 some seams are never accepted as closed on top of that).  The PCM is
+    the oracle's."""
+    d = torch.device("cuda:0")
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    nch, n = 70, 32 * 14 * 55 + 5
+    pcm = vdev.synth_pcm(nch, n, d)
+    coefs = vdev.gc_coefs(pcm, n)
+    adpcm = vdev.gc_encode(pcm, n, coefs)
+    p = _lib.AdxParams()
+    L.vga_adx_default_params(C.byref(p))
+    nb = L.vga_adx_encoded_byte_count(n, C.byref(p))
+    pitch = (nb + 15) // 16 * 16
+    adx = torch.zeros((nch, pitch), dtype=torch.uint8, device=d)
+    hist = torch.zeros(nch, dtype=torch.int16, device=d)
+    status = torch.zeros(1, dtype=torch.int32, device=d)
+    _lib.check(L.vga_adx_encode_device(pcm.data_ptr(), pcm.stride(0), nch, n, C.byref(p), adx.data_ptr(), pitch, hist.data_ptr(), st))
+    torch.cuda.synchronize()
+    want_gc = [po.gc_decode(adpcm[c, :vdev.gc_byte_count(n)].cpu().numpy(), coefs[c].cpu().numpy(), n) for c in (0, 33, 69)]
+    want_adx = po.adx_decode_batch(adx[:, :nb].cpu().numpy()[[0, 33, 69]], n, po.adx_params(), threads=3)
+    L.vga_testing_gc_encoder_segments_this_thread(pieces)
+    try:
+        for mode in (0, 2):
+            old = L.vga_testing_force_open_seams_this_thread(mode)
+            try:
+                dec, _ = vdev.gc_decode(adpcm, coefs, n)
+                back = vdev.alloc_pcm(nch, n, d)
+                _lib.check(L.vga_adx_decode_device(adx.data_ptr(), pitch, nb, nch, n, C.byref(p), back.data_ptr(), back.stride(0),
+                                                   status.data_ptr(), st))
+                torch.cuda.synchronize()
+            finally:
+                L.vga_testing_force_open_seams_this_thread(old)
+            for i, c in enumerate((0, 33, 69)):
+                assert np.array_equal(dec[c, :n].cpu().numpy(), want_gc[i]), (pieces, mode, c)
+                assert np.array_equal(back[c, :n].cpu().numpy(), want_adx[i]), (pieces, mode, c)
+    finally:
+        L.vga_testing_gc_encoder_segments_this_thread(0)
+

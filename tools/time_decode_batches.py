@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--modes", default="0,0,0,0;1,1,0,-1")
     ap.add_argument("--codecs", default="gc,adx,hca")
+    ap.add_argument("--pieces", type=int, default=0, help="force the decoders' time pieces per channel (0 = the launcher's choice)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -30,6 +31,7 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     n = int(args.seconds * 48000)
     modes = [tuple(int(v) for v in m.split(",")) for m in args.modes.split(";")]
+    L.vga_testing_gc_encoder_segments_this_thread(args.pieces)
 
     def timed(name, call, in_bytes, out_bytes, check):
         for mode in modes:

@@ -458,7 +458,7 @@ __device__ __forceinline__ void adx_decode_frame_serial(const uint8_t *fr, const
 template <bool V4>
 __global__ __launch_bounds__(64) void adx_decode_fs18_fixup_kernel(
     const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, AdxDeviceParams p,
-    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ first_open, int force_open)
+    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ first_open, int *__restrict__ seam_open, int force_open)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     const int k = blockIdx.y + 1;
@@ -479,28 +479,55 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_fixup_kernel(
         if (valid == 32 && hist1 == g1 && hist2 == g2 && !seam_forced_open(force_open, ch, k)) return;
         if (valid < 32) return;                         // the stream's last, partial frame: nothing follows
     }
-    if (f0 + seg_frames < ((int64_t)total_samples + 31) / 32) atomicMin(&first_open[ch], k);   // open, and a piece follows
+    if (f0 + seg_frames < ((int64_t)total_samples + 31) / 32) {   // open, and a piece follows
+        seam_open[(int64_t)(k - 1) * nch + ch] = 1;
+        atomicMin(&first_open[ch], k);
+    }
 }
 
 // Channels with an open seam (practically none): decode serially from the piece after it to the end of the stream.
+// The channels with an open seam, piece after piece -- as gc_decode_tail_kernel (gc_decode_kernel.hip): the piece after
+// an open seam is decoded again from the final samples until it agrees with what the piece holds at a frame end; a run
+// that does not meet carries on into the next piece; a later open seam starts the same again.
 template <bool V4>
 __global__ __launch_bounds__(64) void adx_decode_fs18_tail_kernel(
-    const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, AdxDeviceParams p,
-    int16_t *__restrict__ pcm, int64_t pcm_pitch, const int *__restrict__ first_open)
+    const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, int segments, AdxDeviceParams p,
+    int16_t *__restrict__ pcm, int64_t pcm_pitch, const int *__restrict__ first_open, const int *__restrict__ seam_open,
+    int force_open)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= nch) return;
-    const int k = first_open[ch];
-    if (k <= 0 || k >= 0x7f000000) return;
+    const int k0 = first_open[ch];
+    if (k0 <= 0 || k0 >= 0x7f000000) return;
     const uint8_t *src = adpcm + (int64_t)ch * in_pitch;
     int16_t *dst = pcm + (int64_t)ch * pcm_pitch;
-    // seam k ran to the end of piece k (so that piece is final now); everything after it was seeded from samples
-    // that have changed since
-    const int64_t f0 = (int64_t)(k + 1) * seg_frames;
-    int hist1 = dst[f0 * 32 - 1], hist2 = dst[f0 * 32 - 2];
-    for (int64_t f = f0; f * 32 < total_samples; f++) {
-        const int valid = (int)((int64_t)total_samples - f * 32 < 32 ? (int64_t)total_samples - f * 32 : 32);
-        adx_decode_frame_serial<V4>(src + f * 18, p, valid, hist1, hist2, dst + f * 32);
+    bool carry = false;
+    int hist1 = 0, hist2 = 0;
+    for (int k = k0; k < segments; k++) {
+        const int64_t f0 = (int64_t)k * seg_frames;
+        if (f0 * 32 >= total_samples) break;
+        const bool flagged = seam_open[(int64_t)(k - 1) * nch + ch] != 0;
+        bool apart = false;
+        if (carry) {
+            apart = true;
+            for (int64_t f = f0; f < f0 + seg_frames && f * 32 < total_samples; f++) {
+                const int valid = (int)((int64_t)total_samples - f * 32 < 32 ? (int64_t)total_samples - f * 32 : 32);
+                int16_t *o = dst + f * 32;
+                int g1 = 0, g2 = 0;
+                if (valid == 32) { g1 = o[31]; g2 = o[30]; }
+                adx_decode_frame_serial<V4>(src + f * 18, p, valid, hist1, hist2, o);
+                if (valid == 32 && hist1 == g1 && hist2 == g2 && !seam_forced_open(force_open, ch, k)) { apart = false; break; }
+            }
+        }
+        const int64_t f1 = f0 + seg_frames;
+        if (apart) {
+            carry = true;
+        } else if (flagged && f1 * 32 < total_samples) {
+            carry = true;
+            hist1 = dst[f1 * 32 - 1];
+            hist2 = dst[f1 * 32 - 2];
+        } else
+            carry = false;
     }
 }
 
@@ -990,14 +1017,18 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
         // (a few channels may have more: the seams of a launch stay below ~4000 there)
         if (segments > std::max(16, 4096 / nch)) segments = std::max(16, 4096 / nch);
         if (segments > 64) segments = 64;
+        if (encoder_segments_override() > 0) segments = std::min(std::max(frames / 8, 1), encoder_segments_override());   // test hook
         int seg_frames = (frames + segments - 1) / segments;
         seg_frames += seg_frames & 1;
         AsyncBuf scratch;                              // freed (stream-ordered) on every exit path
-        int *first_open = nullptr;
+        int *first_open = nullptr, *seam_open = nullptr;
         if (segments > 1) {
-            VGA_HIP_TRY(scratch.alloc((size_t)nch * sizeof(int), stream));
+            const size_t flag_bytes = (size_t)(segments - 1) * nch * sizeof(int);
+            VGA_HIP_TRY(scratch.alloc((size_t)nch * sizeof(int) + flag_bytes, stream));
             first_open = scratch.as<int>();
+            seam_open = first_open + nch;
             VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
+            VGA_HIP_TRY(hipMemsetAsync(seam_open, 0, flag_bytes, stream));
         }
 #define VGA_ADX_DEC_T(V)                                                                                                 \
         {                                                                                                                \
@@ -1007,10 +1038,11 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
             if (segments > 1) {                                                                                          \
                 hipLaunchKernelGGL(adx_decode_fs18_fixup_kernel<V>, dim3(groups, segments - 1), dim3(64), 0, stream,    \
                                    d_adpcm, in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, first_open,   \
-                                   force_open_seams());                                                          \
+                                   seam_open, force_open_seams());                                                      \
                 VGA_HIP_TRY(hipGetLastError());                                                                          \
                 hipLaunchKernelGGL(adx_decode_fs18_tail_kernel<V>, dim3(groups), dim3(64), 0, stream, d_adpcm, in_pitch, \
-                                   nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, first_open);                      \
+                                   nch, sample_count, seg_frames, segments, p, d_pcm, pcm_pitch, first_open, seam_open,  \
+                                   force_open_seams());                                                                  \
             }                                                                                                            \
         }
         if (p.version == 4) VGA_ADX_DEC_T(true)

@@ -12,6 +12,8 @@
 //     conflict-free b128 per lane; they also write the previous tile's samples to global memory;
 //   decoder wave (lane = channel, 64 channels per workgroup): per sample mad, mad, shift, clamp.
 #include "common.hpp"
+
+#include <algorithm>
 #include "gcadpcm_kernels.hpp"
 
 #include <cstdlib>
@@ -244,7 +246,7 @@ __device__ __forceinline__ void gc_decode_frame_serial(const uint8_t *fr, const 
 __global__ __launch_bounds__(64) void gc_decode_fixup_kernel(
     const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
     int total_samples, int seg_frames, int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ first_open,
-    int force_open)
+    int *__restrict__ seam_open, int force_open)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     const int k = blockIdx.y + 1;
@@ -273,30 +275,63 @@ __global__ __launch_bounds__(64) void gc_decode_fixup_kernel(
         if (valid == 14 && h1 == g1 && h2 == g2 && !seam_forced_open(force_open, ch, k)) return;
         if (valid < 14) return;                        // the stream's last, partial frame: nothing follows
     }
-    if ((f0 + seg_frames) * 14 < total_samples) atomicMin(&first_open[ch], k);   // open, and a piece follows
+    if ((f0 + seg_frames) * 14 < total_samples) {      // open, and a piece follows
+        seam_open[(int64_t)(k - 1) * nch + ch] = 1;
+        atomicMin(&first_open[ch], k);
+    }
 }
 
 // Channels with an open seam (practically none): seam k re-decoded all of piece k, so that piece is final; everything
 // after it was seeded from samples that have changed since and is decoded again here, serially.
+// The channels with an open seam, piece after piece (one lane per channel; lanes without one leave at once).  A seam
+// that ran out of frames has made ITS piece final, but the piece after it was seeded from samples that have changed
+// since: that piece is decoded again from the final samples -- next to what it holds, which is a run of the same
+// recurrence from some other history -- until both agree at a frame end; from there on the stored samples are the
+// serial decoder's.  (Round 1 decoded the whole rest of the channel again: 220 ms for a 60 s channel.)  A run that
+// does not meet by the end of a piece carries on into the next one; a later open seam of the channel starts the same
+// again.  seam_open[(k - 1) * nch + ch] != 0: seam k (the start of piece k) stayed open.
 __global__ __launch_bounds__(64) void gc_decode_tail_kernel(
     const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
-    int total_samples, int seg_frames, int16_t *__restrict__ pcm, int64_t pcm_pitch, const int *__restrict__ first_open)
+    int total_samples, int seg_frames, int segments, int16_t *__restrict__ pcm, int64_t pcm_pitch,
+    const int *__restrict__ first_open, const int *__restrict__ seam_open, int force_open)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= nch) return;
-    const int k = first_open[ch];
-    if (k <= 0 || k >= 0x7f000000) return;
+    const int k0 = first_open[ch];
+    if (k0 <= 0 || k0 >= 0x7f000000) return;
     const uint8_t *src = adpcm + (int64_t)ch * adpcm_pitch;
     int16_t *dst = pcm + (int64_t)ch * pcm_pitch;
     int cf[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) cf[i] = coefs[ch * 16 + i];
     const int full_frames = total_samples / 14;
-    const int64_t f0 = (int64_t)(k + 1) * seg_frames;
-    int h1 = dst[f0 * 14 - 1], h2 = dst[f0 * 14 - 2];
-    for (int64_t f = f0; f * 14 < total_samples; f++) {
-        const int valid = f < full_frames ? 14 : total_samples - (int)(f * 14);
-        gc_decode_frame_serial(src + f * 8, cf, valid, h1, h2, dst + f * 14);
+    bool carry = false;                                // the piece before ended on samples other than the ones this piece was seeded from
+    int h1 = 0, h2 = 0;
+    for (int k = k0; k < segments; k++) {
+        const int64_t f0 = (int64_t)k * seg_frames;
+        if (f0 * 14 >= total_samples) break;
+        const bool flagged = seam_open[(int64_t)(k - 1) * nch + ch] != 0;
+        bool apart = false;
+        if (carry) {
+            apart = true;
+            for (int64_t f = f0; f < f0 + seg_frames && f * 14 < total_samples; f++) {
+                const int valid = f < full_frames ? 14 : total_samples - (int)(f * 14);
+                int16_t *o = dst + f * 14;
+                int g1 = 0, g2 = 0;
+                if (valid == 14) { g1 = o[13]; g2 = o[12]; }
+                gc_decode_frame_serial(src + f * 8, cf, valid, h1, h2, o);
+                if (valid == 14 && h1 == g1 && h2 == g2 && !seam_forced_open(force_open, ch, k)) { apart = false; break; }
+            }
+        }
+        const int64_t f1 = f0 + seg_frames;            // the next piece's first frame
+        if (apart) {
+            carry = true;                              // (h1, h2): the true samples at the end of this piece
+        } else if (flagged && f1 * 14 < total_samples) {
+            carry = true;                              // this piece's own seam ran out of frames: the piece is final, its end the truth
+            h1 = dst[f1 * 14 - 1];
+            h2 = dst[f1 * 14 - 2];
+        } else
+            carry = false;
     }
 }
 
@@ -318,20 +353,24 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
     // every seam is a chance of a run that never meets (see adx_kernels.hip): at most 16 pieces, or ~4000 seams per launch
     const int piece_cap = 4096 / nch > 16 ? (4096 / nch > 64 ? 64 : 4096 / nch) : 16;
     if (segments > piece_cap) segments = piece_cap;
+    if (encoder_segments_override() > 0) segments = std::min(std::max(frames / 8, 1), encoder_segments_override());   // test hook
     const int seg_frames = (frames + segments - 1) / segments;
     hipLaunchKernelGGL(gc_decode_kernel, dim3(groups, segments), dim3(DTHREADS), lds, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
                        sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
     VGA_HIP_TRY(hipGetLastError());
     if (segments > 1) {
         AsyncBuf scratch;                              // freed (stream-ordered) on every exit path
-        VGA_HIP_TRY(scratch.alloc((size_t)nch * sizeof(int), stream));
+        const size_t flag_bytes = (size_t)(segments - 1) * nch * sizeof(int);
+        VGA_HIP_TRY(scratch.alloc((size_t)nch * sizeof(int) + flag_bytes, stream));
         int *first_open = scratch.as<int>();
+        int *seam_open = first_open + nch;
         VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
+        VGA_HIP_TRY(hipMemsetAsync(seam_open, 0, flag_bytes, stream));
         hipLaunchKernelGGL(gc_decode_fixup_kernel, dim3((nch + 63) / 64, segments - 1), dim3(64), 0, stream, d_adpcm, adpcm_pitch,
-                           d_coefs, nch, sample_count, seg_frames, d_pcm, pcm_pitch, first_open, force_open_seams());
+                           d_coefs, nch, sample_count, seg_frames, d_pcm, pcm_pitch, first_open, seam_open, force_open_seams());
         VGA_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(gc_decode_tail_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
-                           sample_count, seg_frames, d_pcm, pcm_pitch, first_open);
+                           sample_count, seg_frames, segments, d_pcm, pcm_pitch, first_open, seam_open, force_open_seams());
         VGA_HIP_TRY(hipGetLastError());
     }
     return VGA_OK;
