@@ -235,3 +235,36 @@ def test_decoders_with_short_pieces_chain_their_open_seams(pieces):
     finally:
         L.vga_testing_gc_encoder_segments_this_thread(0)
 
+
+@pytest.mark.parametrize("n", [32 * 64 * 40, 32 * 64 * 40 + 7])
+def test_adx_encoder_with_short_pieces_chains_its_open_seams(n):
+    """64-frame pieces: the ADX encoder's seams need ~100 frames to close, so most are still open at the end of their piece
+    and the chained tail kernel produces most of the stream.  Bytes and history are the oracle's."""
+    d = torch.device("cuda:0")
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    nch = 70
+    pcm = vdev.synth_pcm(nch, n, d)
+    p = _lib.AdxParams()
+    L.vga_adx_default_params(C.byref(p))
+    nb = L.vga_adx_encoded_byte_count(n, C.byref(p))
+    pitch = (nb + 15) // 16 * 16
+    host = pcm[:, :n].cpu().numpy()
+    want, whist = po.adx_encode_batch(host, po.adx_params(), threads=4)
+    L.vga_testing_gc_encoder_segments_this_thread(1000)
+    try:
+        for mode in (0, 2):
+            old = L.vga_testing_force_open_seams_this_thread(mode)
+            try:
+                adx = torch.zeros((nch, pitch), dtype=torch.uint8, device=d)
+                hist = torch.zeros(nch, dtype=torch.int16, device=d)
+                _lib.check(L.vga_adx_encode_device(pcm.data_ptr(), pcm.stride(0), nch, n, C.byref(p), adx.data_ptr(), pitch,
+                                                   hist.data_ptr(), st))
+                torch.cuda.synchronize()
+            finally:
+                L.vga_testing_force_open_seams_this_thread(old)
+            assert np.array_equal(adx[:, :nb].cpu().numpy(), want), mode
+            assert np.array_equal(hist.cpu().numpy(), whist), mode
+    finally:
+        L.vga_testing_gc_encoder_segments_this_thread(0)
+

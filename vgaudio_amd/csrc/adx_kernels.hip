@@ -822,22 +822,14 @@ __device__ __forceinline__ void adx_encode_frame_serial(const int (&x)[32], int 
     }
 }
 
+// From the TRUE history (ta, tb) at the start of piece k: encode again frame by frame next to a replay of the run whose
+// bytes the piece holds (decoded from ITS start history (sa, sb), before they are overwritten), until both histories
+// coincide at a frame end.  Returns true when the piece ended first; (ta, tb) is then the true history at its end.
 template <bool V4, bool EXPONENTIAL>
-__global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
-    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, AdxDeviceParams p,
-    uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state, int *__restrict__ first_open,
-    int force_open)
+__device__ __forceinline__ bool adx_encode_seam_run(const int16_t *__restrict__ src, uint8_t *__restrict__ dst, int64_t f0, int seg_frames,
+                                                    int total_length, int c0, int c1, int filter_bits, int &ta, int &tb, int sa, int sb,
+                                                    int ch, int k, int force_open)
 {
-    const int ch = blockIdx.x * 64 + threadIdx.x;
-    const int k = blockIdx.y + 1;
-    const int64_t f0 = (int64_t)k * seg_frames;
-    if (ch >= nch || f0 * 32 >= total_length) return;
-    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
-    uint8_t *dst = out + (int64_t)ch * out_pitch;
-    const int c0 = p.coef0, c1 = p.coef1;
-    const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
-    int ta = seg_state[((int64_t)(k - 1) * nch + ch) * 2], tb = seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1];
-    int sa = src[f0 * 32 - 2], sb = src[f0 * 32 - 1];                             // the guessed run's start
     // lane = channel, so every load of the wave touches 64 different rows: a frame is fetched as four 16-byte loads of PCM
     // and nine 16-bit loads of the old frame (instead of 32 + 18 scalar loads), one frame ahead of its use (clamped,
     // unconditional), and leaves as nine 16-bit stores.  All lanes of a wave are at the same frame (same seam index).
@@ -893,38 +885,82 @@ __global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
         uint16_t *o = reinterpret_cast<uint16_t *>(dst + f * 18);
 #pragma unroll
         for (int i = 0; i < 9; i++) o[i] = (uint16_t)fw[i];
-        if (ta == sa && tb == sb && !seam_forced_open(force_open, ch, k)) return;   // closed: the rest of the piece stands
+        if (ta == sa && tb == sb && !seam_forced_open(force_open, ch, k)) return false;   // closed: the rest of the piece stands
 #pragma unroll
         for (int i = 0; i < 4; i++) px[i] = nx[i];
 #pragma unroll
         for (int i = 0; i < 9; i++) ow[i] = nw[i];
     }
-    atomicMin(&first_open[ch], k);
+    return true;
 }
 
-// Channels with an open seam (practically none): encode serially from that piece to the end of the stream.
 template <bool V4, bool EXPONENTIAL>
-__global__ __launch_bounds__(64) void adx_encode_fs18_tail_kernel(
+__global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, AdxDeviceParams p,
-    uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state, const int *__restrict__ first_open)
+    uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state, int *__restrict__ first_open,
+    int *__restrict__ seam_open, int *__restrict__ seam_end, int force_open)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= nch) return;
-    const int k = first_open[ch];
-    if (k <= 0 || k >= 0x7f000000) return;
+    const int k = blockIdx.y + 1;
+    const int64_t f0 = (int64_t)k * seg_frames;
+    if (ch >= nch || f0 * 32 >= total_length) return;
     const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
     uint8_t *dst = out + (int64_t)ch * out_pitch;
     const int c0 = p.coef0, c1 = p.coef1;
     const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
-    // pieces before k closed their seams, so piece k - 1 ended on the real history
-    int a = seg_state[((int64_t)(k - 1) * nch + ch) * 2], b = seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1];
-    for (int64_t f = (int64_t)k * seg_frames; f * 32 < total_length; f++) {
-        int x[32];
-#pragma unroll
-        for (int j = 0; j < 32; j++) x[j] = f * 32 + j < total_length ? (int)src[f * 32 + j] : 0;
-        adx_encode_frame_serial<V4, EXPONENTIAL>(x, a, b, c0, c1, filter_bits, dst + f * 18);
+    int ta = seg_state[((int64_t)(k - 1) * nch + ch) * 2], tb = seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1];
+    const int sa = src[f0 * 32 - 2], sb = src[f0 * 32 - 1];                       // the guessed run's start
+    if (adx_encode_seam_run<V4, EXPONENTIAL>(src, dst, f0, seg_frames, total_length, c0, c1, filter_bits, ta, tb, sa, sb, ch, k,
+                                             force_open)) {
+        // still open at the end of its piece: the chain launch carries on from the history reached here
+        seam_open[(int64_t)(k - 1) * nch + ch] = 1;
+        seam_end[(int64_t)(k - 1) * nch + ch] = (int)(((unsigned)tb << 16) | ((unsigned)ta & 0xFFFFu));
+        atomicMin(&first_open[ch], k);
     }
 }
+
+// The channels with an open seam, piece after piece (one lane per channel; lanes without one leave at once) -- the
+// encoder's counterpart of the decoders' chained tail kernels and of gc_encode_chain_kernel: where the true history at
+// the start of piece k is not seg_state[k - 1], which the fix-up launch assumed, the piece holds the run from
+// seg_state[k - 1]; the same seam run from the true history finds where the two meet.  A run that does not meet by the
+// end of the piece carries on; a later open seam of the channel starts again from its recorded end.  (Round 1 encoded
+// the rest of the channel serially: 0.7 s for a 60 s channel.)
+template <bool V4, bool EXPONENTIAL>
+__global__ __launch_bounds__(64) void adx_encode_fs18_tail_kernel(
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, int segments, AdxDeviceParams p,
+    uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state, const int *__restrict__ first_open,
+    const int *__restrict__ seam_open, const int *__restrict__ seam_end, int force_open)
+{
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= nch) return;
+    const int k0 = first_open[ch];
+    if (k0 <= 0 || k0 >= 0x7f000000) return;
+    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
+    uint8_t *dst = out + (int64_t)ch * out_pitch;
+    const int c0 = p.coef0, c1 = p.coef1;
+    const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
+    bool carry = false;
+    int ta = 0, tb = 0;
+    for (int k = k0; k < segments; k++) {
+        const int64_t f0 = (int64_t)k * seg_frames;
+        if (f0 * 32 >= total_length) break;
+        const int64_t idx = (int64_t)(k - 1) * nch + ch;
+        bool apart = false;
+        if (carry)
+            apart = adx_encode_seam_run<V4, EXPONENTIAL>(src, dst, f0, seg_frames, total_length, c0, c1, filter_bits, ta, tb,
+                                                         seg_state[idx * 2], seg_state[idx * 2 + 1], ch, k, force_open);
+        if (apart) {
+            carry = true;                              // (ta, tb): the true history at the end of this piece
+        } else if (seam_open[idx] != 0) {
+            carry = true;                              // this piece's own seam ran out of frames: its recorded end is the truth
+            const int e = seam_end[idx];
+            ta = (int)(int16_t)(e & 0xFFFF);
+            tb = e >> 16;
+        } else
+            carry = false;
+    }
+}
+
 
 int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_length, const AdxDeviceParams &p,
                   uint8_t *d_out, int64_t out_pitch, int16_t *d_history_out, hipStream_t stream)
@@ -955,13 +991,17 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
         seg_frames += seg_frames & 1;
         AsyncBuf scratch;                              // freed (stream-ordered) on every exit path
         int16_t *seg_state = nullptr;                  // [segments][nch][2] final histories, then [nch] first open seam
-        int *first_open = nullptr;
+        int *first_open = nullptr, *seam_open = nullptr, *seam_end = nullptr;
         if (segments > 1) {
             const size_t state_bytes = round_up((size_t)segments * nch * 2 * sizeof(int16_t), 16);
-            VGA_HIP_TRY(scratch.alloc(state_bytes + (size_t)nch * sizeof(int), stream));
+            const size_t flag_bytes = (size_t)(segments - 1) * nch * sizeof(int);
+            VGA_HIP_TRY(scratch.alloc(state_bytes + (size_t)nch * sizeof(int) + 2 * flag_bytes, stream));
             seg_state = scratch.as<int16_t>();
             first_open = reinterpret_cast<int *>(scratch.as<unsigned char>() + state_bytes);
+            seam_open = first_open + nch;
+            seam_end = seam_open + (size_t)(segments - 1) * nch;
             VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
+            VGA_HIP_TRY(hipMemsetAsync(seam_open, 0, flag_bytes, stream));
         }
 #define VGA_ADX_ENC_T(V, E)                                                                                              \
         {                                                                                                                \
@@ -972,10 +1012,11 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
             if (segments > 1) {                                                                                          \
                 hipLaunchKernelGGL((adx_encode_fs18_fixup_kernel<V, E>), dim3(groups64, segments - 1), dim3(64), 0, stream, \
                                    d_pcm, pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, seg_state,       \
-                                   first_open, force_open_seams());                                              \
+                                   first_open, seam_open, seam_end, force_open_seams());                                \
                 VGA_HIP_TRY(hipGetLastError());                                                                          \
                 hipLaunchKernelGGL((adx_encode_fs18_tail_kernel<V, E>), dim3(groups64), dim3(64), 0, stream, d_pcm,     \
-                                   pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, seg_state, first_open); \
+                                   pcm_pitch, nch, pcm_length, seg_frames, segments, p, d_out, out_pitch, seg_state,    \
+                                   first_open, seam_open, seam_end, force_open_seams());                                \
             }                                                                                                            \
         }
         if (v4 && ex) VGA_ADX_ENC_T(true, true)
