@@ -624,7 +624,7 @@ int vga_gcadpcm_encode_batch(const int16_t *const *pcm, int nch, int sample_coun
         return rc;
     };
     const int chunk = planned_chunk_units(job, GC_CHUNK_CHANNELS);
-    const int lanes_used = chunk < nch ? job.compute_lanes : 1;       // one chunk: one lane
+    const int lanes_used = nch > 1 ? job.compute_lanes : 1;           // (a single chunk is split in two as well)
     for (int l = 0; l < lanes_used; l++) {
         VGA_HIP_TRY(scratch[l].alloc(gc::encode_scratch_bytes(chunk)));
         VGA_HIP_TRY(ws[l].alloc(vga_gcadpcm_coefs_workspace_bytes(chunk, sample_count)));

@@ -66,7 +66,7 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     // upload does, so the tail of the call is one short chunk's kernels running alone (measured at 4096 x 60 s, tail =
     // 192 / 256 / 320 / 384 / 448 / 512 of 1024: 555 / 545 / 539 / 519 / 528 / 529 ms; halving down to 1/8: 533 ms --
     // short chunks that overlap slow each other down)
-    job.tail_units = std::max(1, job.chunk_units * 3 / 8);
+    job.tail_units = in_total + out_total >= ((size_t)256 << 20) ? std::max(1, job.chunk_units * 3 / 8) : 0;   // small calls: one chunk
     const pipe::Result r = pipe::run(job);
     pipe_report().stats = r.stats;
     if (r.code) {

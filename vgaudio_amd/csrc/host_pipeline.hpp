@@ -220,8 +220,9 @@ inline Result run(const Job &job)
     std::vector<int> cbegin;
     for (int u = 0; u < job.units; u += chunk_units) cbegin.push_back(u);
     cbegin.push_back(job.units);
-    if (job.tail_units > 0 && cbegin.size() >= 3 && job.units - cbegin[cbegin.size() - 2] > job.tail_units) {
-        // two kernel lanes: the last chunk as (rest, tail) -- both run side by side, the short one last
+    if (job.tail_units > 0 && cbegin.size() >= 2 && job.units - cbegin[cbegin.size() - 2] > job.tail_units) {
+        // the last chunk (the only one of a small call) as (rest, tail): the tail's upload runs under the rest's kernels,
+        // and with two kernel lanes both parts' kernels run side by side, the short one last
         cbegin.back() = job.units - job.tail_units;
         cbegin.push_back(job.units);
     } else if (job.taper_min_units > 0 && cbegin.size() >= 3) {   // at least two chunks: taper the last one
