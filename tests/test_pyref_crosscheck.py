@@ -260,3 +260,99 @@ def test_hca_golden_vectors(vec):
     case = manifest["hca"]["cases"][0]
     hi, fr = rhca.encode(arrays["hca_high_pcm"].tolist(), rhca.Params(2, 48000, case["n"], quality="High"))
     assert b"".join(fr) == arrays["hca_high_frames"].tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------- encryption
+def test_adx_keys_and_encryption_agree():
+    """oracle/crypt_oracle.c against oracle/pyref/crypt.py (both written from CriAdxKey.cs / CriAdxEncryption.cs)."""
+    from oracle.pyref import crypt as rc
+    assert rc.PRIMES[0] == 16411 and len(rc.PRIMES) == 0x400
+    rng = np.random.default_rng(5)
+    for code in [1, 2, 0x123456789AB, (1 << 42) - 1, 0xFFFFFFFFFFFFFFFF] + [int(v) for v in rng.integers(1, 1 << 42, 20)]:
+        a, b = po.adx_key_from_code(code), rc.AdxKey.from_code(code)
+        assert (a.seed, a.mult, a.inc) == (b.seed, b.mult, b.inc), code
+        assert po.adx_key_code(a) == b.key_code(), code
+    for s in ["a", "karaage", "AdxKey", "~}|{", "0123456789abcdefghij"]:
+        a, b = po.adx_key_from_string(s), rc.AdxKey.from_string(s)
+        assert (a.seed, a.mult, a.inc) == (b.seed, b.mult, b.inc), s
+    for etype in (8, 9):
+        for nch, frame_size, frames in ((1, 18, 40), (2, 18, 33), (5, 18, 9), (2, 10, 21), (3, 34, 7)):
+            audio = [rng.integers(0, 256, frames * frame_size).astype(np.uint8) for _ in range(nch)]
+            for a in audio:                                          # a few empty frames, which the pass skips
+                a[3 * frame_size:4 * frame_size] = 0
+            for key in (rc.AdxKey(0x1234, 0x5671, 0x2345), rc.AdxKey.from_code(0xDEADBEEF123), rc.AdxKey(40000, 70001, 90001)):
+                ok = po.AdxKey(key.seed, key.mult, key.inc)
+                want = po.adx_crypt(audio, ok, etype, frame_size)
+                got = [bytearray(a.tobytes()) for a in audio]
+                for i, g in enumerate(got):
+                    rc.adx_crypt_channel(g, key, etype, frame_size, i, nch)
+                for i in range(nch):
+                    assert bytes(got[i]) == want[i].tobytes(), (etype, nch, frame_size, i)
+                assert bool(po.adx_test_key(want, ok, etype, frame_size)) == rc.adx_test_key([bytes(w) for w in want], key, etype, frame_size)
+                assert bool(po.adx_test_key(audio, ok, etype, frame_size)) == rc.adx_test_key([a.tobytes() for a in audio], key, etype, frame_size)
+
+
+def test_hca_keys_and_encryption_agree():
+    """oracle (crypt_oracle.c, hca_oracle.c: vgo_hca_find_key) against oracle/pyref/crypt.py (from CriHcaKey.cs / CriHcaEncryption.cs)."""
+    from oracle.pyref import crypt as rc
+    rng = np.random.default_rng(6)
+    for ktype, code in [(0, 0), (1, 0)] + [(56, int(v)) for v in rng.integers(1, 1 << 62, 12)] + [(56, 1), (56, 0xFFFFFFFFFFFFFFFF)]:
+        r, dec, enc = po.hca_key_tables(ktype, code)
+        assert r == 0
+        want = rc.hca_decryption_table(ktype, code)
+        assert dec.tolist() == want, (ktype, code)
+        assert enc.tolist() == rc.invert_table(want), (ktype, code)
+    # Crypt + FindKey on a real stream
+    nch, n = 2, 6000
+    x = _signals(n, rng)[0][:nch] if False else (rng.integers(-9000, 9000, (nch, n))).astype(np.int16)
+    r, info, frames = po.hca_encode(x, po.hca_params(nch, n))
+    assert r == 0
+    hi, fr = rhca.encode(x.tolist(), rhca.Params(nch, 48000, n))
+    keys = [0x1122334455, 77, 0xCAFEBABE12345]
+    tables = [rc.hca_decryption_table(56, k) for k in keys]
+    enc_table = rc.invert_table(tables[1])
+    mine = []
+    for f in fr:
+        b = bytearray(f)
+        rc.hca_crypt_frame(b, hi.frame_size, enc_table)
+        mine.append(bytes(b))
+    theirs = po.hca_crypt(np.asarray(frames), info.frame_size, np.asarray(enc_table, np.uint8)).reshape(info.frame_count, info.frame_size)
+    assert [bytes(t) for t in theirs] == mine
+    assert rc.hca_find_key(hi, mine, tables) == 1 == po.hca_find_key(info, theirs, np.asarray(tables, np.uint8))
+    assert rc.hca_find_key(hi, mine, [tables[0], tables[2]]) == -1 == po.hca_find_key(info, theirs, np.asarray([tables[0], tables[2]], np.uint8))
+    # the unencrypted stream: the identity table (type 0) "decrypts" it
+    assert rc.hca_find_key(hi, fr, [tables[0], rc.hca_decryption_table(0)]) == 1
+    assert po.hca_find_key(info, np.asarray(frames), np.asarray([tables[0], rc.hca_decryption_table(0)], np.uint8)) == 1
+
+
+@pytest.mark.parametrize("etype", [8, 9])
+def test_adx_key_guessing_agrees(etype):
+    """GuessAdx's search for one file (VGAudio.Tools/CrackAdx/GuessAdx.cs:113-218) on small candidate lists: the oracle's
+    vgo_adx_guess_keys against oracle/pyref/crypt.py, on streams encrypted with a known key (silent lead-in included, which
+    makes FindStartingKey work)."""
+    from oracle.pyref import crypt as rc
+    rng = np.random.default_rng(40 + etype)
+    dm, di, seeds, _, _ = rc.adx_guess_candidates(etype)
+    frame_size, frames = 18, 60
+    for lead_in in (0, 3):
+        # a plausible plain stream: scales (13 bits) in the first two bytes, zero frames in front
+        audio = rng.integers(0, 256, frames * frame_size).astype(np.uint8)
+        for f in range(frames):
+            sc = int(rng.integers(1, 0x1000))
+            audio[f * frame_size] = sc >> 8
+            audio[f * frame_size + 1] = sc & 0xff
+        audio[:lead_in * frame_size] = 0
+        seed = sorted(seeds)[77]
+        key = rc.AdxKey(seed, dm[5], di[9])
+        enc = bytearray(audio.tobytes())
+        rc.adx_crypt_channel(enc, key, etype, frame_size, 0, 1)
+        scales, start = rc.adx_file(bytes(enc), frame_size)
+        assert start == lead_in
+        mults, incs = dm[3:8], di[6:12]
+        want = rc.adx_guess_keys(scales, start, etype, mults, incs)
+        got = po.adx_guess_keys(np.asarray(scales, np.uint16), start, etype, mults, incs)
+        assert got == want, (etype, lead_in)
+        assert (key.seed, key.mult, key.inc) in want
+    m, i = po.adx_guess_default_candidates(etype)
+    assert m.tolist() == dm and i.tolist() == di
+
