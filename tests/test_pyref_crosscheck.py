@@ -356,3 +356,50 @@ def test_adx_key_guessing_agrees(etype):
     m, i = po.adx_guess_default_candidates(etype)
     assert m.tolist() == dm and i.tolist() == di
 
+
+# ---------------------------------------------------------------------------------------------------- containers
+def test_adx_and_hca_writers_agree():
+    """AdxWriter / HcaWriter: oracle/containers_oracle.c (and hca_oracle.c) against oracle/pyref/containers.py -- the two
+    container writers the reference's own tests do not cover.  Whole files, byte for byte."""
+    from oracle.pyref import containers as rcont, crypt as rcr
+    rng = np.random.default_rng(9)
+    # ADX: looping or not, versions 3 / 4, mono .. 5 channels, an alignment that pushes the v3 loop start a block back
+    for nch, n, kw in [(1, 1000, dict()), (2, 3200, dict(version=3)), (2, 5000, dict(looping=True, loop_start=100, loop_end=4000)),
+                       (1, 5000, dict(looping=True, loop_start=992, loop_end=4999, version=3, alignment_samples=40)),
+                       (5, 700, dict(type=2, highpass_frequency=0)), (3, 9000, dict(looping=True, loop_start=64, loop_end=8000, trim_file=False)),
+                       (2, 4096, dict(frame_size=34)), (2, 4000, dict(encryption_type=8)), (1, 4000, dict(encryption_type=9, version=3))]:
+        p = po.adxfile_params(48000, n, **kw)
+        fs = kw.get("frame_size", 18)
+        spf = (fs - 2) * 2
+        nb = fs * (-(-n // spf))
+        audio = [rng.integers(0, 256, nb).astype(np.uint8) for _ in range(nch)]
+        hist = rng.integers(-30000, 30000, nch).astype(np.int16)
+        rc_, want = po.adxfile_write(audio, hist, p)
+        assert rc_ == 0, kw
+        got = rcont.adx_write([a.tobytes() for a in audio], hist.tolist(), 48000, n, looping=kw.get("looping", False),
+                              loop_start=kw.get("loop_start", 0), loop_end=kw.get("loop_end", 0),
+                              alignment_samples=kw.get("alignment_samples", 0), frame_size=fs, version=kw.get("version", 4),
+                              adx_type=kw.get("type", 3), highpass_frequency=kw.get("highpass_frequency", 500),
+                              encryption_type=kw.get("encryption_type", 0), trim_file=kw.get("trim_file", True))
+        assert got == want.tobytes(), (nch, n, kw)
+    # HCA: plain, looping, with a comment, a volume, encrypted chunk ids
+    for nch, n, ekw, wkw in [(2, 3000, dict(), dict()), (1, 5000, dict(looping=True, loop_start=1000, loop_end=4500), dict()),
+                             (2, 2500, dict(quality="Low"), dict(comment="made by a test")), (2, 2100, dict(), dict(volume=0.5)),
+                             (2, 3000, dict(), dict(encryption_type=56, encrypted_ids=True)),
+                             (2, 3000, dict(), dict(comment="   "))]:
+        x = rng.integers(-8000, 8000, (nch, n)).astype(np.int16)
+        r, info, frames = po.hca_encode(x, po.hca_params(nch, n, **ekw))
+        assert r == 0
+        hi, fr = rhca.encode(x.tolist(), rhca.Params(nch, 48000, n, **ekw))
+        comment = wkw.get("comment")
+        if comment is not None and comment.strip():
+            # the comment's length is part of the header size the encoder derives (CriHcaEncoder.cs:400-418, not looping:
+            # the next multiple of 32 above 96 + length); set on both sides
+            size = -(-(96 + len(comment.encode("utf-8")) + 1) // 32) * 32
+            info.header_size = size
+            hi.header_size = size
+        r, want = po.hcafile_write(info, np.asarray(frames), **wkw)
+        assert r == 0, wkw
+        got = rcont.hca_write(hi, fr, comment=comment, volume=wkw.get("volume", 1.0),
+                              key_type=wkw.get("encryption_type") if wkw.get("encrypted_ids") else None)
+        assert got == want.tobytes(), (nch, n, ekw, wkw)
