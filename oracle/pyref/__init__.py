@@ -19,5 +19,7 @@ arithmetic, double = IEEE binary64 without FMA contraction (Python float), float
 Modules: gcadpcm (GcAdpcmCoefficients.cs, GcAdpcmEncoder.cs, GcAdpcmDecoder.cs, GcAdpcmMath.cs),
 criadx (CriAdxCodec.cs), crihca (CriHcaEncoder.cs, CriHcaDecoder.cs, CriHcaPacking.cs,
 CriHcaFrame.cs, CriHcaTables.cs, HcaInfo.cs, Utilities/Mdct.cs, BitWriter.cs, BitReader.cs,
-Crc16.cs).  Paths are relative to /root/reference/src/VGAudio/.
+Crc16.cs), crypt (CriAdxKey.cs, CriAdxEncryption.cs, CriHcaKey.cs, CriHcaEncryption.cs, Helpers.GetPrimes; and
+VGAudio.Tools/CrackAdx/GuessAdx.cs for one file), containers (Containers/Adx/AdxWriter.cs, Containers/Hca/HcaWriter.cs,
+Utilities/Interleave.cs).  Paths are relative to /root/reference/src/VGAudio/.
 """
