@@ -45,6 +45,15 @@ int vga_set_device(int device);
  * next one (allocation costs more than a call's transfers and kernels: ~1.4 s for the 44 GB of BASELINE configs[1]); at
  * most 64 GiB of device memory and 1 GiB of pinned host memory stay parked.  This returns all of it to the system. */
 void vga_release_cached_memory(void);
+/* Process-wide side effects of the host-buffer (`*_batch`) entry points, stated here because a drop-in must not surprise
+ * its host (details: INTEGRATION.md, "What the host pipeline does to the process"):
+ *  - loading the library sets the environment variable GPU_MAX_HW_QUEUES=16 unless the host has set it (the HIP runtime
+ *    reads it when it initialises; with the default of 4 hardware queues a copy stream shares a queue with a kernel
+ *    stream and every download waits for the last kernel).  A host that initialises HIP first sets it itself; with
+ *    fewer than 6 the calls run one kernel lane instead of two -- slower, not wrong;
+ *  - input rows of 256 KB or more (and the output rows of a decode) are page-locked with hipHostRegister for the duration
+ *    of the call; a row that cannot be registered is copied through the runtime's pageable path;
+ *  - one feeder and two drainer threads per call, joined before it returns. */
 /* library version string */
 const char *vga_version(void);
 
