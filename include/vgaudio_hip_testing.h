@@ -45,6 +45,16 @@ void vga_testing_host_pipeline_this_thread(int feeders, int drainers, int chunk_
  * stream synchronisation [21] drainers page-locking the output rows.  Returns the number of fields. */
 int vga_testing_last_pipeline_stats(double *out, int n);
 
+/* The HCA decoder's second kernel gives a workgroup a run of consecutive frames of one stream and carries the IMDCT overlap
+ * inside the run (1..16 frames, by the size of the batch).  > 0 forces the run length for calls made from the calling
+ * thread (0 = the launcher's choice).  PCM must not depend on it.  Returns the previous value. */
+int vga_testing_hca_frames_per_group_this_thread(int frames);
+
+/* The HCA kernels' view of a stream (vgaudio_amd/csrc/hca_info.hpp: DeviceInfo -- channel types, coded band counts, the
+ * scaled ATH curve), as the library derives it from an HcaInfo; `out` receives sizeof(DeviceInfo) = 240 bytes.  Host code,
+ * needs no GPU: the CPU suite feeds it to the lane emulator of the HCA decoder (tests/host/hca_decode_emulator.cpp). */
+int vga_testing_hca_device_info(const void *hca_info, void *out, int out_bytes);
+
 #ifdef __cplusplus
 }
 #endif

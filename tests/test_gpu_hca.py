@@ -172,3 +172,66 @@ def test_randomised_configurations_match_oracle():
         for c in range(nch):
             assert (dec[c] == wdec[c]).all(), (nch, quality, rate, n, c)
         done += 1
+
+
+def _device_info_words(info):
+    """channel types [11:19] and coded band counts [19:27] as the library derives them (host code)"""
+    import ctypes as C
+    from vgaudio_amd import _lib
+    out = (C.c_uint8 * 240)()
+    pinfo = _lib.HcaInfoC()
+    for name, _ in _lib.HcaInfoC._fields_:
+        setattr(pinfo, name, getattr(info, name))
+    _lib.check(_lib.lib().vga_testing_hca_device_info(C.byref(pinfo), out, 240))
+    return np.frombuffer(bytes(out), np.int32, 27)
+
+
+def test_decode_of_garbage_frames_reads_zeros_past_the_end_like_the_reference():
+    """Random bits behind a valid header (raw 6-bit scale factors, so that delta decoding cannot fail) make the decoder
+    walk far past the frame's end, where BitReader.PeekInt yields zeros (BitReader.cs:55-61); the scan's chunk offsets
+    then point past the frame.  PCM must still equal the oracle's, for every frame alignment."""
+    rng = np.random.default_rng(11)
+    n = 1024 * 40 + 300
+    for nch, quality, bitrate in ((2, "High", 0), (1, "Lowest", 0), (2, "Lowest", 0), (2, "High", 48047), (4, "Middle", 0)):
+        pcm = synth.generate(nch, n)
+        rc, info, frames = po.hca_encode(pcm, po.hca_params(nch, n, quality=quality, bitrate=bitrate))
+        assert rc == 0
+        words = _device_info_words(info)
+        fr = np.array(frames, np.uint8).reshape(info.frame_count, info.frame_size)
+        for f in range(1, info.frame_count, 2):
+            bits = rng.integers(0, 2, info.frame_size * 8).astype(np.uint8)
+            bits[:16] = 1
+            pos = 32
+            for c in range(nch):
+                bits[pos:pos + 3] = (1, 1, int(rng.integers(0, 2)))
+                pos += 3 + 6 * int(words[19 + c])
+                pos += 32 if words[11 + c] == 2 else 6 * info.hfr_group_count
+            if f % 3 == 0:
+                bits[info.frame_size * 4:] = 1
+            fr[f] = np.packbits(bits)
+        rc, want = po.hca_decode(info, fr.reshape(-1))
+        assert rc == 0
+        fmt = CriHcaFormat().EncodeFromPcm16(Pcm16Format(list(pcm), 48000), CriHcaParameters(Quality=Q[quality], Bitrate=bitrate))
+        got = CriHcaDecoder.Decode(fmt.Hca, [fr, fr[::1].copy()])
+        for d in got:
+            assert np.array_equal(np.stack(d), np.asarray(want).reshape(nch, n)), (nch, quality, bitrate)
+
+
+def test_long_streams_carry_the_overlap_across_frame_runs():
+    """Many streams x many frames so that the decoder's workgroups take runs of 16 frames (the overlap is carried inside a
+    run and recomputed at its start); every stream against the oracle."""
+    from vgaudio_amd import _lib
+    ns, n = 12, 1024 * 61 + 77
+    streams = _streams(ns, 2, n)
+    fmts = CriHcaFormat.EncodeBatchFromPcm16([Pcm16Format(list(s), 48000) for s in streams], CriHcaParameters())
+    rc, info = po.hca_init(po.hca_params(2, n))
+    rc, want = po.hca_decode_batch(info, np.stack([fmt.AudioData.reshape(-1) for fmt in fmts]), threads=8)
+    assert rc == 0
+    for run in (16, 1, 2, 3, 7, 64):
+        old = _lib.lib().vga_testing_hca_frames_per_group_this_thread(run)
+        try:
+            dec = CriHcaDecoder.Decode(fmts[0].Hca, [fmt.AudioData for fmt in fmts])
+        finally:
+            _lib.lib().vga_testing_hca_frames_per_group_this_thread(old)
+        for k in range(ns):
+            assert np.array_equal(np.stack(dec[k]), want[k]), (run, k)

@@ -124,6 +124,8 @@ SIGNATURES = {
     "vga_testing_gc_coefs_variant_this_thread": (ci, [ci]),
     "vga_testing_gc_encoder_segments_this_thread": (ci, [ci]),
     "vga_testing_last_pipeline_stats": (ci, [vp, ci]),
+    "vga_testing_hca_device_info": (ci, [vp, vp, ci]),
+    "vga_testing_hca_frames_per_group_this_thread": (ci, [ci]),
     "vga_dsp_layout_for": (ci, [vp, ci, vp]),
     "vga_dsp_write": (ci, [u8pp, ci, i16p, i16p, i16p, i16p, ci, vp, u8p]),
     "vga_dsp_write_device": (ci, [vp, i64, ci, vp, vp, vp, vp, ci, vp, vp, vp]),

@@ -2,19 +2,24 @@
 .so travels to the GPU box with the repo snapshot).
 
     python -m vgaudio_amd.build [--force]
+
+Every .hip file is compiled to its own object (in parallel; objects live in vgaudio_amd/build/ and are
+rebuilt when the source, any header of csrc/ or the public header is newer), then linked.
 """
+import concurrent.futures
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "libvgaudio_hip.so")
 
 # -ffp-contract=off : RyuJIT never contracts a*b+c into an FMA
 # -fwrapv           : C# int arithmetic is unchecked (wraps)
 # no fast-math      : IEEE divide / rint / NaN compares are part of the parity contract
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fwrapv",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fwrapv",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
@@ -22,21 +27,51 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def headers():
+    inc = os.path.join(HERE, "..", "include")
+    return ([os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".hip")] +
+            [os.path.join(inc, f) for f in os.listdir(inc)] + [os.path.abspath(__file__)])
+
+
+def obj_of(src):
+    return os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+
+
+def stale_sources():
+    newest_header = max(os.path.getmtime(h) for h in headers())
+    out = []
+    for s in sources():
+        o = obj_of(s)
+        if not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), newest_header):
+            out.append(s)
+    return out
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "vgaudio_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in sources() + headers())
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + sources() + ["-o", OUT]
+    os.makedirs(OBJ, exist_ok=True)
+    todo = sources() if force else stale_sources()
+
+    def compile_one(src):
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj_of(src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4) or 1) as pool:
+        list(pool.map(compile_one, todo))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj_of(s) for s in sources()] + ["-o", OUT]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return OUT
 

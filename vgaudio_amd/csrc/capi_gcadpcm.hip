@@ -30,6 +30,8 @@ static thread_local int g_coefs_variant = 0;
 int coefs_kernel_variant() { return g_coefs_variant; }
 static thread_local int g_encoder_segments = 0;
 int encoder_segments_override() { return g_encoder_segments; }
+static thread_local int g_hca_frames_per_group = 0;
+int hca_frames_per_group_override() { return g_hca_frames_per_group; }
 
 // The host pipeline runs an upload stream, a download stream and two lanes of kernels next to whatever streams the host
 // has; the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless told otherwise), and a copy
@@ -101,6 +103,12 @@ int vga_testing_gc_encoder_segments_this_thread(int segments)
 {
     const int old = g_encoder_segments;
     g_encoder_segments = segments > 0 ? segments : 0;
+    return old;
+}
+int vga_testing_hca_frames_per_group_this_thread(int frames)
+{
+    const int old = g_hca_frames_per_group;
+    g_hca_frames_per_group = frames > 0 ? frames : 0;
     return old;
 }
 void vga_testing_host_pipeline_this_thread(int feeders, int drainers, int chunk_units, int slot_bytes)

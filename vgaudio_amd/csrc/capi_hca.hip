@@ -149,6 +149,15 @@ namespace vga { namespace hca { int crc_pow_table(const uint16_t **out); } }
 // used by capi_crypt.hip (vga_hca_find_key)
 namespace vga { namespace hca { int device_info_from(const vga_hca_info &h, DeviceInfo &d) { return make_device_info(h, d); } } }
 
+extern "C" int vga_testing_hca_device_info(const void *hca_info, void *out, int out_bytes)
+{
+    if (!hca_info || !out || out_bytes < (int)sizeof(hca::DeviceInfo)) { set_error("bad arguments"); return VGA_ERR_ARGUMENT; }
+    hca::DeviceInfo d;
+    if (int rc = make_device_info(*static_cast<const vga_hca_info *>(hca_info), d)) return rc;
+    memcpy(out, &d, sizeof d);
+    return VGA_OK;
+}
+
 int vga::hca::crc_pow_table(const uint16_t **out)
 {
     int device = 0;
@@ -265,7 +274,9 @@ int vga_hca_encoder_initialize(const vga_hca_params *c, vga_hca_info *h)
 size_t vga_hca_decode_workspace_bytes(const vga_hca_info *h, int nstreams)
 {
     if (!h || nstreams <= 0 || h->frame_count <= 0 || h->channel_count < 1 || h->channel_count > 8) return 0;
-    return hca::unpack_record_bytes(h->channel_count) * (size_t)h->frame_count * (size_t)nstreams;
+    hca::DeviceInfo d;
+    if (make_device_info(*h, d) != VGA_OK) return 0;
+    return hca::decode_record_bytes(d) * (size_t)h->frame_count * (size_t)nstreams;
 }
 
 int vga_hca_encode_device(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, int pcm_length,

@@ -192,6 +192,7 @@ int force_open_seams();          // 0 = off, 1 = every seam, 2 = seams with an e
 int encoder_layout();
 int coefs_kernel_variant();               // 0: four channels + summing wave per workgroup (product); 1: one wave per channel
 int encoder_segments_override();   // > 0: time pieces per channel forced by the test hook
+int hca_frames_per_group_override();   // > 0: frames per workgroup of hca_frames_kernel forced by the test hook
 
 // the per-(channel, seam) reading of that mode inside the seam kernels
 __host__ __device__ inline bool seam_forced_open(int mode, int channel, int seam)

@@ -9,8 +9,8 @@
 namespace vga {
 namespace hca {
 
-// bytes of decoder workspace per (stream, frame)
-size_t unpack_record_bytes(int nch);
+// bytes of decoder workspace per (stream, frame): the scan's hand-over record (hca_decode_core.hpp)
+size_t decode_record_bytes(const DeviceInfo &info);
 
 // frames: stream s at d_frames + s*frames_pitch (frame_count*frame_size bytes + >= 8 bytes slack);
 // pcm: stream s channel c at d_pcm + s*stream_pitch + c*ch_pitch (samples)
