@@ -56,6 +56,83 @@ def gather_channel_metadata(local, counts):
     return torch.cat([parts[r].view(local.dtype)[:counts[r]] for r in range(world)], dim=0)
 
 
+def launch_local_ranks(argv, nproc, master_port=None, extra_env=None, timeout=None):
+    """One process per GPU without torchrun: runs `python argv...` nproc times with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set (the environment torch.distributed.run would give them) and waits for all of them.
+    Rank 0 inherits stdout (it prints the result line); the other ranks' stdout goes to stderr.  Returns the first
+    non-zero exit code, or 0.  A rank that fails takes the others down (they would wait in a collective for ever)."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    if master_port is None:
+        with socket.socket() as sock:                      # a free port on the loop-back interface
+            sock.bind(("127.0.0.1", 0))
+            master_port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(master_port), WORLD_SIZE=str(nproc),
+               LOCAL_WORLD_SIZE=str(nproc), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.update(extra_env or {})
+    procs = []
+    for r in range(nproc):
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=None if r == 0 else sys.stderr))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+        if rc != 0 or (deadline is not None and time.monotonic() > deadline):
+            for p in live:
+                p.kill()
+            for p in live:
+                p.wait()
+            return rc or 124
+        time.sleep(0.05)
+    return rc
+
+
+_GOLD = 0x9E3779B97F4A7C15
+_MIX = 0xC2B2AE3D27D4EB4F
+
+
+def _i64(v):
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def rows_digest(rows, nbytes, coefs, first_channel, chunk=512):
+    """A 64-bit position-weighted checksum of a block of output rows, computed where the rows live (CPU or GPU):
+    sum over rows of a(g) * sum over words of x[g][j] * b(j)  (mod 2^64), g = GLOBAL channel index, the row's first
+    `nbytes` bytes read as little-endian 64-bit words (+ the tail bytes one by one) followed by its 16 coefficients.
+    A row that arrives in another row's place, truncated, stale or shifted changes the sum.  Returns a Python int."""
+    count = rows.shape[0]
+    dev = rows.device
+    n8 = nbytes // 8
+    tail = nbytes - 8 * n8
+    assert rows.dtype == torch.uint8 and rows.stride(1) == 1 and rows.stride(0) % 8 == 0 and rows.data_ptr() % 8 == 0
+    jw = torch.arange(n8 + tail + 4, dtype=torch.int64, device=dev)
+    b = (jw * _i64(_MIX) + 1) | 1
+    total = 0
+    for c0 in range(0, count, chunk):
+        c1 = min(c0 + chunk, count)
+        inner = torch.zeros(c1 - c0, dtype=torch.int64, device=dev)
+        if n8:
+            inner += (rows[c0:c1, :8 * n8].view(torch.int64) * b[:n8]).sum(dim=1)
+        if tail:
+            inner += (rows[c0:c1, 8 * n8:nbytes].to(torch.int64) * b[n8:n8 + tail]).sum(dim=1)
+        inner += (coefs[c0:c1].reshape(c1 - c0, 16).contiguous().view(torch.int64) * b[n8 + tail:n8 + tail + 4]).sum(dim=1)
+        g = torch.arange(first_channel + c0, first_channel + c1, dtype=torch.int64, device=dev)
+        a = (g * _i64(_GOLD) + _i64(_MIX)) | 1
+        total += int((inner * a).sum().item())
+    return total & ((1 << 64) - 1)
+
+
 def max_over_ranks(value, device):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
@@ -85,15 +162,27 @@ class BitstreamGather:
         self.pitch = int(pitch)
         self.chunk = max(1, int(chunk_channels))
         self.all_adpcm = self.all_coefs = None
+        self.device = device
+        self.peer_digests = None               # rank 0: [world] int64, what every rank says its rows sum to (rows_digest)
         if self.rank == 0:
+            self.peer_digests = torch.zeros(self.world, dtype=torch.int64, device=device)
             total = sum(self.counts)
             self.all_adpcm = torch.empty((total, self.pitch), dtype=torch.uint8, device=device)
             self.all_coefs = torch.empty((total, 16), dtype=torch.int16, device=device)
 
-    def gather(self, adpcm, coefs, async_op=False):
+    def gather(self, adpcm, coefs, async_op=False, nbytes=None):
         """adpcm [count, pitch] uint8, coefs [count, 16] int16 (this rank's rows).  Returns a list of work handles
-        (empty when the transfer has completed)."""
+        (empty when the transfer has completed).  With `nbytes` (the bytes of a row that carry data) every rank also
+        sends the 64-bit digest of what it is sending (rows_digest over its global channel indices), which verify()
+        holds against a digest recomputed over what arrived."""
         n = self.counts[self.rank]
+        digest = None
+        if nbytes is not None:
+            digest = torch.tensor([_i64(rows_digest(adpcm[:n], nbytes, coefs[:n], self.firsts[self.rank]))],
+                                  dtype=torch.int64, device=adpcm.device)
+            self._keep = digest                            # alive until the transfer is done
+            if self.rank == 0:
+                self.peer_digests[0:1].copy_(digest)
         assert adpcm.shape[0] >= n and adpcm.shape[1] == self.pitch and coefs.shape[0] >= n
         if self.rank == 0:
             self.all_adpcm[:n].copy_(adpcm[:n], non_blocking=True)
@@ -119,6 +208,12 @@ class BitstreamGather:
                     ops.append(dist.P2POp(dist.isend, coef_bytes[c0:c1], 0))
             if ops:
                 works.extend(dist.batch_isend_irecv(ops))
+        if digest is not None:
+            if self.rank == 0:
+                ops = [dist.P2POp(dist.irecv, self.peer_digests[r:r + 1].view(torch.uint8), r) for r in range(1, self.world)]
+            else:
+                ops = [dist.P2POp(dist.isend, digest.view(torch.uint8), 0)]
+            works.extend(dist.batch_isend_irecv(ops))
         if async_op:
             return works
         for w in works:
@@ -126,14 +221,21 @@ class BitstreamGather:
         return []
 
     def verify(self, adpcm, coefs, nbytes):
-        """rank 0: its own rows arrived unchanged and every peer's rows are populated (frame headers name a
-        predictor 0..7 and a scale 0..12, GcAdpcmEncoder.cs:83,118-170).  Returns a short description."""
+        """rank 0, after a gather(..., nbytes=nbytes): its own rows arrived unchanged, and for EVERY rank the digest
+        recomputed over the rows that arrived (in the places they arrived at) equals the digest that rank sent.
+        Returns a short description, "MISMATCH ..." naming the ranks that differ otherwise."""
         if self.rank != 0:
             return None
         n = self.counts[0]
-        ok = bool(torch.equal(self.all_adpcm[:n, :nbytes], adpcm[:n, :nbytes]) and
-                  torch.equal(self.all_coefs[:n], coefs[:n].reshape(n, 16)))
-        full = nbytes - nbytes % 8
-        heads = self.all_adpcm[:, :full].reshape(self.all_adpcm.shape[0], -1, 8)[:, :, 0]
-        ok = ok and int((heads >> 4).max()) <= 7 and int((heads & 15).max()) <= 12
-        return "own rows identical, all %d channels' frame headers valid" % self.all_adpcm.shape[0] if ok else "MISMATCH"
+        own = bool(torch.equal(self.all_adpcm[:n, :nbytes], adpcm[:n, :nbytes]) and
+                   torch.equal(self.all_coefs[:n], coefs[:n].reshape(n, 16)))
+        sent = [int(v) & ((1 << 64) - 1) for v in self.peer_digests.tolist()]
+        bad = []
+        for r in range(self.world):
+            f, c = self.firsts[r], self.counts[r]
+            got = rows_digest(self.all_adpcm[f:f + c], nbytes, self.all_coefs[f:f + c], f)
+            if got != sent[r]:
+                bad.append(r)
+        if own and not bad:
+            return "own rows identical; per-rank 64-bit digests of all %d channels match what each rank sent" % self.all_adpcm.shape[0]
+        return "MISMATCH (own rows %s, ranks with a wrong digest: %s)" % ("ok" if own else "differ", bad)
