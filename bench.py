@@ -3,7 +3,8 @@
 
     python bench.py --gpus N --steps K --warmup W                  (headline: --codec gc)
     python bench.py --codec adx|hca ...                            (BASELINE configs[2] / configs[3], same contract)
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   -- or plain
+          python bench.py --gpus N, which starts its own N ranks, one per GPU, and prints rank 0's line)
 
 --codec gc  (default; BASELINE.json's metric): configs[1], 4096 independent mono channels x 48 kHz x 60 s per GPU.
             A step = gc_coefs_kernel (GcAdpcmCoefficients.CalculateCoefficients for every channel) +
@@ -62,6 +63,10 @@ def parse():
     ap.add_argument("--cpu-channels", type=int, default=0, help="units in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-pointer ABI measurement")
     ap.add_argument("--e2e-channels", type=int, default=0, help="channels of the e2e call (0 = as many of --channels as host memory allows)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend for N > 1 (nccl = RCCL; gloo moves the gather through host memory: for trying "
+                         "the N > 1 path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (N > 1 plumbing test on a 1-GPU box; implies --backend gloo)")
     return ap.parse_args()
 
 
@@ -123,17 +128,24 @@ def setup(args):
     cx.world = int(os.environ.get("WORLD_SIZE", "1"))
     cx.rank = int(os.environ.get("RANK", "0"))
     cx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and cx.world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={cx.world})")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    torch.cuda.set_device(cx.local_rank)
-    cx.dev = torch.device("cuda", cx.local_rank)
     from vgaudio_amd import _lib, device as vdev, distributed as vdist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: be the launcher -- N ranks of this same command line, one per GPU
+        raise SystemExit(vdist.launch_local_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    if args.gpus > 1 and cx.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={cx.world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    if args.share_gpu:
+        args.backend = "gloo"
+    device_index = 0 if args.share_gpu else cx.local_rank
+    torch.cuda.set_device(device_index)
+    cx.dev = torch.device("cuda", device_index)
     cx.lib, cx.vdev, cx.vdist = _lib, vdev, vdist
     cx.L = _lib.lib()
-    _lib.check(cx.L.vga_set_device(cx.local_rank))
+    _lib.check(cx.L.vga_set_device(device_index))
+    cx.backend = args.backend
     if cx.world > 1:
-        vdist.init("nccl", cx.dev)
+        vdist.init(args.backend, cx.dev)
     cx.st = lambda: torch.cuda.current_stream().cuda_stream
     return cx
 
@@ -263,10 +275,13 @@ def host_call_e2e(cx, entry_point, call, in_bytes, out_bytes, units, total_sampl
             "ratio_to_pcie_bound": round(best * 1e3 / bound, 2), "identical_to_device_path": same}
 
 
-def measure_e2e(cx, args, pcm, n, coefs_dev, adpcm_dev):
-    """One vga_gcadpcm_encode_batch call through the host-pointer ABI (pageable numpy rows in and out)."""
+def measure_e2e(cx, args, pcm, n, coefs_dev, adpcm_dev, devices=None):
+    """One vga_gcadpcm_encode_batch call through the host-pointer ABI (pageable numpy rows in and out); with `devices`
+    the library spreads the call's channels over those GPUs (vga_set_devices: one process, several GPUs)."""
     import numpy as np
     torch, L, lib = cx.torch, cx.L, cx.lib
+    if devices:
+        lib.check(L.vga_set_devices((C.c_int * len(devices))(*devices), len(devices)))
     nch = pcm.shape[0]
     nb = cx.vdev.gc_byte_count(n)
     want = args.e2e_channels or nch
@@ -317,6 +332,12 @@ def measure_e2e(cx, args, pcm, n, coefs_dev, adpcm_dev):
            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "breakdown_ms": breakdown}
     if note:
         e2e["note"] = note
+    if devices:
+        lib.check(L.vga_set_devices(None, 0))
+        e2e["devices"] = list(devices)
+        e2e["entry_point"] += f", spread over {len(devices)} GPUs by vga_set_devices"
+        e2e["pcie_bound_ms_all_links"] = round(pcie_ms / len(set(devices)), 1)
+        e2e["ratio_to_pcie_bound_all_links"] = round(best * 1e3 / (pcie_ms / len(set(devices))), 2)
     return e2e
 
 
@@ -350,6 +371,7 @@ def run_gc(args, cx):
     value = samples_per_step / (ms_per_step * 1e-3) / 1e6
 
     gather = None
+    scaling = None
     if cx.world > 1:
         # the results of all channels end up in one place (GcAdpcmFormat.cs:65-74): ADPCM rows + coefs of
         # every rank gathered to rank 0 over RCCL/xGMI, in channel chunks; timed as steps that include it.
@@ -358,6 +380,12 @@ def run_gc(args, cx):
         g.gather(adpcm, coefs)                              # warm-up: communicators, buffers
         torch.cuda.synchronize()
         cx.dist.barrier()
+        # the gather by itself (nothing else running on any rank)
+        t0 = time.perf_counter()
+        g.gather(adpcm, coefs)
+        torch.cuda.synchronize()
+        cx.dist.barrier()
+        ms_alone = cx.vdist.max_over_ranks(time.perf_counter() - t0, cx.dev) * 1e3
         # double-buffered outputs: the gather of step k runs on the process group's stream beside the kernels of
         # step k+1 (a caller converting batch after batch); the last gather is waited for inside the timed region
         bufs = [adpcm, torch.empty_like(adpcm)]
@@ -379,11 +407,55 @@ def run_gc(args, cx):
         el = cx.vdist.max_over_ranks(time.perf_counter() - t0, cx.dev)
         ms_g = el / max(args.steps, 1) * 1e3
         adpcm, coefs = bufs[(args.steps - 1) % 2] if args.steps else adpcm, (keep[-1] if keep else coefs)
+        # one more gather that carries every rank's 64-bit digest of what it sends; rank 0 recomputes the digests over what
+        # arrived (BitstreamGather.verify) -- outside the timed region, it reads every row once more
+        g.gather(adpcm, coefs, nbytes=nb)
+        torch.cuda.synchronize()
+        verified = g.verify(adpcm, coefs, nb) if cx.rank == 0 else None
+        # every shard's output against the digest committed for it (tests/golden/gc_shard_digests.json, written by a
+        # single-GPU run of tests/test_gpu_shards.py's generator): the first 8-GPU run has expected values
+        mine = cx.vdist.rows_digest(adpcm[:nch], nb, coefs[:nch], first_channel)
+        want = None
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "gc_shard_digests.json")))
+            if gold["channels_per_shard"] == nch and gold["samples_per_channel"] == n and cx.rank < len(gold["shards"]):
+                want = int(gold["shards"][cx.rank]["rows_digest"], 16)
+        except (OSError, ValueError, KeyError):
+            pass
+        ok = torch.tensor([1 if (want is None or want == mine) else 0, 0 if want is None else 1], dtype=torch.int64,
+                          device="cpu" if cx.backend == "gloo" else cx.dev)
+        cx.dist.all_reduce(ok, op=cx.dist.ReduceOp.MIN)
+        shard_digests = ("match the committed per-shard digests" if int(ok[0]) == 1 else "MISMATCH against the committed per-shard digests") \
+            if int(ok[1]) == 1 else "no committed digest for this shape"
+        if int(ok[1]) == 1 and int(ok[0]) != 1:
+            raise SystemExit("PARITY FAILURE: a rank's output differs from the committed digest of its shard")
+        # weak scaling inside this job: rank 0 repeats the step while every other GPU is idle
+        torch.cuda.synchronize()
+        cx.dist.barrier()
+        alone_ms = None
+        if cx.rank == 0:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = max(2, min(args.steps, 5))
+            step(None)
+            e0.record()
+            for _ in range(reps):
+                step(None)
+            e1.record()
+            torch.cuda.synchronize()
+            alone_ms = e0.elapsed_time(e1) / reps
+        cx.dist.barrier()
         gather = {"what": "all ranks' ADPCM rows + coefficients to rank 0 (grouped send/recv in 512-channel chunks; the gather "
                           "of step k overlaps the kernels of step k+1)",
-                  "bytes_per_peer": nch * nb + nch * 32, "ms_per_step_with_gather": round(ms_g, 3),
+                  "backend": cx.backend + (" (rows staged through host memory)" if g.via_host else ""),
+                  "bytes_per_peer": nch * nb + nch * 32, "ms_alone": round(ms_alone, 3),
+                  "ms_per_step_with_gather": round(ms_g, 3), "ms_hidden": round(max(0.0, ms_alone - max(0.0, ms_g - ms_per_step)), 3),
+                  "ms_exposed": round(max(0.0, ms_g - ms_per_step), 3),
                   "value_with_gather": round(samples_per_step / (ms_g * 1e-3) / 1e6, 2),
-                  "verified": g.verify(adpcm, coefs, nb) if cx.rank == 0 else None}
+                  "verified": verified, "shard_digests": shard_digests}
+        if alone_ms:
+            scaling = {"rank0_alone_ms_per_step": round(alone_ms, 3), "all_ranks_ms_per_step": round(ms_per_step, 3),
+                       "weak_scaling_efficiency": round(alone_ms / ms_per_step, 4),
+                       "note": "same job: rank 0's step with the other GPUs idle / the max-over-ranks step with all of them busy"}
 
     if cx.rank != 0:
         return None
@@ -471,8 +543,15 @@ def run_gc(args, cx):
                     {"channels_per_gpu": nch, "samples_per_channel": n, "bit_exact_channels_checked": verified}, roofline, cpu)
     if gather:
         out["gather"] = gather
+    if scaling:
+        out["weak_scaling"] = scaling
     if not args.no_e2e and cx.world == 1:
         out["e2e"] = measure_e2e(cx, args, pcm, n, coefs, adpcm)
+    if not args.no_e2e and cx.world > 1:
+        # one process, N GPUs: the same 4096-channel call as the N = 1 line's e2e block, its channels spread over all
+        # GPUs of the job by the library (the other ranks are idle at the final barrier meanwhile)
+        devs = [0] * cx.world if args.share_gpu else list(range(cx.world))
+        out["e2e_multi"] = measure_e2e(cx, args, pcm, n, coefs, adpcm, devices=devs)
     return out
 
 

@@ -41,16 +41,31 @@ const char *vga_last_error(void);
 int vga_device_count(void);
 /* selects the device for the calling thread (one process per GPU: LOCAL_RANK) */
 int vga_set_device(int device);
+/* ONE process, several GPUs -- the shape of the reference's own parallelism (Parallel.For over channels inside one
+ * process, Formats/GcAdpcm/GcAdpcmFormat.cs:65-68; a worker per file, VGAudio.Cli/Batch.cs:24-25) and of a P/Invoke host.
+ * Lists the devices every host-buffer (`*_batch`) entry point spreads a call's units (channels / streams) over: contiguous
+ * shares, one per listed device, each share a whole pipelined call on its own host thread with its own device buffers and
+ * PCIe link; results land directly in the caller's rows, there is no collective and no peer copy.  Shares are at least
+ * 128 channels / 32 streams, so small calls stay on the first listed device.  count = 0 (the default) restores "the calling
+ * thread's current device, nothing is spread".  A device may be listed more than once.  Process-wide; takes effect for
+ * calls that start afterwards.  Output bytes do not depend on the list. */
+int vga_set_devices(const int *devices, int count);
+/* the current list: returns its length and fills devices[0 .. min(length, capacity)) */
+int vga_get_devices(int *devices, int capacity);
 /* The host-buffer entry points keep the device buffers and the page-locked staging rings of their last calls for the
  * next one (allocation costs more than a call's transfers and kernels: ~1.4 s for the 44 GB of BASELINE configs[1]); at
- * most 64 GiB of device memory and 1 GiB of pinned host memory stay parked.  This returns all of it to the system. */
+ * most 64 GiB of device memory PER DEVICE (environment variable VGA_HIP_POOL_GIB changes the figure, 0 turns the cache off)
+ * and 1 GiB of pinned host memory stay parked -- memory other allocators in the process (torch, ...) cannot see or reclaim.
+ * This returns all of it to the system. */
 void vga_release_cached_memory(void);
 /* Process-wide side effects of the host-buffer (`*_batch`) entry points, stated here because a drop-in must not surprise
  * its host (details: INTEGRATION.md, "What the host pipeline does to the process"):
- *  - loading the library sets the environment variable GPU_MAX_HW_QUEUES=16 unless the host has set it (the HIP runtime
- *    reads it when it initialises; with the default of 4 hardware queues a copy stream shares a queue with a kernel
- *    stream and every download waits for the last kernel).  A host that initialises HIP first sets it itself; with
- *    fewer than 6 the calls run one kernel lane instead of two -- slower, not wrong;
+ *  - loading the library sets the environment variable GPU_MAX_HW_QUEUES=16 unless the host has set it or has set
+ *    VGA_HIP_NO_ENV=1 (the HIP runtime reads the variable when it initialises; with the default of 4 hardware queues a
+ *    copy stream shares a queue with a kernel stream and every download waits for the last kernel).  setenv is not
+ *    thread-safe against a host thread calling getenv at that moment: a host that cares sets the variable itself before
+ *    loading the library, or opts out.  If the runtime was already up when the library was loaded (it then never saw the
+ *    value), or fewer than 6 queues are configured, the calls run one kernel lane instead of two -- slower, not wrong;
  *  - input rows of 256 KB or more (and the output rows of a decode) are page-locked with hipHostRegister for the duration
  *    of the call; a row that cannot be registered is copied through the runtime's pageable path;
  *  - one feeder and two drainer threads per call, joined before it returns. */

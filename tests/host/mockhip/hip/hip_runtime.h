@@ -3,12 +3,14 @@
 // records and stream-waits are genuinely asynchronous and ordered as on a device: a missing wait in the pipeline shows
 // up as corrupted data, a lost wake-up as a hang, a data race under -fsanitize=thread.
 #pragma once
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <thread>
 
@@ -73,26 +75,44 @@ typedef MockStream *hipStream_t;
 typedef MockEvent *hipEvent_t;
 
 // knobs of the test driver
-inline int &mock_fail_memcpy_after() { static int n = -1; return n; }      // >= 0: the n-th hipMemcpyAsync from now fails
-inline int &mock_copy_delay_us() { static int us = 0; return us; }
+inline std::atomic<int> &mock_fail_memcpy_after() { static std::atomic<int> n{-1}; return n; }      // >= 0: the n-th hipMemcpyAsync from now fails
+inline std::atomic<int> &mock_copy_delay_us() { static std::atomic<int> us{0}; return us; }
 inline std::mutex &mock_mutex() { static std::mutex m; return m; }
 
 inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "ok" : (e == hipErrorOutOfMemory ? "out of memory" : "mock failure"); }
-inline hipError_t hipSetDevice(int) { return hipSuccess; }
+// four mock devices; the current device is per host thread, as in HIP
+inline int &mock_current_device() { static thread_local int d = 0; return d; }
+inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= 4) return hipErrorInvalidValue; mock_current_device() = d; return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = mock_current_device(); return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
 static const unsigned hipHostRegisterDefault = 0;
 inline int &mock_registered() { static int n = 0; return n; }
+// page-locked rows -> copies issued on them that have not completed yet.  Unregistering a row with a copy pending is the
+// bug the real runtime only hides by synchronising every stream inside hipHostUnregister: counted as a violation here.
+inline std::map<const void *, int> &mock_registered_rows() { static std::map<const void *, int> m; return m; }
+inline int &mock_unregister_violations() { static int n = 0; return n; }
 // every third registration "fails" (already registered / shared page): the caller must fall back to a plain copy
-inline hipError_t hipHostRegister(void *, size_t, unsigned)
+inline hipError_t hipHostRegister(void *p, size_t, unsigned)
 {
     std::lock_guard<std::mutex> g(mock_mutex());
     static int calls = 0;
     if (++calls % 3 == 0) return hipErrorInvalidValue;
     mock_registered()++;
+    mock_registered_rows()[p] = 0;
     return hipSuccess;
 }
-inline hipError_t hipHostUnregister(void *) { std::lock_guard<std::mutex> g(mock_mutex()); mock_registered()--; return hipSuccess; }
+inline hipError_t hipHostUnregister(void *p)
+{
+    std::lock_guard<std::mutex> g(mock_mutex());
+    mock_registered()--;
+    auto it = mock_registered_rows().find(p);
+    if (it != mock_registered_rows().end()) {
+        if (it->second > 0) mock_unregister_violations()++;
+        mock_registered_rows().erase(it);
+    }
+    return hipSuccess;
+}
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new MockStream; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
@@ -147,9 +167,22 @@ inline hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpy
         if (mock_fail_memcpy_after() > 0) mock_fail_memcpy_after()--;
     }
     const int us = mock_copy_delay_us();
+    const void *host = nullptr;                              // the page-locked row this copy reads or writes, if any
+    {
+        std::lock_guard<std::mutex> g(mock_mutex());
+        for (const void *cand : {(const void *)dst, src}) {
+            auto it = mock_registered_rows().find(cand);
+            if (it != mock_registered_rows().end()) { it->second++; host = cand; break; }
+        }
+    }
     s->push([=] {
         if (us) std::this_thread::sleep_for(std::chrono::microseconds(us));
         std::memcpy(dst, src, n);
+        if (host) {
+            std::lock_guard<std::mutex> g(mock_mutex());
+            auto it = mock_registered_rows().find(host);
+            if (it != mock_registered_rows().end()) it->second--;
+        }
     });
     return hipSuccess;
 }

@@ -96,9 +96,59 @@ static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t 
 }
 
 static int all_cases();
+
+// run_on_devices: the units of one call cut into shares, every share a whole pipeline on its own thread with its own
+// device current; here two or three shares run at once (the mock has four devices), one of them may fail.
+static int share_cases()
+{
+    int bad = 0;
+    {
+        const auto plan = plan_shares({0, 1, 2, 3}, 10, 4);       // shares of at least 4 units: two of them
+        if (plan.size() != 2 || plan[0].count != 5 || plan[1].first != 5 || plan[1].device != 1) { std::printf("plan_shares (min units)\n"); bad++; }
+        const auto all = plan_shares({2, 2, 0}, 7, 0);
+        if (all.size() != 3 || all[0].count != 3 || all[1].count != 2 || all[2].first != 5 || all[2].device != 0) { std::printf("plan_shares (split)\n"); bad++; }
+        if (!plan_shares({}, 5, 0).empty() || !plan_shares({0}, 0, 0).empty()) { std::printf("plan_shares (empty)\n"); bad++; }
+    }
+    for (int fail_share : {-1, 1}) {
+        std::mutex m;
+        std::vector<int> devices_seen;
+        const auto shares = plan_shares({3, 1, 2}, 96, 8);
+        (void)hipSetDevice(0);
+        const Result r = run_on_devices(shares, [&](const Share &sh, std::string &why) -> int {
+            int dev = -1;
+            (void)hipGetDevice(&dev);
+            {
+                std::lock_guard<std::mutex> g(m);
+                devices_seen.push_back(dev * 1000 + sh.device);
+            }
+            if (sh.index == fail_share) {
+                why = "share refused";
+                return -7;
+            }
+            // every share is a whole pipelined call over its own units
+            return run_case(sh.count, 1, 1, 700 + sh.index, 90, 8, 2, 2, 2048, 10, -1, false) ? -1 : 0;
+        });
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        if (dev != 0) { std::printf("the caller's device changed to %d\n", dev); bad++; }
+        if (fail_share < 0 && r.code != 0) { std::printf("shares failed: %d %s\n", r.code, r.why.c_str()); bad++; }
+        if (fail_share >= 0 && (r.code != -7 || r.why != "share refused")) { std::printf("failing share not reported: %d\n", r.code); bad++; }
+        std::sort(devices_seen.begin(), devices_seen.end());
+        // share 0 runs on the calling thread, whose device is not touched; the others run with their device current
+        if (devices_seen != std::vector<int>{3, 1001, 2002} && devices_seen != std::vector<int>{1001, 2002, 3003}) {
+            std::printf("shares saw the wrong devices:");
+            for (int d : devices_seen) std::printf(" %d", d);
+            std::printf("\n");
+            bad++;
+        }
+    }
+    return bad;
+}
+
 int main()
 {
     int bad = 0;
+    bad += share_cases();
     // direct uploads, direct downloads, shared copy streams, compute lanes
     const int modes[][4] = {{0, 0, 0, 1}, {1, 1, 0, 1}, {0, 0, 1, 1}, {1, 1, 1, 3}, {1, 0, 1, 2}, {0, 1, 0, 3}};
     for (const auto &m : modes) {
@@ -110,6 +160,7 @@ int main()
     }
     PinnedPool::get().trim();
     if (mock_registered() != 0) { std::printf("%d rows left registered\n", mock_registered()); bad++; }
+    if (mock_unregister_violations() != 0) { std::printf("%d rows unregistered with a copy still pending\n", mock_unregister_violations()); bad++; }
     std::printf(bad ? "FAILED %d\n" : "ok\n", bad);
     return bad ? 1 : 0;
 }

@@ -30,6 +30,39 @@ def test_header_symbols_exported():
     assert not [n for n in names if n not in _lib.SIGNATURES], "ctypes SIGNATURES missing entries"
 
 
+def _declared_arg_counts():
+    inc = os.path.join(ROOT, "include")
+    text = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//.*", "", text)
+    text = re.sub(r"^\s*#.*$", "", text, flags=re.M)
+    out = {}
+    for name, args in re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(([^;{()]*)\)\s*;", text):
+        args = args.strip()
+        out[name] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def test_ctypes_signatures_have_the_headers_argument_counts():
+    """ctypes tolerates extra or missing arguments of cdecl functions silently: hold the table to the header"""
+    from vgaudio_amd import _lib
+    counts = _declared_arg_counts()
+    wrong = {n: (len(_lib.SIGNATURES[n][1]), c) for n, c in counts.items()
+             if n in _lib.SIGNATURES and len(_lib.SIGNATURES[n][1]) != c}
+    assert not wrong, f"(ctypes, header) argument counts differ: {wrong}"
+
+
+def test_device_list_is_host_state_and_validated():
+    """vga_set_devices without a GPU: an empty list is always fine, a device that does not exist is refused loudly"""
+    import ctypes as C
+    from vgaudio_amd import _lib
+    L = _lib.lib()
+    assert L.vga_set_devices(None, 0) == 0 and L.vga_get_devices(None, 0) == 0
+    bad = (C.c_int * 2)(0, 99)
+    assert L.vga_set_devices(bad, 2) != 0
+    assert L.vga_get_devices(None, 0) == 0
+
+
 def test_test_hooks_are_not_in_the_drop_in_header():
     text = open(os.path.join(ROOT, "include", "vgaudio_hip.h")).read()
     assert "debug" not in text.lower() and "testing" not in text.lower()

@@ -52,7 +52,7 @@ WORKER = textwrap.dedent("""
     rows[:, :adpcm.shape[1]] = torch.from_numpy(np.ascontiguousarray(adpcm))
     g = vd.BitstreamGather(counts, pitch, torch.device("cpu"), chunk_channels=2)
     g.gather(rows, torch.from_numpy(coefs).reshape(count, 16))
-    works = g.gather(rows, torch.from_numpy(coefs).reshape(count, 16), async_op=True)      # and the asynchronous form
+    works = g.gather(rows, torch.from_numpy(coefs).reshape(count, 16), async_op=True, nbytes=adpcm.shape[1])      # and the asynchronous form, with digests
     for w in works:
         w.wait()
     if rank == 0:
@@ -60,19 +60,27 @@ WORKER = textwrap.dedent("""
         np.save(os.path.join({out!r}, "gathered_adpcm.npy"), g.all_adpcm[:, :adpcm.shape[1]].numpy())
         np.save(os.path.join({out!r}, "gathered_coefs.npy"), g.all_coefs.numpy())
         assert g.verify(rows, torch.from_numpy(coefs).reshape(count, 16), adpcm.shape[1]).startswith("own rows identical")
+        # a peer's rows arriving permuted, or stale by one byte, must not pass
+        keep = g.all_adpcm.clone()
+        f1 = g.firsts[1]
+        g.all_adpcm[[f1, f1 + 1]] = g.all_adpcm[[f1 + 1, f1]]
+        assert "wrong digest: [1]" in g.verify(rows, torch.from_numpy(coefs).reshape(count, 16), adpcm.shape[1])
+        g.all_adpcm.copy_(keep)
+        g.all_adpcm[f1 + 2, 5] ^= 1
+        assert "wrong digest: [1]" in g.verify(rows, torch.from_numpy(coefs).reshape(count, 16), adpcm.shape[1])
+        g.all_adpcm.copy_(keep)
+        assert g.verify(rows, torch.from_numpy(coefs).reshape(count, 16), adpcm.shape[1]).startswith("own rows identical")
     dist.barrier()
     dist.destroy_process_group()
 """)
 
 
 def test_two_rank_gloo_sharded_encode(tmp_path):
+    """the ranks are started by the launcher `python bench.py --gpus N` uses (distributed.launch_local_ranks)"""
+    from vgaudio_amd.distributed import launch_local_ranks
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
-             for r in range(2)]
-    for p in procs:
-        assert p.wait(timeout=240) == 0
+    assert launch_local_ranks([str(script)], 2, timeout=240) == 0
     from oracle import pyoracle as po
     from vgaudio_amd import synth
     pcm = synth.generate(7, 14 * 200 + 3)
@@ -84,3 +92,27 @@ def test_two_rank_gloo_sharded_encode(tmp_path):
     # the gathered bitstream on rank 0 is the single-process result, channel for channel
     assert (np.load(tmp_path / "gathered_adpcm.npy") == adpcm).all()
     assert (np.load(tmp_path / "gathered_coefs.npy").reshape(7, 16) == np.asarray(coefs).reshape(7, 16)).all()
+
+
+def test_launcher_reports_a_failing_rank_and_stops_the_others(tmp_path):
+    from vgaudio_amd.distributed import launch_local_ranks
+    script = tmp_path / "fail.py"
+    script.write_text("import os, sys, time\n"
+                      "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                      "if os.environ['RANK'] == '1':\n    sys.exit(7)\n"
+                      "time.sleep(60)\n")
+    import time
+    t0 = time.monotonic()
+    assert launch_local_ranks([str(script)], 3, timeout=120) == 7
+    assert time.monotonic() - t0 < 30
+
+
+def test_launcher_passes_rank_zero_stdout_through(tmp_path):
+    script = tmp_path / "echo.py"
+    script.write_text("import os\nprint('line from rank', os.environ['RANK'], os.environ['LOCAL_RANK'], flush=True)\n")
+    code = ("import sys; sys.path.insert(0, %r); from vgaudio_amd.distributed import launch_local_ranks; "
+            "sys.exit(launch_local_ranks([%r], 2, timeout=60))" % (ROOT, str(script)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    assert r.stdout.strip() == "line from rank 0 0"           # one line on stdout: rank 0's
+    assert "line from rank 1 1" in r.stderr

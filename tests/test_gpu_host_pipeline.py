@@ -62,3 +62,58 @@ def test_hca_through_every_pipeline_shape(shape):
     assert rc == 0
     for s in range(ns):
         assert np.array_equal(np.stack(dec[s]), wdec[s]), s
+
+
+@pytest.fixture(params=[[0, 0], [0, 0, 0], "all"], ids=["twice", "thrice", "all-devices"])
+def devices(request):
+    """vga_set_devices: one process, several GPUs (a device may be listed more than once -- which is how a one-GPU box
+    exercises the shares)"""
+    import ctypes as C
+    L = _lib.lib()
+    lst = list(range(L.vga_device_count())) if request.param == "all" else request.param
+    _lib.check(L.vga_set_devices((C.c_int * len(lst))(*lst), len(lst)))
+    yield lst
+    _lib.check(L.vga_set_devices(None, 0))
+
+
+def test_calls_spread_over_listed_devices_give_the_same_bytes(devices):
+    """every *_batch entry point with its units cut into shares (>= 128 channels / 32 streams each), against the oracle"""
+    nch, n = 128 * len(devices) + 41, 14 * 700 + 9
+    pcm = synth.generate(nch, n)
+    fmt = GcAdpcmFormat().EncodeFromPcm16(Pcm16Format(list(pcm), 48000))
+    wc, wa = po.gc_encode_batch(pcm, threads=8)
+    wc = np.asarray(wc).reshape(nch, 16)
+    got_coefs = np.stack([ch.Coefs for ch in fmt.Channels])
+    got_adpcm = np.stack([ch.GetAdpcmAudio() for ch in fmt.Channels])
+    assert np.array_equal(got_coefs, wc) and np.array_equal(got_adpcm, np.asarray(wa)[:, :got_adpcm.shape[1]])
+    dec = GcAdpcmDecoder.Decode(list(got_adpcm), got_coefs, GcAdpcmParameters(SampleCount=n))
+    assert np.array_equal(np.stack(dec), po.gc_decode_batch(got_adpcm, wc, n, threads=8))
+    # ADX
+    cfg = CriAdxParameters()
+    enc = CriAdxCodec.Encode(list(pcm), cfg)
+    want, hist = po.adx_encode_batch(pcm, po.adx_params(), threads=8)
+    assert np.array_equal(np.stack(enc), want) and np.array_equal(np.asarray(cfg.History), hist)
+    assert np.array_equal(np.stack(CriAdxCodec.Decode(enc, n, CriAdxParameters())), po.adx_decode_batch(want, n, po.adx_params(), threads=8))
+    # HCA: streams are the units
+    ns, hn = 32 * len(devices) + 5, 4000
+    streams = [synth.generate(2, hn, first_channel=2 * s) for s in range(ns)]
+    fmts = CriHcaFormat.EncodeBatchFromPcm16([Pcm16Format(list(s), 48000) for s in streams], CriHcaParameters())
+    rc, info, hwant = po.hca_encode_batch(np.stack(streams), po.hca_params(2, hn), threads=8)
+    assert rc == 0
+    for s in range(ns):
+        assert np.array_equal(fmts[s].AudioData.reshape(-1), hwant[s]), s
+    hdec = CriHcaDecoder.Decode(fmts[0].Hca, [f.AudioData for f in fmts])
+    rc, wdec = po.hca_decode_batch(info, hwant, threads=8)
+    for s in range(ns):
+        assert np.array_equal(np.stack(hdec[s]), wdec[s]), s
+
+
+def test_a_failing_share_fails_the_call(devices):
+    import vgaudio_amd
+    nch, n = 128 * len(devices), 14 * 50
+    pcm = synth.generate(nch, n)
+    fmt = GcAdpcmFormat().EncodeFromPcm16(Pcm16Format(list(pcm), 48000))
+    adpcm = [ch.GetAdpcmAudio().copy() for ch in fmt.Channels]
+    adpcm[nch - 3][8] = 0xF0                                  # predictor 15 in the LAST share: IndexOutOfRange in the reference
+    with pytest.raises(vgaudio_amd.ArgumentError):
+        GcAdpcmDecoder.Decode(adpcm, np.stack([ch.Coefs for ch in fmt.Channels]), GcAdpcmParameters(SampleCount=n))

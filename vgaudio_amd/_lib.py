@@ -114,7 +114,7 @@ SIGNATURES = {
     "vga_hca_find_key": (ci, [vp, u8p, ci, u8p, ci, vp]),
     "vga_hca_find_key_device": (ci, [vp, vp, ci, u8p, ci, vp, vp]),
     "vga_hca_byte_position_counts_device": (ci, [vp, i64, ci, ci, ci, ci, vp, vp]),
-    "vga_adx_guess_default_candidates": (ci, [vp, vp, vp, vp]),
+    "vga_adx_guess_default_candidates": (ci, [ci, vp, vp, vp, vp]),
     "vga_adx_guess_keys": (ci, [vp, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp]),
     "vga_hca_crypt_device": (ci, [vp, i64, ci, ci, ci, u8p, vp]),
     "vga_release_cached_memory": (None, []),
@@ -125,6 +125,8 @@ SIGNATURES = {
     "vga_testing_gc_encoder_segments_this_thread": (ci, [ci]),
     "vga_testing_last_pipeline_stats": (ci, [vp, ci]),
     "vga_testing_hca_device_info": (ci, [vp, vp, ci]),
+    "vga_set_devices": (ci, [vp, ci]),
+    "vga_get_devices": (ci, [vp, ci]),
     "vga_testing_hca_frames_per_group_this_thread": (ci, [ci]),
     "vga_dsp_layout_for": (ci, [vp, ci, vp]),
     "vga_dsp_write": (ci, [u8pp, ci, i16p, i16p, i16p, i16p, ci, vp, u8p]),

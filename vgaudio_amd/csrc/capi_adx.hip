@@ -143,8 +143,20 @@ int vga_adx_decode_device(const uint8_t *d_adpcm, int64_t in_pitch, int adpcm_le
                               (hipStream_t)stream);
 }
 
+static constexpr int ADX_MIN_SHARE_CHANNELS = 128;     // channels per share of a call spread over several GPUs (vga_set_devices)
+
+static int adx_encode_batch_one(const int16_t *const *pcm, int nch, int pcm_length, const vga_adx_params *p, uint8_t *const *out,
+                                int16_t *history_out);
 int vga_adx_encode_batch(const int16_t *const *pcm, int nch, int pcm_length, const vga_adx_params *p,
                          uint8_t *const *out, int16_t *history_out)
+{
+    if (nch <= 0 || !pcm || !out) return adx_encode_batch_one(pcm, nch, pcm_length, p, out, history_out);
+    return for_each_device_share(nch, ADX_MIN_SHARE_CHANNELS, [&](int first, int count) {
+        return adx_encode_batch_one(pcm + first, count, pcm_length, p, out + first, history_out ? history_out + first : nullptr);
+    });
+}
+static int adx_encode_batch_one(const int16_t *const *pcm, int nch, int pcm_length, const vga_adx_params *p, uint8_t *const *out,
+                                int16_t *history_out)
 {
     if (int rc = validate(p)) return rc;
     if (nch < 0 || pcm_length < 0) { set_error("negative size"); return VGA_ERR_ARGUMENT; }
@@ -190,8 +202,18 @@ int vga_adx_encode_batch(const int16_t *const *pcm, int nch, int pcm_length, con
     return VGA_OK;
 }
 
+static int adx_decode_batch_one(const uint8_t *const *adpcm, int adpcm_length, int nch, int sample_count, const vga_adx_params *p,
+                                int16_t *const *pcm_out);
 int vga_adx_decode_batch(const uint8_t *const *adpcm, int adpcm_length, int nch, int sample_count,
                          const vga_adx_params *p, int16_t *const *pcm_out)
+{
+    if (nch <= 0 || !adpcm || !pcm_out) return adx_decode_batch_one(adpcm, adpcm_length, nch, sample_count, p, pcm_out);
+    return for_each_device_share(nch, ADX_MIN_SHARE_CHANNELS, [&](int first, int count) {
+        return adx_decode_batch_one(adpcm + first, adpcm_length, count, sample_count, p, pcm_out + first);
+    });
+}
+static int adx_decode_batch_one(const uint8_t *const *adpcm, int adpcm_length, int nch, int sample_count, const vga_adx_params *p,
+                                int16_t *const *pcm_out)
 {
     if (int rc = validate(p)) return rc;
     if (nch < 0 || sample_count < 0 || adpcm_length < 0) { set_error("negative size"); return VGA_ERR_ARGUMENT; }

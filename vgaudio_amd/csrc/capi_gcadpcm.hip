@@ -4,13 +4,18 @@
 #include "../../include/vgaudio_hip_testing.h"
 
 #include <algorithm>
+#include <mutex>
+#include <vector>
 #include "gcadpcm_kernels.hpp"
 
 #include <cmath>
+#include <dirent.h>
+#include <unistd.h>
 
 namespace vga {
 
 static thread_local char g_err[512] = "";
+static thread_local bool g_err_pending = false;
 
 void set_error(const char *fmt, ...)
 {
@@ -18,6 +23,14 @@ void set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
+    g_err_pending = true;
+}
+
+bool take_error_pending()
+{
+    const bool was = g_err_pending;
+    g_err_pending = false;
+    return was;
 }
 
 // test hook (include/vgaudio_hip_testing.h): per calling thread, so that no call on another thread is affected
@@ -39,21 +52,66 @@ int hca_frames_per_group_override() { return g_hca_frames_per_group; }
 // 4096-channel encode ended only when the last kernel had, 660 ms instead of 533 ms).  The variable is read when the
 // runtime initialises, so it is set when this library is loaded -- only if the host has not set it; a host that
 // initialises HIP before loading the library sets it itself.
-__attribute__((constructor)) static void ask_for_hardware_queues()
+// Whether the runtime had already been brought up when this library was loaded: its KFD device is then open.
+static bool runtime_is_up()
 {
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    DIR *d = opendir("/proc/self/fd");
+    if (!d) return false;
+    bool up = false;
+    char path[64], target[64];
+    while (dirent *e = readdir(d)) {
+        std::snprintf(path, sizeof path, "/proc/self/fd/%s", e->d_name);
+        const ssize_t n = readlink(path, target, sizeof target - 1);
+        if (n > 0) {
+            target[n] = 0;
+            if (std::strcmp(target, "/dev/kfd") == 0) { up = true; break; }
+        }
+    }
+    closedir(d);
+    return up;
 }
 
-int hardware_queues_requested()
+static int g_queues_seen_by_runtime = 4;             // what the HIP runtime reads (or read) from GPU_MAX_HW_QUEUES
+__attribute__((constructor)) static void ask_for_hardware_queues()
 {
-    static const int n = [] {
-        const char *e = std::getenv("GPU_MAX_HW_QUEUES");
-        return e ? std::atoi(e) : 4;
-    }();
-    return n;
+    const char *host = std::getenv("GPU_MAX_HW_QUEUES");
+    const char *opt_out = std::getenv("VGA_HIP_NO_ENV");
+    if (host) {
+        g_queues_seen_by_runtime = std::atoi(host);  // the host's choice (set before it brought the runtime up, one assumes)
+    } else if (opt_out && opt_out[0] && opt_out[0] != '0') {
+        g_queues_seen_by_runtime = 4;                // the runtime's default
+    } else if (runtime_is_up()) {
+        g_queues_seen_by_runtime = 4;                // too late: the runtime initialised without the variable
+    } else {
+        setenv("GPU_MAX_HW_QUEUES", "16", 0);
+        g_queues_seen_by_runtime = 16;
+    }
 }
+
+int hardware_queues_requested() { return g_queues_seen_by_runtime; }
 static thread_local PipeOverride g_pipe_override;
 PipeOverride &pipe_override() { return g_pipe_override; }
+
+static std::mutex g_devices_mutex;
+static std::vector<int> g_devices;                   // vga_set_devices(); empty = the caller's current device
+std::vector<int> batch_devices()
+{
+    std::lock_guard<std::mutex> g(g_devices_mutex);
+    return g_devices;
+}
+ThreadHooks capture_thread_hooks()
+{
+    return ThreadHooks{g_force_open_seams, g_encoder_layout, g_coefs_variant, g_encoder_segments, g_hca_frames_per_group, g_pipe_override};
+}
+void apply_thread_hooks(const ThreadHooks &h)
+{
+    g_force_open_seams = h.force_open_seams;
+    g_encoder_layout = h.encoder_layout;
+    g_coefs_variant = h.coefs_variant;
+    g_encoder_segments = h.encoder_segments;
+    g_hca_frames_per_group = h.hca_frames_per_group;
+    g_pipe_override = h.pipe;
+}
 static thread_local PipeReport g_pipe_report;
 PipeReport &pipe_report() { return g_pipe_report; }
 
@@ -147,6 +205,28 @@ int vga_set_device(int device)
 {
     VGA_HIP_TRY(hipSetDevice(device));
     return VGA_OK;
+}
+
+int vga_set_devices(const int *devices, int count)
+{
+    if (count < 0 || (count > 0 && !devices) || count > 64) { set_error("vga_set_devices: bad device list"); return VGA_ERR_ARGUMENT; }
+    int n = 0;
+    if (count > 0 && (hipGetDeviceCount(&n) != hipSuccess || n <= 0)) {
+        set_error("no HIP device available; libvgaudio_hip has no CPU fallback");
+        return VGA_ERR_DEVICE;
+    }
+    for (int i = 0; i < count; i++)
+        if (devices[i] < 0 || devices[i] >= n) { set_error("vga_set_devices: device %d of %d does not exist", devices[i], n); return VGA_ERR_ARGUMENT; }
+    std::lock_guard<std::mutex> g(g_devices_mutex);
+    g_devices.assign(devices, devices + count);
+    return VGA_OK;
+}
+
+int vga_get_devices(int *devices, int capacity)
+{
+    std::lock_guard<std::mutex> g(g_devices_mutex);
+    for (int i = 0; i < (int)g_devices.size() && i < capacity && devices; i++) devices[i] = g_devices[i];
+    return (int)g_devices.size();
 }
 
 int vga_gcadpcm_nibble_count_to_sample_count(int nibble_count)
@@ -494,7 +574,18 @@ int download_adpcm(GcBatch &b, uint8_t *const *adpcm_out, int nch, int nbytes)
 // of configs[1] has arrived, large enough that the coefficient kernel (one wave per channel) still has a wave per SIMD.
 static constexpr int GC_CHUNK_CHANNELS = 1024;
 
+// channels per share when a call is spread over several GPUs (vga_set_devices): below this one GPU's pipeline is faster
+static constexpr int GC_MIN_SHARE_CHANNELS = 128;
+
+static int calculate_coefficients_batch_one(const int16_t *const *pcm, int nch, int length, int16_t *coefs_out);
 int vga_gcadpcm_calculate_coefficients_batch(const int16_t *const *pcm, int nch, int length, int16_t *coefs_out)
+{
+    if (nch <= 0 || !pcm || !coefs_out) return calculate_coefficients_batch_one(pcm, nch, length, coefs_out);
+    return for_each_device_share(nch, GC_MIN_SHARE_CHANNELS, [&](int first, int count) {
+        return calculate_coefficients_batch_one(pcm + first, count, length, coefs_out + (size_t)first * 16);
+    });
+}
+static int calculate_coefficients_batch_one(const int16_t *const *pcm, int nch, int length, int16_t *coefs_out)
 {
     if (length < 0) { set_error("negative length"); return VGA_ERR_ARGUMENT; }
     if (int rc = check_ptrs((const void *const *)pcm, length > 0 ? nch : 0, "pcm")) return rc;
@@ -526,9 +617,21 @@ int vga_gcadpcm_calculate_coefficients_batch(const int16_t *const *pcm, int nch,
     return VGA_OK;
 }
 
+static int encode_with_coefs_batch_one(const int16_t *const *pcm, int nch, int pcm_length, int sample_count, const int16_t *coefs,
+                                      const int16_t *hist1, const int16_t *hist2, uint8_t *const *adpcm_out);
 int vga_gcadpcm_encode_with_coefs_batch(const int16_t *const *pcm, int nch, int pcm_length, int sample_count,
                                         const int16_t *coefs, const int16_t *hist1, const int16_t *hist2,
                                         uint8_t *const *adpcm_out)
+{
+    if (nch <= 0 || !pcm || !coefs || !adpcm_out)
+        return encode_with_coefs_batch_one(pcm, nch, pcm_length, sample_count, coefs, hist1, hist2, adpcm_out);
+    return for_each_device_share(nch, GC_MIN_SHARE_CHANNELS, [&](int first, int count) {
+        return encode_with_coefs_batch_one(pcm + first, count, pcm_length, sample_count, coefs + (size_t)first * 16,
+                                          hist1 ? hist1 + first : nullptr, hist2 ? hist2 + first : nullptr, adpcm_out + first);
+    });
+}
+static int encode_with_coefs_batch_one(const int16_t *const *pcm, int nch, int pcm_length, int sample_count, const int16_t *coefs,
+                                      const int16_t *hist1, const int16_t *hist2, uint8_t *const *adpcm_out)
 {
     if (sample_count == -1) sample_count = pcm_length;
     if (pcm_length < 0 || sample_count < 0) { set_error("negative length"); return VGA_ERR_ARGUMENT; }
@@ -575,8 +678,18 @@ int vga_gcadpcm_encode_with_coefs_batch(const int16_t *const *pcm, int nch, int 
     return run_batch_pipeline(job, GC_CHUNK_CHANNELS);
 }
 
+static int encode_batch_one(const int16_t *const *pcm, int nch, int sample_count, int16_t hist1, int16_t hist2, int16_t *coefs_out,
+                           uint8_t *const *adpcm_out);
 int vga_gcadpcm_encode_batch(const int16_t *const *pcm, int nch, int sample_count, int16_t hist1, int16_t hist2,
                              int16_t *coefs_out, uint8_t *const *adpcm_out)
+{
+    if (nch <= 0 || !pcm || !coefs_out || !adpcm_out) return encode_batch_one(pcm, nch, sample_count, hist1, hist2, coefs_out, adpcm_out);
+    return for_each_device_share(nch, GC_MIN_SHARE_CHANNELS, [&](int first, int count) {
+        return encode_batch_one(pcm + first, count, sample_count, hist1, hist2, coefs_out + (size_t)first * 16, adpcm_out + first);
+    });
+}
+static int encode_batch_one(const int16_t *const *pcm, int nch, int sample_count, int16_t hist1, int16_t hist2, int16_t *coefs_out,
+                           uint8_t *const *adpcm_out)
 {
     if (sample_count < 0) { set_error("negative sample count"); return VGA_ERR_ARGUMENT; }
     if (int rc = check_ptrs((const void *const *)pcm, sample_count > 0 ? nch : 0, "pcm")) return rc;
@@ -644,8 +757,19 @@ int vga_gcadpcm_encode_batch(const int16_t *const *pcm, int nch, int sample_coun
     return VGA_OK;
 }
 
+static int decode_batch_one(const uint8_t *const *adpcm, const int16_t *coefs, int nch, int sample_count, const int16_t *hist1,
+                           const int16_t *hist2, int16_t *const *pcm_out);
 int vga_gcadpcm_decode_batch(const uint8_t *const *adpcm, const int16_t *coefs, int nch, int sample_count,
                              const int16_t *hist1, const int16_t *hist2, int16_t *const *pcm_out)
+{
+    if (nch <= 0 || !adpcm || !coefs || !pcm_out) return decode_batch_one(adpcm, coefs, nch, sample_count, hist1, hist2, pcm_out);
+    return for_each_device_share(nch, GC_MIN_SHARE_CHANNELS, [&](int first, int count) {
+        return decode_batch_one(adpcm + first, coefs + (size_t)first * 16, count, sample_count, hist1 ? hist1 + first : nullptr,
+                               hist2 ? hist2 + first : nullptr, pcm_out + first);
+    });
+}
+static int decode_batch_one(const uint8_t *const *adpcm, const int16_t *coefs, int nch, int sample_count, const int16_t *hist1,
+                           const int16_t *hist2, int16_t *const *pcm_out)
 {
     if (sample_count < 0) { set_error("negative sample count"); return VGA_ERR_ARGUMENT; }
     if (int rc = check_ptrs((const void *const *)adpcm, sample_count > 0 ? nch : 0, "adpcm")) return rc;

@@ -340,8 +340,22 @@ static constexpr int HCA_CHUNK_STREAMS = 256;
 
 // CriHcaFormat.EncodeFromPcm16 (Formats/CriHca/CriHcaFormat.cs:34-84) for a batch of equally shaped streams.
 // pcm: nstreams*channel_count planar pointers (stream-major); frames_out[s]: frame_count*frame_size bytes.
+static constexpr int HCA_MIN_SHARE_STREAMS = 32;       // streams per share of a call spread over several GPUs (vga_set_devices)
+
+static int hca_encode_batch_one(const int16_t *const *pcm, int nstreams, const vga_hca_params *p, vga_hca_info *info_out,
+                                uint8_t *const *frames_out);
 int vga_hca_encode_batch(const int16_t *const *pcm, int nstreams, const vga_hca_params *p, vga_hca_info *info_out,
                          uint8_t *const *frames_out)
+{
+    if (nstreams <= 0 || !pcm || !frames_out || !p || p->channel_count < 1 || p->channel_count > 8)
+        return hca_encode_batch_one(pcm, nstreams, p, info_out, frames_out);
+    const int nch = p->channel_count;
+    return for_each_device_share(nstreams, HCA_MIN_SHARE_STREAMS, [&](int first, int count) {
+        return hca_encode_batch_one(pcm + (size_t)first * nch, count, p, first == 0 ? info_out : nullptr, frames_out + first);
+    });
+}
+static int hca_encode_batch_one(const int16_t *const *pcm, int nstreams, const vga_hca_params *p, vga_hca_info *info_out,
+                                uint8_t *const *frames_out)
 {
     vga_hca_info h;
     if (int rc = vga_hca_encoder_initialize(p, &h)) return rc;
@@ -394,7 +408,17 @@ int vga_hca_encode_batch(const int16_t *const *pcm, int nstreams, const vga_hca_
 }
 
 // CriHcaFormat.ToPcm16 (CriHcaFormat.cs:26-32 -> CriHcaDecoder.Decode, CriHcaDecoder.cs:11-29), batched.
+static int hca_decode_batch_one(const vga_hca_info *h, const uint8_t *const *frames, int nstreams, int16_t *const *pcm_out);
 int vga_hca_decode_batch(const vga_hca_info *h, const uint8_t *const *frames, int nstreams, int16_t *const *pcm_out)
+{
+    if (nstreams <= 0 || !h || !frames || !pcm_out || h->channel_count < 1 || h->channel_count > 8)
+        return hca_decode_batch_one(h, frames, nstreams, pcm_out);
+    const int nch = h->channel_count;
+    return for_each_device_share(nstreams, HCA_MIN_SHARE_STREAMS, [&](int first, int count) {
+        return hca_decode_batch_one(h, frames + first, count, pcm_out + (size_t)first * nch);
+    });
+}
+static int hca_decode_batch_one(const vga_hca_info *h, const uint8_t *const *frames, int nstreams, int16_t *const *pcm_out)
 {
     if (!h) { set_error("null HcaInfo"); return VGA_ERR_ARGUMENT; }
     hca::DeviceInfo d;

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -13,6 +14,8 @@
 namespace vga {
 
 void set_error(const char *fmt, ...);
+// true once after set_error() on this thread (DevBuf: synchronise before a block goes back to the pool)
+bool take_error_pending();
 
 // status helper: HIP failure -> VGA_ERR_DEVICE with message
 #define VGA_HIP_TRY(expr)                                                              \
@@ -27,9 +30,12 @@ void set_error(const char *fmt, ...);
 
 // Process-wide cache of the host-buffer entry points' device allocations.  hipMalloc maps memory at ~25 GB/s (1.4 s for
 // the 44 GB of a configs[1] call: more than the call's transfers and kernels together); a caller converting batch after
-// batch gets the previous call's buffers back instead.  Blocks of at least 1 MiB are parked on release (up to 64 GiB,
-// largest dropped first) and handed to the next request they fit without wasting more than half; smaller ones go
-// straight to hipMalloc / hipFree.  vga_release_cached_memory() empties the cache.
+// batch gets the previous call's buffers back instead.  Blocks of at least 1 MiB are parked on release (up to 64 GiB PER
+// DEVICE -- a process that drives eight GPUs keeps eight working sets; VGA_HIP_POOL_GIB changes the figure, 0 turns the
+// cache off -- largest dropped first) and handed to the next request they fit without wasting more than half; smaller
+// ones go straight to hipMalloc / hipFree.  vga_release_cached_memory() empties the cache.  A block released while the
+// calling thread is unwinding from a failed call (set_error() was called) may still be read or written by work that call
+// enqueued: the device is synchronised first (hipFree used to do that implicitly).
 class DevicePool {
 public:
     static DevicePool &get()
@@ -74,16 +80,18 @@ public:
         {
             std::lock_guard<std::mutex> g(m_);
             bool pooled = false;
-            size_t idle = 0;
-            for (auto &b : blocks_) {
-                if (b.p == p) { b.busy = false; pooled = true; }
-                if (!b.busy) idle += b.bytes;
-            }
+            int device = -1;
+            for (auto &b : blocks_)
+                if (b.p == p) { b.busy = false; pooled = true; device = b.device; }
+            size_t idle = 0;                               // parked on the released block's device
+            for (auto &b : blocks_)
+                if (!b.busy && b.device == device) idle += b.bytes;
             if (!pooled) drop.push_back(p);
-            while (idle > kKeepBytes) {
+            const size_t keep = keep_bytes();
+            while (idle > keep) {
                 int big = -1;
                 for (int i = 0; i < (int)blocks_.size(); i++)
-                    if (!blocks_[i].busy && (big < 0 || blocks_[i].bytes > blocks_[big].bytes)) big = i;
+                    if (!blocks_[i].busy && blocks_[i].device == device && (big < 0 || blocks_[i].bytes > blocks_[big].bytes)) big = i;
                 if (big < 0) break;
                 idle -= blocks_[big].bytes;
                 drop.push_back(blocks_[big].p);
@@ -106,8 +114,26 @@ public:
         for (void *q : drop) (void)hipFree(q);
     }
 
+    // device the block was allocated on (-1: not pooled)
+    int device_of(void *p)
+    {
+        std::lock_guard<std::mutex> g(m_);
+        for (auto &b : blocks_)
+            if (b.p == p) return b.device;
+        return -1;
+    }
+
 private:
-    static constexpr size_t kMinPooled = (size_t)1 << 20, kKeepBytes = (size_t)64 << 30;
+    static constexpr size_t kMinPooled = (size_t)1 << 20;
+    static size_t keep_bytes()
+    {
+        static const size_t v = [] {
+            const char *e = std::getenv("VGA_HIP_POOL_GIB");
+            const long gib = e ? std::atol(e) : 64;
+            return (size_t)(gib < 0 ? 0 : gib) << 30;
+        }();
+        return v;
+    }
     struct Block { void *p; size_t bytes; int device; bool busy; };
     std::mutex m_;
     std::vector<Block> blocks_;
@@ -120,9 +146,16 @@ struct DevBuf {
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { if (p) DevicePool::get().release(p); }
+    ~DevBuf() { drop(); }
+    void drop()
+    {
+        if (!p) return;
+        if (take_error_pending()) (void)hipDeviceSynchronize();   // a failed call's work may still touch the block
+        DevicePool::get().release(p);
+        p = nullptr;
+    }
     hipError_t alloc(size_t n) {
-        if (p) { DevicePool::get().release(p); p = nullptr; }
+        drop();
         bytes = n;
         return DevicePool::get().acquire(&p, n ? n : 1);
     }

@@ -15,6 +15,43 @@ struct PipeReport { pipe::Stats stats; double t_alloc = 0, t_entry = 0; };
 PipeReport &pipe_report();                           // capi_gcadpcm.hip
 int hardware_queues_requested();                     // capi_gcadpcm.hip: GPU_MAX_HW_QUEUES as this process will see it (4 when unset)
 
+// vga_set_devices(): the GPUs the host-pointer entry points spread one call's units over (empty: the calling thread's
+// current device, nothing is spread) -- capi_gcadpcm.hip
+std::vector<int> batch_devices();
+// the calling thread's test hooks (include/vgaudio_hip_testing.h), handed on to the threads that run a call's other shares
+struct ThreadHooks { int force_open_seams, encoder_layout, coefs_variant, encoder_segments, hca_frames_per_group; PipeOverride pipe; };
+ThreadHooks capture_thread_hooks();                  // capi_gcadpcm.hip
+void apply_thread_hooks(const ThreadHooks &h);       // capi_gcadpcm.hip
+
+// Runs body(first_unit, unit_count) -- the single-device form of an entry point, which reports failures through
+// set_error() + its status code -- once per share of `units` over vga_set_devices()'s list (pipe::run_on_devices: a host
+// thread and a whole pipeline per device; results land in the caller's rows, no collective).  Shares are at least
+// `min_units` units, so small calls stay on one GPU.
+template <class Body>
+inline int for_each_device_share(int units, int min_units, Body &&body)
+{
+    const std::vector<int> devices = batch_devices();
+    if (devices.empty() || units <= 0) return body(0, units);
+    const std::vector<pipe::Share> shares = pipe::plan_shares(devices, units, min_units);
+    const ThreadHooks hooks = capture_thread_hooks();
+    if (shares.size() == 1) {                          // one GPU, but the listed one
+        int before = 0;
+        VGA_HIP_TRY(hipGetDevice(&before));
+        VGA_HIP_TRY(hipSetDevice(shares[0].device));
+        const int rc = body(0, units);
+        (void)hipSetDevice(before);
+        return rc;
+    }
+    const pipe::Result r = pipe::run_on_devices(shares, [&](const pipe::Share &sh, std::string &why) -> int {
+        if (sh.index != 0) apply_thread_hooks(hooks);
+        const int rc = body(sh.first, sh.count);
+        if (rc) why = vga_last_error();
+        return rc;
+    });
+    if (r.code) set_error("%s", r.why.c_str());
+    return r.code;
+}
+
 // Units per chunk run_batch_pipeline() will use for this job (callers size per-chunk scratch with it).
 inline int planned_chunk_units(const pipe::Job &job, int default_chunk_units)
 {

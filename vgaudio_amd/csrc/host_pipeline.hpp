@@ -289,17 +289,14 @@ inline Result run(const Job &job)
     if (ok && has_out && !job.direct_out && !out_ring.alloc((size_t)D * R * out_slot_rows * job.d_out_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (output ring)");
 
     auto chunk_units_of = [&](int k) { return cbegin[k + 1] - cbegin[k]; };
+    std::vector<std::vector<void *>> locked_in(F), locked_out(D);      // rows page-locked for the call, per worker (see below)
 
     // ---------------------------------------------------------------- feeder t
     auto feeder = [&](int t) {
         VGA_PIPE_TRY(hipSetDevice(job.device));
         char *ring = static_cast<char *>(in_ring.p) + (size_t)t * R * in_slot_rows * job.d_in_pitch;
         int64_t used = 0;                                  // slots handed to the DMA engine so far
-        std::vector<void *> registered;                    // direct mode: rows this thread page-locked for the call
-        struct Unregister {
-            std::vector<void *> &v; hipStream_t s;
-            ~Unregister() { if (!v.empty()) { (void)hipStreamSynchronize(s); for (void *p : v) (void)hipHostUnregister(p); } }
-        } unregister{registered, fstream[t]};
+        std::vector<void *> &registered = locked_in[t];    // direct mode: rows this thread page-locked for the call
         double t_copy = 0, t_wait = 0, t_issue = 0, t_boundary = 0, t_final = 0;
         const double t_start = now();
         struct Report {
@@ -371,11 +368,7 @@ inline Result run(const Job &job)
         struct Pending { int row = -1, n = 0; };
         std::vector<Pending> pend(R);
         int64_t used = 0;
-        std::vector<void *> registered;
-        struct Unregister {
-            std::vector<void *> &v; hipStream_t s;
-            ~Unregister() { if (!v.empty()) { (void)hipStreamSynchronize(s); for (void *p : v) (void)hipHostUnregister(p); } }
-        } unregister{registered, dstream[u]};
+        std::vector<void *> &registered = locked_out[u];
         double t_wait_comp = 0, t_wait_copy = 0, t_copy = 0, t_register = 0;
         const double t_start = now();
         struct Report {
@@ -468,6 +461,10 @@ inline Result run(const Job &job)
         }
     };
 
+    // Rows page-locked for the call (direct mode), per worker.  They are unlocked only at the end of run(), after every
+    // thread has joined and every stream has drained: a drainer locks its share of the rows up front but copies whatever
+    // rows it claims, so a worker that unlocked "its" rows when it finished could pull them from under another worker's
+    // copy (hipHostUnregister happens to synchronise every stream on ROCm, which hid that; tests/host/mockhip counts it).
     std::vector<std::thread> threads;
     const double t_setup_done = now();
     if (ok) {
@@ -524,6 +521,9 @@ inline Result run(const Job &job)
     for (auto c : cstreams) if (c) (void)hipStreamSynchronize(c);
     for (auto s : fstream) if (s) (void)hipStreamSynchronize(s);
     for (auto s : dstream) if (s) (void)hipStreamSynchronize(s);
+    for (auto *side : {&locked_in, &locked_out})
+        for (auto &rows : *side)
+            for (void *p : rows) (void)hipHostUnregister(p);
     if (timeline && ok && !sh.err.load()) {
         auto at = [&](hipEvent_t e) { float ms = -1; (void)hipEventElapsedTime(&ms, cstart[chunks], e); return ms; };
         for (int k = 0; k < chunks; k++) {
@@ -551,6 +551,69 @@ inline Result run(const Job &job)
 }
 
 #undef VGA_PIPE_TRY
+
+// ---------------------------------------------------------------- several GPUs behind one call
+// The reference's parallelism lives inside one process (Parallel.For over channels, GcAdpcmFormat.cs:65-68; a worker per
+// file, Cli/Batch.cs:24-25), and so does a P/Invoke host: one call, one caller, N GPUs.  Units are independent, every
+// result lands in the caller's own rows, and each GPU has its own PCIe link -- so the units are cut into contiguous
+// shares, one per listed device, and every share runs the whole single-device entry point (its own device buffers,
+// feeder / drainer threads and streams: everything above) on its own host thread with that device current.  No
+// collective, no peer copies.  The calling thread takes share 0.
+struct Share {
+    int index = 0, device = 0, first = 0, count = 0;
+};
+
+// shares of `units` over `devices` (a device may be listed more than once); shares would be smaller than `min_units`
+// -> fewer of them.  Blocks differ by at most one unit.
+inline std::vector<Share> plan_shares(const std::vector<int> &devices, int units, int min_units)
+{
+    std::vector<Share> out;
+    if (units <= 0 || devices.empty()) return out;
+    int n = (int)devices.size();
+    if (min_units > 0) n = std::max(1, std::min(n, units / min_units));
+    n = std::max(1, std::min(n, units));
+    const int base = units / n, extra = units % n;
+    int first = 0;
+    for (int k = 0; k < n; k++) {
+        const int count = base + (k < extra ? 1 : 0);
+        out.push_back({k, devices[k], first, count});
+        first += count;
+    }
+    return out;
+}
+
+// body(const Share &, std::string &why) -> 0 or an error code.  Returns the first failing share's code and message
+// (by share index), after every share has finished.  With one share the body runs inline and the device is not touched.
+template <class Body>
+inline Result run_on_devices(const std::vector<Share> &shares, Body &&body)
+{
+    Result res;
+    if (shares.empty()) return res;
+    if (shares.size() == 1) {
+        res.code = body(shares[0], res.why);
+        return res;
+    }
+    int caller_device = 0;
+    (void)hipGetDevice(&caller_device);
+    std::vector<Result> each(shares.size());
+    auto one = [&](size_t k) {
+        const hipError_t e = hipSetDevice(shares[k].device);
+        if (e != hipSuccess) {
+            each[k].code = -5;
+            each[k].why = detail::hip_msg("hipSetDevice", e);
+            return;
+        }
+        each[k].code = body(shares[k], each[k].why);
+    };
+    std::vector<std::thread> threads;
+    for (size_t k = 1; k < shares.size(); k++) threads.emplace_back(one, k);
+    one(0);
+    for (auto &t : threads) t.join();
+    (void)hipSetDevice(caller_device);
+    for (auto &r : each)
+        if (r.code) return r;
+    return res;
+}
 
 }  // namespace pipe
 }  // namespace vga

@@ -136,7 +136,7 @@ def rows_digest(rows, nbytes, coefs, first_channel, chunk=512):
 def max_over_ranks(value, device):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -163,6 +163,9 @@ class BitstreamGather:
         self.chunk = max(1, int(chunk_channels))
         self.all_adpcm = self.all_coefs = None
         self.device = device
+        # gloo moves host memory only: device rows then travel through host copies (the CPU tests, and trying the N > 1
+        # path on a box with fewer GPUs than ranks); RCCL sends straight from HBM to HBM
+        self.via_host = self.world > 1 and dist.get_backend() == "gloo" and torch.device(device).type != "cpu"
         self.peer_digests = None               # rank 0: [world] int64, what every rank says its rows sum to (rows_digest)
         if self.rank == 0:
             self.peer_digests = torch.zeros(self.world, dtype=torch.int64, device=device)
@@ -191,6 +194,8 @@ class BitstreamGather:
             return []
         coef_bytes = coefs[:n].reshape(n, 16).contiguous().view(torch.uint8)
         works = []
+        if self.via_host:
+            return self._gather_via_host(adpcm, coef_bytes, digest, async_op)
         longest = max(self.counts)
         for c0 in range(0, longest, self.chunk):
             ops = []
@@ -214,6 +219,47 @@ class BitstreamGather:
             else:
                 ops = [dist.P2POp(dist.isend, digest.view(torch.uint8), 0)]
             works.extend(dist.batch_isend_irecv(ops))
+        if async_op:
+            return works
+        for w in works:
+            w.wait()
+        return []
+
+    def _gather_via_host(self, adpcm, coef_bytes, digest, async_op):
+        class Landing:                                  # a receive into host memory, copied to its place when waited for
+            def __init__(self, work, host, dest):
+                self.work, self.host, self.dest = work, host, dest
+
+            def wait(self):
+                self.work.wait()
+                if self.dest is not None:
+                    self.dest.copy_(self.host)
+
+        n = self.counts[self.rank]
+        works = []
+        for c0 in range(0, max(self.counts), self.chunk):
+            if self.rank == 0:
+                for r in range(1, self.world):
+                    c1 = min(c0 + self.chunk, self.counts[r])
+                    if c1 > c0:
+                        f = self.firsts[r]
+                        for dest in (self.all_adpcm[f + c0:f + c1], self.all_coefs[f + c0:f + c1].view(torch.uint8)):
+                            host = torch.empty(dest.shape, dtype=torch.uint8)
+                            works.append(Landing(dist.irecv(host, r), host, dest))
+            else:
+                c1 = min(c0 + self.chunk, n)
+                if c1 > c0:
+                    for src in (adpcm[c0:c1], coef_bytes[c0:c1]):
+                        host = src.cpu()
+                        works.append(Landing(dist.isend(host, 0), host, None))
+        if digest is not None:
+            if self.rank == 0:
+                for r in range(1, self.world):
+                    host = torch.empty(8, dtype=torch.uint8)
+                    works.append(Landing(dist.irecv(host, r), host, self.peer_digests[r:r + 1].view(torch.uint8)))
+            else:
+                host = digest.view(torch.uint8).cpu()
+                works.append(Landing(dist.isend(host, 0), host, None))
         if async_op:
             return works
         for w in works:
