@@ -76,6 +76,9 @@ def main():
         for d in dirs:
             for k, v in read(d).items():
                 res.setdefault(k, {}).update(v)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from vgaudio_amd.build import source_hashes
+    res["_csrc_sha256"] = source_hashes()              # bench.py quotes these counters only while the kernels are unchanged
     json.dump(res, open(outp, "w"), indent=1, sort_keys=True)
     print(json.dumps({k: {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items()} if isinstance(v, dict) else v
                       for k, v in res.items()}, indent=1)[:6000])

@@ -33,6 +33,33 @@ def headers():
             [os.path.join(inc, f) for f in os.listdir(inc)] + [os.path.abspath(__file__)])
 
 
+def source_hashes():
+    """{file name: sha256} of the kernels' sources (csrc/): profiles/ summaries are stamped with them, and bench.py quotes
+    a profile's counters only while the files its kernel is built from still match (a changed kernel silently
+    invalidates measured traffic)."""
+    import hashlib
+    return {f: hashlib.sha256(open(os.path.join(CSRC, f), "rb").read()).hexdigest()
+            for f in sorted(os.listdir(CSRC)) if os.path.isfile(os.path.join(CSRC, f))}
+
+
+# the files a codec's kernels are built from (bench.py: is a committed profile still about this code?)
+KERNEL_SOURCES = {
+    "gc": ["gc_encode_kernel.hip", "gc_encode_core.hpp", "gcadpcm_kernels.hip", "gc_decode_kernel.hip", "common.hpp"],
+    "adx": ["adx_kernels.hip", "common.hpp"],
+    "hca": ["hca_encode_kernel.hip", "hca_decode_kernels.hip", "hca_decode_core.hpp", "hca_device.hpp", "hca_info.hpp",
+            "hca_tables_data.h", "common.hpp"],
+}
+
+
+def profile_is_current(profile, codec):
+    """profile: a JSON object written by tools/summarize_pmc.py (carries "_csrc_sha256")"""
+    stamp = (profile or {}).get("_csrc_sha256")
+    if not isinstance(stamp, dict):
+        return False
+    now = source_hashes()
+    return all(stamp.get(f) == now.get(f) for f in KERNEL_SOURCES[codec])
+
+
 def obj_of(src):
     return os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
 
