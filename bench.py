@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--cpu-channels", type=int, default=0, help="units in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-pointer ABI measurement")
     ap.add_argument("--e2e-channels", type=int, default=0, help="channels of the e2e call (0 = as many of --channels as host memory allows)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="gc: skip the short ADX (configs[2]) and HCA (configs[3]) runs appended to the line as `other_configs`")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend for N > 1 (nccl = RCCL; gloo moves the gather through host memory: for trying "
                          "the N > 1 path on a box with fewer GPUs than ranks)")
@@ -107,13 +109,21 @@ def host_memory_available():
     return avail
 
 
-def load_profile_json(*names):
+def load_profile_json(codec, *names):
+    """The first of profiles/<names> that was measured on the code as it is now: tools/summarize_pmc.py stamps its
+    summaries with the sha256 of every file under csrc/, and a summary whose kernel's files have changed since is not
+    quoted (returns (None, why))."""
+    from vgaudio_amd.build import profile_is_current
+    stale = None
     for name in names:
         try:
-            return json.load(open(os.path.join(ROOT, "profiles", name)))
+            js = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
             continue
-    return None
+        if profile_is_current(js, codec):
+            return js, f"profiles/{name} (source hashes match)"
+        stale = stale or name
+    return None, (f"profiles/{stale} was measured on other kernel sources: not quoted" if stale else "no committed profile")
 
 
 class Ctx:
@@ -475,7 +485,7 @@ def run_gc(args, cx):
     verified = 0
     enc_bytes = ENC_BYTES_PER_SAMPLE * nch * n
     full = nch == 4096 and n == 2880000
-    pmc = load_profile_json("r02_b_pmc_traffic.json", "r01_pmc_traffic.json")
+    pmc, pmc_note = load_profile_json("gc", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
     traffic = None
     if pmc and full:
         try:
@@ -484,7 +494,7 @@ def run_gc(args, cx):
             pass
     # What actually binds the kernel: wave-instruction issue.  From the committed SQ counter pass.
     issue = None
-    sqj = load_profile_json("r02_b_sq_counters.json", "r01_l_sq_counters.json")
+    sqj, sq_note = load_profile_json("gc", "r03_sq_counters.json", "r02_b_sq_counters.json")
     if sqj and full:
         try:
             sq = sqj["gc_encode_kernel"]
@@ -502,7 +512,7 @@ def run_gc(args, cx):
     # kernel stats under profiles/ list them separately (their averages add up to it)
     roofline = {"bound": "hbm", "kernel": "gc_encode_kernel", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "algorithmic_bytes_per_launch": enc_bytes, "launch_ms": round(enc_ms, 3),
+                "traffic": traffic, "traffic_source": pmc_note, "algorithmic_bytes_per_launch": enc_bytes, "launch_ms": round(enc_ms, 3),
                 "launch_parts": ["gc_encode_kernel<false>", "gc_encode_seam_kernel", "gc_encode_chain_kernel", "gc_encode_kernel<true>"],
                 "other_kernels": {"gc_coefs_kernel": {
                     "launch_ms": round(coef_ms, 3),
@@ -512,7 +522,7 @@ def run_gc(args, cx):
                         "achieved": round(ENC_BYTES_PER_SAMPLE * nch * n / (dec_ms * 1e-3) / 1e9, 2) if dec_ms > 0 else 0.0}},
                 "pipeline_achieved": round(PIPE_BYTES_PER_SAMPLE * nch * n / ((coef_ms + enc_ms) * 1e-3) / 1e9, 2)
                 if coef_ms + enc_ms > 0 else 0.0,
-                "issue": issue}
+                "issue": issue, "issue_source": sq_note}
 
     cpu = None
     if not args.no_cpu_baseline and cx.world == 1:          # the CPU leg runs at N=1 only (rank 0's host cores)
@@ -594,12 +604,12 @@ def run_adx(args, cx):
         return None
     bytes_launch = ADX_BYTES_PER_SAMPLE * nch * n
     achieved = bytes_launch / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
-    pmc = load_profile_json("r02_b_pmc_traffic.json")
+    pmc, pmc_note = load_profile_json("adx", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
     traffic = None
     if pmc and nch == 4096 and n == 2880000:
         traffic = (pmc.get("adx_encode_fs18_tiled_kernel") or {}).get("traffic_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": "adx_encode_fs18_tiled_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": pmc_note,
                 "algorithmic_bytes_per_launch": bytes_launch, "launch_ms": round(enc_ms, 3),
                 "launch_parts": ["adx_encode_fs18_tiled_kernel", "adx_encode_fs18_fixup_kernel", "adx_encode_fs18_tail_kernel"],
                 "other_kernels": {"adx_decode_fs18_tiled_kernel (+fixup, tail)": {
@@ -702,14 +712,14 @@ def run_hca(args, cx):
         return None
     bytes_launch = (2.0 + info.frame_size * info.frame_count / (2.0 * n)) * chs if n else 0.0
     achieved = bytes_launch / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
-    pmc = load_profile_json("r02_b_pmc_traffic.json")
+    pmc, pmc_note = load_profile_json("hca", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
     traffic = None
     if pmc and ns == 1024 and n == 2880000:
         traffic = (pmc.get("hca_encode_kernel") or {}).get("traffic_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": "hca_encode_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes_per_launch": bytes_launch,
-                "launch_ms": round(enc_ms, 3),
-                "other_kernels": {"hca_unpack_kernel + hca_imdct_kernel (decode)": {
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": pmc_note,
+                "algorithmic_bytes_per_launch": bytes_launch, "launch_ms": round(enc_ms, 3),
+                "other_kernels": {"hca_scan_kernel + hca_frames_kernel (decode)": {
                     "launch_ms": round(dec_ms, 3),
                     "achieved": round(bytes_launch / (dec_ms * 1e-3) / 1e9, 2) if dec_ms > 0 else 0.0}},
                 "mfma": "the exact path uses no MFMA: a dense 128x128 DCT-IV reassociates the f64 sums (DESIGN.md 4.4; "
@@ -767,10 +777,41 @@ def run_hca(args, cx):
     return out
 
 
+def other_configs(args, cx):
+    """BASELINE configs[2] and configs[3] on the same clock as the headline: three steps each of the ADX round trip and the
+    HCA encode at their full shapes, with the roofline of the dominant kernel and a CPU leg on a small sample."""
+    import copy
+    import torch
+    out = {}
+    for codec, fn in (("adx", run_adx), ("hca", run_hca)):
+        a = copy.copy(args)
+        a.codec, a.steps, a.warmup, a.no_e2e = codec, 3, 1, True
+        a.channels, a.streams, a.seconds = 4096, 1024, 60.0
+        threads, _ = usable_cpus()
+        a.cpu_channels = 8 * threads if codec == "adx" else 2 * max(1, threads - 1)
+        t0 = time.perf_counter()
+        r = fn(a, cx)
+        torch.cuda.empty_cache()
+        rf = r["roofline"]
+        out["configs[2] adx" if codec == "adx" else "configs[3] hca"] = {
+            "metric": r["metric"], "value": r["value"], "unit": r["unit"], "steps": r["steps"], "warmup": r["warmup"],
+            "ms_per_step": r["ms_per_step"], "dtype": r["dtype"], "workload": r["config"]["workload"],
+            "roofline": {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                            "algorithmic_bytes_per_launch", "launch_ms", "other_kernels") if k in rf},
+            "cpu_baseline": r["cpu_baseline"], "speedup_vs_cpu_baseline": r.get("speedup_vs_cpu_baseline"),
+            "bit_exact_units_checked": r["config"].get("bit_exact_channels_checked", r["config"].get("bit_exact_streams_checked")),
+            "wall_s": round(time.perf_counter() - t0, 1)}
+    return out
+
+
 def main():
     args = parse()
     cx = setup(args)
     out = {"gc": run_gc, "adx": run_adx, "hca": run_hca}[args.codec](args, cx)
+    if args.codec == "gc" and cx.world == 1 and out is not None and not args.no_other_configs and args.channels == 4096 and args.seconds == 60.0:
+        import torch
+        torch.cuda.empty_cache()
+        out["other_configs"] = other_configs(args, cx)
     if cx.rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
     if cx.world > 1:

@@ -8,7 +8,7 @@
 
 using namespace vga::pipe;
 
-static int g_taper = 0, g_tail = 0;
+static int g_taper = 0, g_tail = 0, g_head = 0;
 static bool g_direct = false, g_direct_out = false, g_shared = false;
 static int g_lanes = 1;
 static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t out_bytes, int chunk, int feeders, int drainers,
@@ -43,6 +43,7 @@ static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t 
     job.slot_bytes = slot_bytes;
     job.taper_min_units = g_taper;
     job.tail_units = g_tail;
+    job.head_units = g_head;
     job.direct = g_direct;
     job.direct_out = g_direct_out;
     job.shared_streams = g_shared;
@@ -191,5 +192,12 @@ static int all_cases()
     bad += run_case(9, 1, 1, 128, 32, 100, 4, 2, 4096, 5, -1, false);             // one chunk: nothing to split
     bad += run_case(10, 1, 1, 128, 32, 8, 4, 2, 4096, 5, -1, false);              // last chunk shorter than the tail
     g_tail = 0;
+    g_head = 2;                                                                   // short first chunk
+    bad += run_case(37, 1, 1, 1000, 300, 8, 8, 4, 2048, 20, -1, false);
+    bad += run_case(10, 1, 1, 128, 32, 8, 4, 2, 4096, 5, -1, false);              // too few units: no head chunk
+    g_tail = 3;
+    bad += run_case(64, 2, 1, 513, 77, 16, 3, 2, 512, 10, -1, false);             // head and tail together
+    g_tail = 0;
+    g_head = 0;
     return bad;
 }

@@ -533,6 +533,60 @@ VGA_HD void dct_first_half(char *row, int L, const DctLane &K)
     }
 }
 
+// The same, with the lane's twiddles fetched stage by stage from the tables (L1 / constant-cache hits) instead of held
+// in registers: a kernel whose other stages need the registers (the encoder) pays 15 small loads per transform for
+// 60 VGPRs.  The fences keep the compiler from hoisting every load to the top, which would bring the 60 back.
+VGA_HD void stage_fence()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::: "memory");
+#endif
+}
+VGA_HD void dct_first_half_streamed(char *row, int L, const uint64_t *sin_bits, const uint64_t *cos_bits)
+{
+    Cx z[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 8; k++) {
+        const double *p = reinterpret_cast<const double *>(row + slot_byte_offset(L + 8 * k));
+        const double a = p[0], b = p[1];
+        const Twiddle t = twiddle_at(sin_bits, cos_bits, 128, L + 8 * k);
+        z[k].re = a * t.c + b * t.s;
+        z[k].im = a * t.s - b * t.c;
+    }
+    stage_fence();
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; k++) butterfly(z[k], z[k + 4], twiddle_at(sin_bits, cos_bits, 32, L + 8 * k));
+    stage_fence();
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 2; k++) {
+        const Twiddle t = twiddle_at(sin_bits, cos_bits, 16, L + 8 * k);
+        butterfly(z[k], z[k + 2], t);
+        butterfly(z[k + 4], z[k + 6], t);
+    }
+    stage_fence();
+    {
+        const Twiddle t = twiddle_at(sin_bits, cos_bits, 8, L);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int k = 0; k < 8; k += 2) butterfly(z[k], z[k + 1], t);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 8; k++) {
+        double *p = reinterpret_cast<double *>(row + slot_byte_offset(L + 8 * k));
+        p[0] = z[k].re;
+        p[1] = z[k].im;
+    }
+}
+
 // stages 3..5 on z[8L + m]; y[2m], y[2m + 1] = dctTemp[16L + 2m], [16L + 2m + 1]
 VGA_HD void dct_second_half(const char *row, int L, const DctUniform &U, double y[16])
 {

@@ -105,6 +105,8 @@ struct StagedOut {
     }
 };
 
+}  // namespace
+
 __global__ __launch_bounds__(64) void hca_scan_kernel(const uint8_t *__restrict__ frames, int64_t stream_pitch, int nstreams,
                                                       DeviceInfo info, DecodeLayout lay, uint8_t *__restrict__ records,
                                                       int *__restrict__ status)
@@ -164,6 +166,8 @@ __global__ __launch_bounds__(64) void hca_scan_kernel(const uint8_t *__restrict_
 }
 
 // ---- frames -----------------------------------------------------------------------------------
+namespace {
+
 constexpr int FRAMES_THREADS = 128;
 constexpr int MAX_FRAMES_PER_GROUP = 16;
 
@@ -190,6 +194,8 @@ struct Res16 {
         return (int)((w >> (8 * (e & 3))) & 255u);
     }
 };
+
+}  // namespace
 
 __global__ __launch_bounds__(FRAMES_THREADS) void hca_frames_kernel(
     const uint8_t *__restrict__ frames, int64_t frames_pitch, DeviceInfo info, DecodeLayout lay,
@@ -367,8 +373,6 @@ __global__ __launch_bounds__(FRAMES_THREADS) void hca_frames_kernel(
         }
     }
 }
-
-}  // namespace
 
 int launch_decode(const uint8_t *d_frames, int64_t frames_pitch, int nstreams, const DeviceInfo &info, int16_t *d_pcm,
                   int64_t stream_pitch, int64_t ch_pitch, void *d_workspace, int *d_status, hipStream_t stream)

@@ -2,32 +2,61 @@
 //
 // Replaces CriHcaEncoder.EncodeFrame and its stages (VGAudio/Codecs/CriHca/CriHcaEncoder.cs:271-286,
 // :420-858), CriHcaPacking.PackFrame (CriHcaPacking.cs:17-58, :231-295), Mdct.RunMdct
-// (VGAudio/Utilities/Mdct.cs:63-92) and the non-looping streaming shell (:126-269): frame k of a
-// stream encodes samples [1024k, 1024k+1024) of "input followed by zeros", with the previous 128
+// (VGAudio/Utilities/Mdct.cs:63-92) and the streaming shell (:126-269): frame k of a stream encodes samples
+// [1024k, 1024k+1024) of the encoder's input stream (PcmMap, hca_device.hpp), with the previous 128
 // samples as MDCT overlap -- so, unlike the reference's stateful encoder, every frame is independent.
 //
-// workgroup = (stream, frame), 256 threads.  All arithmetic is the reference's f64 in the same
-// operation order (-ffp-contract=off); order-dependent f64 sums (intensity-stereo energies, HFR group
-// averages) are done by one lane each; the bit-allocation searches (CalculateUsedBits, ~16 evaluations)
-// are block reductions; packing is a block-wide prefix sum of code lengths + LDS atomic ORs; the
-// CRC-16 is computed in parallel from per-chunk CRCs multiplied by x^(8*bytes_after) mod 0x18005.
+// workgroup = a run of up to 16 consecutive frames of one stream, 128 threads (round 2: one frame per workgroup of 256
+// threads, every frame paying for 5.5 KB of tables and 25 block-wide barriers).  Per frame:
+//   * window + fold straight from the PCM in HBM into the transform's input layout (hca_decode_core.hpp: the pre-rotation's
+//     operand pairs are adjacent, rows padded against bank conflicts), every lane with its four window values in registers;
+//   * the 128-point DCT-IV on 8 lanes per transform (exact staged butterflies, the decoder's), twiddles in registers;
+//   * a wave per channel, a lane per two bands: scale factor, scaling in place and the band's sixteen bit costs in ONE pass
+//     over its eight coefficients; the frame header's length by DPP sums inside that wave -- no block-wide barrier;
+//   * both binary searches of the bit allocation on wave 0, from the cost tables (4 KB through LDS);
+//   * scale factors packed per channel inside a wave; spectra codes: 16 consecutive codes per lane, offsets from one
+//     block-wide scan, whole dwords ORed into the frame in LDS; CRC-16 from per-lane partial CRCs folded with x^(8k);
+//   * the frame leaves as aligned dwords (consecutive frames of a run complete each other's partial cache lines in L2).
+// All arithmetic is the reference's f64 in the same operation order (-ffp-contract=off); order-dependent f64 sums
+// (intensity-stereo energies, HFR group averages) are done by one lane each.
 #include "common.hpp"
 #include "hca_device.hpp"
+#include "hca_decode_core.hpp"
 #include "hca_kernels.hpp"
 
 namespace vga {
 namespace hca {
 
+namespace {
+
+constexpr int ENC_THREADS = 128;
+constexpr int MAX_ENC_FRAMES_PER_GROUP = 16;
+constexpr int RS = ROW_BYTES / 8;      // doubles between the rows of the spectra: [channel][sub-frame] rows of 128 + padding
+
+struct EncTab {
+    double dequant_scale[64];          // DequantizerScalingTable (FindScaleFactor)
+    double quant_scale[64];            // QuantizerScalingTable
+    double inv_step[16];               // QuantizerInverseStepSize
+    double dead_zone[16];              // QuantizerDeadZone (CriHcaTables.cs:68-78)
+    uint8_t enc_bits[8][16], enc_value[8][16];   // QuantizeSpectrumBits / Value (index q + 8)
+    uint8_t max_bits[16];
+    uint8_t res_curve[64];
+};
+
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // CriHcaEncoder.cs:691-709
-__device__ __forceinline__ int find_scale_factor(const EncTables &T, double value)
+__device__ __forceinline__ int find_scale_factor(const EncTab &T, double value)
 {
     unsigned low = 0, high = 63;
-    while (low < high) {
+#pragma unroll
+    for (int step = 0; step < 6; step++) {               // 64 entries: six halvings, then low == high
         const unsigned mid = (low + high) / 2;
-        if (T.dequant_scale[mid] <= value) low = mid + 1;
-        else high = mid;
+        const bool up = T.dequant_scale[mid] <= value;
+        low = up ? mid + 1 : low;
+        high = up ? high : mid;
     }
     return (int)low;
 }
@@ -48,81 +77,90 @@ __device__ __forceinline__ unsigned gf_mul(unsigned a, unsigned b)
 }
 
 // CalculateUsedBits (:554-597) for one band: the bits its eight scaled coefficients cost at resolution `res`
-// x: the band's eight coefficients, one per sub-frame, XS doubles apart
-template <int XS>
-__device__ __forceinline__ int band_cost(const EncTables &T, const double *x, int res)
+__device__ __forceinline__ int band_cost(const EncTab &T, const double (&x)[8], int res)
 {
     int cost = 0;
     if (res >= 8) {
         const int bits = T.max_bits[res] - 1;
         const double d = T.dead_zone[res];
 #pragma unroll
-        for (int sf = 0; sf < 8; sf++) cost += bits + (fabs(x[sf * XS]) >= d ? 1 : 0);
+        for (int sf = 0; sf < 8; sf++) cost += bits + (fabs(x[sf]) >= d ? 1 : 0);
     } else {
         const double inv = T.inv_step[res];
         const double up = inv + 1;
         const int down = trunc_i(inv + 0.5 - 8);
 #pragma unroll
         for (int sf = 0; sf < 8; sf++) {
-            const int q = trunc_i(x[sf * XS] * inv + up) - down;
+            const int q = trunc_i(x[sf] * inv + up) - down;
             cost += T.enc_bits[res][q];
         }
     }
     return cost;
 }
 
-// 16 costs (each <= 8 * 12 bits) packed into four dwords, plus a "known" bit per resolution
-struct UsedBitsMemo {
-    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, known = 0;
-};
-
-// All sixteen costs of one band at once (the resolution is a compile-time constant in every unrolled step, so each
-// takes one side of band_cost only and the eight coefficients are read from LDS once).  The binary searches touch
-// a new resolution in some lane on nearly every step, which made the lazy variant evaluate band_cost -- both sides,
-// the lanes' resolutions differ -- about fifteen times per frame.
-__device__ __forceinline__ void build_cost_table(const EncTables &T, const double *xs, bool valid, UsedBitsMemo &m)
+// All sixteen costs of one band (each <= 8 * 12 bits: a byte), resolution by resolution with the resolution a
+// compile-time constant: the binary searches below only look costs up.
+__device__ __forceinline__ uint4 band_cost_table(const EncTab &T, const double (&x)[8])
 {
-    double x[8];
-#pragma unroll
-    for (int sf = 0; sf < 8; sf++) x[sf] = xs[sf * 128];               // scaled spectra: [channel][sub-frame][band]
-    uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int r = 0; r < 16; r++) w[r >> 2] |= (uint32_t)band_cost<1>(T, x, r) << (8 * (r & 3));
-    m.w0 = valid ? w[0] : 0u; m.w1 = valid ? w[1] : 0u; m.w2 = valid ? w[2] : 0u; m.w3 = valid ? w[3] : 0u;
-    m.known = 0xFFFFu;
+    // (rolled loops: unrolled, hipcc keeps the constants of all sixteen resolutions live at once -- 250 VGPRs)
+    uint64_t lo = 0, hi = 0;
+#pragma unroll 1
+    for (int r = 1; r < 8; r++) lo |= (uint64_t)band_cost(T, x, r) << (8 * r);       // resolution 0 costs nothing
+#pragma unroll 1
+    for (int r = 8; r < 16; r++) hi |= (uint64_t)band_cost(T, x, r) << (8 * (r - 8));
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
 
-// this thread's share of the frame's spectrum bits.  Up to two channels a thread owns one band and memoises
-// its costs; with more it owns several bands and recomputes.
-__device__ __forceinline__ int used_bits_partial(const EncTables &T, int tid, int nch, const int *s_coded, const uint8_t *sfac,
-                                                 const double *scaled, int noise_level, int eval_boundary, UsedBitsMemo &m)
+__device__ __forceinline__ int cost_at(const uint4 &t, int res)
 {
-    int partial = 0;
-    if (nch * 128 <= 256) {
-        const int i = min(tid, nch * 128 - 1);
-        const int c = i / 128, b = i % 128;
-        const bool valid = tid < nch * 128 && b < s_coded[c];
-        const int noise = b < eval_boundary ? noise_level - 1 : noise_level;
-        const int res = calculate_resolution(T, sfac[i], noise);
-        const int word = res >> 2, shift = 8 * (res & 3);
-        const uint32_t wsel = word == 0 ? m.w0 : word == 1 ? m.w1 : word == 2 ? m.w2 : m.w3;
-        partial = valid ? (int)((wsel >> shift) & 0xFFu) : 0;
-    } else {
-        for (int i = tid; i < nch * 128; i += 256) {
-            const int c = i / 128, b = i % 128;
-            if (b >= s_coded[c]) continue;
-            const int noise = b < eval_boundary ? noise_level - 1 : noise_level;
-            partial += band_cost<128>(T, scaled + (size_t)c * 1024 + b, calculate_resolution(T, sfac[i], noise));
-        }
-    }
-    return partial;
+    const uint64_t lo = ((uint64_t)t.y << 32) | t.x, hi = ((uint64_t)t.w << 32) | t.z;
+    const uint64_t half = res >= 8 ? hi : lo;
+    return (int)((half >> (8 * (res & 7))) & 0xFFu);
+}
+
+template <class Tab>
+__device__ __forceinline__ int resolution_of(const Tab &T, int scale_factor, int noise_level)
+{
+    if (scale_factor == 0) return 0;
+    int p = noise_level - 5 * scale_factor / 2 + 2;
+    p = min(max(p, 0), 58);
+    return T.res_curve[p];
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);     // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ int wave_xor(int v)
+{
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
+    return __builtin_amdgcn_readlane(v, 0) ^ __builtin_amdgcn_readlane(v, 16) ^ __builtin_amdgcn_readlane(v, 32) ^
+           __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+    // Hillis-Steele inside each 16-lane row with row_shr, then the row totals are handed on with row_bcast
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);     // row_shr:1 (no source lane: + 0)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
+    return v;
 }
 
 // One probe of CalculateUsedBits for the four bands a lane of the searching wave owns: resolution from the noise level
-// (CriHcaPacking.CalculateResolution), cost from the band's table.
-// The sixteen byte costs of a band sit in two 64-bit halves (resolutions 0-7, 8-15): one select and one 64-bit shift
-// (a four-way select over a uint4 makes hipcc spill the table to scratch and index it).
-__device__ __forceinline__ int probe_partial(const EncTables &T, const uint64_t (&clo)[4], const uint64_t (&chi)[4],
+// (CriHcaPacking.CalculateResolution), cost from the band's table (two 64-bit halves: resolutions 0-7, 8-15).
+// (a free function, not a lambda: hipcc keeps by-reference captures of register arrays in scratch)
+__device__ __forceinline__ int probe_partial(const EncTab &T, const uint64_t (&clo)[4], const uint64_t (&chi)[4],
                                              const int (&off)[4], const int (&bnd)[4], const bool (&on)[4], int noise_level,
                                              int eval_boundary)
 {
@@ -137,91 +175,124 @@ __device__ __forceinline__ int probe_partial(const EncTables &T, const uint64_t 
     return partial;
 }
 
-// LDS limits the kernel to 3-4 workgroups (12-16 waves) per CU; without the occupancy hint hipcc aims for 10
-// waves per SIMD, caps itself at 48 VGPRs and spills pointers to scratch
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void hca_encode_kernel(
-    const int16_t *__restrict__ pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, PcmMap map,
+// a lane's codes are consecutive in the stream: they are gathered in a 64-bit window and leave as whole dwords (one
+// LDS atomic per dword; the first and last dword of a lane are shared with its neighbours)
+struct Emitter {
+    unsigned *buf;
+    uint64_t acc;
+    int word, p;
+    __device__ __forceinline__ void put(unsigned value, int nbits)     // p < 32, nbits <= 15
+    {
+        acc |= (uint64_t)value << (64 - p - nbits);
+        p += nbits;
+        if (p >= 32) {
+            const unsigned hi = (unsigned)(acc >> 32);
+            if (hi) atomicOr(&buf[word], hi);
+            acc <<= 32;
+            word++;
+            p -= 32;
+        }
+    }
+    __device__ __forceinline__ void finish()
+    {
+        const unsigned hi = (unsigned)(acc >> 32);
+        if (hi) atomicOr(&buf[word], hi);
+    }
+};
+
+}  // namespace
+
+// LDS gives six workgroups = three waves per SIMD; the hint keeps hipcc at the 168 VGPRs that fit (it takes 171 otherwise)
+__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void hca_encode_kernel(
+    const int16_t *__restrict__ pcm, int64_t stream_pitch, int64_t ch_pitch, int frames_per_group, int groups_per_stream, PcmMap map,
     DeviceInfo info, uint8_t *__restrict__ frames, int64_t frames_pitch, const uint16_t *__restrict__ crc_pow,
     int *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
-    __shared__ EncTables T;
+    __shared__ EncTab T;
     const int nch = info.nch;
-    double *spectra = s_mem;                               // [nch][8][128]
-    // LDS decides the occupancy (5 workgroups per CU need <= 32 KB each): ScaleSpectra works IN PLACE -- the scaled
-    // spectra keep the [channel][sub-frame][band] layout of the MDCT output (bands of one sub-frame are contiguous,
-    // which is also what the cost tables and WriteSpectra read conflict-free); only the MDCT staging needs a second
-    // region (dctin, which doubles as the transform's scratch, and xin; later the searching wave's cost tables)
-    const size_t region_b = 11 * 128;
-    double *scaled = spectra;                              // [nch][8][128], bands < coded count (the rest stays unscaled)
-    double *dctin = spectra + (size_t)nch * 1024;          // [8][128]
-    double *tmp = dctin;                                   // the transform permutes in place (hca_device.hpp)
-    int16_t *xin = reinterpret_cast<int16_t *>(dctin + 8 * 128);   // [9][128] raw samples (2.3 KB of the 3 x 128 doubles)
-    double *hfr_avg = dctin + region_b;                    // [nch][8]
-    double *eratio = hfr_avg + nch * 8;                    // [nch][8]
-    int *red = reinterpret_cast<int *>(eratio + nch * 8);  // [32] two alternating slot sets for the block reductions
-    int *hlb = red + 32;                                   // [nch] header length bits
-    int *dbits = hlb + 8;                                  // [nch] scale-factor delta bits
-    int *cand = dbits + 8;                                 // [nch][8]
-    int *empty = cand + 64;                                // [nch]
-    int *intensity = empty + 8;                            // [nch][8]
-    int *hfrs = intensity + 64;                            // [nch][8]
-    uint32_t *fbuf = reinterpret_cast<uint32_t *>(hfrs + 64);    // frame bits, big-endian words [fwords]
+    // LDS: spectra [nch][8] rows of RS doubles | cost tables uint4 [nch][128] | small arrays | frame bits | sfac, ires
+    double *spectra = s_mem;
+    uint4 *costs = reinterpret_cast<uint4 *>(spectra + (size_t)nch * 8 * RS);
+    double *hfr_avg = reinterpret_cast<double *>(costs + nch * 128);      // [nch][8]
+    double *eratio = hfr_avg + nch * 8;                                   // [nch][8]
+    int *red = reinterpret_cast<int *>(eratio + nch * 8);                 // [32]: slots of the block-wide reductions, search result
+    int *hlb = red + 32;                                                  // [8] header length bits
+    int *dbits = hlb + 8;                                                 // [8] scale-factor delta bits
+    int *cand = dbits + 8;                                                // [nch][8]
+    int *empty = cand + 64;                                               // [8]
+    int *intensity = empty + 8;                                           // [nch][8]
+    int *hfrs = intensity + 64;                                           // [nch][8]
+    uint32_t *fbuf = reinterpret_cast<uint32_t *>(hfrs + 64);             // frame bits, big-endian words [fwords]
     const int fwords = (info.frame_size + 3) / 4 + 2;
-    uint8_t *sfac = reinterpret_cast<uint8_t *>(fbuf + fwords);  // [nch][128] scale factors (0..63)
-    uint8_t *ires = sfac + nch * 128;                      // [nch][128] resolutions (0..15)
+    uint8_t *sfac = reinterpret_cast<uint8_t *>(fbuf + fwords);           // [nch][128] scale factors (0..63)
+    uint8_t *ires = sfac + nch * 128;                                     // [nch][128] resolutions (0..15)
+    __shared__ int s_coded[8], s_ctype[8];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int stream = blockIdx.x / info.frame_count;
-    const int frame = blockIdx.x % info.frame_count;
 
-    // block-wide sum / exclusive scan: wave-level shuffles, then ONE barrier for the four wave totals (the slot
-    // set alternates, so the next call cannot overwrite totals a slower wave has not read yet)
+    // ---- once per workgroup: tables, per-lane constants
+    for (int i = tid; i < 64; i += ENC_THREADS) {
+        T.dequant_scale[i] = f64_bits(HCA_DequantizerScalingTableBits[i]);
+        T.quant_scale[i] = f64_bits(HCA_QuantizerScalingTableBits[i]);
+        T.res_curve[i] = i < 59 ? HCA_ScaleToResolutionCurve[i] : 0;
+    }
+    if (tid < 16) {
+        const double st = f64_bits(HCA_QuantizerStepSizeBits[tid]);
+        T.inv_step[tid] = f64_bits(HCA_QuantizerInverseStepSizeBits[tid]);
+        T.dead_zone[tid] = __longlong_as_double(__double_as_longlong(st / 2) - (long long)(HCA_ResolutionMaxValue[tid] + 1));
+        T.max_bits[tid] = HCA_QuantizedSpectrumMaxBits[tid];
+    }
+    (&T.enc_bits[0][0])[tid] = (&HCA_QuantizeSpectrumBits[0][0])[tid];
+    (&T.enc_value[0][0])[tid] = (&HCA_QuantizeSpectrumValue[0][0])[tid];
+    if (tid < 8) {
+        int cc = 0, ct = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (tid == k) { cc = info.coded_count[k]; ct = info.channel_type[k]; }
+        s_coded[tid] = cc;
+        s_ctype[tid] = ct;
+    }
+    const int L = tid & 7;
+    const DctUniform U = make_dct_uniform(MDCT_SinBits, MDCT_CosBits);
+    DctLane out_bases;                                         // only the two store bases of dct_store are used
+    {
+        const int rev = ((L & 1) << 2) | (L & 2) | ((L >> 2) & 1);
+        const int v = rev ^ (rev >> 1) ^ (rev >> 2);
+        out_bases.out_even = 8 * v;
+        out_bases.out_odd = 8 * (v ^ 7);
+    }
+    const int wi = tid & 63;                                   // this lane's position in the fold (Mdct.cs:80-89)
+    const double w_a = (double)__uint_as_float(HCA_MdctWindowF32Bits[63 - wi]);
+    const double w_b = (double)__uint_as_float(HCA_MdctWindowF32Bits[64 + wi]);
+    const double w_c = (double)__uint_as_float(HCA_MdctWindowF32Bits[wi]);
+    const double w_d = (double)__uint_as_float(HCA_MdctWindowF32Bits[127 - wi]);
+
+    const int stream = blockIdx.x / groups_per_stream;
+    const int f0 = (blockIdx.x % groups_per_stream) * frames_per_group;
+    const int f1 = min(f0 + frames_per_group, info.frame_count);
+    const int available = info.frame_size * 8;
+    const bool small = nch <= 2;
+
     int red_par = 0;
+    // block-wide sum / exclusive scan over the two waves: DPP inside the wave, ONE barrier for the two totals (the slot
+    // pair alternates, so the next call cannot overwrite a total the other wave has not read yet)
     auto block_sum = [&](int v) __attribute__((always_inline)) -> int {
-        // wave sum with DPP (quad swaps, half-row and row mirrors: every lane then holds its 16-lane row's sum) and
-        // four v_readlane -- the binary searches wait for this fifteen times in a row, and six dependent
-        // ds_bpermute (what __shfl_xor compiles to) cost several hundred cycles each time
-        v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
-        v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
-        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);     // row_half_mirror
-        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);     // row_mirror
-        const int w = __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
-                      __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
-        int *slot = red + 8 * red_par;
+        const int w = wave_sum(v);
+        int *slot = red + 2 * red_par;
         red_par ^= 1;
         if (lane == 0) slot[wave] = w;
         __syncthreads();
-        return slot[0] + slot[1] + slot[2] + slot[3];
+        return slot[0] + slot[1];
     };
-    auto wave_inclusive_scan = [&](int v) __attribute__((always_inline)) -> int {
-        // Hillis-Steele inside each 16-lane row with row_shr, then the row totals are handed on with row_bcast
-        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);     // row_shr:1 (no source lane: + 0)
-        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);     // row_shr:2
-        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);     // row_shr:4
-        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);     // row_shr:8
-        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1 and 3
-        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
-        return v;
-    };
-    // exclusive scan over groups of `waves_per_group` consecutive waves (4: the whole block; 2: one channel's
-    // 128 bands); total = the group's sum
-    auto group_exclusive_scan = [&](int v, int waves_per_group, int &total) __attribute__((always_inline)) -> int {
+    auto block_exclusive_scan = [&](int v) __attribute__((always_inline)) -> int {
         const int incl = wave_inclusive_scan(v);
-        int *slot = red + 8 * red_par;
+        int *slot = red + 2 * red_par;
         red_par ^= 1;
         if (lane == 63) slot[wave] = incl;
         __syncthreads();
-        const int first = wave / waves_per_group * waves_per_group;
-        int base = 0;
-        total = 0;
-        for (int w = first; w < first + waves_per_group; w++) {
-            const int t = slot[w];
-            if (w < wave) base += t;
-            total += t;
-        }
-        return base + incl - v;
+        return (wave == 1 ? slot[0] : 0) + incl - v;
     };
     auto put_bits = [&](int off, unsigned value, int nbits) __attribute__((always_inline)) {
         if (nbits <= 0) return;
@@ -231,407 +302,407 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         if (lo) atomicOr(&fbuf[(off >> 5) + 1], lo);
     };
 
-    // per-channel layout in LDS: indexing the by-value kernel argument with a per-lane channel number makes
-    // hipcc copy the whole struct to scratch
-    __shared__ int s_coded[8], s_ctype[8];
-    if (tid < 8) {
-        int cc = 0, ct = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (tid == k) { cc = info.coded_count[k]; ct = info.channel_type[k]; }
-        s_coded[tid] = cc;
-        s_ctype[tid] = ct;
-    }
-    for (int i = tid; i < fwords; i += 256) fbuf[i] = 0;
-    load_tables(T, tid, 256);
+    for (int frame = f0; frame < f1; frame++) {
+        __syncthreads();                                   // the previous frame is stored; T / s_coded are written
+        for (int i = tid; i < fwords; i += ENC_THREADS) fbuf[i] = 0;
 
-    // ---- PcmToFloat (:845-858) + RunMdct (:834-843 -> Mdct.cs:63-92), channel by channel
-    const int grp = tid >> 5, t = tid & 31;
-    for (int c = 0; c < nch; c++) {
-        const int16_t *src = pcm + (int64_t)stream * stream_pitch + (int64_t)c * ch_pitch;
-        for (int i = tid; i < 9 * 128; i += 256) {
-            const int64_t pos = (int64_t)frame * SPF - SPSF + i;
-            xin[i] = fetch_pcm(map, src, pos);
-        }
-        __syncthreads();
+        // ---- PcmToFloat (:845-858) + the fold of RunMdct (Mdct.cs:78-89), straight into the transform's input layout
         {
-            // PcmToFloat: pcm * (1.0 / 32768.0), applied on the fly
-            const int16_t *in = xin + (grp + 1) * 128, *prev = xin + grp * 128;
-            double *din = dctin + grp * 128;
-            constexpr double K = 1.0 / 32768.0;
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int i = t + 32 * k;
-                const double a = T.window[63 - i] * -(in[64 + i] * K);
-                const double b = T.window[64 + i] * (in[63 - i] * K);
-                const double cc = T.window[i] * (prev[i] * K);
-                const double d = T.window[127 - i] * (prev[127 - i] * K);
-                din[i] = a - b;
-                din[64 + i] = cc - d;
-            }
-        }
-        __syncthreads();
-        dct4_128(T, dctin + grp * 128, tmp + grp * 128, spectra + ((size_t)c * 8 + grp) * 128, t, wave_sync);
-        __syncthreads();
-    }
-
-    // ---- EncodeIntensityStereo (:711-764)
-    if (info.stereo_band_count > 0) {
-        if (tid < nch * 8) {
-            const int c = tid / 8, sf = tid % 8;
-            if (s_ctype[c] == CH_STEREO_PRIMARY) {
-                const double *l = spectra + ((size_t)c * 8 + sf) * 128;
-                const double *r = spectra + ((size_t)(c + 1) * 8 + sf) * 128;
-                double energy_l = 0, energy_r = 0, energy_total = 0;
-                for (int b = info.base_band_count; b < info.total_band_count; b++) {
-                    energy_l += fabs(l[b]);
-                    energy_r += fabs(r[b]);
-                    energy_total += fabs(l[b] + r[b]);
-                }
-                energy_total *= 2;
-                const double energy_lr = energy_r + energy_l;
-                const double stored = 2 * energy_l / energy_lr;
-                double ratio = energy_lr / energy_total;
-                ratio = clampd(ratio, 0.5, 1.4142135623730951 / 2);
-                int quantized = 1;
-                if (energy_r > 0 || energy_l > 0) {
-                    while (quantized < 13 && f64_bits(HCA_IntensityRatioBoundsTableBits[quantized]) >= stored) quantized++;
+            const int64_t u0 = (int64_t)frame * SPF - SPSF;                    // stream index of the overlap's first sample
+            // the whole window inside the caller's PCM (every frame but a stream's first and last few): plain loads
+            const bool plain = u0 >= map.pre_end && u0 + SPF + SPSF <= map.main_end;
+            constexpr double KQ = 1.0 / 32768.0;
+            for (int item = tid >> 6; item < nch * 8; item += ENC_THREADS / 64) {
+                const int c = item >> 3, sf = item & 7;
+                const int16_t *src = pcm + (int64_t)stream * stream_pitch + (int64_t)c * ch_pitch;
+                const int64_t up = u0 + sf * SPSF, ui = up + SPSF;             // previous sub-frame, this sub-frame
+                int x_in_hi, x_in_lo, x_pv_lo, x_pv_hi;
+                if (plain) {
+                    const int16_t *p = src + (up - map.pre_end);
+                    x_pv_lo = p[wi];
+                    x_pv_hi = p[127 - wi];
+                    x_in_lo = p[SPSF + 63 - wi];
+                    x_in_hi = p[SPSF + 64 + wi];
                 } else {
-                    quantized = 0;
-                    ratio = 1;
+                    x_pv_lo = fetch_pcm(map, src, up + wi);
+                    x_pv_hi = fetch_pcm(map, src, up + 127 - wi);
+                    x_in_lo = fetch_pcm(map, src, ui + 63 - wi);
+                    x_in_hi = fetch_pcm(map, src, ui + 64 + wi);
                 }
-                intensity[(c + 1) * 8 + sf] = quantized;
-                eratio[c * 8 + sf] = ratio;
+                const double a = w_a * -(x_in_hi * KQ);
+                const double b = w_b * (x_in_lo * KQ);
+                const double cc = w_c * (x_pv_lo * KQ);
+                const double d = w_d * (x_pv_hi * KQ);
+                char *row = reinterpret_cast<char *>(spectra + (size_t)item * RS);
+                *reinterpret_cast<double *>(row + spec_byte_offset(wi)) = a - b;
+                *reinterpret_cast<double *>(row + spec_byte_offset(64 + wi)) = cc - d;
             }
         }
         __syncthreads();
-        const int nb = info.total_band_count - info.base_band_count;
-        for (int i = tid; i < nch * 8 * nb; i += 256) {
-            const int c = i / (8 * nb), sf = (i / nb) % 8, b = info.base_band_count + i % nb;
-            if (s_ctype[c] != CH_STEREO_PRIMARY) continue;
-            double *l = spectra + ((size_t)c * 8 + sf) * 128;
-            double *r = spectra + ((size_t)(c + 1) * 8 + sf) * 128;
-            l[b] = (l[b] + r[b]) * eratio[c * 8 + sf];
-            r[b] = 0;
+        // ---- Dct4 (Mdct.cs:126-181): 8 lanes per transform, in place; the output is the row's first 128 doubles
+        for (int row = tid >> 3; row < nch * 8; row += ENC_THREADS / 8) {
+            char *r = reinterpret_cast<char *>(spectra + (size_t)row * RS);
+            // the lane's fifteen twiddles are fetched where they are used (L1 hits): kept in registers across the frame
+            // loop they would cost every other stage 60 VGPRs (the pointers are laundered so that hipcc does not hoist them)
+            const uint64_t *sin_bits = MDCT_SinBits, *cos_bits = MDCT_CosBits;
+            asm volatile("" : "+s"(sin_bits), "+s"(cos_bits));
+            dct_first_half_streamed(r, L, sin_bits, cos_bits);
+            wave_lds_sync();
+            double y[16];
+            dct_second_half(r, L, U, y);
+            wave_lds_sync();
+            dct_store(r, out_bases, y);
         }
         __syncthreads();
-    }
 
-    // ---- CalculateScaleFactors (:673-689)
-    for (int i = tid; i < nch * 128; i += 256) {
-        const int c = i / 128, b = i % 128;
-        int sfv = 0;
-        if (b < s_coded[c]) {
-            double mx = 0;
-            for (int sf = 0; sf < 8; sf++) {
-                const double coeff = fabs(spectra[((size_t)c * 8 + sf) * 128 + b]);
-                mx = coeff > mx ? coeff : mx;
-            }
-            sfv = find_scale_factor(T, mx);
-        }
-        sfac[i] = sfv;
-    }
-    __syncthreads();
-    // ---- ScaleSpectra (:651-671), in place: bands >= the coded count keep their unscaled values (the HFR group
-    // averages below read exactly those), nothing reads a scaled value there
-    for (int i = tid; i < nch * 1024; i += 256) {
-        const int c = i / 1024, b = i % 128;
-        const int sfv = sfac[c * 128 + b];
-        if (b < s_coded[c])
-            spectra[i] = sfv != 0 ? clampd(spectra[i] * T.quant_scale[sfv], -0.999999999999, 0.999999999999) : 0.0;
-    }
-    __syncthreads();
-
-    // ---- CalculateHfrGroupAverages (:766-793) + CalculateHfrScale (:795-832)
-    if (info.hfr_group_count > 0) {
-        if (tid < nch * 8) {
-            const int c = tid / 8, group = tid % 8;
-            if (group < info.hfr_group_count && s_ctype[c] != CH_STEREO_SECONDARY) {
-                const int hfr_start = info.stereo_band_count + info.base_band_count;
-                double sum = 0.0;
-                int count = 0;
-                int band = hfr_start + group * info.bands_per_hfr_group;
-                for (int i = 0; i < info.bands_per_hfr_group && band < SPSF; band++, i++) {
-                    for (int sf = 0; sf < 8; sf++) sum += fabs(spectra[((size_t)c * 8 + sf) * 128 + band]);
-                    count += 8;
+        // ---- EncodeIntensityStereo (:711-764)
+        if (info.stereo_band_count > 0) {
+            if (tid < nch * 8) {
+                const int c = tid / 8, sf = tid % 8;
+                if (s_ctype[c] == CH_STEREO_PRIMARY) {
+                    const double *l = spectra + ((size_t)c * 8 + sf) * RS;
+                    const double *r = spectra + ((size_t)(c + 1) * 8 + sf) * RS;
+                    double energy_l = 0, energy_r = 0, energy_total = 0;
+                    for (int b = info.base_band_count; b < info.total_band_count; b++) {
+                        energy_l += fabs(l[b]);
+                        energy_r += fabs(r[b]);
+                        energy_total += fabs(l[b] + r[b]);
+                    }
+                    energy_total *= 2;
+                    const double energy_lr = energy_r + energy_l;
+                    const double stored = 2 * energy_l / energy_lr;
+                    double ratio = energy_lr / energy_total;
+                    ratio = clampd(ratio, 0.5, 1.4142135623730951 / 2);
+                    int quantized = 1;
+                    if (energy_r > 0 || energy_l > 0) {
+                        while (quantized < 13 && f64_bits(HCA_IntensityRatioBoundsTableBits[quantized]) >= stored) quantized++;
+                    } else {
+                        quantized = 0;
+                        ratio = 1;
+                    }
+                    intensity[(c + 1) * 8 + sf] = quantized;
+                    eratio[c * 8 + sf] = ratio;
                 }
-                double avg = sum / count;
-                const int lim = min(info.hfr_band_count, info.total_band_count - info.hfr_band_count);
-                sum = 0.0;
-                count = 0;
-                band = group * info.bands_per_hfr_group;
-                for (int i = 0; i < info.bands_per_hfr_group && band < lim; band++, i++) {
-                    for (int sf = 0; sf < 8; sf++) sum += fabs(scaled[((size_t)c * 8 + sf) * 128 + (hfr_start - band - 1)]);
-                    count += 8;
-                }
-                const double average = sum / count;
-                if (average > 0.0) {
-                    const double inv = 1.0 / average;
-                    avg *= inv < 1.4142135623730951 ? inv : 1.4142135623730951;
-                }
-                hfrs[c * 8 + group] = find_scale_factor(T, avg);
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- CalculateFrameHeaderLength (:599-649)
-    // Up to two channels (every BASELINE shape): lane = (channel, band).  The five candidate delta widths' lengths are
-    // 11-bit sums packed three to a register and reduced with DPP -- the serial form below walks 128 bands on ten lanes
-    // while the other 246 wait at the barrier (~13 k cycles of a 66 k-cycle frame).
-    const bool small = nch * 128 <= 256;
-    auto wave_sum = [&](int v) __attribute__((always_inline)) -> int {
-        v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
-        v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
-        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);     // row_half_mirror
-        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);     // row_mirror
-        return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
-               __builtin_amdgcn_readlane(v, 48);
-    };
-    auto header_lengths_fast = [&]() __attribute__((always_inline)) {
-        const int c = tid >> 7, band = tid & 127;
-        const bool in = c < nch && band < s_coded[min(c, nch - 1)];
-        const int sf = in ? sfac[c * 128 + band] : 0;
-        const int delta = (in && band >= 1) ? abs(sf - (int)sfac[c * 128 + band - 1]) : 0;
-        const bool counted = in && band >= 1;
-        // per-lane costs <= 11, at most 127 lanes: 16-bit fields cannot carry into each other
-        int a = 0, b = 0, e = 0;
-        if (counted) {
-            a = (delta > 0 ? 7 : 1) | ((delta > 1 ? 8 : 2) << 16);
-            b = (delta > 3 ? 9 : 3) | ((delta > 7 ? 10 : 4) << 16);
-            e = delta > 15 ? 11 : 5;
-        }
-        e |= (in && sf != 0) ? 1 << 16 : 0;                               // non-zero scale factors: "empty channel" test
-        a = wave_sum(a);
-        b = wave_sum(b);
-        e = wave_sum(e);
-        int *slot = red + 16;                                             // [3][4]: red[16..27]; red[28..29] hold the search result
-        if (lane == 0) { slot[wave] = a; slot[4 + wave] = b; slot[8 + wave] = e; }
-        __syncthreads();
-        if (tid < nch) {
-            const int cc = tid;
-            const int sa = slot[2 * cc] + slot[2 * cc + 1], sb = slot[4 + 2 * cc] + slot[4 + 2 * cc + 1],
-                      se = slot[8 + 2 * cc] + slot[8 + 2 * cc + 1];
-            const int cand_len[6] = {0, 9 + (sa & 0xFFFF), 9 + (sa >> 16), 9 + (sb & 0xFFFF), 9 + (sb >> 16), 9 + (se & 0xFFFF)};
-            int len, db;
-            if ((se >> 16) == 0) { len = 3; db = 0; }
-            else {
-                db = 6;
-                len = 3 + 6 * s_coded[cc];
-#pragma unroll
-                for (int k = 1; k < 6; k++)
-                    if (cand_len[k] < len) { len = cand_len[k]; db = k; }
-            }
-            if (s_ctype[cc] == CH_STEREO_SECONDARY) len += 32;
-            else if (info.hfr_group_count > 0) len += 6 * info.hfr_group_count;
-            hlb[cc] = len;
-            dbits[cc] = db;
-        }
-        __syncthreads();
-    };
-    auto header_lengths = [&]() __attribute__((always_inline)) {
-        if (tid < nch * 5) {
-            const int c = tid / 5, db = 1 + tid % 5;
-            const int max_delta = (1 << (db - 1)) - 1;
-            int length = 3 + 6;
-            for (int band = 1; band < s_coded[c]; band++) {
-                const int delta = sfac[c * 128 + band] - sfac[c * 128 + band - 1];
-                length += abs(delta) > max_delta ? db + 6 : db;
-            }
-            cand[c * 8 + db] = length;
-        } else if (tid >= 64 && tid < 64 + nch) {
-            const int c = tid - 64;
-            int e = 1;
-            for (int i = 0; i < s_coded[c]; i++)
-                if (sfac[c * 128 + i] != 0) { e = 0; break; }
-            empty[c] = e;
-        }
-        __syncthreads();
-        if (tid < nch) {
-            const int c = tid;
-            int len, db;
-            if (empty[c]) { len = 3; db = 0; }
-            else {
-                db = 6;
-                len = 3 + 6 * s_coded[c];
-                for (int k = 1; k < 6; k++)
-                    if (cand[c * 8 + k] < len) { len = cand[c * 8 + k]; db = k; }
-            }
-            if (s_ctype[c] == CH_STEREO_SECONDARY) len += 32;
-            else if (info.hfr_group_count > 0) len += 6 * info.hfr_group_count;
-            hlb[c] = len;
-            dbits[c] = db;
-        }
-        __syncthreads();
-    };
-    if (small) header_lengths_fast();
-    else header_lengths();
-
-    // ---- CalculateUsedBits (:554-597)
-    // The bit cost of a band's eight coefficients depends only on its resolution (the scaled spectra are fixed): every
-    // (band, resolution) cost is computed once (build_cost_table: 16 costs of <= 96 bits in four dwords per band).
-    UsedBitsMemo memo;
-    if (small) {
-        const int i = min(tid, nch * 128 - 1);
-        build_cost_table(T, scaled + (size_t)(i >> 7) * 1024 + (i & 127), tid < nch * 128 && (i & 127) < s_coded[i >> 7], memo);
-    }
-    auto used_bits = [&](int noise_level, int eval_boundary) __attribute__((always_inline)) -> int {
-        const int partial = used_bits_partial(T, tid, nch, s_coded, sfac, scaled, noise_level, eval_boundary, memo);
-        int total = block_sum(partial) + 16 + 16 + 16;
-        for (int c = 0; c < nch; c++) total += hlb[c];
-        return total;
-    };
-
-    // ---- CalculateNoiseLevel (:457-485) / BinarySearchLevel (:502-523) and CalculateEvaluationBoundary (:487-500) /
-    // BinarySearchBoundary (:525-552).
-    const int available = info.frame_size * 8;
-    int level = 0, boundary = 0;
-    bool too_low = false;
-    bool searched = false;
-    if (small) {
-        // ONE wave runs both binary searches: the cost tables of all bands travel to it through LDS (4 KB, in the dead
-        // MDCT staging region), each of its lanes then owns four bands and every probe is ~45 instructions and a DPP
-        // reduction -- no LDS round trip, no barrier -- where the block-wide form issued the same ~45 instructions on
-        // four waves and met at a barrier sixteen times per frame.  The other three waves wait once.
-        uint4 *costs = reinterpret_cast<uint4 *>(dctin);
-        costs[tid] = make_uint4(memo.w0, memo.w1, memo.w2, memo.w3);
-        __syncthreads();
-        if (wave == 0) {
-            uint64_t clo[4], chi[4];
-            int off[4], bnd[4];
-            bool on[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int slot = lane + 64 * k;
-                const int sf = slot < nch * 128 ? sfac[slot] : 0;
-                on[k] = slot < nch * 128 && sf != 0 && (slot & 127) < s_coded[min(slot >> 7, nch - 1)];
-                off[k] = 2 - 5 * sf / 2;
-                bnd[k] = slot & 127;
-                const uint4 cw = costs[slot];
-                clo[k] = ((uint64_t)cw.y << 32) | cw.x;
-                chi[k] = ((uint64_t)cw.w << 32) | cw.z;
-            }
-            int hsum = 48;
-            for (int c = 0; c < nch; c++) hsum += hlb[c];
-            // (a free function, not a lambda: hipcc keeps by-reference captures of register arrays in scratch)
-#define probe(NL, EB) (wave_sum(probe_partial(T, clo, chi, off, bnd, on, (NL), (EB))) + hsum)
-            int low = 0, high = 255, mid_value = 0;
-            while (low != high) {
-                const int mid = (low + high) / 2;
-                mid_value = probe(mid, 0);
-                if (mid_value > available) low = mid + 1;
-                else high = mid;
-            }
-            int lv = (low == 255 && mid_value > available) ? -1 : low;
-            int bd = 0;
-            if (lv > 0) {
-                int lo2 = 0, hi2 = 127;
-                while (abs(hi2 - lo2) > 1) {
-                    const int mid = (lo2 + hi2) / 2;
-                    const int mid_value2 = probe(lv, mid);
-                    if (available < mid_value2) hi2 = mid - 1;
-                    else lo2 = mid;
-                }
-                if (lo2 == hi2) bd = lo2 < 127 ? lo2 : -1;
-                else bd = probe(lv, hi2) > available ? lo2 : hi2;
-            }
-#undef probe
-            if (lane == 0) { red[28] = lv; red[29] = bd; }
-        }
-        __syncthreads();
-        level = red[28];
-        boundary = red[29];
-        searched = level >= 0;                         // level < 0 (bands must be dropped): the block-wide form below
-    }
-    if (!searched) {
-        auto search_level = [&]() __attribute__((always_inline)) -> int {
-            int low = 0, high = 255, mid_value = 0;
-            while (low != high) {
-                const int mid = (low + high) / 2;
-                mid_value = used_bits(mid, 0);
-                if (mid_value > available) low = mid + 1;
-                else high = mid;
-            }
-            return (low == 255 && mid_value > available) ? -1 : low;
-        };
-        level = small ? -1 : search_level();
-        int highest_band = info.base_band_count + info.stereo_band_count - 1;
-        while (level < 0) {
-            highest_band -= 2;
-            if (highest_band < 0) { too_low = true; break; }
-            if (tid < nch) {
-                sfac[tid * 128 + highest_band + 1] = 0;
-                sfac[tid * 128 + highest_band + 2] = 0;
             }
             __syncthreads();
-            header_lengths();
-            level = search_level();
-        }
-        if (too_low) {                       // InvalidDataException("Bitrate is set too low.")
-            if (tid == 0 && status) atomicOr(status, 4);
-            level = 255;
-        }
-        boundary = 0;
-        if (level != 0) {
-            int low = 0, high = 127;
-            while (abs(high - low) > 1) {
-                const int mid = (low + high) / 2;
-                const int mid_value = used_bits(level, mid);
-                if (available < mid_value) high = mid - 1;
-                else low = mid;
+            const int nb = info.total_band_count - info.base_band_count;
+            for (int i = tid; i < nch * 8 * nb; i += ENC_THREADS) {
+                const int c = i / (8 * nb), sf = (i / nb) % 8, b = info.base_band_count + i % nb;
+                if (s_ctype[c] != CH_STEREO_PRIMARY) continue;
+                double *l = spectra + ((size_t)c * 8 + sf) * RS;
+                double *r = spectra + ((size_t)(c + 1) * 8 + sf) * RS;
+                l[b] = (l[b] + r[b]) * eratio[c * 8 + sf];
+                r[b] = 0;
             }
-            if (low == high) boundary = low < 127 ? low : -1;
-            else {
-                const int hi_value = used_bits(level, high);
-                boundary = hi_value > available ? low : high;
+            __syncthreads();
+        }
+
+        // ---- CalculateScaleFactors (:673-689), ScaleSpectra (:651-671) in place and the band's bit costs at all sixteen
+        // resolutions (CalculateUsedBits :554-597), in one pass: wave = channel (mod 2), lane = bands `lane` and `lane + 64`.
+        // Bands >= the coded count keep their unscaled values (the HFR group averages below read exactly those).
+        for (int c = wave; c < nch; c += 2) {
+#pragma unroll 1
+            for (int h = 0; h < 2; h++) {
+                const int b = lane + 64 * h;
+                int sfv = 0;
+                uint4 ct = make_uint4(0, 0, 0, 0);
+                if (b < s_coded[c]) {
+                    double *col = spectra + (size_t)c * 8 * RS + b;
+                    double x[8];
+                    double mx = 0;
+#pragma unroll
+                    for (int sf = 0; sf < 8; sf++) {
+                        x[sf] = col[(size_t)sf * RS];
+                        const double coeff = fabs(x[sf]);
+                        mx = coeff > mx ? coeff : mx;
+                    }
+                    sfv = find_scale_factor(T, mx);
+                    const double qs = T.quant_scale[sfv];
+#pragma unroll
+                    for (int sf = 0; sf < 8; sf++) {
+                        x[sf] = sfv != 0 ? clampd(x[sf] * qs, -0.999999999999, 0.999999999999) : 0.0;
+                        col[(size_t)sf * RS] = x[sf];
+                    }
+                    ct = band_cost_table(T, x);
+                }
+                sfac[c * 128 + b] = (uint8_t)sfv;
+                costs[c * 128 + b] = ct;
             }
         }
-    }
-    if (boundary < 0) {                       // NotImplementedException in the reference
-        if (tid == 0 && status) atomicOr(status, 8);
-        boundary = 0;
-    }
+        __syncthreads();
 
-    // ---- CalculateFrameResolutions (:441-455)
-    for (int i = tid; i < nch * 128; i += 256) {
-        const int c = i / 128, b = i % 128;
-        ires[i] = b < s_coded[c] ? calculate_resolution(T, sfac[i], b < boundary ? level - 1 : level) : 0;
-    }
-    __syncthreads();
+        // ---- CalculateHfrGroupAverages (:766-793) + CalculateHfrScale (:795-832)
+        if (info.hfr_group_count > 0) {
+            if (tid < nch * 8) {
+                const int c = tid / 8, group = tid % 8;
+                if (group < info.hfr_group_count && s_ctype[c] != CH_STEREO_SECONDARY) {
+                    const int hfr_start = info.stereo_band_count + info.base_band_count;
+                    double sum = 0.0;
+                    int count = 0;
+                    int band = hfr_start + group * info.bands_per_hfr_group;
+                    for (int i = 0; i < info.bands_per_hfr_group && band < SPSF; band++, i++) {
+                        for (int sf = 0; sf < 8; sf++) sum += fabs(spectra[((size_t)c * 8 + sf) * RS + band]);
+                        count += 8;
+                    }
+                    double avg = sum / count;
+                    const int lim = min(info.hfr_band_count, info.total_band_count - info.hfr_band_count);
+                    sum = 0.0;
+                    count = 0;
+                    band = group * info.bands_per_hfr_group;
+                    for (int i = 0; i < info.bands_per_hfr_group && band < lim; band++, i++) {
+                        for (int sf = 0; sf < 8; sf++) sum += fabs(spectra[((size_t)c * 8 + sf) * RS + (hfr_start - band - 1)]);
+                        count += 8;
+                    }
+                    const double average = sum / count;
+                    if (average > 0.0) {
+                        const double inv = 1.0 / average;
+                        avg *= inv < 1.4142135623730951 ? inv : 1.4142135623730951;
+                    }
+                    hfrs[c * 8 + group] = find_scale_factor(T, avg);
+                }
+            }
+            __syncthreads();
+        }
 
-    // ---- PackFrame (CriHcaPacking.cs:17-58); a frame the reference refuses ("Bitrate is set too low.")
-    // is left zero -- its codes would not fit the frame
-    if (tid == 0 && !too_low) fbuf[0] = 0xFFFF0000u | ((unsigned)level << 7) | (unsigned)boundary;
-    // WriteScaleFactors (:262-295): lane = (channel, band), two channels per pass; the variable-length codes
-    // get their bit offsets from a 128-lane exclusive scan
-    for (int c0 = 0; c0 < nch; c0 += 2) {
-        const int c = c0 + (tid >> 7), band = tid & 127;
-        unsigned code = 0;
-        int nbits = 0;
-        if (c < nch && !too_low) {
-            const int db = dbits[c];
-            const uint8_t *sc = sfac + c * 128;
-            if (band == 0) {                           // the 3-bit delta width, then the first scale factor
-                code = (unsigned)db;
-                nbits = 3;
-                if (db != 0) { code = (code << 6) | (unsigned)sc[0]; nbits = 9; }
-            } else if (band < s_coded[c] && db != 0) {
-                if (db == 6) { code = (unsigned)sc[band]; nbits = 6; }
+        // ---- CalculateFrameHeaderLength (:599-649): a channel's five candidate delta widths' lengths are 11-bit sums packed
+        // three to a register and reduced with DPP inside the channel's wave
+        auto header_lengths_fast = [&]() __attribute__((always_inline)) {
+            for (int c = wave; c < nch; c += 2) {
+                int a = 0, b = 0, e = 0;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int band = lane + 64 * h;
+                    const bool in = band < s_coded[c];
+                    const int sf = in ? sfac[c * 128 + band] : 0;
+                    const bool counted = in && band >= 1;
+                    const int delta = counted ? abs(sf - (int)sfac[c * 128 + band - 1]) : 0;
+                    // per-lane costs <= 22, at most 64 lanes: 16-bit fields cannot carry into each other
+                    if (counted) {
+                        a += (delta > 0 ? 7 : 1) | ((delta > 1 ? 8 : 2) << 16);
+                        b += (delta > 3 ? 9 : 3) | ((delta > 7 ? 10 : 4) << 16);
+                        e += delta > 15 ? 11 : 5;
+                    }
+                    e += (in && sf != 0) ? 1 << 16 : 0;                       // non-zero scale factors: "empty channel" test
+                }
+                a = wave_sum(a);
+                b = wave_sum(b);
+                e = wave_sum(e);
+                if (lane == 0) {
+                    const int cand_len[6] = {0, 9 + (a & 0xFFFF), 9 + (a >> 16), 9 + (b & 0xFFFF), 9 + (b >> 16), 9 + (e & 0xFFFF)};
+                    int len, db;
+                    if ((e >> 16) == 0) { len = 3; db = 0; }
+                    else {
+                        db = 6;
+                        len = 3 + 6 * s_coded[c];
+#pragma unroll
+                        for (int k = 1; k < 6; k++)
+                            if (cand_len[k] < len) { len = cand_len[k]; db = k; }
+                    }
+                    if (s_ctype[c] == CH_STEREO_SECONDARY) len += 32;
+                    else if (info.hfr_group_count > 0) len += 6 * info.hfr_group_count;
+                    hlb[c] = len;
+                    dbits[c] = db;
+                }
+            }
+            __syncthreads();
+        };
+        // the serial form (after bands were dropped, CalculateNoiseLevel :469-484)
+        auto header_lengths = [&]() __attribute__((always_inline)) {
+            if (tid < nch * 5) {
+                const int c = tid / 5, db = 1 + tid % 5;
+                const int max_delta = (1 << (db - 1)) - 1;
+                int length = 3 + 6;
+                for (int band = 1; band < s_coded[c]; band++) {
+                    const int delta = sfac[c * 128 + band] - sfac[c * 128 + band - 1];
+                    length += abs(delta) > max_delta ? db + 6 : db;
+                }
+                cand[c * 8 + db] = length;
+            } else if (tid >= 64 && tid < 64 + nch) {
+                const int c = tid - 64;
+                int e = 1;
+                for (int i = 0; i < s_coded[c]; i++)
+                    if (sfac[c * 128 + i] != 0) { e = 0; break; }
+                empty[c] = e;
+            }
+            __syncthreads();
+            if (tid < nch) {
+                const int c = tid;
+                int len, db;
+                if (empty[c]) { len = 3; db = 0; }
                 else {
-                    const int max_delta = (1 << (db - 1)) - 1;
-                    const int delta = sc[band] - sc[band - 1];
-                    if (abs(delta) > max_delta) { code = ((((1u << db) - 1)) << 6) | (unsigned)sc[band]; nbits = db + 6; }
-                    else { code = (unsigned)(max_delta + delta); nbits = db; }
+                    db = 6;
+                    len = 3 + 6 * s_coded[c];
+                    for (int k = 1; k < 6; k++)
+                        if (cand[c * 8 + k] < len) { len = cand[c * 8 + k]; db = k; }
+                }
+                if (s_ctype[c] == CH_STEREO_SECONDARY) len += 32;
+                else if (info.hfr_group_count > 0) len += 6 * info.hfr_group_count;
+                hlb[c] = len;
+                dbits[c] = db;
+            }
+            __syncthreads();
+        };
+        header_lengths_fast();
+
+        // ---- CalculateUsedBits (:554-597), block-wide (more than two channels, or after bands were dropped)
+        auto used_bits = [&](int noise_level, int eval_boundary) __attribute__((always_inline)) -> int {
+            int partial = 0;
+            for (int i = tid; i < nch * 128; i += ENC_THREADS) {
+                const int c = i >> 7, b = i & 127;
+                if (b >= s_coded[c]) continue;
+                const int noise = b < eval_boundary ? noise_level - 1 : noise_level;
+                partial += cost_at(costs[i], resolution_of(T, sfac[i], noise));
+            }
+            int total = block_sum(partial) + 16 + 16 + 16;
+            for (int c = 0; c < nch; c++) total += hlb[c];
+            return total;
+        };
+
+        // ---- CalculateNoiseLevel (:457-485) / BinarySearchLevel (:502-523) and CalculateEvaluationBoundary (:487-500) /
+        // BinarySearchBoundary (:525-552)
+        int level = 0, boundary = 0;
+        bool too_low = false;
+        bool searched = false;
+        if (small) {
+            // ONE wave runs both binary searches: each of its lanes owns four bands' cost tables and every probe is ~45
+            // instructions and a DPP reduction -- no LDS round trip, no barrier.  The other wave waits once.
+            if (wave == 0) {
+                uint64_t clo[4], chi[4];
+                int off[4], bnd[4];
+                bool on[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int slot = lane + 64 * k;
+                    const int sf = slot < nch * 128 ? sfac[slot] : 0;
+                    on[k] = slot < nch * 128 && sf != 0 && (slot & 127) < s_coded[min(slot >> 7, nch - 1)];
+                    off[k] = 2 - 5 * sf / 2;
+                    bnd[k] = slot & 127;
+                    const uint4 cw = slot < nch * 128 ? costs[slot] : make_uint4(0, 0, 0, 0);
+                    clo[k] = ((uint64_t)cw.y << 32) | cw.x;
+                    chi[k] = ((uint64_t)cw.w << 32) | cw.z;
+                }
+                int hsum = 48;
+                for (int c = 0; c < nch; c++) hsum += hlb[c];
+#define probe(NL, EB) (wave_sum(probe_partial(T, clo, chi, off, bnd, on, (NL), (EB))) + hsum)
+                int low = 0, high = 255, mid_value = 0;
+                while (low != high) {
+                    const int mid = (low + high) / 2;
+                    mid_value = probe(mid, 0);
+                    if (mid_value > available) low = mid + 1;
+                    else high = mid;
+                }
+                const int lv = (low == 255 && mid_value > available) ? -1 : low;
+                int bd = 0;
+                if (lv > 0) {
+                    int lo2 = 0, hi2 = 127;
+                    while (abs(hi2 - lo2) > 1) {
+                        const int mid = (lo2 + hi2) / 2;
+                        const int mid_value2 = probe(lv, mid);
+                        if (available < mid_value2) hi2 = mid - 1;
+                        else lo2 = mid;
+                    }
+                    if (lo2 == hi2) bd = lo2 < 127 ? lo2 : -1;
+                    else bd = probe(lv, hi2) > available ? lo2 : hi2;
+                }
+#undef probe
+                if (lane == 0) { red[28] = lv; red[29] = bd; }
+            }
+            __syncthreads();
+            level = red[28];
+            boundary = red[29];
+            searched = level >= 0;                     // level < 0 (bands must be dropped): the block-wide form below
+        }
+        if (!searched) {
+            auto search_level = [&]() __attribute__((always_inline)) -> int {
+                int low = 0, high = 255, mid_value = 0;
+                while (low != high) {
+                    const int mid = (low + high) / 2;
+                    mid_value = used_bits(mid, 0);
+                    if (mid_value > available) low = mid + 1;
+                    else high = mid;
+                }
+                return (low == 255 && mid_value > available) ? -1 : low;
+            };
+            level = small ? -1 : search_level();
+            int highest_band = info.base_band_count + info.stereo_band_count - 1;
+            while (level < 0) {
+                highest_band -= 2;
+                if (highest_band < 0) { too_low = true; break; }
+                if (tid < nch) {
+                    sfac[tid * 128 + highest_band + 1] = 0;
+                    sfac[tid * 128 + highest_band + 2] = 0;
+                }
+                __syncthreads();
+                header_lengths();
+                level = search_level();
+            }
+            if (too_low) {                   // InvalidDataException("Bitrate is set too low.")
+                if (tid == 0 && status) atomicOr(status, 4);
+                level = 255;
+            }
+            boundary = 0;
+            if (level != 0) {
+                int low = 0, high = 127;
+                while (abs(high - low) > 1) {
+                    const int mid = (low + high) / 2;
+                    const int mid_value = used_bits(level, mid);
+                    if (available < mid_value) high = mid - 1;
+                    else low = mid;
+                }
+                if (low == high) boundary = low < 127 ? low : -1;
+                else {
+                    const int hi_value = used_bits(level, high);
+                    boundary = hi_value > available ? low : high;
                 }
             }
         }
-        int total;
-        const int rel = group_exclusive_scan(nbits, 2, total);
-        if (c < nch && !too_low) {
+        if (boundary < 0) {                   // NotImplementedException in the reference
+            if (tid == 0 && status) atomicOr(status, 8);
+            boundary = 0;
+        }
+
+        // ---- CalculateFrameResolutions (:441-455)
+        for (int i = tid; i < nch * 128; i += ENC_THREADS) {
+            const int c = i >> 7, b = i & 127;
+            ires[i] = b < s_coded[c] ? resolution_of(T, sfac[i], b < boundary ? level - 1 : level) : 0;
+        }
+        // ---- PackFrame (CriHcaPacking.cs:17-58); a frame the reference refuses ("Bitrate is set too low.")
+        // is left zero -- its codes would not fit the frame
+        if (tid == 0 && !too_low) atomicOr(&fbuf[0], 0xFFFF0000u | ((unsigned)level << 7) | (unsigned)boundary);
+        int header_bits = 32;
+        for (int k = 0; k < nch; k++) header_bits += hlb[k];
+        // WriteScaleFactors (:262-295): wave = channel (mod 2), lane = bands 2 lane and 2 lane + 1; the variable-length
+        // codes get their bit offsets from a scan inside the wave
+        for (int c = wave; c < nch && !too_low; c += 2) {
+            const int db = dbits[c];
+            const uint8_t *sc = sfac + c * 128;
+            unsigned code[2] = {0, 0};
+            int nb2[2] = {0, 0};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int band = 2 * lane + h;
+                if (band == 0) {                               // the 3-bit delta width, then the first scale factor
+                    code[h] = (unsigned)db;
+                    nb2[h] = 3;
+                    if (db != 0) { code[h] = (code[h] << 6) | (unsigned)sc[0]; nb2[h] = 9; }
+                } else if (band < s_coded[c] && db != 0) {
+                    if (db == 6) { code[h] = (unsigned)sc[band]; nb2[h] = 6; }
+                    else {
+                        const int max_delta = (1 << (db - 1)) - 1;
+                        const int delta = sc[band] - sc[band - 1];
+                        if (abs(delta) > max_delta) { code[h] = ((((1u << db) - 1)) << 6) | (unsigned)sc[band]; nb2[h] = db + 6; }
+                        else { code[h] = (unsigned)(max_delta + delta); nb2[h] = db; }
+                    }
+                }
+            }
+            const int mine = nb2[0] + nb2[1];
+            const int incl = wave_inclusive_scan(mine);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
             int off = 32;
             for (int k = 0; k < c; k++) off += hlb[k];
-            put_bits(off + rel, code, nbits);
-            if (band == 0) {                           // intensity / HFR scales follow the scale factors
+            put_bits(off + incl - mine, code[0], nb2[0]);
+            put_bits(off + incl - mine + nb2[0], code[1], nb2[1]);
+            if (lane == 0) {                                   // intensity / HFR scales follow the scale factors
                 off += total;
                 if (s_ctype[c] == CH_STEREO_SECONDARY) {
                     for (int i = 0; i < 8; i++) { put_bits(off, (unsigned)intensity[c * 8 + i], 4); off += 4; }
@@ -640,151 +711,133 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 }
             }
         }
-    }
-    // WriteSpectra (:238-260) in (sub-frame, channel, band) order: slot = (sf*nch + c)*128 + band;
-    // QuantizeSpectra (:420-439) on the fly
-    {
-        const int per_thread = nch * 4;               // nch*8*128 / 256, divides 128
-        // per_thread divides 128: a thread's slots share the sub-frame and the channel, the band runs on
-        const int slot0 = tid * per_thread;
-        const int sf = slot0 / (nch * 128), c = (slot0 / 128) % nch, band0 = slot0 % 128;
-        const double *xs = scaled + ((size_t)c * 8 + sf) * 128 + band0;
-        const uint8_t *rs = ires + c * 128 + band0;
-        auto code_of = [&](int k, unsigned &code, int &nbits) __attribute__((always_inline)) {
-            const int res = rs[k];
-            code = 0;
-            nbits = 0;
-            if (res == 0) return;
-            const double inv = T.inv_step[res];
-            const double up = inv + 1;
-            const int down = trunc_i(inv + 0.5);
-            // a thread's slots run on across a channel boundary when 4 * nch does not divide 128 (3, 5, 6, 7 channels):
-            // the sub-frame stays, the band wraps into the next channel
-            const int bk = band0 + k;
-            const int q = trunc_i(xs[(size_t)(bk >> 7) * 1024 + (bk & 127) - band0] * inv + up) - down;
-            if (res < 8) {
-                nbits = T.enc_bits[res][q + 8];
-                code = T.enc_value[res][q + 8];
-            } else {
-                nbits = T.max_bits[res] - 1;
-                code = (unsigned)abs(q);
-                if (q != 0) { code = (code << 1) | (q > 0 ? 0u : 1u); nbits++; }
-            }
-        };
-        // a thread's codes are consecutive in the stream: they are gathered in a 64-bit window and leave as whole
-        // dwords (one LDS atomic per dword instead of up to two per code)
-        struct Emitter {
-            unsigned *buf;
-            uint64_t acc;
-            int word, p;
-            __device__ __forceinline__ void put(unsigned value, int nbits)
-            {
-                acc |= (uint64_t)value << (64 - p - nbits);            // p < 32, nbits <= 13
-                p += nbits;
-                if (p >= 32) {
-                    const unsigned hi = (unsigned)(acc >> 32);
-                    if (hi) atomicOr(&buf[word], hi);
-                    acc <<= 32;
-                    word++;
-                    p -= 32;
-                }
-            }
-            __device__ __forceinline__ void finish()
-            {
-                const unsigned hi = (unsigned)(acc >> 32);
-                if (hi) atomicOr(&buf[word], hi);
-            }
-        };
-        int header_bits = 32;
-        for (int k = 0; k < nch; k++) header_bits += hlb[k];
-        if (per_thread <= 8) {                         // up to two channels: the codes stay in registers
-            unsigned codes[8];
-            int nb[8];
-            int local = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                codes[k] = 0;
-                nb[k] = 0;
-                if (k < per_thread) code_of(k, codes[k], nb[k]);
-                local += nb[k];
-            }
-            int all_bits;
-            const int off = header_bits + group_exclusive_scan(local, 4, all_bits);
-            Emitter e{fbuf, 0, off >> 5, off & 31};
-            if (!too_low) {
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    if (nb[k] > 0) e.put(codes[k], nb[k]);
-                e.finish();
-            }
-        } else {
-            int local = 0;
-            for (int k = 0; k < per_thread; k++) {
-                unsigned code;
-                int nbits;
-                code_of(k, code, nbits);
-                local += nbits;
-            }
-            int all_bits;
-            const int off = header_bits + group_exclusive_scan(local, 4, all_bits);
-            Emitter e{fbuf, 0, off >> 5, off & 31};
-            for (int k = 0; k < per_thread && !too_low; k++) {
-                unsigned code;
-                int nbits;
-                code_of(k, code, nbits);
-                if (nbits > 0) e.put(code, nbits);
-            }
-            if (!too_low) e.finish();
-        }
-    }
-    __syncthreads();
-
-    // ---- WriteChecksum (:231-236): CRC-16 (poly 0x8005, init 0) over the first frame_size-2 bytes
-    {
-        const int nbytes = info.frame_size - 2;
-        const int chunk = (nbytes + 255) / 256;
-        const int begin = tid * chunk, end = min(begin + chunk, nbytes);
-        unsigned crc = 0;
-        for (int i = begin; i < end; i++) {
-            const unsigned byte = (fbuf[i >> 2] >> (24 - 8 * (i & 3))) & 0xFFu;
-            crc ^= byte << 8;
-#pragma unroll
-            for (int j = 0; j < 8; j++) crc = ((crc << 1) ^ ((crc & 0x8000u) ? 0x8005u : 0u)) & 0xFFFFu;
-        }
-        unsigned part = (begin < end) ? gf_mul(crc, crc_pow[nbytes - end]) : 0u;
+        __syncthreads();                               // ires is complete
+        // WriteSpectra (:238-260) in (sub-frame, channel, band) order: slot = (sf * nch + c) * 128 + band;
+        // QuantizeSpectra (:420-439) on the fly.  A lane owns nch * 8 consecutive slots; 8 nch divides 128 for 1, 2, 4
+        // and 8 channels, otherwise a lane's slots run on into the next channel's row.
         {
-            int v = (int)part;
-            v ^= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);  // as block_sum, with xor
-            v ^= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
-            v ^= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
-            v ^= __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
-            part = (unsigned)(__builtin_amdgcn_readlane(v, 0) ^ __builtin_amdgcn_readlane(v, 16) ^
-                              __builtin_amdgcn_readlane(v, 32) ^ __builtin_amdgcn_readlane(v, 48));
+            const int per_thread = nch * 8;
+            const int slot0 = tid * per_thread;
+            // (sub-frame, channel, band) of the lane's first slot, then stepped (a division per code would cost more than
+            // the code)
+            int w_sf = slot0 / (nch * 128), w_c = (slot0 >> 7) - w_sf * nch, w_band = slot0 & 127;
+            auto rewind = [&]() __attribute__((always_inline)) {
+                w_sf = slot0 / (nch * 128);
+                w_c = (slot0 >> 7) - w_sf * nch;
+                w_band = slot0 & 127;
+            };
+            auto code_of = [&](unsigned &code, int &nbits) __attribute__((always_inline)) {
+                const int sf = w_sf, c = w_c, band = w_band;
+                w_band++;
+                if (w_band == 128) {
+                    w_band = 0;
+                    w_c++;
+                    if (w_c == nch) { w_c = 0; w_sf++; }
+                }
+                const int res = ires[c * 128 + band];
+                code = 0;
+                nbits = 0;
+                if (res == 0) return;
+                const double inv = T.inv_step[res];
+                const double up = inv + 1;
+                const int down = trunc_i(inv + 0.5);
+                const int q = trunc_i(spectra[((size_t)c * 8 + sf) * RS + band] * inv + up) - down;
+                if (res < 8) {
+                    nbits = T.enc_bits[res][q + 8];
+                    code = T.enc_value[res][q + 8];
+                } else {
+                    nbits = T.max_bits[res] - 1;
+                    code = (unsigned)abs(q);
+                    if (q != 0) { code = (code << 1) | (q > 0 ? 0u : 1u); nbits++; }
+                }
+            };
+            if (per_thread <= 16) {                        // up to two channels: the codes stay in registers (13 + 4 bits each)
+                unsigned packed[16];
+                int local = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    packed[k] = 0;
+                    if (k < per_thread) {
+                        unsigned code;
+                        int nbits;
+                        code_of(code, nbits);
+                        packed[k] = (code << 4) | (unsigned)nbits;
+                        local += nbits;
+                    }
+                }
+                const int off = header_bits + block_exclusive_scan(local);
+                Emitter e{fbuf, 0, off >> 5, off & 31};
+                if (!too_low) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        if (packed[k] & 15u) e.put(packed[k] >> 4, (int)(packed[k] & 15u));
+                    e.finish();
+                }
+            } else {
+                int local = 0;
+                for (int k = 0; k < per_thread; k++) {
+                    unsigned code;
+                    int nbits;
+                    code_of(code, nbits);
+                    local += nbits;
+                }
+                rewind();
+                const int off = header_bits + block_exclusive_scan(local);
+                Emitter e{fbuf, 0, off >> 5, off & 31};
+                for (int k = 0; k < per_thread && !too_low; k++) {
+                    unsigned code;
+                    int nbits;
+                    code_of(code, nbits);
+                    if (nbits > 0) e.put(code, nbits);
+                }
+                if (!too_low) e.finish();
+            }
         }
-        if (lane == 0) red[wave] = (int)part;
         __syncthreads();
-        if (tid == 0) {
-            const unsigned total = (unsigned)(red[0] ^ red[1] ^ red[2] ^ red[3]) & 0xFFFFu;
-            const int pos = nbytes;        // big-endian 16-bit value at the last two bytes
-            fbuf[pos >> 2] |= (total >> 8) << (24 - 8 * (pos & 3));
-            fbuf[(pos + 1) >> 2] |= (total & 0xFF) << (24 - 8 * ((pos + 1) & 3));
-        }
-        __syncthreads();
-    }
 
-    // ---- store the frame (frame offsets are even: 2-byte stores)
-    {
-        uint16_t *dst = reinterpret_cast<uint16_t *>(frames + (int64_t)stream * frames_pitch + (int64_t)frame * info.frame_size);
-        for (int i = tid; i < info.frame_size / 2; i += 256) {
-            const int b = 2 * i;
-            const unsigned b0 = (fbuf[b >> 2] >> (24 - 8 * (b & 3))) & 0xFFu;
-            const unsigned b1 = (fbuf[(b + 1) >> 2] >> (24 - 8 * ((b + 1) & 3))) & 0xFFu;
-            dst[i] = (uint16_t)(b0 | (b1 << 8));
+        // ---- WriteChecksum (:231-236): CRC-16 (poly 0x8005, init 0) over the first frame_size-2 bytes
+        {
+            const int nbytes = info.frame_size - 2;
+            const int chunk = (nbytes + ENC_THREADS - 1) / ENC_THREADS;
+            const int begin = tid * chunk, end = min(begin + chunk, nbytes);
+            unsigned crc = 0;
+            for (int i = begin; i < end; i++) {
+                const unsigned byte = (fbuf[i >> 2] >> (24 - 8 * (i & 3))) & 0xFFu;
+                crc ^= byte << 8;
+#pragma unroll
+                for (int j = 0; j < 8; j++) crc = ((crc << 1) ^ ((crc & 0x8000u) ? 0x8005u : 0u)) & 0xFFFFu;
+            }
+            unsigned part = (begin < end) ? gf_mul(crc, crc_pow[nbytes - end]) : 0u;
+            part = (unsigned)wave_xor((int)part);
+            if (lane == 0) red[30 + wave] = (int)part;
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned total = (unsigned)(red[30] ^ red[31]) & 0xFFFFu;
+                const int pos = nbytes;        // big-endian 16-bit value at the last two bytes
+                fbuf[pos >> 2] |= (total >> 8) << (24 - 8 * (pos & 3));
+                fbuf[(pos + 1) >> 2] |= (total & 0xFF) << (24 - 8 * ((pos + 1) & 3));
+            }
+            __syncthreads();
         }
-        if ((info.frame_size & 1) && tid == 0) {
-            const int b = info.frame_size - 1;
-            frames[(int64_t)stream * frames_pitch + (int64_t)frame * info.frame_size + b] =
-                (uint8_t)((fbuf[b >> 2] >> (24 - 8 * (b & 3))) & 0xFFu);
+
+        // ---- store the frame: whole aligned dwords (the frame starts at any byte: its k-th dword is a funnel shift of two
+        // big-endian words of fbuf), the few bytes before the first and after the last aligned dword one by one
+        {
+            uint8_t *dst = frames + (int64_t)stream * frames_pitch + (int64_t)frame * info.frame_size;
+            const int lead = (int)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3);       // bytes before the first aligned dword
+            const int ndw = (info.frame_size - lead) / 4;
+            auto byte_at = [&](int b) { return (fbuf[b >> 2] >> (24 - 8 * (b & 3))) & 0xFFu; };
+            uint32_t *dw = reinterpret_cast<uint32_t *>(dst + lead);
+            for (int k = tid; k < ndw; k += ENC_THREADS) {
+                const int b = lead + 4 * k;                                                   // frame byte of the dword's first byte
+                const uint32_t hi = fbuf[b >> 2], lo = fbuf[(b >> 2) + 1];
+                const int sh = 8 * (b & 3);
+                const uint32_t be = sh ? (hi << sh) | (lo >> (32 - sh)) : hi;                 // frame bytes b .. b+3, first byte on top
+                dw[k] = bswap32(be);
+            }
+            const int tail0 = lead + 4 * ndw;
+            if (tid < lead) dst[tid] = (uint8_t)byte_at(tid);
+            if (tid >= 64 && tid - 64 < info.frame_size - tail0) dst[tail0 + tid - 64] = (uint8_t)byte_at(tail0 + tid - 64);
         }
     }
 }
@@ -795,16 +848,19 @@ int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, 
 {
     if (nstreams <= 0 || info.frame_count <= 0) return VGA_OK;
     const int nch = info.nch;
-    const size_t region_b = 11 * 128;
-    const size_t doubles = (size_t)nch * 1024 + region_b + (size_t)nch * 16;
+    const size_t doubles = (size_t)nch * 8 * RS + (size_t)nch * 16;
     const size_t ints = 32 + 8 + 8 + 64 + 8 + 64 + 64;
-    const size_t lds = doubles * 8 + ints * 4 + ((size_t)(info.frame_size + 3) / 4 + 2) * 4 + (size_t)nch * 256;
-    if (lds > 64 * 1024)
-        VGA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hca_encode_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(hca_encode_kernel, dim3((unsigned)((int64_t)nstreams * info.frame_count)), dim3(256), lds, stream,
-                       d_pcm, stream_pitch, ch_pitch, nstreams, map, info, d_frames, frames_pitch, d_crc_pow,
-                       d_status);
+    const size_t lds = doubles * 8 + (size_t)nch * 128 * 16 + ints * 4 + ((size_t)(info.frame_size + 3) / 4 + 2) * 4 + (size_t)nch * 256;
+    if (lds > 32 * 1024) VGA_HIP_TRY(allow_dynamic_lds(hca_encode_kernel, lds));
+    // frames per workgroup: long runs amortise the per-workgroup set-up (tables, twiddles), short ones keep small inputs
+    // spread over the chip
+    const int64_t total = (int64_t)nstreams * info.frame_count;
+    int per_group = (int)std::min<int64_t>(MAX_ENC_FRAMES_PER_GROUP, std::max<int64_t>(1, total / 8192));
+    if (hca_frames_per_group_override() > 0) per_group = std::min(hca_frames_per_group_override(), 64);
+    per_group = std::min(per_group, info.frame_count);
+    const int groups = (info.frame_count + per_group - 1) / per_group;
+    hipLaunchKernelGGL(hca_encode_kernel, dim3((unsigned)((int64_t)nstreams * groups)), dim3(ENC_THREADS), lds, stream,
+                       d_pcm, stream_pitch, ch_pitch, per_group, groups, map, info, d_frames, frames_pitch, d_crc_pow, d_status);
     VGA_HIP_TRY(hipGetLastError());
     return VGA_OK;
 }

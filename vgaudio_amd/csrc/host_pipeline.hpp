@@ -118,6 +118,8 @@ struct Job {
     int taper_min_units = 0;             // > 0: the LAST chunk is split into halves down to this size (chunk, ..., chunk/2,
                                          // chunk/4, chunk/4): what runs after the last upload is a small chunk's kernels
     int tail_units = 0;                  // > 0 (takes precedence): the last chunk is split once, into (rest, tail_units)
+    int head_units = 0;                  // > 0: the FIRST chunk is this short (when more than one chunk follows it), so that
+                                         // the first kernels start after a fraction of a chunk's upload
     // input side (rows of in_row_bytes bytes at host pointers in_rows[r]; device row r at d_in + r * d_in_pitch)
     int in_rows_per_unit = 1;
     const void *const *in_rows = nullptr;
@@ -218,7 +220,14 @@ inline Result run(const Job &job)
     const int chunk_units = std::max(1, std::min(job.chunk_units > 0 ? job.chunk_units : job.units, job.units));
     // chunk k covers units [cbegin[k], cbegin[k + 1])
     std::vector<int> cbegin;
-    for (int u = 0; u < job.units; u += chunk_units) cbegin.push_back(u);
+    {
+        int u = 0;
+        if (job.head_units > 0 && job.head_units < chunk_units && job.units > job.head_units + chunk_units) {
+            cbegin.push_back(0);
+            u = job.head_units;
+        }
+        for (; u < job.units; u += chunk_units) cbegin.push_back(u);
+    }
     cbegin.push_back(job.units);
     if (job.tail_units > 0 && cbegin.size() >= 2 && job.units - cbegin[cbegin.size() - 2] > job.tail_units) {
         // the last chunk (the only one of a small call) as (rest, tail): the tail's upload runs under the rest's kernels,
