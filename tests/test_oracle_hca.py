@@ -173,3 +173,56 @@ def test_batch_matches_single():
     rc, dec = po.hca_decode_batch(info, fr, threads=2)
     for s in range(5):
         assert (dec[s] == po.hca_decode(info, fr[s].reshape(info.frame_count, info.frame_size))[1]).all()
+
+
+def _table_from_header(name):
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vgaudio_amd", "csrc", "hca_tables_data.h")).read()
+    m = re.search(name + r"\[[^\]]*\](?:\[[^\]]*\])?\s*=\s*\{(.*?)\};", src, re.S)
+    return [int(t.rstrip("uUlL"), 0) for t in re.findall(r"-?0x[0-9a-fA-F]+|-?\d+", m.group(1))]
+
+
+def test_two_shortcuts_of_the_hca_encode_kernel_are_exact():
+    """vgaudio_amd/csrc/hca_encode_kernel.hip replaces (1) the bitwise CRC-16 step by a byte-at-a-time formula and (2) the
+    table look-up QuantizeSpectrumBits[res][(int)(x * inv + up) - down] of CalculateUsedBits (CriHcaEncoder.cs:583-593) by
+    two compares against thresholds found by bisection.  Both are restated here and held to the literal forms."""
+    import struct
+    # (1) every (register, byte) pair
+    crc = np.arange(65536, dtype=np.uint32)
+    for byte in range(256):
+        want = crc ^ np.uint32(byte << 8)
+        for _ in range(8):
+            want = ((want << 1) ^ np.where(want & 0x8000, 0x8005, 0).astype(np.uint32)) & 0xFFFF
+        t = ((crc >> 8) ^ byte) & 0xFF
+        par = np.zeros_like(t)
+        for b in range(8):
+            par ^= (t >> b) & 1
+        got = ((crc << 8) & 0xFFFF) ^ np.where(par == 1, 0x8003, 0).astype(np.uint32) ^ (t << 1) ^ (t << 2)
+        assert np.array_equal(want, got), byte
+    # (2) the quantiser is monotone, the code length steps up once per side
+    bits = np.array(_table_from_header("HCA_QuantizeSpectrumBits")).reshape(8, 16)
+    inv = [struct.unpack("<d", struct.pack("<Q", v))[0] for v in _table_from_header("HCA_QuantizerInverseStepSizeBits")]
+    top = 0.999999999999
+    f2b = lambda x: struct.unpack("<q", struct.pack("<d", x))[0]
+    b2f = lambda b: struct.unpack("<d", struct.pack("<q", b))[0]
+    rng = np.random.default_rng(3)
+    for r in range(1, 8):
+        up, down = inv[r] + 1.0, int(inv[r] + 0.5 - 8)
+        index_of = lambda x: int(x * inv[r] + up) - down
+        b0 = bits[r][8]
+        k = next(j for j in range(1, 9) if bits[r][8 + j] != b0)
+        assert all(bits[r][8 + j] == b0 + 1 and bits[r][8 - j] == b0 + 1 for j in range(k, r + 1)) and index_of(top) == 8 + r
+        lo, hi = 0, f2b(top)
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            lo, hi = (lo, mid) if index_of(b2f(mid)) >= 8 + k else (mid, hi)
+        tp = b2f(hi)
+        lo, hi = 0, f2b(top)
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            lo, hi = (lo, mid) if index_of(-b2f(mid)) <= 8 - k else (mid, hi)
+        tn = -b2f(hi)
+        xs = list(rng.uniform(-top, top, 20000)) + [0.0, -0.0, top, -top]
+        xs += [s * b2f(f2b(abs(t)) + d) for t, s in ((tp, 1.0), (tn, -1.0)) for d in range(-40, 41)]
+        for x in xs:
+            assert bits[r][index_of(x)] == b0 + (x >= tp) + (x <= tn), (r, x)

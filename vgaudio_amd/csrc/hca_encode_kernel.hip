@@ -29,6 +29,13 @@ namespace hca {
 
 namespace {
 
+// Timing-only builds (tools/build_variants.sh stopN:"-DVGA_HCA_ENC_STOP_AFTER=N", tools/time_hca_decode.py) leave the frame
+// loop after stage N to attribute the kernel's time; the product is built without the macro (never stops).
+#ifndef VGA_HCA_ENC_STOP_AFTER
+#define VGA_HCA_ENC_STOP_AFTER 99
+#endif
+#define ENC_STOP_AFTER(n) if (VGA_HCA_ENC_STOP_AFTER == (n)) continue
+
 constexpr int ENC_THREADS = 128;
 constexpr int MAX_ENC_FRAMES_PER_GROUP = 16;
 constexpr int RS = ROW_BYTES / 8;      // doubles between the rows of the spectra: [channel][sub-frame] rows of 128 + padding
@@ -39,9 +46,48 @@ struct EncTab {
     double inv_step[16];               // QuantizerInverseStepSize
     double dead_zone[16];              // QuantizerDeadZone (CriHcaTables.cs:68-78)
     uint8_t enc_bits[8][16], enc_value[8][16];   // QuantizeSpectrumBits / Value (index q + 8)
+    uint8_t enc_pair[8][16];                     // value << 4 | bits
     uint8_t max_bits[16];
     uint8_t res_curve[64];
+    // Resolutions 1..7: the code length of a coefficient depends on its quantised magnitude only, and steps up ONCE
+    // (QuantizeSpectrumBits: 1: |q| >= 1, 2: >= 2, 3: >= 1, 4: >= 4, 5: >= 3, 6: >= 2, 7: >= 1).  The quantiser
+    // q = (int)(x * inv + up) - down (CriHcaEncoder.cs:589-591) is non-decreasing in x -- a product with a positive
+    // constant, a sum and a truncation of a positive value are, rounding included -- so "|q| >= k" is exactly
+    // "x >= thr_pos or x <= thr_neg" for two doubles found by bisection with the quantiser's own arithmetic
+    // (threshold_init).  A band's cost at such a resolution is 8 * base_bits + the number of coefficients outside.
+    double thr_pos[8], thr_neg[8];
+    uint8_t base_bits[8];
 };
+
+// lane r = 1..7 of the first wave: the two thresholds of resolution r
+__device__ __forceinline__ void threshold_init(EncTab &T, int r)
+{
+    const double inv = f64_bits(HCA_QuantizerInverseStepSizeBits[r]);
+    const double up = inv + 1;
+    const int down = (int)(inv + 0.5 - 8);
+    const uint8_t *bits = HCA_QuantizeSpectrumBits[r];
+    const int b0 = bits[8];
+    int k = 1;
+    while (k < 8 && bits[8 + k] == b0) k++;                  // the first magnitude that costs a bit more
+    auto index_of = [&](double x) { return (int)(x * inv + up) - down; };
+    // ScaleSpectra clamps to +-0.999999999999 (:668): the largest magnitude a coefficient can have
+    const long long top = __double_as_longlong(0.999999999999);
+    long long lo = 0, hi = top;                               // idx(lo) < 8 + k <= idx(hi); doubles >= 0 order like their bits
+    while (hi - lo > 1) {
+        const long long mid = (lo + hi) / 2;
+        if (index_of(__longlong_as_double(mid)) >= 8 + k) hi = mid;
+        else lo = mid;
+    }
+    T.thr_pos[r] = __longlong_as_double(hi);
+    lo = 0, hi = top;
+    while (hi - lo > 1) {
+        const long long mid = (lo + hi) / 2;
+        if (index_of(-__longlong_as_double(mid)) <= 8 - k) hi = mid;
+        else lo = mid;
+    }
+    T.thr_neg[r] = -__longlong_as_double(hi);
+    T.base_bits[r] = (uint8_t)b0;
+}
 
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
@@ -86,14 +132,12 @@ __device__ __forceinline__ int band_cost(const EncTab &T, const double (&x)[8], 
 #pragma unroll
         for (int sf = 0; sf < 8; sf++) cost += bits + (fabs(x[sf]) >= d ? 1 : 0);
     } else {
-        const double inv = T.inv_step[res];
-        const double up = inv + 1;
-        const int down = trunc_i(inv + 0.5 - 8);
+        // QuantizeSpectrumBits[res][(int)(x * inv + up) - down] through the two thresholds (see EncTab): two compares
+        // and two carry-adds per coefficient instead of a multiply, an add, a conversion and a dependent table read
+        const double tp = T.thr_pos[res], tn = T.thr_neg[res];
+        cost = 8 * T.base_bits[res];
 #pragma unroll
-        for (int sf = 0; sf < 8; sf++) {
-            const int q = trunc_i(x[sf] * inv + up) - down;
-            cost += T.enc_bits[res][q];
-        }
+        for (int sf = 0; sf < 8; sf++) cost += (x[sf] >= tp ? 1 : 0) + (x[sf] <= tn ? 1 : 0);
     }
     return cost;
 }
@@ -224,7 +268,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     int *intensity = empty + 8;                                           // [nch][8]
     int *hfrs = intensity + 64;                                           // [nch][8]
     uint32_t *fbuf = reinterpret_cast<uint32_t *>(hfrs + 64);             // frame bits, big-endian words [fwords]
-    const int fwords = (info.frame_size + 3) / 4 + 2;
+    const int fwords = ((info.frame_size + 3) / 4 + 3) & ~1;              // even: what follows stays 8-byte aligned
     uint8_t *sfac = reinterpret_cast<uint8_t *>(fbuf + fwords);           // [nch][128] scale factors (0..63)
     uint8_t *ires = sfac + nch * 128;                                     // [nch][128] resolutions (0..15)
     __shared__ int s_coded[8], s_ctype[8];
@@ -244,7 +288,9 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         T.dead_zone[tid] = __longlong_as_double(__double_as_longlong(st / 2) - (long long)(HCA_ResolutionMaxValue[tid] + 1));
         T.max_bits[tid] = HCA_QuantizedSpectrumMaxBits[tid];
     }
+    if (tid >= 1 && tid < 8) threshold_init(T, tid);
     (&T.enc_bits[0][0])[tid] = (&HCA_QuantizeSpectrumBits[0][0])[tid];
+    (&T.enc_pair[0][0])[tid] = (uint8_t)(((&HCA_QuantizeSpectrumValue[0][0])[tid] << 4) | (&HCA_QuantizeSpectrumBits[0][0])[tid]);
     (&T.enc_value[0][0])[tid] = (&HCA_QuantizeSpectrumValue[0][0])[tid];
     if (tid < 8) {
         int cc = 0, ct = 0;
@@ -302,33 +348,59 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         if (lo) atomicOr(&fbuf[(off >> 5) + 1], lo);
     };
 
+    // A frame's input: 9 x 128 samples per channel (its 1024 and the 128 before them), staged in LDS as int16 in the region
+    // the cost tables and the small arrays use later in the frame.  Up to two channels a lane fetches sample tid + 128 k of
+    // both channels (k = 0..8), packed into nine registers -- and does so for the NEXT frame while this frame's bit
+    // allocation and packing run, so that the HBM latency is off the frame's critical path.
+    int16_t *xin = reinterpret_cast<int16_t *>(costs);                        // [nch][9 * 128]
+    const int16_t *spcm = pcm + (int64_t)stream * stream_pitch;
+    // 9 x 128 int16 per channel = 576 dwords; lane `tid` moves dwords tid + 128 k of the [channel][576] array (k = 0..8 for
+    // two channels, 0..4 for one): nine independent dword loads, nine registers, nothing to unpack
+    uint32_t pk[9];
+    bool pk_valid = false;
+    auto prefetch = [&](int frame) __attribute__((always_inline)) {
+        const int64_t u0 = (int64_t)frame * SPF - SPSF;                        // stream index of the overlap's first sample
+        // only when the whole window lies inside the caller's PCM (every frame but a stream's first and last few) and
+        // starts on a dword: straight-line loads.  Other frames go through the stream map at the top of their iteration.
+        const int64_t first = u0 - map.pre_end;
+        pk_valid = small && u0 >= map.pre_end && u0 + SPF + SPSF <= map.main_end && ((first | ch_pitch) & 1) == 0 &&
+                   (reinterpret_cast<uintptr_t>(spcm) & 3) == 0;
+        if (pk_valid) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int d = tid + 128 * k;                                   // dword of the [nch][576] array
+                if (d < nch * 576) {
+                    const int c = d >= 576 ? 1 : 0;
+                    pk[k] = *reinterpret_cast<const uint32_t *>(spcm + (int64_t)c * ch_pitch + first + 2 * (d - 576 * c));
+                }
+            }
+        }
+    };
+    prefetch(f0);
+
     for (int frame = f0; frame < f1; frame++) {
         __syncthreads();                                   // the previous frame is stored; T / s_coded are written
-        for (int i = tid; i < fwords; i += ENC_THREADS) fbuf[i] = 0;
+        if (pk_valid) {
+#pragma unroll
+            for (int k = 0; k < 9; k++)
+                if (tid + 128 * k < nch * 576) reinterpret_cast<uint32_t *>(xin)[tid + 128 * k] = pk[k];
+        } else {
+            const int64_t u0 = (int64_t)frame * SPF - SPSF;
+            for (int i = tid; i < nch * 9 * 128; i += ENC_THREADS)
+                xin[i] = fetch_pcm(map, spcm + (int64_t)(i / (9 * 128)) * ch_pitch, u0 + i % (9 * 128));
+        }
+        __syncthreads();
 
         // ---- PcmToFloat (:845-858) + the fold of RunMdct (Mdct.cs:78-89), straight into the transform's input layout
         {
-            const int64_t u0 = (int64_t)frame * SPF - SPSF;                    // stream index of the overlap's first sample
-            // the whole window inside the caller's PCM (every frame but a stream's first and last few): plain loads
-            const bool plain = u0 >= map.pre_end && u0 + SPF + SPSF <= map.main_end;
             constexpr double KQ = 1.0 / 32768.0;
             for (int item = tid >> 6; item < nch * 8; item += ENC_THREADS / 64) {
                 const int c = item >> 3, sf = item & 7;
-                const int16_t *src = pcm + (int64_t)stream * stream_pitch + (int64_t)c * ch_pitch;
-                const int64_t up = u0 + sf * SPSF, ui = up + SPSF;             // previous sub-frame, this sub-frame
-                int x_in_hi, x_in_lo, x_pv_lo, x_pv_hi;
-                if (plain) {
-                    const int16_t *p = src + (up - map.pre_end);
-                    x_pv_lo = p[wi];
-                    x_pv_hi = p[127 - wi];
-                    x_in_lo = p[SPSF + 63 - wi];
-                    x_in_hi = p[SPSF + 64 + wi];
-                } else {
-                    x_pv_lo = fetch_pcm(map, src, up + wi);
-                    x_pv_hi = fetch_pcm(map, src, up + 127 - wi);
-                    x_in_lo = fetch_pcm(map, src, ui + 63 - wi);
-                    x_in_hi = fetch_pcm(map, src, ui + 64 + wi);
-                }
+                const int16_t *p = xin + c * (9 * 128) + sf * SPSF;            // previous sub-frame, then this sub-frame
+                const int x_pv_lo = p[wi];
+                const int x_pv_hi = p[127 - wi];
+                const int x_in_lo = p[SPSF + 63 - wi];
+                const int x_in_hi = p[SPSF + 64 + wi];
                 const double a = w_a * -(x_in_hi * KQ);
                 const double b = w_b * (x_in_lo * KQ);
                 const double cc = w_c * (x_pv_lo * KQ);
@@ -339,6 +411,8 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
             }
         }
         __syncthreads();
+        for (int i = tid; i < fwords; i += ENC_THREADS) fbuf[i] = 0;           // (the staged samples may have covered it)
+        ENC_STOP_AFTER(1);
         // ---- Dct4 (Mdct.cs:126-181): 8 lanes per transform, in place; the output is the row's first 128 doubles
         for (int row = tid >> 3; row < nch * 8; row += ENC_THREADS / 8) {
             char *r = reinterpret_cast<char *>(spectra + (size_t)row * RS);
@@ -354,6 +428,8 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
             dct_store(r, out_bases, y);
         }
         __syncthreads();
+        if (frame + 1 < f1) prefetch(frame + 1);           // lands while this frame is allocated and packed
+        ENC_STOP_AFTER(2);
 
         // ---- EncodeIntensityStereo (:711-764)
         if (info.stereo_band_count > 0) {
@@ -430,6 +506,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
             }
         }
         __syncthreads();
+        ENC_STOP_AFTER(3);
 
         // ---- CalculateHfrGroupAverages (:766-793) + CalculateHfrScale (:795-832)
         if (info.hfr_group_count > 0) {
@@ -543,6 +620,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
             __syncthreads();
         };
         header_lengths_fast();
+        ENC_STOP_AFTER(4);
 
         // ---- CalculateUsedBits (:554-597), block-wide (more than two channels, or after bands were dropped)
         auto used_bits = [&](int noise_level, int eval_boundary) __attribute__((always_inline)) -> int {
@@ -656,6 +734,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
                 }
             }
         }
+        ENC_STOP_AFTER(5);
         if (boundary < 0) {                   // NotImplementedException in the reference
             if (tid == 0 && status) atomicOr(status, 8);
             boundary = 0;
@@ -712,6 +791,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
             }
         }
         __syncthreads();                               // ires is complete
+        ENC_STOP_AFTER(6);
         // WriteSpectra (:238-260) in (sub-frame, channel, band) order: slot = (sf * nch + c) * 128 + band;
         // QuantizeSpectra (:420-439) on the fly.  A lane owns nch * 8 consecutive slots; 8 nch divides 128 for 1, 2, 4
         // and 8 channels, otherwise a lane's slots run on into the next channel's row.
@@ -751,18 +831,32 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
                     if (q != 0) { code = (code << 1) | (q > 0 ? 0u : 1u); nbits++; }
                 }
             };
-            if (per_thread <= 16) {                        // up to two channels: the codes stay in registers (13 + 4 bits each)
+            if (per_thread <= 16) {
+                // up to two channels: a lane's 8 or 16 slots are consecutive bands of one (sub-frame, channel) row; their
+                // resolutions arrive as one or two 64-bit LDS reads and the codes stay in registers (13 + 4 bits each).
+                // The quantiser's constants need no table: QuantizerInverseStepSize[r] = ResolutionMaxValue[r] + 0.5
+                // (CriHcaTables.cs:57), so inv = max + 0.5, shiftUp = inv + 1, shiftDown = (int)(inv + 0.5) = max + 1,
+                // and QuantizedSpectrumMaxBits[r] = r - 3 from resolution 8 on.
+                const double *xs = spectra + ((size_t)w_c * 8 + w_sf) * RS + w_band;
+                const uint64_t *rs = reinterpret_cast<const uint64_t *>(ires + w_c * 128 + w_band);
+                const uint64_t res_lo = rs[0], res_hi = per_thread > 8 ? rs[1] : 0;
                 unsigned packed[16];
                 int local = 0;
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     packed[k] = 0;
                     if (k < per_thread) {
-                        unsigned code;
-                        int nbits;
-                        code_of(code, nbits);
-                        packed[k] = (code << 4) | (unsigned)nbits;
-                        local += nbits;
+                        const int res = (int)(((k < 8 ? res_lo : res_hi) >> (8 * (k & 7))) & 0xFFu);
+                        const int maxv = res < 8 ? res : (1 << (res - 4)) - 1;
+                        const double inv = (double)maxv + 0.5;
+                        const int q = trunc_i(xs[k] * inv + (inv + 1)) - (maxv + 1);
+                        const unsigned small_pair = T.enc_pair[min(res, 7)][(q + 8) & 15];   // value << 4 | bits
+                        const unsigned mag = (unsigned)abs(q);
+                        const unsigned large_pair = q != 0 ? ((((mag << 1) | (q > 0 ? 0u : 1u)) << 4) | (unsigned)(res - 3))
+                                                           : (unsigned)(res - 4);
+                        const unsigned pair = res == 0 ? 0u : (res < 8 ? small_pair : large_pair);
+                        packed[k] = pair;
+                        local += (int)(pair & 15u);
                     }
                 }
                 const int off = header_bits + block_exclusive_scan(local);
@@ -794,6 +888,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
             }
         }
         __syncthreads();
+        ENC_STOP_AFTER(7);
 
         // ---- WriteChecksum (:231-236): CRC-16 (poly 0x8005, init 0) over the first frame_size-2 bytes
         {
@@ -803,9 +898,11 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
             unsigned crc = 0;
             for (int i = begin; i < end; i++) {
                 const unsigned byte = (fbuf[i >> 2] >> (24 - 8 * (i & 3))) & 0xFFu;
-                crc ^= byte << 8;
-#pragma unroll
-                for (int j = 0; j < 8; j++) crc = ((crc << 1) ^ ((crc & 0x8000u) ? 0x8005u : 0u)) & 0xFFFFu;
+                // eight shift-and-xor steps of x^16 + x^15 + x^2 + 1 at once: with t = the byte entering the register,
+                // t * x^16 mod P = t << 1 ^ t << 2 ^ (parity(t) ? 0x8003 : 0)   (checked against the bitwise form
+                // for every (crc, byte) pair: tests/test_oracle_hca.py)
+                const unsigned t = ((crc >> 8) ^ byte) & 0xFFu;
+                crc = ((crc << 8) & 0xFFFFu) ^ ((__popc(t) & 1) ? 0x8003u : 0u) ^ (t << 1) ^ (t << 2);
             }
             unsigned part = (begin < end) ? gf_mul(crc, crc_pow[nbytes - end]) : 0u;
             part = (unsigned)wave_xor((int)part);
@@ -819,6 +916,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
             }
             __syncthreads();
         }
+        ENC_STOP_AFTER(8);
 
         // ---- store the frame: whole aligned dwords (the frame starts at any byte: its k-th dword is a funnel shift of two
         // big-endian words of fbuf), the few bytes before the first and after the last aligned dword one by one
@@ -850,7 +948,7 @@ int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, 
     const int nch = info.nch;
     const size_t doubles = (size_t)nch * 8 * RS + (size_t)nch * 16;
     const size_t ints = 32 + 8 + 8 + 64 + 8 + 64 + 64;
-    const size_t lds = doubles * 8 + (size_t)nch * 128 * 16 + ints * 4 + ((size_t)(info.frame_size + 3) / 4 + 2) * 4 + (size_t)nch * 256;
+    const size_t lds = doubles * 8 + (size_t)nch * 128 * 16 + ints * 4 + (size_t)((((info.frame_size + 3) / 4 + 3) & ~1) * 4) + (size_t)nch * 256;
     if (lds > 32 * 1024) VGA_HIP_TRY(allow_dynamic_lds(hca_encode_kernel, lds));
     // frames per workgroup: long runs amortise the per-workgroup set-up (tables, twiddles), short ones keep small inputs
     // spread over the chip
