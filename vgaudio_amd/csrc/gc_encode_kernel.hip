@@ -713,6 +713,69 @@ __device__ __forceinline__ void seam_run(const int16_t *__restrict__ src, uint8_
     }
 }
 
+// The zero-padded partial last frame of a stream (GcAdpcmEncoder.cs:32-38) from the true history (h0, h1), by the eight
+// lanes of a channel exactly as seam_run encodes a frame; SampleCountToByteCount(tail) bytes are stored.  For the chain
+// kernel: a run that is still apart at the very end of the stream has only this frame left to correct.
+__device__ __forceinline__ void encode_tail_frame(const int16_t *__restrict__ src, uint8_t *__restrict__ dst, int c0, int c1,
+                                                  bool coef_ok, int pr, int total_samples, int h0, int h1, bool act)
+{
+    const int full_frames = total_samples / 14, tail = total_samples - full_frames * 14;
+    int x[16], m[14], mp[14];
+    x[0] = h0;
+    x[1] = h1;
+#pragma unroll
+    for (int i = 0; i < 14; i++) x[2 + i] = i < tail ? (int)src[(int64_t)full_frames * 14 + i] : 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        m[i] = x[2 + i] * 2048;
+        mp[i] = m[i] + 1024;
+    }
+    int s1;
+    {
+        int dmax = 0, dmin = 0;
+        prescan_range(x, c0, c1, 0, 14, dmax, dmin);
+        s1 = first_scale_power_from_range(dmax, dmin);
+        if (s1 == -100) s1 = first_scale_power_from_md(prescan_sequential(x, c0, c1));
+    }
+    const int sp_a = imin(s1, 12), sp_b = imin(s1 + 1, 12);
+    const PassOut rb = pass_fast_core(x, m, mp, c0, c1, sp_b);
+    const PassOut ra = pass_fast_core(x, m, mp, c0, c1, sp_a);
+    const bool cap_a = sp_a >= 12, cap_b = sp_b >= 12;
+    const bool rare = !coef_ok || (unsigned)ra.max_overflow > (cap_a ? 3u : 248u) || (unsigned)rb.max_overflow > (cap_b ? 3u : 248u);
+    const int eff_a = cap_a ? 0 : ra.max_overflow, eff_b = cap_b ? 0 : rb.max_overflow;
+    const bool fin_a = eff_a < 2;
+    const bool resume = !fin_a && eff_b >= 2;
+    PassOut r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.q[i] = fin_a ? ra.q[i] : rb.q[i];
+    r.total = fin_a ? ra.total : rb.total;
+    int final_sp = fin_a ? sp_a : sp_b;
+    if (rare || resume) {
+        const PassOut rc = resume_passes(x, c0, c1, rare ? s1 - 1 : s1 + 1, final_sp);
+#pragma unroll
+        for (int i = 0; i < 14; i++) r.q[i] = rc.q[i];
+        r.total = rc.total;
+    }
+    uint64_t key = act ? ((r.total << 3) | (uint64_t)pr) : ~0ull;
+#define VGA_MIN64_STAGE(CTRL)                                                          \
+    {                                                                                  \
+        const unsigned olo = (unsigned)dpp<CTRL>((int)(uint32_t)key);                  \
+        const unsigned ohi = (unsigned)dpp<CTRL>((int)(uint32_t)(key >> 32));          \
+        const uint64_t okey = ((uint64_t)ohi << 32) | olo;                             \
+        key = okey < key ? okey : key;                                                 \
+    }
+    VGA_MIN64_STAGE(DPP_QUAD_XOR1)
+    VGA_MIN64_STAGE(DPP_QUAD_XOR2)
+    VGA_MIN64_STAGE(DPP_ROW_HALF_MIRROR)
+#undef VGA_MIN64_STAGE
+    if (act && pr == (int)(key & 7u)) {
+        uint32_t d0, d1;
+        pack_frame(r.q, pr, final_sp, d0, d1);
+        const int nibbles = tail + 2;                                   // SampleCountToNibbleCount of the tail (GcAdpcmMath.cs:24-30)
+        store_frame_bytes(dst + (int64_t)full_frames * 8, d0, d1, nibbles / 2 + (nibbles & 1));
+    }
+}
+
 // All seams at once, each from the history the piece before ended on (seg_state: the real one provided THAT piece's own
 // seam closes).  A seam still open at the end of its piece leaves a flag and the true history it arrived at
 // (seam_flag / seam_end) and its index in first_open[channel]: gc_encode_chain_kernel carries on from there.
@@ -809,11 +872,20 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
         } else
             have = false;
     }
-    // apart to the very end: only a partial last frame is left to encode from V
-    if (live && pr == 0) first_open[ch] = (have && total_samples % 14 != 0) ? last_k : 0x7f7f7f7f;
+    // apart to the very end: only the partial last frame is left to encode from V -- here, by the channel's eight lanes (the
+    // serial repair launch that used to take over re-ran the whole last piece: 4.9 ms of a 256-channel encode's 31)
+    if (total_samples % 14 != 0 && __any(live && have))
+        encode_tail_frame(src, dst, c0, c1, coef_ok, pr, total_samples, v0, v1, live && have);
+    (void)last_k;
+    if (live && pr == 0) first_open[ch] = 0x7f7f7f7f;
 }
 
-constexpr int MIN_PIECE_FRAMES = 512;
+// A piece must be longer than the slowest seam of the batch takes to close, or that channel's seams all stay open and the
+// chain kernel ends up walking the whole channel serially: channels 64..95 of the synthetic set hold one whose seams need
+// ~3000 frames (profiles/r03_b_encode_pieces.log: 96 channels x 60 s in 20.9 ms with 64 pieces of 3214 frames, 60.8 ms
+// with 128, 150 ms with 256; without such a channel more pieces only help: 64 channels 6.7 / 5.5 / 4.0 ms).  Round 2 cut
+// pieces down to 512 frames.
+constexpr int MIN_PIECE_FRAMES = 3072;
 
 template <int CPW>
 static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
@@ -822,8 +894,9 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
 {
     constexpr int CS = Lay<CPW>::CS;
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
-    // one encoder wave per SIMD fills the chip: fewer channels than that are cut into time pieces (each at least 512
-    // frames: a seam re-encodes a few dozen as a rule; the ones that take longer than their piece go to the chain launch)
+    // two encoder waves per SIMD fill the chip: fewer channels than that are cut into time pieces (each at least
+    // MIN_PIECE_FRAMES frames: a seam re-encodes a few dozen as a rule; the ones that take longer than their piece go to
+    // the chain launch)
     const int groups = (nch + CS - 1) / CS;
     const int cus = device_cu_count();
     const int frames = (sample_count + 13) / 14;

@@ -104,9 +104,11 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     // 192 / 256 / 320 / 384 / 448 / 512 of 1024: 555 / 545 / 539 / 519 / 528 / 529 ms; halving down to 1/8: 533 ms --
     // short chunks that overlap slow each other down)
     job.tail_units = in_total + out_total >= ((size_t)256 << 20) ? std::max(1, job.chunk_units * 3 / 8) : 0;   // small calls: one chunk
-    // ... and the first chunk is a quarter of a chunk: nothing can compute before the first chunk has arrived (4096 x 60 s:
-    // the first kernel started 115 ms into a 526 ms call)
-    job.head_units = (o.chunk_units <= 0 && in_total + out_total >= ((size_t)1 << 30)) ? std::max(1, job.chunk_units / 4) : 0;
+    // A short FIRST chunk (job.head_units: a quarter chunk starts the first kernel 29 ms instead of 115 ms into a
+    // 4096 x 60 s call) was measured and is not used: the call is bound by its upload (461 of ~530 ms) and ends one short
+    // chunk's kernels + download after it, whenever the first kernel started (profiles/r03_b_pipeline_timeline_head_chunk.log:
+    // 539 and 550 ms against 518-538 ms without).
+    job.head_units = 0;
     const pipe::Result r = pipe::run(job);
     pipe_report().stats = r.stats;
     if (r.code) {
