@@ -182,6 +182,17 @@ def test_hca_find_key_matches_oracle():
     bad[1, 0] = 0x12
     with pytest.raises(vgaudio_amd.InvalidDataError):
         CriHcaEncryption.FindKey(fmt.Hca, bad, keys)
+    # TestKey walks a key's frames in order and FindKey the keys in order (CriHcaEncryption.cs:34-63): a wrong sync word
+    # in frame 2 throws only for a key that gets that far.  Wrong keys are rejected at their first frame, so a list
+    # without the right key yields null; the right key throws; a key placed before it that unpacks everything wins first.
+    bad = enc.copy()
+    bad[2, 0] = 0x00                                    # 0x00 and 0xFF are fixed points of every substitution table
+    others = keys[:true] + keys[true + 1:]
+    assert po.hca_find_key(info, bad, np.stack([k.DecryptionTable for k in others])) == -1
+    assert CriHcaEncryption.FindKey(fmt.Hca, bad, others) is None
+    assert po.hca_find_key(info, bad, tables) == -3
+    with pytest.raises(vgaudio_amd.InvalidDataError):
+        CriHcaEncryption.FindKey(fmt.Hca, bad, keys)
 
 
 def test_hca_find_key_random_frames_agree_with_oracle():

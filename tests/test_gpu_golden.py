@@ -107,3 +107,26 @@ def test_hca_golden_vectors(vec):
         assert bad.size == 0, (case["name"], bad[0].tolist(), len(bad))
         dec = CriHcaDecoder.Decode(fmt.Hca, want)
         assert np.array_equal(np.stack(dec), arrays[f"hca_{case['name']}_decoded"]), case["name"]
+
+
+def test_full_length_digests_of_one_channel_and_one_stream():
+    """60 s of audio (2 880 000 samples: 205 714 GC frames, 90 000 ADX frames, 2 813 HCA frames) through every codec, against
+    digests both restatements agreed on (tests/golden/make_full_length_digests.py): channel 0 of configs[1] and configs[2],
+    stream 0 of configs[3]."""
+    d = json.load(open(os.path.join(GOLD, "full_length_digests.json")))
+    n = d["sample_count"]
+    x = synth.generate(2, n)
+    assert _sha(x[0]) == d["gc"]["input_sha256"] and _sha(x) == d["hca"]["input_sha256"]
+    coefs = GcAdpcmCoefficients.CalculateCoefficients(x[0])
+    assert [int(v) for v in coefs] == d["gc"]["coefs"]
+    adpcm = GcAdpcmEncoder.Encode(x[0], coefs)
+    assert _sha(adpcm) == d["gc"]["adpcm_sha256"]
+    assert _sha(GcAdpcmDecoder.Decode(adpcm, coefs, GcAdpcmParameters(SampleCount=n))) == d["gc"]["decoded_sha256"]
+    cfg = CriAdxParameters()
+    bytes_ = CriAdxCodec.Encode(x[0], cfg)
+    assert _sha(bytes_) == d["adx"]["bytes_sha256"] and int(cfg.History) == d["adx"]["history"]
+    assert _sha(CriAdxCodec.Decode(bytes_, n, CriAdxParameters())) == d["adx"]["decoded_sha256"]
+    fmt = CriHcaFormat().EncodeFromPcm16(Pcm16Format(list(x), 48000), CriHcaParameters())
+    assert fmt.AudioData.shape == (d["hca"]["frame_count"], d["hca"]["frame_size"]) and _sha(fmt.AudioData) == d["hca"]["frames_sha256"]
+    dec = CriHcaDecoder.Decode(fmt.Hca, fmt.AudioData)
+    assert _sha(np.stack(dec).astype(np.int16)) == d["hca"]["decoded_sha256"]

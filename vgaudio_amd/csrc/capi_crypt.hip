@@ -381,9 +381,13 @@ int vga_hca_find_key_device(const vga_hca_info *h, const uint8_t *d_frames, int 
     VGA_HIP_TRY(hipMemcpyAsync(valid.data(), d_valid.p, (size_t)nkeys * sizeof(int), hipMemcpyDeviceToHost, s));
     VGA_HIP_TRY(hipMemcpyAsync(&flags, d_small.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     VGA_HIP_TRY(hipStreamSynchronize(s));
-    if (flags & 1) { set_error("Invalid frame header"); return VGA_ERR_INVALID_DATA; }
-    for (int i = 0; i < nkeys; i++)
-        if (valid[i]) { *index_out = i; break; }
+    (void)flags;
+    // keys in the caller's order, as the reference tries them: the first that unpacks wins; one that meets a wrong sync
+    // word before its first unpack failure is where the reference throws -- unless an earlier key had already won
+    for (int i = 0; i < nkeys; i++) {
+        if (valid[i] == 2) { set_error("Invalid frame header"); return VGA_ERR_INVALID_DATA; }
+        if (valid[i] == 1) { *index_out = i; break; }
+    }
     return VGA_OK;
 }
 

@@ -166,8 +166,11 @@ __global__ __launch_bounds__(256) void adx_guess_keys_kernel(
 // One workgroup per candidate key, one lane per tested frame (at most FramesToTest = 10): the frame is decrypted on the
 // fly (substitution table in LDS, the CRC CryptFrame refreshes is computed for the last two bytes) and walked with
 // CriHcaPacking.UnpackFrame's bit reader for validity only (UnpackFrameHeader / DeltaDecode failures,
-// UnpackingWasSuccessful; CriHcaPacking.cs:10-15, :71-237).  valid[key] = 1 when every tested frame unpacks.
-// flags[0] |= 1 when a frame's sync word is wrong (the reference throws InvalidDataException).
+// UnpackingWasSuccessful; CriHcaPacking.cs:10-15, :71-237).  The reference tests a key's frames ONE AFTER THE OTHER and
+// stops at the first that does not unpack; a wrong sync word throws InvalidDataException out of the whole search.  The
+// lanes test all frames at once and the outcome is put back in order: valid[key] = 1 when every tested frame unpacks,
+// 2 when a frame with a wrong sync word comes before the first frame that fails to unpack (the reference throws while
+// testing this key), 0 otherwise (rejected at its first failing frame; what later frames hold is never looked at).
 struct HcaTestReader {
     const uint8_t *frame;
     const uint8_t *sub;
@@ -201,11 +204,11 @@ __global__ __launch_bounds__(64) void hca_test_keys_kernel(
 {
     __shared__ hca::DecTables T;
     __shared__ uint8_t sub[256];
-    __shared__ int ok_all;
+    __shared__ int first_fail, first_bad_sync;               // lowest tested frame that fails to unpack / has a wrong sync word
     const int lane = threadIdx.x;
     hca::load_tables(T, lane, 64);
     for (int i = lane; i < 256; i += 64) sub[i] = tables[(size_t)blockIdx.x * 256 + i];
-    if (lane == 0) ok_all = 1;
+    if (lane == 0) { first_fail = 64; first_bad_sync = 64; }
     __syncthreads();
     bool ok = true;
     if (lane < ntest) {
@@ -222,7 +225,8 @@ __global__ __launch_bounds__(64) void hca_test_keys_kernel(
             for (int j = 0; j < 8; j++) crc = ((crc << 1) ^ ((crc & 0x8000u) ? 0x8005u : 0u)) & 0xFFFFu;
         }
         r.crc = crc;
-        if (r.read(16) != 0xffff) { atomicOr(flags, 1); ok = false; }
+        const bool bad_sync = r.read(16) != 0xffff;
+        if (bad_sync) { atomicMin(&first_bad_sync, lane); ok = false; }
         const int noise_level = r.read(9);
         const int eval_boundary = r.read(7);
         bool any_delta_bits = false;
@@ -269,10 +273,14 @@ __global__ __launch_bounds__(64) void hca_test_keys_kernel(
             const bool empty = noise_level <= 0 && !any_delta_bits;
             ok = (remaining >= 16 && remaining <= 128) || empty || (noise_level == 0 && remaining >= 16);
         }
-        if (!ok) atomicAnd(&ok_all, 0);
+        if (!ok && !bad_sync) atomicMin(&first_fail, lane);
     }
     __syncthreads();
-    if (lane == 0) valid[blockIdx.x] = ok_all;
+    if (lane == 0) {
+        const int outcome = first_bad_sync < first_fail ? 2 : (first_fail < 64 ? 0 : 1);
+        valid[blockIdx.x] = outcome;
+        if (outcome == 2) atomicOr(flags, 1);
+    }
 }
 
 // FindFirstNonEmptyFrame (CriHcaEncryption.cs:65-88): smallest frame index with a non-zero byte in [2, size - 2)
