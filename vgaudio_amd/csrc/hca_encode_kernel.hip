@@ -142,16 +142,51 @@ __device__ __forceinline__ int band_cost(const EncTab &T, const double (&x)[8], 
     return cost;
 }
 
-// All sixteen costs of one band (each <= 8 * 12 bits: a byte), resolution by resolution with the resolution a
-// compile-time constant: the binary searches below only look costs up.
+// All sixteen costs of one band (each <= 8 * 12 bits: a byte; band_cost above is the same thing one resolution at a time,
+// kept for the block-wide fall-back).  A band's cost at resolution r is a constant (8 x the base length) plus the NUMBER of
+// its coefficients beyond the threshold(s): the table is two 64-bit constants plus fifteen byte-wide counts, each count
+// eight (or sixteen) compare + carry-add pairs against thresholds fetched up front -- first the fourteen of resolutions
+// 1..7, then the eight dead zones (all 22 at once, next to the band's coefficients, do not fit the 168 VGPRs three waves
+// per SIMD allow).  No byte can carry: a cost is at most 96.
 __device__ __forceinline__ uint4 band_cost_table(const EncTab &T, const double (&x)[8])
 {
-    // (rolled loops: unrolled, hipcc keeps the constants of all sixteen resolutions live at once -- 250 VGPRs)
     uint64_t lo = 0, hi = 0;
-#pragma unroll 1
-    for (int r = 1; r < 8; r++) lo |= (uint64_t)band_cost(T, x, r) << (8 * r);       // resolution 0 costs nothing
-#pragma unroll 1
-    for (int r = 8; r < 16; r++) hi |= (uint64_t)band_cost(T, x, r) << (8 * (r - 8));
+    {
+        double tp[8], tn[8];
+        uint64_t base = 0;
+#pragma unroll
+        for (int r = 1; r < 8; r++) {                          // resolution 0 costs nothing
+            tp[r] = T.thr_pos[r];
+            tn[r] = T.thr_neg[r];
+            base |= (uint64_t)(8 * T.base_bits[r]) << (8 * r);
+        }
+#pragma unroll
+        for (int r = 1; r < 8; r++) {
+            int cnt = 0;
+#pragma unroll
+            for (int sf = 0; sf < 8; sf++) cnt += (x[sf] >= tp[r] ? 1 : 0) + (x[sf] <= tn[r] ? 1 : 0);
+            lo |= (uint64_t)cnt << (8 * r);
+        }
+        lo += base;
+    }
+    asm volatile("" ::: "memory");                             // the second half's loads stay behind the first half
+    {
+        double dz[8];
+        uint64_t base = 0;
+#pragma unroll
+        for (int r = 8; r < 16; r++) {
+            dz[r - 8] = T.dead_zone[r];
+            base |= (uint64_t)(8 * (T.max_bits[r] - 1)) << (8 * (r - 8));
+        }
+#pragma unroll
+        for (int r = 8; r < 16; r++) {
+            int cnt = 0;
+#pragma unroll
+            for (int sf = 0; sf < 8; sf++) cnt += fabs(x[sf]) >= dz[r - 8] ? 1 : 0;
+            hi |= (uint64_t)cnt << (8 * (r - 8));
+        }
+        hi += base;
+    }
     return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
 
