@@ -22,7 +22,8 @@ int vga_testing_force_open_seams_this_thread(int mode);
  * the same bytes.  Returns the previous value; other arguments leave it unchanged. */
 int vga_testing_gc_encoder_layout_this_thread(int channels_per_wave);
 /* GC-ADPCM coefficient-search kernel for calls made from the calling thread: 0 = the launcher's choice by channel count
- * (the product), 1 = one wave per channel, 2 = workgroups of four channels and a summing wave.  Same coefficients.
+ * (the product), 1 = one wave per channel, 2 = workgroups of four channels and a summing wave, 3 = the same five waves on
+ * one channel (the choice for small batches).  Same coefficients.
  * Returns the previous value; other arguments leave it unchanged. */
 int vga_testing_gc_coefs_variant_this_thread(int variant);
 /* Forces the number of time pieces a channel is cut into by the kernels that speculate over time -- the GC-ADPCM and ADX

@@ -418,7 +418,7 @@ def test_encoder_layouts_and_piece_counts_give_the_same_bytes():
         L.vga_testing_gc_encoder_segments_this_thread(0)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_all_coefficient_kernels_match_the_oracle(variant):
     """0 = the launcher's choice, 1 = one wave per channel, 2 = four channels + a summing wave per workgroup: the ordered
     f64 sums must come out the same in all, on channel counts that fill no workgroup and on the edge inputs."""

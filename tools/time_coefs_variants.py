@@ -26,7 +26,7 @@ def main():
         ws = torch.empty(max(L.vga_gcadpcm_coefs_workspace_bytes(nch, n), 16), dtype=torch.uint8, device=dev)
         out = {}
         res = {}
-        for variant in (1, 2, 0):
+        for variant in (1, 2, 3, 0):
             L.vga_testing_gc_coefs_variant_this_thread(variant)
             for _ in range(2):
                 c = vdev.gc_coefs(pcm, n, workspace=ws)
@@ -40,8 +40,10 @@ def main():
             res[variant] = c.clone()
         L.vga_testing_gc_coefs_variant_this_thread(0)
         print(json.dumps({"channels": nch, "samples": n, "one_wave_per_channel_ms": out[1],
-                          "four_channels_and_summing_wave_ms": out[2], "launcher_choice_ms": out[0],
-                          "same_coefficients": bool(torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]))}), flush=True)
+                          "four_channels_and_summing_wave_ms": out[2], "five_waves_on_one_channel_ms": out[3],
+                          "launcher_choice_ms": out[0],
+                          "same_coefficients": bool(torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]) and
+                                                    torch.equal(res[0], res[3]))}), flush=True)
         del pcm, ws
 
 

@@ -154,7 +154,7 @@ int vga_testing_gc_encoder_layout_this_thread(int channels_per_wave)
 int vga_testing_gc_coefs_variant_this_thread(int variant)
 {
     const int old = g_coefs_variant;
-    if (variant >= 0 && variant <= 2) g_coefs_variant = variant;
+    if (variant >= 0 && variant <= 3) g_coefs_variant = variant;
     return old;
 }
 int vga_testing_gc_encoder_segments_this_thread(int segments)

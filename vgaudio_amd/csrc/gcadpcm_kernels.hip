@@ -547,9 +547,16 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
 // (double-buffered LDS, one LDS-only barrier per chunk); it also owns the per-pass codebook updates.  Measured at
 // 4096 x 60 s: 14.0 G VALU wave-instructions instead of 16.3 G, but the five waves of a workgroup move in lockstep and
 // wait more (SQ_WAIT_ANY 40 % of the wave-cycles instead of 31 %): 43.0 ms against 41.6.
-constexpr int COEF_CW = 4;                                  // channels per workgroup
+//
+// SOLO (round 3): the same five waves on ONE channel.  One wave per channel makes a lone 60 s channel wait 15.6 ms for its
+// coefficients (205 714 frames x seven passes down one wave's dependent chain) -- the latency floor of every small batch
+// and of the host pipeline's last chunk.  In this mode record wave w takes chunks 4 r + w of round r, and the summing
+// wave adds the four chunks of the previous round IN CHUNK ORDER on its first sixteen lanes (bucket, component): the
+// order of every f64 addition is the reference's, only the records / nearest-codeword work runs four chunks wide.
+constexpr int COEF_CW = 4;                                  // record waves per workgroup (= channels unless SOLO)
 constexpr int COEF_THREADS = (COEF_CW + 1) * 64;
 
+template <bool SOLO>
 __global__ __launch_bounds__(COEF_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void gc_coefs_kernel4(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int length,
     double2 *__restrict__ records, int16_t *__restrict__ coefs_out)
@@ -562,30 +569,44 @@ __global__ __launch_bounds__(COEF_THREADS) __attribute__((amdgpu_waves_per_eu(5,
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool summer = wave == COEF_CW;
-    const int cs = summer ? 0 : wave;                              // this record wave's channel slot
-    const int ch_raw = blockIdx.x * COEF_CW + cs;
+    const int ws = summer ? 0 : wave;                              // this record wave's LDS slot (chunk hand-over)
+    const int cs = SOLO ? 0 : ws;                                  // ... and its channel slot (codebooks)
+    const int ch_raw = SOLO ? (int)blockIdx.x : (int)blockIdx.x * COEF_CW + cs;
     const bool live = !summer && ch_raw < nch;
     const int ch = ch_raw < nch ? ch_raw : nch - 1;
     const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
     const int frames = (length + 13) / 14;
     const int chunks = (frames + 63) / 64;
+    // a record wave's chunks: c = round (four channels), c = 4 round + wave (SOLO)
+    const int rounds = SOLO ? (chunks + COEF_CW - 1) / COEF_CW : chunks;
+    const int cstep = SOLO ? COEF_CW : 1, cfirst = SOLO ? ws : 0;
     double2 *rec = records + (int64_t)ch * frames;
-    // summing-wave lane = (channel slot, bucket, component)
+    // summing-wave lane = (channel slot, bucket, component); SOLO: the sixteen lanes of slot 0 carry the one channel
     const int sc = lane >> 4, sb = (lane >> 1) & 7, sk = lane & 1;
 
     auto zero_fill = [&](int par) {
-        reinterpret_cast<double2 *>(&s_d[cs][par][0][0])[lane] = make_double2(0.0, 0.0);
-        reinterpret_cast<double2 *>(&s_d[cs][par][1][0])[lane] = make_double2(0.0, 0.0);
+        reinterpret_cast<double2 *>(&s_d[ws][par][0][0])[lane] = make_double2(0.0, 0.0);
+        reinterpret_cast<double2 *>(&s_d[ws][par][1][0])[lane] = make_double2(0.0, 0.0);
     };
     double acc = 0.0;                                              // summing wave: this lane's chain
     int cnt = 0;
-    // the summing wave's share of one chunk: buckets < nb take part
+    // the summing wave's share of one round: buckets < nb take part
     auto sum_chunk = [&](int par, int nb) {
-        const int meta = s_meta[par][sc][sb];
-        const int trip = max(max(s_maxn[par][0], s_maxn[par][1]), max(s_maxn[par][2], s_maxn[par][3]));
-        const int n = sb < nb ? (meta & 0xFF) : 0;
-        acc = ordered_sum(acc, &s_d[sc][par][sk][meta >> 8], n, trip);
-        cnt += n;
+        if (SOLO) {
+#pragma unroll
+            for (int w4 = 0; w4 < COEF_CW; w4++) {                 // the round's four chunks, in chunk order
+                const int meta = s_meta[par][w4][sb];
+                const int n = (sc == 0 && sb < nb) ? (meta & 0xFF) : 0;
+                acc = ordered_sum(acc, &s_d[w4][par][sk][meta >> 8], n, s_maxn[par][w4]);
+                cnt += n;
+            }
+        } else {
+            const int meta = s_meta[par][sc][sb];
+            const int trip = max(max(s_maxn[par][0], s_maxn[par][1]), max(s_maxn[par][2], s_maxn[par][3]));
+            const int n = sb < nb ? (meta & 0xFF) : 0;
+            acc = ordered_sum(acc, &s_d[sc][par][sk][meta >> 8], n, trip);
+            cnt += n;
+        }
     };
 
     // ---- pass 0: per-frame records (:40-61) + ordered mean of MatrixFilter outputs (:63-74)
@@ -598,9 +619,10 @@ __global__ __launch_bounds__(COEF_THREADS) __attribute__((amdgpu_waves_per_eu(5,
 #pragma unroll
         for (int i = 0; i < 8; i++) w[i] = p32[i];
     };
-    if (!summer && have_interior) prefetch(lane);
-    for (int c = 0; c < chunks; c++) {
-        const int par = c & 1;
+    if (!summer && have_interior) prefetch(cfirst * 64 + lane);
+    for (int rd = 0; rd < rounds; rd++) {
+        const int par = rd & 1;
+        const int c = rd * cstep + cfirst;
         if (!summer) {
             const int f = c * 64 + lane;
             bool valid = false;
@@ -608,7 +630,7 @@ __global__ __launch_bounds__(COEF_THREADS) __attribute__((amdgpu_waves_per_eu(5,
             uint32_t wc[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) wc[i] = w[i];
-            if (have_interior) prefetch(f + 64);
+            if (have_interior) prefetch(f + 64 * cstep);
             if (f < frames) {
                 FrameSums fs;
                 if (have_interior && f >= 1 && f <= f_hi) {
@@ -628,18 +650,18 @@ __global__ __launch_bounds__(COEF_THREADS) __attribute__((amdgpu_waves_per_eu(5,
             zero_fill(par);
             if (valid) {
                 const int slot = lane_rank(mask);
-                s_d[cs][par][0][slot] = d1;
-                s_d[cs][par][1][slot] = d2;
+                s_d[ws][par][0][slot] = d1;
+                s_d[ws][par][1][slot] = d2;
             }
-            if (lane < 8) s_meta[par][cs][lane] = lane == 0 ? n : 0;
-            if (lane == 8) s_maxn[par][cs] = n;
-        } else if (c > 0) {
+            if (lane < 8) s_meta[par][ws][lane] = lane == 0 ? n : 0;
+            if (lane == 8) s_maxn[par][ws] = n;
+        } else if (rd > 0) {
             sum_chunk(par ^ 1, 1);
         }
         lds_barrier();
     }
     if (summer) {
-        if (chunks > 0) sum_chunk((chunks - 1) & 1, 1);
+        if (rounds > 0) sum_chunk((rounds - 1) & 1, 1);
         const double other = __shfl_xor(acc, 1);
         if (sb == 0 && sk == 0) {
             double vec1[3];
@@ -658,7 +680,7 @@ __global__ __launch_bounds__(COEF_THREADS) __attribute__((amdgpu_waves_per_eu(5,
     auto lloyd_iterations = [&](auto exp_c) {
         constexpr int EXP = decltype(exp_c)::value;
         for (int iter = 0; iter < 2; iter++) {
-            if (!summer && lane < EXP) {
+            if (!summer && lane < EXP && (!SOLO || wave == 0)) {
                 const double a = s_vb[cs][lane][0], b = s_vb[cs][lane][1], c3 = s_vb[cs][lane][2];
                 s_cw[cs][lane][0] = (a * a) + (b * b) + (c3 * c3);
                 s_cw[cs][lane][1] = (a * b) + (b * c3);
@@ -675,16 +697,17 @@ __global__ __launch_bounds__(COEF_THREADS) __attribute__((amdgpu_waves_per_eu(5,
             acc = 0.0;
             cnt = 0;
             double2 r_next = make_double2(0.0, 0.0);
-            if (!summer && frames > 0) r_next = rec[min(lane, frames - 1)];
-            for (int c = 0; c < chunks; c++) {
-                const int par = c & 1;
+            if (!summer && frames > 0) r_next = rec[min(cfirst * 64 + lane, frames - 1)];
+            for (int rd = 0; rd < rounds; rd++) {
+                const int par = rd & 1;
+                const int c = rd * cstep + cfirst;
                 if (!summer) {
                     const int f = c * 64 + lane;
                     bool valid = false;
                     int idx = 0;
                     double d1 = 0.0, d2 = 0.0;
                     const double2 r = r_next;
-                    r_next = rec[min(f + 64, frames - 1)];           // in flight during this chunk
+                    r_next = rec[min(f + 64 * cstep, frames - 1)];   // in flight during this chunk
                     if (live && f < frames && r.x == r.x) {
                         valid = true;
                         const double val_x2 = 2.0 * r.x, bterm_x2 = 2.0 * r.y;
@@ -711,18 +734,18 @@ __global__ __launch_bounds__(COEF_THREADS) __attribute__((amdgpu_waves_per_eu(5,
                     }
                     zero_fill(par);
                     if (valid) {
-                        s_d[cs][par][0][slot] = d1;
-                        s_d[cs][par][1][slot] = d2;
+                        s_d[ws][par][0][slot] = d1;
+                        s_d[ws][par][1][slot] = d2;
                     }
-                    if (lane < 8) s_meta[par][cs][lane] = my_meta;
-                    if (lane == 8) s_maxn[par][cs] = max_n;
-                } else if (c > 0) {
+                    if (lane < 8) s_meta[par][ws][lane] = my_meta;
+                    if (lane == 8) s_maxn[par][ws] = max_n;
+                } else if (rd > 0) {
                     sum_chunk(par ^ 1, EXP);
                 }
                 lds_barrier();
             }
             if (summer) {
-                if (chunks > 0) sum_chunk((chunks - 1) & 1, EXP);
+                if (rounds > 0) sum_chunk((rounds - 1) & 1, EXP);
                 const double other = __shfl_xor(acc, 1);
                 if (sb < EXP && sk == 0) {
                     double bl[3];
@@ -743,7 +766,7 @@ __global__ __launch_bounds__(COEF_THREADS) __attribute__((amdgpu_waves_per_eu(5,
     // ---- 3 splits x 2 Lloyd iterations (:77-91, FilterRecords :344-396)
     for (int wsplit = 0; wsplit < 3; wsplit++) {
         const int half = 1 << wsplit;
-        if (!summer && lane < half) {
+        if (!summer && lane < half && (!SOLO || wave == 0)) {
             s_vb[cs][half + lane][0] = (0.01 * 0.0) + s_vb[cs][lane][0];
             s_vb[cs][half + lane][1] = (0.01 * -1.0) + s_vb[cs][lane][1];
             s_vb[cs][half + lane][2] = (0.01 * 0.0) + s_vb[cs][lane][2];
@@ -755,7 +778,7 @@ __global__ __launch_bounds__(COEF_THREADS) __attribute__((amdgpu_waves_per_eu(5,
     }
 
     // ---- output :94-108
-    if (live && lane < 16) {
+    if (live && lane < 16 && (!SOLO || wave == 0)) {
         const int z = lane >> 1;
         const double d = -s_vb[cs][z][1 + (lane & 1)] * 2048.0;
         int out;
@@ -805,6 +828,8 @@ __global__ __launch_bounds__(256) void synth_kernel(int16_t *__restrict__ pcm, i
 }
 
 // ---------------------------------------------------------------- launchers
+constexpr int SOLO_MAX_CHANNELS = 896;                      // 768 channels: 15.2 vs 19.2 ms, 1024: 24.1 vs 19.2 (profiles/r03_d_coefs_variants.log)
+
 int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, int16_t *d_coefs,
                  void *d_workspace, hipStream_t stream)
 {
@@ -816,13 +841,18 @@ int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, i
     // -- the same roles with the chunks handed over through a ring of LDS slots and producer / consumer counters instead
     // of a workgroup barrier per chunk -- was measured at 70 ms (polling LDS counters costs more than the barriers) and
     // dropped.
+    // Round 3: below VGA_SOLO_MAX channels the five waves work on ONE channel (SOLO, see the kernel).
     const int variant = coefs_kernel_variant();
     const bool per_channel = variant == 1 || (variant == 0 && nch > device_cu_count() * 14);
+    const bool solo = variant == 3 || (variant == 0 && nch <= SOLO_MAX_CHANNELS);
     if (per_channel)
         hipLaunchKernelGGL(gc_coefs_kernel, dim3(nch), dim3(64), 0, stream, d_pcm, pcm_pitch, nch, length,
                            reinterpret_cast<double2 *>(d_workspace), d_coefs);
+    else if (solo)
+        hipLaunchKernelGGL(gc_coefs_kernel4<true>, dim3(nch), dim3(COEF_THREADS), 0, stream, d_pcm, pcm_pitch, nch, length,
+                           reinterpret_cast<double2 *>(d_workspace), d_coefs);
     else
-        hipLaunchKernelGGL(gc_coefs_kernel4, dim3((nch + COEF_CW - 1) / COEF_CW), dim3(COEF_THREADS), 0, stream, d_pcm, pcm_pitch,
+        hipLaunchKernelGGL(gc_coefs_kernel4<false>, dim3((nch + COEF_CW - 1) / COEF_CW), dim3(COEF_THREADS), 0, stream, d_pcm, pcm_pitch,
                            nch, length, reinterpret_cast<double2 *>(d_workspace), d_coefs);
     VGA_HIP_TRY(hipGetLastError());
     return VGA_OK;
