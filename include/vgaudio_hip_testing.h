@@ -37,6 +37,10 @@ int vga_testing_gc_encoder_segments_this_thread(int segments);
  * thread counts, units (channels, streams) per chunk, bytes per ring slot.  Results must not depend on any of them. */
 void vga_testing_host_pipeline_this_thread(int feeders, int drainers, int chunk_units, int slot_bytes);
 
+/* ... and the size of the call's LAST chunk (the last regular chunk is split once into (rest, tail); 0 = automatic: 3/8 of a
+ * chunk). */
+void vga_testing_host_pipeline_tail_this_thread(int tail_units);
+
 /* Where the wall time of the calling thread's last pipelined call went, in seconds (diagnostics for bench.py's e2e
  * block): [0] total [1] set-up [2] feeders' memcpy (sum over threads) [3] feeders waiting for a ring slot [4] feeders
  * inside hipMemcpyAsync/hipEventRecord [5] slowest feeder [6] caller waiting for uploads [7] caller launching kernels

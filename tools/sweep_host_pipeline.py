@@ -42,8 +42,9 @@ def main():
              "feeders_chunk_boundary_sum", "feeders_final_sync_sum", "drainers_register_sum"]
     ref = None
     for shape in args.shapes.split(";"):
-        f, d, ch, sl = (int(v) for v in shape.split(","))
+        f, d, ch, sl, *rest = (int(v) for v in shape.split(","))
         L.vga_testing_host_pipeline_this_thread(f, d, ch, sl)
+        L.vga_testing_host_pipeline_tail_this_thread(rest[0] if rest else 0)        # optional 5th field: the last chunk's size
         best, bd = None, None
         for _ in range(3):
             t0 = time.perf_counter()

@@ -176,6 +176,7 @@ void vga_testing_host_pipeline_this_thread(int feeders, int drainers, int chunk_
     g_pipe_override.chunk_units = chunk_units;
     g_pipe_override.slot_bytes = slot_bytes;
 }
+void vga_testing_host_pipeline_tail_this_thread(int tail_units) { g_pipe_override.tail_units = tail_units > 0 ? tail_units : 0; }
 int vga_testing_last_pipeline_stats(double *out, int n)
 {
     const PipeReport &r = g_pipe_report;

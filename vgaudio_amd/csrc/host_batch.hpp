@@ -8,7 +8,7 @@ namespace vga {
 
 // Per-thread overrides of the pipeline's shape (vga_testing_host_pipeline_this_thread): the tests force many feeders,
 // one-row slots and small chunks on small inputs so that every hand-off of the pipeline is exercised on the GPU box.
-struct PipeOverride { int feeders = 0, drainers = 0, chunk_units = 0, slot_bytes = 0; };   // slot_bytes < 0: direct copies (no staging ring); > 0: staged
+struct PipeOverride { int feeders = 0, drainers = 0, chunk_units = 0, slot_bytes = 0, tail_units = 0; };   // slot_bytes < 0: direct copies (no staging ring); > 0: staged
 PipeOverride &pipe_override();                       // capi_gcadpcm.hip
 // the calling thread's last pipeline run, plus what the entry point spent around it (device allocation, small copies)
 struct PipeReport { pipe::Stats stats; double t_alloc = 0, t_entry = 0; };
@@ -104,6 +104,7 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     // 192 / 256 / 320 / 384 / 448 / 512 of 1024: 555 / 545 / 539 / 519 / 528 / 529 ms; halving down to 1/8: 533 ms --
     // short chunks that overlap slow each other down)
     job.tail_units = in_total + out_total >= ((size_t)256 << 20) ? std::max(1, job.chunk_units * 3 / 8) : 0;   // small calls: one chunk
+    if (o.tail_units > 0) job.tail_units = o.tail_units;
     // A short FIRST chunk (job.head_units: a quarter chunk starts the first kernel 29 ms instead of 115 ms into a
     // 4096 x 60 s call) was measured and is not used: the call is bound by its upload (461 of ~530 ms) and ends one short
     // chunk's kernels + download after it, whenever the first kernel started (profiles/r03_b_pipeline_timeline_head_chunk.log:
