@@ -52,6 +52,17 @@ int vga_set_device(int device);
 int vga_set_devices(const int *devices, int count);
 /* the current list: returns its length and fills devices[0 .. min(length, capacity)) */
 int vga_get_devices(int *devices, int capacity);
+/* Progress of the host-buffer (`*_batch`) entry points: IProgressReport (VGAudio/IProgressReport.cs:3-28), which the
+ * reference drives with ReportAdd(1) per frame (GcAdpcmEncoder.cs:42, CriAdxCodec.cs:101, CriHcaFormat.cs:71,79).  Here a
+ * call works through its channels / streams in chunks (512 or 1024 channels, 256 streams; one chunk for small calls), and
+ * fn(user, done, total) is called once per chunk when that chunk's results are complete in the caller's rows: `done`
+ * counts channels (GC-ADPCM, ADX) or streams (HCA) finished so far, `total` is the call's count; the host multiplies by
+ * its frames per channel for ReportAdd.  With vga_set_devices() the shares of all devices report into the same count.
+ * fn runs on a worker thread of the library while the call is in progress, never concurrently with itself; it must not
+ * call back into the library and should return quickly (a drainer thread is waiting for it).  Per calling thread: the
+ * callback applies to `*_batch` calls made afterwards from the thread that set it; fn = NULL removes it. */
+typedef void (*vga_progress_fn)(void *user, int64_t done, int64_t total);
+int vga_set_progress_callback(vga_progress_fn fn, void *user);
 /* The host-buffer entry points keep the device buffers and the page-locked staging rings of their last calls for the
  * next one (allocation costs more than a call's transfers and kernels: ~1.4 s for the 44 GB of BASELINE configs[1]); at
  * most 64 GiB of device memory PER DEVICE (environment variable VGA_HIP_POOL_GIB changes the figure, 0 turns the cache off)

@@ -3,6 +3,7 @@
 // -fsanitize=thread by tests/test_host_pipeline.py.
 #include "../../vgaudio_amd/csrc/host_pipeline.hpp"
 
+#include <atomic>
 #include <cstdio>
 #include <random>
 
@@ -71,6 +72,26 @@ static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t 
         });
         return 0;
     };
+    // progress: chunks are reported once each, in order, one at a time, and when a chunk is reported its output rows are
+    // already complete in the caller's memory
+    auto expected = [&](int u, int j, size_t i) {
+        unsigned v = (unsigned)j + (unsigned)i;
+        for (int k = 0; k < in_rpu; k++) v += in[u * in_rpu + k][i % in_bytes];
+        return (unsigned char)v;
+    };
+    int reported = 0, report_calls = 0, report_bad = 0;
+    std::atomic<int> in_report{0};
+    job.chunk_done = [&](int first, int count) {
+        if (in_report.fetch_add(1) != 0) report_bad++;
+        if (first != reported || count <= 0 || first + count > units) report_bad++;
+        for (int u = first; u < first + count && u < units; u++)
+            for (int j = 0; j < out_rpu; j++)
+                for (size_t i = 0; i < out_bytes; i++)
+                    if (out[u * out_rpu + j][i] != expected(u, j, i)) { report_bad++; break; }
+        reported = first + count;
+        report_calls++;
+        in_report.fetch_sub(1);
+    };
     mock_copy_delay_us() = delay_us;
     mock_fail_memcpy_after() = fail_after;
     const Result r = run(job);
@@ -78,9 +99,14 @@ static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t 
     mock_copy_delay_us() = 0;
     if (fail_after >= 0 || compute_fails) {
         if (r.code == 0) { std::printf("expected a failure (units %d)\n", units); return 1; }
+        if (report_bad || reported > units) { std::printf("progress after a failure: %d bad reports\n", report_bad); return 1; }
         return 0;
     }
     if (r.code != 0) { std::printf("unexpected failure %d: %s\n", r.code, r.why.c_str()); return 1; }
+    if (report_bad || reported != units || report_calls != r.stats.chunks) {
+        std::printf("progress: %d bad reports, %d of %d units in %d calls for %d chunks\n", report_bad, reported, units, report_calls, r.stats.chunks);
+        return 1;
+    }
     for (int u = 0; u < units; u++)
         if (seen[u] != 1) { std::printf("unit %d computed %d times\n", u, seen[u]); return 1; }
     for (int u = 0; u < units; u++)

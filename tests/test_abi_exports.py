@@ -15,6 +15,7 @@ def _declared_symbols():
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//.*", "", text)
     text = re.sub(r"^\s*#.*$", "", text, flags=re.M)
+    text = re.sub(r"\btypedef\b[^;{]*;", "", text)          # function-pointer types are not symbols
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", text)
     return sorted(set(names))
 
@@ -36,6 +37,7 @@ def _declared_arg_counts():
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//.*", "", text)
     text = re.sub(r"^\s*#.*$", "", text, flags=re.M)
+    text = re.sub(r"\btypedef\b[^;{]*;", "", text)
     out = {}
     for name, args in re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(([^;{()]*)\)\s*;", text):
         args = args.strip()
@@ -50,6 +52,18 @@ def test_ctypes_signatures_have_the_headers_argument_counts():
     wrong = {n: (len(_lib.SIGNATURES[n][1]), c) for n, c in counts.items()
              if n in _lib.SIGNATURES and len(_lib.SIGNATURES[n][1]) != c}
     assert not wrong, f"(ctypes, header) argument counts differ: {wrong}"
+
+
+def test_progress_callback_is_per_thread_host_state():
+    """vga_set_progress_callback without a GPU: installing and removing a callback is host state only"""
+    from vgaudio_amd import _lib
+    L = _lib.lib()
+    calls = []
+    fn = _lib.PROGRESS_FN(lambda user, done, total: calls.append((done, total)))
+    import ctypes as C
+    assert L.vga_set_progress_callback(C.cast(fn, C.c_void_p), None) == 0
+    assert L.vga_set_progress_callback(None, None) == 0
+    assert calls == []
 
 
 def test_device_list_is_host_state_and_validated():

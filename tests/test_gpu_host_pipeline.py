@@ -117,3 +117,79 @@ def test_a_failing_share_fails_the_call(devices):
     adpcm[nch - 3][8] = 0xF0                                  # predictor 15 in the LAST share: IndexOutOfRange in the reference
     with pytest.raises(vgaudio_amd.ArgumentError):
         GcAdpcmDecoder.Decode(adpcm, np.stack([ch.Coefs for ch in fmt.Channels]), GcAdpcmParameters(SampleCount=n))
+
+
+class _Progress:
+    """IProgressReport (VGAudio/IProgressReport.cs:3-28) as a recorder"""
+
+    def __init__(self):
+        self.total, self.adds = None, []
+
+    def SetTotal(self, total):
+        self.total = total
+
+    def ReportAdd(self, value):
+        self.adds.append(value)
+
+
+def test_progress_is_reported_chunk_by_chunk(shape):
+    """vga_set_progress_callback through the host mirrors: SetTotal(frames x channels) as the reference (GcAdpcmFormat.cs:63,
+    CriAdxFormat.cs:65, CriHcaFormat.cs:48), ReportAdd per finished chunk, adding up to the total -- and the bytes do not
+    care whether anybody listens"""
+    chunk = shape[2]
+    nch, n = 37, 14 * 300 + 5
+    pcm = synth.generate(nch, n)
+    quiet = GcAdpcmFormat().EncodeFromPcm16(Pcm16Format(list(pcm), 48000))
+    pg = _Progress()
+    fmt = GcAdpcmFormat().EncodeFromPcm16(Pcm16Format(list(pcm), 48000), GcAdpcmParameters(Progress=pg))
+    frames = -(-n // 14)
+    assert pg.total == frames * nch and sum(pg.adds) == frames * nch and all(a > 0 and a % frames == 0 for a in pg.adds)
+    if 0 < chunk < nch:
+        assert len(pg.adds) >= -(-nch // chunk)                 # one report per chunk (the last chunk may be split)
+    for a, b in zip(fmt.Channels, quiet.Channels):
+        assert np.array_equal(a.GetAdpcmAudio(), b.GetAdpcmAudio())
+    # ADX
+    pa = _Progress()
+    cfg = CriAdxParameters(Progress=pa)
+    enc = CriAdxCodec.Encode(list(pcm), cfg)
+    per = len(enc[0]) // cfg.FrameSize
+    assert sum(pa.adds) == per * nch and all(a % per == 0 for a in pa.adds)
+    assert np.array_equal(np.stack(enc), np.stack(CriAdxCodec.Encode(list(pcm), CriAdxParameters())))
+    # HCA: streams are the units
+    ns, hn = 9, 3000
+    streams = [Pcm16Format(list(synth.generate(2, hn, first_channel=2 * s)), 48000) for s in range(ns)]
+    ph = _Progress()
+    fmts = CriHcaFormat.EncodeBatchFromPcm16(streams, CriHcaParameters(Progress=ph))
+    fc = fmts[0].Hca.FrameCount
+    assert ph.total == fc * ns and sum(ph.adds) == fc * ns and all(a % fc == 0 for a in ph.adds)
+    # a callback that was removed stays removed
+    L = _lib.lib()
+    calls = []
+    fn = _lib.PROGRESS_FN(lambda u, d, t: calls.append(d))
+    import ctypes as C
+    L.vga_set_progress_callback(C.cast(fn, C.c_void_p), None)
+    L.vga_set_progress_callback(None, None)
+    CriAdxCodec.Encode(list(pcm[:3]), CriAdxParameters())
+    assert calls == []
+
+
+def test_progress_of_a_call_spread_over_devices_is_one_count(devices):
+    """the shares of all listed devices report into the same (done, total), one report at a time"""
+    import ctypes as C
+    L = _lib.lib()
+    nch, n = 128 * len(devices) + 41, 14 * 200
+    pcm = synth.generate(nch, n)
+    seen = []
+    fn = _lib.PROGRESS_FN(lambda user, done, total: seen.append((done, total)))
+    L.vga_testing_host_pipeline_this_thread(2, 2, 40, 4096)
+    L.vga_set_progress_callback(C.cast(fn, C.c_void_p), None)
+    try:
+        enc = CriAdxCodec.Encode(list(pcm), CriAdxParameters())
+    finally:
+        L.vga_set_progress_callback(None, None)
+        L.vga_testing_host_pipeline_this_thread(0, 0, 0, 0)
+    assert seen and seen[-1] == (nch, nch) and all(t == nch for _, t in seen)
+    assert [d for d, _ in seen] == sorted(d for d, _ in seen) and len(set(d for d, _ in seen)) == len(seen)
+    assert len(seen) >= len(devices) * 3
+    want, _ = po.adx_encode_batch(pcm, po.adx_params(), threads=8)
+    assert np.array_equal(np.stack(enc), want)

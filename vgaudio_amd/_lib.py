@@ -44,6 +44,33 @@ class DeviceError(VgaError):                         # HIP failure / no device
     code = VGA_ERR_DEVICE
 
 
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)     # vga_progress_fn
+
+
+class reporting:
+    """`with reporting(progress, frames_per_unit):` around a *_batch call: IProgressReport.ReportAdd once per chunk of
+    channels / streams the call finishes (vga_set_progress_callback), where the reference reports once per frame
+    (GcAdpcmEncoder.cs:42, CriAdxCodec.cs:101, CriHcaFormat.cs:71,79).  progress None: nothing is installed."""
+
+    def __init__(self, progress, per_unit):
+        self.progress, self.per_unit, self.last, self.fn = progress, per_unit, 0, None
+
+    def _report(self, _user, done, _total):
+        self.progress.ReportAdd((done - self.last) * self.per_unit)
+        self.last = done
+
+    def __enter__(self):
+        if self.progress is not None:
+            self.fn = PROGRESS_FN(self._report)
+            lib().vga_set_progress_callback(C.cast(self.fn, C.c_void_p), None)
+        return self
+
+    def __exit__(self, *exc):
+        if self.fn is not None:
+            lib().vga_set_progress_callback(None, None)
+        return False
+
+
 _EXC = {e.code: e for e in (ArgumentError, ArgumentOutOfRangeError, InvalidDataError, InvalidOperationError,
                             DeviceError)}
 
@@ -127,6 +154,7 @@ SIGNATURES = {
     "vga_testing_host_pipeline_tail_this_thread": (None, [ci]),
     "vga_testing_hca_device_info": (ci, [vp, vp, ci]),
     "vga_set_devices": (ci, [vp, ci]),
+    "vga_set_progress_callback": (ci, [vp, vp]),
     "vga_get_devices": (ci, [vp, ci]),
     "vga_testing_hca_frames_per_group_this_thread": (ci, [ci]),
     "vga_dsp_layout_for": (ci, [vp, ci, vp]),

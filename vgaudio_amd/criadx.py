@@ -69,11 +69,10 @@ class CriAdxCodec:
             check(nbytes)
         outs = [np.zeros(nbytes, dtype=np.uint8) for _ in range(nch)]
         hist = np.zeros(max(nch, 1), dtype=np.int16)
-        check(_lib.lib().vga_adx_encode_batch(_ptr_array(i16p, chans), nch, n, C.byref(cp), _ptr_array(u8p, outs),
-                                               _i16(hist)))
+        with _lib.reporting(config.Progress, nbytes // config.FrameSize):      # frames per channel (CriAdxCodec.cs:101)
+            check(_lib.lib().vga_adx_encode_batch(_ptr_array(i16p, chans), nch, n, C.byref(cp), _ptr_array(u8p, outs),
+                                                   _i16(hist)))
         config.History = int(hist[0]) if single else hist[:nch].copy()
-        if config.Progress is not None:
-            config.Progress.ReportAdd(nbytes // config.FrameSize * nch)
         return outs[0] if single else outs
 
     @staticmethod

@@ -102,11 +102,12 @@ class CriHcaDecoder:
             raise _lib.ArgumentError("audio shorter than FrameCount * FrameSize")
         nch, n = hca.ChannelCount, max(hca.SampleCount, 0)
         outs = [np.zeros(n, dtype=np.int16) for _ in range(len(streams) * nch)]
-        check(_lib.lib().vga_hca_decode_batch(C.byref(hca.c), _ptr_array(u8p, flat), len(streams),
-                                               _ptr_array(i16p, outs)))
-        if config is not None and config.Progress is not None:
-            config.Progress.SetTotal(hca.FrameCount * len(streams))
-            config.Progress.ReportAdd(hca.FrameCount * len(streams))
+        progress = config.Progress if config is not None else None
+        if progress is not None:
+            progress.SetTotal(hca.FrameCount * len(streams))
+        with _lib.reporting(progress, hca.FrameCount):                 # frames per stream (CriHcaFormat.cs:71,79)
+            check(_lib.lib().vga_hca_decode_batch(C.byref(hca.c), _ptr_array(u8p, flat), len(streams),
+                                                   _ptr_array(i16p, outs)))
         per = [outs[s * nch:(s + 1) * nch] for s in range(len(streams))]
         return per[0] if single else per
 
@@ -142,10 +143,9 @@ class CriHcaFormat:
         outs = [np.zeros(hca.FrameCount * hca.FrameSize, dtype=np.uint8) for _ in pcm16_list]
         info = _lib.HcaInfoC()
         cp = config._c()
-        check(_lib.lib().vga_hca_encode_batch(_ptr_array(i16p, chans), len(pcm16_list), C.byref(cp), C.byref(info),
-                                               _ptr_array(u8p, outs)))
-        if config.Progress is not None:
-            config.Progress.ReportAdd(hca.FrameCount * len(pcm16_list))
+        with _lib.reporting(config.Progress, hca.FrameCount):
+            check(_lib.lib().vga_hca_encode_batch(_ptr_array(i16p, chans), len(pcm16_list), C.byref(cp), C.byref(info),
+                                                   _ptr_array(u8p, outs)))
         return [CriHcaFormat(o.reshape(hca.FrameCount, hca.FrameSize), HcaInfo(info)) for o in outs]
 
     def ToPcm16(self, config=None):

@@ -114,6 +114,10 @@ void apply_thread_hooks(const ThreadHooks &h)
 }
 static thread_local PipeReport g_pipe_report;
 PipeReport &pipe_report() { return g_pipe_report; }
+static thread_local ProgressCallback g_progress_callback;
+ProgressCallback progress_callback() { return g_progress_callback; }
+static thread_local ProgressSink *g_progress_sink = nullptr;
+ProgressSink *&current_progress_sink() { return g_progress_sink; }
 
 int require_device()
 {
@@ -220,6 +224,13 @@ int vga_set_devices(const int *devices, int count)
         if (devices[i] < 0 || devices[i] >= n) { set_error("vga_set_devices: device %d of %d does not exist", devices[i], n); return VGA_ERR_ARGUMENT; }
     std::lock_guard<std::mutex> g(g_devices_mutex);
     g_devices.assign(devices, devices + count);
+    return VGA_OK;
+}
+
+int vga_set_progress_callback(vga_progress_fn fn, void *user)
+{
+    vga::g_progress_callback.fn = fn;
+    vga::g_progress_callback.user = fn ? user : nullptr;
     return VGA_OK;
 }
 

@@ -1,6 +1,7 @@
 // host_batch.hpp -- glue between the host-pointer entry points of the C ABI and host_pipeline.hpp.
 #pragma once
 #include <cstdlib>
+#include <mutex>
 #include "common.hpp"
 #include "host_pipeline.hpp"
 
@@ -23,6 +24,23 @@ struct ThreadHooks { int force_open_seams, encoder_layout, coefs_variant, encode
 ThreadHooks capture_thread_hooks();                  // capi_gcadpcm.hip
 void apply_thread_hooks(const ThreadHooks &h);       // capi_gcadpcm.hip
 
+// vga_set_progress_callback(): the calling thread's callback, and the state of one call's reports -- shared by the call's
+// device shares, whose pipelines report chunks from their own worker threads
+struct ProgressCallback { void (*fn)(void *user, int64_t done, int64_t total) = nullptr; void *user = nullptr; };
+ProgressCallback progress_callback();                // capi_gcadpcm.hip (thread-local)
+struct ProgressSink {
+    ProgressCallback cb;
+    int64_t total = 0, done = 0;
+    std::mutex m;
+    void add(int64_t units)
+    {
+        std::lock_guard<std::mutex> g(m);            // one report at a time, whatever thread it comes from
+        done += units;
+        cb.fn(cb.user, done, total);
+    }
+};
+ProgressSink *&current_progress_sink();              // capi_gcadpcm.hip (thread-local): the call this thread works for
+
 // Runs body(first_unit, unit_count) -- the single-device form of an entry point, which reports failures through
 // set_error() + its status code -- once per share of `units` over vga_set_devices()'s list (pipe::run_on_devices: a host
 // thread and a whole pipeline per device; results land in the caller's rows, no collective).  Shares are at least
@@ -30,6 +48,14 @@ void apply_thread_hooks(const ThreadHooks &h);       // capi_gcadpcm.hip
 template <class Body>
 inline int for_each_device_share(int units, int min_units, Body &&body)
 {
+    ProgressSink sink;
+    sink.cb = progress_callback();
+    sink.total = units;
+    struct SinkScope {                                 // the pipelines this thread starts report to `sink`
+        ProgressSink *before;
+        explicit SinkScope(ProgressSink *s) : before(current_progress_sink()) { current_progress_sink() = s; }
+        ~SinkScope() { current_progress_sink() = before; }
+    } scope(sink.cb.fn && units > 0 ? &sink : nullptr);
     const std::vector<int> devices = batch_devices();
     if (devices.empty() || units <= 0) return body(0, units);
     const std::vector<pipe::Share> shares = pipe::plan_shares(devices, units, min_units);
@@ -42,8 +68,12 @@ inline int for_each_device_share(int units, int min_units, Body &&body)
         (void)hipSetDevice(before);
         return rc;
     }
+    ProgressSink *const shared_sink = current_progress_sink();
     const pipe::Result r = pipe::run_on_devices(shares, [&](const pipe::Share &sh, std::string &why) -> int {
-        if (sh.index != 0) apply_thread_hooks(hooks);
+        if (sh.index != 0) {
+            apply_thread_hooks(hooks);
+            current_progress_sink() = shared_sink;
+        }
         const int rc = body(sh.first, sh.count);
         if (rc) why = vga_last_error();
         return rc;
@@ -110,6 +140,8 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     // chunk's kernels + download after it, whenever the first kernel started (profiles/r03_b_pipeline_timeline_head_chunk.log:
     // 539 and 550 ms against 518-538 ms without).
     job.head_units = 0;
+    if (ProgressSink *sink = current_progress_sink())  // vga_set_progress_callback(): one report per chunk
+        job.chunk_done = [sink](int, int count) { sink->add(count); };
     const pipe::Result r = pipe::run(job);
     pipe_report().stats = r.stats;
     if (r.code) {

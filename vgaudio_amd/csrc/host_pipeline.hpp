@@ -138,6 +138,9 @@ struct Job {
     // before it (the short chunks at the end are bound by their kernels' latency, not by the chip).  The callback learns
     // the lane through compute_lane() and must keep per-lane scratch; chunks of one lane still run in order.
     int compute_lanes = 1;
+    // called once per chunk, chunks in order, when the chunk's output rows are complete in the caller's memory (jobs
+    // without output rows: when its kernels have run) -- on one of the call's worker threads, never concurrently
+    std::function<void(int first, int count)> chunk_done;
     int feeders = 8, drainers = 4;
     size_t slot_bytes = (size_t)8 << 20;   // target size of one ring slot (whole rows; at least one row)
     int ring = 3;                          // slots per feeder / drainer
@@ -297,6 +300,23 @@ inline Result run(const Job &job)
     if (ok && has_in && !job.direct && !in_ring.alloc((size_t)F * R * in_slot_rows * job.d_in_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (input ring)");
     if (ok && has_out && !job.direct_out && !out_ring.alloc((size_t)D * R * out_slot_rows * job.d_out_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (output ring)");
 
+    // progress (job.chunk_done): every drainer marks the end of its copies of chunk k with an event and, while it waits for
+    // the next chunk's kernels anyway, for that event; the drainer that is last to see chunk k complete reports it, after
+    // the chunks before it (report_mutex / next_report keep the order)
+    const bool progress = (bool)job.chunk_done;
+    std::vector<hipEvent_t> dend(progress ? (size_t)D * chunks : 0, nullptr);
+    for (auto &e : dend) check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    std::vector<int> chunk_seen(chunks, 0);            // drainers that have seen chunk k's copies complete (under report_mutex)
+    std::mutex report_mutex;
+    int next_report = 0;
+    auto chunk_complete = [&](int k) {
+        std::lock_guard<std::mutex> g(report_mutex);
+        chunk_seen[k]++;
+        while (next_report < chunks && chunk_seen[next_report] >= std::max(D, 1)) {
+            job.chunk_done(cbegin[next_report], cbegin[next_report + 1] - cbegin[next_report]);
+            next_report++;
+        }
+    };
     auto chunk_units_of = [&](int k) { return cbegin[k + 1] - cbegin[k]; };
     std::vector<std::vector<void *>> locked_in(F), locked_out(D);      // rows page-locked for the call, per worker (see below)
 
@@ -377,6 +397,7 @@ inline Result run(const Job &job)
         struct Pending { int row = -1, n = 0; };
         std::vector<Pending> pend(R);
         int64_t used = 0;
+        int reported = 0;                                  // progress: chunks [0, reported) of this drainer are complete
         std::vector<void *> &registered = locked_out[u];
         double t_wait_comp = 0, t_wait_copy = 0, t_copy = 0, t_register = 0;
         const double t_start = now();
@@ -459,6 +480,21 @@ inline Result run(const Job &job)
                 used++;
             }
             if (timeline) VGA_PIPE_TRY(hipEventRecord(dlev[u * chunks + k], dstream[u]));
+            if (progress && !sh.err.load()) {
+                // this chunk's copies are queued; the ones of the chunk before have had its kernels' time to finish: see
+                // them complete (staged mode: hand their rows out now rather than when the slot is needed again) and
+                // say so.  Nothing is waiting for this thread until the next chunk's kernels have run.
+                VGA_PIPE_TRY(hipEventRecord(dend[u * chunks + k], dstream[u]));
+                if (k > 0) {
+                    const double ta = now();
+                    VGA_PIPE_TRY(hipEventSynchronize(dend[u * chunks + k - 1]));
+                    t_wait_copy += now() - ta;
+                    for (int s = 0; s < R; s++)
+                        if (pend[s].row >= 0 && pend[s].row < row0 && !flush(s)) return;
+                    chunk_complete(k - 1);
+                    reported = k;
+                }
+            }
         }
         if (!sh.err.load())
             for (int s = 0; s < R; s++)
@@ -468,6 +504,8 @@ inline Result run(const Job &job)
             VGA_PIPE_TRY(hipStreamSynchronize(dstream[u]));   // the caller's rows are complete when run() returns
             t_wait_copy += now() - ta;
         }
+        if (progress && !sh.err.load())
+            for (; reported < chunks; reported++) chunk_complete(reported);
     };
 
     // Rows page-locked for the call (direct mode), per worker.  They are unlocked only at the end of run(), after every
@@ -519,6 +557,8 @@ inline Result run(const Job &job)
                 std::lock_guard<std::mutex> g(sh.m);
                 sh.st.main_tail_sync = now() - tc;
             }
+            if (progress && D == 0 && !sh.err.load())
+                for (int k = 0; k < chunks; k++) chunk_complete(k);
         }();
         for (auto &th : threads) th.join();
         if (sh.err.load()) {
@@ -543,7 +583,7 @@ inline Result run(const Job &job)
             std::fprintf(stderr, " ms\n");
         }
     }
-    for (auto *v : {&fslot, &dslot, &upl, &comp, &cstart, &dlev})
+    for (auto *v : {&fslot, &dslot, &upl, &comp, &cstart, &dlev, &dend})
         for (auto e : *v) if (e) (void)hipEventDestroy(e);
     if (shared_streams) { fstream.resize(F > 0 ? 1 : 0); dstream.resize(D > 0 ? 1 : 0); }
     for (auto s : fstream) if (s) (void)hipStreamDestroy(s);

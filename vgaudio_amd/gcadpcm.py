@@ -110,11 +110,10 @@ class GcAdpcmEncoder:
         h2 = np.ascontiguousarray(np.broadcast_to(np.asarray(config.History2, dtype=np.int16), (nch,)))
         nbytes = GcAdpcmMath.SampleCountToByteCount(max(sample_count, 0))
         outs = [np.zeros(nbytes, dtype=np.uint8) for _ in range(nch)]
-        check(_lib.lib().vga_gcadpcm_encode_with_coefs_batch(
-            _ptr_array(i16p, chans), nch, n, config.SampleCount, _i16(coefs), _i16(h1), _i16(h2),
-            _ptr_array(u8p, outs)))
-        if config.Progress is not None:
-            config.Progress.ReportAdd(-(-sample_count // 14) * nch)   # one report per batch (boundary)
+        with _lib.reporting(config.Progress, -(-sample_count // 14)):   # frames per channel (GcAdpcmEncoder.cs:42)
+            check(_lib.lib().vga_gcadpcm_encode_with_coefs_batch(
+                _ptr_array(i16p, chans), nch, n, config.SampleCount, _i16(coefs), _i16(h1), _i16(h2),
+                _ptr_array(u8p, outs)))
         return outs[0] if single else outs
 
     @staticmethod
@@ -359,10 +358,9 @@ class GcAdpcmFormat:
             adpcm = [np.zeros(nbytes, dtype=np.uint8) for _ in range(nch)]
             h1 = config.History1 if config else 0
             h2 = config.History2 if config else 0
-            check(_lib.lib().vga_gcadpcm_encode_batch(_ptr_array(i16p, pcm16.Channels), nch, n, h1, h2, _i16(coefs),
-                                                       _ptr_array(u8p, adpcm)))
-            if config is not None and config.Progress is not None:
-                config.Progress.ReportAdd(-(-n // 14) * nch)
+            with _lib.reporting(config.Progress if config is not None else None, -(-n // 14)):
+                check(_lib.lib().vga_gcadpcm_encode_batch(_ptr_array(i16p, pcm16.Channels), nch, n, h1, h2, _i16(coefs),
+                                                           _ptr_array(u8p, adpcm)))
         chans = [GcAdpcmChannel(adpcm[i], coefs[i].copy(), n) for i in range(nch)]
         # new GcAdpcmFormatBuilder(channels, rate).WithLoop(pcm16.Looping, LoopStart, LoopEnd).Build() (:70-73)
         return GcAdpcmFormat(chans, pcm16.SampleRate, pcm16.Looping, pcm16.LoopStart, pcm16.LoopEnd)
