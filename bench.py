@@ -155,7 +155,7 @@ def setup(args):
     _lib.check(cx.L.vga_set_device(device_index))
     cx.backend = args.backend
     if cx.world > 1:
-        vdist.init(args.backend, cx.dev)
+        vdist.init(args.backend, cx.dev, timeout_s=300)
     cx.st = lambda: torch.cuda.current_stream().cuda_stream
     return cx
 
@@ -351,6 +351,30 @@ def measure_e2e(cx, args, pcm, n, coefs_dev, adpcm_dev, devices=None):
     return e2e
 
 
+def guarded(cx, line, fn, limit_s=240.0):
+    """Runs fn() -- the N > 1 extras, which every rank takes part in -- so that rank 0's result line survives them: an
+    exception becomes {"error": ...} in place of fn's result, and on rank 0 (line is not None) a watchdog thread prints
+    the line with the time-out named and ends the process if fn has not returned after limit_s (a collective waiting
+    for a rank that is gone never raises; the process group's own time-out, setup(), aborts the other ranks)."""
+    import threading
+    timer = None
+    if line is not None:
+        def give_up():
+            out = dict(line, gather={"error": f"the multi-GPU extras did not finish within {limit_s:g} s; the line holds the timed steps only"})
+            print(json.dumps(out), flush=True)
+            os._exit(0)
+        timer = threading.Timer(limit_s, give_up)
+        timer.daemon = True
+        timer.start()
+    try:
+        return fn()
+    except Exception as e:                              # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        if timer is not None:
+            timer.cancel()
+
+
 def run_gc(args, cx):
     import numpy as np
     torch, vdev, L = cx.torch, cx.vdev, cx.L
@@ -373,16 +397,10 @@ def run_gc(args, cx):
         if events is not None:
             events[2].record()
 
-    elapsed, evs = timed_steps(cx, args, step, 3)
-    coefs = state["coefs"]
-    coef_ms, enc_ms = mean_ms(evs, 0, 1), mean_ms(evs, 1, 2)
-    ms_per_step = elapsed / max(args.steps, 1) * 1e3
-    samples_per_step = nch * n * cx.world
-    value = samples_per_step / (ms_per_step * 1e-3) / 1e6
-
-    gather = None
-    scaling = None
-    if cx.world > 1:
+    def multi_gpu_extras(adpcm, coefs):
+        """N > 1 only, after the timed steps: the final gather (alone, and underneath the next step), its digest check, the
+        per-shard digests, rank 0's step with the other GPUs idle.  Returns (gather, scaling, adpcm, coefs)."""
+        scaling = None
         # SURVEY.md 8e: the results of all channels end up in one place (GcAdpcmFormat.cs:65-74): ADPCM rows + coefs of
         # every rank gathered to rank 0 over RCCL/xGMI, in channel chunks; timed as steps that include it.
         nb = vdev.gc_byte_count(n)
@@ -467,7 +485,19 @@ def run_gc(args, cx):
                        "weak_scaling_efficiency": round(alone_ms / ms_per_step, 4),
                        "note": "same job: rank 0's step with the other GPUs idle / the max-over-ranks step with all of them busy"}
 
+        return gather, scaling, adpcm, coefs
+
+    elapsed, evs = timed_steps(cx, args, step, 3)
+    coefs = state["coefs"]
+    coef_ms, enc_ms = mean_ms(evs, 0, 1), mean_ms(evs, 1, 2)
+    ms_per_step = elapsed / max(args.steps, 1) * 1e3
+    samples_per_step = nch * n * cx.world
+    value = samples_per_step / (ms_per_step * 1e-3) / 1e6
+
+    gather = scaling = None
     if cx.rank != 0:
+        if cx.world > 1:
+            guarded(cx, None, lambda: multi_gpu_extras(adpcm, coefs))
         return None
     # the other direction (GcAdpcmDecoder.Decode), outside the timed steps: three launches between HIP events
     dec_ms = 0.0
@@ -551,6 +581,14 @@ def run_gc(args, cx):
                     "int32", f"BASELINE configs[1]: {nch} mono channels x 48 kHz x {args.seconds:g} s GC-ADPCM coefficient "
                              f"search + encode per GPU",
                     {"channels_per_gpu": nch, "samples_per_channel": n, "bit_exact_channels_checked": verified}, roofline, cpu)
+    if cx.world > 1:
+        # the line so far is complete without what follows: if the extras fail, it is printed with the failure named; if
+        # they hang (a collective that never returns), a watchdog prints it and ends this rank
+        res = guarded(cx, out, lambda: multi_gpu_extras(adpcm, coefs))
+        if isinstance(res, tuple):
+            gather, scaling, adpcm, coefs = res
+        else:
+            gather = res
     if gather:
         out["gather"] = gather
     if scaling:
@@ -561,7 +599,10 @@ def run_gc(args, cx):
         # one process, N GPUs: the same 4096-channel call as the N = 1 line's e2e block, its channels spread over all
         # GPUs of the job by the library (the other ranks are idle at the final barrier meanwhile)
         devs = [0] * cx.world if args.share_gpu else list(range(cx.world))
-        out["e2e_multi"] = measure_e2e(cx, args, pcm, n, coefs, adpcm, devices=devs)
+        try:
+            out["e2e_multi"] = measure_e2e(cx, args, pcm, n, coefs, adpcm, devices=devs)
+        except Exception as e:                          # noqa: BLE001 -- the line is worth more than this block
+            out["e2e_multi"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
@@ -815,8 +856,11 @@ def main():
     if cx.rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
     if cx.world > 1:
-        cx.dist.barrier()
-        cx.dist.destroy_process_group()
+        try:
+            cx.dist.barrier()
+            cx.dist.destroy_process_group()
+        except Exception:                               # noqa: BLE001 -- the line is out; a rank that failed is gone
+            pass
 
 
 if __name__ == "__main__":

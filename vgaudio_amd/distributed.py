@@ -28,15 +28,18 @@ def shard_channels(total_channels, world, rank):
     return first, count
 
 
-def init(backend, device=None):
+def init(backend, device=None, timeout_s=None):
+    """timeout_s: how long a collective may wait for a rank that never arrives (default: torch's ten minutes for RCCL)"""
+    import datetime
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     if dist.is_initialized():
         return
+    kw = {} if timeout_s is None else {"timeout": datetime.timedelta(seconds=timeout_s)}
     if backend == "nccl":
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group("nccl", device_id=device, **kw)
     else:
-        dist.init_process_group(backend)
+        dist.init_process_group(backend, **kw)
 
 
 def gather_channel_metadata(local, counts):
@@ -60,7 +63,8 @@ def launch_local_ranks(argv, nproc, master_port=None, extra_env=None, timeout=No
     """One process per GPU without torchrun: runs `python argv...` nproc times with RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT set (the environment torch.distributed.run would give them) and waits for all of them.
     Rank 0 inherits stdout (it prints the result line); the other ranks' stdout goes to stderr.  Returns the first
-    non-zero exit code, or 0.  A rank that fails takes the others down (they would wait in a collective for ever)."""
+    non-zero exit code, or 0.  A rank that fails takes the others down (they would wait in a collective for ever); once
+    rank 0 has finished cleanly -- its line is out -- the others get `grace` seconds and then go the same way."""
     import socket
     import subprocess
     import sys
@@ -77,6 +81,8 @@ def launch_local_ranks(argv, nproc, master_port=None, extra_env=None, timeout=No
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                                       stdout=None if r == 0 else sys.stderr))
     deadline = None if timeout is None else time.monotonic() + timeout
+    grace = 20.0
+    rank0_done_at = None
     rc = 0
     live = list(procs)
     while live:
@@ -85,14 +91,17 @@ def launch_local_ranks(argv, nproc, master_port=None, extra_env=None, timeout=No
             if code is None:
                 continue
             live.remove(p)
-            if code != 0 and rc == 0:
+            if p is procs[0] and code == 0:
+                rank0_done_at = time.monotonic()
+            if code != 0 and rc == 0 and rank0_done_at is None:
                 rc = code
-        if rc != 0 or (deadline is not None and time.monotonic() > deadline):
+        straggling = rank0_done_at is not None and time.monotonic() > rank0_done_at + grace
+        if rc != 0 or straggling or (deadline is not None and time.monotonic() > deadline):
             for p in live:
                 p.kill()
             for p in live:
                 p.wait()
-            return rc or 124
+            return rc if (rc or straggling) else 124
         time.sleep(0.05)
     return rc
 
