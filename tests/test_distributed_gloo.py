@@ -116,3 +116,19 @@ def test_launcher_passes_rank_zero_stdout_through(tmp_path):
     assert r.returncode == 0
     assert r.stdout.strip() == "line from rank 0 0"           # one line on stdout: rank 0's
     assert "line from rank 1 1" in r.stderr
+
+
+def test_bench_result_line_survives_failing_and_hanging_multi_gpu_extras():
+    """bench.py's N > 1 extras run under `guarded`: an exception is named in the line, a hang ends with the line printed"""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.guarded(None, {"metric": "m"}, lambda: (1, 2)) == (1, 2)
+    res = bench.guarded(None, {"metric": "m"}, lambda: 1 // 0)
+    assert "ZeroDivisionError" in res["error"]
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; "
+            "bench.guarded(None, {'metric': 'm', 'value': 1.0}, lambda: time.sleep(60), limit_s=0.5)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["metric"] == "m" and line["value"] == 1.0 and "did not finish" in line["gather"]["error"]
