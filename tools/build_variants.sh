@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fwrapv -fno-fast-math -w"
-VARIED="gc_encode_kernel gcadpcm_kernels hca_encode_kernel hca_decode_kernels"
+VARIED="${VARIED:-gc_encode_kernel gcadpcm_kernels hca_encode_kernel hca_decode_kernels}"
 mkdir -p tools/variants/obj
 for f in vgaudio_amd/csrc/*.hip; do
   b=$(basename $f .hip)

@@ -228,7 +228,8 @@ __device__ __forceinline__ void adx_load32(const int16_t *src, int64_t first, in
 // the header (CriAdxCodec.cs:23-27), pick the coefficient pair and turn every nibble into scale * nibble
 // (:33-35), laid out in LDS for conflict-free b128 reads; the decoder wave (lane = channel) keeps only the
 // recurrence (:36-45): mad, shift, add, clamp per sample.  The helpers also write the previous tile out.
-constexpr int ATF = 4;                                 // frames (of 32 samples) per tile
+constexpr int ATF = 4;                                 // frames (of 32 samples) per tile (2: 16.3, 1: 18.9 ms instead of 15.1 at
+                                                       // configs[2] -- twice / four times the pieces in flight, but a barrier every frame or two)
 struct AdxDecodeTile {
     int4 dist[ATF][8][64];                             // [frame][eighth][channel]: 32 x scale*nibble
     int2 coef[ATF][64];                                // [frame][channel]
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_tail_kernel(
 // (:120-138).  scale_short_to_nibble (:167-171) is done on the magnitude: |q| = ((|v| + 2340) * 114692) >> 29 is
 // floor((|v| + 2340) / 4681) for |v| <= 32768 (2^29 / 4681 = 114691.5.., error term 2340 per unit: exact below
 // 229 432), the result is at most 7 so Clamp4 and the Clamp16 of scale * q (scale <= 4096) cannot bind.
-constexpr int EATF = 2;                                // frames per tile
+constexpr int EATF = 2;                                // frames per tile (1: 35.5 instead of 27.0 ms at configs[2])
 constexpr int ECW = 128;                               // channels per workgroup: TWO encoder waves (on different SIMDs of the
                                                        // CU) and six helper waves; the double-buffered tiles fill one CU's LDS
 constexpr int ETHREADS = ECW * 4, EHELPERS = ETHREADS - ECW;

@@ -21,7 +21,8 @@
 namespace vga {
 namespace gc {
 
-constexpr int DTF = 4;                    // frames per tile
+constexpr int DTF = 4;                    // frames per tile (2 would fit two workgroups per CU, i.e. twice the pieces: 15.4
+                                          // instead of 10.0 ms at configs[1] -- the barrier every other frame costs more)
 constexpr int DCW = 128;                  // channels per workgroup: TWO decoder waves (they land on different SIMDs of the
                                           // CU; two 64-channel workgroups would put both of theirs on SIMD 0) + 6 helpers
 constexpr int DTHREADS = DCW * 4;
@@ -347,7 +348,8 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
     const int frames = (sample_count + 13) / 14;
     const int groups = (nch + DCW - 1) / DCW;
     const int cus = device_cu_count();
-    int segments = cus / groups;
+    const int per_cu = std::max(1, (int)((160 * 1024) / lds));
+    int segments = cus * per_cu / groups;
     if (segments > frames / 1024) segments = frames / 1024;
     if (segments < 1) segments = 1;
     // every seam is a chance of a run that never meets (see adx_kernels.hip): at most 16 pieces, or ~4000 seams per launch
