@@ -223,201 +223,186 @@ __device__ __forceinline__ void adx_load32(const int16_t *src, int64_t first, in
     }
 }
 
-// ---------------------------------------------------------------- 18-byte frames, serial wave + helper waves
-// Same division of labour as gc_decode_kernel.hip: three helper waves load the frames one tile ahead, split
-// the header (CriAdxCodec.cs:23-27), pick the coefficient pair and turn every nibble into scale * nibble
-// (:33-35), laid out in LDS for conflict-free b128 reads; the decoder wave (lane = channel) keeps only the
-// recurrence (:36-45): mad, shift, add, clamp per sample.  The helpers also write the previous tile out.
-constexpr int ATF = 4;                                 // frames (of 32 samples) per tile (2: 16.3, 1: 18.9 ms instead of 15.1 at
-                                                       // configs[2] -- twice / four times the pieces in flight, but a barrier every frame or two)
-struct AdxDecodeTile {
-    int4 dist[ATF][8][64];                             // [frame][eighth][channel]: 32 x scale*nibble
-    int2 coef[ATF][64];                                // [frame][channel]
-    int4 out[ATF][4][64];                              // [frame][quarter][channel]: 32 samples as 16 packed pairs
-};
-
-// Time segments (blockIdx.y), as in gc_decode_kernel.hip: a channel's stream is cut into pieces of `seg_frames`
-// frames (an even number: frame parity decides the load alignment) decoded side by side, every piece but the first
-// from a guessed history (0, 0); adx_decode_fs18_fixup_kernel then closes the seams.
+// ---------------------------------------------------------------- 18-byte frames: lane = channel, one wave per 64 channels and piece
+// CriAdxCodec.Decode (CriAdxCodec.cs:9-54) for the common shape (18-byte frames, no padding), without helper waves.
+// Time segments (blockIdx.y), as in gc_decode_kernel.hip: a channel's stream is cut into pieces of `seg_frames` frames (an
+// even number: frame parity decides the load alignment) decoded side by side, every piece but the first from a guessed
+// history -- (0, 0), 512 frames before the piece (see the warm-up below); adx_decode_fs18_fixup_kernel then closes the seams.
+// A lane reads its own frames two at a time (36 contiguous bytes from a dword boundary, the next pair in flight during
+// this one), takes the nibbles out of the loaded dwords with one v_bfe_i32 each, runs the recurrence (:36-45) and hands
+// its samples to the wave's LDS block, from which they leave as whole lines (below).
+// Rounds 1-2 had a serial wave + three helper waves here (the helpers unpacked scale * nibble into LDS tiles and wrote the
+// samples out): 100 KB of LDS per 64 channels, so one workgroup per CU, four pieces per channel at 4096 channels and a
+// quarter of the SIMDs busy -- 15.1 ms at configs[2].  This kernel: 8.0 ms, of which the recurrence is free: a build that
+// skips it takes 7.7 ms, i.e. the kernel runs at the rate its 23.6 GB of PCM can be written (3.0 TB/s).
+constexpr int ADX_DECODE_WARM_FRAMES = 512;           // even: a piece's frames keep their alignment
 template <bool V4>
-__global__ __launch_bounds__(256) void adx_decode_fs18_tiled_kernel(
+__global__ __launch_bounds__(64) void adx_decode_fs18_direct_kernel(
     const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, AdxDeviceParams p,
     int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ status)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    AdxDecodeTile *s_tile = reinterpret_cast<AdxDecodeTile *>(s_raw);          // [2]
-    const int tid = threadIdx.x;
-    const int ch0 = blockIdx.x * 64;
-    const int64_t first_frame = (int64_t)blockIdx.y * seg_frames;
+    const int64_t first_frame = (int64_t)blockIdx.y * seg_frames;          // even (seg_frames is)
     if (first_frame * 32 >= total_samples) return;
     const int sample_count = (int)((int64_t)total_samples - first_frame * 32 < (int64_t)seg_frames * 32
                                        ? (int64_t)total_samples - first_frame * 32 : (int64_t)seg_frames * 32);
-    adpcm += first_frame * 18;
-    pcm += first_frame * 32;
-    if (blockIdx.y > 0) p.history = 0;
     const int frame_count = (sample_count + 31) / 32;
-    const int tiles = (frame_count + ATF - 1) / ATF;
-
-    if (tid >= 64) {
-        // ------------------------------------------------------------ helper waves (192 lanes)
-        const int hl = tid - 64;
-        bool bad = false;
-        constexpr int ITEMS = (64 * ATF + 191) / 192;
-        struct Raw { uint32_t w[5]; };
-        auto load_tile = [&](int tile, Raw (&raw)[ITEMS]) {          // unconditional loads, clamped frame index
-#pragma unroll
-            for (int k = 0; k < ITEMS; k++) {
-                const int item = min(hl + 192 * k, 64 * ATF - 1);
-                const int c = item / ATF, j = item - c * ATF;
-                const int i = min(tile * ATF + j, frame_count - 1);
-                const int ch = min(ch0 + c, nch - 1);
-                const uint16_t *f = reinterpret_cast<const uint16_t *>(adpcm + (int64_t)ch * in_pitch) + (int64_t)i * 9;
-                // frames are 18 bytes: even frames start on a dword, odd ones two bytes after one
-                const uint32_t *f32 = reinterpret_cast<const uint32_t *>(f - (i & 1));
-                uint32_t t[5];
-#pragma unroll
-                for (int q = 0; q < 5; q++) t[q] = f32[q];
-                if (i & 1) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) raw[k].w[q] = (t[q] >> 16) | (t[q + 1] << 16);
-                    raw[k].w[4] = t[4] >> 16;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 5; q++) raw[k].w[q] = t[q];
-                }
-            }
-        };
-        auto prepare = [&](int tile, const Raw (&raw)[ITEMS]) {
-            AdxDecodeTile &T = s_tile[tile & 1];
-#pragma unroll
-            for (int k = 0; k < ITEMS; k++) {
-                const int item = hl + 192 * k;
-                if (item >= 64 * ATF) continue;
-                const int c = item / ATF, j = item - c * ATF;
-                if (tile * ATF + j >= frame_count) continue;
-                const uint32_t(&w)[5] = raw[k].w;
-                const int hb0 = w[0] & 0xff, hb1 = (w[0] >> 8) & 0xff;
-                int filter_num = ((hb0 >> 4) & 0xF) >> 1;
-                int cf0, cf1;
-                if (p.type == 2) {
-                    if (filter_num > 3) { bad = true; filter_num = 3; }
-                    cf0 = filter_num == 0 ? 0 : (filter_num == 1 ? 0x0F00 : (filter_num == 2 ? 0x1CC0 : 0x1880));
-                    cf1 = filter_num == 0 ? 0 : (filter_num == 1 ? 0 : (filter_num == 2 ? (int)(int16_t)0xF300 : (int)(int16_t)0xF240));
-                } else {
-                    if (filter_num > 0) bad = true;
-                    cf0 = p.coef0;
-                    cf1 = p.coef1;
-                }
-                int scale = (int)(int16_t)(((hb0 << 8) | hb1) & 0x1FFF);
-                scale = (int)(int16_t)(p.type == 4 ? (1 << ((12 - scale) & 31)) : scale + 1);
-                T.coef[j][c] = make_int2(cf0, cf1);
-                int d[32];
-#pragma unroll
-                for (int s = 0; s < 32; s++) {
-                    const int byte_index = 2 + (s >> 1);
-                    const int byte = (w[byte_index >> 2] >> (8 * (byte_index & 3))) & 0xff;
-                    const int nib = (s & 1) ? (byte & 0xF) : (byte >> 4);
-                    d[s] = scale * ((nib ^ 8) - 8);
-                }
-#pragma unroll
-                for (int q = 0; q < 8; q++) T.dist[j][q][c] = make_int4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
-            }
-        };
-        auto flush = [&](int tile) {
-            const AdxDecodeTile &T = s_tile[tile & 1];
-            for (int item = hl; item < 64 * ATF; item += 192) {
-                const int c = item / ATF, j = item - c * ATF;
-                const int i = tile * ATF + j;
-                if (i >= frame_count || ch0 + c >= nch) continue;
-                int16_t *dst = pcm + (int64_t)(ch0 + c) * pcm_pitch + (int64_t)i * 32;
-                const int to_read = min(32, sample_count - i * 32);
-                if (to_read == 32) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) reinterpret_cast<int4 *>(dst)[q] = T.out[j][q][c];
-                } else {
-                    for (int s = 0; s < to_read; s++) {
-                        const int4 v = T.out[j][s >> 3][c];
-                        const int pair = (s >> 1) & 3;
-                        const uint32_t wv = (uint32_t)(pair == 0 ? v.x : pair == 1 ? v.y : pair == 2 ? v.z : v.w);
-                        dst[s] = (int16_t)(wv >> (16 * (s & 1)));
-                    }
-                }
-            }
-        };
-        Raw ra[ITEMS], rb[ITEMS];
-        load_tile(0, ra);
-        load_tile(1, rb);
-        if (tiles > 0) prepare(0, ra);
-        lds_barrier();
-        for (int tile = 0; tile < tiles; tile += 2) {
-            load_tile(tile + 2, ra);
-            if (tile + 1 < tiles) prepare(tile + 1, rb);
-            if (tile > 0) flush(tile - 1);
-            lds_barrier();
-            if (tile + 1 < tiles) {
-                load_tile(tile + 3, rb);
-                if (tile + 2 < tiles) prepare(tile + 2, ra);
-                flush(tile);
-                lds_barrier();
-            }
-        }
-        if (tiles > 0) flush(tiles - 1);
-        if (bad && status) atomicOr(status, 1);
-        return;
-    }
-
-    // ---------------------------------------------------------------- decoder wave: lane = channel
-    __builtin_amdgcn_s_setprio(3);
-    int hist1 = p.history, hist2 = p.history;
-    struct Row { int2 cf; int4 q[8]; };
-    auto read_row = [&](const AdxDecodeTile &T, int j, Row &R) {
-        R.cf = T.coef[j][tid];
-#pragma unroll
-        for (int q = 0; q < 8; q++) R.q[q] = T.dist[j][q][tid];
+    const int ch_raw = blockIdx.x * 64 + threadIdx.x;
+    const bool live = ch_raw < nch;
+    const int ch = live ? ch_raw : nch - 1;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(adpcm + (int64_t)ch * in_pitch + first_frame * 18);
+    int16_t *dst = pcm + (int64_t)ch * pcm_pitch + first_frame * 32;
+    int hist1 = blockIdx.y > 0 ? 0 : p.history, hist2 = hist1;             // later pieces: the guess (0, 0)
+    bool bad = false;
+    // Output: lane = channel holds one 64-byte line per frame; stored as it is, every store instruction would touch 64
+    // rows, 16 bytes of each (measured: 20 of the kernel's 23 ms).  TURN frames of every channel (TURN x 64 contiguous
+    // bytes of its row) are collected in the wave's own LDS and written out turned: LPR lanes per row, 64 / LPR rows per
+    // store instruction.  One wave per workgroup and LDS operations of a wave complete in order: no barrier.
+    constexpr int TURN = 2;                                                // (4 and 8 frames per block: no faster)
+    constexpr int LPR = TURN * 4;                                          // lanes (16 bytes each) per row
+    constexpr int RPI = 64 / LPR;                                          // rows per store instruction
+    __shared__ int4 s_turn[64 * (LPR + 1)];                                // rows one int4 apart from a multiple of 8: no conflicts
+    const int lane = threadIdx.x;
+    // Rows past the last channel: those lanes decode channel nch - 1 again (`ch` above), so their lines ARE that channel's
+    // and go to its row once more -- which keeps the stores unconditional: behind a branch hipcc can no longer count them
+    // and waits for ALL outstanding stores before it touches the prefetched frames (s_waitcnt vmcnt counts both).
+    auto turned_row = [&](int i) {
+        const int c = blockIdx.x * 64 + lane / LPR + RPI * i;
+        return pcm + (int64_t)(c < nch ? c : nch - 1) * pcm_pitch + first_frame * 32 + (lane % LPR) * 8;
     };
-    auto decode_frame = [&](AdxDecodeTile &T, int j, const Row &R) {
+    // one frame whose 18 bytes are w[0 .. 4] (little-endian dwords, two bytes of slack)
+    auto decode_frame = [&](const uint32_t (&w)[5], auto mode_tag, int frame, int valid) {
+        constexpr int MODE = decltype(mode_tag)::value;          // 0: whole frame, stored turned; 1: whole frame, stored by its lane; 2: partial; 3: not stored (warm-up)
+        const int hb0 = w[0] & 0xff, hb1 = (w[0] >> 8) & 0xff;
+        int filter_num = ((hb0 >> 4) & 0xF) >> 1;
+        int cf0, cf1;
+        if (p.type == 2) {
+            if (filter_num > 3) { bad = true; filter_num = 3; }
+            cf0 = filter_num == 0 ? 0 : (filter_num == 1 ? 0x0F00 : (filter_num == 2 ? 0x1CC0 : 0x1880));
+            cf1 = filter_num == 0 ? 0 : (filter_num == 1 ? 0 : (filter_num == 2 ? (int)(int16_t)0xF300 : (int)(int16_t)0xF240));
+        } else {
+            if (filter_num > 0) bad = true;
+            cf0 = p.coef0;
+            cf1 = p.coef1;
+        }
+        int scale = (int)(int16_t)(((hb0 << 8) | hb1) & 0x1FFF);
+        scale = (int)(int16_t)(p.type == 4 ? (1 << ((12 - scale) & 31)) : scale + 1);
         int o[32];
 #pragma unroll
         for (int s = 0; s < 32; s++) {
-            const int4 v4 = R.q[s >> 2];
-            const int dist = (s & 3) == 0 ? v4.x : (s & 3) == 1 ? v4.y : (s & 3) == 2 ? v4.z : v4.w;
+            const int b = 2 + (s >> 1);                                    // the byte that holds sample s: high nibble first
+            const int nib = __builtin_amdgcn_sbfe((int)w[b >> 2], 8 * (b & 3) + ((s & 1) ? 0 : 4), 4);
             int sample;
             if (V4) {                                  // :38-39
-                int rest = __mul24(hist2, R.cf.y);
+                int rest = __mul24(hist2, cf1);
                 asm("" : "+v"(rest));
-                sample = dist + ((__mul24(hist1, R.cf.x) + rest) >> 12);
+                sample = __mul24(scale, nib) + ((__mul24(hist1, cf0) + rest) >> 12);
             } else {                                   // :41-42
-                int rest = (__mul24(hist2, R.cf.y) >> 12) + dist;
+                int rest = (__mul24(hist2, cf1) >> 12) + __mul24(scale, nib);
                 asm("" : "+v"(rest));
-                sample = (__mul24(hist1, R.cf.x) >> 12) + rest;
+                sample = (__mul24(hist1, cf0) >> 12) + rest;
             }
             const int fin = clamp16(sample);
             hist2 = hist1;                             // a partial last frame runs on: nothing reads the history after it
             hist1 = fin;
             o[s] = fin;
         }
+        if (MODE == 0) {
+            int4 *mine = s_turn + lane * (LPR + 1) + (frame % TURN) * 4;
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            T.out[j][q][tid] = make_int4((o[8 * q] & 0xFFFF) | (o[8 * q + 1] << 16), (o[8 * q + 2] & 0xFFFF) | (o[8 * q + 3] << 16),
-                                         (o[8 * q + 4] & 0xFFFF) | (o[8 * q + 5] << 16), (o[8 * q + 6] & 0xFFFF) | (o[8 * q + 7] << 16));
-    };
-    lds_barrier();                                     // tile 0 prepared
-    for (int tile = 0; tile < tiles; tile++) {
-        AdxDecodeTile &T = s_tile[tile & 1];
-        const int nf = min(ATF, frame_count - tile * ATF);
-        Row RA, RB;
-        read_row(T, 0, RA);
-#pragma unroll 1
-        for (int j = 0; j < nf; j += 2) {
-            read_row(T, min(j + 1, ATF - 1), RB);
-            decode_frame(T, j, RA);
-            if (j + 1 < nf) {
-                read_row(T, min(j + 2, ATF - 1), RA);
-                decode_frame(T, j + 1, RB);
+            for (int q = 0; q < 4; q++)
+                mine[q] = make_int4((o[8 * q] & 0xFFFF) | (o[8 * q + 1] << 16), (o[8 * q + 2] & 0xFFFF) | (o[8 * q + 3] << 16),
+                                    (o[8 * q + 4] & 0xFFFF) | (o[8 * q + 5] << 16), (o[8 * q + 6] & 0xFFFF) | (o[8 * q + 7] << 16));
+            if (frame % TURN == TURN - 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < LPR; i++)            // read, wait, store -- one at a time: LPR stores back to back were
+                    *reinterpret_cast<int4 *>(turned_row(i) + (int64_t)(frame - (TURN - 1)) * 32) =       // 5 ms slower
+                        s_turn[(lane / LPR + RPI * i) * (LPR + 1) + lane % LPR];
+                asm volatile("" ::: "memory");
             }
+        } else if (MODE == 1) {
+            if (live) {
+                int16_t *d = dst + (int64_t)frame * 32;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    reinterpret_cast<int4 *>(d)[q] =
+                        make_int4((o[8 * q] & 0xFFFF) | (o[8 * q + 1] << 16), (o[8 * q + 2] & 0xFFFF) | (o[8 * q + 3] << 16),
+                                  (o[8 * q + 4] & 0xFFFF) | (o[8 * q + 5] << 16), (o[8 * q + 6] & 0xFFFF) | (o[8 * q + 7] << 16));
+            }
+        } else if (MODE == 2 && live) {
+            int16_t *d = dst + (int64_t)frame * 32;
+#pragma unroll
+            for (int s2 = 0; s2 < 32; s2++)
+                if (s2 < valid) d[s2] = (int16_t)o[s2];
         }
-        lds_barrier();
+    };
+    // ---- warm-up of a later piece: the WARM frames before it are decoded from the guess (0, 0) and not stored, so that the
+    // piece itself starts from a history that has, as a rule, already fallen into step with the true run (the decoder
+    // forgets a wrong history within 2000 samples on audio): its seam then closes on the first frame the fix-up launch
+    // checks (15 seams per channel at configs[2]: 3.7 ms of fix-up without this, against 7.9 ms for the decode itself)
+    if (blockIdx.y > 0) {
+        const int warm = (int)(first_frame < ADX_DECODE_WARM_FRAMES ? first_frame : ADX_DECODE_WARM_FRAMES);      // even
+        const uint32_t *wsrc = src - (int64_t)warm / 2 * 9;
+#pragma unroll 1
+        for (int k = 0; k < warm / 2; k++) {
+            uint32_t c9[9];
+#pragma unroll
+            for (int q = 0; q < 9; q++) c9[q] = wsrc[(int64_t)k * 9 + q];
+            const uint32_t a[5] = {c9[0], c9[1], c9[2], c9[3], c9[4]};
+            const uint32_t b[5] = {(c9[4] >> 16) | (c9[5] << 16), (c9[5] >> 16) | (c9[6] << 16), (c9[6] >> 16) | (c9[7] << 16),
+                                   (c9[7] >> 16) | (c9[8] << 16), c9[8] >> 16};
+            decode_frame(a, std::integral_constant<int, 3>{}, 0, 32);
+            decode_frame(b, std::integral_constant<int, 3>{}, 0, 32);
+        }
     }
+    // ---- whole pairs of full frames: 36 bytes from a dword boundary, the next pair's loads in flight meanwhile
+    const int full_pairs = (sample_count / 32) / TURN * (TURN / 2);          // whole blocks of TURN full frames
+    uint32_t cur[9], nxt[9];
+    {
+        const uint32_t *f = src;                                           // pair 0 (or, with no pair at all, five dwords of
+        const int nq = full_pairs > 0 ? 9 : 5;                             // the row's first frame: unused)
+#pragma unroll
+        for (int q = 0; q < 9; q++) cur[q] = q < nq ? f[q] : 0u;
+        // the first pair is waited for HERE: left to the loop header, the wait would also sit on the back edge, where it
+        // means "every store of the pair before has completed"
+#pragma unroll
+        for (int q = 0; q < 9; q++) asm volatile("" : "+v"(cur[q]));
+    }
+#pragma unroll 1
+    for (int k = 0; k < full_pairs; k++) {
+        const uint32_t *f = src + (int64_t)min(k + 1, full_pairs - 1) * 9;
+#pragma unroll
+        for (int q = 0; q < 9; q++) nxt[q] = f[q];
+        const uint32_t a[5] = {cur[0], cur[1], cur[2], cur[3], cur[4]};
+        // the second frame starts two bytes into cur[4]
+        const uint32_t b[5] = {(cur[4] >> 16) | (cur[5] << 16), (cur[5] >> 16) | (cur[6] << 16), (cur[6] >> 16) | (cur[7] << 16),
+                               (cur[7] >> 16) | (cur[8] << 16), cur[8] >> 16};
+        decode_frame(a, std::integral_constant<int, 0>{}, 2 * k, 32);
+        decode_frame(b, std::integral_constant<int, 0>{}, 2 * k + 1, 32);
+#pragma unroll
+        for (int q = 0; q < 9; q++) cur[q] = nxt[q];
+    }
+    // ---- what is left of the piece: fewer than TURN full frames and a partial one
+#pragma unroll 1
+    for (int i = 2 * full_pairs; i < frame_count; i++) {
+        // frame i starts at byte 18 i: on a dword for even i, two bytes after one for odd i
+        const uint32_t *f = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint16_t *>(src) + (int64_t)i * 9 - (i & 1));
+        uint32_t t[5], w[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) t[q] = f[q];
+        if (i & 1) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) w[q] = (t[q] >> 16) | (t[q + 1] << 16);
+            w[4] = t[4] >> 16;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 5; q++) w[q] = t[q];
+        }
+        const int valid = min(32, sample_count - i * 32);
+        if (valid == 32) decode_frame(w, std::integral_constant<int, 1>{}, i, 32);
+        else decode_frame(w, std::integral_constant<int, 2>{}, i, valid);
+    }
+    if (bad && live && status) atomicOr(status, 1);
 }
 
 // One frame of CriAdxCodec.Decode (:23-45) from the history (hist1, hist2) into o[0 .. valid).
@@ -1040,24 +1025,19 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
     const bool fast = p.frame_size == 18 && p.padding == 0 && (pcm_pitch % 8) == 0 && ((uintptr_t)d_pcm % 16) == 0 &&
                       (in_pitch % 4) == 0 && ((uintptr_t)d_adpcm % 4) == 0;
     if (fast) {
-        const size_t lds = 2 * sizeof(AdxDecodeTile);
-        if (p.version == 4) VGA_HIP_TRY(allow_dynamic_lds(adx_decode_fs18_tiled_kernel<true>, lds));
-        else VGA_HIP_TRY(allow_dynamic_lds(adx_decode_fs18_tiled_kernel<false>, lds));
-        // as many time segments as fill the device once (one workgroup of this LDS size per CU), each at least 512
-        // frames long and an even number of frames
+        // as many time pieces as put ONE wave on every SIMD (a wave = 64 channels of one piece), each at least 512 frames long
+        // and an even number of frames.  The kernel is bound by its stores, and what the memory system holds open is one
+        // row position per (channel, piece): at configs[2] 8 / 16 / 32 / 64 pieces take 8.5 / 8.0 / 13.1 / 12.1 ms (and 12 or
+        // 24, which leave some SIMDs with two waves and some with one, 11 ms)
         const int groups = (nch + 63) / 64;
         const int cus = device_cu_count();
         const int frames = (sample_count + 31) / 32;
-        const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
-        int segments = cus * per_cu / groups;
+        int segments = cus * 4 / groups;
         if (segments > frames / 512) segments = frames / 512;
         if (segments < 1) segments = 1;
-        // at most 16 pieces: a seam that is still open at the end of its piece (an integer IIR can keep two runs one LSB
-        // apart for good) sends its channel to the serial tail kernel -- up to 220 ms for a 60 s channel -- and every
-        // piece boundary is one more chance of that: 256-channel chunks cut into 64 pieces hit it twice in 4096 channels
-        // (profiles/r02_c_adx_decode_timeline_open_seams.log)
-        // (a few channels may have more: the seams of a launch stay below ~4000 there)
-        if (segments > std::max(16, 4096 / nch)) segments = std::max(16, 4096 / nch);
+        // every piece boundary is a seam that may still be open at the end of its piece (an integer IIR can keep two runs
+        // one LSB apart for good; the tail kernel then decodes the next piece again from the true history, piece after
+        // piece while the runs stay apart): at most 64 pieces
         if (segments > 64) segments = 64;
         if (encoder_segments_override() > 0) segments = std::min(std::max(frames / 8, 1), encoder_segments_override());   // test hook
         int seg_frames = (frames + segments - 1) / segments;
@@ -1074,7 +1054,7 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
         }
 #define VGA_ADX_DEC_T(V)                                                                                                 \
         {                                                                                                                \
-            hipLaunchKernelGGL(adx_decode_fs18_tiled_kernel<V>, dim3(groups, segments), dim3(256), lds, stream, d_adpcm, \
+            hipLaunchKernelGGL(adx_decode_fs18_direct_kernel<V>, dim3(groups, segments), dim3(64), 0, stream, d_adpcm,   \
                                in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status);                  \
             VGA_HIP_TRY(hipGetLastError());                                                                              \
             if (segments > 1) {                                                                                          \
