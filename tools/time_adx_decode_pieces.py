@@ -1,5 +1,7 @@
-import sys, ctypes as C, torch
-sys.path.insert(0, '/root/repo')
+"""ADX decode at configs[2] (4096 channels x 60 s) for several numbers of time pieces per channel (0 = the launcher's choice),
+through vga_testing_gc_encoder_segments_this_thread.  Honours VGAUDIO_HIP_LIBRARY (tools/variants/)."""
+import os, sys, ctypes as C, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vgaudio_amd import _lib, device as vdev
 L = _lib.lib(); d = torch.device("cuda:0"); n = 2880000; nch = 4096
 st = torch.cuda.current_stream().cuda_stream
