@@ -468,3 +468,28 @@ def test_short_pieces_leave_seams_open_and_the_chain_closes_them(n):
                 assert np.array_equal(out[:, :nb].cpu().numpy(), np.asarray(wa)[:, :nb]), (segments, mode)
     finally:
         L.vga_testing_gc_encoder_segments_this_thread(0)
+
+
+def test_decode_into_rows_that_are_only_dword_aligned():
+    """include/vgaudio_hip.h promises rows of samples on 4-byte boundaries and an even pitch, no more: the decoder's
+    16-byte stores of whole runs are for rows that happen to sit on 16-byte boundaries, every other layout takes its
+    dword path -- same samples (several pieces, ragged tail, 70 channels = a wave that is not full)"""
+    import torch
+    from vgaudio_amd import device as vdev
+    d = torch.device("cuda:0")
+    nch, n = 70, 14 * 9000 + 5
+    pcm = vdev.synth_pcm(nch, n, d)
+    coefs = vdev.gc_coefs(pcm, n)
+    adpcm = vdev.gc_encode(pcm, n, coefs)
+    want, st0 = vdev.gc_decode(adpcm, coefs, n)
+    host = po.gc_decode_batch(adpcm[:, :vdev.gc_byte_count(n)].cpu().numpy(), coefs.cpu().numpy().reshape(nch, 16), n, threads=4)
+    assert np.array_equal(want[:, :n].cpu().numpy(), host) and int(want[:, n:].abs().sum()) == 0
+    for pitch_extra, shift in ((2, 0), (0, 2), (6, 6)):                  # pitch % 8 != 0, base % 16 != 0, both
+        pitch = (n + 7) // 8 * 8 + 8 + pitch_extra
+        buf = torch.zeros(nch * pitch + 16, dtype=torch.int16, device=d)
+        out = buf[shift:shift + nch * pitch].view(nch, pitch)
+        assert (out.data_ptr() % 16 != 0) or (pitch % 8 != 0)
+        got, st = vdev.gc_decode(adpcm, coefs, n, out=out)
+        torch.cuda.synchronize()
+        assert int(st.item()) == 0 and np.array_equal(got[:, :n].cpu().numpy(), host), (pitch_extra, shift)
+        assert int(buf[:shift].abs().sum()) == 0 and int(out[:, n:].abs().sum()) == 0       # nothing outside the rows' samples

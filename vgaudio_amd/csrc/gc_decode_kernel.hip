@@ -1,16 +1,14 @@
-// gc_decode_kernel.hip -- GC-ADPCM decoder for gfx950, serial wave + helper waves.
+// gc_decode_kernel.hip -- GC-ADPCM decoder for gfx950.
 //
 // Replaces VGAudio/Codecs/GcAdpcm/GcAdpcmDecoder.cs:10-54, bit-exact.
 //
-// The decoder is a second-order IIR with saturation and a truncating shift per sample (:38-45): serial
-// inside a channel, and 4096 channels are only 64 waves -- so time = frames x (instructions per frame on
-// the wave that carries the recurrence).  As in gc_encode_kernel.hip everything that does not depend on the
-// history leaves that wave:
-//   helper waves (3 per workgroup), one tile of frames AHEAD: load the 8-byte frames, split the header
-//     (:25-29), look the coefficient pair up, turn every nibble into scale * nibble + 1024 (:36-37, :41 with
-//     the rounding constant folded in) and lay all of it out in LDS so that the decoder's reads are one
-//     conflict-free b128 per lane; they also write the previous tile's samples to global memory;
-//   decoder wave (lane = channel, 64 channels per workgroup): per sample mad, mad, shift, clamp.
+// The decoder is a second-order IIR with saturation and a truncating shift per sample (:38-45): serial inside a
+// channel.  Lane = channel; a channel's stream is cut into time pieces decoded side by side (every piece but the first
+// from a guessed history), gc_decode_fixup_kernel closes the seams, gc_decode_tail_kernel chains the ones that stay
+// open.  Rounds 1-2 split the work between a serial wave and three helper waves through LDS tiles (the helpers unpacked
+// scale * nibble + 1024 and wrote the samples out); the tiles' 108 KB per 128 channels limited a CU to one workgroup and
+// 4096 channels to eight pieces.  The kernel below needs no helpers: 9.9 -> 8.1 ms at configs[1] -- the rate at which
+// 23.6 GB of samples can be written -- and 4.4 -> 1.2 ms for 256 channels.
 #include "common.hpp"
 
 #include <algorithm>
@@ -21,201 +19,170 @@
 namespace vga {
 namespace gc {
 
-constexpr int DTF = 4;                    // frames per tile (2 would fit two workgroups per CU, i.e. twice the pieces: 15.4
-                                          // instead of 10.0 ms at configs[1] -- the barrier every other frame costs more)
-constexpr int DCW = 128;                  // channels per workgroup: TWO decoder waves (they land on different SIMDs of the
-                                          // CU; two 64-channel workgroups would put both of theirs on SIMD 0) + 6 helpers
-constexpr int DTHREADS = DCW * 4;
-constexpr int DHELPERS = DTHREADS - DCW;
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
-struct GcDecodeTile {
-    int4 dist[DTF][4][DCW];                // [frame][quarter][channel]: 14 x (scale*nibble + 1024), 2 padding
-    int2 coef[DTF][DCW];                   // [frame][channel]: (coef1, coef2) of the frame's predictor
-    int4 out[DTF][2][DCW];                 // [frame][half][channel]: 14 samples as 7 packed pairs, 1 padding
-};
-
-// Time segments (blockIdx.y): a channel's stream is cut into pieces of `seg_frames` frames that are decoded side by
-// side.  Segment 0 starts from the caller's history; the others start from (0, 0) -- a guess -- and
-// gc_decode_fixup_kernel afterwards re-decodes the head of each until its history meets the guessed run's.
-__global__ __launch_bounds__(DTHREADS) void gc_decode_kernel(
+// ---------------------------------------------------------------------------------------------------------------
+// Lane = channel, one wave per 64 channels and time piece, as many pieces as put one wave on every SIMD (the ADX decoder
+// in adx_kernels.hip has the measurements behind this shape).  A lane reads its own
+// frames eight at a time (64 contiguous bytes, the next block in flight during this one), takes the nibbles out of the
+// loaded dwords with one v_bfe_i32 each, looks its coefficient pair up in the wave's LDS table and runs the recurrence
+// (:38-45).  The 8 x 28 bytes of samples a lane produces per block are contiguous in its row; they leave through the
+// wave's LDS block turned, fourteen lanes per row, as 16-byte stores of whole 224-byte runs (TURNED; rows that are not
+// 16-byte aligned are stored by their own lane, a dword at a time).  Later pieces start from the guess (0, 0) GC_DECODE_WARM
+// frames early without storing, so that they have, as a rule, fallen into step with the true run where they begin and
+// their seam closes on the first frame gc_decode_fixup_kernel checks.
+constexpr int GC_DECODE_WARM = 512;                  // frames; a multiple of 8
+template <bool TURNED>
+__global__ __launch_bounds__(64) void gc_decode_direct_kernel(
     const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
     int total_samples, int seg_frames, const int16_t *__restrict__ hist1, const int16_t *__restrict__ hist2,
     int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ status)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    GcDecodeTile *s_tile = reinterpret_cast<GcDecodeTile *>(s_raw);            // [2]
-    int16_t *s_coefs = reinterpret_cast<int16_t *>(s_raw + 2 * sizeof(GcDecodeTile));   // [DCW][16]: the coefficient sets of the workgroup's DCW (= 128) channels
-
-    const int tid = threadIdx.x;
-    const int ch0 = blockIdx.x * DCW;
-    // this workgroup's segment, seen as a stream of its own: frames are 8 bytes / 14 samples, so both rows stay
-    // aligned (28-byte sample offsets for the dword stores, 8-byte frame offsets for the loads)
-    const int64_t first_frame = (int64_t)blockIdx.y * seg_frames;
+    const int64_t first_frame = (int64_t)blockIdx.y * seg_frames;          // a multiple of 8 (seg_frames is)
     const int64_t first_sample = first_frame * 14;
     if (first_sample >= total_samples) return;
     const int sample_count = (int)((int64_t)total_samples - first_sample < (int64_t)seg_frames * 14
                                        ? (int64_t)total_samples - first_sample : (int64_t)seg_frames * 14);
-    adpcm += first_frame * 8;
-    pcm += first_sample;
-    if (blockIdx.y > 0) hist1 = hist2 = nullptr;
     const int full_frames = sample_count / 14;
     const int tail = sample_count - full_frames * 14;
-    const int frames = full_frames + (tail ? 1 : 0);
-    const int tiles = (frames + DTF - 1) / DTF;
-
-    for (int i = tid; i < DCW * 16; i += DTHREADS) {
-        const int c = imin(ch0 + (i >> 4), nch - 1);
-        s_coefs[i] = coefs[c * 16 + (i & 15)];
+    const int lane = threadIdx.x;
+    const int ch_raw = blockIdx.x * 64 + lane;
+    const bool live = ch_raw < nch;
+    const int ch = live ? ch_raw : nch - 1;
+    const uint8_t *src = adpcm + (int64_t)ch * adpcm_pitch + first_frame * 8;
+    int16_t *dst = pcm + (int64_t)ch * pcm_pitch + first_sample;
+    __shared__ uint32_t s_cf[8 * 64];                                      // [predictor][lane]: (coef1 & 0xFFFF) | coef2 << 16
+    __shared__ int4 s_turn[64 * 15];                                       // 64 rows of 14 int4 (8 frames), one int4 apart from a multiple of 8
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+        s_cf[q * 64 + lane] = (uint32_t)(uint16_t)coefs[ch * 16 + 2 * q] | ((uint32_t)(uint16_t)coefs[ch * 16 + 2 * q + 1] << 16);
+    int h1 = 0, h2 = 0;
+    if (blockIdx.y == 0) {
+        h1 = hist1 ? hist1[ch] : 0;
+        h2 = hist2 ? hist2[ch] : 0;
     }
-    __syncthreads();
-
-    if (tid >= DCW) {
-        // ------------------------------------------------------------ helper waves (192 lanes)
-        const int hl = tid - DCW;
-        bool bad = false;
-        // the lane's (up to 3) frames of a tile, loaded a whole tile period before they are unpacked:
-        // unconditional loads with a clamped frame index (a load under a divergent condition is waited for
-        // at once, and the helpers would then pay three HBM round trips per tile)
-        constexpr int ITEMS = (DCW * DTF + DHELPERS - 1) / DHELPERS;
-        auto load_tile = [&](int tile, uint2 (&raw)[ITEMS]) {
-#pragma unroll
-            for (int k = 0; k < ITEMS; k++) {
-                const int item = imin(hl + DHELPERS * k, DCW * DTF - 1);
-                const int c = item / DTF, j = item - c * DTF;
-                const int fr = imin(tile * DTF + j, imax(full_frames - 1, 0));
-                const int ch = imin(ch0 + c, nch - 1);
-                // (no full frame at all: frame 0's 8 bytes still lie inside the row -- pitch is a multiple of 8)
-                raw[k] = *reinterpret_cast<const uint2 *>(adpcm + (int64_t)ch * adpcm_pitch + (int64_t)fr * 8);
-            }
-        };
-        auto prepare = [&](int tile, const uint2 (&raw)[ITEMS]) {
-            GcDecodeTile &T = s_tile[tile & 1];
-#pragma unroll
-            for (int k = 0; k < ITEMS; k++) {
-                const int item = hl + DHELPERS * k;
-                if (item >= DCW * DTF) continue;
-                const int c = item / DTF, j = item - c * DTF;         // consecutive lanes: consecutive frames
-                const int fr = tile * DTF + j;
-                if (fr >= frames) continue;
-                uint64_t bits = ((uint64_t)raw[k].y << 32) | raw[k].x;
-                if (fr >= full_frames) {                               // partial last frame: only its bytes exist
-                    const int ch = imin(ch0 + c, nch - 1);
-                    const uint8_t *src = adpcm + (int64_t)ch * adpcm_pitch + (int64_t)fr * 8;
-                    const int nbytes = (tail + 2 + 1) / 2;
-                    bits = 0;
-                    for (int b = 0; b < nbytes; b++) bits |= (uint64_t)src[b] << (8 * b);
-                }
-                const int ps = (int)(bits & 0xFF);
-                const int scale = (1 << (ps & 0xF)) * 2048;            // :26
-                int predictor = (ps >> 4) & 0xF;                       // :27
-                if (predictor > 7) { bad = true; predictor &= 7; }
-                T.coef[j][c] = make_int2(s_coefs[c * 16 + predictor * 2], s_coefs[c * 16 + predictor * 2 + 1]);
-                int d[16];
-#pragma unroll
-                for (int s = 0; s < 14; s++) {
-                    const int byte = (int)((bits >> (8 * (1 + s / 2))) & 0xFF);
-                    const int nib = (s & 1) ? (byte & 0xF) : (byte >> 4);
-                    d[s] = scale * ((nib ^ 8) - 8) + 1024;             // SignedNibbles (Helpers.cs:50), :36, + the 1024 of :41
-                }
-                d[14] = d[15] = 0;
-#pragma unroll
-                for (int q = 0; q < 4; q++) T.dist[j][q][c] = make_int4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
-            }
-        };
-        auto flush = [&](int tile) {
-            const GcDecodeTile &T = s_tile[tile & 1];
-            for (int item = hl; item < DCW * DTF; item += DHELPERS) {
-                const int c = item / DTF, j = item - c * DTF;
-                const int fr = tile * DTF + j;
-                if (fr >= frames || ch0 + c >= nch) continue;
-                const int4 a = T.out[j][0][c], b = T.out[j][1][c];
-                const uint32_t w[7] = {(uint32_t)a.x, (uint32_t)a.y, (uint32_t)a.z, (uint32_t)a.w,
-                                       (uint32_t)b.x, (uint32_t)b.y, (uint32_t)b.z};
-                int16_t *dst = pcm + (int64_t)(ch0 + c) * pcm_pitch + (int64_t)fr * 14;
-                if (fr < full_frames) {
-                    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
-#pragma unroll
-                    for (int i = 0; i < 7; i++) d32[i] = w[i];
-                } else {
-                    for (int s = 0; s < tail; s++) dst[s] = (int16_t)(w[s >> 1] >> (16 * (s & 1)));
-                }
-            }
-        };
-        uint2 ra[ITEMS], rb[ITEMS];                    // ping-pong: tile t+1 being unpacked, tile t+2 in flight
-        load_tile(0, ra);
-        load_tile(1, rb);
-        if (tiles > 0) prepare(0, ra);
-        lds_barrier();
-        for (int tile = 0; tile < tiles; tile += 2) {
-            load_tile(tile + 2, ra);
-            if (tile + 1 < tiles) prepare(tile + 1, rb);
-            if (tile > 0) flush(tile - 1);
-            lds_barrier();
-            if (tile + 1 < tiles) {
-                load_tile(tile + 3, rb);
-                if (tile + 2 < tiles) prepare(tile + 2, ra);
-                flush(tile);
-                lds_barrier();
-            }
-        }
-        if (tiles > 0) flush(tiles - 1);
-        if (bad && status) atomicOr(status, 1);
-        return;
-    }
-
-    // ---------------------------------------------------------------- decoder wave: lane = channel
-    __builtin_amdgcn_s_setprio(3);
-    const int ch = imin(ch0 + tid, nch - 1);
-    int h1 = hist1 ? hist1[ch] : 0;
-    int h2 = hist2 ? hist2[ch] : 0;
-    lds_barrier();                                   // tile 0 prepared
-    struct Row { int2 cf; int4 q0, q1, q2, q3; };
-    auto read_row = [&](const GcDecodeTile &T, int j, Row &R) {
-        R.cf = T.coef[j][tid];
-        R.q0 = T.dist[j][0][tid]; R.q1 = T.dist[j][1][tid]; R.q2 = T.dist[j][2][tid]; R.q3 = T.dist[j][3][tid];
-    };
-    auto decode_frame = [&](GcDecodeTile &T, int j, const Row &R) {
-        const int d[14] = {R.q0.x, R.q0.y, R.q0.z, R.q0.w, R.q1.x, R.q1.y, R.q1.z, R.q1.w,
-                           R.q2.x, R.q2.y, R.q2.z, R.q2.w, R.q3.x, R.q3.y};
+    bool bad = false;
+    // one frame (bits = its 8 bytes, little-endian) -> 14 samples as 7 packed pairs
+    auto decode_frame = [&](uint32_t lo, uint32_t hi, uint32_t (&o7)[7]) {
+        const int ps = (int)(lo & 0xFF);
+        const int sh = (ps & 0xF) + 11;                                    // scale = (1 << (ps & 0xF)) * 2048 (:26)
+        int predictor = (ps >> 4) & 0xF;                                   // :27
+        if (predictor > 7) { bad = true; predictor &= 7; }
+        const uint32_t cf = s_cf[predictor * 64 + lane];
+        const int c1 = (int)(int16_t)(cf & 0xFFFF), c2 = (int)cf >> 16;
         int o[14];
 #pragma unroll
         for (int s = 0; s < 14; s++) {
-            // :38-45: (coef1*hist1 + coef2*hist2 + distance + 1024) >> 11, clamped; int32 wrap like the reference.
-            // Two mads: the hist2 term is ready one sample early, so the dependent chain is mad, shift, clamp.
-            int rest = __mul24(R.cf.y, h2) + d[s];
+            const int b = 1 + (s >> 1);                                    // the byte that holds sample s: high nibble first
+            const uint32_t w = b < 4 ? lo : hi;
+            const int nib = __builtin_amdgcn_sbfe((int)w, 8 * (b & 3) + ((s & 1) ? 0 : 4), 4);   // SignedNibbles (Helpers.cs:50)
+            // :38-45: (coef1*hist1 + coef2*hist2 + scale*nibble + 1024) >> 11, clamped; int32 wrap like the reference
+            int rest = __mul24(c2, h2) + (int)(((uint32_t)nib << sh) + 1024u);
             asm("" : "+v"(rest));
-            const int t = __mul24(R.cf.x, h1) + rest;
+            const int t = __mul24(c1, h1) + rest;
             const int v = imin(imax(t >> 11, -32768), 32767);
             h2 = h1;
             h1 = v;
             o[s] = v;
         }
-        // a partial last frame decodes all 14 positions here; the flush writes only the valid ones and the
-        // history is not used afterwards
-        T.out[j][0][tid] = make_int4((o[0] & 0xFFFF) | (o[1] << 16), (o[2] & 0xFFFF) | (o[3] << 16),
-                                     (o[4] & 0xFFFF) | (o[5] << 16), (o[6] & 0xFFFF) | (o[7] << 16));
-        T.out[j][1][tid] = make_int4((o[8] & 0xFFFF) | (o[9] << 16), (o[10] & 0xFFFF) | (o[11] << 16),
-                                     (o[12] & 0xFFFF) | (o[13] << 16), 0);
+#pragma unroll
+        for (int q = 0; q < 7; q++) o7[q] = (uint32_t)(o[2 * q] & 0xFFFF) | ((uint32_t)o[2 * q + 1] << 16);
     };
-    for (int tile = 0; tile < tiles; tile++) {
-        GcDecodeTile &T = s_tile[tile & 1];
-        const int nf = imin(DTF, frames - tile * DTF);
-        // two row register sets, ping-pong: the LDS reads of frame j+1 are in flight during frame j
-        Row RA, RB;
-        read_row(T, 0, RA);
+    auto turned_row = [&](int i, int l) {                                  // rows past the last channel: channel nch - 1 again,
+        const int c = blockIdx.x * 64 + l / 14 + 4 * i;                    // whose samples those lanes hold -- unconditional stores
+        return pcm + (int64_t)(c < nch ? c : nch - 1) * pcm_pitch + first_sample + (l % 14) * 8;
+    };
+    // ---- warm-up of a later piece (not stored)
+    if (blockIdx.y > 0) {
+        const int warm = (int)(first_frame < GC_DECODE_WARM ? first_frame : GC_DECODE_WARM);
+        const uint2 *wsrc = reinterpret_cast<const uint2 *>(src) - warm;
 #pragma unroll 1
-        for (int j = 0; j < nf; j += 2) {
-            read_row(T, imin(j + 1, DTF - 1), RB);
-            decode_frame(T, j, RA);
-            if (j + 1 < nf) {
-                read_row(T, imin(j + 2, DTF - 1), RA);
-                decode_frame(T, j + 1, RB);
+        for (int k = 0; k < warm; k += 4) {                                // warm is a multiple of 8
+            uint2 f[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) f[j] = wsrc[k + j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t o7[7];
+                decode_frame(f[j].x, f[j].y, o7);
             }
         }
-        lds_barrier();
     }
+    // ---- whole blocks of eight full frames
+    const int blocks = full_frames / 8;
+    const uint4 *bsrc = reinterpret_cast<const uint4 *>(src);
+    uint4 cur[4], nxt[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) cur[q] = blocks > 0 ? bsrc[q] : make_uint4(0, 0, 0, 0);
+    // the first block is waited for HERE, not at the loop header (where the wait would also mean "every store of the
+    // block before has completed")
+#pragma unroll
+    for (int q = 0; q < 4; q++) asm volatile("" : "+v"(cur[q].x), "+v"(cur[q].y), "+v"(cur[q].z), "+v"(cur[q].w));
+#pragma unroll 1
+    for (int k = 0; k < blocks; k++) {
+        const uint4 *f = bsrc + (int64_t)imin(k + 1, blocks - 1) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) nxt[q] = f[q];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            uint32_t d28[28];                                              // four frames = 112 bytes = seven int4
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint4 v = cur[2 * half + (j >> 1)];
+                uint32_t o7[7];
+                decode_frame((j & 1) ? v.z : v.x, (j & 1) ? v.w : v.y, o7);
+#pragma unroll
+                for (int q = 0; q < 7; q++) d28[7 * j + q] = o7[q];
+            }
+            if (TURNED) {
+#pragma unroll
+                for (int q = 0; q < 7; q++)
+                    s_turn[lane * 15 + half * 7 + q] = make_int4((int)d28[4 * q], (int)d28[4 * q + 1], (int)d28[4 * q + 2], (int)d28[4 * q + 3]);
+            } else if (live) {
+                uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + ((int64_t)k * 8 + half * 4) * 14);
+#pragma unroll
+                for (int q = 0; q < 28; q++) d32[q] = d28[q];
+            }
+        }
+        if (TURNED) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int l = imin(lane, 55);                                  // 4 rows x 14 lanes per store; the last eight lanes repeat lane 55's
+#pragma unroll
+            for (int i = 0; i < 16; i++)                                   // read, store -- one at a time (see adx_kernels.hip)
+                *reinterpret_cast<int4 *>(turned_row(i, l) + (int64_t)k * 8 * 14) = s_turn[(l / 14 + 4 * i) * 15 + l % 14];
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+    }
+    // ---- what is left of the piece: fewer than eight full frames and a partial one
+#pragma unroll 1
+    for (int fr = blocks * 8; fr < full_frames + (tail ? 1 : 0); fr++) {
+        uint32_t lo = 0, hi = 0;
+        if (fr < full_frames) {
+            const uint2 v = reinterpret_cast<const uint2 *>(src)[fr];
+            lo = v.x;
+            hi = v.y;
+        } else {                                                           // partial last frame: only its bytes exist
+            const int nbytes = (tail + 2 + 1) / 2;
+            uint64_t bits = 0;
+            for (int b = 0; b < nbytes; b++) bits |= (uint64_t)src[(int64_t)fr * 8 + b] << (8 * b);
+            lo = (uint32_t)bits;
+            hi = (uint32_t)(bits >> 32);
+        }
+        uint32_t o7[7];
+        decode_frame(lo, hi, o7);
+        if (!live) continue;
+        int16_t *d = dst + (int64_t)fr * 14;
+        if (fr < full_frames) {
+#pragma unroll
+            for (int q = 0; q < 7; q++) reinterpret_cast<uint32_t *>(d)[q] = o7[q];
+        } else {
+            for (int s2 = 0; s2 < tail; s2++) d[s2] = (int16_t)(o7[s2 >> 1] >> (16 * (s2 & 1)));
+        }
+    }
+    if (bad && live && status) atomicOr(status, 1);
 }
 
 // One frame of GcAdpcmDecoder.Decode (:25-45) from the history (h1, h2) into o[0 .. valid).
@@ -341,24 +308,25 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
                   hipStream_t stream)
 {
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
-    const size_t lds = 2 * sizeof(GcDecodeTile) + DCW * 16 * sizeof(int16_t);
-    VGA_HIP_TRY(allow_dynamic_lds(gc_decode_kernel, lds));
-    // As many time segments as fill the device once (one workgroup of this LDS size per CU, 64 channels each), each
-    // at least 1024 frames long so that the seams stay a small part of the work
+    // as many time pieces as put one wave on every SIMD (a wave = 64 channels of one piece), each at least 1024 frames long
+    // and a multiple of eight frames; at most 64 (every seam is a chance of a run that never meets, see adx_kernels.hip)
     const int frames = (sample_count + 13) / 14;
-    const int groups = (nch + DCW - 1) / DCW;
+    const int groups = (nch + 63) / 64;
     const int cus = device_cu_count();
-    const int per_cu = std::max(1, (int)((160 * 1024) / lds));
-    int segments = cus * per_cu / groups;
+    int segments = cus * 4 / groups;
     if (segments > frames / 1024) segments = frames / 1024;
     if (segments < 1) segments = 1;
-    // every seam is a chance of a run that never meets (see adx_kernels.hip): at most 16 pieces, or ~4000 seams per launch
-    const int piece_cap = 4096 / nch > 16 ? (4096 / nch > 64 ? 64 : 4096 / nch) : 16;
-    if (segments > piece_cap) segments = piece_cap;
+    if (segments > 64) segments = 64;
     if (encoder_segments_override() > 0) segments = std::min(std::max(frames / 8, 1), encoder_segments_override());   // test hook
-    const int seg_frames = (frames + segments - 1) / segments;
-    hipLaunchKernelGGL(gc_decode_kernel, dim3(groups, segments), dim3(DTHREADS), lds, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
-                       sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
+    const int seg_frames = ((frames + segments - 1) / segments + 7) / 8 * 8;
+    // rows of samples on 16-byte boundaries: whole 224-byte runs leave as 16-byte stores
+    const bool turned = (pcm_pitch % 8) == 0 && ((uintptr_t)d_pcm % 16) == 0;
+    if (turned)
+        hipLaunchKernelGGL(gc_decode_direct_kernel<true>, dim3(groups, segments), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
+                           sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
+    else
+        hipLaunchKernelGGL(gc_decode_direct_kernel<false>, dim3(groups, segments), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
+                           sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
     VGA_HIP_TRY(hipGetLastError());
     if (segments > 1) {
         AsyncBuf scratch;                              // freed (stream-ordered) on every exit path
