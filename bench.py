@@ -547,7 +547,8 @@ def run_gc(args, cx):
                 "other_kernels": {"gc_coefs_kernel": {
                     "launch_ms": round(coef_ms, 3),
                     "achieved": round(COEF_BYTES_PER_SAMPLE * nch * n / (coef_ms * 1e-3) / 1e9, 2) if coef_ms > 0 else 0.0},
-                    "gc_decode_kernel (+fixup, tail; not part of the step)": {
+                    "gc_decode_direct_kernel (+fixup, tail; not part of the step)": {
+                        "traffic": (pmc.get("gc_decode_direct_kernel") or {}).get("traffic_bytes_per_launch") if pmc and full else None,
                         "launch_ms": round(dec_ms, 3),
                         "achieved": round(ENC_BYTES_PER_SAMPLE * nch * n / (dec_ms * 1e-3) / 1e9, 2) if dec_ms > 0 else 0.0}},
                 "pipeline_achieved": round(PIPE_BYTES_PER_SAMPLE * nch * n / ((coef_ms + enc_ms) * 1e-3) / 1e9, 2)
@@ -653,9 +654,11 @@ def run_adx(args, cx):
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": pmc_note,
                 "algorithmic_bytes_per_launch": bytes_launch, "launch_ms": round(enc_ms, 3),
                 "launch_parts": ["adx_encode_fs18_tiled_kernel", "adx_encode_fs18_fixup_kernel", "adx_encode_fs18_tail_kernel"],
-                "other_kernels": {"adx_decode_fs18_tiled_kernel (+fixup, tail)": {
+                "other_kernels": {"adx_decode_fs18_direct_kernel (+fixup, tail)": {
                     "launch_ms": round(dec_ms, 3),
-                    "achieved": round(bytes_launch / (dec_ms * 1e-3) / 1e9, 2) if dec_ms > 0 else 0.0}},
+                    "achieved": round(bytes_launch / (dec_ms * 1e-3) / 1e9, 2) if dec_ms > 0 else 0.0,
+                    "traffic": (pmc.get("adx_decode_fs18_direct_kernel") or {}).get("traffic_bytes_per_launch")
+                    if pmc and nch == 4096 and n == 2880000 else None}},
                 "pipeline_achieved": round(2 * bytes_launch / ((enc_ms + dec_ms) * 1e-3) / 1e9, 2) if enc_ms + dec_ms > 0 else 0.0}
     cpu, verified = None, 0
     if not args.no_cpu_baseline and cx.world == 1:
