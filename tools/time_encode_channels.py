@@ -10,8 +10,9 @@ def t(f):
         a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
         a.record(); f(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     return min(ts)
-for nch, n in ((1, 480000), (1, 2880000), (2, 2880000), (8, 2880000), (64, 2880000), (512, 2880000), (2048, 2880000),
-               (4096, 2880000)):
+SHAPES = tuple((int(a), 2880000) for a in sys.argv[1:]) or ((1, 480000), (1, 2880000), (2, 2880000), (8, 2880000), (64, 2880000), (96, 2880000), (256, 2880000), (384, 2880000),
+          (512, 2880000), (1024, 2880000), (2048, 2880000), (4096, 2880000))
+for nch, n in SHAPES:
     pcm = vdev.synth_pcm(nch, n, d); coefs = vdev.gc_coefs(pcm, n); out = vdev.alloc_adpcm(nch, n, d)
     dec = vdev.alloc_pcm(nch, n, d)
     tc = t(lambda: vdev.gc_coefs(pcm, n)); te = t(lambda: vdev.gc_encode(pcm, n, coefs, out=out))
