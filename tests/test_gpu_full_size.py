@@ -272,3 +272,43 @@ def test_adx_encoder_with_short_pieces_chains_its_open_seams(n):
     finally:
         L.vga_testing_gc_encoder_segments_this_thread(0)
 
+
+
+@pytest.mark.parametrize("nch", [1, 63, 65])
+def test_decoders_block_boundaries(nch):
+    """The helper-free decoders work in blocks (GC: 8 frames of 14 samples, ADX: 2 frames of 32) with a per-frame path for
+    what is left of a piece and a partial last frame: lengths on, just before and just after every such boundary, one piece
+    and several, against the oracle"""
+    d = torch.device("cuda:0")
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    p = _lib.AdxParams()
+    L.vga_adx_default_params(C.byref(p))
+    lengths = sorted({base + k for base in (14 * 8 * 3, 32 * 2 * 5, 14 * 8 * 32 * 3) for k in (-33, -15, -14, -1, 0, 1, 13, 14, 31, 32, 45)} | {1, 13, 14, 15, 31, 32, 33})
+    for n in lengths:
+        pcm = vdev.synth_pcm(nch, n, d)
+        coefs = vdev.gc_coefs(pcm, n)
+        adpcm = vdev.gc_encode(pcm, n, coefs)
+        nb = L.vga_adx_encoded_byte_count(n, C.byref(p))
+        pitch = (nb + 15) // 16 * 16
+        adx = torch.zeros((nch, pitch), dtype=torch.uint8, device=d)
+        hist = torch.zeros(nch, dtype=torch.int16, device=d)
+        status = torch.zeros(1, dtype=torch.int32, device=d)
+        _lib.check(L.vga_adx_encode_device(pcm.data_ptr(), pcm.stride(0), nch, n, C.byref(p), adx.data_ptr(), pitch, hist.data_ptr(), st))
+        torch.cuda.synchronize()
+        want_gc = po.gc_decode_batch(adpcm[:, :vdev.gc_byte_count(n)].cpu().numpy(), coefs.cpu().numpy().reshape(nch, 16), n, threads=4)
+        want_adx = po.adx_decode_batch(adx[:, :nb].cpu().numpy(), n, po.adx_params(), threads=4)
+        for pieces in (0, 5):
+            L.vga_testing_gc_encoder_segments_this_thread(pieces)
+            try:
+                dec, s1 = vdev.gc_decode(adpcm, coefs, n)
+                back = vdev.alloc_pcm(nch, n, d)
+                _lib.check(L.vga_adx_decode_device(adx.data_ptr(), pitch, nb, nch, n, C.byref(p), back.data_ptr(), back.stride(0),
+                                                   status.data_ptr(), st))
+                torch.cuda.synchronize()
+            finally:
+                L.vga_testing_gc_encoder_segments_this_thread(0)
+            assert int(s1.item()) == 0 and int(status.item()) == 0
+            assert np.array_equal(dec[:, :n].cpu().numpy(), want_gc), (n, pieces)
+            assert np.array_equal(back[:, :n].cpu().numpy(), want_adx), (n, pieces)
+            assert int(dec[:, n:].abs().sum()) == 0 and int(back[:, n:].abs().sum()) == 0, (n, pieces)
