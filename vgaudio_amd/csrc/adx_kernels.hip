@@ -762,7 +762,7 @@ __device__ __forceinline__ void adx_encode_frame_words(const int (&x)[32], int &
         int pa = a, pb = b;
 #pragma unroll
         for (int j = 0; j < 32; j++) {
-            const int predicted = ((pb * c0) >> 12) + ((pa * c1) >> 12);
+            const int predicted = (__mul24(pb, c0) >> 12) + (__mul24(pa, c1) >> 12);     // 16-bit x 16-bit: exact in 24 bits
             int distance = clamp16(x[j] - predicted);
             distance = distance < 0 ? -distance : distance;
             max_distance = max(max_distance, distance);
@@ -774,26 +774,37 @@ __device__ __forceinline__ void adx_encode_frame_words(const int (&x)[32], int &
     int scale_out;
     const int scale = calculate_scale(max_distance, EXPONENTIAL, gain, scale_out);
     fw[0] = (uint32_t)((((scale_out >> 8) & 0x1f) | filter_bits) & 0xff) | ((uint32_t)(scale_out & 0xff) << 8);
-    int byte = 0;
+    // the quantise recurrence (:122-138) as the tiled kernel has it: 24-bit multiplies, ScaleShortToNibble on the magnitude
+    // (see there), and the RyuJIT overflow semantics of the cast only for a frame whose gain can push rawDistance past 2^31
+    // (a wave-uniform, practically never taken branch)
+    int qv[32];
+    auto quantise = [&](auto guard_c) __attribute__((always_inline)) {
+        constexpr bool GUARD = decltype(guard_c)::value;
 #pragma unroll
-    for (int j = 0; j < 32; j++) {
-        int predicted = ((b * c0) >> 12) + ((a * c1) >> 12);
-        const int raw = x[j] - predicted;
-        const int scaled = clamp16(trunc_i32_ryujit((double)raw * gain));
-        const int q = scale_short_to_nibble(scaled);
-        const int decoded_distance = clamp16(scale * q);
-        if (V4) predicted = (b * c0 + a * c1) >> 12;
-        const int rec = clamp16(decoded_distance + predicted);
-        a = b;
-        b = rec;
-        if (j & 1) {
-            const uint32_t full = (uint32_t)(byte | (q & 0xF));
-            // frame byte 2 + (j >> 1): even frame bytes are the low half of word (2 + (j >> 1)) / 2
-            if (((j >> 1) & 1) == 0) fw[1 + (j >> 2)] = full;
-            else fw[1 + (j >> 2)] |= full << 8;
-        } else
-            byte = (q & 0xF) << 4;
-    }
+        for (int j = 0; j < 32; j++) {
+            const int pb = __mul24(a, c1) >> 12;
+            const int pa = __mul24(b, c0) >> 12;
+            const int raw = (x[j] - pb) - pa;
+            const double prod = (double)raw * gain;
+            const int scaled = clamp16(GUARD ? trunc_i32_ryujit(prod) : (int)prod);
+            const int sm = scaled >> 31;
+            const unsigned mag = (unsigned)((scaled ^ sm) - sm);
+            const int aq = (int)((mag * 114692u + 2340u * 114692u) >> 29);
+            const int q = (aq ^ sm) - sm;
+            const int predicted = V4 ? (__mul24(b, c0) + __mul24(a, c1)) >> 12 : pa + pb;
+            const int rec = clamp16(__mul24(scale, q) + predicted);
+            a = b;
+            b = rec;
+            qv[j] = q;
+        }
+    };
+    const double raw_bound = 32770.0 + 8.0 * (double)((c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1));
+    if (__any(gain * raw_bound >= 2147483648.0)) quantise(std::true_type{});
+    else quantise(std::false_type{});
+#pragma unroll
+    for (int w = 0; w < 8; w++)                  // frame bytes 2 + 2w, 3 + 2w: four nibbles, high first
+        fw[1 + w] = (uint32_t)(((qv[4 * w] & 0xF) << 4) | (qv[4 * w + 1] & 0xF)) |
+                    ((uint32_t)(((qv[4 * w + 2] & 0xF) << 4) | (qv[4 * w + 3] & 0xF)) << 8);
 }
 
 template <bool V4, bool EXPONENTIAL>
@@ -862,8 +873,8 @@ __device__ __forceinline__ bool adx_encode_seam_run(const int16_t *__restrict__ 
             const int byte = (int)((ow[bi >> 1] >> (8 * (bi & 1))) & 0xff);
             int v = (j & 1) ? (byte & 0xF) : (byte >> 4);
             v = (v ^ 8) - 8;
-            if (V4) v = scale * v + ((sb * c0 + sa * c1) >> 12);
-            else v = scale * v + ((sb * c0) >> 12) + ((sa * c1) >> 12);
+            if (V4) v = __mul24(scale, v) + ((__mul24(sb, c0) + __mul24(sa, c1)) >> 12);
+            else v = __mul24(scale, v) + (__mul24(sb, c0) >> 12) + (__mul24(sa, c1) >> 12);
             sa = sb;
             sb = clamp16(v);
         }
