@@ -55,9 +55,11 @@ int vga_get_devices(int *devices, int capacity);
 /* Progress of the host-buffer (`*_batch`) entry points: IProgressReport (VGAudio/IProgressReport.cs:3-28), which the
  * reference drives with ReportAdd(1) per frame (GcAdpcmEncoder.cs:42, CriAdxCodec.cs:101, CriHcaFormat.cs:71,79).  Here a
  * call works through its channels / streams in chunks (512 or 1024 channels, 256 streams; one chunk for small calls), and
- * fn(user, done, total) is called once per chunk when that chunk's results are complete in the caller's rows: `done`
- * counts channels (GC-ADPCM, ADX) or streams (HCA) finished so far, `total` is the call's count; the host multiplies by
- * its frames per channel for ReportAdd.  With vga_set_devices() the shares of all devices report into the same count.
+ * fn(user, done, total) is called once per chunk when that chunk's ROWS (adpcm_out / pcm_out / frames_out / out) are
+ * complete in the caller's memory: `done` counts channels (GC-ADPCM, ADX) or streams (HCA) finished so far, `total` is the
+ * call's count; the host multiplies by its frames per channel for ReportAdd.  The small per-call arrays (coefs_out,
+ * history_out, info_out) are complete when the call RETURNS, not when done == total is reported (a coefficients-only
+ * call has no rows: its chunks are reported when their kernels have run).  With vga_set_devices() the shares of all devices report into the same count.
  * fn runs on a worker thread of the library while the call is in progress, never concurrently with itself; it must not
  * call back into the library and should return quickly (a drainer thread is waiting for it).  Per calling thread: the
  * callback applies to `*_batch` calls made afterwards from the thread that set it; fn = NULL removes it. */
@@ -167,6 +169,47 @@ int vga_gcadpcm_encode_device(const int16_t *d_pcm, int64_t pcm_pitch, int nch, 
 int vga_gcadpcm_decode_device(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs,
                               int nch, int sample_count, const int16_t *d_hist1, const int16_t *d_hist2,
                               int16_t *d_pcm, int64_t pcm_pitch, int *d_status, void *stream);
+
+/* ---- ragged batches: channels of DIFFERENT lengths in one call ------------
+ * The reference's batch conversion is a Parallel.ForEach over files (VGAudio.Cli/Batch.cs:24-25 -> Convert.cs:19): every
+ * file has its own length and channel count and ends in GcAdpcmFormat.EncodeFromPcm16 (GcAdpcmFormat.cs:58-74), one
+ * EncodeChannel (:129-135) per channel.  The `_v` entry points take the channels of many files at once, each with its own
+ * sample count; results are byte for byte those of one call per channel.  Equal counts take the equal-length kernels.
+ * hist1 / hist2: per-channel arrays (GcAdpcmParameters.History1/2 of that channel's file) or NULL for 0.
+ * pcm[c] / adpcm_out[c] may be NULL for a channel of 0 samples.  coefs_out: nch*16 (a channel without samples gets the
+ * coefficients the reference computes for an empty array: all 0). */
+int vga_gcadpcm_encode_batch_v(const int16_t *const *pcm, const int *sample_counts, int nch,
+                               const int16_t *hist1, const int16_t *hist2,
+                               int16_t *coefs_out, uint8_t *const *adpcm_out);
+int vga_gcadpcm_calculate_coefficients_batch_v(const int16_t *const *pcm, const int *lengths, int nch,
+                                               int16_t *coefs_out);
+int vga_gcadpcm_encode_with_coefs_batch_v(const int16_t *const *pcm, const int *sample_counts, int nch,
+                                          const int16_t *coefs, const int16_t *hist1, const int16_t *hist2,
+                                          uint8_t *const *adpcm_out);
+int vga_gcadpcm_decode_batch_v(const uint8_t *const *adpcm, const int16_t *coefs, const int *sample_counts, int nch,
+                               const int16_t *hist1, const int16_t *hist2, int16_t *const *pcm_out);
+/* Device-resident ragged batches.  vga_gcadpcm_ragged_create() fixes the batch's shape (the channels' sample counts) and
+ * the PACKED layout of its device buffers: channel c's PCM starts pcm_offsets[c] samples into d_pcm, its ADPCM
+ * adpcm_offsets[c] bytes into d_adpcm (rows follow each other, rounded up to 8 samples / 16 bytes); d_pcm must hold
+ * vga_gcadpcm_ragged_pcm_samples() samples and d_adpcm vga_gcadpcm_ragged_adpcm_bytes() bytes (both include a guard the
+ * kernels' clamped loads may touch), both 16-byte aligned.  The object keeps its tables in the memory of the device that
+ * was current when it was created and may be used by any number of calls (concurrently too); d_coefs: nch*16 shorts,
+ * d_hist1 / d_hist2: nch shorts or NULL. */
+typedef struct vga_gcadpcm_ragged vga_gcadpcm_ragged;
+int vga_gcadpcm_ragged_create(const int *sample_counts, int nch, vga_gcadpcm_ragged **out);
+void vga_gcadpcm_ragged_destroy(vga_gcadpcm_ragged *r);
+int vga_gcadpcm_ragged_channels(const vga_gcadpcm_ragged *r);
+int64_t vga_gcadpcm_ragged_pcm_samples(const vga_gcadpcm_ragged *r);
+int64_t vga_gcadpcm_ragged_adpcm_bytes(const vga_gcadpcm_ragged *r);
+size_t vga_gcadpcm_ragged_coefs_workspace_bytes(const vga_gcadpcm_ragged *r);
+int vga_gcadpcm_ragged_offsets(const vga_gcadpcm_ragged *r, int64_t *pcm_offsets_out, int64_t *adpcm_offsets_out);
+int vga_gcadpcm_coefs_device_v(const vga_gcadpcm_ragged *r, const int16_t *d_pcm, int16_t *d_coefs,
+                               void *d_workspace, size_t workspace_bytes, void *stream);
+int vga_gcadpcm_encode_device_v(const vga_gcadpcm_ragged *r, const int16_t *d_pcm, const int16_t *d_coefs,
+                                const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, void *stream);
+int vga_gcadpcm_decode_device_v(const vga_gcadpcm_ragged *r, const uint8_t *d_adpcm, const int16_t *d_coefs,
+                                const int16_t *d_hist1, const int16_t *d_hist2, int16_t *d_pcm, int *d_status,
+                                void *stream);
 
 /* ----------------------------------------------------------------------
  * GC-ADPCM channel metadata: what the reference derives when a channel is

@@ -25,6 +25,11 @@
 extern "C" {
 #endif
 
+/* ---- synthetic PCM16 of the benchmark (vgaudio_amd/synth.py in C; not part of the reference) ---- */
+void vgo_synth_channel_params(int c, uint32_t out[4]);
+void vgo_synth_channel(int c, int64_t first_sample, int n, int16_t *out);
+void vgo_synth_generate(int16_t *out, long pitch, int nch, int n, int first_channel, int threads);
+
 /* ---- GC-ADPCM size math: Codecs/GcAdpcm/GcAdpcmMath.cs:7-47 ---- */
 int vgo_gc_nibble_count_to_sample_count(int nibble_count);
 int vgo_gc_sample_count_to_nibble_count(int sample_count);

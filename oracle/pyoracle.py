@@ -124,6 +124,18 @@ def _u8(a):
 
 
 # ---------------- GC-ADPCM ----------------
+def synth_generate(nch, n, first_channel=0, threads=1, out=None):
+    """vgaudio_amd.synth.generate in C (oracle/synth_oracle.c): int16 [nch, n]"""
+    L = lib()
+    L.vgo_synth_generate.argtypes = [C.POINTER(C.c_int16), C.c_long, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.vgo_synth_generate.restype = None
+    if out is None:
+        out = np.empty((nch, n), dtype=np.int16)
+    assert out.dtype == np.int16 and out.shape[0] >= nch and out.shape[1] >= n and out.strides[1] == 2
+    L.vgo_synth_generate(_i16(out), out.strides[0] // 2, nch, n, first_channel, threads)
+    return out
+
+
 def gc_sample_count_to_byte_count(n):
     return lib().vgo_gc_sample_count_to_byte_count(int(n))
 

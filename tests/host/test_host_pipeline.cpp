@@ -122,6 +122,107 @@ static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t 
     return 0;
 }
 
+// Ragged jobs (the `*_v` entry points): every row its own size (some empty), packed on the "device" with 16-byte alignment,
+// chunks cut by explicit unit boundaries.  Output row u: byte i = input byte (i mod size) of row u + i.
+static int run_ragged_case(int units, int seed, int chunks_wanted, int feeders, int drainers, size_t slot_bytes, int delay_us, int fail_after)
+{
+    std::mt19937 rng(seed);
+    std::vector<size_t> in_size(units), out_size(units), in_off(units), out_off(units);
+    size_t ia = 0, oa = 0, in_max = 16, out_max = 16;
+    for (int u = 0; u < units; u++) {
+        const unsigned pick = rng() % 10;
+        in_size[u] = pick == 0 ? 0 : (pick < 7 ? 1 + rng() % 300 : 500 + rng() % 4000);
+        out_size[u] = in_size[u] == 0 ? 0 : (in_size[u] * 9 + 31) / 32;
+        in_off[u] = ia;
+        out_off[u] = oa;
+        ia += (in_size[u] + 15) / 16 * 16;
+        oa += (out_size[u] + 15) / 16 * 16;
+        in_max = std::max(in_max, (in_size[u] + 15) / 16 * 16);
+        out_max = std::max(out_max, (out_size[u] + 15) / 16 * 16);
+    }
+    std::vector<std::vector<unsigned char>> in(units), out(units);
+    for (int u = 0; u < units; u++) {
+        in[u].resize(in_size[u] + 1);                          // (+1: a valid pointer for empty rows)
+        out[u].assign(out_size[u] + 1, 0xEE);
+        for (auto &b : in[u]) b = (unsigned char)rng();
+    }
+    std::vector<const void *> in_ptrs(units);
+    std::vector<void *> out_ptrs(units);
+    for (int u = 0; u < units; u++) { in_ptrs[u] = in[u].data(); out_ptrs[u] = out[u].data(); }
+    std::vector<char> d_in(ia + 64, 0x11), d_out(oa + 64, 0x22);
+    Job job;
+    job.units = units;
+    job.in_rows = in_ptrs.data();
+    job.in_row_bytes = in_max;
+    job.in_row_sizes = in_size.data();
+    job.d_in = d_in.data();
+    job.d_in_pitch = in_max;
+    job.d_in_offsets = in_off.data();
+    job.out_rows = out_ptrs.data();
+    job.out_row_bytes = out_max;
+    job.out_row_sizes = out_size.data();
+    job.d_out = d_out.data();
+    job.d_out_pitch = out_max;
+    job.d_out_offsets = out_off.data();
+    job.feeders = feeders;
+    job.drainers = drainers;
+    job.slot_bytes = slot_bytes;
+    job.direct = g_direct;
+    job.direct_out = g_direct_out;
+    job.shared_streams = g_shared;
+    job.compute_lanes = g_lanes;
+    // chunks by bytes: a boundary whenever a chunk holds its share of the input
+    job.chunk_begin.push_back(0);
+    size_t acc = 0;
+    for (int u = 0; u < units; u++) {
+        acc += in_size[u];
+        if (acc >= ia / std::max(chunks_wanted, 1) + 1 && u + 1 < units) { job.chunk_begin.push_back(u + 1); acc = 0; }
+    }
+    job.chunk_begin.push_back(units);
+    std::vector<int> seen(units, 0);
+    job.compute = [&](int first, int count, hipStream_t s, std::string &) -> int {
+        for (int u = first; u < first + count; u++) seen[u]++;
+        mockLaunch(s, [&, first, count] {
+            for (int u = first; u < first + count; u++)
+                for (size_t i = 0; i < out_size[u]; i++)
+                    d_out[out_off[u] + i] = (char)((unsigned char)d_in[in_off[u] + i % in_size[u]] + (unsigned)i);
+        });
+        return 0;
+    };
+    int reported = 0, report_bad = 0;
+    job.chunk_done = [&](int first, int count) {
+        if (first != reported) report_bad++;
+        for (int u = first; u < first + count; u++)
+            for (size_t i = 0; i < out_size[u]; i++)
+                if (out[u][i] != (unsigned char)(in[u][i % in_size[u]] + (unsigned)i)) { report_bad++; break; }
+        reported = first + count;
+    };
+    mock_copy_delay_us() = delay_us;
+    mock_fail_memcpy_after() = fail_after;
+    const Result r = run(job);
+    mock_fail_memcpy_after() = -1;
+    mock_copy_delay_us() = 0;
+    if (fail_after >= 0) {
+        if (r.code == 0) { std::printf("ragged: expected a failure\n"); return 1; }
+        return report_bad ? 1 : 0;
+    }
+    if (r.code != 0) { std::printf("ragged: unexpected failure %d: %s\n", r.code, r.why.c_str()); return 1; }
+    if (report_bad || reported != units || r.stats.chunks != (int)job.chunk_begin.size() - 1) {
+        std::printf("ragged progress: %d bad, %d of %d units, %d chunks\n", report_bad, reported, units, r.stats.chunks);
+        return 1;
+    }
+    for (int u = 0; u < units; u++) {
+        if (seen[u] != 1) { std::printf("ragged: unit %d computed %d times\n", u, seen[u]); return 1; }
+        for (size_t i = 0; i < out_size[u]; i++)
+            if (out[u][i] != (unsigned char)(in[u][i % in_size[u]] + (unsigned)i)) {
+                std::printf("ragged mismatch: units %d seed %d unit %d byte %zu\n", units, seed, u, i);
+                return 1;
+            }
+        if (out[u][out_size[u]] != 0xEE) { std::printf("ragged: wrote past the end of row %d\n", u); return 1; }
+    }
+    return 0;
+}
+
 static int all_cases();
 
 // run_on_devices: the units of one call cut into shares, every share a whole pipeline on its own thread with its own
@@ -225,5 +326,11 @@ static int all_cases()
     bad += run_case(64, 2, 1, 513, 77, 16, 3, 2, 512, 10, -1, false);             // head and tail together
     g_tail = 0;
     g_head = 0;
+    // ragged rows, chunks by bytes
+    bad += run_ragged_case(1, 5, 1, 2, 2, 4096, 0, -1);
+    bad += run_ragged_case(57, 6, 4, 3, 2, 2048, 10, -1);                         // several rows per slot, rows larger than a slot
+    bad += run_ragged_case(200, 7, 7, 4, 3, 8192, 5, -1);
+    bad += run_ragged_case(33, 8, 1, 1, 1, 512, 5, -1);                           // one chunk
+    bad += run_ragged_case(64, 9, 5, 3, 2, 2048, 10, 9);                          // a copy fails mid-way
     return bad;
 }

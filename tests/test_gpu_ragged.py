@@ -1,0 +1,230 @@
+"""Ragged batches (the `*_v` entry points): channels of different lengths in ONE call -- the shape of the reference's
+file-level batch (VGAudio.Cli/Batch.cs:24-25: Parallel.ForEach over files, each through GcAdpcmFormat.EncodeFromPcm16,
+Formats/GcAdpcm/GcAdpcmFormat.cs:58-74).  Every channel of every call must be what one call of the oracle on that
+channel alone produces: coefficients, bitstream, decoded samples."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from vgaudio_amd import _lib, synth
+from vgaudio_amd.gcadpcm import GcAdpcmFormat, GcAdpcmParameters, Pcm16Format, decode_files, encode_files
+
+pytestmark = pytest.mark.gpu
+
+i16p, u8p = _lib.i16p, _lib.u8p
+
+
+def _ptrs(t, arrays):
+    return (t * len(arrays))(*[a.ctypes.data_as(t) for a in arrays])
+
+
+def _lengths(n, lo, hi, seed, extra=()):
+    """log-uniform lengths in [lo, hi] samples plus the reference's awkward ones"""
+    rng = np.random.default_rng(seed)
+    lens = np.exp(rng.uniform(np.log(lo), np.log(hi), n)).astype(np.int64)
+    lens[:len(extra)] = extra
+    rng.shuffle(lens)
+    return [int(x) for x in lens]
+
+
+def _channels(lens, first_channel=0):
+    return [po.synth_generate(1, n, first_channel=first_channel + c)[0] if n else np.zeros(0, np.int16) for c, n in enumerate(lens)]
+
+
+def _oracle(pcm, h1=0, h2=0):
+    coefs = po.gc_calculate_coefficients(pcm)
+    return coefs, po.gc_encode(pcm, coefs, hist1=h1, hist2=h2)
+
+
+def _encode_v(chans, h1=None, h2=None):
+    L = _lib.lib()
+    nch = len(chans)
+    counts = np.array([len(c) for c in chans], dtype=np.int32)
+    coefs = np.full((nch, 16), 0x5A5A, dtype=np.int16)
+    outs = [np.full(L.vga_gcadpcm_sample_count_to_byte_count(int(n)) + 1, 0xEE, dtype=np.uint8) for n in counts]
+    _lib.check(L.vga_gcadpcm_encode_batch_v(_ptrs(i16p, chans), counts.ctypes.data_as(C.POINTER(C.c_int)), nch,
+                                            h1.ctypes.data_as(i16p) if h1 is not None else None,
+                                            h2.ctypes.data_as(i16p) if h2 is not None else None,
+                                            coefs.ctypes.data_as(i16p), _ptrs(u8p, outs)))
+    for o in outs:
+        assert o[-1] == 0xEE, "wrote past the end of a row"
+    return coefs, [o[:-1] for o in outs]
+
+
+def _decode_v(adpcm, coefs, counts, h1=None, h2=None):
+    L = _lib.lib()
+    nch = len(adpcm)
+    counts = np.array(counts, dtype=np.int32)
+    outs = [np.full(int(n) + 1, 0x7777, dtype=np.int16) for n in counts]
+    co = np.ascontiguousarray(coefs, dtype=np.int16)
+    _lib.check(L.vga_gcadpcm_decode_batch_v(_ptrs(u8p, adpcm), co.ctypes.data_as(i16p), counts.ctypes.data_as(C.POINTER(C.c_int)), nch,
+                                            h1.ctypes.data_as(i16p) if h1 is not None else None,
+                                            h2.ctypes.data_as(i16p) if h2 is not None else None, _ptrs(i16p, outs)))
+    for o in outs:
+        assert o[-1] == 0x7777, "wrote past the end of a row"
+    return [o[:-1] for o in outs]
+
+
+AWKWARD = (0, 1, 13, 14, 15, 27, 28, 29, 8 * 14, 8 * 14 + 1, 3072 * 14, 3072 * 14 + 5)
+
+
+def test_ragged_encode_and_decode_match_the_oracle_per_channel():
+    lens = _lengths(96, 200, 400_000, 1, AWKWARD)
+    chans = _channels(lens)
+    coefs, adpcm = _encode_v(chans)
+    for c, pcm in enumerate(chans):
+        wc, wa = _oracle(pcm)
+        assert coefs[c].tolist() == wc.tolist(), (c, lens[c])
+        assert np.array_equal(adpcm[c], wa), (c, lens[c])
+    pcm_back = _decode_v(adpcm, coefs, lens)
+    for c in range(len(chans)):
+        assert np.array_equal(pcm_back[c], po.gc_decode(adpcm[c], coefs[c], lens[c])), (c, lens[c])
+
+
+def test_ragged_with_per_channel_history():
+    lens = _lengths(40, 100, 60_000, 2, (0, 1, 14, 15))
+    chans = _channels(lens, first_channel=500)
+    rng = np.random.default_rng(5)
+    h1 = rng.integers(-32768, 32768, len(lens)).astype(np.int16)
+    h2 = rng.integers(-32768, 32768, len(lens)).astype(np.int16)
+    coefs, adpcm = _encode_v(chans, h1, h2)
+    for c, pcm in enumerate(chans):
+        wc, wa = _oracle(pcm, int(h1[c]), int(h2[c]))
+        assert coefs[c].tolist() == wc.tolist() and np.array_equal(adpcm[c], wa), (c, lens[c])
+    back = _decode_v(adpcm, coefs, lens, h1, h2)
+    for c in range(len(chans)):
+        assert np.array_equal(back[c], po.gc_decode(adpcm[c], coefs[c], lens[c], hist1=int(h1[c]), hist2=int(h2[c]))), c
+
+
+@pytest.mark.parametrize("force_open", [0, 1, 2])
+def test_ragged_many_pieces_and_open_seams(force_open):
+    """few long channels next to many short ones: the long ones are cut into many time pieces; with the seam hook every
+    seam (or every other one) is refused, so the chain / tail paths produce the output"""
+    L = _lib.lib()
+    lens = [14 * 40_000 + 3, 14 * 31_000, 14 * 25_000 + 13] + _lengths(61, 50, 30_000, 3, (0, 5, 14 * 3072))
+    chans = _channels(lens, first_channel=64)          # (channels 64.. hold the slow-closing seams of the synthetic set)
+    L.vga_testing_force_open_seams_this_thread(force_open)
+    L.vga_testing_gc_encoder_segments_this_thread(24)
+    try:
+        coefs, adpcm = _encode_v(chans)
+        back = _decode_v(adpcm, coefs, lens)
+    finally:
+        L.vga_testing_force_open_seams_this_thread(0)
+        L.vga_testing_gc_encoder_segments_this_thread(0)
+    for c, pcm in enumerate(chans):
+        wc, wa = _oracle(pcm)
+        assert coefs[c].tolist() == wc.tolist() and np.array_equal(adpcm[c], wa), (c, lens[c])
+        assert np.array_equal(back[c], po.gc_decode(wa, wc, lens[c])), (c, lens[c])
+
+
+def test_equal_lengths_through_the_ragged_entry_point_equal_the_batch_entry_point():
+    L = _lib.lib()
+    n = 14 * 5000 + 9
+    chans = list(synth.generate(20, n))
+    coefs, adpcm = _encode_v(chans)
+    want = np.zeros((20, 16), dtype=np.int16)
+    outs = [np.zeros(L.vga_gcadpcm_sample_count_to_byte_count(n), dtype=np.uint8) for _ in chans]
+    _lib.check(L.vga_gcadpcm_encode_batch(_ptrs(i16p, chans), 20, n, 0, 0, want.ctypes.data_as(i16p), _ptrs(u8p, outs)))
+    assert np.array_equal(coefs, want)
+    for a, b in zip(adpcm, outs):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("chunk,slot", [(7, 0), (5, 4096), (64, -1)])
+def test_ragged_through_every_pipeline_shape(chunk, slot):
+    """small chunks, staged / direct copies: every hand-off of the host pipeline with rows of different sizes"""
+    L = _lib.lib()
+    lens = _lengths(50, 10, 20_000, 4, (0, 0, 1, 14))
+    chans = _channels(lens, first_channel=200)
+    L.vga_testing_host_pipeline_this_thread(2, 2, chunk, slot)
+    try:
+        coefs, adpcm = _encode_v(chans)
+        back = _decode_v(adpcm, coefs, lens)
+    finally:
+        L.vga_testing_host_pipeline_this_thread(0, 0, 0, 0)
+    for c, pcm in enumerate(chans):
+        wc, wa = _oracle(pcm)
+        assert coefs[c].tolist() == wc.tolist() and np.array_equal(adpcm[c], wa), (c, lens[c])
+        assert np.array_equal(back[c], po.gc_decode(wa, wc, lens[c])), c
+
+
+def test_coefficients_only_and_encode_with_given_coefficients():
+    L = _lib.lib()
+    lens = _lengths(30, 20, 50_000, 6, (0, 13))
+    chans = _channels(lens, first_channel=900)
+    counts = np.array(lens, dtype=np.int32)
+    coefs = np.zeros((len(lens), 16), dtype=np.int16)
+    _lib.check(L.vga_gcadpcm_calculate_coefficients_batch_v(_ptrs(i16p, chans), counts.ctypes.data_as(C.POINTER(C.c_int)), len(lens),
+                                                            coefs.ctypes.data_as(i16p)))
+    for c, pcm in enumerate(chans):
+        assert coefs[c].tolist() == po.gc_calculate_coefficients(pcm).tolist(), c
+    rng = np.random.default_rng(9)
+    given = rng.integers(-3000, 3000, (len(lens), 16)).astype(np.int16)
+    outs = [np.zeros(L.vga_gcadpcm_sample_count_to_byte_count(n), dtype=np.uint8) for n in lens]
+    _lib.check(L.vga_gcadpcm_encode_with_coefs_batch_v(_ptrs(i16p, chans), counts.ctypes.data_as(C.POINTER(C.c_int)), len(lens),
+                                                       given.ctypes.data_as(i16p), None, None, _ptrs(u8p, outs)))
+    for c, pcm in enumerate(chans):
+        assert np.array_equal(outs[c], po.gc_encode(pcm, given[c])), c
+
+
+def test_files_of_different_shapes_in_one_call():
+    """the host mirror of Batch.cs: one Pcm16Format per file, any length and channel count"""
+    rng = np.random.default_rng(12)
+    files = []
+    for f in range(9):
+        n = int(rng.integers(1, 40_000))
+        k = int(rng.integers(1, 4))
+        files.append(Pcm16Format(list(po.synth_generate(k, n, first_channel=10 * f)), sampleRate=32000 + f))
+    files.append(Pcm16Format([], 48000))
+    got = encode_files(files, [GcAdpcmParameters(History1=3 * i, History2=-i) if i % 2 else None for i in range(len(files))])
+    for i, (f, g) in enumerate(zip(files, got)):
+        want = GcAdpcmFormat().EncodeFromPcm16(f, GcAdpcmParameters(History1=3 * i, History2=-i) if i % 2 else None)
+        assert g.ChannelCount == f.ChannelCount and g.SampleRate == f.SampleRate
+        for a, b in zip(g.Channels, want.Channels):
+            assert a.Coefs.tolist() == b.Coefs.tolist() and np.array_equal(a.Adpcm, b.Adpcm), i
+    back = decode_files(got)
+    for i, (g, p) in enumerate(zip(got, back)):
+        want = g.ToPcm16()
+        for a, b in zip(p.Channels, want.Channels):
+            assert np.array_equal(a, b), i
+
+
+def test_ragged_arguments():
+    L = _lib.lib()
+    a = np.zeros(20, dtype=np.int16)
+    out = np.zeros(16, dtype=np.uint8)
+    coefs = np.zeros(16, dtype=np.int16)
+    bad = np.array([-1], dtype=np.int32)
+    assert L.vga_gcadpcm_encode_batch_v(_ptrs(i16p, [a]), bad.ctypes.data_as(C.POINTER(C.c_int)), 1, None, None, coefs.ctypes.data_as(i16p),
+                                        _ptrs(u8p, [out])) == _lib.VGA_ERR_ARGUMENT
+    ok = np.array([20], dtype=np.int32)
+    assert L.vga_gcadpcm_encode_batch_v(_ptrs(i16p, [a]), ok.ctypes.data_as(C.POINTER(C.c_int)), 1, None, None, coefs.ctypes.data_as(i16p),
+                                        None) == _lib.VGA_ERR_ARGUMENT
+    assert L.vga_gcadpcm_encode_batch_v(None, None, 0, None, None, None, None) == _lib.VGA_OK
+
+
+def test_device_resident_ragged_batch():
+    import torch
+    from vgaudio_amd import device as vdev
+    dev = torch.device("cuda", 0)
+    lens = _lengths(300, 500, 300_000, 8, AWKWARD)
+    rb = vdev.GcRaggedBatch(lens, dev)
+    pcm = rb.synth(first_channel=1000)
+    host = rb.rows(pcm, rb.pcm_offsets, rb.counts)
+    for c in (0, 17, 150, 299):
+        assert np.array_equal(host[c], po.synth_generate(1, lens[c], first_channel=1000 + c)[0] if lens[c] else host[c]), c
+    coefs = rb.coefs(pcm)
+    adpcm = rb.encode(pcm, coefs)
+    dec, status = rb.decode(adpcm, coefs)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    co = coefs.cpu().numpy()
+    rows = rb.rows(adpcm, rb.adpcm_offsets, rb.byte_counts)
+    back = rb.rows(dec, rb.pcm_offsets, rb.counts)
+    for c in range(0, 300, 7):
+        wc, wa = _oracle(host[c])
+        assert co[c].tolist() == wc.tolist() and np.array_equal(rows[c], wa), (c, lens[c])
+        assert np.array_equal(back[c], po.gc_decode(wa, wc, lens[c])), (c, lens[c])
+    rb.close()

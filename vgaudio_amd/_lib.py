@@ -108,6 +108,20 @@ SIGNATURES = {
     "vga_gcadpcm_calculate_coefficients_batch": (ci, [i16pp, ci, ci, i16p]),
     "vga_gcadpcm_encode_with_coefs_batch": (ci, [i16pp, ci, ci, ci, i16p, i16p, i16p, u8pp]),
     "vga_gcadpcm_decode_batch": (ci, [u8pp, i16p, ci, ci, i16p, i16p, i16pp]),
+    "vga_gcadpcm_encode_batch_v": (ci, [i16pp, C.POINTER(ci), ci, i16p, i16p, i16p, u8pp]),
+    "vga_gcadpcm_calculate_coefficients_batch_v": (ci, [i16pp, C.POINTER(ci), ci, i16p]),
+    "vga_gcadpcm_encode_with_coefs_batch_v": (ci, [i16pp, C.POINTER(ci), ci, i16p, i16p, i16p, u8pp]),
+    "vga_gcadpcm_decode_batch_v": (ci, [u8pp, i16p, C.POINTER(ci), ci, i16p, i16p, i16pp]),
+    "vga_gcadpcm_ragged_create": (ci, [C.POINTER(ci), ci, C.POINTER(vp)]),
+    "vga_gcadpcm_ragged_destroy": (None, [vp]),
+    "vga_gcadpcm_ragged_channels": (ci, [vp]),
+    "vga_gcadpcm_ragged_pcm_samples": (i64, [vp]),
+    "vga_gcadpcm_ragged_adpcm_bytes": (i64, [vp]),
+    "vga_gcadpcm_ragged_coefs_workspace_bytes": (C.c_size_t, [vp]),
+    "vga_gcadpcm_ragged_offsets": (ci, [vp, C.POINTER(i64), C.POINTER(i64)]),
+    "vga_gcadpcm_coefs_device_v": (ci, [vp, vp, vp, vp, C.c_size_t, vp]),
+    "vga_gcadpcm_encode_device_v": (ci, [vp, vp, vp, vp, vp, vp, vp]),
+    "vga_gcadpcm_decode_device_v": (ci, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "encode": (None, [i16p, u8p, C.POINTER(ADPCMINFO), C.c_uint32]),
     "decode": (None, [u8p, i16p, C.POINTER(ADPCMINFO), C.c_uint32]),
     "correlateCoefs": (None, [i16p, C.c_uint32, i16p]),

@@ -33,27 +33,43 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 // frames early without storing, so that they have, as a rule, fallen into step with the true run where they begin and
 // their seam closes on the first frame gc_decode_fixup_kernel checks.
 constexpr int GC_DECODE_WARM = 512;                  // frames; a multiple of 8
-template <bool TURNED>
+// RAGGED (the `*_v` entry points): lane i of workgroup x decodes channel order[64 x + i] (longest first), with its own
+// length and offsets; a piece exists for a lane only as far as its channel reaches, the wave runs as many blocks as its
+// longest lane has (lane 0) and every row of the turned store is guarded by its own block count.
+template <bool TURNED, bool RAGGED>
 __global__ __launch_bounds__(64) void gc_decode_direct_kernel(
     const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
     int total_samples, int seg_frames, const int16_t *__restrict__ hist1, const int16_t *__restrict__ hist2,
-    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ status)
+    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ status, const Ragged rg)
 {
     const int64_t first_frame = (int64_t)blockIdx.y * seg_frames;          // a multiple of 8 (seg_frames is)
     const int64_t first_sample = first_frame * 14;
-    if (first_sample >= total_samples) return;
-    const int sample_count = (int)((int64_t)total_samples - first_sample < (int64_t)seg_frames * 14
-                                       ? (int64_t)total_samples - first_sample : (int64_t)seg_frames * 14);
+    const int lane = threadIdx.x;
+    const int slot_raw = blockIdx.x * 64 + lane;
+    const bool live = slot_raw < nch;
+    const int slot = live ? slot_raw : nch - 1;
+    const int ch = RAGGED ? rg.order[slot] : slot;
+    if (RAGGED) {
+        if (first_sample >= rg.length[rg.order[blockIdx.x * 64]]) return;  // the wave's longest channel ends before this piece
+        total_samples = rg.length[ch];
+    } else if (first_sample >= total_samples)
+        return;
+    const bool exists = !RAGGED || first_sample < total_samples;           // this lane's channel reaches the piece
+    const int sample_count = !exists ? 0 : (int)((int64_t)total_samples - first_sample < (int64_t)seg_frames * 14
+                                                     ? (int64_t)total_samples - first_sample : (int64_t)seg_frames * 14);
     const int full_frames = sample_count / 14;
     const int tail = sample_count - full_frames * 14;
-    const int lane = threadIdx.x;
-    const int ch_raw = blockIdx.x * 64 + lane;
-    const bool live = ch_raw < nch;
-    const int ch = live ? ch_raw : nch - 1;
-    const uint8_t *src = adpcm + (int64_t)ch * adpcm_pitch + first_frame * 8;
-    int16_t *dst = pcm + (int64_t)ch * pcm_pitch + first_sample;
+    // a lane without the piece points at its channel's first bytes (valid memory for its clamped loads) and stores nothing
+    const uint8_t *src = adpcm + (RAGGED ? rg.adpcm_off[ch] : (int64_t)ch * adpcm_pitch) + (exists ? first_frame * 8 : 0);
+    int16_t *dst = pcm + (RAGGED ? rg.pcm_off[ch] : (int64_t)ch * pcm_pitch) + (exists ? first_sample : 0);
     __shared__ uint32_t s_cf[8 * 64];                                      // [predictor][lane]: (coef1 & 0xFFFF) | coef2 << 16
     __shared__ int4 s_turn[64 * 15];                                       // 64 rows of 14 int4 (8 frames), one int4 apart from a multiple of 8
+    __shared__ int64_t s_row[RAGGED ? 64 : 1];                             // RAGGED: a row's first sample of the piece, counted from pcm
+    __shared__ int s_rowblocks[RAGGED ? 64 : 1];                           // ... and its whole blocks of eight frames
+    if (RAGGED) {
+        s_row[lane] = (int64_t)(dst - pcm);
+        s_rowblocks[lane] = live ? full_frames / 8 : 0;
+    }
 #pragma unroll
     for (int q = 0; q < 8; q++)
         s_cf[q * 64 + lane] = (uint32_t)(uint16_t)coefs[ch * 16 + 2 * q] | ((uint32_t)(uint16_t)coefs[ch * 16 + 2 * q + 1] << 16);
@@ -62,6 +78,7 @@ __global__ __launch_bounds__(64) void gc_decode_direct_kernel(
         h1 = hist1 ? hist1[ch] : 0;
         h2 = hist2 ? hist2[ch] : 0;
     }
+    bool bad_seen = false;
     bool bad = false;
     // one frame (bits = its 8 bytes, little-endian) -> 14 samples as 7 packed pairs
     auto decode_frame = [&](uint32_t lo, uint32_t hi, uint32_t (&o7)[7]) {
@@ -94,7 +111,7 @@ __global__ __launch_bounds__(64) void gc_decode_direct_kernel(
         return pcm + (int64_t)(c < nch ? c : nch - 1) * pcm_pitch + first_sample + (l % 14) * 8;
     };
     // ---- warm-up of a later piece (not stored)
-    if (blockIdx.y > 0) {
+    if (blockIdx.y > 0 && exists) {
         const int warm = (int)(first_frame < GC_DECODE_WARM ? first_frame : GC_DECODE_WARM);
         const uint2 *wsrc = reinterpret_cast<const uint2 *>(src) - warm;
 #pragma unroll 1
@@ -109,8 +126,10 @@ __global__ __launch_bounds__(64) void gc_decode_direct_kernel(
             }
         }
     }
+    bad_seen = bad;                                                        // (the warm-up reads real frames: a bad header there is a bad header)
     // ---- whole blocks of eight full frames
-    const int blocks = full_frames / 8;
+    const int my_blocks = full_frames / 8;
+    const int blocks = RAGGED ? __shfl(my_blocks, 0) : my_blocks;          // lane 0 holds the wave's longest channel
     const uint4 *bsrc = reinterpret_cast<const uint4 *>(src);
     uint4 cur[4], nxt[4];
 #pragma unroll
@@ -121,7 +140,8 @@ __global__ __launch_bounds__(64) void gc_decode_direct_kernel(
     for (int q = 0; q < 4; q++) asm volatile("" : "+v"(cur[q].x), "+v"(cur[q].y), "+v"(cur[q].z), "+v"(cur[q].w));
 #pragma unroll 1
     for (int k = 0; k < blocks; k++) {
-        const uint4 *f = bsrc + (int64_t)imin(k + 1, blocks - 1) * 4;
+        const uint4 *f = bsrc + (int64_t)(RAGGED ? imax(imin(k + 1, my_blocks - 1), 0) : imin(k + 1, blocks - 1)) * 4;
+        const int keep1 = h1, keep2 = h2;                                  // RAGGED: a lane past its last block keeps its history
 #pragma unroll
         for (int q = 0; q < 4; q++) nxt[q] = f[q];
 #pragma unroll
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(64) void gc_decode_direct_kernel(
 #pragma unroll
                 for (int q = 0; q < 7; q++)
                     s_turn[lane * 15 + half * 7 + q] = make_int4((int)d28[4 * q], (int)d28[4 * q + 1], (int)d28[4 * q + 2], (int)d28[4 * q + 3]);
-            } else if (live) {
+            } else if (live && (!RAGGED || k < my_blocks)) {
                 uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + ((int64_t)k * 8 + half * 4) * 14);
 #pragma unroll
                 for (int q = 0; q < 28; q++) d32[q] = d28[q];
@@ -149,16 +169,28 @@ __global__ __launch_bounds__(64) void gc_decode_direct_kernel(
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int l = imin(lane, 55);                                  // 4 rows x 14 lanes per store; the last eight lanes repeat lane 55's
 #pragma unroll
-            for (int i = 0; i < 16; i++)                                   // read, store -- one at a time (see adx_kernels.hip)
-                *reinterpret_cast<int4 *>(turned_row(i, l) + (int64_t)k * 8 * 14) = s_turn[(l / 14 + 4 * i) * 15 + l % 14];
+            for (int i = 0; i < 16; i++) {                                 // read, store -- one at a time (see adx_kernels.hip)
+                const int row = l / 14 + 4 * i;
+                if (RAGGED) {
+                    if (k < s_rowblocks[row])
+                        *reinterpret_cast<int4 *>(pcm + s_row[row] + (l % 14) * 8 + (int64_t)k * 8 * 14) = s_turn[row * 15 + l % 14];
+                } else
+                    *reinterpret_cast<int4 *>(turned_row(i, l) + (int64_t)k * 8 * 14) = s_turn[row * 15 + l % 14];
+            }
             asm volatile("" ::: "memory");
         }
+        if (RAGGED && k >= my_blocks) {                                    // blocks past this lane's end decoded whatever was there
+            bad = bad_seen;
+            h1 = keep1;
+            h2 = keep2;
+        }
+        bad_seen = bad;
 #pragma unroll
         for (int q = 0; q < 4; q++) cur[q] = nxt[q];
     }
     // ---- what is left of the piece: fewer than eight full frames and a partial one
 #pragma unroll 1
-    for (int fr = blocks * 8; fr < full_frames + (tail ? 1 : 0); fr++) {
+    for (int fr = my_blocks * 8; fr < full_frames + (tail ? 1 : 0); fr++) {
         uint32_t lo = 0, hi = 0;
         if (fr < full_frames) {
             const uint2 v = reinterpret_cast<const uint2 *>(src)[fr];
@@ -214,14 +246,17 @@ __device__ __forceinline__ void gc_decode_frame_serial(const uint8_t *fr, const 
 __global__ __launch_bounds__(64) void gc_decode_fixup_kernel(
     const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
     int total_samples, int seg_frames, int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ first_open,
-    int *__restrict__ seam_open, int force_open)
+    int *__restrict__ seam_open, int force_open, const Ragged rg)
 {
-    const int ch = blockIdx.x * 64 + threadIdx.x;
+    const int slot = blockIdx.x * 64 + threadIdx.x;
     const int k = blockIdx.y + 1;
     const int64_t f0 = (int64_t)k * seg_frames;
-    if (ch >= nch || f0 * 14 >= total_samples) return;
-    const uint8_t *src = adpcm + (int64_t)ch * adpcm_pitch;
-    int16_t *dst = pcm + (int64_t)ch * pcm_pitch;
+    if (slot >= nch) return;
+    const int ch = rg.order ? rg.order[slot] : slot;
+    if (rg.order) total_samples = rg.length[ch];
+    if (f0 * 14 >= total_samples) return;
+    const uint8_t *src = adpcm + (rg.order ? rg.adpcm_off[ch] : (int64_t)ch * adpcm_pitch);
+    int16_t *dst = pcm + (rg.order ? rg.pcm_off[ch] : (int64_t)ch * pcm_pitch);
     int cf[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) cf[i] = coefs[ch * 16 + i];
@@ -261,14 +296,16 @@ __global__ __launch_bounds__(64) void gc_decode_fixup_kernel(
 __global__ __launch_bounds__(64) void gc_decode_tail_kernel(
     const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
     int total_samples, int seg_frames, int segments, int16_t *__restrict__ pcm, int64_t pcm_pitch,
-    const int *__restrict__ first_open, const int *__restrict__ seam_open, int force_open)
+    const int *__restrict__ first_open, const int *__restrict__ seam_open, int force_open, const Ragged rg)
 {
-    const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= nch) return;
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= nch) return;
+    const int ch = rg.order ? rg.order[slot] : slot;
+    if (rg.order) total_samples = rg.length[ch];
     const int k0 = first_open[ch];
     if (k0 <= 0 || k0 >= 0x7f000000) return;
-    const uint8_t *src = adpcm + (int64_t)ch * adpcm_pitch;
-    int16_t *dst = pcm + (int64_t)ch * pcm_pitch;
+    const uint8_t *src = adpcm + (rg.order ? rg.adpcm_off[ch] : (int64_t)ch * adpcm_pitch);
+    int16_t *dst = pcm + (rg.order ? rg.pcm_off[ch] : (int64_t)ch * pcm_pitch);
     int cf[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) cf[i] = coefs[ch * 16 + i];
@@ -305,8 +342,10 @@ __global__ __launch_bounds__(64) void gc_decode_tail_kernel(
 
 int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs, int nch, int sample_count,
                   const int16_t *d_hist1, const int16_t *d_hist2, int16_t *d_pcm, int64_t pcm_pitch, int *d_status,
-                  hipStream_t stream)
+                  hipStream_t stream, const Ragged *rgp)
 {
+    const Ragged rg = rgp ? *rgp : Ragged{};
+    if (rgp) sample_count = rg.max_length;
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
     // as many time pieces as put one wave on every SIMD (a wave = 64 channels of one piece), each at least 1024 frames long
     // and a multiple of eight frames; at most 64 (every seam is a chance of a run that never meets, see adx_kernels.hip)
@@ -314,6 +353,13 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
     const int groups = (nch + 63) / 64;
     const int cus = device_cu_count();
     int segments = cus * 4 / groups;
+    if (rgp) {
+        // ragged: pieces of one length for every channel, twice as many waves as the chip holds at once (the short ones
+        // make room), `segments` = what the longest channel needs
+        const int64_t want = (int64_t)cus * 4 * 2;
+        const int64_t piece = std::max<int64_t>((rg.total_frames + 64 * want - 1) / (64 * want), 1024);
+        segments = (int)((frames + piece - 1) / piece);
+    }
     if (segments > frames / 1024) segments = frames / 1024;
     if (segments < 1) segments = 1;
     if (segments > 64) segments = 64;
@@ -321,12 +367,15 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
     const int seg_frames = ((frames + segments - 1) / segments + 7) / 8 * 8;
     // rows of samples on 16-byte boundaries: whole 224-byte runs leave as 16-byte stores
     const bool turned = (pcm_pitch % 8) == 0 && ((uintptr_t)d_pcm % 16) == 0;
-    if (turned)
-        hipLaunchKernelGGL(gc_decode_direct_kernel<true>, dim3(groups, segments), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
-                           sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
+    if (rgp)                                           // (the ragged layout keeps every row on a 16-byte boundary)
+        hipLaunchKernelGGL((gc_decode_direct_kernel<true, true>), dim3(groups, segments), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
+                           sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status, rg);
+    else if (turned)
+        hipLaunchKernelGGL((gc_decode_direct_kernel<true, false>), dim3(groups, segments), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
+                           sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status, rg);
     else
-        hipLaunchKernelGGL(gc_decode_direct_kernel<false>, dim3(groups, segments), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
-                           sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status);
+        hipLaunchKernelGGL((gc_decode_direct_kernel<false, false>), dim3(groups, segments), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
+                           sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status, rg);
     VGA_HIP_TRY(hipGetLastError());
     if (segments > 1) {
         AsyncBuf scratch;                              // freed (stream-ordered) on every exit path
@@ -337,10 +386,10 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
         VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
         VGA_HIP_TRY(hipMemsetAsync(seam_open, 0, flag_bytes, stream));
         hipLaunchKernelGGL(gc_decode_fixup_kernel, dim3((nch + 63) / 64, segments - 1), dim3(64), 0, stream, d_adpcm, adpcm_pitch,
-                           d_coefs, nch, sample_count, seg_frames, d_pcm, pcm_pitch, first_open, seam_open, force_open_seams());
+                           d_coefs, nch, sample_count, seg_frames, d_pcm, pcm_pitch, first_open, seam_open, force_open_seams(), rg);
         VGA_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(gc_decode_tail_kernel, dim3((nch + 63) / 64), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
-                           sample_count, seg_frames, segments, d_pcm, pcm_pitch, first_open, seam_open, force_open_seams());
+                           sample_count, seg_frames, segments, d_pcm, pcm_pitch, first_open, seam_open, force_open_seams(), rg);
         VGA_HIP_TRY(hipGetLastError());
     }
     return VGA_OK;

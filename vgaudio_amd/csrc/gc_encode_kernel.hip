@@ -172,12 +172,16 @@ ColdOut encode_frame_cold(ColdState st, PassOut r, int final_sp, int fin)
 // seg_state[piece][channel] receives every piece's final history.  At BASELINE configs[1] there is one piece.
 // REPAIR is a template parameter only so that the two launches carry different names in profiles (the repair launch
 // normally returns at once and would halve the kernel's average duration).
-template <bool REPAIR, int CPW>
+// RAGGED (the `*_v` entry points): channel slots map to channels through rg.order (longest first: slot 0 of a workgroup
+// holds its longest channel), every slot has its own length and offsets, a piece exists for a slot only as far as its
+// channel reaches.  The workgroup runs as many tiles as its longest slot needs; a slot whose frames have run out keeps
+// encoding (clamped loads, nothing flushed) with its history frozen.
+template <bool REPAIR, int CPW, bool RAGGED>
 __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void gc_encode_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, int seg_frames,
     const int16_t *__restrict__ coefs, const int16_t *__restrict__ hist1,
     const int16_t *__restrict__ hist2, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, int16_t *__restrict__ seg_state,
-    const int *__restrict__ first_open)
+    const int *__restrict__ first_open, const Ragged rg)
 {
     // Repair launch (first_open != nullptr, one workgroup row): channels with a seam that would not close are encoded
     // again, serially, from the earliest such seam among the workgroup's four channels to the end of the stream --
@@ -191,17 +195,24 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     if (repair) {
         int k = 0x7f000000;
         for (int g = 0; g < CS; g++) {
-            const int c = blockIdx.x * CS + g;
-            if (c < nch) k = first_open[c] < k ? first_open[c] : k;
+            const int slot = blockIdx.x * CS + g;
+            if (slot < nch) {
+                const int c = RAGGED ? rg.order[slot] : slot;
+                k = first_open[c] < k ? first_open[c] : k;
+            }
         }
         if (k <= 0 || k >= 0x7f000000) return;
         repair_piece = k;
         first_frame = (int64_t)k * seg_frames;
     }
-    if (first_frame * 14 >= total_samples) return;
-    const int64_t piece_samples = repair ? (int64_t)total_samples : (int64_t)seg_frames * 14;
-    const int sample_count = (int)((int64_t)total_samples - first_frame * 14 < piece_samples
-                                       ? (int64_t)total_samples - first_frame * 14 : piece_samples);
+    // the workgroup's longest channel (slot 0 when ragged) decides whether the piece exists and how many tiles it has
+    const int total_wg = RAGGED ? rg.length[rg.order[blockIdx.x * CS]] : total_samples;
+    if (first_frame * 14 >= total_wg) return;
+    const int64_t piece_samples = repair ? (int64_t)0x7fffffff : (int64_t)seg_frames * 14;
+    auto piece_samples_of = [&](int total) {
+        const int64_t rem = (int64_t)total - first_frame * 14;
+        return (int)(rem < 0 ? 0 : (rem < piece_samples ? rem : piece_samples));
+    };
     pcm += first_frame * 14;
     adpcm += first_frame * 8;
     __shared__ GcTile s_tile[2];
@@ -216,16 +227,19 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     const int grp = helper ? lane / TF : wave * CPW + lane / LPC;  // channel slot of this lane
     const int l16 = lane & (LPC - 1);
     const int hfr = lane % TF;                         // helper lanes: the frame inside the tile
-    const int ch_raw = blockIdx.x * CS + grp;
-    const bool live = ch_raw < nch;
-    const int ch = live ? ch_raw : nch - 1;
-    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
-    uint8_t *dst = adpcm + (int64_t)ch * adpcm_pitch;
+    const int slot_raw = blockIdx.x * CS + grp;
+    const bool live = slot_raw < nch;
+    const int slot = live ? slot_raw : nch - 1;
+    const int ch = RAGGED ? rg.order[slot] : slot;
+    const int16_t *src = pcm + (RAGGED ? rg.pcm_off[ch] : (int64_t)ch * pcm_pitch);
+    uint8_t *dst = adpcm + (RAGGED ? rg.adpcm_off[ch] : (int64_t)ch * adpcm_pitch);
 
+    const int sample_count = piece_samples_of(RAGGED ? rg.length[ch] : total_samples);   // this slot's share of the piece
     const int full_frames = sample_count / 14;
     const int tail = sample_count - full_frames * 14;
     const int frames = full_frames + (tail ? 1 : 0);
-    const int tiles = (frames + TF - 1) / TF;
+    const int frames_wg = RAGGED ? (piece_samples_of(total_wg) + 13) / 14 : frames;
+    const int tiles = (frames_wg + TF - 1) / TF;
 
     if (helper) {
         // ---------------------------------------------------------------- helper wave
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         for (int p = 0; p < 8; p++)
             cpk[p] = (uint32_t)(uint16_t)coefs[ch * 16 + 2 * p + 1] | ((uint32_t)(uint16_t)coefs[ch * 16 + 2 * p] << 16);
         auto prepare = [&](int tile) {
-            const int fr = imin(tile * TF + hfr, frames - 1);
+            const int fr = RAGGED ? imax(imin(tile * TF + hfr, frames - 1), 0) : imin(tile * TF + hfr, frames - 1);
             int in[14];
             uint32_t w[7];                             // the frame as packed pairs (in[2i], in[2i+1])
             if (fr < full_frames) {
@@ -334,7 +348,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     if (repair) {
         h0 = seg_state[((int64_t)(repair_piece - 1) * nch + ch) * 2];
         h1 = seg_state[((int64_t)(repair_piece - 1) * nch + ch) * 2 + 1];
-    } else if (blockIdx.y > 0) {                       // a later piece: the guess
+    } else if (blockIdx.y > 0 && (!RAGGED || frames > 0)) {   // a later piece: the guess
         h0 = src[-2];
         h1 = src[-1];
     }
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         return xs;
     };
 
-    auto encode_frame = [&](Row &R, int buf, int j) {
+    auto encode_frame = [&](Row &R, int buf, int j, bool upd) {
         int (&x)[16] = R.x;
         x[0] = h0;
         x[1] = h1;
@@ -440,8 +454,10 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
                 rec[2] = make_int4(r.q[8], r.q[9], r.q[10], r.q[11]);
                 rec[3] = make_int4(r.q[12], r.q[13], p, final_sp);
             }
-            h0 = (int)(int16_t)(pay & 0xFFFF);   // pcmBuffer[0] = pcmBuffer[14] (:40)
-            h1 = (int)pay >> 16;                 // pcmBuffer[1] = pcmBuffer[15] (:41)
+            if (!RAGGED || upd) {
+                h0 = (int)(int16_t)(pay & 0xFFFF);   // pcmBuffer[0] = pcmBuffer[14] (:40)
+                h1 = (int)pay >> 16;                 // pcmBuffer[1] = pcmBuffer[15] (:41)
+            }
             VGA_OPAQUE(h0);                      // hide the 16-bit range: keeps the 24-bit multiplies the next frame
             VGA_OPAQUE(h1);                      // asks for (the compiler otherwise widens them to 64-bit mads)
         };
@@ -462,7 +478,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
 
     // ---- CPW = 8: lane = (channel, predictor); candidate B (s1 + 1) and candidate A (s1) are two passes of the SAME lane,
     // inlined back to back (two independent dependent chains: the wave has instructions to issue while one waits).
-    auto encode_frame8 = [&](Row &R, int buf, int j) {
+    auto encode_frame8 = [&](Row &R, int buf, int j, bool upd) {
         int (&x)[16] = R.x;
         x[0] = h0;
         x[1] = h1;
@@ -531,8 +547,10 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
                 rec[2] = make_int4(r.q[8], r.q[9], r.q[10], r.q[11]);
                 rec[3] = make_int4(r.q[12], r.q[13], p, final_sp);
             }
-            h0 = (int)(int16_t)(pay & 0xFFFF);
-            h1 = (int)pay >> 16;
+            if (!RAGGED || upd) {                // (a slot past its last frame keeps the history it ended on)
+                h0 = (int)(int16_t)(pay & 0xFFFF);
+                h1 = (int)pay >> 16;
+            }
             VGA_OPAQUE(h0);
             VGA_OPAQUE(h1);
         };
@@ -549,15 +567,16 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         } else
             finish(r, final_sp, true, false);
     };
-    auto encode_one = [&](Row &R, int buf, int j) __attribute__((always_inline)) {
-        if constexpr (CPW == 4) encode_frame(R, buf, j);
-        else encode_frame8(R, buf, j);
+    auto encode_one = [&](Row &R, int buf, int j, bool upd) __attribute__((always_inline)) {
+        if constexpr (CPW == 4) encode_frame(R, buf, j, upd);
+        else encode_frame8(R, buf, j, upd);
     };
 
     __syncthreads();                                   // tile 0 prepared
     for (int tile = 0; tile < tiles; tile++) {
         const int buf = tile & 1;
-        const int nf = imin(TF, frames - tile * TF);
+        const int nf = imin(TF, frames_wg - tile * TF);
+        const int left = frames - tile * TF;           // RAGGED: this slot's own frames in the tile
         const GcTile &T = s_tile[buf];
         // two row register sets, ping-pong: the LDS reads of frame j+1 are in flight during frame j
         Row RA, RB;
@@ -565,10 +584,10 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
 #pragma unroll 1
         for (int j = 0; j < nf; j += 2) {
             read_row(T, imin(j + 1, TF - 1), RB);
-            encode_one(RA, buf, j);
+            encode_one(RA, buf, j, j < left);
             if (j + 1 < nf) {
                 read_row(T, imin(j + 2, TF - 1), RA);
-                encode_one(RB, buf, j + 1);
+                encode_one(RB, buf, j + 1, j + 1 < left);
             }
         }
         __syncthreads();                               // tile done: helper may flush it and refill this buffer later
@@ -783,17 +802,19 @@ __global__ __launch_bounds__(64) void gc_encode_seam_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, int seg_frames,
     const int16_t *__restrict__ coefs, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch,
     const int16_t *__restrict__ seg_state, int *__restrict__ first_open, int *__restrict__ seam_flag,
-    int *__restrict__ seam_end, int max_frames, int force_open)
+    int *__restrict__ seam_end, int max_frames, int force_open, const Ragged rg)
 {
     const int lane = threadIdx.x;
     const int pr = lane & 7;                            // this lane's predictor
-    const int ch_raw = blockIdx.x * 8 + (lane >> 3);
+    const int slot_raw = blockIdx.x * 8 + (lane >> 3);
     const int k = blockIdx.y + 1;
     const int64_t f0 = (int64_t)k * seg_frames;
-    const bool valid = ch_raw < nch && f0 * 14 < total_samples;
-    const int ch = ch_raw < nch ? ch_raw : nch - 1;
-    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
-    uint8_t *dst = adpcm + (int64_t)ch * adpcm_pitch;
+    const int slot = slot_raw < nch ? slot_raw : nch - 1;
+    const int ch = rg.order ? rg.order[slot] : slot;
+    if (rg.order) total_samples = rg.length[ch];        // ragged: the seam exists only where the channel reaches piece k
+    const bool valid = slot_raw < nch && f0 * 14 < total_samples;
+    const int16_t *src = pcm + (rg.order ? rg.pcm_off[ch] : (int64_t)ch * pcm_pitch);
+    uint8_t *dst = adpcm + (rg.order ? rg.adpcm_off[ch] : (int64_t)ch * adpcm_pitch);
     const int16_t *cf = coefs + ch * 16;
     const int c0 = cf[2 * pr], c1 = cf[2 * pr + 1];
     const bool coef_ok = (c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1) <= 32767;
@@ -823,20 +844,22 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, int seg_frames, int segments,
     const int16_t *__restrict__ coefs, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch,
     int16_t *__restrict__ seg_state, int *__restrict__ first_open, const int *__restrict__ seam_flag,
-    const int *__restrict__ seam_end, int force_open)
+    const int *__restrict__ seam_end, int force_open, const Ragged rg)
 {
     const int lane = threadIdx.x;
     const int pr = lane & 7;
-    const int ch_raw = blockIdx.x * 8 + (lane >> 3);
-    const bool live = ch_raw < nch;
-    const int ch = live ? ch_raw : nch - 1;
+    const int slot_raw = blockIdx.x * 8 + (lane >> 3);
+    const bool live = slot_raw < nch;
+    const int slot = live ? slot_raw : nch - 1;
+    const int ch = rg.order ? rg.order[slot] : slot;
+    if (rg.order) total_samples = rg.length[ch];        // ragged: per lane from here on
     const int mine = live ? first_open[ch] : 0x7f7f7f7f;
     int kmin = mine;
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) kmin = imin(kmin, __shfl_xor(kmin, o));
     if (kmin >= segments) return;                       // no open seam among these eight channels
-    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
-    uint8_t *dst = adpcm + (int64_t)ch * adpcm_pitch;
+    const int16_t *src = pcm + (rg.order ? rg.pcm_off[ch] : (int64_t)ch * pcm_pitch);
+    uint8_t *dst = adpcm + (rg.order ? rg.adpcm_off[ch] : (int64_t)ch * adpcm_pitch);
     const int16_t *cf = coefs + ch * 16;
     const int c0 = cf[2 * pr], c1 = cf[2 * pr + 1];
     const bool coef_ok = (c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1) <= 32767;
@@ -845,13 +868,16 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
     int last_k = 0;
     for (int k = kmin; k < segments; k++) {
         const int64_t f0 = (int64_t)k * seg_frames;
-        if (f0 * 14 >= total_samples) break;            // uniform: pieces past the end do not exist
+        // pieces past a channel's end do not exist (ragged batches: per lane -- such a lane keeps what it had at its
+        // own end, for the partial last frame below)
+        const bool exists = f0 * 14 < total_samples;
+        if (!__any(exists)) break;
         last_k = k;
         const bool is_last = (int64_t)(k + 1) * seg_frames * 14 >= total_samples || k == segments - 1;
         const int64_t idx = (int64_t)(k - 1) * nch + ch;
-        const bool flagged = live && seam_flag[idx] != 0;
+        const bool flagged = live && exists && seam_flag[idx] != 0;
         const int ended = seam_end[idx];
-        const bool ran = live && have;
+        const bool ran = live && have && exists;
         bool open = ran;
         int h0 = v0, h1 = v1;
         if (__any(ran)) {
@@ -862,7 +888,8 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
             }
             seam_run(src, dst, c0, c1, coef_ok, pr, ch, k, total_samples, seg_frames, seg_frames, force_open, h0, h1, g2, g1, open);
         }
-        if (ran && open) {                              // still apart at the piece's end: carry on into the next one
+        if (!exists) {
+        } else if (ran && open) {                       // still apart at the piece's end: carry on into the next one
             v0 = h0;
             v1 = h1;
         } else if (flagged) {                           // met the run from T, whose own seam ran out of frames: its end is the truth
@@ -874,8 +901,8 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
     }
     // apart to the very end: only the partial last frame is left to encode from V -- here, by the channel's eight lanes (the
     // serial repair launch that used to take over re-ran the whole last piece: 4.9 ms of a 256-channel encode's 31)
-    if (total_samples % 14 != 0 && __any(live && have))
-        encode_tail_frame(src, dst, c0, c1, coef_ok, pr, total_samples, v0, v1, live && have);
+    if (__any(live && have && total_samples % 14 != 0))
+        encode_tail_frame(src, dst, c0, c1, coef_ok, pr, total_samples, v0, v1, live && have && total_samples % 14 != 0);
     (void)last_k;
     if (live && pr == 0) first_open[ch] = 0x7f7f7f7f;
 }
@@ -887,12 +914,18 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
 // pieces down to 512 frames.
 constexpr int MIN_PIECE_FRAMES = 3072;
 
-template <int CPW>
+// Ragged batches cut their channels into pieces of ONE length (a channel has as many as it reaches into); with a few
+// times more workgroups than the chip holds at once, the ones that end early (short channels, short last pieces) make
+// room for the rest instead of leaving their SIMDs idle.
+constexpr int RAGGED_OVERSUBSCRIPTION = 4;
+
+template <int CPW, bool RAGGED>
 static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
                                 const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,
-                                hipStream_t stream, void *d_scratch, size_t scratch_bytes)
+                                hipStream_t stream, void *d_scratch, size_t scratch_bytes, const Ragged &rg)
 {
     constexpr int CS = Lay<CPW>::CS;
+    if (RAGGED) sample_count = rg.max_length;
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
     // two encoder waves per SIMD fill the chip: fewer channels than that are cut into time pieces (each at least
     // MIN_PIECE_FRAMES frames: a seam re-encodes a few dozen as a rule; the ones that take longer than their piece go to
@@ -901,6 +934,13 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
     const int cus = device_cu_count();
     const int frames = (sample_count + 13) / 14;
     int segments = cus * 4 / groups;                   // = SW encoder waves on every SIMD
+    if (RAGGED) {
+        // pieces of total / (workgroups wanted) frames for every channel; `segments` = what the longest channel needs
+        const int64_t want = (int64_t)cus * 4 * RAGGED_OVERSUBSCRIPTION;
+        int64_t piece = (rg.total_frames + CS * want - 1) / (CS * want);
+        if (piece < MIN_PIECE_FRAMES) piece = MIN_PIECE_FRAMES;
+        segments = (int)((frames + piece - 1) / piece);
+    }
     if (segments > frames / MIN_PIECE_FRAMES) segments = frames / MIN_PIECE_FRAMES;
     if (segments < 1) segments = 1;
     if (segments > 1024) segments = 1024;
@@ -925,24 +965,24 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
         first_open = reinterpret_cast<int *>(base + 3 * state_bytes);
         VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
     }
-    hipLaunchKernelGGL((gc_encode_kernel<false, CPW>), dim3(groups, segments), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch,
+    hipLaunchKernelGGL((gc_encode_kernel<false, CPW, RAGGED>), dim3(groups, segments), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch,
                        sample_count, seg_frames, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state,
-                       (const int *)nullptr);
+                       (const int *)nullptr, rg);
     VGA_HIP_TRY(hipGetLastError());
     if (segments > 1) {
         hipLaunchKernelGGL(gc_encode_seam_kernel, dim3((nch + 7) / 8, segments - 1), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
                            sample_count, seg_frames, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
-                           seg_frames, force_open_seams());
+                           seg_frames, force_open_seams(), rg);
         VGA_HIP_TRY(hipGetLastError());
         // the seams that were still open at the end of their piece, chained piece after piece (none: every wave returns)
         hipLaunchKernelGGL(gc_encode_chain_kernel, dim3((nch + 7) / 8), dim3(64), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
                            seg_frames, segments, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
-                           force_open_seams());
+                           force_open_seams(), rg);
         VGA_HIP_TRY(hipGetLastError());
         // repair: the same encoder, serially over the last piece, for a channel the chain could not finish (a partial
         // last frame after a run that never met; none: every workgroup returns)
-        hipLaunchKernelGGL((gc_encode_kernel<true, CPW>), dim3(groups, 1), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
-                           seg_frames, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state, (const int *)first_open);
+        hipLaunchKernelGGL((gc_encode_kernel<true, CPW, RAGGED>), dim3(groups, 1), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
+                           seg_frames, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state, (const int *)first_open, rg);
         VGA_HIP_TRY(hipGetLastError());
     }
     return VGA_OK;
@@ -953,13 +993,16 @@ size_t encode_scratch_bytes(int nch) { return (size_t)(nch > 0 ? nch : 0) * (102
 
 int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
                   const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,
-                  hipStream_t stream, void *d_scratch, size_t scratch_bytes)
+                  hipStream_t stream, void *d_scratch, size_t scratch_bytes, const Ragged *rg)
 {
+    if (rg)                                            // ragged batches: the (channel, predictor) layout only
+        return launch_encode_layout<8, true>(d_pcm, 0, nch, 0, d_coefs, d_hist1, d_hist2, d_adpcm, 0, stream, d_scratch,
+                                             scratch_bytes, *rg);
     if (encoder_layout() == 4)
-        return launch_encode_layout<4>(d_pcm, pcm_pitch, nch, sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, stream,
-                                       d_scratch, scratch_bytes);
-    return launch_encode_layout<8>(d_pcm, pcm_pitch, nch, sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, stream,
-                                   d_scratch, scratch_bytes);
+        return launch_encode_layout<4, false>(d_pcm, pcm_pitch, nch, sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, stream,
+                                              d_scratch, scratch_bytes, Ragged{});
+    return launch_encode_layout<8, false>(d_pcm, pcm_pitch, nch, sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, stream,
+                                          d_scratch, scratch_bytes, Ragged{});
 }
 
 }  // namespace gc

@@ -325,9 +325,18 @@ __device__ __forceinline__ void wave_lds_sync()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+#ifndef VGA_COEFS_PF_REC
+#define VGA_COEFS_PF_REC 1
+#endif
+#ifndef VGA_COEFS_PF_PCM
+#define VGA_COEFS_PF_PCM 1
+#endif
+constexpr int COEF_PF_PCM = VGA_COEFS_PF_PCM;      // chunks of PCM in flight per wave in pass 0
+constexpr int COEF_PF_REC = VGA_COEFS_PF_REC;      // chunks of records in flight per wave in the Lloyd passes
+
 __global__ __launch_bounds__(64) void gc_coefs_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int length,
-    double2 *__restrict__ records, int16_t *__restrict__ coefs_out)
+    double2 *__restrict__ records, int16_t *__restrict__ coefs_out, const Ragged rg)
 {
     // compacted (d1, d2) of the current chunk, bucket-major, every bucket starting on a multiple of 8 slots and
     // zero-padded to the next one (<= 64 + 8 * 7 slots); two buffers (chunk parity): one barrier per chunk
@@ -337,11 +346,13 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     __shared__ double s_sum[8][3];     // bufferList
     __shared__ int s_cnt[8];           // buffer1
 
-    const int ch = blockIdx.x;
+    // ragged batch: workgroup i takes channel order[i] (longest first), with its own length and offsets
+    const int ch = rg.order ? rg.order[blockIdx.x] : (int)blockIdx.x;
+    if (rg.order) length = rg.length[ch];
     const int lane = threadIdx.x;
-    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
+    const int16_t *src = pcm + (rg.order ? rg.pcm_off[ch] : (int64_t)ch * pcm_pitch);
     const int frames = (length + 13) / 14;
-    double2 *rec = records + (int64_t)ch * frames;
+    double2 *rec = records + (rg.order ? rg.rec_off[ch] : (int64_t)ch * frames);
     const int my_bucket = lane >> 1;   // accumulator lanes: lane < 16
     const int my_comp = lane & 1;
 
@@ -360,22 +371,21 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     // the record prefetch below; frame 0 and the zero-padded tail take load_frame16()'s slow path.
     const int f_hi = (length - 14) / 14;               // last frame with a full window
     const bool have_interior = f_hi >= 1;
-    uint32_t w[8];
-    auto prefetch = [&](int f) {
+    uint32_t wr[COEF_PF_PCM][8];                       // ring: chunks of PCM in flight
+    auto prefetch = [&](int f, uint32_t (&w)[8]) {
         const int fp = min(max(f, 1), max(f_hi, 1));
         const uint32_t *p32 = reinterpret_cast<const uint32_t *>(src + (int64_t)fp * 14 - 2);
 #pragma unroll
         for (int i = 0; i < 8; i++) w[i] = p32[i];
     };
-    if (have_interior) prefetch(lane);
-    for (int base = 0; base < frames; base += 64, par ^= 1) {
+    if (have_interior) {
+#pragma unroll
+        for (int q = 0; q < COEF_PF_PCM; q++) prefetch(lane + 64 * q, wr[q]);
+    }
+    auto record_chunk = [&](int base, const uint32_t (&wc)[8]) __attribute__((always_inline)) {
         const int f = base + lane;
         bool valid = false;
         double d1 = 0.0, d2 = 0.0;
-        uint32_t wc[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) wc[i] = w[i];
-        if (have_interior) prefetch(f + 64);           // in flight during this chunk
         if (f < frames) {
             FrameSums fs;
             if (have_interior && f >= 1 && f <= f_hi) {
@@ -405,6 +415,19 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
         wave_lds_sync();
         if (lane < 2) acc = ordered_sum(acc, &s_d[par][lane][0], n, n);
         cnt += n;
+        par ^= 1;
+    };
+    for (int base = 0; base < frames; base += 64 * COEF_PF_PCM) {
+#pragma unroll
+        for (int q = 0; q < COEF_PF_PCM; q++) {
+            if (base + 64 * q < frames) {              // wave-uniform
+                uint32_t wc[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) wc[i] = wr[q][i];
+                if (have_interior) prefetch(base + 64 * (q + COEF_PF_PCM) + lane, wr[q]);   // in flight during the next chunks
+                record_chunk(base + 64 * q, wc);
+            }
+        }
     }
     __syncthreads();
     if (lane < 2) s_sum[0][1 + lane] = acc;
@@ -442,16 +465,17 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
 
             acc = 0.0;
             cnt = 0;
-            // record prefetch, one chunk ahead.  The loads are unconditional (clamped index): a load under
-            // a lane-divergent condition makes the compiler wait for it right at the join.
-            double2 r_next = rec[min(lane, frames - 1)];
-            for (int base = 0; base < frames; base += 64, par ^= 1) {
+            // record prefetch, COEF_PF_REC chunks ahead (a ring of registers; the chunk loop is unrolled by the ring's
+            // length so that the ring is indexed statically).  The loads are unconditional (clamped index): a load
+            // under a lane-divergent condition makes the compiler wait for it right at the join.
+            double2 ring[COEF_PF_REC];
+#pragma unroll
+            for (int q = 0; q < COEF_PF_REC; q++) ring[q] = rec[max(min(lane + 64 * q, frames - 1), 0)];   // (an empty channel still owns one slot)
+            auto lloyd_chunk = [&](int base, const double2 r) __attribute__((always_inline)) {
                 const int f = base + lane;
                 bool valid = false;
                 int idx = 0;
                 double d1 = 0.0, d2 = 0.0;
-                const double2 r = r_next;
-                r_next = rec[min(f + 64, frames - 1)];               // in flight during this chunk
                 if (f < frames && r.x == r.x) {
                     valid = true;
                     // r = (dst[1], dst[2]) of MatrixFilter, stored by pass 0 (one f64 divide per frame there,
@@ -487,6 +511,17 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
                 if (lane < 2 * EXP) {
                     acc = ordered_sum(acc, &s_d[par][my_comp][my_start], my_n, max_n);
                     cnt += my_n;
+                }
+                par ^= 1;
+            };
+            for (int base = 0; base < frames; base += 64 * COEF_PF_REC) {
+#pragma unroll
+                for (int q = 0; q < COEF_PF_REC; q++) {
+                    if (base + 64 * q < frames) {                    // wave-uniform
+                        const double2 r = ring[q];
+                        ring[q] = rec[min(base + 64 * (q + COEF_PF_REC) + lane, frames - 1)];   // in flight during the next COEF_PF_REC chunks
+                        lloyd_chunk(base + 64 * q, r);
+                    }
                 }
             }
             __syncthreads();
@@ -831,9 +866,16 @@ __global__ __launch_bounds__(256) void synth_kernel(int16_t *__restrict__ pcm, i
 constexpr int SOLO_MAX_CHANNELS = 896;                      // 768 channels: 15.2 vs 19.2 ms, 1024: 24.1 vs 19.2 (profiles/r03_d_coefs_variants.log)
 
 int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, int16_t *d_coefs,
-                 void *d_workspace, hipStream_t stream)
+                 void *d_workspace, hipStream_t stream, const Ragged *rg)
 {
     if (nch <= 0) return VGA_OK;
+    if (rg) {
+        // ragged: one wave per channel whatever the count (the workgroup forms share one `length`), longest channel first
+        hipLaunchKernelGGL(gc_coefs_kernel, dim3(nch), dim3(64), 0, stream, d_pcm, (int64_t)0, nch, 0,
+                           reinterpret_cast<double2 *>(d_workspace), d_coefs, *rg);
+        VGA_HIP_TRY(hipGetLastError());
+        return VGA_OK;
+    }
     // One wave per channel is the faster kernel only when it fills the chip (4 waves per SIMD at 4096 channels: 41.7 vs
     // 43.1 ms for 60 s channels); with fewer channels the workgroups of four channels + summing wave win, because a chunk
     // costs max(records, sums) instead of their sum: 3072 channels 31.1 vs 34.4 ms, 2048: 24.7 vs 28.3, 1024: 19.1 vs
@@ -847,7 +889,7 @@ int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, i
     const bool solo = variant == 3 || (variant == 0 && nch <= SOLO_MAX_CHANNELS);
     if (per_channel)
         hipLaunchKernelGGL(gc_coefs_kernel, dim3(nch), dim3(64), 0, stream, d_pcm, pcm_pitch, nch, length,
-                           reinterpret_cast<double2 *>(d_workspace), d_coefs);
+                           reinterpret_cast<double2 *>(d_workspace), d_coefs, Ragged{});
     else if (solo)
         hipLaunchKernelGGL(gc_coefs_kernel4<true>, dim3(nch), dim3(COEF_THREADS), 0, stream, d_pcm, pcm_pitch, nch, length,
                            reinterpret_cast<double2 *>(d_workspace), d_coefs);

@@ -6,17 +6,34 @@
 namespace vga {
 namespace gc {
 
+// A ragged batch (the `*_v` entry points: channels of different lengths, the reference's file-level batch,
+// VGAudio.Cli/Batch.cs:24-25): per-channel shapes in device tables.  Channel c's PCM starts at d_pcm + pcm_off[c]
+// (samples; a multiple of 8), its ADPCM at d_adpcm + adpcm_off[c] (bytes; a multiple of 16), its records at
+// workspace + rec_off[c].  Work slots (workgroup / wave / lane indices) map to channels through `order`, longest channel
+// first: the slots that share a wave or a workgroup then hold channels of similar length and the long ones start first.
+// The kernels take the struct by value; order == nullptr means "uniform batch" (rows `pitch` apart, one length).
+struct Ragged {
+    const int *order = nullptr;         // [nch] work slot -> channel
+    const int *length = nullptr;        // [nch] samples
+    const int64_t *pcm_off = nullptr;   // [nch]
+    const int64_t *adpcm_off = nullptr; // [nch]
+    const int64_t *rec_off = nullptr;   // [nch]
+    int max_length = 0;                 // host-side copy: the longest channel
+    int64_t total_frames = 0;           // host-side copy: sum of ceil(length / 14)
+};
+
+// rg != nullptr: pcm_pitch / length (sample_count) are ignored, d_pcm / d_adpcm are the bases the offsets count from
 int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, int16_t *d_coefs,
-                 void *d_workspace, hipStream_t stream);
+                 void *d_workspace, hipStream_t stream, const Ragged *rg = nullptr);
 // d_scratch (optional, encode_scratch_bytes(nch) bytes): where the time pieces' states go; allocated stream-ordered when null
 int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
                   const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,
-                  hipStream_t stream, void *d_scratch = nullptr, size_t scratch_bytes = 0);
+                  hipStream_t stream, void *d_scratch = nullptr, size_t scratch_bytes = 0, const Ragged *rg = nullptr);
 size_t encode_scratch_bytes(int nch);
-// gc_decode_kernel.hip (serial wave + helper waves)
+// gc_decode_kernel.hip
 int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs, int nch, int sample_count,
                   const int16_t *d_hist1, const int16_t *d_hist2, int16_t *d_pcm, int64_t pcm_pitch, int *d_status,
-                  hipStream_t stream);
+                  hipStream_t stream, const Ragged *rg = nullptr);
 // gc_channel_kernels.hip (channel metadata)
 int launch_align_gather(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int loop_start, int loop_end,
                         int samples_to_keep, int samples_to_encode, int16_t *d_new_pcm, int64_t new_pitch,

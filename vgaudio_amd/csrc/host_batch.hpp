@@ -82,12 +82,32 @@ inline int for_each_device_share(int units, int min_units, Body &&body)
     return r.code;
 }
 
+// bytes a job uploads / downloads (ragged jobs: the sum of their rows)
+inline size_t job_in_total(const pipe::Job &job)
+{
+    if (!job.in_rows) return 0;
+    const size_t rows = (size_t)job.units * job.in_rows_per_unit;
+    if (!job.in_row_sizes) return rows * job.in_row_bytes;
+    size_t t = 0;
+    for (size_t r = 0; r < rows; r++) t += job.in_row_sizes[r];
+    return t;
+}
+inline size_t job_out_total(const pipe::Job &job)
+{
+    if (!job.out_rows) return 0;
+    const size_t rows = (size_t)job.units * job.out_rows_per_unit;
+    if (!job.out_row_sizes) return rows * job.out_row_bytes;
+    size_t t = 0;
+    for (size_t r = 0; r < rows; r++) t += job.out_row_sizes[r];
+    return t;
+}
+
 // Units per chunk run_batch_pipeline() will use for this job (callers size per-chunk scratch with it).
 inline int planned_chunk_units(const pipe::Job &job, int default_chunk_units)
 {
     const PipeOverride &o = pipe_override();
-    const size_t in_total = job.in_rows ? (size_t)job.units * job.in_rows_per_unit * job.in_row_bytes : 0;
-    const size_t out_total = job.out_rows ? (size_t)job.units * job.out_rows_per_unit * job.out_row_bytes : 0;
+    const size_t in_total = job_in_total(job);
+    const size_t out_total = job_out_total(job);
     int chunk = o.chunk_units > 0 ? o.chunk_units : default_chunk_units;
     // a call that downloads more than it uploads (a decode) is bound by the download, which cannot start before the first
     // chunk's kernels have run: quarter chunks there (GC decode, 4096 x 60 s: the first download started at 87 ms)
@@ -107,8 +127,11 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     int device = 0;
     VGA_HIP_TRY(hipGetDevice(&device));
     job.device = device;
-    const size_t in_total = job.in_rows ? (size_t)job.units * job.in_rows_per_unit * job.in_row_bytes : 0;
-    const size_t out_total = job.out_rows ? (size_t)job.units * job.out_rows_per_unit * job.out_row_bytes : 0;
+    const size_t in_total = job_in_total(job);
+    const size_t out_total = job_out_total(job);
+    // a ragged job's typical row decides between page-locking rows one by one and the staging ring
+    const size_t in_row_typical = job.in_row_sizes ? in_total / std::max<size_t>(1, (size_t)job.units * job.in_rows_per_unit) : job.in_row_bytes;
+    const size_t out_row_typical = job.out_row_sizes ? out_total / std::max<size_t>(1, (size_t)job.units * job.out_rows_per_unit) : job.out_row_bytes;
     // Measured on the MI355X box (tools/bench_h2d_modes.hip, tools/bench_overlap.hip, tools/sweep_host_pipeline.py;
     // profiles/r02_*): page-locking the caller's rows for the call (hipHostRegister) lets ONE stream of direct copies
     // run at the link's rate (~56 GB/s) on the DMA engines next to the kernels; copies issued on several streams at once
@@ -121,11 +144,11 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     job.feeders = o.feeders > 0 ? o.feeders : 1;
     job.drainers = o.drainers > 0 ? o.drainers : (out_total >= ((size_t)256 << 20) ? 2 : 1);
     // rows worth page-locking one by one: from 256 KB on (smaller rows are cheap to copy into the ring)
-    job.direct = o.slot_bytes < 0 || (o.slot_bytes == 0 && job.in_row_bytes >= ((size_t)256 << 10));
+    job.direct = o.slot_bytes < 0 || (o.slot_bytes == 0 && in_row_typical >= ((size_t)256 << 10));
     // downloads: through the ring when they are the smaller direction (an encode), direct into page-locked caller rows
     // when they are the larger one (a decode: 23.6 GB of PCM through two memcpy threads would be the bottleneck;
     // tools/time_decode_batches.py: ADX 582 -> 527 ms, HCA 323 -> 271 ms)
-    job.direct_out = o.slot_bytes < 0 || (o.slot_bytes == 0 && job.out_row_bytes >= ((size_t)256 << 10) && out_total > in_total);
+    job.direct_out = o.slot_bytes < 0 || (o.slot_bytes == 0 && out_row_typical >= ((size_t)256 << 10) && out_total > in_total);
     job.shared_streams = true;
     job.slot_bytes = o.slot_bytes > 0 ? (size_t)o.slot_bytes : (o.slot_bytes < -1 ? (size_t)(-o.slot_bytes) : (size_t)32 << 20);
     job.chunk_units = planned_chunk_units(job, default_chunk_units);

@@ -142,6 +142,15 @@ struct Job {
     // without output rows: when its kernels have run) -- on one of the call's worker threads, never concurrently
     std::function<void(int first, int count)> chunk_done;
     int feeders = 8, drainers = 4;
+    // Ragged jobs (the `*_v` entry points: rows of different sizes, packed on the device).  in_row_sizes[r] / d_in_offsets[r]
+    // replace in_row_bytes / r * d_in_pitch (same for the output side); in_row_bytes / d_in_pitch then hold the largest row
+    // (what a ring slot must be able to take).  A staged slot takes consecutive rows and mirrors their device layout, gaps
+    // included, so that it still travels with one copy.
+    const size_t *in_row_sizes = nullptr, *d_in_offsets = nullptr;
+    const size_t *out_row_sizes = nullptr, *d_out_offsets = nullptr;
+    // explicit chunk boundaries in units: chunk k = [chunk_begin[k], chunk_begin[k + 1]) (ragged jobs cut by bytes, not by
+    // count); empty = by chunk_units / head_units / tail_units
+    std::vector<int> chunk_begin;
     size_t slot_bytes = (size_t)8 << 20;   // target size of one ring slot (whole rows; at least one row)
     int ring = 3;                          // slots per feeder / drainer
     // true: no staging -- the workers hand the caller's rows straight to hipMemcpyAsync (the runtime moves pageable
@@ -223,16 +232,19 @@ inline Result run(const Job &job)
     const int chunk_units = std::max(1, std::min(job.chunk_units > 0 ? job.chunk_units : job.units, job.units));
     // chunk k covers units [cbegin[k], cbegin[k + 1])
     std::vector<int> cbegin;
-    {
+    if (job.chunk_begin.size() >= 2 && job.chunk_begin.front() == 0 && job.chunk_begin.back() == job.units) {
+        cbegin = job.chunk_begin;
+    } else {
         int u = 0;
         if (job.head_units > 0 && job.head_units < chunk_units && job.units > job.head_units + chunk_units) {
             cbegin.push_back(0);
             u = job.head_units;
         }
         for (; u < job.units; u += chunk_units) cbegin.push_back(u);
+        cbegin.push_back(job.units);
     }
-    cbegin.push_back(job.units);
-    if (job.tail_units > 0 && cbegin.size() >= 2 && job.units - cbegin[cbegin.size() - 2] > job.tail_units) {
+    if (!job.chunk_begin.empty()) {
+    } else if (job.tail_units > 0 && cbegin.size() >= 2 && job.units - cbegin[cbegin.size() - 2] > job.tail_units) {
         // the last chunk (the only one of a small call) as (rest, tail): the tail's upload runs under the rest's kernels,
         // and with two kernel lanes both parts' kernels run side by side, the short one last
         cbegin.back() = job.units - job.tail_units;
@@ -257,8 +269,48 @@ inline Result run(const Job &job)
     const int R = std::max(2, job.ring);
     const int in_slot_rows = has_in ? (int)std::max<size_t>(1, job.slot_bytes / std::max<size_t>(1, job.d_in_pitch)) : 0;
     const int out_slot_rows = has_out ? (int)std::max<size_t>(1, job.slot_bytes / std::max<size_t>(1, job.d_out_pitch)) : 0;
+    // per-row shapes (uniform jobs: the pitch and the one size)
+    auto in_size = [&](int r) { return job.in_row_sizes ? job.in_row_sizes[r] : job.in_row_bytes; };
+    auto in_off = [&](int r) { return job.d_in_offsets ? job.d_in_offsets[r] : (size_t)r * job.d_in_pitch; };
+    auto out_size = [&](int r) { return job.out_row_sizes ? job.out_row_sizes[r] : job.out_row_bytes; };
+    auto out_off = [&](int r) { return job.d_out_offsets ? job.d_out_offsets[r] : (size_t)r * job.d_out_pitch; };
+    // What a worker takes at a time: a group of consecutive rows of one chunk whose device extent fits a ring slot
+    // (uniform jobs: in_slot_rows rows).  groups of chunk k = [gfirst[k], gfirst[k + 1]).
+    struct Groups { std::vector<int> begin; std::vector<int> gfirst; size_t slot_cap = 0; };
+    auto make_groups = [&](bool have, int rows_per_unit, int slot_rows, size_t pitch, const size_t *sizes, const size_t *offs) {
+        Groups g;
+        g.slot_cap = (size_t)std::max(slot_rows, 1) * pitch;
+        g.gfirst.push_back(0);
+        for (int k = 0; k < chunks && have; k++) {
+            const int row0 = cbegin[k] * rows_per_unit, row1 = cbegin[k + 1] * rows_per_unit;
+            int r = row0;
+            while (r < row1) {
+                g.begin.push_back(r);
+                if (!sizes) {
+                    r = std::min(r + slot_rows, row1);
+                } else {
+                    int e = r + 1;                             // at least one row, then as many as fit the slot
+                    while (e < row1 && offs[e] + sizes[e] - offs[r] <= g.slot_cap) e++;
+                    r = e;
+                }
+            }
+            g.gfirst.push_back((int)g.begin.size());
+        }
+        if (!have)
+            for (int k = 0; k < chunks; k++) g.gfirst.push_back(0);
+        g.begin.push_back(has_in || has_out ? job.units * rows_per_unit : 0);   // sentinel: one past the last row
+        return g;
+    };
+    const Groups gin = make_groups(has_in, job.in_rows_per_unit, in_slot_rows, job.d_in_pitch, job.in_row_sizes, job.d_in_offsets);
+    const Groups gout = make_groups(has_out, job.out_rows_per_unit, out_slot_rows, job.d_out_pitch, job.out_row_sizes, job.d_out_offsets);
+    // rows of group i of a side: [begin[i], min(begin[i + 1], the chunk's last row))
+    auto group_rows = [&](const Groups &g, int k, int i, int rows_per_unit, int &r, int &n) {
+        r = g.begin[i];
+        const int row1 = cbegin[k + 1] * rows_per_unit;
+        n = std::min(g.begin[i + 1], row1) - r;
+    };
 
-    std::vector<std::atomic<int>> next_in(chunks), next_out(chunks);   // per chunk: first row not yet taken by a worker
+    std::vector<std::atomic<int>> next_in(chunks), next_out(chunks);   // per chunk: first group not yet taken by a worker
     for (auto &a : next_in) a.store(0);
     for (auto &a : next_out) a.store(0);
     Shared sh;
@@ -297,8 +349,8 @@ inline Result run(const Job &job)
     for (auto *v : {&upl, &comp, &cstart, &dlev})
         for (auto &e : *v) check(hipEventCreateWithFlags(&e, timeline ? hipEventDefault : hipEventDisableTiming), "hipEventCreate");
     if (timeline) check(hipEventRecord(cstart[chunks], cstreams[0]), "hipEventRecord");
-    if (ok && has_in && !job.direct && !in_ring.alloc((size_t)F * R * in_slot_rows * job.d_in_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (input ring)");
-    if (ok && has_out && !job.direct_out && !out_ring.alloc((size_t)D * R * out_slot_rows * job.d_out_pitch)) check(hipErrorOutOfMemory, "hipHostMalloc (output ring)");
+    if (ok && has_in && !job.direct && !in_ring.alloc((size_t)F * R * gin.slot_cap)) check(hipErrorOutOfMemory, "hipHostMalloc (input ring)");
+    if (ok && has_out && !job.direct_out && !out_ring.alloc((size_t)D * R * gout.slot_cap)) check(hipErrorOutOfMemory, "hipHostMalloc (output ring)");
 
     // progress (job.chunk_done): every drainer marks the end of its copies of chunk k with an event and, while it waits for
     // the next chunk's kernels anyway, for that event; the drainer that is last to see chunk k complete reports it, after
@@ -323,7 +375,7 @@ inline Result run(const Job &job)
     // ---------------------------------------------------------------- feeder t
     auto feeder = [&](int t) {
         VGA_PIPE_TRY(hipSetDevice(job.device));
-        char *ring = static_cast<char *>(in_ring.p) + (size_t)t * R * in_slot_rows * job.d_in_pitch;
+        char *ring = static_cast<char *>(in_ring.p) + (size_t)t * R * gin.slot_cap;
         int64_t used = 0;                                  // slots handed to the DMA engine so far
         std::vector<void *> &registered = locked_in[t];    // direct mode: rows this thread page-locked for the call
         double t_copy = 0, t_wait = 0, t_issue = 0, t_boundary = 0, t_final = 0;
@@ -335,15 +387,14 @@ inline Result run(const Job &job)
                         sh.st.feed_max = std::max(sh.st.feed_max, now() - t0); }
         } report{sh, t_copy, t_wait, t_issue, t_boundary, t_final, t_start};
         for (int k = 0; k < chunks && !sh.err.load(); k++) {
-            const int row0 = cbegin[k] * job.in_rows_per_unit;
-            const int row1 = cbegin[k + 1] * job.in_rows_per_unit;
             // row groups are handed out on demand: a feeder that runs on a core far from the caller's pages (or shares
             // its core) simply takes fewer of them -- with a fixed split the slowest thread set the upload time
             for (;;) {
                 if (sh.err.load()) break;
-                const int r = row0 + next_in[k].fetch_add(in_slot_rows);
-                if (r >= row1) break;
-                const int n = std::min(in_slot_rows, row1 - r);
+                const int gi = gin.gfirst[k] + next_in[k].fetch_add(1);
+                if (gi >= gin.gfirst[k + 1]) break;
+                int r, n;
+                group_rows(gin, k, gi, job.in_rows_per_unit, r, n);
                 if (job.direct) {
                     const double ta = now();
                     for (int i = 0; i < n; i++) {
@@ -351,12 +402,13 @@ inline Result run(const Job &job)
                         // that cannot be registered (already registered by the caller, shares a page with its neighbour,
                         // ...) is copied by the runtime's pageable path, which is correct but blocks this thread
                         void *row = const_cast<void *>(job.in_rows[r + i]);
-                        if (job.register_rows && hipHostRegister(row, job.in_row_bytes, hipHostRegisterDefault) == hipSuccess)
+                        const size_t bytes = in_size(r + i);
+                        if (bytes == 0) continue;
+                        if (job.register_rows && hipHostRegister(row, bytes, hipHostRegisterDefault) == hipSuccess)
                             registered.push_back(row);
                         else
                             (void)hipGetLastError();
-                        VGA_PIPE_TRY(hipMemcpyAsync(job.d_in + (size_t)(r + i) * job.d_in_pitch, row, job.in_row_bytes,
-                                                    hipMemcpyHostToDevice, fstream[t]));
+                        VGA_PIPE_TRY(hipMemcpyAsync(job.d_in + in_off(r + i), row, bytes, hipMemcpyHostToDevice, fstream[t]));
                     }
                     t_issue += now() - ta;
                     continue;
@@ -366,12 +418,13 @@ inline Result run(const Job &job)
                 if (used >= R) VGA_PIPE_TRY(hipEventSynchronize(fslot[t * R + s]));      // the slot's previous upload is done
                 double tb = now();
                 t_wait += tb - ta;
-                char *slot = ring + (size_t)s * in_slot_rows * job.d_in_pitch;
-                for (int i = 0; i < n; i++) std::memcpy(slot + (size_t)i * job.d_in_pitch, job.in_rows[r + i], job.in_row_bytes);
+                char *slot = ring + (size_t)s * gin.slot_cap;
+                for (int i = 0; i < n; i++)
+                    if (in_size(r + i)) std::memcpy(slot + (in_off(r + i) - in_off(r)), job.in_rows[r + i], in_size(r + i));
                 ta = now();
                 t_copy += ta - tb;
-                const size_t bytes = (size_t)(n - 1) * job.d_in_pitch + job.in_row_bytes;
-                VGA_PIPE_TRY(hipMemcpyAsync(job.d_in + (size_t)r * job.d_in_pitch, slot, bytes, hipMemcpyHostToDevice, fstream[t]));
+                const size_t bytes = in_off(r + n - 1) - in_off(r) + in_size(r + n - 1);
+                if (bytes) VGA_PIPE_TRY(hipMemcpyAsync(job.d_in + in_off(r), slot, bytes, hipMemcpyHostToDevice, fstream[t]));
                 VGA_PIPE_TRY(hipEventRecord(fslot[t * R + s], fstream[t]));
                 t_issue += now() - ta;
                 used++;
@@ -393,7 +446,7 @@ inline Result run(const Job &job)
     // ---------------------------------------------------------------- drainer u
     auto drainer = [&](int u) {
         VGA_PIPE_TRY(hipSetDevice(job.device));
-        char *ring = static_cast<char *>(out_ring.p) + (size_t)u * R * out_slot_rows * job.d_out_pitch;
+        char *ring = static_cast<char *>(out_ring.p) + (size_t)u * R * gout.slot_cap;
         struct Pending { int row = -1, n = 0; };
         std::vector<Pending> pend(R);
         int64_t used = 0;
@@ -414,7 +467,8 @@ inline Result run(const Job &job)
             const int total_rows = job.units * job.out_rows_per_unit;
             for (int r = u; r < total_rows; r += D) {
                 void *row = job.out_rows[r];
-                if (hipHostRegister(row, job.out_row_bytes, hipHostRegisterDefault) == hipSuccess)
+                if (out_size(r) == 0) continue;
+                if (hipHostRegister(row, out_size(r), hipHostRegisterDefault) == hipSuccess)
                     registered.push_back(row);
                 else
                     (void)hipGetLastError();
@@ -431,9 +485,10 @@ inline Result run(const Job &job)
             }
             const double tb = now();
             t_wait_copy += tb - ta;
-            const char *slot = ring + (size_t)s * out_slot_rows * job.d_out_pitch;
+            const char *slot = ring + (size_t)s * gout.slot_cap;
             for (int i = 0; i < pend[s].n; i++)
-                std::memcpy(job.out_rows[pend[s].row + i], slot + (size_t)i * job.d_out_pitch, job.out_row_bytes);
+                if (out_size(pend[s].row + i))
+                    std::memcpy(job.out_rows[pend[s].row + i], slot + (out_off(pend[s].row + i) - out_off(pend[s].row)), out_size(pend[s].row + i));
             t_copy += now() - tb;
             pend[s].row = -1;
             return true;
@@ -453,27 +508,27 @@ inline Result run(const Job &job)
                 t_wait_comp += now() - ta;
             }
             const int row0 = cbegin[k] * job.out_rows_per_unit;
-            const int row1 = cbegin[k + 1] * job.out_rows_per_unit;
             for (;;) {
                 if (sh.err.load()) break;
-                const int r = row0 + next_out[k].fetch_add(out_slot_rows);
-                if (r >= row1) break;
-                const int n = std::min(out_slot_rows, row1 - r);
+                const int gi = gout.gfirst[k] + next_out[k].fetch_add(1);
+                if (gi >= gout.gfirst[k + 1]) break;
+                int r, n;
+                group_rows(gout, k, gi, job.out_rows_per_unit, r, n);
                 if (job.direct_out) {
                     const double ta = now();
                     for (int i = 0; i < n; i++) {
                         void *row = job.out_rows[r + i];
-                        VGA_PIPE_TRY(hipMemcpyAsync(row, job.d_out + (size_t)(r + i) * job.d_out_pitch, job.out_row_bytes,
-                                                    hipMemcpyDeviceToHost, dstream[u]));
+                        if (out_size(r + i) == 0) continue;
+                        VGA_PIPE_TRY(hipMemcpyAsync(row, job.d_out + out_off(r + i), out_size(r + i), hipMemcpyDeviceToHost, dstream[u]));
                     }
                     t_copy += now() - ta;
                     continue;
                 }
                 const int s = (int)(used % R);
                 if (!flush(s)) return;
-                char *slot = ring + (size_t)s * out_slot_rows * job.d_out_pitch;
-                const size_t bytes = (size_t)(n - 1) * job.d_out_pitch + job.out_row_bytes;
-                VGA_PIPE_TRY(hipMemcpyAsync(slot, job.d_out + (size_t)r * job.d_out_pitch, bytes, hipMemcpyDeviceToHost, dstream[u]));
+                char *slot = ring + (size_t)s * gout.slot_cap;
+                const size_t bytes = out_off(r + n - 1) - out_off(r) + out_size(r + n - 1);
+                if (bytes) VGA_PIPE_TRY(hipMemcpyAsync(slot, job.d_out + out_off(r), bytes, hipMemcpyDeviceToHost, dstream[u]));
                 VGA_PIPE_TRY(hipEventRecord(dslot[u * R + s], dstream[u]));
                 pend[s].row = r;
                 pend[s].n = n;

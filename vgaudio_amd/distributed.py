@@ -115,11 +115,10 @@ def _i64(v):
     return v - (1 << 64) if v >= (1 << 63) else v
 
 
-def rows_digest(rows, nbytes, coefs, first_channel, chunk=512):
-    """A 64-bit position-weighted checksum of a block of output rows, computed where the rows live (CPU or GPU):
-    sum over rows of a(g) * sum over words of x[g][j] * b(j)  (mod 2^64), g = GLOBAL channel index, the row's first
-    `nbytes` bytes read as little-endian 64-bit words (+ the tail bytes one by one) followed by its 16 coefficients.
-    A row that arrives in another row's place, truncated, stale or shifted changes the sum.  Returns a Python int."""
+def row_digests(rows, nbytes, coefs, chunk=512):
+    """Per-row part of rows_digest: [count] int64 = sum over words of x[j] * b(j) (mod 2^64) of every row (its first
+    `nbytes` bytes as little-endian 64-bit words + the tail bytes one by one, then its 16 coefficients).  Independent of
+    the row's position in the batch, so a committed list of them names the channel that differs."""
     count = rows.shape[0]
     dev = rows.device
     n8 = nbytes // 8
@@ -127,7 +126,7 @@ def rows_digest(rows, nbytes, coefs, first_channel, chunk=512):
     assert rows.dtype == torch.uint8 and rows.stride(1) == 1 and rows.stride(0) % 8 == 0 and rows.data_ptr() % 8 == 0
     jw = torch.arange(n8 + tail + 4, dtype=torch.int64, device=dev)
     b = (jw * _i64(_MIX) + 1) | 1
-    total = 0
+    out = torch.empty(count, dtype=torch.int64, device=dev)
     for c0 in range(0, count, chunk):
         c1 = min(c0 + chunk, count)
         inner = torch.zeros(c1 - c0, dtype=torch.int64, device=dev)
@@ -136,10 +135,23 @@ def rows_digest(rows, nbytes, coefs, first_channel, chunk=512):
         if tail:
             inner += (rows[c0:c1, 8 * n8:nbytes].to(torch.int64) * b[n8:n8 + tail]).sum(dim=1)
         inner += (coefs[c0:c1].reshape(c1 - c0, 16).contiguous().view(torch.int64) * b[n8 + tail:n8 + tail + 4]).sum(dim=1)
-        g = torch.arange(first_channel + c0, first_channel + c1, dtype=torch.int64, device=dev)
-        a = (g * _i64(_GOLD) + _i64(_MIX)) | 1
-        total += int((inner * a).sum().item())
-    return total & ((1 << 64) - 1)
+        out[c0:c1] = inner
+    return out
+
+
+def combine_row_digests(inner, first_channel):
+    """rows_digest from row_digests: sum over rows of a(g) * inner[g] (mod 2^64), g = GLOBAL channel index."""
+    g = torch.arange(first_channel, first_channel + inner.shape[0], dtype=torch.int64, device=inner.device)
+    a = (g * _i64(_GOLD) + _i64(_MIX)) | 1
+    return int((inner * a).sum().item()) & ((1 << 64) - 1)
+
+
+def rows_digest(rows, nbytes, coefs, first_channel, chunk=512):
+    """A 64-bit position-weighted checksum of a block of output rows, computed where the rows live (CPU or GPU):
+    sum over rows of a(g) * sum over words of x[g][j] * b(j)  (mod 2^64), g = GLOBAL channel index, the row's first
+    `nbytes` bytes read as little-endian 64-bit words (+ the tail bytes one by one) followed by its 16 coefficients.
+    A row that arrives in another row's place, truncated, stale or shifted changes the sum.  Returns a Python int."""
+    return combine_row_digests(row_digests(rows, nbytes, coefs, chunk), first_channel)
 
 
 def max_over_ranks(value, device):

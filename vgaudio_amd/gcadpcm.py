@@ -392,3 +392,64 @@ class GcAdpcmFormat:
         m = min(len(out), len(inter))
         out[:m] = inter[:m]
         return out.astype(">i2" if bigEndian else "<i2").tobytes()
+
+
+def encode_files(pcm16_list, configs=None):
+    """The reference's batch conversion (VGAudio.Cli/Batch.cs:24-25: Parallel.ForEach over files, each file
+    GcAdpcmFormat.EncodeFromPcm16) as ONE ragged GPU call (vga_gcadpcm_encode_batch_v): `pcm16_list` holds one
+    Pcm16Format per file, of any length and channel count; returns one GcAdpcmFormat per file, each what
+    GcAdpcmFormat().EncodeFromPcm16(file) returns.  configs: None or one GcAdpcmParameters (or None) per file
+    (History1 / History2; a SampleCount override takes the per-file path)."""
+    files = list(pcm16_list)
+    configs = list(configs) if configs is not None else [None] * len(files)
+    if any(c is not None and c.SampleCount != -1 for c in configs):
+        return [GcAdpcmFormat().EncodeFromPcm16(f, c) for f, c in zip(files, configs)]
+    chans, counts, h1, h2 = [], [], [], []
+    for f, c in zip(files, configs):
+        for ch in f.Channels:
+            chans.append(ch)
+            counts.append(f.SampleCount)
+            h1.append(c.History1 if c else 0)
+            h2.append(c.History2 if c else 0)
+    nch = len(chans)
+    counts = np.array(counts, dtype=np.int32)
+    coefs = np.zeros((nch, 16), dtype=np.int16)
+    adpcm = [np.zeros(GcAdpcmMath.SampleCountToByteCount(int(n)), dtype=np.uint8) for n in counts]
+    h1 = np.array(h1, dtype=np.int16)
+    h2 = np.array(h2, dtype=np.int16)
+    if nch:
+        check(_lib.lib().vga_gcadpcm_encode_batch_v(_ptr_array(i16p, chans), counts.ctypes.data_as(C.POINTER(C.c_int)), nch,
+                                                     _i16(h1), _i16(h2), _i16(coefs), _ptr_array(u8p, adpcm)))
+    out, at = [], 0
+    for f in files:
+        k = f.ChannelCount
+        cs = [GcAdpcmChannel(adpcm[at + i], coefs[at + i].copy(), f.SampleCount) for i in range(k)]
+        out.append(GcAdpcmFormat(cs, f.SampleRate, f.Looping, f.LoopStart, f.LoopEnd))
+        at += k
+    return out
+
+
+def decode_files(formats):
+    """ToPcm16 (GcAdpcmFormat.cs:42-54) of many files in ONE ragged GPU call (vga_gcadpcm_decode_batch_v)."""
+    formats = list(formats)
+    chans, coefs, counts = [], [], []
+    for f in formats:
+        for c in f.Channels:
+            chans.append(np.ascontiguousarray(c.GetAdpcmAudio(), dtype=np.uint8))
+            coefs.append(c.Coefs)
+            counts.append(c.SampleCount)
+    nch = len(chans)
+    counts = np.array(counts, dtype=np.int32)
+    pcm = [np.zeros(int(n), dtype=np.int16) for n in counts]
+    if nch:
+        co = np.ascontiguousarray(np.stack(coefs), dtype=np.int16)
+        check(_lib.lib().vga_gcadpcm_decode_batch_v(_ptr_array(u8p, chans), _i16(co), counts.ctypes.data_as(C.POINTER(C.c_int)), nch,
+                                                     None, None, _ptr_array(i16p, pcm)))
+    out, at = [], 0
+    for f in formats:
+        k = f.ChannelCount
+        p = Pcm16Format(pcm[at:at + k], f.SampleRate)
+        p.Looping, p.LoopStart, p.LoopEnd = f.Looping, f.LoopStart, f.LoopEnd
+        out.append(p)
+        at += k
+    return out
