@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--cpu-channels", type=int, default=0, help="units in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-pointer ABI measurement")
     ap.add_argument("--e2e-channels", type=int, default=0, help="channels of the e2e call (0 = as many of --channels as host memory allows)")
+    ap.add_argument("--no-mixed", action="store_true", help="gc: skip the mixed-lengths block (ragged batch of files)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="gc: skip the short ADX (configs[2]) and HCA (configs[3]) runs appended to the line as `other_configs`")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -351,6 +352,195 @@ def measure_e2e(cx, args, pcm, n, coefs_dev, adpcm_dev, devices=None):
     return e2e
 
 
+def measure_mixed_lengths(cx, args, equal_length_value):
+    """The reference's batch path is a Parallel.ForEach over FILES of different lengths (VGAudio.Cli/Batch.cs:24-25 ->
+    Convert.cs:19 -> GcAdpcmFormat.EncodeFromPcm16): mono files with log-uniform lengths between 1 s and 120 s, as many
+    as hold the samples of configs[1] (4096 x 60 s).  Measured: (1) ONE ragged call, device resident -- the same kernels
+    as the headline step, per-channel shapes from tables -- and through the host-pointer ABI (vga_gcadpcm_encode_batch_v);
+    (2) the drop-in a maintainer would write first: 16 host threads, each converting whole files with one
+    vga_gcadpcm_encode_batch call per file (a sample of the files); (3) the CPU port scheduled per file.  A sample of the
+    files is held to the oracle bit for bit."""
+    import threading
+    import numpy as np
+    torch, vdev, L, lib = cx.torch, cx.vdev, cx.L, cx.lib
+    rng = np.random.default_rng(0xBA7C4)
+    target = 4096 * 2_880_000 if (args.channels == 4096 and args.seconds == 60.0) else int(args.channels * args.seconds * 48000)
+    lens, total = [], 0
+    while total < target:
+        n = int(np.exp(rng.uniform(np.log(48000.0), np.log(120 * 48000.0))))
+        lens.append(n)
+        total += n
+    nfiles = len(lens)
+    first_channel = 1 << 20                                # channels no other block of the bench uses
+    rb = vdev.GcRaggedBatch(lens, cx.dev)
+    pcm = rb.synth(first_channel=first_channel)
+    adpcm = rb.alloc_adpcm()
+    ws = torch.empty(max(rb.workspace_bytes, 16), dtype=torch.uint8, device=cx.dev)
+    torch.cuda.synchronize()
+    coefs = None
+    for _ in range(2):
+        coefs = rb.coefs(pcm, workspace=ws)
+        rb.encode(pcm, coefs, out=adpcm)
+    reps = 3
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * reps)]
+    for k in range(reps):
+        ev[3 * k].record()
+        coefs = rb.coefs(pcm, workspace=ws)
+        ev[3 * k + 1].record()
+        rb.encode(pcm, coefs, out=adpcm)
+        ev[3 * k + 2].record()
+    torch.cuda.synchronize()
+    coef_ms = float(np.mean([ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(reps)]))
+    enc_ms = float(np.mean([ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(reps)]))
+    value = total / ((coef_ms + enc_ms) * 1e-3) / 1e6
+    out = {"what": "mono files with log-uniform lengths in [1 s, 120 s] (seeded), as many as hold the samples of the headline "
+                   "workload; a step = coefficient search + encode of every file, inputs resident in HBM",
+           "reference": "VGAudio.Cli/Batch.cs:24-25 (Parallel.ForEach over files) -> GcAdpcmFormat.EncodeFromPcm16",
+           "files": nfiles, "samples": total, "shortest": int(min(lens)), "longest": int(max(lens)),
+           "one_ragged_call_device_resident": {
+               "entry_points": "vga_gcadpcm_coefs_device_v + vga_gcadpcm_encode_device_v", "coefs_ms": round(coef_ms, 3),
+               "encode_ms": round(enc_ms, 3), "ms": round(coef_ms + enc_ms, 3), "value": round(value, 1), "unit": "Msamples/s",
+               "ratio_to_equal_length_step": round(value / equal_length_value, 3) if equal_length_value else None}}
+    co = coefs.cpu().numpy().reshape(nfiles, 16)
+    # ---- a sample of the files against the oracle (and as the CPU port scheduled per file): every 64th file of the
+    # length-sorted list up to ~8 s of CPU work
+    threads, cpu_note = usable_cpus()
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle as po                 # the oracle appears in this leg only
+        po.lib()
+        order = np.argsort(lens)
+        pick = [int(i) for i in order[::max(1, nfiles // 160)]]
+        budget = int(3e6 * threads)                        # ~ samples the port encodes in a second on these threads
+        chosen, acc = [], 0
+        for i in pick:
+            if acc + lens[i] > 8 * budget:
+                break
+            chosen.append(i)
+            acc += lens[i]
+        host_files = [pcm[int(rb.pcm_offsets[i]):int(rb.pcm_offsets[i]) + lens[i]].cpu().numpy() for i in chosen]
+        results = [None] * len(chosen)
+        nxt = [0]
+        lock = threading.Lock()
+
+        def worker():
+            while True:
+                with lock:
+                    j = nxt[0]
+                    nxt[0] += 1
+                if j >= len(chosen):
+                    return
+                c = po.gc_calculate_coefficients(host_files[j])
+                results[j] = (c, po.gc_encode(host_files[j], c))
+
+        t0 = time.perf_counter()
+        ts = [threading.Thread(target=worker) for _ in range(threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        dt = time.perf_counter() - t0
+        for j, i in enumerate(chosen):
+            row = adpcm[int(rb.adpcm_offsets[i]):int(rb.adpcm_offsets[i]) + int(rb.byte_counts[i])].cpu().numpy()
+            if not (co[i].tolist() == results[j][0].tolist() and np.array_equal(row, results[j][1])):
+                raise SystemExit(f"PARITY FAILURE: ragged call, file {i} ({lens[i]} samples) differs from the CPU restatement")
+        out["bit_exact_files_checked"] = len(chosen)
+        out["cpu_port_per_file"] = {"value": round(acc / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads,
+                                    "sample": f"{len(chosen)} of the files ({acc} samples), one task per file on {threads} threads "
+                                              f"({cpu_note}), {dt:.1f} s wall"}
+        del host_files, results
+    if args.no_e2e:
+        rb.close()
+        return out
+    # ---- through the host-pointer ABI: pageable numpy rows, one per file
+    avail = host_memory_available()
+    nb = rb.byte_counts
+    use = nfiles
+    need = np.cumsum(2 * np.asarray(lens, dtype=np.int64) + nb)
+    if avail is not None and need[-1] > 0.6 * avail:
+        use = max(1, int(np.searchsorted(need, 0.6 * avail)))
+        out["note"] = f"host memory allows the first {use} of {nfiles} files through the host-pointer ABI ({avail / 2**30:.0f} GiB available)"
+    host = [pcm[int(rb.pcm_offsets[i]):int(rb.pcm_offsets[i]) + lens[i]].cpu().numpy() for i in range(use)]
+    outs = [np.zeros(int(nb[i]), dtype=np.uint8) for i in range(use)]
+    cf = np.zeros((use, 16), dtype=np.int16)
+    counts = np.asarray(lens[:use], dtype=np.int32)
+    pp = (lib.i16p * use)(*[a.ctypes.data_as(lib.i16p) for a in host])
+    op = (lib.u8p * use)(*[a.ctypes.data_as(lib.u8p) for a in outs])
+    cp = counts.ctypes.data_as(C.POINTER(C.c_int))
+    samples_used = int(counts.astype(np.int64).sum())
+    # the library's cache of device blocks still holds the equal-length call's (44 GB, a few bytes too small for this
+    # call's packed rows): start from an empty cache, then one untimed call of the full size fills it for the timed ones
+    L.vga_release_cached_memory()
+    lib.check(L.vga_gcadpcm_encode_batch_v(pp, cp, use, None, None, cf.ctypes.data_as(lib.i16p), op))                 # warm-up
+    rates = pcie_rates(cx)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        lib.check(L.vga_gcadpcm_encode_batch_v(pp, cp, use, None, None, cf.ctypes.data_as(lib.i16p), op))
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    st = (C.c_double * 32)()
+    nf = L.vga_testing_last_pipeline_stats(st, 32)
+    names = ["total", "setup", "feeders_memcpy_sum", "feeders_wait_slot_sum", "feeders_issue_sum", "slowest_feeder", "caller_wait_upload",
+             "caller_launch", "caller_tail_sync", "drainers_wait_compute_sum", "drainers_wait_download_sum", "drainers_memcpy_sum",
+             "slowest_drainer", "feeders", "drainers", "chunks", "units_per_chunk", "device_alloc", "entry_point",
+             "feeders_chunk_boundary_sum", "feeders_final_sync_sum", "drainers_register_sum"]
+    breakdown = {k: (int(st[i]) if 13 <= i <= 16 else round(st[i] * 1e3, 1)) for i, k in enumerate(names[:nf])}
+    same = bool(np.array_equal(cf, co[:use]))
+    flat_out = adpcm.cpu().numpy()
+    for i in range(use):
+        if not same:
+            break
+        same = np.array_equal(outs[i], flat_out[int(rb.adpcm_offsets[i]):int(rb.adpcm_offsets[i]) + int(nb[i])])
+    if not same:
+        raise SystemExit("PARITY FAILURE: vga_gcadpcm_encode_batch_v and the device-resident ragged path disagree")
+    in_bytes, out_bytes = 2 * samples_used, int(nb[:use].sum())
+    bound = pcie_bound_ms(rates, in_bytes, out_bytes)
+    out["one_ragged_call_host_pointers"] = {
+        "entry_point": "vga_gcadpcm_encode_batch_v (pageable host arrays in and out)", "files": use, "samples": samples_used,
+        "ms": round(best * 1e3, 1), "value": round(samples_used / best / 1e6, 1), "unit": "Msamples/s",
+        "pcie_bound_ms": round(bound, 1), "ratio_to_pcie_bound": round(best * 1e3 / bound, 2), "identical_to_device_path": True,
+        "breakdown_ms": breakdown}
+    # ---- the first drop-in: a worker per file (Batch.cs), every file one equal-length call.  A sample of the files (every
+    # k-th, so that the length mix is the batch's), 16 host threads.
+    step_k = max(1, use // 512)
+    sample = list(range(0, use, step_k))
+    workers = 16
+    nxt = [0]
+    lock = threading.Lock()
+    errors = []
+
+    def file_worker():
+        while True:
+            with lock:
+                j = nxt[0]
+                nxt[0] += 1
+            if j >= len(sample):
+                return
+            i = sample[j]
+            p1 = (lib.i16p * 1)(host[i].ctypes.data_as(lib.i16p))
+            o1 = (lib.u8p * 1)(outs[i].ctypes.data_as(lib.u8p))
+            rc = L.vga_gcadpcm_encode_batch(p1, 1, int(counts[i]), 0, 0, cf[i].ctypes.data_as(lib.i16p), o1)
+            if rc:
+                errors.append(rc)
+
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=file_worker) for _ in range(workers)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    done = int(counts[sample].astype(np.int64).sum())
+    out["one_call_per_file"] = {"entry_point": "vga_gcadpcm_encode_batch, one channel per call, 16 host threads (pageable host arrays)",
+                                "files": len(sample), "samples": done, "ms": round(dt * 1e3, 1), "value": round(done / dt / 1e6, 1),
+                                "unit": "Msamples/s", "errors": len(errors)}
+    if best:
+        out["one_call_per_file"]["ragged_call_speedup"] = round((samples_used / best) / (done / dt), 1)
+    del host, outs
+    rb.close()
+    return out
+
+
 def guarded(cx, line, fn, limit_s=240.0):
     """Runs fn() -- the N > 1 extras, which every rank takes part in -- so that rank 0's result line survives them: an
     exception becomes {"error": ...} in place of fn's result, and on rank 0 (line is not None) a watchdog thread prints
@@ -440,12 +630,12 @@ def run_gc(args, cx):
         g.gather(adpcm, coefs, nbytes=nb)
         torch.cuda.synchronize()
         verified = g.verify(adpcm, coefs, nb) if cx.rank == 0 else None
-        # every shard's output against the digest committed for it (tests/golden/gc_shard_digests.json, written by a
-        # single-GPU run of tests/test_gpu_shards.py's generator): the first 8-GPU run has expected values
+        # every shard's output against the digest committed for it (tests/golden/gc_shard_oracle_digests.json: what the
+        # ORACLE produces for the shard's 4096 channels, written in the build container): the first 8-GPU run has expected values
         mine = cx.vdist.rows_digest(adpcm[:nch], nb, coefs[:nch], first_channel)
         want = None
         try:
-            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "gc_shard_digests.json")))
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "gc_shard_oracle_digests.json")))   # provenance: the oracle
             if gold["channels_per_shard"] == nch and gold["samples_per_channel"] == n and cx.rank < len(gold["shards"]):
                 want = int(gold["shards"][cx.rank]["rows_digest"], 16)
         except (OSError, ValueError, KeyError):
@@ -596,6 +786,15 @@ def run_gc(args, cx):
         out["weak_scaling"] = scaling
     if not args.no_e2e and cx.world == 1:
         out["e2e"] = measure_e2e(cx, args, pcm, n, coefs, adpcm)
+    if not args.no_mixed and cx.world == 1:
+        del pcm, adpcm, ws
+        torch.cuda.empty_cache()
+        try:
+            out["mixed_lengths"] = measure_mixed_lengths(cx, args, value)
+        except SystemExit:
+            raise
+        except Exception as e:                          # noqa: BLE001 -- the line is worth more than this block
+            out["mixed_lengths"] = {"error": f"{type(e).__name__}: {e}"}
     if not args.no_e2e and cx.world > 1:
         # one process, N GPUs: the same 4096-channel call as the N = 1 line's e2e block, its channels spread over all
         # GPUs of the job by the library (the other ranks are idle at the final barrier meanwhile)

@@ -30,6 +30,10 @@ int vga_testing_gc_coefs_variant_this_thread(int variant);
  * encoders (pieces of 64 frames or more) and decoders (8 frames or more) -- for calls made from the calling thread (0 = the
  * launcher's own choice).  Results must not depend on it.  Returns the previous value. */
 int vga_testing_gc_encoder_segments_this_thread(int segments);
+/* How the GC-ADPCM encoder hands its (channel group, time piece) items to workgroups, for calls made from the calling
+ * thread: 0 = the launcher's choice, 1 = one workgroup per item (a plain grid), 2 = persistent workgroups taking items from
+ * a queue.  Results must not depend on it.  Returns the previous value. */
+int vga_testing_gc_encoder_persistent_this_thread(int mode);
 
 /* The host-pointer entry points (vga_*_batch) move data through a pipeline of feeder threads, pinned rings, per-chunk
  * kernel launches and drainer threads (vgaudio_amd/csrc/host_pipeline.hpp); its shape normally follows the volume of

@@ -1,8 +1,10 @@
 """Full BASELINE.json sizes on one GPU: config 2 (4096 channels x 60 s GC-ADPCM), config 3 (the same through CRI ADX),
 config 4 (1024 stereo HCA streams).  Every unit is checked through decode(encode(x)) ~ x; against the oracle, bit for bit:
 EVERY channel of config 3 and EVERY stream of config 4, encoded bytes and decoded PCM (the C restatements of ADX and HCA
-run a whole configuration in ~10 s on the box's 16 host threads, a slice of the batch at a time), and 256 channels of
-config 2 spread over the batch, first and last included (the GC-ADPCM restatement needs 150 s for all 4096)."""
+run a whole configuration in ~10 s on the box's 16 host threads, a slice of the batch at a time), and for config 2
+256 channels spread over the batch encoded by the oracle in the test itself plus ALL 4096 channels against the digests
+the oracle wrote in the build container (tests/golden/gc_shard_oracle_digests.json; the GC-ADPCM restatement needs
+150 s for 4096 channels on the box's host threads)."""
 import ctypes as C
 import os
 
@@ -61,6 +63,26 @@ def test_config2_gcadpcm_4096_channels():
     # every frame header names a predictor 0..7 and a scale 0..12 (GcAdpcmEncoder.cs:83, :118-170)
     heads = adpcm[:, :nb - nb % 8].reshape(nch, -1, 8)[:, :, 0]
     assert int((heads >> 4).max()) <= 7 and int((heads & 15).max()) <= 12
+    # EVERY channel against the oracle: the digests of what oracle/gcadpcm_oracle.c produces for these 4096 channels,
+    # written in the build container without a GPU (tests/golden/make_gc_shard_oracle_digests.py, 11 core-minutes per
+    # 1024 channels) -- one 64-bit digest per channel (names the channel that differs), the shard's positional digest
+    # and SHA-256 over coefficients + rows
+    import hashlib
+    import json
+    from vgaudio_amd import distributed as vdist
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    gold = json.load(open(os.path.join(gold_dir, "gc_shard_oracle_digests.json")))
+    assert gold["provenance"] == "oracle" and gold["samples_per_channel"] == N and gold["bytes_per_row"] == nb
+    per_channel = np.load(os.path.join(gold_dir, "gc_channel_oracle_digests.npy"))
+    inner = vdist.row_digests(adpcm, nb, coefs).cpu().numpy().view(np.uint64)
+    differ = np.nonzero(inner != per_channel[:nch])[0]
+    assert differ.size == 0, "channels that differ from the oracle: %s" % differ[:16].tolist()
+    sha = hashlib.sha256()
+    sha.update(coefs.cpu().numpy().tobytes())
+    for c0 in range(0, nch, 512):
+        sha.update(adpcm[c0:c0 + 512, :nb].cpu().numpy().tobytes())
+    shard0 = [s for s in gold["shards"] if s["rank"] == 0][0]
+    assert "0x%016x" % vdist.rows_digest(adpcm, nb, coefs, 0) == shard0["rows_digest"] and sha.hexdigest() == shard0["sha256"]
 
 
 def test_config3_adx_4096_channels():

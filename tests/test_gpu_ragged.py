@@ -119,6 +119,32 @@ def test_ragged_many_pieces_and_open_seams(force_open):
         assert np.array_equal(back[c], po.gc_decode(wa, wc, lens[c])), (c, lens[c])
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("force_open", [0, 1, 2])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_persistent_workgroups_and_plain_grid_give_the_oracles_bytes(mode, force_open, ragged):
+    """the encoder hands its (channel group, piece) items out either as a plain grid + a seam launch (1) or to persistent
+    workgroups that take them from a queue and close the seams themselves (2); neither may change a byte"""
+    L = _lib.lib()
+    if ragged:
+        lens = [14 * 30_000 + 5, 14 * 30_000, 14 * 22_000 + 1] + _lengths(45, 100, 14 * 25_000, 21, (0, 3, 14 * 2500))
+    else:
+        lens = [14 * 20_000 + 9] * 40
+    chans = _channels(lens, first_channel=64)
+    L.vga_testing_gc_encoder_persistent_this_thread(mode)
+    L.vga_testing_force_open_seams_this_thread(force_open)
+    L.vga_testing_gc_encoder_segments_this_thread(12)
+    try:
+        coefs, adpcm = _encode_v(chans)
+    finally:
+        L.vga_testing_gc_encoder_persistent_this_thread(0)
+        L.vga_testing_force_open_seams_this_thread(0)
+        L.vga_testing_gc_encoder_segments_this_thread(0)
+    for c, pcm in enumerate(chans):
+        wc, wa = _oracle(pcm)
+        assert coefs[c].tolist() == wc.tolist() and np.array_equal(adpcm[c], wa), (c, lens[c])
+
+
 def test_equal_lengths_through_the_ragged_entry_point_equal_the_batch_entry_point():
     L = _lib.lib()
     n = 14 * 5000 + 9

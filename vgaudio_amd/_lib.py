@@ -164,6 +164,7 @@ SIGNATURES = {
     "vga_testing_gc_encoder_layout_this_thread": (ci, [ci]),
     "vga_testing_gc_coefs_variant_this_thread": (ci, [ci]),
     "vga_testing_gc_encoder_segments_this_thread": (ci, [ci]),
+    "vga_testing_gc_encoder_persistent_this_thread": (ci, [ci]),
     "vga_testing_last_pipeline_stats": (ci, [vp, ci]),
     "vga_testing_host_pipeline_tail_this_thread": (None, [ci]),
     "vga_testing_hca_device_info": (ci, [vp, vp, ci]),

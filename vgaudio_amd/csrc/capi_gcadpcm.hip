@@ -43,6 +43,8 @@ static thread_local int g_coefs_variant = 0;
 int coefs_kernel_variant() { return g_coefs_variant; }
 static thread_local int g_encoder_segments = 0;
 int encoder_segments_override() { return g_encoder_segments; }
+static thread_local int g_encoder_persistent = 0;
+int encoder_persistent_mode() { return g_encoder_persistent; }
 static thread_local int g_hca_frames_per_group = 0;
 int hca_frames_per_group_override() { return g_hca_frames_per_group; }
 
@@ -101,7 +103,7 @@ std::vector<int> batch_devices()
 }
 ThreadHooks capture_thread_hooks()
 {
-    return ThreadHooks{g_force_open_seams, g_encoder_layout, g_coefs_variant, g_encoder_segments, g_hca_frames_per_group, g_pipe_override};
+    return ThreadHooks{g_force_open_seams, g_encoder_layout, g_coefs_variant, g_encoder_segments, g_hca_frames_per_group, g_pipe_override, g_encoder_persistent};
 }
 void apply_thread_hooks(const ThreadHooks &h)
 {
@@ -109,6 +111,7 @@ void apply_thread_hooks(const ThreadHooks &h)
     g_encoder_layout = h.encoder_layout;
     g_coefs_variant = h.coefs_variant;
     g_encoder_segments = h.encoder_segments;
+    g_encoder_persistent = h.encoder_persistent;
     g_hca_frames_per_group = h.hca_frames_per_group;
     g_pipe_override = h.pipe;
 }
@@ -166,6 +169,12 @@ int vga_testing_gc_encoder_segments_this_thread(int segments)
     const int old = g_encoder_segments;
     g_encoder_segments = segments > 0 ? segments : 0;
     return old;
+}
+int vga_testing_gc_encoder_persistent_this_thread(int mode)
+{
+    const int before = g_encoder_persistent;
+    g_encoder_persistent = mode >= 0 && mode <= 2 ? mode : 0;
+    return before;
 }
 int vga_testing_hca_frames_per_group_this_thread(int frames)
 {

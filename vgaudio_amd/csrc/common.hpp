@@ -225,6 +225,7 @@ int force_open_seams();          // 0 = off, 1 = every seam, 2 = seams with an e
 int encoder_layout();
 int coefs_kernel_variant();               // 0: four channels + summing wave per workgroup (product); 1: one wave per channel
 int encoder_segments_override();   // > 0: time pieces per channel forced by the test hook
+int encoder_persistent_mode();     // 0: the launcher decides; 1: one workgroup per (channel group, piece); 2: persistent workgroups + queue
 int hca_frames_per_group_override();   // > 0: frames per workgroup of hca_frames_kernel forced by the test hook
 
 // the per-(channel, seam) reading of that mode inside the seam kernels

@@ -23,6 +23,7 @@
 #include "gc_encode_core.hpp"
 #include "gcadpcm_kernels.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace vga {
@@ -71,6 +72,23 @@ __device__ __forceinline__ unsigned row16_reduce(unsigned v, Op op)
 // The SIMDs have idle issue slots next to a lone latency-bound wave (tools/ubench_valu.hip: two waves
 // per SIMD do not slow each other's dependent chains), so the helper costs the encoder nothing.
 // measured at configs[1]: 1 encoder wave -> 209.5 ms, 2 -> 200.1 ms (two pieces per channel)
+#ifdef VGA_DEBUG_TIMESTAMPS
+// tools/time_wave_ends.py (a -DVGA_DEBUG_TIMESTAMPS build under tools/variants/ only): when every workgroup's encoder wave
+// 0 started and ended, in ticks of the 100 MHz wall clock
+__device__ unsigned long long g_vga_enc_ts[1 << 16];
+extern "C" int vga_debug_encode_timestamps(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vga_enc_ts), (size_t)n * sizeof(unsigned long long));
+}
+#endif
+// Where the time pieces of a channel begin: `nb` pieces of `big` frames, then pieces of `small` frames.  The persistent
+// workgroups take items piece-major, so the pieces with the highest indices are the last items of the launch: short ones
+// there leave little to wait for when the queue runs dry (a plain grid uses one size: nb = every piece).
+struct Pieces {
+    int big, nb, small;
+    __host__ __device__ int64_t first(int k) const { return (int64_t)(k < nb ? k : nb) * big + (int64_t)(k > nb ? k - nb : 0) * small; }
+    __host__ __device__ int frames(int k) const { return k < nb ? big : small; }
+};
 constexpr int SW = 2;              // encoder (serial) waves per workgroup; one helper wave serves them all
 constexpr int ENC_THREADS = 64 * (SW + 1);
 // Two lane layouts of the encoder wave (template parameter CPW = channels per encoder wave):
@@ -176,12 +194,15 @@ ColdOut encode_frame_cold(ColdState st, PassOut r, int final_sp, int fin)
 // holds its longest channel), every slot has its own length and offsets, a piece exists for a slot only as far as its
 // channel reaches.  The workgroup runs as many tiles as its longest slot needs; a slot whose frames have run out keeps
 // encoding (clamped loads, nothing flushed) with its history frozen.
+// One (channel group, time piece) = what a workgroup of the plain launch does: gc_encode_kernel calls it once with its
+// block indices, gc_encode_persistent_kernel once per item it takes from the queue.
 template <bool REPAIR, int CPW, bool RAGGED>
-__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void gc_encode_kernel(
-    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, int seg_frames,
+__device__ __forceinline__ void gc_encode_piece(
+    const int bx, const int by,
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, const Pieces seg,
     const int16_t *__restrict__ coefs, const int16_t *__restrict__ hist1,
     const int16_t *__restrict__ hist2, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, int16_t *__restrict__ seg_state,
-    const int *__restrict__ first_open, const Ragged rg)
+    const int *__restrict__ first_open, const Ragged &rg)
 {
     // Repair launch (first_open != nullptr, one workgroup row): channels with a seam that would not close are encoded
     // again, serially, from the earliest such seam among the workgroup's four channels to the end of the stream --
@@ -190,12 +211,12 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     constexpr bool repair = REPAIR;
     constexpr int CS = Lay<CPW>::CS, TF = Lay<CPW>::TF;
     using GcTile = GcTileT<CS, TF>;
-    int64_t first_frame = (int64_t)blockIdx.y * seg_frames;
+    int64_t first_frame = seg.first(by);
     int repair_piece = 0;
     if (repair) {
         int k = 0x7f000000;
         for (int g = 0; g < CS; g++) {
-            const int slot = blockIdx.x * CS + g;
+            const int slot = bx * CS + g;
             if (slot < nch) {
                 const int c = RAGGED ? rg.order[slot] : slot;
                 k = first_open[c] < k ? first_open[c] : k;
@@ -203,12 +224,12 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         }
         if (k <= 0 || k >= 0x7f000000) return;
         repair_piece = k;
-        first_frame = (int64_t)k * seg_frames;
+        first_frame = seg.first(k);
     }
     // the workgroup's longest channel (slot 0 when ragged) decides whether the piece exists and how many tiles it has
-    const int total_wg = RAGGED ? rg.length[rg.order[blockIdx.x * CS]] : total_samples;
+    const int total_wg = RAGGED ? rg.length[rg.order[bx * CS]] : total_samples;
     if (first_frame * 14 >= total_wg) return;
-    const int64_t piece_samples = repair ? (int64_t)0x7fffffff : (int64_t)seg_frames * 14;
+    const int64_t piece_samples = repair ? (int64_t)0x7fffffff : (int64_t)seg.frames(by) * 14;
     auto piece_samples_of = [&](int total) {
         const int64_t rem = (int64_t)total - first_frame * 14;
         return (int)(rem < 0 ? 0 : (rem < piece_samples ? rem : piece_samples));
@@ -227,7 +248,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     const int grp = helper ? lane / TF : wave * CPW + lane / LPC;  // channel slot of this lane
     const int l16 = lane & (LPC - 1);
     const int hfr = lane % TF;                         // helper lanes: the frame inside the tile
-    const int slot_raw = blockIdx.x * CS + grp;
+    const int slot_raw = bx * CS + grp;
     const bool live = slot_raw < nch;
     const int slot = live ? slot_raw : nch - 1;
     const int ch = RAGGED ? rg.order[slot] : slot;
@@ -348,7 +369,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     if (repair) {
         h0 = seg_state[((int64_t)(repair_piece - 1) * nch + ch) * 2];
         h1 = seg_state[((int64_t)(repair_piece - 1) * nch + ch) * 2 + 1];
-    } else if (blockIdx.y > 0 && (!RAGGED || frames > 0)) {   // a later piece: the guess
+    } else if (by > 0 && (!RAGGED || frames > 0)) {   // a later piece: the guess
         h0 = src[-2];
         h1 = src[-1];
     }
@@ -572,6 +593,9 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         else encode_frame8(R, buf, j, upd);
     };
 
+#ifdef VGA_DEBUG_TIMESTAMPS
+    if (!repair && tid == 0 && gridDim.y != 1) g_vga_enc_ts[2 * ((blockIdx.y * gridDim.x + blockIdx.x) & 32767)] = wall_clock64();
+#endif
     __syncthreads();                                   // tile 0 prepared
     for (int tile = 0; tile < tiles; tile++) {
         const int buf = tile & 1;
@@ -593,10 +617,25 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         __syncthreads();                               // tile done: helper may flush it and refill this buffer later
     }
     if (seg_state && !repair && live && l16 == 0) {   // one lane per channel
-        int16_t *st = seg_state + ((int64_t)blockIdx.y * nch + ch) * 2;
+        int16_t *st = seg_state + ((int64_t)by * nch + ch) * 2;
         st[0] = (int16_t)h0;
         st[1] = (int16_t)h1;
     }
+#ifdef VGA_DEBUG_TIMESTAMPS
+    if (!repair && tid == 0 && gridDim.y != 1) g_vga_enc_ts[2 * ((blockIdx.y * gridDim.x + blockIdx.x) & 32767) + 1] = wall_clock64();
+#endif
+}
+
+
+template <bool REPAIR, int CPW, bool RAGGED>
+__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void gc_encode_kernel(
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, const Pieces seg,
+    const int16_t *__restrict__ coefs, const int16_t *__restrict__ hist1,
+    const int16_t *__restrict__ hist2, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, int16_t *__restrict__ seg_state,
+    const int *__restrict__ first_open, const Ragged rg)
+{
+    gc_encode_piece<REPAIR, CPW, RAGGED>(blockIdx.x, blockIdx.y, pcm, pcm_pitch, nch, total_samples, seg, coefs, hist1, hist2, adpcm,
+                                         adpcm_pitch, seg_state, first_open, rg);
 }
 
 // ---------------------------------------------------------------- seams of the time segments
@@ -612,16 +651,15 @@ __device__ __forceinline__ void store_frame_bytes(uint8_t *dst, uint32_t d0, uin
 // histories coincide at a frame end: from there on the piece holds what the serial encoder writes.  Returns with
 // open == true when the piece ended first; (h0, h1) is then the true history at the piece's end.
 __device__ __forceinline__ void seam_run(const int16_t *__restrict__ src, uint8_t *__restrict__ dst, int c0, int c1, bool coef_ok,
-                                         int pr, int ch, int k, int total_samples, int seg_frames, int max_frames, int force_open,
+                                         int pr, int ch, int k, int64_t f0, int total_samples, int piece_frames, int max_frames, int force_open,
                                          int &h0, int &h1, int g2, int g1, bool &open)
 {
-    const int64_t f0 = (int64_t)k * seg_frames;
     const int full_frames = total_samples / 14;
     // The frame loop is one wave's dependent chain (nothing else runs on its SIMD for long: the slowest seam IS the
     // kernel's run time), so it is the encoder's fast path -- range pre-scan, the two speculative passes of the
     // (channel, predictor) layout, DPP argmin -- with the next frame's PCM and old bytes already in flight; the
     // reference's loop as written (resume_passes) only behind the same `rare` / `resume` conditions as there.
-    const int64_t f_end = imin((int)imin((int)(f0 + seg_frames), (int)(f0 + max_frames)), full_frames);   // frames [f0, f_end)
+    const int64_t f_end = imin((int)imin((int)(f0 + piece_frames), (int)(f0 + max_frames)), full_frames);   // frames [f0, f_end)
     const int64_t f_last = full_frames > 0 ? full_frames - 1 : 0;
     auto fetch = [&](int64_t f, uint32_t (&w)[7], uint2 &old) {
         const int64_t fc = f < f_last ? f : f_last;     // clamped: always a valid full frame (unconditional loads)
@@ -798,17 +836,14 @@ __device__ __forceinline__ void encode_tail_frame(const int16_t *__restrict__ sr
 // All seams at once, each from the history the piece before ended on (seg_state: the real one provided THAT piece's own
 // seam closes).  A seam still open at the end of its piece leaves a flag and the true history it arrived at
 // (seam_flag / seam_end) and its index in first_open[channel]: gc_encode_chain_kernel carries on from there.
-__global__ __launch_bounds__(64) void gc_encode_seam_kernel(
-    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, int seg_frames,
-    const int16_t *__restrict__ coefs, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch,
-    const int16_t *__restrict__ seg_state, int *__restrict__ first_open, int *__restrict__ seam_flag,
-    int *__restrict__ seam_end, int max_frames, int force_open, const Ragged rg)
+__device__ __forceinline__ void seam_piece(
+    const int slot_raw, const int k, const int lane,
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, const Pieces seg,
+    const int16_t *__restrict__ coefs, uint8_t *adpcm, int64_t adpcm_pitch,
+    const int16_t *seg_state, int *first_open, int *seam_flag, int *seam_end, int force_open, const Ragged &rg)
 {
-    const int lane = threadIdx.x;
     const int pr = lane & 7;                            // this lane's predictor
-    const int slot_raw = blockIdx.x * 8 + (lane >> 3);
-    const int k = blockIdx.y + 1;
-    const int64_t f0 = (int64_t)k * seg_frames;
+    const int64_t f0 = seg.first(k);
     const int slot = slot_raw < nch ? slot_raw : nch - 1;
     const int ch = rg.order ? rg.order[slot] : slot;
     if (rg.order) total_samples = rg.length[ch];        // ragged: the seam exists only where the channel reaches piece k
@@ -822,7 +857,7 @@ __global__ __launch_bounds__(64) void gc_encode_seam_kernel(
     int h1 = valid ? seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1] : 0;
     const int g2 = valid ? src[f0 * 14 - 2] : 0, g1 = valid ? src[f0 * 14 - 1] : 0;   // the guessed run's history (g1 = newest)
     bool open = valid;                                  // uniform inside a group of eight
-    seam_run(src, dst, c0, c1, coef_ok, pr, ch, k, total_samples, seg_frames, max_frames, force_open, h0, h1, g2, g1, open);
+    seam_run(src, dst, c0, c1, coef_ok, pr, ch, k, f0, total_samples, seg.frames(k), seg.frames(k), force_open, h0, h1, g2, g1, open);
     // still open at the piece's end (half the seams close within nine frames, one in a hundred needs more than 400, a
     // few channels never meet)
     if (valid && pr == 0) {
@@ -834,6 +869,96 @@ __global__ __launch_bounds__(64) void gc_encode_seam_kernel(
     }
 }
 
+__global__ __launch_bounds__(64) void gc_encode_seam_kernel(
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, const Pieces seg,
+    const int16_t *__restrict__ coefs, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch,
+    const int16_t *__restrict__ seg_state, int *__restrict__ first_open, int *__restrict__ seam_flag,
+    int *__restrict__ seam_end, int force_open, const Ragged rg)
+{
+    seam_piece(blockIdx.x * 8 + (threadIdx.x >> 3), blockIdx.y + 1, threadIdx.x, pcm, pcm_pitch, nch, total_samples, seg, coefs, adpcm,
+               adpcm_pitch, seg_state, first_open, seam_flag, seam_end, force_open, rg);
+}
+
+// The same work from a queue: as many workgroups as the chip holds at once (cus x 4: two encoder waves and a helper on
+// every SIMD, placed once), each taking (channel group, piece) items -- piece-major, so the early items are the ones every
+// channel has -- until none is left.  Measured at BASELINE configs[1] with one workgroup per item and four pieces per
+// channel (profiles/r04_a_wave_ends.log): the four pieces of a channel group share a CU, the groups' frames differ in how
+// often they take the third-trip block, and the CUs end between 136 and 162 ms (mean 147) -- the launch lasts as long as
+// its slowest CU.  More, shorter pieces from a plain grid made it worse (212 ms with eight): workgroups of the second
+// round land on whichever SIMD has a free slot and two encoder waves end up sharing one.  Persistent workgroups keep
+// their SIMDs and balance at the granularity of an item.
+//
+// The seams travel with the items: a workgroup that has finished piece y of a group announces it on the counters of the
+// seams at the piece's two ends (seam_count[seam - 1][group]); whoever finds the other side already there closes that
+// seam at once -- its two encoder waves have the seam code's lane layout (8 channels x 8 predictors), the group's sixteen
+// channels are theirs -- while the other workgroups carry on with their items.  What the separate seam launch cost at the
+// end of the encode (8 ms at four pieces per channel, as long as its slowest seam; 36 ms at 64 pieces) runs underneath
+// the other workgroups' items.  A seam reads what two other workgroups wrote (the piece state before it, the bytes
+// after it): both sides put a device-scope fence between their stores / loads and the counter.
+template <int CPW, bool RAGGED>
+__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void gc_encode_persistent_kernel(
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, const Pieces seg,
+    const int16_t *__restrict__ coefs, const int16_t *__restrict__ hist1,
+    const int16_t *__restrict__ hist2, uint8_t *adpcm, int64_t adpcm_pitch, int16_t *seg_state,
+    const Ragged rg, int groups, int segments, int *__restrict__ queue, int *__restrict__ seam_count, int *first_open,
+    int *seam_flag, int *seam_end, int force_open)
+{
+    static_assert(CPW == 8, "the seams inside the persistent kernel use the (channel, predictor) layout");
+    constexpr int CS = Lay<CPW>::CS;
+    __shared__ int s_item;
+    __shared__ int s_seam[2];
+    const int items = groups * segments;
+#ifdef VGA_DEBUG_TIMESTAMPS
+    if (threadIdx.x == 0) g_vga_enc_ts[2 * (blockIdx.x & 32767)] = wall_clock64();
+#endif
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(queue, 1);
+        __syncthreads();
+        const int item = s_item;
+        __syncthreads();                               // everyone has read it before thread 0 takes the next one
+        if (item >= items) {
+#ifdef VGA_DEBUG_TIMESTAMPS
+            if (threadIdx.x == 0) g_vga_enc_ts[2 * (blockIdx.x & 32767) + 1] = wall_clock64();
+#endif
+            return;
+        }
+        const int g = item % groups, y = item / groups;
+        gc_encode_piece<false, CPW, RAGGED>(g, y, pcm, pcm_pitch, nch, total_samples, seg, coefs, hist1, hist2, adpcm, adpcm_pitch,
+                                            seg_state, (const int *)nullptr, rg);
+        if (segments <= 1) continue;
+        // ---- the seams at this piece's ends
+        __threadfence();                               // this workgroup's bytes and piece state are out before it says so
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // (pieces past the end of the group's longest channel do not exist: nobody waits for them)
+            const int total_wg = RAGGED ? rg.length[rg.order[g * CS]] : total_samples;
+            auto exists = [&](int piece) { return piece < segments && seg.first(piece) * 14 < total_wg; };
+            int at_start = 0, at_end = 0;
+            if (exists(y)) {
+                if (y >= 1 && atomicAdd(&seam_count[(int64_t)(y - 1) * groups + g], 1) == 1) at_start = y;
+                if (exists(y + 1) && atomicAdd(&seam_count[(int64_t)y * groups + g], 1) == 1) at_end = y + 1;
+            }
+            s_seam[0] = at_start;
+            s_seam[1] = at_end;
+        }
+        __syncthreads();
+        const int seam_a = s_seam[0], seam_b = s_seam[1];
+        if ((seam_a | seam_b) != 0) {
+            __threadfence();                           // the other workgroup's stores, before anything of them is read
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            if (wave < SW) {
+                const int slot = g * CS + wave * CPW + (lane >> 3);
+                if (seam_a)
+                    seam_piece(slot, seam_a, lane, pcm, pcm_pitch, nch, total_samples, seg, coefs, adpcm, adpcm_pitch, seg_state,
+                               first_open, seam_flag, seam_end, force_open, rg);
+                if (seam_b)
+                    seam_piece(slot, seam_b, lane, pcm, pcm_pitch, nch, total_samples, seg, coefs, adpcm, adpcm_pitch, seg_state,
+                               first_open, seam_flag, seam_end, force_open, rg);
+            }
+        }
+    }
+}
+
 // The channels with an open seam, piece after piece: where the true history V at the start of piece k is not the one the
 // seam launch assumed there (T = seg_state[k - 1]), the piece's bytes are the run from T, so the same seam_run from V next
 // to a replay from T finds where the two meet -- as a rule a few frames in, and the chain ends unless a later seam of the
@@ -841,7 +966,7 @@ __global__ __launch_bounds__(64) void gc_encode_seam_kernel(
 // stream with a partial last frame goes to the serial repair launch (first_open[channel] = last piece; seg_state gets
 // that piece's true start), which also remains the fall-back when the scratch cannot hold the flags.
 __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
-    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, int seg_frames, int segments,
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, const Pieces seg, int segments,
     const int16_t *__restrict__ coefs, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch,
     int16_t *__restrict__ seg_state, int *__restrict__ first_open, const int *__restrict__ seam_flag,
     const int *__restrict__ seam_end, int force_open, const Ragged rg)
@@ -867,13 +992,13 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
     int v0 = 0, v1 = 0;                                 // V (x[0], x[1])
     int last_k = 0;
     for (int k = kmin; k < segments; k++) {
-        const int64_t f0 = (int64_t)k * seg_frames;
+        const int64_t f0 = seg.first(k);
         // pieces past a channel's end do not exist (ragged batches: per lane -- such a lane keeps what it had at its
         // own end, for the partial last frame below)
         const bool exists = f0 * 14 < total_samples;
         if (!__any(exists)) break;
         last_k = k;
-        const bool is_last = (int64_t)(k + 1) * seg_frames * 14 >= total_samples || k == segments - 1;
+        const bool is_last = seg.first(k + 1) * 14 >= total_samples || k == segments - 1;
         const int64_t idx = (int64_t)(k - 1) * nch + ch;
         const bool flagged = live && exists && seam_flag[idx] != 0;
         const int ended = seam_end[idx];
@@ -886,7 +1011,7 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
                 seg_state[idx * 2] = (int16_t)v0;
                 seg_state[idx * 2 + 1] = (int16_t)v1;
             }
-            seam_run(src, dst, c0, c1, coef_ok, pr, ch, k, total_samples, seg_frames, seg_frames, force_open, h0, h1, g2, g1, open);
+            seam_run(src, dst, c0, c1, coef_ok, pr, ch, k, f0, total_samples, seg.frames(k), seg.frames(k), force_open, h0, h1, g2, g1, open);
         }
         if (!exists) {
         } else if (ran && open) {                       // still apart at the piece's end: carry on into the next one
@@ -918,6 +1043,14 @@ constexpr int MIN_PIECE_FRAMES = 3072;
 // times more workgroups than the chip holds at once, the ones that end early (short channels, short last pieces) make
 // room for the rest instead of leaving their SIMDs idle.
 constexpr int RAGGED_OVERSUBSCRIPTION = 4;
+// Persistent workgroups from this many channel groups per eight workgroups on (2048 channels on an MI355X): below, a channel
+// has to be cut into so many pieces to fill the queue that its seams cost more than the balance gains (1024 channels: 46-62 ms
+// over the schedules tried against 47 ms for the plain grid; 2048: 79-98 against 89; profiles/r04_a_encode_schedules.log)
+constexpr int PERSISTENT_MIN_GROUPS_FACTOR = 8;
+constexpr int PERSISTENT_ITEMS_PER_WORKGROUP = 4;      // uniform pieces (the test hook's mode 2 without a schedule): items per workgroup
+constexpr int PERSISTENT_BIG_ROUNDS = 3;       // a workgroup's share of the frames in this many big items ...
+constexpr int PERSISTENT_SMALL_ROUNDS = 2;     // ... followed by this many rounds of short items
+constexpr int PERSISTENT_SMALL_FRAMES = 4096;  // ... of this many frames
 
 template <int CPW, bool RAGGED>
 static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
@@ -933,10 +1066,15 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
     const int groups = (nch + CS - 1) / CS;
     const int cus = device_cu_count();
     const int frames = (sample_count + 13) / 14;
+    // persistent workgroups taking (channel group, piece) items from a queue (gc_encode_persistent_kernel) once the batch
+    // has more items than the chip holds workgroups; test hook: 1 = never, 2 = always
+    const int pmode = encoder_persistent_mode();
+    const bool persistent = CPW == 8 && (pmode == 2 || (pmode == 0 && (RAGGED || groups * PERSISTENT_MIN_GROUPS_FACTOR >= cus * 4)));
     int segments = cus * 4 / groups;                   // = SW encoder waves on every SIMD
+    if (persistent) segments = (cus * 4 * PERSISTENT_ITEMS_PER_WORKGROUP + groups - 1) / groups;
     if (RAGGED) {
-        // pieces of total / (workgroups wanted) frames for every channel; `segments` = what the longest channel needs
-        const int64_t want = (int64_t)cus * 4 * RAGGED_OVERSUBSCRIPTION;
+        // pieces of total / (items wanted) frames for every channel; `segments` = what the longest channel needs
+        const int64_t want = (int64_t)cus * 4 * (persistent ? PERSISTENT_ITEMS_PER_WORKGROUP : RAGGED_OVERSUBSCRIPTION);
         int64_t piece = (rg.total_frames + CS * want - 1) / (CS * want);
         if (piece < MIN_PIECE_FRAMES) piece = MIN_PIECE_FRAMES;
         segments = (int)((frames + piece - 1) / piece);
@@ -945,13 +1083,44 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
     if (segments < 1) segments = 1;
     if (segments > 1024) segments = 1024;
     if (encoder_segments_override() > 0) segments = imin(imax(frames / 64, 1), encoder_segments_override());   // test hook
-    const int seg_frames = (frames + segments - 1) / segments;
+    Pieces seg;
+    seg.big = (frames + segments - 1) / segments;
+    seg.nb = segments;
+    seg.small = seg.big;
+    if (persistent && encoder_segments_override() <= 0 && frames >= 4 * MIN_PIECE_FRAMES) {
+        // Items leave the queue piece-major; with items of one size d the workgroups end spread over the last d of the
+        // launch (152 ms at configs[1] with 16 pieces of 35 ms: mean life 136 ms + d / 2).  So: big pieces first, and
+        // enough short ones (the shortest a seam can still close in) at the end to take up the spread the big ones leave.
+        int big_rounds = PERSISTENT_BIG_ROUNDS, small_rounds = PERSISTENT_SMALL_ROUNDS, small = PERSISTENT_SMALL_FRAMES;
+        if (const char *e = std::getenv("VGA_HIP_GC_SCHEDULE")) std::sscanf(e, "%d,%d,%d", &big_rounds, &small_rounds, &small);   // tuning (tools/)
+        small = imax(small, MIN_PIECE_FRAMES);
+        big_rounds = imax(big_rounds, 1);
+        const int wgs = cus * 4;
+        // a workgroup's share of the frames (in units of a channel group's frames): small_rounds short items at the end, the
+        // rest in big_rounds items
+        const int64_t per_wg = (RAGGED ? rg.total_frames / CS : (int64_t)groups * frames) / wgs + 1;
+        int ns = (small_rounds * wgs + groups / 2) / groups;                                // piece indices that make small_rounds rounds of items
+        if ((int64_t)ns * small > frames / 2) ns = frames / (2 * small);
+        int big = (int)imax((int)((per_wg - (int64_t)small_rounds * small) / big_rounds), small);
+        int nb = (int)((frames - (int64_t)ns * small + big - 1) / big);
+        if (nb < 1) nb = 1;
+        if (!RAGGED) big = (int)((frames - (int64_t)ns * small + nb - 1) / nb);             // equal big pieces
+        if (big < small) big = small;
+        seg.big = big;
+        seg.nb = nb;
+        seg.small = small;
+        segments = nb + ns;
+        while (segments > 1 && seg.first(segments - 1) >= frames) segments--;
+        if (segments > 1024) { segments = 1024; }
+    }
     AsyncBuf scratch;                                  // freed (stream-ordered) on every exit path
     int16_t *seg_state = nullptr;
-    int *first_open = nullptr, *seam_flag = nullptr, *seam_end = nullptr;
-    if (segments > 1) {
-        const size_t state_bytes = (size_t)round_up((int64_t)segments * nch * 2 * (int64_t)sizeof(int16_t), 16);
-        const size_t need = 3 * state_bytes + (size_t)nch * sizeof(int);
+    int *first_open = nullptr, *seam_flag = nullptr, *seam_end = nullptr, *queue = nullptr, *seam_count = nullptr;
+    if (segments > 1 || persistent) {
+        const size_t state_bytes = segments > 1 ? (size_t)round_up((int64_t)segments * nch * 2 * (int64_t)sizeof(int16_t), 16) : 0;
+        const size_t open_bytes = (size_t)round_up((int64_t)nch * (int64_t)sizeof(int), 16);
+        const size_t count_bytes = persistent && segments > 1 ? (size_t)round_up((int64_t)(segments - 1) * groups * (int64_t)sizeof(int), 16) : 0;
+        const size_t need = 3 * state_bytes + open_bytes + 16 + count_bytes;
         // the caller's scratch when it brought one (the host pipeline: hipMallocAsync next to busy copy streams stalled
         // its launching thread for up to 300 ms per call), a stream-ordered allocation otherwise
         unsigned char *base = static_cast<unsigned char *>(d_scratch);
@@ -959,37 +1128,54 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
             VGA_HIP_TRY(scratch.alloc(need, stream));
             base = scratch.as<unsigned char>();
         }
-        seg_state = reinterpret_cast<int16_t *>(base);
         seam_flag = reinterpret_cast<int *>(base + state_bytes);
         seam_end = reinterpret_cast<int *>(base + 2 * state_bytes);
         first_open = reinterpret_cast<int *>(base + 3 * state_bytes);
-        VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
+        queue = reinterpret_cast<int *>(base + 3 * state_bytes + open_bytes);
+        if (segments > 1) {
+            seg_state = reinterpret_cast<int16_t *>(base);
+            VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
+        } else
+            seg_state = nullptr;
+        seam_count = queue + 4;
+        if (persistent) VGA_HIP_TRY(hipMemsetAsync(queue, 0, 16 + count_bytes, stream));    // the queue's head and every seam's counter
     }
-    hipLaunchKernelGGL((gc_encode_kernel<false, CPW, RAGGED>), dim3(groups, segments), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch,
-                       sample_count, seg_frames, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state,
-                       (const int *)nullptr, rg);
+    if (persistent) {
+        const int items = groups * segments;
+        const int wgs = imin(items, cus * 4);
+        if constexpr (CPW == 8)
+            hipLaunchKernelGGL((gc_encode_persistent_kernel<CPW, RAGGED>), dim3(wgs), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch,
+                               sample_count, seg, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state, rg, groups, segments, queue,
+                               seam_count, first_open, seam_flag, seam_end, force_open_seams());
+    } else
+        hipLaunchKernelGGL((gc_encode_kernel<false, CPW, RAGGED>), dim3(groups, segments), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch,
+                           sample_count, seg, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state,
+                           (const int *)nullptr, rg);
     VGA_HIP_TRY(hipGetLastError());
     if (segments > 1) {
-        hipLaunchKernelGGL(gc_encode_seam_kernel, dim3((nch + 7) / 8, segments - 1), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
-                           sample_count, seg_frames, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
-                           seg_frames, force_open_seams(), rg);
-        VGA_HIP_TRY(hipGetLastError());
+        if (!persistent) {                             // (the persistent workgroups close the seams themselves)
+            hipLaunchKernelGGL(gc_encode_seam_kernel, dim3((nch + 7) / 8, segments - 1), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
+                               sample_count, seg, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
+                               force_open_seams(), rg);
+            VGA_HIP_TRY(hipGetLastError());
+        }
         // the seams that were still open at the end of their piece, chained piece after piece (none: every wave returns)
         hipLaunchKernelGGL(gc_encode_chain_kernel, dim3((nch + 7) / 8), dim3(64), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
-                           seg_frames, segments, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
+                           seg, segments, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
                            force_open_seams(), rg);
         VGA_HIP_TRY(hipGetLastError());
         // repair: the same encoder, serially over the last piece, for a channel the chain could not finish (a partial
         // last frame after a run that never met; none: every workgroup returns)
         hipLaunchKernelGGL((gc_encode_kernel<true, CPW, RAGGED>), dim3(groups, 1), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
-                           seg_frames, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state, (const int *)first_open, rg);
+                           seg, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state, (const int *)first_open, rg);
         VGA_HIP_TRY(hipGetLastError());
     }
     return VGA_OK;
 }
 
 // upper bound of what launch_encode wants as scratch for nch channels (1024 pieces x (state, flag, end) + 4 B per channel, + alignment)
-size_t encode_scratch_bytes(int nch) { return (size_t)(nch > 0 ? nch : 0) * (1024 * 12 + 4) + 64; }
+// (+ the persistent kernel's queue and seam counters: 4 B per channel group and seam)
+size_t encode_scratch_bytes(int nch) { return (size_t)(nch > 0 ? nch : 0) * (1024 * 12 + 4 + 256) + 8192; }
 
 int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
                   const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,

@@ -325,8 +325,16 @@ __device__ __forceinline__ void wave_lds_sync()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+#ifdef VGA_DEBUG_TIMESTAMPS
+// tools/time_wave_ends.py: start, end of pass 0, end of every gc_coefs_kernel wave (100 MHz wall clock)
+__device__ unsigned long long g_vga_coef_ts[3 * 8192];
+extern "C" int vga_debug_coefs_timestamps(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vga_coef_ts), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 #ifndef VGA_COEFS_PF_REC
-#define VGA_COEFS_PF_REC 1
+#define VGA_COEFS_PF_REC 2
 #endif
 #ifndef VGA_COEFS_PF_PCM
 #define VGA_COEFS_PF_PCM 1
@@ -362,6 +370,9 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
         reinterpret_cast<double2 *>(&s_d[par][1][0])[lane] = make_double2(0.0, 0.0);
     };
 
+#ifdef VGA_DEBUG_TIMESTAMPS
+    if (lane == 0) g_vga_coef_ts[3 * (blockIdx.x & 8191)] = wall_clock64();
+#endif
     // ---- pass 0: per-frame records (:40-61) + ordered mean of MatrixFilter outputs (:63-74)
     double acc = 0.0;
     int cnt = 0;
@@ -429,6 +440,9 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
             }
         }
     }
+#ifdef VGA_DEBUG_TIMESTAMPS
+    if (lane == 0) g_vga_coef_ts[3 * (blockIdx.x & 8191) + 1] = wall_clock64();
+#endif
     __syncthreads();
     if (lane < 2) s_sum[0][1 + lane] = acc;
     __syncthreads();
@@ -570,6 +584,9 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
         else out = (d < -32768.0) ? -32768 : ((d != d) ? 0 : (int)__builtin_rint(d));
         coefs_out[ch * 16 + lane] = (int16_t)out;
     }
+#ifdef VGA_DEBUG_TIMESTAMPS
+    if (lane == 0) g_vga_coef_ts[3 * (blockIdx.x & 8191) + 2] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------- coefficients, v3: four channels + a summing wave

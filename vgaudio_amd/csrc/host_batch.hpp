@@ -20,7 +20,7 @@ int hardware_queues_requested();                     // capi_gcadpcm.hip: GPU_MA
 // current device, nothing is spread) -- capi_gcadpcm.hip
 std::vector<int> batch_devices();
 // the calling thread's test hooks (include/vgaudio_hip_testing.h), handed on to the threads that run a call's other shares
-struct ThreadHooks { int force_open_seams, encoder_layout, coefs_variant, encoder_segments, hca_frames_per_group; PipeOverride pipe; };
+struct ThreadHooks { int force_open_seams, encoder_layout, coefs_variant, encoder_segments, hca_frames_per_group; PipeOverride pipe; int encoder_persistent = 0; };
 ThreadHooks capture_thread_hooks();                  // capi_gcadpcm.hip
 void apply_thread_hooks(const ThreadHooks &h);       // capi_gcadpcm.hip
 
