@@ -283,6 +283,16 @@ struct RaggedCall {
                 acc = 0;
             }
         }
+        // the last chunk once more, into (5/8, 3/8) of its samples: what runs after the last upload is a short chunk's kernels
+        // and download (the equal-length entry points do the same: host_batch.hpp, tail_units)
+        if (!small && o.chunk_units <= 0 && n - chunk_begin.back() >= 2) {
+            const int first = chunk_begin.back();
+            int64_t rest = 0, head = 0;
+            for (int c = first; c < n; c++) rest += counts[c];
+            int cut = first;
+            while (cut + 1 < n && head + counts[cut] <= rest * 5 / 8) head += counts[cut++];
+            if (cut > first && cut < n) chunk_begin.push_back(cut);
+        }
         chunk_begin.push_back(n);
         chunks.resize(chunk_begin.size() - 1);
         int64_t pcm_base = 0, adpcm_base = 0;

@@ -336,11 +336,26 @@ extern "C" int vga_debug_coefs_timestamps(unsigned long long *out, int n)
 #ifndef VGA_COEFS_PF_REC
 #define VGA_COEFS_PF_REC 2
 #endif
+// timing-only ablations for tools/build_variants.sh (wrong results): 1 = no ordered sums in the Lloyd passes, 2 = no
+// nearest-codeword evaluation, 4 = no partition (every record to bucket 0's slots), 8 = pass 0 without the record
+// arithmetic, 16 = pass 0 without its ordered sum, 32 = no Lloyd passes at all
+#ifndef VGA_COEFS_ABLATE
+#define VGA_COEFS_ABLATE 0
+#endif
 #ifndef VGA_COEFS_PF_PCM
 #define VGA_COEFS_PF_PCM 1
 #endif
 constexpr int COEF_PF_PCM = VGA_COEFS_PF_PCM;      // chunks of PCM in flight per wave in pass 0
-constexpr int COEF_PF_REC = VGA_COEFS_PF_REC;      // chunks of records in flight per wave in the Lloyd passes
+constexpr int COEF_PF_REC = VGA_COEFS_PF_REC;
+// Lloyd passes: records per chunk of the one-wave-per-channel kernel, in units of 64.  K x 64: every lane classifies K
+// records, the stable partition takes the K groups in record order, the ordered sums run over up to 64 K records per
+// bucket -- the per-chunk costs (loop, LDS fill, hand-over) are paid once per 64 K records and the sums' batches of eight
+// are rounded up once per 64 K records instead of once per 64 (measured at configs[1]: K = 1: 42.2 ms, K = 2: 39.0 ms).
+#ifndef VGA_COEFS_CHUNKS
+#define VGA_COEFS_CHUNKS 4
+#endif
+constexpr int COEF_K = VGA_COEFS_CHUNKS;
+constexpr int COEF_SLOTS = (64 * COEF_K + 56 + 63) / 64 * 64;   // 64 K + 8 x 7 slots of padding, a multiple of 64      // chunks of records in flight per wave in the Lloyd passes
 
 __global__ __launch_bounds__(64) void gc_coefs_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int length,
@@ -348,7 +363,12 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
 {
     // compacted (d1, d2) of the current chunk, bucket-major, every bucket starting on a multiple of 8 slots and
     // zero-padded to the next one (<= 64 + 8 * 7 slots); two buffers (chunk parity): one barrier per chunk
-    __shared__ __align__(64) double s_d[2][2][128];
+    // pass 0: [chunk parity][component][128 slots]; Lloyd passes: [component][COEF_SLOTS slots] (one buffer: a wave's LDS
+    // operations execute in program order, the next chunk's fill cannot overtake this chunk's reads)
+    constexpr int COEF_BUF = 2 * COEF_SLOTS > 512 ? 2 * COEF_SLOTS : 512;
+    __shared__ __align__(64) double s_buf[COEF_BUF];
+    auto p0 = [&](int par, int comp) { return s_buf + (2 * par + comp) * 128; };
+    auto ll = [&](int comp) { return s_buf + comp * COEF_SLOTS; };
     __shared__ double s_vb[8][3];      // vecBest
     __shared__ double s_cw[8][3];      // val1, val2, val3 of ContrastVectors per codeword
     __shared__ double s_sum[8][3];     // bufferList
@@ -366,8 +386,13 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
 
     // one wave: its LDS operations execute in program order, so the fill needs no barrier before the writes
     auto zero_fill = [&](int par) {
-        reinterpret_cast<double2 *>(&s_d[par][0][0])[lane] = make_double2(0.0, 0.0);
-        reinterpret_cast<double2 *>(&s_d[par][1][0])[lane] = make_double2(0.0, 0.0);
+        reinterpret_cast<double2 *>(p0(par, 0))[lane] = make_double2(0.0, 0.0);
+        reinterpret_cast<double2 *>(p0(par, 1))[lane] = make_double2(0.0, 0.0);
+    };
+    auto zero_fill2 = [&](int) {                       // both components' COEF_SLOTS slots: COEF_SLOTS / 64 x 16 bytes per lane
+        double2 *z = reinterpret_cast<double2 *>(ll(0));
+#pragma unroll
+        for (int q = 0; q < COEF_SLOTS / 64; q++) z[q * 64 + lane] = make_double2(0.0, 0.0);
     };
 
 #ifdef VGA_DEBUG_TIMESTAMPS
@@ -406,9 +431,11 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
                 load_frame16(src, f, length, x);
                 fs = frame_sums(x);
             }
-            const Record r = frame_record(fs);
+            Record r;
+            if (VGA_COEFS_ABLATE & 8) { r.valid = fs.vec[0] != 0.0; r.r1 = fs.m11 * 1e-12; r.r2 = fs.m12 * 1e-12; }
+            else r = frame_record(fs);
             valid = r.valid;
-            if (valid) matrix_filter(r.r1, r.r2, d1, d2);
+            if (valid) { if (VGA_COEFS_ABLATE & 8) { d1 = r.r1; d2 = r.r2; } else matrix_filter(r.r1, r.r2, d1, d2); }
             // The scratch keeps MatrixFilter's output (dst[1], dst[2]), not the record: it is all the later
             // passes need -- ContrastVectors' `val` (:335-342) is the same expression as mtx[1][1] = dst[1]
             // (:295-296) and its second term, -r1*val + -r2, the same as dst[2] (sign flips are exact; a
@@ -420,11 +447,11 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
         zero_fill(par);
         if (valid) {
             const int slot = lane_rank(mask);
-            s_d[par][0][slot] = d1;
-            s_d[par][1][slot] = d2;
+            p0(par, 0)[slot] = d1;
+            p0(par, 1)[slot] = d2;
         }
         wave_lds_sync();
-        if (lane < 2) acc = ordered_sum(acc, &s_d[par][lane][0], n, n);
+        if (lane < 2 && !(VGA_COEFS_ABLATE & 16)) acc = ordered_sum(acc, p0(par, lane), n, n);
         cnt += n;
         par ^= 1;
     };
@@ -496,18 +523,20 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
                     // none here)
                     const double val_x2 = 2.0 * r.x, bterm_x2 = 2.0 * r.y;
                     double value = 1.0e30;
+                    if (!(VGA_COEFS_ABLATE & 2)) {
 #pragma unroll
                     for (int i = 0; i < EXP; i++) {
                         const double t = cw1[i] + (val_x2 * cw2[i]) + (bterm_x2 * cw3[i]);
                         if (t < value) { value = t; idx = i; }
                     }
+                    } else idx = (int)(__double_as_longlong(val_x2) >> 40) & (EXP - 1);
                     d1 = r.x;
                     d2 = r.y;
                 }
                 // stable partition by bucket
                 int slot = 0, my_start = 0, my_n = 0, start = 0, max_n = 0;
 #pragma unroll
-                for (int b = 0; b < EXP; b++) {
+                for (int b = 0; b < ((VGA_COEFS_ABLATE & 4) ? 1 : EXP); b++) {
                     const bool mine = valid && idx == b;
                     const uint64_t m = __ballot(mine);
                     const int n_b = __popcll(m);
@@ -518,16 +547,81 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
                 }
                 zero_fill(par);
                 if (valid) {
-                    s_d[par][0][slot] = d1;
-                    s_d[par][1][slot] = d2;
+                    p0(par, 0)[slot] = d1;
+                    p0(par, 1)[slot] = d2;
                 }
                 wave_lds_sync();
-                if (lane < 2 * EXP) {
-                    acc = ordered_sum(acc, &s_d[par][my_comp][my_start], my_n, max_n);
+                if (lane < 2 * EXP && !(VGA_COEFS_ABLATE & 1)) {
+                    acc = ordered_sum(acc, p0(par, my_comp) + my_start, my_n, max_n);
                     cnt += my_n;
                 }
                 par ^= 1;
             };
+            auto classify = [&](int f, const double2 r, bool &valid, int &idx) __attribute__((always_inline)) {
+                valid = false;
+                idx = 0;
+                if (f < frames && r.x == r.x) {
+                    valid = true;
+                    const double val_x2 = 2.0 * r.x, bterm_x2 = 2.0 * r.y;
+                    double value = 1.0e30;
+#pragma unroll
+                    for (int i = 0; i < EXP; i++) {
+                        const double t = cw1[i] + (val_x2 * cw2[i]) + (bterm_x2 * cw3[i]);
+                        if (t < value) { value = t; idx = i; }
+                    }
+                }
+            };
+            // K chunks at once: lane = records base + 64 k + lane, k = 0 .. K-1
+            auto lloyd_chunks = [&](int base, const double2 (&r)[COEF_K]) __attribute__((always_inline)) {
+                bool v[COEF_K];
+                int ix[COEF_K], slot[COEF_K];
+#pragma unroll
+                for (int k = 0; k < COEF_K; k++) {
+                    classify(base + 64 * k + lane, r[k], v[k], ix[k]);
+                    slot[k] = 0;
+                }
+                int my_start = 0, my_n = 0, start = 0, max_n = 0;
+#pragma unroll
+                for (int b = 0; b < EXP; b++) {
+                    int n = 0;
+#pragma unroll
+                    for (int k = 0; k < COEF_K; k++) {                     // record order: group 0's records first
+                        const bool mine = v[k] && ix[k] == b;
+                        const uint64_t mask = __ballot(mine);
+                        if (mine) slot[k] = start + n + lane_rank(mask);
+                        n += __popcll(mask);
+                    }
+                    if (my_bucket == b) { my_start = start; my_n = n; }
+                    start += (n + 7) & ~7;
+                    max_n = max(max_n, n);
+                }
+                zero_fill2(0);
+#pragma unroll
+                for (int k = 0; k < COEF_K; k++)
+                    if (v[k]) {
+                        ll(0)[slot[k]] = r[k].x;
+                        ll(1)[slot[k]] = r[k].y;
+                    }
+                wave_lds_sync();
+                if (lane < 2 * EXP) {
+                    acc = ordered_sum(acc, ll(my_comp) + my_start, my_n, max_n);
+                    cnt += my_n;
+                }
+            };
+            if (COEF_K > 1) {
+                double2 nxt[COEF_K];
+#pragma unroll
+                for (int k = 0; k < COEF_K; k++) nxt[k] = rec[max(min(lane + 64 * k, frames - 1), 0)];
+                for (int base = 0; base < frames; base += 64 * COEF_K) {
+                    double2 cur[COEF_K];
+#pragma unroll
+                    for (int k = 0; k < COEF_K; k++) {
+                        cur[k] = nxt[k];
+                        nxt[k] = rec[min(base + 64 * (COEF_K + k) + lane, frames - 1)];    // in flight during this chunk
+                    }
+                    lloyd_chunks(base, cur);
+                }
+            } else
             for (int base = 0; base < frames; base += 64 * COEF_PF_REC) {
 #pragma unroll
                 for (int q = 0; q < COEF_PF_REC; q++) {
@@ -560,7 +654,7 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     };
 
     // ---- 3 splits x 2 Lloyd iterations (:77-91, FilterRecords :344-396)
-    for (int w = 0; w < 3; w++) {
+    for (int w = 0; w < ((VGA_COEFS_ABLATE & 32) ? 0 : 3); w++) {
         const int half = 1 << w;
         if (lane < half) {
             s_vb[half + lane][0] = (0.01 * 0.0) + s_vb[lane][0];
