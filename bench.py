@@ -1051,6 +1051,12 @@ def main():
     args = parse()
     cx = setup(args)
     out = {"gc": run_gc, "adx": run_adx, "hca": run_hca}[args.codec](args, cx)
+    if cx.world > 1 and cx.rank != 0:
+        # this rank's tensors are gone with run_*'s frame; give the blocks back too: rank 0 may still be measuring
+        # (e2e_multi spreads a call over every GPU of the job) while this rank only waits at the final barrier
+        import gc
+        gc.collect()
+        cx.torch.cuda.empty_cache()
     if args.codec == "gc" and cx.world == 1 and out is not None and not args.no_other_configs and args.channels == 4096 and args.seconds == 60.0:
         import torch
         torch.cuda.empty_cache()

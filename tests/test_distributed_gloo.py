@@ -35,7 +35,7 @@ WORKER = textwrap.dedent("""
     from oracle import pyoracle as po
     rank, local_rank, world = vd.env_world()
     vd.init("gloo")
-    total, n = 7, 14 * 200 + 3
+    total, n = {total}, 14 * 200 + 3
     first, count = vd.shard_channels(total, world, rank)
     counts = [vd.shard_channels(total, world, r)[1] for r in range(world)]
     pcm = synth.generate(count, n, first_channel=first)           # each rank generates only its shard
@@ -79,7 +79,7 @@ def test_two_rank_gloo_sharded_encode(tmp_path):
     """the ranks are started by the launcher `python bench.py --gpus N` uses (distributed.launch_local_ranks)"""
     from vgaudio_amd.distributed import launch_local_ranks
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
+    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path), total=7))
     assert launch_local_ranks([str(script)], 2, timeout=240) == 0
     from oracle import pyoracle as po
     from vgaudio_amd import synth
@@ -92,6 +92,27 @@ def test_two_rank_gloo_sharded_encode(tmp_path):
     # the gathered bitstream on rank 0 is the single-process result, channel for channel
     assert (np.load(tmp_path / "gathered_adpcm.npy") == adpcm).all()
     assert (np.load(tmp_path / "gathered_coefs.npy").reshape(7, 16) == np.asarray(coefs).reshape(7, 16)).all()
+
+
+def test_eight_rank_gloo_sharded_encode_uneven_counts(tmp_path):
+    """BASELINE configs[4]'s world size: eight ranks, 35 channels (shares of 5 and 4), every rank's rows and coefficients
+    gathered to rank 0 in channel order with the digests verified for all eight"""
+    from vgaudio_amd.distributed import launch_local_ranks, shard_channels
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path), total=35))
+    assert launch_local_ranks([str(script)], 8, timeout=400) == 0
+    counts = [shard_channels(35, 8, r)[1] for r in range(8)]
+    assert sorted(set(counts)) == [4, 5] and sum(counts) == 35
+    from oracle import pyoracle as po
+    from vgaudio_amd import synth
+    pcm = synth.generate(35, 14 * 200 + 3)
+    coefs, adpcm = po.gc_encode_batch(pcm, threads=4)
+    assert (np.load(tmp_path / "coefs_all.npy") == coefs).all()
+    parts = [np.load(tmp_path / f"adpcm_{r}.npy") for r in range(8)]
+    assert [p.shape[0] for p in parts] == counts
+    assert (np.concatenate(parts) == adpcm).all()
+    assert (np.load(tmp_path / "gathered_adpcm.npy") == adpcm).all()
+    assert (np.load(tmp_path / "gathered_coefs.npy").reshape(35, 16) == np.asarray(coefs).reshape(35, 16)).all()
 
 
 def test_launcher_reports_a_failing_rank_and_stops_the_others(tmp_path):

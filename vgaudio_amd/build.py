@@ -42,22 +42,43 @@ def source_hashes():
             for f in sorted(os.listdir(CSRC)) if os.path.isfile(os.path.join(CSRC, f))}
 
 
-# the files a codec's kernels are built from (bench.py: is a committed profile still about this code?)
-KERNEL_SOURCES = {
-    "gc": ["gc_encode_kernel.hip", "gc_encode_core.hpp", "gcadpcm_kernels.hip", "gc_decode_kernel.hip", "common.hpp"],
-    "adx": ["adx_kernels.hip", "common.hpp"],
-    "hca": ["hca_encode_kernel.hip", "hca_decode_kernels.hip", "hca_decode_core.hpp", "hca_device.hpp", "hca_info.hpp",
-            "hca_tables_data.h", "common.hpp"],
+# the .hip files that hold a codec's kernels; the headers come from their #include lines (bench.py: is a committed
+# profile still about this code?)
+KERNEL_FILES = {
+    "gc": ["gc_encode_kernel.hip", "gcadpcm_kernels.hip", "gc_decode_kernel.hip"],
+    "adx": ["adx_kernels.hip"],
+    "hca": ["hca_encode_kernel.hip", "hca_decode_kernels.hip"],
 }
 
 
+def kernel_sources(codec):
+    """The codec's kernel files and every file of csrc/ they include, directly or not."""
+    import re
+    seen, todo = [], list(KERNEL_FILES[codec])
+    while todo:
+        f = todo.pop()
+        if f in seen:
+            continue
+        seen.append(f)
+        try:
+            text = open(os.path.join(CSRC, f)).read()
+        except OSError:
+            continue
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+            inc = os.path.basename(inc)
+            if os.path.exists(os.path.join(CSRC, inc)):
+                todo.append(inc)
+    return sorted(seen)
+
+
 def profile_is_current(profile, codec):
-    """profile: a JSON object written by tools/summarize_pmc.py (carries "_csrc_sha256")"""
+    """profile: a JSON object written by tools/summarize_pmc.py (carries "_csrc_sha256").  A file missing from either side
+    counts as changed."""
     stamp = (profile or {}).get("_csrc_sha256")
     if not isinstance(stamp, dict):
         return False
     now = source_hashes()
-    return all(stamp.get(f) == now.get(f) for f in KERNEL_SOURCES[codec])
+    return all(f in stamp and f in now and stamp[f] == now[f] for f in kernel_sources(codec))
 
 
 def obj_of(src):

@@ -124,6 +124,9 @@ ProgressSink *&current_progress_sink() { return g_progress_sink; }
 
 int require_device()
 {
+    // every entry point that is going to touch the device passes here first: a failure of an EARLIER call on this thread
+    // (an argument check, say) must not make this call's buffers synchronise the device when they are released
+    g_err_pending = false;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {

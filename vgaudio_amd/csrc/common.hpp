@@ -150,7 +150,15 @@ struct DevBuf {
     void drop()
     {
         if (!p) return;
-        if (take_error_pending()) (void)hipDeviceSynchronize();   // a failed call's work may still touch the block
+        if (take_error_pending()) {                        // a failed call's work may still touch the block: wait for ITS device
+            const int dev = DevicePool::get().device_of(p);
+            int cur = -1;
+            if (dev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess) {
+                (void)hipDeviceSynchronize();
+                (void)hipSetDevice(cur);
+            } else
+                (void)hipDeviceSynchronize();
+        }
         DevicePool::get().release(p);
         p = nullptr;
     }

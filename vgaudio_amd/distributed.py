@@ -62,47 +62,70 @@ def gather_channel_metadata(local, counts):
 def launch_local_ranks(argv, nproc, master_port=None, extra_env=None, timeout=None):
     """One process per GPU without torchrun: runs `python argv...` nproc times with RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT set (the environment torch.distributed.run would give them) and waits for all of them.
-    Rank 0 inherits stdout (it prints the result line); the other ranks' stdout goes to stderr.  Returns the first
-    non-zero exit code, or 0.  A rank that fails takes the others down (they would wait in a collective for ever); once
-    rank 0 has finished cleanly -- its line is out -- the others get `grace` seconds and then go the same way."""
+    Rank 0 inherits stdout (it prints the result line); the other ranks' stdout goes to stderr.
+
+    Exit code: 0 only if every rank ended with 0.  Otherwise the first non-zero code seen (a rank that fails takes the
+    others down: they would wait in a collective for ever), 124 if `timeout` ran out, 125 if ranks were still running
+    `grace` seconds after rank 0 had finished cleanly (they are killed; rank 0's line is out by then).
+
+    The rendezvous port: when the caller names none, a free loop-back port is looked up and released again before the
+    ranks bind it -- another process can take it in between, so a launch whose rank 0 dies within the first seconds is
+    tried again on another port (twice).  HSA_ENABLE_IPC_MODE_LEGACY=0 is set for the ranks when the caller's environment
+    does not set it: this image's driver only supports dmabuf IPC, and RCCL fails with hipIpcGetMemHandle errors without
+    it (the variable is read by the ROCm runtime of the rank processes only; the launcher's own process is not touched)."""
     import socket
     import subprocess
     import sys
     import time
-    if master_port is None:
+
+    def free_port():
         with socket.socket() as sock:                      # a free port on the loop-back interface
             sock.bind(("127.0.0.1", 0))
-            master_port = sock.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(master_port), WORLD_SIZE=str(nproc),
-               LOCAL_WORLD_SIZE=str(nproc), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    env.update(extra_env or {})
-    procs = []
-    for r in range(nproc):
-        procs.append(subprocess.Popen([sys.executable] + list(argv), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                                      stdout=None if r == 0 else sys.stderr))
-    deadline = None if timeout is None else time.monotonic() + timeout
-    grace = 20.0
-    rank0_done_at = None
+            return sock.getsockname()[1]
+
+    def run_once(port):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(nproc),
+                   LOCAL_WORLD_SIZE=str(nproc), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(extra_env or {})
+        procs = []
+        for r in range(nproc):
+            procs.append(subprocess.Popen([sys.executable] + list(argv), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                          stdout=None if r == 0 else sys.stderr))
+        started = time.monotonic()
+        deadline = None if timeout is None else started + timeout
+        grace = 20.0
+        rank0_done_at = None
+        rc = 0
+        early_rank0_failure = False
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if p is procs[0] and code == 0:
+                    rank0_done_at = time.monotonic()
+                if code != 0 and rc == 0:
+                    rc = code
+                    early_rank0_failure = p is procs[0] and time.monotonic() - started < 15.0
+            straggling = rank0_done_at is not None and time.monotonic() > rank0_done_at + grace
+            if rc != 0 or straggling or (deadline is not None and time.monotonic() > deadline):
+                for p in live:
+                    p.kill()
+                for p in live:
+                    p.wait()
+                return (rc if rc else (125 if straggling else 124)), early_rank0_failure
+            time.sleep(0.05)
+        return rc, early_rank0_failure
+
+    if master_port is not None:
+        return run_once(master_port)[0]
     rc = 0
-    live = list(procs)
-    while live:
-        for p in list(live):
-            code = p.poll()
-            if code is None:
-                continue
-            live.remove(p)
-            if p is procs[0] and code == 0:
-                rank0_done_at = time.monotonic()
-            if code != 0 and rc == 0 and rank0_done_at is None:
-                rc = code
-        straggling = rank0_done_at is not None and time.monotonic() > rank0_done_at + grace
-        if rc != 0 or straggling or (deadline is not None and time.monotonic() > deadline):
-            for p in live:
-                p.kill()
-            for p in live:
-                p.wait()
-            return rc if (rc or straggling) else 124
-        time.sleep(0.05)
+    for _attempt in range(3):
+        rc, early = run_once(free_port())
+        if rc == 0 or not early:
+            break
     return rc
 
 
