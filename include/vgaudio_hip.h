@@ -328,6 +328,16 @@ int vga_adx_encode_batch(const int16_t *const *pcm, int nch, int pcm_length, con
  * reads, or a frame naming a filter outside the coefficient table, -> VGA_ERR_ARGUMENT. */
 int vga_adx_decode_batch(const uint8_t *const *adpcm, int adpcm_length, int nch, int sample_count,
                          const vga_adx_params *p, int16_t *const *pcm_out);
+/* Ragged batches: the channels of many files in one call (VGAudio.Cli/Batch.cs:24-25 runs a worker per file, each through
+ * CriAdxFormat.EncodeFromPcm16 / ToPcm16), channel c with its own length and its own parameters (params: nch entries; a
+ * file's sample rate sets its high-pass coefficients, CriAdxCodec.cs:64).  out[c]: vga_adx_encoded_byte_count(
+ * pcm_lengths[c], &params[c]) bytes; results are byte for byte those of one call per channel.  Channels are grouped by
+ * parameter set and length (buckets a quarter wide, zero-padded on the device: the encoder is causal and pads its last
+ * frame with zeros itself, CriAdxCodec.cs:78-91). */
+int vga_adx_encode_batch_v(const int16_t *const *pcm, const int *pcm_lengths, int nch, const vga_adx_params *params,
+                           uint8_t *const *out, int16_t *history_out);
+int vga_adx_decode_batch_v(const uint8_t *const *adpcm, const int *adpcm_lengths, int nch, const int *sample_counts,
+                           const vga_adx_params *params, int16_t *const *pcm_out);
 /* device-resident variants (pitches: pcm in samples, bytes for ADX data and even) */
 int vga_adx_encode_device(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_length,
                           const vga_adx_params *p, uint8_t *d_out, int64_t out_pitch,
@@ -412,6 +422,17 @@ int vga_hca_encode_batch(const int16_t *const *pcm, int nstreams, const vga_hca_
  * VGA_ERR_INVALID_DATA ("Invalid frame header"). */
 int vga_hca_decode_batch(const vga_hca_info *info, const uint8_t *const *frames, int nstreams,
                          int16_t *const *pcm_out);
+/* Ragged batches: streams of different shapes in one call (a worker per file, VGAudio.Cli/Batch.cs:24-25).  configs /
+ * infos_out: nstreams entries; pcm: the streams' channels one after the other (sum of the channel counts pointers);
+ * frames_out[s]: infos_out[s].frame_count * frame_size bytes.  Streams that differ in length only (not looping) share
+ * their launches (zero-padded buckets a quarter wide: frame size and band counts follow from the bitrate,
+ * CriHcaEncoder.cs:288-368, every frame is encoded on its own and the encoder's input past the PCM is silence, :234-240);
+ * results are byte for byte those of one call per stream.  Decoding groups the streams by HcaInfo: streams of one shape
+ * decode together, a batch of all-different lengths costs a call per stream. */
+int vga_hca_encode_batch_v(const int16_t *const *pcm, int nstreams, const vga_hca_params *configs,
+                           vga_hca_info *infos_out, uint8_t *const *frames_out);
+int vga_hca_decode_batch_v(const vga_hca_info *infos, const uint8_t *const *frames, int nstreams,
+                           int16_t *const *pcm_out);
 /* device-resident variants: pcm stream s / channel c at d_pcm + s*stream_pitch + c*ch_pitch (samples);
  * frames of stream s at d_frames + s*frames_pitch (even; decode: 4-byte aligned with >= 8 bytes of
  * slack after frame_count*frame_size).  *d_status receives flag bits (1 bad sync, 2 bad scale-factor

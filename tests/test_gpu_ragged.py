@@ -254,3 +254,113 @@ def test_device_resident_ragged_batch():
         assert co[c].tolist() == wc.tolist() and np.array_equal(rows[c], wa), (c, lens[c])
         assert np.array_equal(back[c], po.gc_decode(wa, wc, lens[c])), (c, lens[c])
     rb.close()
+
+
+# ---------------------------------------------------------------------------------------------- CRI ADX, CRI HCA
+def _adx_param_sets():
+    """(reference-side parameters for the oracle, the same as vga_adx_params) -- different files, different parameters"""
+    sets = [dict(), dict(sample_rate=44100), dict(sample_rate=22050, version=3), dict(type=4), dict(type=2, filter=2),
+            dict(frame_size=34), dict(sample_rate=32000, highpass_frequency=500)]
+    return sets
+
+
+def test_adx_ragged_encode_and_decode_match_the_oracle_per_channel():
+    L = _lib.lib()
+    sets = _adx_param_sets()
+    lens = _lengths(70, 40, 120_000, 31, (1, 31, 32, 33, 63, 64, 65))
+    chans = _channels(lens, first_channel=300)
+    nch = len(lens)
+    params = (_lib.AdxParams * nch)()
+    oracle_params = []
+    for c in range(nch):
+        L.vga_adx_default_params(C.byref(params[c]))
+        kw = sets[c % len(sets)]
+        for k, v in kw.items():
+            setattr(params[c], k, v)
+        oracle_params.append(po.adx_params(**kw))
+    counts = np.array(lens, dtype=np.int32)
+    outs = [np.full(L.vga_adx_encoded_byte_count(n, C.byref(params[c])) + 1, 0xEE, dtype=np.uint8) for c, n in enumerate(lens)]
+    hist = np.full(nch, 0x1234, dtype=np.int16)
+    _lib.check(L.vga_adx_encode_batch_v(_ptrs(i16p, chans), counts.ctypes.data_as(C.POINTER(C.c_int)), nch, params, _ptrs(u8p, outs),
+                                        hist.ctypes.data_as(i16p)))
+    for c, pcm in enumerate(chans):
+        p = oracle_params[c]
+        want = po.adx_encode(pcm, p)
+        assert outs[c][-1] == 0xEE and np.array_equal(outs[c][:-1], want), (c, lens[c], sets[c % len(sets)])
+        assert int(hist[c]) == int(p.history), c                    # CriAdxCodec.cs:73: the encoder leaves History in the config
+    # decode what was encoded, every channel with its own length and parameters
+    enc = [o[:-1].copy() for o in outs]
+    alens = np.array([len(e) for e in enc], dtype=np.int32)
+    pcm_out = [np.full(n + 1, 0x7777, dtype=np.int16) for n in lens]
+    _lib.check(L.vga_adx_decode_batch_v(_ptrs(u8p, enc), alens.ctypes.data_as(C.POINTER(C.c_int)), nch,
+                                        counts.ctypes.data_as(C.POINTER(C.c_int)), params, _ptrs(i16p, pcm_out)))
+    for c in range(nch):
+        p = po.adx_params(**sets[c % len(sets)])
+        want = po.adx_decode(enc[c], lens[c], p)
+        assert pcm_out[c][-1] == 0x7777 and np.array_equal(pcm_out[c][:-1], want), (c, lens[c])
+
+
+def test_adx_ragged_rejects_what_the_reference_rejects():
+    L = _lib.lib()
+    params = (_lib.AdxParams * 2)()
+    for c in range(2):
+        L.vga_adx_default_params(C.byref(params[c]))
+    chans = [np.zeros(64, np.int16), np.zeros(0, np.int16)]
+    counts = np.array([64, 0], dtype=np.int32)                       # an empty version-4 channel: the reference reads pcm[0]
+    outs = [np.zeros(64, np.uint8), np.zeros(16, np.uint8)]
+    assert L.vga_adx_encode_batch_v(_ptrs(i16p, chans), counts.ctypes.data_as(C.POINTER(C.c_int)), 2, params, _ptrs(u8p, outs),
+                                    None) == _lib.VGA_ERR_ARGUMENT
+
+
+def test_hca_ragged_streams_match_the_oracle_per_stream():
+    """mono and stereo files, two sample rates, three qualities, one looping stream, lengths from half a frame to 60 frames"""
+    L = _lib.lib()
+    rng = np.random.default_rng(41)
+    shapes = []
+    for s in range(22):
+        nch = 1 if s % 3 == 0 else 2
+        n = int(rng.integers(300, 60 * 1024))
+        shapes.append(dict(channel_count=nch, sample_count=n, sample_rate=48000 if s % 4 else 44100,
+                           quality=("High", "Middle", "Highest")[s % 3]))
+    shapes.append(dict(channel_count=2, sample_count=20_000, looping=True, loop_start=3000, loop_end=17_000))
+    shapes.append(dict(channel_count=2, sample_count=1024 * 7))
+    shapes.append(dict(channel_count=2, sample_count=1024 * 7 - 128))
+    ns = len(shapes)
+    pcm, rows = [], []
+    for s, sh in enumerate(shapes):
+        a = po.synth_generate(sh["channel_count"], sh["sample_count"], first_channel=40 * s)
+        pcm.append(a)
+        rows += [a[c] for c in range(sh["channel_count"])]
+    configs = (_lib.HcaParamsC * ns)()
+    oparams = []
+    for s, sh in enumerate(shapes):
+        op = po.hca_params(**sh)
+        oparams.append(op)
+        for f, _ in _lib.HcaParamsC._fields_:
+            setattr(configs[s], f, getattr(op, f))
+    infos = (_lib.HcaInfoC * ns)()
+    want = []
+    for s in range(ns):
+        rc, info, frames = po.hca_encode(pcm[s], oparams[s])
+        assert rc == 0, s
+        want.append((info, frames))
+    outs = [np.full(w[0].frame_count * w[0].frame_size + 1, 0xEE, dtype=np.uint8) for w in want]
+    _lib.check(L.vga_hca_encode_batch_v(_ptrs(i16p, rows), ns, configs, infos, _ptrs(u8p, outs)))
+    for s in range(ns):
+        info, frames = want[s]
+        for f, _ in _lib.HcaInfoC._fields_:
+            assert getattr(infos[s], f) == getattr(info, f), (s, f)
+        assert outs[s][-1] == 0xEE and np.array_equal(outs[s][:-1], frames.reshape(-1)), (s, shapes[s])
+    # decode: every stream from its own HcaInfo
+    enc = [o[:-1].copy() for o in outs]
+    pcm_out = []
+    for s in range(ns):
+        pcm_out += [np.full(max(infos[s].sample_count, 0) + 1, 0x7777, dtype=np.int16) for _ in range(infos[s].channel_count)]
+    _lib.check(L.vga_hca_decode_batch_v(infos, _ptrs(u8p, enc), ns, _ptrs(i16p, pcm_out)))
+    at = 0
+    for s in range(ns):
+        rc, dec = po.hca_decode(want[s][0], want[s][1])
+        assert rc == 0
+        for c in range(infos[s].channel_count):
+            assert pcm_out[at][-1] == 0x7777 and np.array_equal(pcm_out[at][:-1], dec[c]), (s, c)
+            at += 1

@@ -187,6 +187,10 @@ SIGNATURES = {
     "vga_adx_encoded_byte_count": (ci, [ci, vp]),
     "vga_adx_encode_batch": (ci, [i16pp, ci, ci, vp, u8pp, i16p]),
     "vga_adx_decode_batch": (ci, [u8pp, ci, ci, ci, vp, i16pp]),
+    "vga_adx_encode_batch_v": (ci, [i16pp, C.POINTER(ci), ci, vp, u8pp, i16p]),
+    "vga_adx_decode_batch_v": (ci, [u8pp, C.POINTER(ci), ci, C.POINTER(ci), vp, i16pp]),
+    "vga_hca_encode_batch_v": (ci, [i16pp, ci, vp, vp, u8pp]),
+    "vga_hca_decode_batch_v": (ci, [vp, u8pp, ci, i16pp]),
     "vga_adx_encode_device": (ci, [vp, i64, ci, ci, vp, vp, i64, vp, vp]),
     "vga_adx_decode_device": (ci, [vp, i64, ci, ci, ci, vp, vp, i64, vp, vp]),
     "vga_hca_encoder_initialize": (ci, [vp, vp]),

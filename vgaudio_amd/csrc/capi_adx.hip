@@ -4,6 +4,8 @@
 #include "adx_kernels.hpp"
 
 #include <cmath>
+#include <cstring>
+#include <vector>
 
 using namespace vga;
 
@@ -261,6 +263,234 @@ static int adx_decode_batch_one(const uint8_t *const *adpcm, int adpcm_length, i
         return VGA_ERR_ARGUMENT;
     }
     return VGA_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- ragged batches (VGAudio.Cli/Batch.cs:24-25: a worker per FILE)
+// Every channel with its own length and its own CriAdxParameters (a file's sample rate sets the high-pass coefficients,
+// CriAdxCodec.cs:64): the channels are sorted into buckets of one parameter set and similar length (host_batch.hpp,
+// plan_buckets), a bucket's rows are zero-padded on the device to its longest channel and run through the equal-length
+// kernels; every channel receives the prefix that is its own encoding / decoding.
+namespace {
+
+// parameter groups: channels whose device parameters are the same bytes
+int group_of(std::vector<adx::AdxDeviceParams> &seen, const adx::AdxDeviceParams &d)
+{
+    for (size_t i = 0; i < seen.size(); i++)
+        if (memcmp(&seen[i], &d, sizeof d) == 0) return (int)i;
+    seen.push_back(d);
+    return (int)seen.size() - 1;
+}
+
+constexpr int64_t ADX_BUCKET_VOLUME = (int64_t)1024 * 2880000;   // padded samples per chunk: what ADX_CHUNK_CHANNELS x 60 s hold
+
+int adx_encode_batch_v_one(const int16_t *const *pcm, const int *lengths, int nch, const vga_adx_params *params, uint8_t *const *out,
+                           int16_t *history_out)
+{
+    if (nch < 0) { set_error("negative channel count"); return VGA_ERR_ARGUMENT; }
+    if (nch == 0) return VGA_OK;
+    if (!pcm || !lengths || !params || !out) { set_error("null array"); return VGA_ERR_ARGUMENT; }
+    std::vector<adx::AdxDeviceParams> dps;
+    std::vector<int> group(nch), length(nch);
+    for (int c = 0; c < nch; c++) {
+        if (int rc = validate(&params[c])) return rc;
+        if (lengths[c] < 0) { set_error("channel %d: negative length", c); return VGA_ERR_ARGUMENT; }
+        if (lengths[c] == 0 && params[c].version == 4 && params[c].padding == 0) {
+            set_error("channel %d: empty PCM: the reference reads pcm[0] (CriAdxCodec.cs:71)", c);
+            return VGA_ERR_ARGUMENT;
+        }
+        if ((!pcm[c] && lengths[c] > 0) || !out[c]) { set_error("channel %d is null", c); return VGA_ERR_ARGUMENT; }
+        adx::AdxDeviceParams d;
+        memset(&d, 0, sizeof d);
+        d = device_params(&params[c], true);
+        group[c] = group_of(dps, d);
+        length[c] = lengths[c];
+    }
+    if (int rc = require_device()) return rc;
+    const BucketPlan plan = plan_buckets(group, length, ADX_CHUNK_CHANNELS, ADX_BUCKET_VOLUME);
+    const int chunks = (int)plan.chunk_begin.size() - 1;
+    // device layout: chunk k's rows pitch_k apart behind the chunks before it
+    std::vector<int64_t> pcm_base(chunks + 1, 0), out_base(chunks + 1, 0), pcm_pitch(chunks), out_pitch(chunks);
+    std::vector<const vga_adx_params *> chunk_params(chunks);
+    for (int k = 0; k < chunks; k++) {
+        const int count = plan.chunk_begin[k + 1] - plan.chunk_begin[k];
+        chunk_params[k] = &params[plan.order[plan.chunk_begin[k]]];
+        pcm_pitch[k] = round_up(std::max(plan.chunk_length[k], 1), 8);
+        out_pitch[k] = round_up(std::max(vga_adx_encoded_byte_count(plan.chunk_length[k], chunk_params[k]), 2), 16);
+        pcm_base[k + 1] = pcm_base[k] + pcm_pitch[k] * count;
+        out_base[k + 1] = out_base[k] + out_pitch[k] * count;
+    }
+    std::vector<const void *> in_rows(nch);
+    std::vector<void *> out_rows(nch);
+    std::vector<size_t> in_size(nch), in_off(nch), out_size(nch), out_off(nch);
+    size_t max_in = 16, max_out = 16;
+    for (int k = 0; k < chunks; k++)
+        for (int i = plan.chunk_begin[k]; i < plan.chunk_begin[k + 1]; i++) {
+            const int c = plan.order[i], j = i - plan.chunk_begin[k];
+            in_rows[i] = pcm[c];
+            out_rows[i] = out[c];
+            in_size[i] = (size_t)lengths[c] * 2;
+            in_off[i] = (size_t)(pcm_base[k] + j * pcm_pitch[k]) * 2;
+            out_size[i] = (size_t)vga_adx_encoded_byte_count(lengths[c], &params[c]);
+            out_off[i] = (size_t)(out_base[k] + j * out_pitch[k]);
+            max_in = std::max(max_in, (size_t)pcm_pitch[k] * 2);
+            max_out = std::max(max_out, (size_t)out_pitch[k]);
+        }
+    DevBuf d_pcm, d_out, d_hist;
+    VGA_HIP_TRY(d_pcm.alloc((size_t)pcm_base[chunks] * 2 + 64));
+    VGA_HIP_TRY(hipMemset(d_pcm.p, 0, (size_t)pcm_base[chunks] * 2 + 64));           // the padding behind every row is silence
+    VGA_HIP_TRY(d_out.alloc((size_t)out_base[chunks] + 64));
+    VGA_HIP_TRY(d_hist.alloc((size_t)nch * 2));
+    pipe::Job job;
+    job.units = nch;
+    job.chunk_begin = plan.chunk_begin;
+    job.in_rows = in_rows.data();
+    job.in_row_sizes = in_size.data();
+    job.d_in_offsets = in_off.data();
+    job.in_row_bytes = max_in;
+    job.d_in_pitch = max_in;
+    job.d_in = d_pcm.as<char>();
+    job.out_rows = out_rows.data();
+    job.out_row_sizes = out_size.data();
+    job.d_out_offsets = out_off.data();
+    job.out_row_bytes = max_out;
+    job.d_out_pitch = max_out;
+    job.d_out = d_out.as<char>();
+    job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
+        const int k = plan.chunk_of(first);
+        const int rc = adx::launch_encode(d_pcm.as<int16_t>() + pcm_base[k], pcm_pitch[k], count, plan.chunk_length[k], dps[plan.chunk_group[k]],
+                                          d_out.as<uint8_t>() + out_base[k], out_pitch[k], d_hist.as<int16_t>() + first, s);
+        if (rc) why = vga_last_error();
+        return rc;
+    };
+    if (int rc = run_batch_pipeline(job, ADX_CHUNK_CHANNELS)) return rc;
+    if (history_out) {
+        std::vector<int16_t> h(nch);
+        VGA_HIP_TRY(hipMemcpy(h.data(), d_hist.p, (size_t)nch * 2, hipMemcpyDeviceToHost));
+        for (int i = 0; i < nch; i++) history_out[plan.order[i]] = h[i];
+    }
+    return VGA_OK;
+}
+
+int adx_decode_batch_v_one(const uint8_t *const *adpcm, const int *adpcm_lengths, int nch, const int *sample_counts,
+                           const vga_adx_params *params, int16_t *const *pcm_out)
+{
+    if (nch < 0) { set_error("negative channel count"); return VGA_ERR_ARGUMENT; }
+    if (nch == 0) return VGA_OK;
+    if (!adpcm || !adpcm_lengths || !sample_counts || !params || !pcm_out) { set_error("null array"); return VGA_ERR_ARGUMENT; }
+    std::vector<adx::AdxDeviceParams> dps;
+    std::vector<int> group(nch), length(nch);
+    std::vector<size_t> need(nch);
+    for (int c = 0; c < nch; c++) {
+        if (int rc = validate(&params[c])) return rc;
+        if (sample_counts[c] < 0 || adpcm_lengths[c] < 0) { set_error("channel %d: negative size", c); return VGA_ERR_ARGUMENT; }
+        const int spf = (params[c].frame_size - 2) * 2;
+        need[c] = sample_counts[c] == 0 ? 0 : (size_t)(params[c].padding / spf) * params[c].frame_size +
+                                                  (size_t)divide_by_round_up(sample_counts[c], spf) * params[c].frame_size;
+        if ((size_t)adpcm_lengths[c] < need[c]) {
+            set_error("channel %d: ADX stream too short: %d bytes, decoder reads %zu", c, adpcm_lengths[c], need[c]);
+            return VGA_ERR_ARGUMENT;
+        }
+        if (sample_counts[c] > 0 && (!adpcm[c] || !pcm_out[c])) { set_error("channel %d is null", c); return VGA_ERR_ARGUMENT; }
+        adx::AdxDeviceParams d;
+        memset(&d, 0, sizeof d);
+        d = device_params(&params[c], false);
+        group[c] = group_of(dps, d);
+        length[c] = sample_counts[c];
+    }
+    if (int rc = require_device()) return rc;
+    const BucketPlan plan = plan_buckets(group, length, ADX_CHUNK_CHANNELS, ADX_BUCKET_VOLUME);
+    const int chunks = (int)plan.chunk_begin.size() - 1;
+    std::vector<int64_t> in_base(chunks + 1, 0), pcm_base(chunks + 1, 0), in_pitch(chunks), pcm_pitch(chunks);
+    for (int k = 0; k < chunks; k++) {
+        const int count = plan.chunk_begin[k + 1] - plan.chunk_begin[k];
+        const vga_adx_params &p = params[plan.order[plan.chunk_begin[k]]];
+        const int spf = (p.frame_size - 2) * 2;
+        const int64_t bytes = (int64_t)(p.padding / spf) * p.frame_size + (int64_t)divide_by_round_up(plan.chunk_length[k], spf) * p.frame_size;
+        in_pitch[k] = round_up(std::max<int64_t>(bytes, 2), 16);
+        pcm_pitch[k] = round_up(std::max(plan.chunk_length[k], 1), 8);
+        in_base[k + 1] = in_base[k] + in_pitch[k] * count;
+        pcm_base[k + 1] = pcm_base[k] + pcm_pitch[k] * count;
+    }
+    std::vector<const void *> in_rows(nch);
+    std::vector<void *> out_rows(nch);
+    std::vector<size_t> in_size(nch), in_off(nch), out_size(nch), out_off(nch);
+    size_t max_in = 16, max_out = 16;
+    for (int k = 0; k < chunks; k++)
+        for (int i = plan.chunk_begin[k]; i < plan.chunk_begin[k + 1]; i++) {
+            const int c = plan.order[i], j = i - plan.chunk_begin[k];
+            in_rows[i] = adpcm[c];
+            out_rows[i] = pcm_out[c];
+            in_size[i] = need[c];
+            in_off[i] = (size_t)(in_base[k] + j * in_pitch[k]);
+            out_size[i] = (size_t)sample_counts[c] * 2;
+            out_off[i] = (size_t)(pcm_base[k] + j * pcm_pitch[k]) * 2;
+            max_in = std::max(max_in, (size_t)in_pitch[k]);
+            max_out = std::max(max_out, (size_t)pcm_pitch[k] * 2);
+        }
+    DevBuf d_in, d_pcm, d_status;
+    VGA_HIP_TRY(d_in.alloc((size_t)in_base[chunks] + 64));
+    VGA_HIP_TRY(hipMemset(d_in.p, 0, (size_t)in_base[chunks] + 64));                 // frames behind a row's end: scale 0, filter 0
+    VGA_HIP_TRY(d_pcm.alloc((size_t)pcm_base[chunks] * 2 + 64));
+    VGA_HIP_TRY(d_status.alloc(sizeof(int)));
+    VGA_HIP_TRY(hipMemset(d_status.p, 0, sizeof(int)));
+    pipe::Job job;
+    job.units = nch;
+    job.chunk_begin = plan.chunk_begin;
+    job.in_rows = in_rows.data();
+    job.in_row_sizes = in_size.data();
+    job.d_in_offsets = in_off.data();
+    job.in_row_bytes = max_in;
+    job.d_in_pitch = max_in;
+    job.d_in = d_in.as<char>();
+    job.out_rows = out_rows.data();
+    job.out_row_sizes = out_size.data();
+    job.d_out_offsets = out_off.data();
+    job.out_row_bytes = max_out;
+    job.d_out_pitch = max_out;
+    job.d_out = d_pcm.as<char>();
+    job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
+        const int k = plan.chunk_of(first);
+        int rc = VGA_OK;
+        if (plan.chunk_length[k] > 0)
+            rc = adx::launch_decode(d_in.as<uint8_t>() + in_base[k], in_pitch[k], count, plan.chunk_length[k], dps[plan.chunk_group[k]],
+                                    d_pcm.as<int16_t>() + pcm_base[k], pcm_pitch[k], d_status.as<int>(), s);
+        if (rc) why = vga_last_error();
+        return rc;
+    };
+    if (int rc = run_batch_pipeline(job, ADX_CHUNK_CHANNELS)) return rc;
+    int status = 0;
+    VGA_HIP_TRY(hipMemcpy(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (status != 0) {
+        set_error("a frame names a filter the coefficient table lacks (IndexOutOfRangeException in the reference)");
+        return VGA_ERR_ARGUMENT;
+    }
+    return VGA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vga_adx_encode_batch_v(const int16_t *const *pcm, const int *pcm_lengths, int nch, const vga_adx_params *params,
+                           uint8_t *const *out, int16_t *history_out)
+{
+    if (nch <= 0 || !pcm || !pcm_lengths || !params || !out) return adx_encode_batch_v_one(pcm, pcm_lengths, nch, params, out, history_out);
+    return for_each_device_share(nch, ADX_MIN_SHARE_CHANNELS, [&](int first, int count) {
+        return adx_encode_batch_v_one(pcm + first, pcm_lengths + first, count, params + first, out + first,
+                                      history_out ? history_out + first : nullptr);
+    });
+}
+
+int vga_adx_decode_batch_v(const uint8_t *const *adpcm, const int *adpcm_lengths, int nch, const int *sample_counts,
+                           const vga_adx_params *params, int16_t *const *pcm_out)
+{
+    if (nch <= 0 || !adpcm || !adpcm_lengths || !sample_counts || !params || !pcm_out)
+        return adx_decode_batch_v_one(adpcm, adpcm_lengths, nch, sample_counts, params, pcm_out);
+    return for_each_device_share(nch, ADX_MIN_SHARE_CHANNELS, [&](int first, int count) {
+        return adx_decode_batch_v_one(adpcm + first, adpcm_lengths + first, count, sample_counts + first, params + first, pcm_out + first);
+    });
 }
 
 }  // extern "C"

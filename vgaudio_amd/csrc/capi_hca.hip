@@ -6,7 +6,9 @@
 #include "hca_kernels.hpp"
 
 #include <cmath>
+#include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace hosttab {
 #include "hca_tables_host.inc"
@@ -474,6 +476,174 @@ static int hca_decode_batch_one(const vga_hca_info *h, const uint8_t *const *fra
     int status = 0;
     VGA_HIP_TRY(hipMemcpy(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost));
     return status_to_error(status);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- ragged batches (VGAudio.Cli/Batch.cs:24-25: a worker per FILE)
+// Every stream with its own CriHcaParameters (channel count, sample rate, length, quality, loop).  Streams that are not
+// looping and differ in length only share their launches: sorted into buckets of similar length (host_batch.hpp,
+// plan_buckets), zero-padded on the device to the bucket's longest and encoded with THAT stream's HcaInfo -- frame size
+// and band counts come from the bitrate (CriHcaEncoder.cs:288-368), not from the length, every frame is encoded
+// independently of the others (hca_encode_kernel.hip) and the encoder's own input past the end of the PCM is silence
+// (:234-240), so a shorter stream's frames are the first frames of the padded one.  Looping streams (their loop audio is
+// replayed behind the main audio, :209-232) only share a launch with streams of exactly their shape.
+namespace {
+
+struct HcaGroupKey {
+    int quality, bitrate, limit_bitrate, channel_count, sample_rate, looping, loop_start, loop_end, exact_count;
+};
+
+int hca_group_of(std::vector<HcaGroupKey> &seen, const vga_hca_params &c)
+{
+    HcaGroupKey k = {c.quality, c.bitrate, c.limit_bitrate, c.channel_count, c.sample_rate, c.looping ? 1 : 0,
+                     c.looping ? c.loop_start : 0, c.looping ? c.loop_end : 0, c.looping ? c.sample_count : -1};
+    for (size_t i = 0; i < seen.size(); i++)
+        if (memcmp(&seen[i], &k, sizeof k) == 0) return (int)i;
+    seen.push_back(k);
+    return (int)seen.size() - 1;
+}
+
+constexpr int64_t HCA_BUCKET_VOLUME = (int64_t)HCA_CHUNK_STREAMS * 2880000;      // padded samples per chunk and channel
+
+// the streams of `units` (indices into the caller's arrays) that have `nch` channels: one pipelined job
+int hca_encode_v_job(const std::vector<int> &units, int nch, const int16_t *const *pcm, const std::vector<size_t> &first_row,
+                     const vga_hca_params *configs, const vga_hca_info *infos, uint8_t *const *frames_out)
+{
+    const int n = (int)units.size();
+    std::vector<HcaGroupKey> keys;
+    std::vector<int> group(n), length(n);
+    for (int i = 0; i < n; i++) {
+        group[i] = hca_group_of(keys, configs[units[i]]);
+        length[i] = configs[units[i]].sample_count;
+    }
+    const BucketPlan plan = plan_buckets(group, length, HCA_CHUNK_STREAMS, HCA_BUCKET_VOLUME);
+    const int chunks = (int)plan.chunk_begin.size() - 1;
+    std::vector<vga_hca_info> chunk_info(chunks);
+    std::vector<int64_t> pcm_base(chunks + 1, 0), fr_base(chunks + 1, 0), ch_pitch(chunks), fr_pitch(chunks);
+    for (int k = 0; k < chunks; k++) {
+        const int count = plan.chunk_begin[k + 1] - plan.chunk_begin[k];
+        chunk_info[k] = infos[units[plan.order[plan.chunk_begin[k + 1] - 1]]];       // the bucket's longest stream
+        ch_pitch[k] = round_up(std::max(plan.chunk_length[k], 1), 8);
+        fr_pitch[k] = round_up((int64_t)chunk_info[k].frame_count * chunk_info[k].frame_size + 8, 16);
+        pcm_base[k + 1] = pcm_base[k] + ch_pitch[k] * nch * count;
+        fr_base[k + 1] = fr_base[k] + fr_pitch[k] * count;
+    }
+    std::vector<const void *> in_rows((size_t)n * nch);
+    std::vector<void *> out_rows(n);
+    std::vector<size_t> in_size((size_t)n * nch), in_off((size_t)n * nch), out_size(n), out_off(n);
+    size_t max_in = 16, max_out = 16;
+    for (int k = 0; k < chunks; k++)
+        for (int i = plan.chunk_begin[k]; i < plan.chunk_begin[k + 1]; i++) {
+            const int u = units[plan.order[i]], j = i - plan.chunk_begin[k];
+            for (int c = 0; c < nch; c++) {
+                in_rows[(size_t)i * nch + c] = pcm[first_row[u] + c];
+                in_size[(size_t)i * nch + c] = (size_t)configs[u].sample_count * 2;
+                in_off[(size_t)i * nch + c] = (size_t)(pcm_base[k] + ((int64_t)j * nch + c) * ch_pitch[k]) * 2;
+            }
+            out_rows[i] = frames_out[u];
+            out_size[i] = (size_t)infos[u].frame_count * infos[u].frame_size;
+            out_off[i] = (size_t)(fr_base[k] + j * fr_pitch[k]);
+            max_in = std::max(max_in, (size_t)ch_pitch[k] * 2);
+            max_out = std::max(max_out, (size_t)fr_pitch[k]);
+        }
+    DevBuf d_pcm, d_frames, d_status;
+    VGA_HIP_TRY(d_pcm.alloc((size_t)pcm_base[chunks] * 2 + 64));
+    VGA_HIP_TRY(hipMemset(d_pcm.p, 0, (size_t)pcm_base[chunks] * 2 + 64));           // silence behind every row
+    VGA_HIP_TRY(d_frames.alloc((size_t)fr_base[chunks] + 64));
+    VGA_HIP_TRY(d_status.alloc(sizeof(int)));
+    VGA_HIP_TRY(hipMemset(d_status.p, 0, sizeof(int)));
+    pipe::Job job;
+    job.units = n;
+    job.chunk_begin = plan.chunk_begin;
+    job.in_rows_per_unit = nch;
+    job.in_rows = in_rows.data();
+    job.in_row_sizes = in_size.data();
+    job.d_in_offsets = in_off.data();
+    job.in_row_bytes = max_in;
+    job.d_in_pitch = max_in;
+    job.d_in = d_pcm.as<char>();
+    job.out_rows = out_rows.data();
+    job.out_row_sizes = out_size.data();
+    job.d_out_offsets = out_off.data();
+    job.out_row_bytes = max_out;
+    job.d_out_pitch = max_out;
+    job.d_out = d_frames.as<char>();
+    job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
+        const int k = plan.chunk_of(first);
+        int rc = VGA_OK;
+        if (chunk_info[k].frame_count > 0)
+            rc = vga_hca_encode_device(d_pcm.as<int16_t>() + pcm_base[k], ch_pitch[k] * nch, ch_pitch[k], count, plan.chunk_length[k],
+                                       &chunk_info[k], d_frames.as<uint8_t>() + fr_base[k], fr_pitch[k], d_status.as<int>(), s);
+        if (rc) why = vga_last_error();
+        return rc;
+    };
+    if (int rc = run_batch_pipeline(job, HCA_CHUNK_STREAMS)) return rc;
+    int status = 0;
+    VGA_HIP_TRY(hipMemcpy(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost));
+    return status_to_error(status);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vga_hca_encode_batch_v(const int16_t *const *pcm, int nstreams, const vga_hca_params *configs, vga_hca_info *infos_out,
+                           uint8_t *const *frames_out)
+{
+    if (nstreams < 0) { set_error("negative stream count"); return VGA_ERR_ARGUMENT; }
+    if (nstreams == 0) return VGA_OK;
+    if (!pcm || !configs || !infos_out || !frames_out) { set_error("null array"); return VGA_ERR_ARGUMENT; }
+    std::vector<size_t> first_row(nstreams);
+    size_t rows = 0;
+    for (int s = 0; s < nstreams; s++) {
+        if (int rc = vga_hca_encoder_initialize(&configs[s], &infos_out[s])) return rc;
+        first_row[s] = rows;
+        rows += (size_t)configs[s].channel_count;
+        if (!frames_out[s] && infos_out[s].frame_count > 0) { set_error("frames_out[%d] is null", s); return VGA_ERR_ARGUMENT; }
+        for (int c = 0; c < configs[s].channel_count; c++)
+            if (!pcm[first_row[s] + c] && configs[s].sample_count > 0) { set_error("stream %d channel %d is null", s, c); return VGA_ERR_ARGUMENT; }
+    }
+    if (int rc = require_device()) return rc;
+    // a pipeline job has one row count per unit: one job per channel count
+    for (int nch = 1; nch <= 8; nch++) {
+        std::vector<int> units;
+        for (int s = 0; s < nstreams; s++)
+            if (configs[s].channel_count == nch) units.push_back(s);
+        if (units.empty()) continue;
+        if (int rc = hca_encode_v_job(units, nch, pcm, first_row, configs, infos_out, frames_out)) return rc;
+    }
+    return VGA_OK;
+}
+
+int vga_hca_decode_batch_v(const vga_hca_info *infos, const uint8_t *const *frames, int nstreams, int16_t *const *pcm_out)
+{
+    if (nstreams < 0) { set_error("negative stream count"); return VGA_ERR_ARGUMENT; }
+    if (nstreams == 0) return VGA_OK;
+    if (!infos || !frames || !pcm_out) { set_error("null array"); return VGA_ERR_ARGUMENT; }
+    // streams of one shape (the same HcaInfo) decode together; a batch of all-different lengths is one call per stream --
+    // the decoder's launches carry one frame count (hca_decode_kernels.hip)
+    std::vector<size_t> first_row(nstreams);
+    size_t rows = 0;
+    for (int s = 0; s < nstreams; s++) {
+        if (infos[s].channel_count < 1 || infos[s].channel_count > 8) { set_error("stream %d: bad channel count", s); return VGA_ERR_ARGUMENT; }
+        first_row[s] = rows;
+        rows += (size_t)infos[s].channel_count;
+    }
+    std::vector<char> done(nstreams, 0);
+    for (int s = 0; s < nstreams; s++) {
+        if (done[s]) continue;
+        std::vector<const uint8_t *> fr;
+        std::vector<int16_t *> out;
+        for (int t = s; t < nstreams; t++)
+            if (!done[t] && memcmp(&infos[t], &infos[s], sizeof(vga_hca_info)) == 0) {
+                done[t] = 1;
+                fr.push_back(frames[t]);
+                for (int c = 0; c < infos[t].channel_count; c++) out.push_back(pcm_out[first_row[t] + c]);
+            }
+        if (int rc = vga_hca_decode_batch(&infos[s], fr.data(), (int)fr.size(), out.data())) return rc;
+    }
+    return VGA_OK;
 }
 
 }  // extern "C"

@@ -1,5 +1,6 @@
 // host_batch.hpp -- glue between the host-pointer entry points of the C ABI and host_pipeline.hpp.
 #pragma once
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 #include "common.hpp"
@@ -172,6 +173,50 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
         return r.code;
     }
     return VGA_OK;
+}
+
+// ---------------------------------------------------------------- ragged calls by length buckets
+// The `_v` entry points of codecs whose kernels take one length per launch (ADX, HCA): units are sorted by (parameter
+// group, length) and cut into chunks whose lengths differ by at most a quarter; a chunk's rows are zero-padded on the
+// device to the chunk's longest and the kernels run once per chunk.  Every unit's output is the prefix it would get alone:
+// the encoders are causal (a frame depends on the samples up to its end and on the frames before it) and the
+// reference pads a last partial frame with zeros itself (CriAdxCodec.cs:78-91; CriHcaEncoder.cs:234-240).
+struct BucketPlan {
+    std::vector<int> order;          // position -> the caller's unit
+    std::vector<int> chunk_begin;    // positions: chunk k = [chunk_begin[k], chunk_begin[k + 1])
+    std::vector<int> chunk_length;   // the chunk's largest length
+    std::vector<int> chunk_group;    // the chunk's parameter group
+    int chunk_of(int first) const { return (int)(std::upper_bound(chunk_begin.begin(), chunk_begin.end(), first) - chunk_begin.begin()) - 1; }
+};
+// group[i]: units of different groups never share a chunk; max_units / max_volume (sum of padded lengths) bound a chunk
+inline BucketPlan plan_buckets(const std::vector<int> &group, const std::vector<int> &length, int max_units, int64_t max_volume)
+{
+    BucketPlan b;
+    const int n = (int)group.size();
+    b.order.resize(n);
+    for (int i = 0; i < n; i++) b.order[i] = i;
+    std::stable_sort(b.order.begin(), b.order.end(), [&](int x, int y) {
+        return group[x] != group[y] ? group[x] < group[y] : length[x] < length[y];
+    });
+    const PipeOverride &o = pipe_override();
+    if (o.chunk_units > 0) max_units = o.chunk_units;
+    int first = 0;
+    for (int i = 0; i <= n; i++) {
+        bool cut = i == n;
+        if (!cut && i > first) {
+            const int u = b.order[i], f = b.order[first];
+            cut = group[u] != group[f] || (int64_t)length[u] > (int64_t)length[f] + length[f] / 4 + 1024 || i - first >= max_units ||
+                  (int64_t)(i - first + 1) * std::max(length[u], 1) > max_volume;
+        }
+        if (cut && i > first) {
+            b.chunk_begin.push_back(first);
+            b.chunk_length.push_back(length[b.order[i - 1]]);
+            b.chunk_group.push_back(group[b.order[first]]);
+            first = i;
+        }
+    }
+    b.chunk_begin.push_back(n);
+    return b;
 }
 
 }  // namespace vga

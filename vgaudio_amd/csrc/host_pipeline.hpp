@@ -419,8 +419,13 @@ inline Result run(const Job &job)
                 double tb = now();
                 t_wait += tb - ta;
                 char *slot = ring + (size_t)s * gin.slot_cap;
-                for (int i = 0; i < n; i++)
-                    if (in_size(r + i)) std::memcpy(slot + (in_off(r + i) - in_off(r)), job.in_rows[r + i], in_size(r + i));
+                for (int i = 0; i < n; i++) {
+                    const size_t at = in_off(r + i) - in_off(r);
+                    if (in_size(r + i)) std::memcpy(slot + at, job.in_rows[r + i], in_size(r + i));
+                    // ragged rows: the slot travels as one copy, gaps included -- what lies between two rows on the device
+                    // (padding the kernels may rely on being zero) must not receive the slot's previous contents
+                    if (job.in_row_sizes && i + 1 < n) std::memset(slot + at + in_size(r + i), 0, in_off(r + i + 1) - in_off(r) - at - in_size(r + i));
+                }
                 ta = now();
                 t_copy += ta - tb;
                 const size_t bytes = in_off(r + n - 1) - in_off(r) + in_size(r + n - 1);
