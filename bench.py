@@ -712,7 +712,7 @@ def run_gc(args, cx):
             traffic = round(pmc["gc_encode_kernel"]["traffic_bytes_per_launch"])
         except KeyError:
             pass
-    # What actually binds the kernel: wave-instruction issue.  From the committed SQ counter pass.
+    # What actually binds the kernel (LABNOTES.md 4.1): wave-instruction issue.  From the committed SQ counter pass.
     issue = None
     sqj, sq_note = load_profile_json("gc", "r03_sq_counters.json", "r02_b_sq_counters.json")
     if sqj and full:
@@ -965,7 +965,7 @@ def run_hca(args, cx):
                 "other_kernels": {"hca_scan_kernel + hca_frames_kernel (decode)": {
                     "launch_ms": round(dec_ms, 3),
                     "achieved": round(bytes_launch / (dec_ms * 1e-3) / 1e9, 2) if dec_ms > 0 else 0.0}},
-                "mfma": "the exact path uses no MFMA: a dense 128x128 DCT-IV reassociates the f64 sums (DESIGN.md 4.4; "
+                "mfma": "the exact path uses no MFMA: a dense 128x128 DCT-IV reassociates the f64 sums (LABNOTES.md 4.4; "
                         "measured variant: tools/bench_hca_mfma.py, profiles/)"}
     cpu, verified = None, 0
     if not args.no_cpu_baseline and cx.world == 1:

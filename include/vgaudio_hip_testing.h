@@ -10,7 +10,7 @@ extern "C" {
 #endif
 
 /* GC-ADPCM encode/decode and ADX encode/decode cut long channels into time segments that run side by side and
- * close the seams afterwards.  mode = 1: calls made FROM THE CALLING THREAD never accept a seam
+ * close the seams afterwards (LABNOTES.md 4.3).  mode = 1: calls made FROM THE CALLING THREAD never accept a seam
  * as closed; 2: only the even seams of every third channel are kept open (a mix of open and closed seams inside
  * one workgroup); 0: normal operation.  The serial fall-backs then produce the output, which must not change.
  * The setting is thread-local (no other thread's calls see it) and is passed to the kernels as a launch argument.

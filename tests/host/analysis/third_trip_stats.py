@@ -1,5 +1,5 @@
 """Analysis, not a test: on the bench's synthetic channels, how often does a predictor that needs a third quantise pass
-(GcAdpcmEncoder.cs:127-170) win the frame (:66-76)?  Numbers in DESIGN.md section 6, item 1.
+(GcAdpcmEncoder.cs:127-170) win the frame (:66-76)?  Numbers in LABNOTES.md section 6, item 1.
     python tests/host/analysis/third_trip_stats.py"""
 import os, subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -166,7 +166,7 @@ def test_config4_hca_1024_stereo_streams():
 
 def test_time_segment_fallbacks_are_exact():
     """GC decode and ADX encode/decode cut long channels into time pieces decoded side by side from a guessed history
-    and close the seams afterwards.  With the test hook no seam is ever accepted as closed, so the
+    and close the seams afterwards (LABNOTES.md 4.3).  With the test hook no seam is ever accepted as closed, so the
     fall-back paths (serial redo of the rest of the channel) produce the output: it must not change."""
     d = torch.device("cuda:0")
     L = _lib.lib()

@@ -1,5 +1,5 @@
 """How do the GC-ADPCM kernels' times scale with the number of channels?  (Few channels are cut into time pieces that
-run side by side; BASELINE configs[0] is 1 channel x 480 000 samples, configs[1] 4096 x 2 880 000.)"""
+run side by side, LABNOTES.md 4.3; BASELINE configs[0] is 1 channel x 480 000 samples, configs[1] 4096 x 2 880 000.)"""
 import sys, torch, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vgaudio_amd import device as vdev

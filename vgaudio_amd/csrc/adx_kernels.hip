@@ -235,7 +235,7 @@ __device__ __forceinline__ void adx_load32(const int16_t *src, int64_t first, in
 // samples out): 100 KB of LDS per 64 channels, so one workgroup per CU, four pieces per channel at 4096 channels and a
 // quarter of the SIMDs busy -- 15.1 ms at configs[2].  This kernel: 8.0 ms, of which the recurrence is free: a build that
 // skips it takes 7.7 ms: the kernel is bound by its stores -- 23.6 GB at 3.0 TB/s, 43 % of what a plain fill reaches on
-// this box (tools/bench_fill.py): 65 536 slow sequential streams, one per channel and piece.
+// this box (tools/bench_fill.py): 65 536 slow sequential streams, one per channel and piece (LABNOTES.md 4.3).
 constexpr int ADX_DECODE_WARM_FRAMES = 512;           // even: a piece's frames keep their alignment
 template <bool V4>
 __global__ __launch_bounds__(64) void adx_decode_fs18_direct_kernel(

@@ -594,7 +594,7 @@ int download_adpcm(GcBatch &b, uint8_t *const *adpcm_out, int nch, int nbytes)
 
 }  // namespace
 
-// Channels per pipeline chunk (host path): small enough that the first kernels start after a quarter
+// Channels per pipeline chunk (LABNOTES.md 5, host path): small enough that the first kernels start after a quarter
 // of configs[1] has arrived, large enough that the coefficient kernel (one wave per channel) still has a wave per SIMD.
 static constexpr int GC_CHUNK_CHANNELS = 1024;
 

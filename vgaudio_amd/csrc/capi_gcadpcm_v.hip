@@ -11,6 +11,7 @@
 #include "host_batch.hpp"
 
 #include <algorithm>
+#include <cstring>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -30,6 +31,12 @@ struct RaggedShape {
     int64_t total_frames = 0, records = 0;     // records: slots of the coefficient workspace (an empty channel owns one)
     bool uniform = false;                      // every channel the same length: the equal-length kernels apply
     int64_t pcm_pitch = 0, adpcm_pitch = 0;    // ... with these pitches
+    // the encoder's plan (gc::plan_encode_pieces) and, for persistent workgroups, its items biggest first: the queue then
+    // ends with the short ones (a channel's partial last piece, the pieces of short files) and little is left to wait for
+    gc::Pieces seg;
+    int segments = 1;
+    bool persistent = false;
+    std::vector<uint32_t> items;
 
     // lengths[0 .. count); the rows start at pcm_base (samples) / adpcm_base (bytes) and follow each other, every row
     // rounded up to 8 samples / 16 bytes
@@ -64,9 +71,32 @@ struct RaggedShape {
         }
         if (pcm_end) *pcm_end = pcm_base;
         if (adpcm_end) *adpcm_end = adpcm_base;
+        items.clear();
+        if (n > 0 && !uniform && max_length > 0) {
+            const int groups = (n + 15) / 16;
+            std::vector<int> gframes(groups);
+            int64_t group_frames = 0;
+            for (int g = 0; g < groups; g++) {
+                gframes[g] = (length[order[g * 16]] + 13) / 14;                   // slot 0 of a group holds its longest channel
+                group_frames += gframes[g];
+            }
+            segments = gc::plan_encode_pieces(groups, (max_length + 13) / 14, group_frames, true, &persistent, &seg);
+            if (persistent && groups < (1 << 20) && segments <= 4096) {
+                struct Item { int size, y, g; };
+                std::vector<Item> list;
+                for (int y = 0; y < segments; y++)
+                    for (int g = 0; g < groups; g++)
+                        if (seg.first(y) < gframes[g])
+                            list.push_back({(int)std::min<int64_t>(seg.frames(y), gframes[g] - seg.first(y)), y, g});
+                std::stable_sort(list.begin(), list.end(), [](const Item &a, const Item &b) { return a.size > b.size; });
+                items.reserve(list.size());
+                for (const Item &it : list) items.push_back(((uint32_t)it.y << 20) | (uint32_t)it.g);
+            } else
+                persistent = false;
+        }
     }
     // bytes of the device image of the tables: order, length (int32), then pcm_off, adpcm_off, rec_off (int64)
-    size_t table_bytes() const { return (size_t)round_up((int64_t)count * 8, 16) + (size_t)count * 24; }
+    size_t table_bytes() const { return (size_t)round_up((int64_t)count * 8, 16) + (size_t)count * 24 + items.size() * 4; }
     void write_tables(unsigned char *host) const
     {
         int *o = reinterpret_cast<int *>(host);
@@ -79,6 +109,7 @@ struct RaggedShape {
             p[count + c] = adpcm_off[c];
             p[2 * count + c] = rec_off[c];
         }
+        if (!items.empty()) memcpy(p + 3 * (size_t)count, items.data(), items.size() * 4);
     }
     gc::Ragged device_view(const unsigned char *dev) const
     {
@@ -90,6 +121,13 @@ struct RaggedShape {
         r.rec_off = r.pcm_off + 2 * count;
         r.max_length = max_length;
         r.total_frames = total_frames;
+        if (!items.empty()) {
+            r.items = reinterpret_cast<const uint32_t *>(r.pcm_off + 3 * (size_t)count);
+            r.n_items = (int)items.size();
+            r.segments = segments;
+            r.persistent = persistent ? 1 : 0;
+            r.seg = seg;
+        }
         return r;
     }
 };

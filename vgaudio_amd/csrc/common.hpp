@@ -216,7 +216,7 @@ __device__ __forceinline__ void lds_barrier()
 // fails loudly when no gfx950 device is present: there is no CPU fallback.
 int require_device();
 
-// compute units of the current device (256 on an MI355X): how many time pieces fill the chip
+// compute units of the current device (256 on an MI355X): how many time pieces fill the chip (LABNOTES.md 4.3)
 inline int device_cu_count()
 {
     int device = 0, cus = 256;

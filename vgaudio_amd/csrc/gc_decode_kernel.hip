@@ -8,7 +8,7 @@
 // open.  Rounds 1-2 split the work between a serial wave and three helper waves through LDS tiles (the helpers unpacked
 // scale * nibble + 1024 and wrote the samples out); the tiles' 108 KB per 128 channels limited a CU to one workgroup and
 // 4096 channels to eight pieces.  The kernel below needs no helpers: 9.9 -> 8.1 ms at configs[1] -- bound by its stores,
-// 3 TB/s -- and 4.4 -> 1.2 ms for 256 channels.
+// 3 TB/s (LABNOTES.md 4.3) -- and 4.4 -> 1.2 ms for 256 channels.
 #include "common.hpp"
 
 #include <algorithm>

@@ -7,7 +7,7 @@
 // Reference: VGAudio/Codecs/GcAdpcm/GcAdpcmEncoder.cs:96-171 (DspEncodeCoef).
 //
 // Three exact reformulations of the reference's arithmetic are used; each is proven in
-// DESIGN.md "GC-ADPCM encode: exact shortcuts" and exercised exhaustively by the tests:
+// LABNOTES.md 4.1 ("GC-ADPCM encode: exact shortcuts") and exercised exhaustively by the tests:
 //  (S1) pre-scan (:107-124): the signed maxDistance only needs max(d), min(d) over the
 //       frame unless +M and -M both occur (rare; sequential rescan then), and the
 //       halving loop has a closed form in clz().

@@ -6,7 +6,7 @@
 // ADPCM is a serial recurrence inside a channel (the reconstructed samples 12,13 of frame
 // k are the history of frame k+1, :40-41; sample s+1 needs reconstructed sample s, :138,160),
 // so time = frames x (wave-instructions per frame): the kernel is bound by VALU issue (one
-// instruction per 4 cycles per SIMD for this mix), not by HBM.
+// instruction per 4 cycles per SIMD for this mix; LABNOTES.md 4.0), not by HBM.
 //
 //  * lane = (channel, predictor, scale candidate): 16 lanes per channel, 4 channels per
 //    encoder wave; a helper wave per workgroup prepares 16-frame tiles in LDS (below).
@@ -81,21 +81,13 @@ extern "C" int vga_debug_encode_timestamps(unsigned long long *out, int n)
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vga_enc_ts), (size_t)n * sizeof(unsigned long long));
 }
 #endif
-// Where the time pieces of a channel begin: `nb` pieces of `big` frames, then pieces of `small` frames.  The persistent
-// workgroups take items piece-major, so the pieces with the highest indices are the last items of the launch: short ones
-// there leave little to wait for when the queue runs dry (a plain grid uses one size: nb = every piece).
-struct Pieces {
-    int big, nb, small;
-    __host__ __device__ int64_t first(int k) const { return (int64_t)(k < nb ? k : nb) * big + (int64_t)(k > nb ? k - nb : 0) * small; }
-    __host__ __device__ int frames(int k) const { return k < nb ? big : small; }
-};
 constexpr int SW = 2;              // encoder (serial) waves per workgroup; one helper wave serves them all
 constexpr int ENC_THREADS = 64 * (SW + 1);
 // Two lane layouts of the encoder wave (template parameter CPW = channels per encoder wave):
 //   CPW = 4: lane = (channel, predictor, scale candidate A/B) -- the candidates of the retry loop run side by side;
 //   CPW = 8: lane = (channel, predictor) -- candidate B (s1 + 1) and candidate A (s1) run one after the other in the
 //            same lane.  Twice the channels share every per-frame fixed cost (row reads, pre-scan, resolution,
-//            argmin, the cold block's pass), which is worth more than the second pass costs: DESIGN.md 4.1.
+//            argmin, the cold block's pass), which is worth more than the second pass costs: LABNOTES.md 4.1.
 template <int CPW>
 struct Lay {
     static constexpr int CS = CPW * SW;    // channel slots per workgroup
@@ -184,7 +176,7 @@ ColdOut encode_frame_cold(ColdState st, PassOut r, int final_sp, int fin)
     return o;
 }
 
-// Time segments (blockIdx.y): with fewer channels than fill the chip, a channel's stream is cut into
+// Time segments (blockIdx.y; LABNOTES.md 4.3): with fewer channels than fill the chip, a channel's stream is cut into
 // pieces of `seg_frames` frames encoded side by side.  Piece 0 starts from the caller's history, the others from a
 // guess -- the two INPUT samples before the piece -- and gc_encode_seam_kernel closes the seams afterwards.
 // seg_state[piece][channel] receives every piece's final history.  At BASELINE configs[1] there is one piece.
@@ -522,7 +514,11 @@ __device__ __forceinline__ void gc_encode_piece(
         const bool rare = !coef_ok || (unsigned)ra.max_overflow > (cap_a ? 3u : 248u) || (unsigned)rb.max_overflow > (cap_b ? 3u : 248u);
         const int eff_a = cap_a ? 0 : ra.max_overflow, eff_b = cap_b ? 0 : rb.max_overflow;
         const bool fin_a = eff_a < 2;                              // the reference stops after the pass at s1
+#ifdef VGA_GC_ABLATE_THIRD_TRIPS                                     // timing only (tools/build_variants.sh): what the cold block costs
+        const bool resume = false;
+#else
         const bool resume = !fin_a && eff_b >= 2;                  // both overflowed: on to s1 + 2 in the cold block
+#endif
         PassOut r;
 #pragma unroll
         for (int i = 0; i < 14; i++) r.q[i] = fin_a ? ra.q[i] : rb.q[i];
@@ -907,7 +903,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     constexpr int CS = Lay<CPW>::CS;
     __shared__ int s_item;
     __shared__ int s_seam[2];
-    const int items = groups * segments;
+    const int items = RAGGED && rg.items ? rg.n_items : groups * segments;
 #ifdef VGA_DEBUG_TIMESTAMPS
     if (threadIdx.x == 0) g_vga_enc_ts[2 * (blockIdx.x & 32767)] = wall_clock64();
 #endif
@@ -922,7 +918,12 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
 #endif
             return;
         }
-        const int g = item % groups, y = item / groups;
+        int g = item % groups, y = item / groups;      // piece-major ...
+        if (RAGGED && rg.items) {                      // ... or the host's list: biggest items first
+            const uint32_t v = rg.items[item];
+            g = (int)(v & 0xFFFFFu);
+            y = (int)(v >> 20);
+        }
         gc_encode_piece<false, CPW, RAGGED>(g, y, pcm, pcm_pitch, nch, total_samples, seg, coefs, hist1, hist2, adpcm, adpcm_pitch,
                                             seg_state, (const int *)nullptr, rg);
         if (segments <= 1) continue;
@@ -1052,6 +1053,64 @@ constexpr int PERSISTENT_BIG_ROUNDS = 3;       // a workgroup's share of the fra
 constexpr int PERSISTENT_SMALL_ROUNDS = 2;     // ... followed by this many rounds of short items
 constexpr int PERSISTENT_SMALL_FRAMES = 4096;  // ... of this many frames
 
+// The piece schedule (see Pieces, gcadpcm_kernels.hpp).  Plain grid: as many equal pieces as put two encoder waves on
+// every SIMD, each at least MIN_PIECE_FRAMES long.  Persistent workgroups: a workgroup's share of the frames in
+// PERSISTENT_BIG_ROUNDS big items followed by PERSISTENT_SMALL_ROUNDS rounds of short ones -- with items of one size d
+// the workgroups end spread over the last d of the launch (152 ms at configs[1] with 16 pieces of 35 ms: mean life
+// 136 ms + d / 2).
+int plan_encode_pieces(int groups, int frames, int64_t group_frames, bool ragged, bool *persistent_out, Pieces *seg_out)
+{
+    constexpr int CS = 16;
+    const int cus = device_cu_count();
+    // persistent workgroups taking (channel group, piece) items from a queue (gc_encode_persistent_kernel) once the batch
+    // has enough channel groups; test hook: 1 = never, 2 = always
+    const int pmode = encoder_persistent_mode();
+    const bool persistent = encoder_layout() != 4 && (pmode == 2 || (pmode == 0 && (ragged || groups * PERSISTENT_MIN_GROUPS_FACTOR >= cus * 4)));
+    int segments = cus * 4 / (groups > 0 ? groups : 1);   // = SW encoder waves on every SIMD
+    if (persistent) segments = (cus * 4 * PERSISTENT_ITEMS_PER_WORKGROUP + groups - 1) / groups;
+    if (ragged) {
+        // pieces of total / (items wanted) frames for every channel; `segments` = what the longest channel needs
+        const int64_t want = (int64_t)cus * 4 * (persistent ? PERSISTENT_ITEMS_PER_WORKGROUP : RAGGED_OVERSUBSCRIPTION);
+        int64_t piece = (group_frames + want - 1) / want;
+        if (piece < MIN_PIECE_FRAMES) piece = MIN_PIECE_FRAMES;
+        segments = (int)((frames + piece - 1) / piece);
+    }
+    if (segments > frames / MIN_PIECE_FRAMES) segments = frames / MIN_PIECE_FRAMES;
+    if (segments < 1) segments = 1;
+    if (segments > 1024) segments = 1024;
+    if (encoder_segments_override() > 0) segments = imin(imax(frames / 64, 1), encoder_segments_override());   // test hook
+    Pieces seg;
+    seg.big = (frames + segments - 1) / segments;
+    seg.nb = segments;
+    seg.small = seg.big;
+    if (persistent && encoder_segments_override() <= 0 && frames >= 4 * MIN_PIECE_FRAMES) {
+        // (ragged batches, mixed-lengths set of bench.py: 4 rounds 151.7 ms, 3: 158.2, 6: 154.5, 8: 169.5; profiles/r04_a_ragged_schedules.log)
+        int big_rounds = ragged ? PERSISTENT_BIG_ROUNDS + 1 : PERSISTENT_BIG_ROUNDS, small_rounds = PERSISTENT_SMALL_ROUNDS, small = PERSISTENT_SMALL_FRAMES;
+        if (const char *e = std::getenv("VGA_HIP_GC_SCHEDULE")) std::sscanf(e, "%d,%d,%d", &big_rounds, &small_rounds, &small);   // tuning (tools/)
+        small = imax(small, MIN_PIECE_FRAMES);
+        big_rounds = imax(big_rounds, 1);
+        const int wgs = cus * 4;
+        const int64_t per_wg = group_frames / wgs + 1;                                      // a workgroup's share of the frames
+        int ns = (small_rounds * wgs + groups / 2) / groups;                                // piece indices that make small_rounds rounds of items
+        if ((int64_t)ns * small > frames / 2) ns = frames / (2 * small);
+        int big = (int)imax((int)((per_wg - (int64_t)small_rounds * small) / big_rounds), small);
+        int nb = (int)((frames - (int64_t)ns * small + big - 1) / big);
+        if (nb < 1) nb = 1;
+        if (!ragged) big = (int)((frames - (int64_t)ns * small + nb - 1) / nb);             // equal big pieces
+        if (big < small) big = small;
+        seg.big = big;
+        seg.nb = nb;
+        seg.small = small;
+        segments = nb + ns;
+        while (segments > 1 && seg.first(segments - 1) >= frames) segments--;
+        if (segments > 1024) segments = 1024;
+    }
+    (void)CS;
+    *persistent_out = persistent;
+    *seg_out = seg;
+    return segments;
+}
+
 template <int CPW, bool RAGGED>
 static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_count, const int16_t *d_coefs,
                                 const int16_t *d_hist1, const int16_t *d_hist2, uint8_t *d_adpcm, int64_t adpcm_pitch,
@@ -1066,52 +1125,17 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
     const int groups = (nch + CS - 1) / CS;
     const int cus = device_cu_count();
     const int frames = (sample_count + 13) / 14;
-    // persistent workgroups taking (channel group, piece) items from a queue (gc_encode_persistent_kernel) once the batch
-    // has more items than the chip holds workgroups; test hook: 1 = never, 2 = always
-    const int pmode = encoder_persistent_mode();
-    const bool persistent = CPW == 8 && (pmode == 2 || (pmode == 0 && (RAGGED || groups * PERSISTENT_MIN_GROUPS_FACTOR >= cus * 4)));
-    int segments = cus * 4 / groups;                   // = SW encoder waves on every SIMD
-    if (persistent) segments = (cus * 4 * PERSISTENT_ITEMS_PER_WORKGROUP + groups - 1) / groups;
-    if (RAGGED) {
-        // pieces of total / (items wanted) frames for every channel; `segments` = what the longest channel needs
-        const int64_t want = (int64_t)cus * 4 * (persistent ? PERSISTENT_ITEMS_PER_WORKGROUP : RAGGED_OVERSUBSCRIPTION);
-        int64_t piece = (rg.total_frames + CS * want - 1) / (CS * want);
-        if (piece < MIN_PIECE_FRAMES) piece = MIN_PIECE_FRAMES;
-        segments = (int)((frames + piece - 1) / piece);
-    }
-    if (segments > frames / MIN_PIECE_FRAMES) segments = frames / MIN_PIECE_FRAMES;
-    if (segments < 1) segments = 1;
-    if (segments > 1024) segments = 1024;
-    if (encoder_segments_override() > 0) segments = imin(imax(frames / 64, 1), encoder_segments_override());   // test hook
+    // the piece schedule: planned by the host for ragged batches (with the item list), here otherwise
+    bool persistent = false;
     Pieces seg;
-    seg.big = (frames + segments - 1) / segments;
-    seg.nb = segments;
-    seg.small = seg.big;
-    if (persistent && encoder_segments_override() <= 0 && frames >= 4 * MIN_PIECE_FRAMES) {
-        // Items leave the queue piece-major; with items of one size d the workgroups end spread over the last d of the
-        // launch (152 ms at configs[1] with 16 pieces of 35 ms: mean life 136 ms + d / 2).  So: big pieces first, and
-        // enough short ones (the shortest a seam can still close in) at the end to take up the spread the big ones leave.
-        int big_rounds = PERSISTENT_BIG_ROUNDS, small_rounds = PERSISTENT_SMALL_ROUNDS, small = PERSISTENT_SMALL_FRAMES;
-        if (const char *e = std::getenv("VGA_HIP_GC_SCHEDULE")) std::sscanf(e, "%d,%d,%d", &big_rounds, &small_rounds, &small);   // tuning (tools/)
-        small = imax(small, MIN_PIECE_FRAMES);
-        big_rounds = imax(big_rounds, 1);
-        const int wgs = cus * 4;
-        // a workgroup's share of the frames (in units of a channel group's frames): small_rounds short items at the end, the
-        // rest in big_rounds items
-        const int64_t per_wg = (RAGGED ? rg.total_frames / CS : (int64_t)groups * frames) / wgs + 1;
-        int ns = (small_rounds * wgs + groups / 2) / groups;                                // piece indices that make small_rounds rounds of items
-        if ((int64_t)ns * small > frames / 2) ns = frames / (2 * small);
-        int big = (int)imax((int)((per_wg - (int64_t)small_rounds * small) / big_rounds), small);
-        int nb = (int)((frames - (int64_t)ns * small + big - 1) / big);
-        if (nb < 1) nb = 1;
-        if (!RAGGED) big = (int)((frames - (int64_t)ns * small + nb - 1) / nb);             // equal big pieces
-        if (big < small) big = small;
-        seg.big = big;
-        seg.nb = nb;
-        seg.small = small;
-        segments = nb + ns;
-        while (segments > 1 && seg.first(segments - 1) >= frames) segments--;
-        if (segments > 1024) { segments = 1024; }
+    int segments;
+    if (RAGGED && rg.items) {
+        persistent = rg.persistent != 0;
+        seg = rg.seg;
+        segments = rg.segments;
+    } else {
+        segments = plan_encode_pieces(groups, frames, RAGGED ? rg.total_frames / CS : (int64_t)groups * frames, RAGGED, &persistent, &seg);
+        if (CPW != 8) persistent = false;              // (the persistent kernel's seams use the (channel, predictor) layout)
     }
     AsyncBuf scratch;                                  // freed (stream-ordered) on every exit path
     int16_t *seg_state = nullptr;
@@ -1141,7 +1165,7 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
         if (persistent) VGA_HIP_TRY(hipMemsetAsync(queue, 0, 16 + count_bytes, stream));    // the queue's head and every seam's counter
     }
     if (persistent) {
-        const int items = groups * segments;
+        const int items = RAGGED && rg.items ? rg.n_items : groups * segments;
         const int wgs = imin(items, cus * 4);
         if constexpr (CPW == 8)
             hipLaunchKernelGGL((gc_encode_persistent_kernel<CPW, RAGGED>), dim3(wgs), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch,

@@ -12,7 +12,24 @@ namespace gc {
 // workspace + rec_off[c].  Work slots (workgroup / wave / lane indices) map to channels through `order`, longest channel
 // first: the slots that share a wave or a workgroup then hold channels of similar length and the long ones start first.
 // The kernels take the struct by value; order == nullptr means "uniform batch" (rows `pitch` apart, one length).
+// Where the time pieces of a channel begin (gc_encode_kernel.hip): `nb` pieces of `big` frames, then pieces of `small`
+// frames.  The persistent encoder workgroups take their items in an order that ends with the short ones, so that little
+// is left to wait for when the queue runs dry (a plain grid uses one size: nb = every piece).
+struct Pieces {
+    int big = 0, nb = 0, small = 0;
+    __host__ __device__ int64_t first(int k) const { return (int64_t)(k < nb ? k : nb) * big + (int64_t)(k > nb ? k - nb : 0) * small; }
+    __host__ __device__ int frames(int k) const { return k < nb ? big : small; }
+};
+// The encoder's piece schedule for `groups` channel groups (16 channels each) whose longest channel has `frames` frames and
+// which hold `group_frames` frames of work in all (sum over groups of the group's longest channel); persistent = workgroups
+// that take (group, piece) items from a queue.  Returns the number of pieces the longest channel has.
+int plan_encode_pieces(int groups, int frames, int64_t group_frames, bool ragged, bool *persistent, Pieces *seg);
+
 struct Ragged {
+    // the encoder's items (channel group | piece << 20), biggest first, when the host has planned them (ragged batches)
+    const uint32_t *items = nullptr;
+    int n_items = 0, segments = 0, persistent = 0;
+    Pieces seg;
     const int *order = nullptr;         // [nch] work slot -> channel
     const int *length = nullptr;        // [nch] samples
     const int64_t *pcm_off = nullptr;   // [nch]

@@ -8,7 +8,7 @@
 // 0), CriHcaDecoder.cs:83-192 (DequantizeFrame, RestoreMissingBands, RunImdct, PcmFloatToShort),
 // Utilities/Mdct.cs:94-181 (RunImdct, Dct4).
 //
-// The decoder is two launches:
+// The decoder is two launches (LABNOTES.md 4.4):
 //   scan   : lane = frame.  The frame is variable-length coded, so WHERE a symbol starts is a serial walk -- but only its
 //            LENGTH is needed for that.  The scan reads the frame header (scale factors, intensity / HFR scales) and
 //            then walks the 8 x nch x count spectral codes length-only, noting the bit offset of every 16th symbol.
