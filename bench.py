@@ -705,35 +705,46 @@ def run_gc(args, cx):
     verified = 0
     enc_bytes = ENC_BYTES_PER_SAMPLE * nch * n
     full = nch == 4096 and n == 2880000
-    pmc, pmc_note = load_profile_json("gc", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
+    pmc, pmc_note = load_profile_json("gc", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
     traffic = None
+    enc_key = "gc_encode_persistent_kernel"            # from 2048 channels on (gc_encode_kernel.hip); the plain grid below
     if pmc and full:
         try:
-            traffic = round(pmc["gc_encode_kernel"]["traffic_bytes_per_launch"])
+            if enc_key not in pmc:
+                enc_key = "gc_encode_kernel"
+            traffic = round(pmc[enc_key]["traffic_bytes_per_launch"])
         except KeyError:
             pass
     # What actually binds the kernel (LABNOTES.md 4.1): wave-instruction issue.  From the committed SQ counter pass.
     issue = None
-    sqj, sq_note = load_profile_json("gc", "r03_sq_counters.json", "r02_b_sq_counters.json")
+    sqj, sq_note = load_profile_json("gc", "r04_sq_counters.json", "r03_sq_counters.json", "r02_b_sq_counters.json")
     if sqj and full:
         try:
-            sq = sqj["gc_encode_kernel"]
-            clk_quads = sq["SQ_WAVE_CYCLES"] / sq["SQ_WAVES"]          # every wave lives the whole launch
+            sq = sqj[enc_key if enc_key in sqj else "gc_encode_kernel"]
+            # the clock of the profiled launch: SQ_BUSY_CYCLES is summed over the 32 shader engines, each busy for the whole
+            # launch.  (Rounds 1-3 divided by the waves' mean lifetime instead -- SQ_WAVE_CYCLES / SQ_WAVES -- which reads
+            # as "the clock" only if every wave lives the whole launch; in the plain grid workgroups ended between 106 and
+            # 162 ms, so that figure, 0.92, was the issue fraction of a wave's lifetime, not of the launch: 0.79.)
+            clock_ghz = sq["SQ_BUSY_CYCLES"] / 32 / (sq["_dur_ms"] * 1e6)
+            quads = sq["_dur_ms"] * 1e6 * clock_ghz / 4                # issue slots of one SIMD over the launch
             issue = {"valu_wave_instructions_per_launch": round(sq["SQ_INSTS_VALU"]),
-                     "valu_issue_frac": round(sq["SQ_ACTIVE_INST_VALU"] / (1024 * clk_quads), 3),
-                     "profiled_launch_ms": round(sq["_dur_ms"], 1),
-                     "clock_GHz_seen_by_the_waves": round(4 * clk_quads / (sq["_dur_ms"] * 1e6), 2),
-                     "note": "1024 SIMDs x one wave-instruction per 4 cycles at that clock; profiled launch, not this run"}
+                     "valu_issue_frac": round(sq["SQ_ACTIVE_INST_VALU"] / (1024 * quads), 3),
+                     "valu_issue_frac_of_the_waves_lifetime": round(sq["SQ_ACTIVE_INST_VALU"] / (1024 * sq["SQ_WAVE_CYCLES"] / sq["SQ_WAVES"]), 3),
+                     "profiled_launch_ms": round(sq["_dur_ms"], 1), "clock_GHz": round(clock_ghz, 2),
+                     "note": "SQ_ACTIVE_INST_VALU (quad-cycles) / (1024 SIMDs x launch cycles / 4); profiled launch, not this run"}
         except (KeyError, ZeroDivisionError):
             pass
     achieved = enc_bytes / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
-    # one encode = gc_encode_kernel<false> (all time pieces at once) + gc_encode_seam_kernel + gc_encode_chain_kernel +
-    # gc_encode_kernel<true> (chain and repair return at once unless a seam stayed open); launch_ms spans the four, the rocprofv3
-    # kernel stats under profiles/ list them separately (their averages add up to it)
-    roofline = {"bound": "hbm", "kernel": "gc_encode_kernel", "achieved": round(achieved, 2),
+    # one encode = gc_encode_persistent_kernel (time pieces from a queue, seams closed inside; below 2048 channels:
+    # gc_encode_kernel<false> + gc_encode_seam_kernel) + gc_encode_chain_kernel + gc_encode_kernel<true> (chain and repair
+    # return at once unless a seam stayed open); launch_ms spans them, the rocprofv3 kernel stats under profiles/ list them
+    # separately (their averages add up to it)
+    persistent = nch >= 2048
+    roofline = {"bound": "hbm", "kernel": "gc_encode_persistent_kernel" if persistent else "gc_encode_kernel", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "traffic_source": pmc_note, "algorithmic_bytes_per_launch": enc_bytes, "launch_ms": round(enc_ms, 3),
-                "launch_parts": ["gc_encode_kernel<false>", "gc_encode_seam_kernel", "gc_encode_chain_kernel", "gc_encode_kernel<true>"],
+                "launch_parts": (["gc_encode_persistent_kernel (pieces from a queue, seams inside)"] if persistent else
+                                 ["gc_encode_kernel<false>", "gc_encode_seam_kernel"]) + ["gc_encode_chain_kernel", "gc_encode_kernel<true>"],
                 "other_kernels": {"gc_coefs_kernel": {
                     "launch_ms": round(coef_ms, 3),
                     "achieved": round(COEF_BYTES_PER_SAMPLE * nch * n / (coef_ms * 1e-3) / 1e9, 2) if coef_ms > 0 else 0.0},
@@ -845,7 +856,7 @@ def run_adx(args, cx):
         return None
     bytes_launch = ADX_BYTES_PER_SAMPLE * nch * n
     achieved = bytes_launch / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
-    pmc, pmc_note = load_profile_json("adx", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
+    pmc, pmc_note = load_profile_json("adx", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
     traffic = None
     if pmc and nch == 4096 and n == 2880000:
         traffic = (pmc.get("adx_encode_fs18_tiled_kernel") or {}).get("traffic_bytes_per_launch")
@@ -955,7 +966,7 @@ def run_hca(args, cx):
         return None
     bytes_launch = (2.0 + info.frame_size * info.frame_count / (2.0 * n)) * chs if n else 0.0
     achieved = bytes_launch / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
-    pmc, pmc_note = load_profile_json("hca", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
+    pmc, pmc_note = load_profile_json("hca", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
     traffic = None
     if pmc and ns == 1024 and n == 2880000:
         traffic = (pmc.get("hca_encode_kernel") or {}).get("traffic_bytes_per_launch")

@@ -364,3 +364,28 @@ def test_hca_ragged_streams_match_the_oracle_per_stream():
         for c in range(infos[s].channel_count):
             assert pcm_out[at][-1] == 0x7777 and np.array_equal(pcm_out[at][:-1], dec[c]), (s, c)
             at += 1
+
+
+def test_adx_and_hca_files_of_different_shapes_in_one_call():
+    """the host mirrors of Batch.cs for the other two codecs: the per-file classes must return the same formats"""
+    from vgaudio_amd import criadx, crihca
+    rng = np.random.default_rng(77)
+    files = []
+    for f in range(8):
+        n = int(rng.integers(2000, 50_000))
+        k = int(rng.integers(1, 3))
+        p = Pcm16Format(list(po.synth_generate(k, n, first_channel=30 * f)), sampleRate=(48000, 44100, 32000)[f % 3])
+        if f == 5:
+            p.WithLoop(True, 1234, n - 500)
+        files.append(p)
+    got = criadx.encode_files(files, [criadx.CriAdxParameters(Version=3) if f % 4 == 3 else None for f in range(len(files))])
+    for f, (pcm16, g) in enumerate(zip(files, got)):
+        want = criadx.CriAdxFormat().EncodeFromPcm16(pcm16, criadx.CriAdxParameters(Version=3) if f % 4 == 3 else None)
+        assert (g.SampleRate, g.AlignmentSamples, g.Version, g.Looping) == (want.SampleRate, want.AlignmentSamples, want.Version, want.Looping)
+        for a, b in zip(g.Channels, want.Channels):
+            assert np.array_equal(a.Audio, b.Audio) and a.History == b.History, f
+    got = crihca.encode_files(files)
+    for f, (pcm16, g) in enumerate(zip(files, got)):
+        want = crihca.CriHcaFormat().EncodeFromPcm16(pcm16)
+        assert g.Hca.FrameCount == want.Hca.FrameCount and g.Hca.Looping == want.Hca.Looping
+        assert np.array_equal(g.AudioData, want.AudioData), f

@@ -171,3 +171,38 @@ def test_reference_nontermination_hazard_is_guarded_and_flagged():
     for _ in range(20):                               # |c| <= 16383: the predictor cannot wrap
         po.gc_encode(noise, rng.integers(-16383, 16384, 16).astype(np.int16))
         assert not po.gc_last_encode_hit_nontermination()
+
+
+def test_c_generator_of_the_bench_pcm_equals_its_definition():
+    """oracle/synth_oracle.c (fast enough to generate all of configs[4] for the whole-shard digests) against
+    vgaudio_amd/synth.py, the generator's definition: lengths around the noise window, high channel numbers"""
+    from vgaudio_amd import synth
+    for first, nch, n in ((0, 3, 5000), (95, 2, 14 * 300 + 5), (4095, 2, 777), (32767, 1, 20000), (1 << 20, 2, 3), (7, 1, 0)):
+        want = synth.generate(nch, n, first_channel=first)
+        got = po.synth_generate(nch, n, first_channel=first, threads=2)
+        assert np.array_equal(want, got), (first, nch, n)
+
+
+def test_whole_shard_oracle_digests_are_the_oracles():
+    """tests/golden/gc_shard_oracle_digests.json + gc_channel_oracle_digests.npy: written by the oracle for all 32 768
+    channels of configs[4] (95 core-minutes); here two channels are encoded again and must reproduce their digests, and the
+    file must agree with what a GPU wrote in round 3 (tests/golden/gc_shard_digests.json)"""
+    import json
+    import os
+    import torch
+    from vgaudio_amd import distributed as vdist
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    gold = json.load(open(os.path.join(gold_dir, "gc_shard_oracle_digests.json")))
+    assert gold["provenance"] == "oracle" and gold["channels_per_shard"] == 4096 and len(gold["shards"]) == 8
+    gpu = json.load(open(os.path.join(gold_dir, "gc_shard_digests.json")))
+    assert gold["shards"] == gpu["shards"] and gold["bytes_per_row"] == gpu["bytes_per_row"]
+    per_channel = np.load(os.path.join(gold_dir, "gc_channel_oracle_digests.npy"))
+    assert per_channel.shape == (32768,) and per_channel.dtype == np.uint64
+    n, nb = gold["samples_per_channel"], gold["bytes_per_row"]
+    for ch in (0, 20000):
+        pcm = po.synth_generate(1, n, first_channel=ch)
+        coefs, adpcm = po.gc_encode_batch(pcm)
+        rows = torch.zeros((1, (nb + 15) // 16 * 16), dtype=torch.uint8)
+        rows[0, :nb] = torch.from_numpy(np.ascontiguousarray(adpcm[0]))
+        inner = vdist.row_digests(rows, nb, torch.from_numpy(np.asarray(coefs).reshape(1, 16)))
+        assert int(inner.numpy().view(np.uint64)[0]) == int(per_channel[ch]), ch

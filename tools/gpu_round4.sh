@@ -19,6 +19,9 @@ fi
 if has pieces; then
   timeout 600 python tools/time_encode_pieces.py --channels 4096 --pieces 0 4 6 8 12 16 > $O/encode_pieces_4096.log 2>&1; echo "pieces rc=$?"; cat $O/encode_pieces_4096.log
 fi
+if has channels; then
+  timeout 900 python tools/time_encode_channels.py > $O/channel_scaling.log 2>&1; echo "channels rc=$?"; grep -v amdgpu $O/channel_scaling.log
+fi
 if has coefsvariants; then
   timeout 600 python tools/time_coefs_variants.py --channels 4096 1024 256 1 > $O/coefs_variants.log 2>&1; echo "coefs variants rc=$?"; cat $O/coefs_variants.log
 fi

@@ -164,6 +164,49 @@ class CriAdxFormat:
         return out
 
 
+def encode_files(pcm16_list, configs=None):
+    """CriAdxFormat.EncodeFromPcm16 (CriAdxFormat.cs:57-88) of many files -- any lengths, channel counts, sample rates and
+    parameters -- in ONE ragged GPU call (vga_adx_encode_batch_v): the reference's Batch.cs runs a worker per file
+    (VGAudio.Cli/Batch.cs:24-25).  Returns one CriAdxFormat per file, each what CriAdxFormat().EncodeFromPcm16(file, config)
+    returns."""
+    files = list(pcm16_list)
+    configs = [c or CriAdxParameters() for c in (configs if configs is not None else [None] * len(files))]
+    chans, lens, per, align = [], [], [], []
+    for f, cfg in zip(files, configs):
+        spf = (cfg.FrameSize - 2) * 2
+        multiple = spf * 2 if f.ChannelCount == 1 else spf
+        loop_start = f.LoopStart if f.Looping else 0
+        a = _get_next_multiple(loop_start, multiple) - loop_start                              # CriAdxFormat.cs:59-62
+        align.append(a)
+        for ch in f.Channels:
+            chans.append(ch)
+            lens.append(f.SampleCount)
+            per.append(CriAdxParameters(SampleRate=f.SampleRate, FrameSize=cfg.FrameSize, Padding=a, Filter=cfg.Filter,
+                                        Type=cfg.Type, Version=cfg.Version)._c())
+    nch = len(chans)
+    L = _lib.lib()
+    params = (_lib.AdxParams * max(nch, 1))(*per)
+    counts = np.array(lens, dtype=np.int32)
+    outs = []
+    for c in range(nch):
+        nb = L.vga_adx_encoded_byte_count(int(counts[c]), C.byref(params[c]))
+        if nb < 0:
+            check(nb)
+        outs.append(np.zeros(nb, dtype=np.uint8))
+    hist = np.zeros(max(nch, 1), dtype=np.int16)
+    if nch:
+        check(L.vga_adx_encode_batch_v(_ptr_array(i16p, chans), counts.ctypes.data_as(C.POINTER(C.c_int)), nch, params,
+                                       _ptr_array(u8p, outs), _i16(hist)))
+    result, at = [], 0
+    for f, cfg, a in zip(files, configs, align):
+        k = f.ChannelCount
+        cs = [CriAdxChannel(outs[at + i], int(hist[at + i]), cfg.Version) for i in range(k)]
+        result.append(CriAdxFormat(cs, f.SampleCount, f.SampleRate, cfg.FrameSize, 500, a, cfg.Type, cfg.Version, f.Looping,
+                                   f.LoopStart, f.LoopEnd))
+        at += k
+    return result
+
+
 class CriAdxKey:
     """Codecs/CriAdx/CriAdxKey.cs:10-56: CriAdxKey(seed, mult, inc) | CriAdxKey(keyCode) | CriAdxKey(keyString)."""
 

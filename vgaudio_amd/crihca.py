@@ -153,6 +153,33 @@ class CriHcaFormat:
         return Pcm16Format(pcm, self.Hca.SampleRate)
 
 
+def encode_files(pcm16_list, configs=None):
+    """CriHcaFormat.EncodeFromPcm16 (CriHcaFormat.cs:34-84) of many files of any shape in ONE ragged GPU call
+    (vga_hca_encode_batch_v); the reference encodes one file per worker (VGAudio.Cli/Batch.cs:24-25).  Returns one
+    CriHcaFormat per file."""
+    files = list(pcm16_list)
+    configs = [c or CriHcaParameters() for c in (configs if configs is not None else [None] * len(files))]
+    ns = len(files)
+    cps = (_lib.HcaParamsC * max(ns, 1))()
+    for s_, (f, cfg) in enumerate(zip(files, configs)):
+        cfg.ChannelCount, cfg.SampleRate, cfg.SampleCount = f.ChannelCount, f.SampleRate, f.SampleCount     # :36-41
+        cfg.Looping, cfg.LoopStart, cfg.LoopEnd = f.Looping, f.LoopStart, f.LoopEnd
+        cps[s_] = cfg._c()
+    infos = (_lib.HcaInfoC * max(ns, 1))()
+    L = _lib.lib()
+    for s_ in range(ns):
+        check(L.vga_hca_encoder_initialize(C.byref(cps[s_]), C.byref(infos[s_])))                             # sizes the outputs
+    outs = [np.zeros(infos[s_].frame_count * infos[s_].frame_size, dtype=np.uint8) for s_ in range(ns)]
+    chans = [c for f in files for c in f.Channels]
+    if ns:
+        check(L.vga_hca_encode_batch_v(_ptr_array(i16p, chans), ns, cps, infos, _ptr_array(u8p, outs)))
+    result = []
+    for s_ in range(ns):
+        info = _lib.HcaInfoC.from_buffer_copy(infos[s_])
+        result.append(CriHcaFormat(outs[s_].reshape(info.frame_count, info.frame_size), HcaInfo(info)))
+    return result
+
+
 class CriHcaKey:
     """Codecs/CriHca/CriHcaKey.cs:8-39: CriHcaKey(keyCode) (KeyType 56) | CriHcaKey.Type0 / Type1."""
     Type0, Type1 = "Type0", "Type1"

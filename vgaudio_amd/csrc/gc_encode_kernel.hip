@@ -1038,16 +1038,22 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
 // ~3000 frames (profiles/r03_b_encode_pieces.log: 96 channels x 60 s in 20.9 ms with 64 pieces of 3214 frames, 60.8 ms
 // with 128, 150 ms with 256; without such a channel more pieces only help: 64 channels 6.7 / 5.5 / 4.0 ms).  Round 2 cut
 // pieces down to 512 frames.
-constexpr int MIN_PIECE_FRAMES = 3072;
+// (3072 until round 4: at 128 channels that made 66 pieces of 3117 frames and the slow channel's seams stayed open -- 33.5 ms
+// against 21.2 ms with 64 pieces of 3215)
+constexpr int MIN_PIECE_FRAMES = 3584;
 
 // Ragged batches cut their channels into pieces of ONE length (a channel has as many as it reaches into); with a few
 // times more workgroups than the chip holds at once, the ones that end early (short channels, short last pieces) make
 // room for the rest instead of leaving their SIMDs idle.
 constexpr int RAGGED_OVERSUBSCRIPTION = 4;
-// Persistent workgroups from this many channel groups per eight workgroups on (2048 channels on an MI355X): below, a channel
-// has to be cut into so many pieces to fill the queue that its seams cost more than the balance gains (1024 channels: 46-62 ms
-// over the schedules tried against 47 ms for the plain grid; 2048: 79-98 against 89; profiles/r04_a_encode_schedules.log)
-constexpr int PERSISTENT_MIN_GROUPS_FACTOR = 8;
+// Persistent workgroups from one channel group per 32 workgroups on (512 channels on an MI355X): 512 channels 30.3 ms
+// against 34.1 for the plain grid with the same 32 pieces, 1024 channels 42.9 against 47.1 (16 pieces) -- the seams run
+// inside instead of in a launch of their own; 256 channels and fewer: no difference or slower (25.0 grid, 26.8 persistent;
+// profiles/r04_a_encode_persistent.log).  The two-size schedule only from one group per 8 workgroups on (2048 channels):
+// below, a channel has to be cut into so many pieces to fill the queue's rounds that its seams cost more than the balance
+// gains (1024 channels: 46-62 ms over the schedules tried; profiles/r04_a_encode_schedules.log).
+constexpr int PERSISTENT_MIN_GROUPS_FACTOR = 32;
+constexpr int PERSISTENT_SCHEDULE_GROUPS_FACTOR = 8;
 constexpr int PERSISTENT_ITEMS_PER_WORKGROUP = 4;      // uniform pieces (the test hook's mode 2 without a schedule): items per workgroup
 constexpr int PERSISTENT_BIG_ROUNDS = 3;       // a workgroup's share of the frames in this many big items ...
 constexpr int PERSISTENT_SMALL_ROUNDS = 2;     // ... followed by this many rounds of short items
@@ -1067,7 +1073,7 @@ int plan_encode_pieces(int groups, int frames, int64_t group_frames, bool ragged
     const int pmode = encoder_persistent_mode();
     const bool persistent = encoder_layout() != 4 && (pmode == 2 || (pmode == 0 && (ragged || groups * PERSISTENT_MIN_GROUPS_FACTOR >= cus * 4)));
     int segments = cus * 4 / (groups > 0 ? groups : 1);   // = SW encoder waves on every SIMD
-    if (persistent) segments = (cus * 4 * PERSISTENT_ITEMS_PER_WORKGROUP + groups - 1) / groups;
+    if (persistent && (pmode == 2 || ragged)) segments = (cus * 4 * PERSISTENT_ITEMS_PER_WORKGROUP + groups - 1) / groups;
     if (ragged) {
         // pieces of total / (items wanted) frames for every channel; `segments` = what the longest channel needs
         const int64_t want = (int64_t)cus * 4 * (persistent ? PERSISTENT_ITEMS_PER_WORKGROUP : RAGGED_OVERSUBSCRIPTION);
@@ -1083,7 +1089,8 @@ int plan_encode_pieces(int groups, int frames, int64_t group_frames, bool ragged
     seg.big = (frames + segments - 1) / segments;
     seg.nb = segments;
     seg.small = seg.big;
-    if (persistent && encoder_segments_override() <= 0 && frames >= 4 * MIN_PIECE_FRAMES) {
+    if (persistent && encoder_segments_override() <= 0 && frames >= 4 * MIN_PIECE_FRAMES &&
+        (ragged || groups * PERSISTENT_SCHEDULE_GROUPS_FACTOR >= cus * 4)) {
         // (ragged batches, mixed-lengths set of bench.py: 4 rounds 151.7 ms, 3: 158.2, 6: 154.5, 8: 169.5; profiles/r04_a_ragged_schedules.log)
         int big_rounds = ragged ? PERSISTENT_BIG_ROUNDS + 1 : PERSISTENT_BIG_ROUNDS, small_rounds = PERSISTENT_SMALL_ROUNDS, small = PERSISTENT_SMALL_FRAMES;
         if (const char *e = std::getenv("VGA_HIP_GC_SCHEDULE")) std::sscanf(e, "%d,%d,%d", &big_rounds, &small_rounds, &small);   // tuning (tools/)
