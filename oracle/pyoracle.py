@@ -131,6 +131,8 @@ def synth_generate(nch, n, first_channel=0, threads=1, out=None):
     L.vgo_synth_generate.restype = None
     if out is None:
         out = np.empty((nch, n), dtype=np.int16)
+    if nch == 0 or n == 0:
+        return out
     assert out.dtype == np.int16 and out.shape[0] >= nch and out.shape[1] >= n and out.strides[1] == 2
     L.vgo_synth_generate(_i16(out), out.strides[0] // 2, nch, n, first_channel, threads)
     return out
