@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--schedules", nargs="+", default=["3,2,4096", "4,2,4096", "6,2,4096", "8,2,4096", "3,4,4096", "6,4,3072", "12,2,4096", "4,0,4096"])
+    ap.add_argument("--with-coefs", action="store_true")
     args = ap.parse_args()
     import torch
     from vgaudio_amd import device as vdev
@@ -30,7 +31,10 @@ def main():
     pcm = coefs = None
     ref = None
     for sch in args.schedules:
-        os.environ["VGA_HIP_GC_SCHEDULE"] = sch
+        if sch == "default":
+            os.environ.pop("VGA_HIP_GC_SCHEDULE", None)
+        else:
+            os.environ["VGA_HIP_GC_SCHEDULE"] = sch
         rb = vdev.GcRaggedBatch(lens, dev)
         if pcm is None:
             pcm = rb.synth(first_channel=1 << 20)
@@ -44,6 +48,15 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         row[sch] = round(e0.elapsed_time(e1) / 3, 2)
+        if args.with_coefs:                              # as bench.py times it: the coefficient kernel before every encode
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+            for k in range(3):
+                rb.coefs(pcm)
+                ev[2 * k].record()
+                rb.encode(pcm, coefs, out=out)
+                ev[2 * k + 1].record()
+            torch.cuda.synchronize()
+            row[sch + " after coefs"] = round(sum(ev[2 * k].elapsed_time(ev[2 * k + 1]) for k in range(3)) / 3, 2)
         h = int(out[:out.numel() // 8 * 8].view(torch.int64).sum().item())
         ref = h if ref is None else ref
         assert h == ref, "the schedule changed the output"
