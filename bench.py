@@ -859,11 +859,11 @@ def run_adx(args, cx):
     pmc, pmc_note = load_profile_json("adx", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
     traffic = None
     if pmc and nch == 4096 and n == 2880000:
-        traffic = (pmc.get("adx_encode_fs18_tiled_kernel") or {}).get("traffic_bytes_per_launch")
-    roofline = {"bound": "hbm", "kernel": "adx_encode_fs18_tiled_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        traffic = (pmc.get("adx_encode_fs18_direct_kernel") or {}).get("traffic_bytes_per_launch")
+    roofline = {"bound": "hbm", "kernel": "adx_encode_fs18_direct_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": pmc_note,
                 "algorithmic_bytes_per_launch": bytes_launch, "launch_ms": round(enc_ms, 3),
-                "launch_parts": ["adx_encode_fs18_tiled_kernel", "adx_encode_fs18_fixup_kernel", "adx_encode_fs18_tail_kernel"],
+                "launch_parts": ["adx_encode_fs18_direct_kernel", "adx_encode_fs18_fixup_kernel", "adx_encode_fs18_tail_kernel"],
                 "other_kernels": {"adx_decode_fs18_direct_kernel (+fixup, tail)": {
                     "launch_ms": round(dec_ms, 3),
                     "achieved": round(bytes_launch / (dec_ms * 1e-3) / 1e9, 2) if dec_ms > 0 else 0.0,

@@ -13,6 +13,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef VGA_ADX_ABLATE
+#define VGA_ADX_ABLATE 0
+#endif
+
 namespace vga {
 namespace adx {
 
@@ -53,6 +57,35 @@ __device__ __forceinline__ int scale_short_to_nibble(int sample)
     const int sign = (sample > 0) - (sample < 0);
     sample = (sample + 2340 * sign) / 4681;     // short.MaxValue/14, short.MaxValue/7
     return clamp4(sample);
+}
+
+// One sample of the quantise recurrence (CriAdxCodec.cs:122-138) for the 18-byte-frame kernels, arranged so that the
+// chain from the newest reconstructed sample `b` to the next one is ten instructions (the encoder wave's rate is what
+// these kernels run at).  Returns u = q + 7 (0..14); (a, b) move on one sample.  Needs |c0|, |c1| <= 16384 (launch_encode
+// checks; the reference's coefficients are at most 8192, CriAdxCodec.cs:173-191).
+//  * rawDistance = (x - (a c1 >> 12)) - (b c0 >> 12) = (((x - (a c1 >> 12)) << 12) + 4095 - b c0) >> 12: subtracting a floor
+//    is adding the ceiling of the negative, and ceil(n / 4096) = floor((n + 4095) / 4096); below 2^31 for such coefficients;
+//  * ScaleShortToNibble (:167-171), truncating division of s + 2340 sign(s) by 4681, is floor((s + 2340) / 4681) for
+//    either sign (-floor((|s| + 2340) / d) = ceil((s - 2340) / d) = floor((s - 2340 + d - 1) / d), d - 1 = 4680); with
+//    t = s + 2340 + 7 * 4681 >= 2339 that is (t * 57346 >> 28) - 7: 57346 * 4681 = 2^28 + 1170, exact while
+//    4680 * 57346 + 1170 k < 2^28 (k = t / 4681 <= 48; here <= 14), and t * 57346 < 2^32.  -7 .. 7: Clamp4 cannot bind, nor
+//    the Clamp16 of scale * q (scale <= 4096);
+//  * the sample is Clamp16(scale * q + predicted) = Clamp16(scale * u + (predicted - 7 scale)).
+template <bool V4, bool GUARD>
+__device__ __forceinline__ int adx_quantise_step(int x, int &a, int &b, int c0, int c1, double gain, int scale, int scale7)
+{
+    const int ac1 = __mul24(a, c1);                          // the older sample's share: ready a step early
+    const int xb = x - (ac1 >> 12);
+    const int k = (xb << 12) + 4095;
+    const int raw = (__mul24(b, -c0) + k) >> 12;
+    const double prod = (double)raw * gain;
+    const int scaled = clamp16(GUARD ? trunc_i32_ryujit(prod) : (int)prod);
+    const unsigned u = (unsigned)(__mul24(scaled, 57346) + 35107 * 57346) >> 28;
+    const int predicted = V4 ? (__mul24(b, c0) + ac1) >> 12 : (__mul24(b, c0) >> 12) + (ac1 >> 12);
+    const int rec = clamp16(__mul24(scale, (int)u) + (predicted - scale7));
+    a = b;
+    b = rec;
+    return (int)u;
 }
 
 // Encode (CriAdxCodec.cs:56-105): the stream the frames are cut from is `padding` untouched
@@ -199,28 +232,6 @@ __global__ __launch_bounds__(64) void adx_decode_kernel(
     }
     for (; current < sample_count; current++) dst[current] = 0;     // `new short[sampleCount]` tail
     if (bad && status) atomicOr(status, 1);
-}
-
-// ---- FrameSize 18 (32 samples), no padding -- BASELINE config 3 and the reference's defaults: one frame's
-// 32 samples as 16 dwords (the tiled encoder's loader)
-__device__ __forceinline__ void adx_load32(const int16_t *src, int64_t first, int pcm_length, uint32_t (&w)[16])
-{
-    if (first + 32 <= pcm_length) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(src + first);       // 64-byte aligned: first % 32 == 0
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint4 v = p[k];
-            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int64_t i0 = first + 2 * k, i1 = i0 + 1;
-            const uint32_t lo = i0 < pcm_length ? (uint16_t)src[i0] : 0u;
-            const uint32_t hi = i1 < pcm_length ? (uint16_t)src[i1] : 0u;
-            w[k] = lo | (hi << 16);
-        }
-    }
 }
 
 // ---------------------------------------------------------------- 18-byte frames: lane = channel, one wave per 64 channels and piece
@@ -414,7 +425,7 @@ __device__ __forceinline__ void adx_decode_frame_serial(const uint8_t *fr, const
     const int hb0 = fr[0], hb1 = fr[1];
     int filter_num = ((hb0 >> 4) & 0xF) >> 1;
     int cf0, cf1;
-    if (p.type == 2) {                                  // as the tiled kernel's `prepare`
+    if (p.type == 2) {                                  // the fixed filters (CriAdxCodec.cs:186-191)
         if (filter_num > 3) filter_num = 3;
         cf0 = filter_num == 0 ? 0 : (filter_num == 1 ? 0x0F00 : (filter_num == 2 ? 0x1CC0 : 0x1880));
         cf1 = filter_num == 0 ? 0 : (filter_num == 1 ? 0 : (filter_num == 2 ? (int)(int16_t)0xF300 : (int)(int16_t)0xF240));
@@ -518,305 +529,231 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_tail_kernel(
     }
 }
 
-// ---------------------------------------------------------------- 18-byte frames, encoder wave + helper waves
-// CriAdxCodec.EncodeFrame (:107-147) with the same division of labour as the decoders: three helper waves load
-// and unpack the 32 samples of every frame one tile ahead, pre-scan the 30 distances that involve input
-// samples only (:112-118; the first two use the reconstructed history) and pack / store the previous tile's
-// nibbles; the encoder wave (lane = channel) keeps the scale computation and the quantise recurrence
-// (:120-138).  scale_short_to_nibble (:167-171) is done on the magnitude: |q| = ((|v| + 2340) * 114692) >> 29 is
-// floor((|v| + 2340) / 4681) for |v| <= 32768 (2^29 / 4681 = 114691.5.., error term 2340 per unit: exact below
-// 229 432), the result is at most 7 so Clamp4 and the Clamp16 of scale * q (scale <= 4096) cannot bind.
-constexpr int EATF = 2;                                // frames per tile (1: 35.5 instead of 27.0 ms at configs[2])
-constexpr int ECW = 128;                               // channels per workgroup: TWO encoder waves (on different SIMDs of the
-                                                       // CU) and six helper waves; the double-buffered tiles fill one CU's LDS
-constexpr int ETHREADS = ECW * 4, EHELPERS = ETHREADS - ECW;
-struct AdxEncodeTile {
-    int4 x[EATF][8][ECW];                                // [frame][eighth][channel]: the 32 input samples
-    int pmax[EATF][ECW];                                 // max |Clamp16(distance)| over samples 2..31
-    int4 q[EATF][8][ECW];                                // encoder output: 32 nibbles (-7..7)
-    int hdr[EATF][ECW];                                  // encoder output: the 16 header bits (scale, filter)
-};
-
-template <bool V4, bool EXPONENTIAL>
-// Time segments (blockIdx.y): every piece of `seg_frames` frames (an even number) but the first is encoded from a
-// guessed history -- the two INPUT samples before it -- and adx_encode_fs18_fixup_kernel closes the seams afterwards.
-// seg_state[segment][channel] receives each piece's final history (two int16).
-__global__ __launch_bounds__(ETHREADS) void adx_encode_fs18_tiled_kernel(
-    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, AdxDeviceParams p,
-    uint8_t *__restrict__ out, int64_t out_pitch, int16_t *__restrict__ history_out, int16_t *__restrict__ seg_state)
+// A frame's 32 input samples as the 16 dwords they are loaded as; sample j sign-extended (one v_bfe_i32 / v_ashrrev, or an
+// SDWA operand, where it is used: 32 unpacked samples are 32 live registers)
+__device__ __forceinline__ int adx_sample(const uint32_t (&xw)[16], int j)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    AdxEncodeTile *s_tile = reinterpret_cast<AdxEncodeTile *>(s_raw);          // [2]
-    const int tid = threadIdx.x;
-    const int ch0 = blockIdx.x * ECW;
-    const int64_t first_frame = (int64_t)blockIdx.y * seg_frames;
-    if (first_frame > 0 && first_frame * 32 >= total_length) return;
-    const int pcm_length = (int)((int64_t)total_length - first_frame * 32 < (int64_t)seg_frames * 32
-                                     ? (int64_t)total_length - first_frame * 32 : (int64_t)seg_frames * 32);
-    pcm += first_frame * 32;
-    out += first_frame * 18;
-    const int frame_count = (pcm_length + 31) / 32;
-    const int tiles = (frame_count + EATF - 1) / EATF;
-    const int c0 = p.coef0, c1 = p.coef1;
-
-    if (tid >= ECW) {
-        // ------------------------------------------------------------ helper waves (192 lanes)
-        const int hl = tid - ECW;
-        constexpr int ITEMS = (ECW * EATF + EHELPERS - 1) / EHELPERS;
-        struct Raw { uint4 v[4]; };
-        auto load_tile = [&](int tile, Raw (&raw)[ITEMS]) {          // unconditional loads, clamped frame index
-#pragma unroll
-            for (int k = 0; k < ITEMS; k++) {
-                const int item = min(hl + EHELPERS * k, ECW * EATF - 1);
-                const int c = item / EATF, j = item - c * EATF;
-                // the last frame may be partial: clamp to the last FULL frame (re-read below if needed)
-                const int i = min(tile * EATF + j, max(pcm_length / 32 - 1, 0));
-                const int ch = min(ch0 + c, nch - 1);
-                const uint4 *src = reinterpret_cast<const uint4 *>(pcm + (int64_t)ch * pcm_pitch + (int64_t)i * 32);
-                if (pcm_length < 32) {                  // no full frame at all: nothing to prefetch (uniform)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) raw[k].v[q] = make_uint4(0, 0, 0, 0);
-                    continue;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) raw[k].v[q] = src[q];
-            }
-        };
-        auto prepare = [&](int tile, const Raw (&raw)[ITEMS]) {
-            AdxEncodeTile &T = s_tile[tile & 1];
-#pragma unroll
-            for (int k = 0; k < ITEMS; k++) {
-                const int item = hl + EHELPERS * k;
-                if (item >= ECW * EATF) continue;
-                const int c = item / EATF, j = item - c * EATF;
-                const int i = tile * EATF + j;
-                if (i >= frame_count) continue;
-                uint32_t w[16];
-                if ((int64_t)i * 32 + 32 <= pcm_length) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        w[4 * q] = raw[k].v[q].x; w[4 * q + 1] = raw[k].v[q].y; w[4 * q + 2] = raw[k].v[q].z; w[4 * q + 3] = raw[k].v[q].w;
-                    }
-                } else {                               // zero-padded last frame
-                    const int ch = min(ch0 + c, nch - 1);
-                    adx_load32(pcm + (int64_t)ch * pcm_pitch, (int64_t)i * 32, pcm_length, w);
-                }
-                int x[32];
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    x[2 * q] = (int)(int16_t)(w[q] & 0xFFFF);
-                    x[2 * q + 1] = (int)w[q] >> 16;
-                }
-                int pm = 0;
-#pragma unroll
-                for (int s = 2; s < 32; s++) {         // history = the two input samples before (:112-118)
-                    const int predicted = ((x[s - 1] * c0) >> 12) + ((x[s - 2] * c1) >> 12);
-                    int distance = clamp16(x[s] - predicted);
-                    distance = distance < 0 ? -distance : distance;
-                    pm = max(pm, distance);
-                }
-                T.pmax[j][c] = pm;
-#pragma unroll
-                for (int q = 0; q < 8; q++) T.x[j][q][c] = make_int4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
-            }
-        };
-        auto flush = [&](int tile) {
-            const AdxEncodeTile &T = s_tile[tile & 1];
-            for (int item = hl; item < ECW * EATF; item += EHELPERS) {
-                const int c = item / EATF, j = item - c * EATF;
-                const int i = tile * EATF + j;
-                if (i >= frame_count || ch0 + c >= nch) continue;
-                uint32_t bytes[5] = {(uint32_t)T.hdr[j][c], 0, 0, 0, 0};       // 18 bytes + 2 spare
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int4 v = T.q[j][q][c];
-                    const int qq[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int s = 4 * q + e;
-                        const int byte_index = 2 + (s >> 1);
-                        bytes[byte_index >> 2] |= (uint32_t)(qq[e] & 0xF) << (8 * (byte_index & 3) + ((s & 1) ? 0 : 4));
-                    }
-                }
-                uint16_t *f = reinterpret_cast<uint16_t *>(out + (int64_t)(ch0 + c) * out_pitch) + (int64_t)i * 9;
-                if ((i & 1) == 0) {                    // 36*k bytes: dword aligned
-                    uint32_t *f32 = reinterpret_cast<uint32_t *>(f);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) f32[q] = bytes[q];
-                    f[8] = (uint16_t)bytes[4];
-                } else {                               // 2 bytes past a dword boundary
-                    f[0] = (uint16_t)bytes[0];
-                    uint32_t *f32 = reinterpret_cast<uint32_t *>(f + 1);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) f32[q] = (bytes[q] >> 16) | (bytes[q + 1] << 16);
-                }
-            }
-        };
-        Raw ra[ITEMS], rb[ITEMS];
-        load_tile(0, ra);
-        load_tile(1, rb);
-        if (tiles > 0) prepare(0, ra);
-        lds_barrier();
-        for (int tile = 0; tile < tiles; tile += 2) {
-            load_tile(tile + 2, ra);
-            if (tile + 1 < tiles) prepare(tile + 1, rb);
-            if (tile > 0) flush(tile - 1);
-            lds_barrier();
-            if (tile + 1 < tiles) {
-                load_tile(tile + 3, rb);
-                if (tile + 2 < tiles) prepare(tile + 2, ra);
-                flush(tile);
-                lds_barrier();
-            }
-        }
-        if (tiles > 0) flush(tiles - 1);
-        return;
-    }
-
-    // ---------------------------------------------------------------- encoder wave: lane = channel
-    __builtin_amdgcn_s_setprio(3);
-    const int ch = min(ch0 + tid, nch - 1);
-    const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
-    const double raw_bound = 32770.0 + 8.0 * (double)((c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1));
-    int h0 = 0, h1 = 0, hist = p.history;             // h1 = the newer sample
-    if (blockIdx.y > 0) {                              // the guess: the input just before this piece
-        h0 = pcm[(int64_t)ch * pcm_pitch - 2];
-        h1 = pcm[(int64_t)ch * pcm_pitch - 1];
-    } else {
-        if (V4 && pcm_length > 0) { h0 = h1 = pcm[(int64_t)ch * pcm_pitch]; hist = h0; }      // :69-74
-        if (history_out && ch0 + tid < nch) history_out[ch] = (int16_t)hist;
-    }
-
-    lds_barrier();                                     // tile 0 prepared
-    for (int tile = 0; tile < tiles; tile++) {
-        AdxEncodeTile &T = s_tile[tile & 1];
-        const int nf = min(EATF, frame_count - tile * EATF);
-#pragma unroll 1
-        for (int j = 0; j < nf; j++) {
-            int x[32];
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int4 v = T.x[j][q][tid];
-                x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
-            }
-            // pre-scan (:112-118): the helpers' maximum + the two distances that see the reconstructed history
-            int max_distance = T.pmax[j][tid];
-            {
-                int d0 = clamp16(x[0] - (((h1 * c0) >> 12) + ((h0 * c1) >> 12)));
-                int d1 = clamp16(x[1] - (((x[0] * c0) >> 12) + ((h1 * c1) >> 12)));
-                d0 = d0 < 0 ? -d0 : d0;
-                d1 = d1 < 0 ? -d1 : d1;
-                max_distance = max(max_distance, max(d0, d1));
-            }
-            double gain;
-            int scale_out;
-            const int scale = calculate_scale(max_distance, EXPONENTIAL, gain, scale_out);
-            T.hdr[j][tid] = (((scale_out >> 8) & 0x1f) | filter_bits) | ((scale_out & 0xff) << 8);     // :140-141, :95
-            int a = h0, b = h1, qv[32];
-            auto quantise = [&](auto guard_c) __attribute__((always_inline)) {
-                constexpr bool GUARD = decltype(guard_c)::value;
-#pragma unroll
-                for (int s = 0; s < 32; s++) {         // :122-138
-                    const int pb = (__mul24(a, c1)) >> 12;           // older sample: ready a step early
-                    const int pa = (__mul24(b, c0)) >> 12;
-                    const int raw = (x[s] - pb) - pa;
-                    const double prod = (double)raw * gain;
-                    const int scaled = clamp16(GUARD ? trunc_i32_ryujit(prod) : (int)prod);
-                    const int sm = scaled >> 31;                      // scale_short_to_nibble on the magnitude
-                    const unsigned mag = (unsigned)((scaled ^ sm) - sm);
-                    const int aq = (int)((mag * 114692u + 2340u * 114692u) >> 29);
-                    const int q = (aq ^ sm) - sm;
-                    const int predicted = V4 ? (__mul24(b, c0) + __mul24(a, c1)) >> 12 : pa + pb;
-                    const int rec = clamp16(__mul24(scale, q) + predicted);
-                    a = b;
-                    b = rec;
-                    qv[s] = q;
-                }
-            };
-            // |rawDistance| <= 32768 + 8 (|c0| + |c1|): only a frame whose gain can push that past 2^31 needs the
-            // RyuJIT overflow semantics of the cast (a wave-uniform, practically never taken branch)
-            if (__any(gain * raw_bound >= 2147483648.0)) quantise(std::true_type{});
-            else quantise(std::false_type{});
-            h0 = a;
-            h1 = b;
-#pragma unroll
-            for (int q = 0; q < 8; q++) T.q[j][q][tid] = make_int4(qv[4 * q], qv[4 * q + 1], qv[4 * q + 2], qv[4 * q + 3]);
-        }
-        lds_barrier();
-    }
-    if (seg_state && ch0 + tid < nch) {
-        int16_t *st = seg_state + ((int64_t)blockIdx.y * nch + ch) * 2;
-        st[0] = (int16_t)h0;
-        st[1] = (int16_t)h1;
-    }
+    return (j & 1) ? (int)xw[j >> 1] >> 16 : (int)(int16_t)(xw[j >> 1] & 0xFFFFu);
 }
 
-// One frame of CriAdxCodec.EncodeFrame (:107-147) from the history (a, b); maths as adx_encode_kernel.
-// The frame leaves as nine 16-bit words (low byte = the earlier byte of the frame).
-template <bool V4, bool EXPONENTIAL>
-__device__ __forceinline__ void adx_encode_frame_words(const int (&x)[32], int &a, int &b, int c0, int c1, int filter_bits,
-                                                       uint32_t (&fw)[9])
+// The pre-scan (CriAdxCodec.cs:112-118) of the 30 distances whose history is input only (samples 2..31): max |Clamp16(d)|
+// from the two signed extremes (clamp and magnitude are monotone on either side of zero: two instructions per sample
+// less than clamping each).  The encoder's pieces leave it in their crumbs, the seam runs take it from there.
+__device__ __forceinline__ int adx_prescan30(const uint32_t (&xw)[16], int c0, int c1)
 {
-    int max_distance = 0;
-    {
-        int pa = a, pb = b;
+    int hi = 0, lo = 0;
 #pragma unroll
-        for (int j = 0; j < 32; j++) {
-            const int predicted = (__mul24(pb, c0) >> 12) + (__mul24(pa, c1) >> 12);     // 16-bit x 16-bit: exact in 24 bits
-            int distance = clamp16(x[j] - predicted);
-            distance = distance < 0 ? -distance : distance;
-            max_distance = max(max_distance, distance);
-            pa = pb;
-            pb = x[j];
-        }
+    for (int j = 2; j < 32; j++) {
+        // 16-bit x 16-bit: exact in 24 bits
+        const int d = (adx_sample(xw, j) - (__mul24(adx_sample(xw, j - 1), c0) >> 12)) - (__mul24(adx_sample(xw, j - 2), c1) >> 12);
+        hi = max(hi, d);
+        lo = min(lo, d);
+    }
+    return max(clamp16(hi), -clamp16(lo));
+}
+
+// One frame of CriAdxCodec.EncodeFrame (:107-147) from the history (a, b); maths as adx_encode_kernel.  pm30 = adx_prescan30(xw).
+// The frame leaves as its 16 header bits (low byte = the frame's first byte) and four dwords of nibbles in memory order
+// (frame bytes 2..17: eight samples a dword, the first sample in the high nibble of the lowest byte).
+template <bool V4, bool EXPONENTIAL>
+__device__ __forceinline__ void adx_encode_frame_packed(const uint32_t (&xw)[16], int &a, int &b, int c0, int c1, int filter_bits, int pm30,
+                                                        uint32_t &hdr, uint32_t (&nib)[4])
+{
+    int max_distance;
+    {                                                    // the two distances that see the reconstructed history
+        const int x0 = adx_sample(xw, 0), x1 = adx_sample(xw, 1);
+        const int d0 = (x0 - (__mul24(b, c0) >> 12)) - (__mul24(a, c1) >> 12);
+        const int d1 = (x1 - (__mul24(x0, c0) >> 12)) - (__mul24(b, c1) >> 12);
+        max_distance = max(max(clamp16(max(d0, d1)), -clamp16(min(d0, d1))), pm30);
     }
     double gain;
     int scale_out;
     const int scale = calculate_scale(max_distance, EXPONENTIAL, gain, scale_out);
-    fw[0] = (uint32_t)((((scale_out >> 8) & 0x1f) | filter_bits) & 0xff) | ((uint32_t)(scale_out & 0xff) << 8);
-    // the quantise recurrence (:122-138) as the tiled kernel has it: 24-bit multiplies, ScaleShortToNibble on the magnitude
-    // (see there), and the RyuJIT overflow semantics of the cast only for a frame whose gain can push rawDistance past 2^31
-    // (a wave-uniform, practically never taken branch)
-    int qv[32];
+    hdr = (uint32_t)((((scale_out >> 8) & 0x1f) | filter_bits) & 0xff) | ((uint32_t)(scale_out & 0xff) << 8);
+    // the quantise recurrence (:122-138) (adx_quantise_step), and the RyuJIT overflow semantics of the cast only for a frame
+    // whose gain can push rawDistance past 2^31 (a wave-uniform, practically never taken branch).  Eight samples' u = q + 7
+    // are gathered into a dword a nibble at a time (u <= 14: no carries), first sample on top; the nibble of q is
+    // (u + 9) mod 16 = (u + 1) ^ 8 -- one add and one xor for all eight -- and memory order wants the bytes reversed.
+    const int scale7 = 7 * scale;
     auto quantise = [&](auto guard_c) __attribute__((always_inline)) {
         constexpr bool GUARD = decltype(guard_c)::value;
 #pragma unroll
-        for (int j = 0; j < 32; j++) {
-            const int pb = __mul24(a, c1) >> 12;
-            const int pa = __mul24(b, c0) >> 12;
-            const int raw = (x[j] - pb) - pa;
-            const double prod = (double)raw * gain;
-            const int scaled = clamp16(GUARD ? trunc_i32_ryujit(prod) : (int)prod);
-            const int sm = scaled >> 31;
-            const unsigned mag = (unsigned)((scaled ^ sm) - sm);
-            const int aq = (int)((mag * 114692u + 2340u * 114692u) >> 29);
-            const int q = (aq ^ sm) - sm;
-            const int predicted = V4 ? (__mul24(b, c0) + __mul24(a, c1)) >> 12 : pa + pb;
-            const int rec = clamp16(__mul24(scale, q) + predicted);
-            a = b;
-            b = rec;
-            qv[j] = q;
+        for (int w = 0; w < 4; w++) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int j = 8 * w; j < 8 * w + 8; j++)
+                acc = (acc << 4) + (uint32_t)adx_quantise_step<V4, GUARD>(adx_sample(xw, j), a, b, c0, c1, gain, scale, scale7);
+            nib[w] = __builtin_bswap32((acc + 0x11111111u) ^ 0x88888888u);
         }
     };
     const double raw_bound = 32770.0 + 8.0 * (double)((c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1));
     if (__any(gain * raw_bound >= 2147483648.0)) quantise(std::true_type{});
     else quantise(std::false_type{});
-#pragma unroll
-    for (int w = 0; w < 8; w++)                  // frame bytes 2 + 2w, 3 + 2w: four nibbles, high first
-        fw[1 + w] = (uint32_t)(((qv[4 * w] & 0xF) << 4) | (qv[4 * w + 1] & 0xF)) |
-                    ((uint32_t)(((qv[4 * w + 2] & 0xF) << 4) | (qv[4 * w + 3] & 0xF)) << 8);
 }
 
+// The same as nine 16-bit words (low byte = the earlier byte of the frame): for the seam runs' 16-bit stores.
 template <bool V4, bool EXPONENTIAL>
-__device__ __forceinline__ void adx_encode_frame_serial(const int (&x)[32], int &a, int &b, int c0, int c1, int filter_bits,
-                                                        uint8_t *fr)
+__device__ __forceinline__ void adx_encode_frame_words(const uint32_t (&xw)[16], int &a, int &b, int c0, int c1, int filter_bits, int pm30,
+                                                       uint32_t (&fw)[9])
 {
-    uint32_t fw[9];
-    adx_encode_frame_words<V4, EXPONENTIAL>(x, a, b, c0, c1, filter_bits, fw);
+    uint32_t nib[4];
+    adx_encode_frame_packed<V4, EXPONENTIAL>(xw, a, b, c0, c1, filter_bits, pm30, fw[0], nib);
 #pragma unroll
-    for (int i = 0; i < 9; i++) {
-        fr[2 * i] = (uint8_t)(fw[i] & 0xff);
-        fr[2 * i + 1] = (uint8_t)(fw[i] >> 8);
+    for (int w = 0; w < 4; w++) {
+        fw[1 + 2 * w] = nib[w] & 0xFFFFu;
+        fw[2 + 2 * w] = nib[w] >> 16;
+    }
+}
+
+// A frame with fewer than 32 samples left (zero padded, :86-91), or any frame a sample at a time
+__device__ __forceinline__ void adx_load_frame_slow(const int16_t *src, int64_t f, int total_length, uint32_t (&xw)[16])
+{
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int64_t i0 = f * 32 + 2 * j;
+        const uint32_t lo = i0 < total_length ? (uint16_t)src[i0] : 0u, hi = i0 + 1 < total_length ? (uint16_t)src[i0 + 1] : 0u;
+        xw[j] = lo | (hi << 16);
+    }
+}
+
+// ---------------------------------------------------------------- 18-byte frames: lane = channel, one wave per 64 channels and piece
+// CriAdxCodec.Encode / EncodeFrame (:56-147) for the common shape, one wave on its own (no helper waves, no LDS, no barrier).
+// Time segments (blockIdx.y), as the decoder above has them: every piece but the first starts from a guessed history -- the
+// two INPUT samples before it -- and adx_encode_fs18_fixup_kernel closes the seams afterwards; seg_state[piece][channel] gets
+// each piece's final history.  A lane reads its own frames (two at a time: a 128-byte line, the next pair's loads in flight
+// during this one) and writes eight frames at a time (144 bytes from a dword boundary).
+// Every frame costs the same, so a plain grid with as many waves as the chip holds is balanced: the wave's ~900
+// instructions per frame (pre-scan 8 per sample, adx_quantise_step 18) are what it runs at -- configs[2]: 12.1 ms with 32
+// pieces per channel, 84 % of the VALU issue slots, 23.6 GB fetched and 10.8 GB written (9.6 GB with the crumbs;
+// tools/pmc_adx_encode.sh).  The tiled kernel of rounds 2-4 -- one encoder wave and three helper waves per 64 channels, the
+// tiles in LDS, hence two encoder waves per CU -- took 19.7 ms, 17.5 ms with this file's arithmetic.
+// Crumbs: 8 bytes per frame and channel in a scratch array [frame][channel] -- what a seam run needs to know about the
+// guessed run it replaces (see adx_encode_seam_crumbs).
+typedef uint32_t adx_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+template <bool V4, bool EXPONENTIAL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void adx_encode_fs18_direct_kernel(
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, AdxDeviceParams p,
+    uint8_t *__restrict__ out, int64_t out_pitch, int16_t *__restrict__ history_out, int16_t *__restrict__ seg_state,
+    uint2 *__restrict__ crumbs)
+{
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    const int k = blockIdx.y;
+    const int64_t f0 = (int64_t)k * seg_frames;
+    if (ch >= nch || (k > 0 && f0 * 32 >= total_length)) return;
+    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
+    uint8_t *dst = out + (int64_t)ch * out_pitch;
+    const int c0 = p.coef0, c1 = p.coef1;
+    const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
+    int a = 0, b = 0;
+    if (k > 0) {                                       // the guess: the input just before this piece
+        a = src[f0 * 32 - 2];
+        b = src[f0 * 32 - 1];
+    } else {
+        int hist = p.history;
+        if (V4 && total_length > 0) { a = b = src[0]; hist = a; }                      // :69-74
+        if (history_out) history_out[ch] = (int16_t)hist;
+    }
+    const int64_t frames = ((int64_t)total_length + 31) / 32, full_frames = total_length / 32;
+    const int64_t fe = f0 + seg_frames < frames ? f0 + seg_frames : frames;
+    // Two frames (one 128-byte line of the lane's row) are loaded together, the pair after them in flight meanwhile: the
+    // halves of a line loaded a frame apart did not survive in the L1 between the two (30.5 GB fetched for 23.6).
+    auto fetch2 = [&](int64_t f, uint4 (&px)[8]) {     // unconditional, clamped to the last full frames
+        const int64_t fc = f + 1 < full_frames ? f : (full_frames >= 2 ? full_frames - 2 : 0);
+        if (full_frames >= 2) {
+            const uint4 *q = reinterpret_cast<const uint4 *>(src + fc * 32);
+#pragma unroll
+            for (int i = 0; i < 8; i++) px[i] = q[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) px[i] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto encode_x = [&](int64_t f, const uint32_t (&xw)[16], uint32_t &hdr, uint32_t (&nib)[4]) {
+#if VGA_ADX_ABLATE & 4                                  // (timing-only builds: tools/build_variants.sh)
+        const int pm30 = (int)(xw[5] & 0x7FFFu);
+#else
+        const int pm30 = adx_prescan30(xw, c0, c1);
+#endif
+        adx_encode_frame_packed<V4, EXPONENTIAL>(xw, a, b, c0, c1, filter_bits, pm30, hdr, nib);
+        // the crumb of this frame, for the seam that may run over it: the history this run leaves it with and the part
+        // of the pre-scan that does not depend on any history (a wave's 64 crumbs are 512 contiguous bytes)
+#if !(VGA_ADX_ABLATE & 3)
+        if (crumbs && k > 0) crumbs[f * nch + ch] = make_uint2(((uint32_t)a & 0xFFFFu) | ((uint32_t)b << 16), (uint32_t)pm30);
+#endif
+    };
+    auto encode = [&](int64_t f, const uint4 (&px)[8], auto half_c, uint32_t &hdr, uint32_t (&nib)[4]) {   // the pair's first or second frame
+        constexpr int H = decltype(half_c)::value * 4;
+        uint32_t xw[16];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            xw[4 * i] = px[H + i].x; xw[4 * i + 1] = px[H + i].y; xw[4 * i + 2] = px[H + i].z; xw[4 * i + 3] = px[H + i].w;
+        }
+        encode_x(f, xw, hdr, nib);
+    };
+    // Eight frames at a time: their 144 bytes leave as nine 16-byte stores (whole lines for the L2 to write back, where 36
+    // bytes per pair of frames left partial ones: 17.0 GB written for 9.6)
+    const int64_t fe8 = fe < full_frames ? fe : full_frames;                           // groups of eight need full frames
+    uint4 cur[8], nxt[8];
+    int64_t f = f0;
+    if (f + 8 <= fe8) fetch2(f, cur);
+    for (; f + 8 <= fe8; f += 8) {
+        uint32_t w[36];
+        auto pair = [&](auto pr_c) __attribute__((always_inline)) {                    // (a lambda per pair: constant indices into w)
+            constexpr int pr = decltype(pr_c)::value;
+            uint32_t he, ho, ne[4], no[4];
+#if VGA_ADX_ABLATE & 8                                  // no loads after the first: the same frames over and over
+            if (f == f0 && pr == 0) fetch2(f + 2, nxt);
+#else
+            fetch2(f + 2 * pr + 2, nxt);
+#endif
+            encode(f + 2 * pr, cur, std::integral_constant<int, 0>{}, he, ne);
+            encode(f + 2 * pr + 1, cur, std::integral_constant<int, 1>{}, ho, no);
+            // 36 bytes: header, 16 bytes of nibbles, header, 16 bytes of nibbles
+            uint32_t *d = w + 9 * pr;
+            d[0] = he | (ne[0] << 16);
+            d[1] = (ne[0] >> 16) | (ne[1] << 16);
+            d[2] = (ne[1] >> 16) | (ne[2] << 16);
+            d[3] = (ne[2] >> 16) | (ne[3] << 16);
+            d[4] = (ne[3] >> 16) | (ho << 16);
+            d[5] = no[0]; d[6] = no[1]; d[7] = no[2]; d[8] = no[3];
+#if !(VGA_ADX_ABLATE & 8)
+#pragma unroll
+            for (int i = 0; i < 8; i++) cur[i] = nxt[i];
+#endif
+            __builtin_amdgcn_sched_barrier(0);          // (the next pair's work stays behind this one: registers)
+        };
+        pair(std::integral_constant<int, 0>{});
+        pair(std::integral_constant<int, 1>{});
+        pair(std::integral_constant<int, 2>{});
+        pair(std::integral_constant<int, 3>{});
+#if VGA_ADX_ABLATE & 2
+        if (w[0] == 0x12345678u && w[35] == 0x9abcdef0u && w[17] == 77u) dst[f * 18] = 1;
+#else
+        adx_u32x4_a4 *d = reinterpret_cast<adx_u32x4_a4 *>(dst + f * 18);              // f - f0 is a multiple of 8, f0 even
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            adx_u32x4_a4 v;
+            v.x = w[4 * i]; v.y = w[4 * i + 1]; v.z = w[4 * i + 2]; v.w = w[4 * i + 3];
+            d[i] = v;
+        }
+#endif
+    }
+    for (; f < fe; f++) {                               // what is left of the piece, the zero-padded last frame included
+        uint32_t xw[16], hdr, nib[4];
+        adx_load_frame_slow(src, f, total_length, xw);
+        encode_x(f, xw, hdr, nib);
+        uint16_t *d = reinterpret_cast<uint16_t *>(dst + f * 18);
+        d[0] = (uint16_t)hdr;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            d[1 + 2 * i] = (uint16_t)(nib[i] & 0xFFFFu);
+            d[2 + 2 * i] = (uint16_t)(nib[i] >> 16);
+        }
+    }
+    if (seg_state) {
+        int16_t *st = seg_state + ((int64_t)k * nch + ch) * 2;
+        st[0] = (int16_t)a;
+        st[1] = (int16_t)b;
     }
 }
 
@@ -846,20 +783,14 @@ __device__ __forceinline__ bool adx_encode_seam_run(const int16_t *__restrict__ 
     fetch(f0, px, ow);
     for (int64_t f = f0; f < f0 + seg_frames && f * 32 < total_length; f++) {
         fetch(f + 1, nx, nw);                           // in flight during this frame
-        int x[32];
+        uint32_t xw[16];
         if (f < full_frames) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const uint32_t wv[4] = {px[i].x, px[i].y, px[i].z, px[i].w};
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    x[8 * i + 2 * t] = (int)(int16_t)(wv[t] & 0xFFFF);
-                    x[8 * i + 2 * t + 1] = (int)wv[t] >> 16;
-                }
+                xw[4 * i] = px[i].x; xw[4 * i + 1] = px[i].y; xw[4 * i + 2] = px[i].z; xw[4 * i + 3] = px[i].w;
             }
         } else {                                        // the zero-padded last frame: its own loads
-#pragma unroll
-            for (int j = 0; j < 32; j++) x[j] = f * 32 + j < total_length ? (int)src[f * 32 + j] : 0;
+            adx_load_frame_slow(src, f, total_length, xw);
             const uint16_t *q = reinterpret_cast<const uint16_t *>(dst + f * 18);
 #pragma unroll
             for (int i = 0; i < 9; i++) ow[i] = q[i];
@@ -879,7 +810,7 @@ __device__ __forceinline__ bool adx_encode_seam_run(const int16_t *__restrict__ 
             sb = clamp16(v);
         }
         uint32_t fw[9];
-        adx_encode_frame_words<V4, EXPONENTIAL>(x, ta, tb, c0, c1, filter_bits, fw);
+        adx_encode_frame_words<V4, EXPONENTIAL>(xw, ta, tb, c0, c1, filter_bits, adx_prescan30(xw, c0, c1), fw);
         uint16_t *o = reinterpret_cast<uint16_t *>(dst + f * 18);
 #pragma unroll
         for (int i = 0; i < 9; i++) o[i] = (uint16_t)fw[i];
@@ -892,28 +823,110 @@ __device__ __forceinline__ bool adx_encode_seam_run(const int16_t *__restrict__ 
     return true;
 }
 
+// The fix-up launch: every seam of the batch -- (channel, piece) pairs, `items` of them -- from a queue, a LANE at a time.
+// A seam is a serial run of unknown length (at configs[2]: 200 frames on average, 2500 for the longest of 127 000; the
+// lengths are close to exponentially distributed, tests/host/analysis/adx_seam_stats.c), so a wave that kept 64 seams
+// until the last of them closed would run 1000 frames for 200 frames of work per lane.  Here a lane whose seam has closed
+// takes the next one (the wave asks the queue when ADX_FIXUP_REFILL lanes are idle), and the launch lasts about as long as
+// its longest seam run by a wave that has its SIMD to itself.
+// The guessed run's crumbs stand in for a replay of its bytes (adx_encode_seam_run, which the tail kernel keeps): per frame
+// one 8-byte load replaces nine 16-bit loads and the 32-sample decode, and the pre-scan is down to the two distances
+// that see the history -- 650 instructions per frame instead of 1100.
+// A lane's frame is loaded an iteration ahead (a lane that has just taken a seam sits its first iteration out).
+constexpr int ADX_FIXUP_REFILL = 8;
 template <bool V4, bool EXPONENTIAL>
 __global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
-    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, AdxDeviceParams p,
-    uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state, int *__restrict__ first_open,
-    int *__restrict__ seam_open, int *__restrict__ seam_end, int force_open)
+    const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, int segments, AdxDeviceParams p,
+    uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state, const uint2 *__restrict__ crumbs,
+    int *__restrict__ first_open, int *__restrict__ seam_open, int *__restrict__ seam_end, int force_open, int *__restrict__ queue)
 {
-    const int ch = blockIdx.x * 64 + threadIdx.x;
-    const int k = blockIdx.y + 1;
-    const int64_t f0 = (int64_t)k * seg_frames;
-    if (ch >= nch || f0 * 32 >= total_length) return;
-    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
-    uint8_t *dst = out + (int64_t)ch * out_pitch;
+    const int lane = threadIdx.x;
     const int c0 = p.coef0, c1 = p.coef1;
     const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
-    int ta = seg_state[((int64_t)(k - 1) * nch + ch) * 2], tb = seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1];
-    const int sa = src[f0 * 32 - 2], sb = src[f0 * 32 - 1];                       // the guessed run's start
-    if (adx_encode_seam_run<V4, EXPONENTIAL>(src, dst, f0, seg_frames, total_length, c0, c1, filter_bits, ta, tb, sa, sb, ch, k,
-                                             force_open)) {
-        // still open at the end of its piece: the chain launch carries on from the history reached here
-        seam_open[(int64_t)(k - 1) * nch + ch] = 1;
-        seam_end[(int64_t)(k - 1) * nch + ch] = (int)(((unsigned)tb << 16) | ((unsigned)ta & 0xFFFFu));
-        atomicMin(&first_open[ch], k);
+    const int64_t frames = ((int64_t)total_length + 31) / 32;
+    const int64_t full_frames = total_length / 32;     // frames with all 32 samples (>= 64 here: pieces are that long at least)
+    // the pieces that exist: seam k (1 .. pieces - 1) starts piece k
+    const int pieces = (int)((frames + seg_frames - 1) / seg_frames) < segments ? (int)((frames + seg_frames - 1) / seg_frames) : segments;
+    const int items = nch * (pieces - 1);
+    bool active = false, have = false, drained = false;
+    int ch = 0, k = 0, ta = 0, tb = 0;
+    int64_t f = 0, fend = 0;
+    const int16_t *src = pcm;
+    uint8_t *dst = out;
+    uint4 cur[4], nxt[4];
+    uint2 ccr = make_uint2(0, 0), ncr = make_uint2(0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) cur[i] = nxt[i] = make_uint4(0, 0, 0, 0);
+    for (;;) {
+        const uint64_t idle = __ballot(!active);
+        const int n_idle = __popcll(idle);
+        if (!drained && (n_idle >= ADX_FIXUP_REFILL || n_idle == 64)) {
+            int base = 0;
+            if (lane == __ffsll((long long)idle) - 1) base = atomicAdd(queue, n_idle);
+            base = __shfl(base, __ffsll((long long)idle) - 1);
+            if (!active) {
+                const int idx = base + (int)__popcll(idle & ((1ull << lane) - 1ull));
+                if (idx < items) {                      // channel-fastest: neighbouring lanes start on neighbouring crumbs
+                    k = 1 + idx / nch;
+                    ch = idx - (k - 1) * nch;
+                    f = (int64_t)k * seg_frames;
+                    fend = f + seg_frames < frames ? f + seg_frames : frames;
+                    src = pcm + (int64_t)ch * pcm_pitch;
+                    dst = out + (int64_t)ch * out_pitch;
+                    ta = seg_state[((int64_t)(k - 1) * nch + ch) * 2];
+                    tb = seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1];
+                    active = true;
+                    have = false;
+                }
+            }
+            if (base + n_idle >= items) drained = true;
+        }
+        if (!__any(active)) {
+            if (drained) return;
+            continue;
+        }
+        if (active) {                                   // the frame after this one (a new seam: its first), clamped
+            const int64_t fl = have ? f + 1 : f;
+            const int64_t fc = fl < full_frames ? fl : full_frames - 1;
+            const uint4 *q = reinterpret_cast<const uint4 *>(src + fc * 32);
+#pragma unroll
+            for (int i = 0; i < 4; i++) nxt[i] = q[i];
+            ncr = crumbs[fc * nch + ch];
+        }
+        if (active && have) {
+            uint32_t xw[16];
+            if (f < full_frames) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    xw[4 * i] = cur[i].x; xw[4 * i + 1] = cur[i].y; xw[4 * i + 2] = cur[i].z; xw[4 * i + 3] = cur[i].w;
+                }
+            } else {                                    // the zero-padded last frame: its own loads
+                adx_load_frame_slow(src, f, total_length, xw);
+                ccr = crumbs[f * nch + ch];
+            }
+            uint32_t fw[9];
+            adx_encode_frame_words<V4, EXPONENTIAL>(xw, ta, tb, c0, c1, filter_bits, (int)ccr.y, fw);
+            uint16_t *o = reinterpret_cast<uint16_t *>(dst + f * 18);
+#pragma unroll
+            for (int i = 0; i < 9; i++) o[i] = (uint16_t)fw[i];
+            const int sa = (int)(int16_t)(ccr.x & 0xFFFFu), sb = (int)ccr.x >> 16;       // the guessed run's history after this frame
+            f++;
+            if (ta == sa && tb == sb && !seam_forced_open(force_open, ch, k)) {
+                active = false;                         // closed: the rest of the piece stands
+            } else if (f >= fend) {
+                // still open at the end of its piece: the chain launch carries on from the history reached here
+                seam_open[(int64_t)(k - 1) * nch + ch] = 1;
+                seam_end[(int64_t)(k - 1) * nch + ch] = (int)(((unsigned)tb << 16) | ((unsigned)ta & 0xFFFFu));
+                atomicMin(&first_open[ch], k);
+                active = false;
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) cur[i] = nxt[i];
+            ccr = ncr;
+            have = true;
+        }
     }
 }
 
@@ -960,28 +973,32 @@ __global__ __launch_bounds__(64) void adx_encode_fs18_tail_kernel(
 }
 
 
+// The one-wave encoder's pieces: two waves on every SIMD, each piece at least this long (a seam takes 200 frames to close on
+// average and 2500 at the worst of 28 000 at configs[2], tests/host/analysis/adx_seam_stats.c; one still open at the end
+// of its piece carries on in the tail kernel)
+constexpr int ADX_DIRECT_WAVES_PER_SIMD = 2;
+constexpr int ADX_DIRECT_MIN_PIECE_FRAMES = 2560;
+constexpr int ADX_FIXUP_WAVES_PER_SIMD = 1;
+
 int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_length, const AdxDeviceParams &p,
                   uint8_t *d_out, int64_t out_pitch, int16_t *d_history_out, hipStream_t stream)
 {
     if (nch <= 0) return VGA_OK;
     const dim3 grid((nch + 63) / 64), block(64);
     // pcm rows must be 16-byte aligned for the vector loads, output rows 4-byte aligned for the dword stores
+    // (and coefficients of the size the reference can produce: adx_quantise_step's 32-bit bound)
     const bool fast = p.frame_size == 18 && p.padding == 0 && (pcm_pitch % 8) == 0 && ((uintptr_t)d_pcm % 16) == 0 &&
-                      (out_pitch % 4) == 0 && ((uintptr_t)d_out % 4) == 0;
+                      (out_pitch % 4) == 0 && ((uintptr_t)d_out % 4) == 0 && std::abs((int)p.coef0) <= 16384 &&
+                      std::abs((int)p.coef1) <= 16384;
     if (fast) {
         const bool v4 = p.version == 4, ex = p.type == 4;
-        const size_t lds = 2 * sizeof(AdxEncodeTile);
-        // as many time segments as fill the device once, each an even number of frames and at least 8192 frames long: a
-        // seam still open at the end of its piece sends its channel to the serial tail kernel (0.7 s for a 60 s
-        // channel), and with 2048-frame pieces a 1024-channel launch (44 pieces, 44 000 seams) had such seams -- the host
-        // pipeline's chunks took 250 ms each instead of 10.  The longest seam seen at configs[2] is ~1100 frames.
-        // (the seams re-encode some hundred frames each)
-        const int groups = (nch + ECW - 1) / ECW, groups64 = (nch + 63) / 64;
+        // as many time segments as put ADX_DIRECT_WAVES_PER_SIMD waves on every SIMD, each an even number of frames and at
+        // least ADX_DIRECT_MIN_PIECE_FRAMES long
+        const int groups64 = (nch + 63) / 64;
         const int cus = device_cu_count();
         const int frames = (pcm_length + 31) / 32;
-        const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
-        int segments = cus * per_cu / groups;
-        if (segments > frames / 8192) segments = frames / 8192;
+        int segments = cus * 4 * ADX_DIRECT_WAVES_PER_SIMD / groups64;
+        if (segments > frames / ADX_DIRECT_MIN_PIECE_FRAMES) segments = frames / ADX_DIRECT_MIN_PIECE_FRAMES;
         if (segments < 1) segments = 1;
         if (segments > 64) segments = 64;
         if (encoder_segments_override() > 0) segments = std::min(std::max(frames / 64, 1), encoder_segments_override());   // test hook
@@ -989,28 +1006,37 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
         seg_frames += seg_frames & 1;
         AsyncBuf scratch;                              // freed (stream-ordered) on every exit path
         int16_t *seg_state = nullptr;                  // [segments][nch][2] final histories, then [nch] first open seam
-        int *first_open = nullptr, *seam_open = nullptr, *seam_end = nullptr;
+        int *first_open = nullptr, *seam_open = nullptr, *seam_end = nullptr, *queue = nullptr;
+        uint2 *crumbs = nullptr;                       // [frames][nch]: 8 bytes per frame and channel (2.9 GB at configs[2])
         if (segments > 1) {
             const size_t state_bytes = round_up((size_t)segments * nch * 2 * sizeof(int16_t), 16);
             const size_t flag_bytes = (size_t)(segments - 1) * nch * sizeof(int);
-            VGA_HIP_TRY(scratch.alloc(state_bytes + (size_t)nch * sizeof(int) + 2 * flag_bytes, stream));
+            const size_t small_bytes = round_up(state_bytes + (size_t)nch * sizeof(int) + 2 * flag_bytes + 16, 16);   // (+ the fix-up's queue)
+            VGA_HIP_TRY(scratch.alloc(small_bytes + (size_t)frames * nch * sizeof(uint2), stream));
             seg_state = scratch.as<int16_t>();
             first_open = reinterpret_cast<int *>(scratch.as<unsigned char>() + state_bytes);
             seam_open = first_open + nch;
             seam_end = seam_open + (size_t)(segments - 1) * nch;
+            queue = seam_end + (size_t)(segments - 1) * nch;
+            crumbs = reinterpret_cast<uint2 *>(scratch.as<unsigned char>() + small_bytes);
             VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
             VGA_HIP_TRY(hipMemsetAsync(seam_open, 0, flag_bytes, stream));
+            VGA_HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int), stream));
         }
+        // the fix-up's persistent waves: one per SIMD, fewer when there are not that many seams
+        int fixup_waves = cus * 4 * ADX_FIXUP_WAVES_PER_SIMD;
+        if (const char *e = std::getenv("VGA_HIP_ADX_FIXUP_WAVES")) fixup_waves = std::max(1, std::atoi(e));   // tuning (tools/)
+        fixup_waves = (int)std::min<int64_t>(fixup_waves, ((int64_t)nch * (segments - 1) + 63) / 64);
+        if (fixup_waves < 1) fixup_waves = 1;
 #define VGA_ADX_ENC_T(V, E)                                                                                              \
         {                                                                                                                \
-            VGA_HIP_TRY(allow_dynamic_lds(adx_encode_fs18_tiled_kernel<V, E>, lds));                                     \
-            hipLaunchKernelGGL((adx_encode_fs18_tiled_kernel<V, E>), dim3(groups, segments), dim3(ETHREADS), lds, stream, d_pcm, \
-                               pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, d_history_out, seg_state);  \
+            hipLaunchKernelGGL((adx_encode_fs18_direct_kernel<V, E>), dim3(groups64, segments), dim3(64), 0, stream, d_pcm, \
+                               pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, d_history_out, seg_state, crumbs); \
             VGA_HIP_TRY(hipGetLastError());                                                                              \
             if (segments > 1) {                                                                                          \
-                hipLaunchKernelGGL((adx_encode_fs18_fixup_kernel<V, E>), dim3(groups64, segments - 1), dim3(64), 0, stream, \
-                                   d_pcm, pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, seg_state,       \
-                                   first_open, seam_open, seam_end, force_open_seams());                                \
+                hipLaunchKernelGGL((adx_encode_fs18_fixup_kernel<V, E>), dim3(fixup_waves), dim3(64), 0, stream,         \
+                                   d_pcm, pcm_pitch, nch, pcm_length, seg_frames, segments, p, d_out, out_pitch, seg_state, crumbs, \
+                                   first_open, seam_open, seam_end, force_open_seams(), queue);                         \
                 VGA_HIP_TRY(hipGetLastError());                                                                          \
                 hipLaunchKernelGGL((adx_encode_fs18_tail_kernel<V, E>), dim3(groups64), dim3(64), 0, stream, d_pcm,     \
                                    pcm_pitch, nch, pcm_length, seg_frames, segments, p, d_out, out_pitch, seg_state,    \

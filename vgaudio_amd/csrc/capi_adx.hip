@@ -63,7 +63,7 @@ adx::AdxDeviceParams device_params(const vga_adx_params *p, bool encode)
 
 }  // namespace
 
-// channels per chunk of the host pipeline (host_pipeline.hpp): the tiled kernels fill the chip from 1024 channels on
+// channels per chunk of the host pipeline (host_pipeline.hpp): the piece-wise kernels fill the chip from 1024 channels on
 static constexpr int ADX_CHUNK_CHANNELS = 1024;
 
 extern "C" {
