@@ -44,3 +44,28 @@ void third_trip_stats(const int16_t *pcm, int n_samples, const int16_t coefs_in[
         buf[1] = (int16_t)pcm_out[best][15];
     }
 }
+
+/* How many quantise passes does a (frame, predictor) take?  hist[t] counts pairs that took t passes (t = 1 ..), frame_max[t]
+   the frames whose slowest predictor took t: what a pass-level work queue (lanes that take passes instead of frames) would
+   have to schedule -- the encoder's waves run passes for all 64 lanes as long as one lane needs another. */
+void trip_histogram(const int16_t *pcm, int n_samples, const int16_t coefs_in[16], uint64_t hist[16], uint64_t frame_max[16])
+{
+    int16_t buf[16] = {0};
+    int frames = n_samples / 14;
+    for (int f = 0; f < frames; f++) {
+        memcpy(buf + 2, pcm + (long)f * 14, 28);
+        int pcm_out[8][16], adpcm[8][14], scale[8], mx = 0;
+        double dist[8];
+        for (int i = 0; i < 8; i++) {
+            int16_t c[2] = { coefs_in[2 * i], coefs_in[2 * i + 1] };
+            const int t = trips_of(buf, 14, c, pcm_out[i], adpcm[i], &scale[i], &dist[i]);
+            hist[t < 15 ? t : 15]++;
+            if (t > mx) mx = t;
+        }
+        frame_max[mx < 15 ? mx : 15]++;
+        int best = 0; double mn = 1.7976931348623157e308;
+        for (int i = 0; i < 8; i++) if (dist[i] < mn) { mn = dist[i]; best = i; }
+        buf[0] = (int16_t)pcm_out[best][14];
+        buf[1] = (int16_t)pcm_out[best][15];
+    }
+}

@@ -567,7 +567,11 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
 #pragma unroll
                     for (int i = 0; i < EXP; i++) {
                         const double t = cw1[i] + (val_x2 * cw2[i]) + (bterm_x2 * cw3[i]);
-                        if (t < value) { value = t; idx = i; }
+                        // `if (t < value) { value = t; idx = i; }` (:355-360) with the running minimum as ONE v_min_f64
+                        // instead of two selects: value is only ever compared (a -0.0 for a +0.0 changes no decision),
+                        // and a NaN t leaves both alone either way
+                        idx = t < value ? i : idx;
+                        asm("v_min_f64 %0, %1, %2" : "=v"(value) : "v"(value), "v"(t));
                     }
                 }
             };
@@ -861,7 +865,8 @@ __global__ __launch_bounds__(COEF_THREADS) __attribute__((amdgpu_waves_per_eu(5,
 #pragma unroll
                         for (int i = 0; i < EXP; i++) {
                             const double t = cw1[i] + (val_x2 * cw2[i]) + (bterm_x2 * cw3[i]);
-                            if (t < value) { value = t; idx = i; }
+                            idx = t < value ? i : idx;                       // (one v_min_f64: see gc_coefs_kernel's classify)
+                            asm("v_min_f64 %0, %1, %2" : "=v"(value) : "v"(value), "v"(t));
                         }
                         d1 = r.x;
                         d2 = r.y;

@@ -707,15 +707,41 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
                 const int lv = (low == 255 && mid_value > available) ? -1 : low;
                 int bd = 0;
                 if (lv > 0) {
+                    // BinarySearchBoundary (:525-552) probes CalculateUsedBits(level, boundary): the bands below the
+                    // boundary at level - 1, the others at level.  That is the frame's bits at `level` plus, for every band
+                    // below the boundary, what the band costs more at level - 1: ONE exclusive scan over the bands gives
+                    // the value of every possible probe (band b: lane b & 63, first or second half), and the search's
+                    // seven or eight dependent probes are lane reads -- the same probes, the same decisions, in the
+                    // reference's order (the bits need not be monotone in the boundary and nothing here assumes it).
+                    int at_level = 0, d_lo = 0, d_hi = 0;                      // bands `lane` and `lane + 64`, both channels
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int r1 = T.res_curve[min(max(lv + off[k], 0), 58)], r0 = T.res_curve[min(max(lv - 1 + off[k], 0), 58)];
+                        const int c1 = (int)(((r1 >= 8 ? chi[k] : clo[k]) >> (8 * (r1 & 7))) & 0xFFu);
+                        const int c0 = (int)(((r0 >= 8 ? chi[k] : clo[k]) >> (8 * (r0 & 7))) & 0xFFu);
+                        at_level += on[k] ? c1 : 0;
+                        const int more = on[k] ? c0 - c1 : 0;
+                        if (k & 1) d_hi += more;
+                        else d_lo += more;
+                    }
+                    const int base = wave_sum(at_level) + hsum;
+                    const int in_lo = wave_inclusive_scan(d_lo), in_hi = wave_inclusive_scan(d_hi);
+                    const int all_lo = __builtin_amdgcn_readlane(in_lo, 63);
+                    const int ex_lo = base + in_lo - d_lo, ex_hi = base + all_lo + in_hi - d_hi;      // probe(lv, band)
+                    auto probe_boundary = [&](int eb) {                       // eb is wave-uniform, 0 .. 127
+                        const int a = __builtin_amdgcn_readlane(ex_lo, __builtin_amdgcn_readfirstlane(eb) & 63);
+                        const int b = __builtin_amdgcn_readlane(ex_hi, __builtin_amdgcn_readfirstlane(eb) & 63);
+                        return eb < 64 ? a : b;
+                    };
                     int lo2 = 0, hi2 = 127;
                     while (abs(hi2 - lo2) > 1) {
                         const int mid = (lo2 + hi2) / 2;
-                        const int mid_value2 = probe(lv, mid);
+                        const int mid_value2 = probe_boundary(mid);
                         if (available < mid_value2) hi2 = mid - 1;
                         else lo2 = mid;
                     }
                     if (lo2 == hi2) bd = lo2 < 127 ? lo2 : -1;
-                    else bd = probe(lv, hi2) > available ? lo2 : hi2;
+                    else bd = probe_boundary(hi2) > available ? lo2 : hi2;
                 }
 #undef probe
                 if (lane == 0) { red[28] = lv; red[29] = bd; }
