@@ -735,11 +735,11 @@ def run_gc(args, cx):
         except (KeyError, ZeroDivisionError):
             pass
     achieved = enc_bytes / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
-    # one encode = gc_encode_persistent_kernel (time pieces from a queue, seams closed inside; below 2048 channels:
+    # one encode = gc_encode_persistent_kernel (time pieces from a queue, seams closed inside; below 512 channels on 256 CUs:
     # gc_encode_kernel<false> + gc_encode_seam_kernel) + gc_encode_chain_kernel + gc_encode_kernel<true> (chain and repair
     # return at once unless a seam stayed open); launch_ms spans them, the rocprofv3 kernel stats under profiles/ list them
     # separately (their averages add up to it)
-    persistent = nch >= 2048
+    persistent = nch >= 512                 # plan_encode_pieces: one channel group per 32 workgroups (gc_encode_kernel.hip)
     roofline = {"bound": "hbm", "kernel": "gc_encode_persistent_kernel" if persistent else "gc_encode_kernel", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "traffic_source": pmc_note, "algorithmic_bytes_per_launch": enc_bytes, "launch_ms": round(enc_ms, 3),
