@@ -107,3 +107,51 @@ def test_format_roundtrip_config3_shape_reduced():
         assert (back.Channels[c] == wdec[c]).all()
     err = np.stack(back.Channels).astype(float) - pcm
     assert np.sqrt((err ** 2).mean()) < 0.12 * np.sqrt((pcm.astype(float) ** 2).mean())   # 4-bit ADPCM, fixed high-pass predictor
+
+
+def test_encoder_pieces_and_seams_on_random_shapes():
+    """The 18-byte-frame encoder cuts channels into time pieces and hands the seams between them out a lane at a time
+    (adx_encode_fs18_fixup_kernel, LABNOTES.md 8.7): random channel counts (the queue's refills start and end anywhere),
+    lengths with and without a partial last frame, piece counts from 2 to the shortest the hook allows (64 frames), the
+    encodings the kernel is instantiated for, seams forced open in none / all / a pattern of the places.  Bytes and the
+    returned history are the oracle's."""
+    import ctypes as C
+
+    import torch
+
+    from vgaudio_amd import _lib, device as vdev
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(20260927)
+    cases = []
+    for _ in range(14):
+        cases.append((int(rng.integers(1, 200)), 32 * int(rng.integers(130, 900)) + int(rng.choice([0, 0, 1, 13, 31])),
+                      int(rng.choice([2, 3, 5, 8, 13, 1000])), int(rng.choice([0, 0, 1, 2])),
+                      [dict(Type=3), dict(Type=4), dict(Type=3, Version=3), dict(Type=2, Filter=2), dict(Type=4, Version=3)][int(rng.integers(0, 5))]))
+    for nch, n, pieces, mode, kw in cases:
+        host = np.stack([synth.generate(1, n, first_channel=int(rng.integers(0, 4096)))[0] for _ in range(min(nch, 6))])
+        host = np.concatenate([host, rng.integers(-32768, 32768, (nch - len(host), n)).astype(np.int16)]) if nch > len(host) else host
+        pcm = vdev.alloc_pcm(nch, n, d)
+        pcm[:, :n] = torch.from_numpy(host).to(d)
+        cfg = CriAdxParameters(**kw)
+        p = _lib.AdxParams()
+        L.vga_adx_default_params(C.byref(p))
+        p.type, p.version, p.filter = cfg.Type, cfg.Version, cfg.Filter
+        nb = L.vga_adx_encoded_byte_count(n, C.byref(p))
+        pitch = (nb + 15) // 16 * 16
+        adx = torch.zeros((nch, pitch), dtype=torch.uint8, device=d)
+        hist = torch.zeros(nch, dtype=torch.int16, device=d)
+        L.vga_testing_gc_encoder_segments_this_thread(pieces)
+        old = L.vga_testing_force_open_seams_this_thread(mode)
+        try:
+            _lib.check(L.vga_adx_encode_device(pcm.data_ptr(), pcm.stride(0), nch, n, C.byref(p), adx.data_ptr(), pitch,
+                                               hist.data_ptr(), st))
+            torch.cuda.synchronize()
+        finally:
+            L.vga_testing_force_open_seams_this_thread(old)
+            L.vga_testing_gc_encoder_segments_this_thread(0)
+        want, whist = po.adx_encode_batch(host, _op(kw), threads=8)
+        got = adx[:, :nb].cpu().numpy()
+        assert np.array_equal(got, want), (nch, n, pieces, mode, kw, int(np.argmax((got != want).any(axis=1))))
+        assert np.array_equal(hist.cpu().numpy(), whist), (nch, n, pieces, mode, kw)

@@ -624,11 +624,11 @@ __device__ __forceinline__ void adx_load_frame_slow(const int16_t *src, int64_t 
 // during this one) and writes eight frames at a time (144 bytes from a dword boundary).
 // Every frame costs the same, so a plain grid with as many waves as the chip holds is balanced: the wave's ~900
 // instructions per frame (pre-scan 8 per sample, adx_quantise_step 18) are what it runs at -- configs[2]: 12.1 ms with 32
-// pieces per channel, 84 % of the VALU issue slots, 23.6 GB fetched and 10.8 GB written (9.6 GB with the crumbs;
-// tools/pmc_adx_encode.sh).  The tiled kernel of rounds 2-4 -- one encoder wave and three helper waves per 64 channels, the
+// pieces per channel, 84 % of the VALU issue slots, 23.6 GB fetched and 11.0 GB written (23.6 and 9.6 GB algorithmic, the
+// crumbs included; tools/pmc_adx_encode.sh).  The tiled kernel of rounds 2-4 -- one encoder wave and three helper waves per 64 channels, the
 // tiles in LDS, hence two encoder waves per CU -- took 19.7 ms, 17.5 ms with this file's arithmetic.
 // Crumbs: 8 bytes per frame and channel in a scratch array [frame][channel] -- what a seam run needs to know about the
-// guessed run it replaces (see adx_encode_seam_crumbs).
+// guessed run it replaces (see adx_encode_fs18_fixup_kernel).
 typedef uint32_t adx_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 template <bool V4, bool EXPONENTIAL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void adx_encode_fs18_direct_kernel(
