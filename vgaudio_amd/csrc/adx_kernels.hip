@@ -974,8 +974,9 @@ __global__ __launch_bounds__(64) void adx_encode_fs18_tail_kernel(
 
 
 // The one-wave encoder's pieces: two waves on every SIMD, each piece at least this long (a seam takes 200 frames to close on
-// average and 2500 at the worst of 28 000 at configs[2], tests/host/analysis/adx_seam_stats.c; one still open at the end
-// of its piece carries on in the tail kernel)
+// average and 2500 for the longest of configs[2]'s 127 000, tests/host/analysis/adx_seam_stats.c; one still open at the end
+// of its piece carries on in the tail kernel).  The fix-up's lanes take seams from a queue: one persistent wave per SIMD
+// (profiles/r04_e_adx_parts.log: 512 / 1024 / 2048 waves 5.8 / 5.4 / 6.4 ms).
 constexpr int ADX_DIRECT_WAVES_PER_SIMD = 2;
 constexpr int ADX_DIRECT_MIN_PIECE_FRAMES = 2560;
 constexpr int ADX_FIXUP_WAVES_PER_SIMD = 1;
