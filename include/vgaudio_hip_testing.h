@@ -17,9 +17,10 @@ extern "C" {
  * Returns the calling thread's previous mode. */
 int vga_testing_force_open_seams_this_thread(int mode);
 
-/* GC-ADPCM encoder wave layout for calls made FROM THE CALLING THREAD: 8 = lane per (channel, predictor), the product's
- * choice; 4 = lane per (channel, predictor, scale candidate), the round-1 layout kept for A/B measurements.  Both produce
- * the same bytes.  Returns the previous value; other arguments leave it unchanged. */
+/* GC-ADPCM encoder wave layout for calls made FROM THE CALLING THREAD: 0 = the launcher's choice (the product: 4 for
+ * batches below ~512 channels, 8 from there on and for ragged batches); 8 = lane per (channel, predictor); 4 = lane per
+ * (channel, predictor, scale candidate).  Both produce the same bytes.  Returns the previous value; other arguments leave
+ * it unchanged. */
 int vga_testing_gc_encoder_layout_this_thread(int channels_per_wave);
 /* GC-ADPCM coefficient-search kernel for calls made from the calling thread: 0 = the launcher's choice by channel count
  * (the product), 1 = one wave per channel, 2 = workgroups of four channels and a summing wave, 3 = the same five waves on

@@ -414,7 +414,7 @@ def test_encoder_layouts_and_piece_counts_give_the_same_bytes():
                 torch.cuda.synchronize()
                 assert np.array_equal(out[:, :nb].cpu().numpy(), np.asarray(wa)[:, :nb]), (layout, segments)
     finally:
-        L.vga_testing_gc_encoder_layout_this_thread(8)
+        L.vga_testing_gc_encoder_layout_this_thread(0)
         L.vga_testing_gc_encoder_segments_this_thread(0)
 
 

@@ -39,7 +39,7 @@ for nch in (4096, 1024, 64, 1):
         outs[layout] = o
     out[nch] = {"ms_layout4": res[4], "ms_layout8": res[8], "identical": bool(torch.equal(outs[4], outs[8]))}
     del pcm, outs
-L.vga_testing_gc_encoder_layout_this_thread(8)
+L.vga_testing_gc_encoder_layout_this_thread(0)
 print(json.dumps(out))
 # time pieces per channel at configs[1], layout 8
 nch = 4096

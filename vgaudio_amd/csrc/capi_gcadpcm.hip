@@ -37,7 +37,7 @@ bool take_error_pending()
 static thread_local int g_force_open_seams = 0;
 int force_open_seams() { return g_force_open_seams; }
 
-static thread_local int g_encoder_layout = 8;
+static thread_local int g_encoder_layout = 0;      // 0: the launcher's choice by batch size
 int encoder_layout() { return g_encoder_layout; }
 static thread_local int g_coefs_variant = 0;
 int coefs_kernel_variant() { return g_coefs_variant; }
@@ -158,7 +158,7 @@ int vga_testing_force_open_seams_this_thread(int mode)
 int vga_testing_gc_encoder_layout_this_thread(int channels_per_wave)
 {
     const int old = g_encoder_layout;
-    if (channels_per_wave == 4 || channels_per_wave == 8) g_encoder_layout = channels_per_wave;
+    if (channels_per_wave == 0 || channels_per_wave == 4 || channels_per_wave == 8) g_encoder_layout = channels_per_wave;
     return old;
 }
 int vga_testing_gc_coefs_variant_this_thread(int variant)

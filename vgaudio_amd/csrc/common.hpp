@@ -228,8 +228,9 @@ inline int device_cu_count()
 // closed, so that their fall-back (re-computing the rest of the channel serially) is what produces the output
 int force_open_seams();          // 0 = off, 1 = every seam, 2 = seams with an even index of every third channel
 
-// lane layout of the GC-ADPCM encoder wave (gc_encode_kernel.hip): 8 = (channel, predictor), the default; 4 = (channel,
-// predictor, candidate).  Thread-local test hook vga_testing_gc_encoder_layout_this_thread: both must give the same bytes.
+// lane layout of the GC-ADPCM encoder wave (gc_encode_kernel.hip): 8 = (channel, predictor); 4 = (channel, predictor,
+// candidate); 0 = the launcher's choice (4 for batches too small for persistent workgroups, 8 otherwise).  Thread-local
+// test hook vga_testing_gc_encoder_layout_this_thread: both must give the same bytes.
 int encoder_layout();
 int coefs_kernel_variant();               // 0: four channels + summing wave per workgroup (product); 1: one wave per channel
 int encoder_segments_override();   // > 0: time pieces per channel forced by the test hook

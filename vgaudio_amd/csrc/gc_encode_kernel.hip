@@ -1064,14 +1064,14 @@ constexpr int PERSISTENT_SMALL_FRAMES = 4096;  // ... of this many frames
 // PERSISTENT_BIG_ROUNDS big items followed by PERSISTENT_SMALL_ROUNDS rounds of short ones -- with items of one size d
 // the workgroups end spread over the last d of the launch (152 ms at configs[1] with 16 pieces of 35 ms: mean life
 // 136 ms + d / 2).
-int plan_encode_pieces(int groups, int frames, int64_t group_frames, bool ragged, bool *persistent_out, Pieces *seg_out)
+int plan_encode_pieces(int groups, int frames, int64_t group_frames, bool ragged, bool *persistent_out, Pieces *seg_out, int layout)
 {
     constexpr int CS = 16;
     const int cus = device_cu_count();
     // persistent workgroups taking (channel group, piece) items from a queue (gc_encode_persistent_kernel) once the batch
     // has enough channel groups; test hook: 1 = never, 2 = always
     const int pmode = encoder_persistent_mode();
-    const bool persistent = encoder_layout() != 4 && (pmode == 2 || (pmode == 0 && (ragged || groups * PERSISTENT_MIN_GROUPS_FACTOR >= cus * 4)));
+    const bool persistent = layout != 4 && (pmode == 2 || (pmode == 0 && (ragged || groups * PERSISTENT_MIN_GROUPS_FACTOR >= cus * 4)));
     int segments = cus * 4 / (groups > 0 ? groups : 1);   // = SW encoder waves on every SIMD
     if (persistent && (pmode == 2 || ragged)) segments = (cus * 4 * PERSISTENT_ITEMS_PER_WORKGROUP + groups - 1) / groups;
     if (ragged) {
@@ -1141,8 +1141,7 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
         seg = rg.seg;
         segments = rg.segments;
     } else {
-        segments = plan_encode_pieces(groups, frames, RAGGED ? rg.total_frames / CS : (int64_t)groups * frames, RAGGED, &persistent, &seg);
-        if (CPW != 8) persistent = false;              // (the persistent kernel's seams use the (channel, predictor) layout)
+        segments = plan_encode_pieces(groups, frames, RAGGED ? rg.total_frames / CS : (int64_t)groups * frames, RAGGED, &persistent, &seg, CPW);
     }
     AsyncBuf scratch;                                  // freed (stream-ordered) on every exit path
     int16_t *seg_state = nullptr;
@@ -1215,7 +1214,16 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int sample_c
     if (rg)                                            // ragged batches: the (channel, predictor) layout only
         return launch_encode_layout<8, true>(d_pcm, 0, nch, 0, d_coefs, d_hist1, d_hist2, d_adpcm, 0, stream, d_scratch,
                                              scratch_bytes, *rg);
-    if (encoder_layout() == 4)
+    // The wave layout: (channel, predictor) lanes run the two scale candidates of a pair back to back -- fewer instructions
+    // per channel, the layout of every batch that fills the chip (and of the persistent workgroups).  A batch too small for
+    // those is a few hundred workgroups on 1024 SIMDs, each alone on its SIMD and as fast as its own instruction stream: with a
+    // lane per (channel, predictor, candidate) that stream is half as long per frame and there are twice the workgroups
+    // (60 s channels: 1 channel 3.0 ms against 4.8, 96: 18.5 / 21.8, 256: 23.3 / 25.7, 384: 25.5 / 31.5, 512: 28.9 / 28.2 with
+    // persistent workgroups; tools/time_layouts_small.py).
+    int layout = encoder_layout();
+    if (layout == 0)                                   // (the test hook that forces persistent workgroups needs their layout)
+        layout = encoder_persistent_mode() != 2 && ((nch + 15) / 16) * PERSISTENT_MIN_GROUPS_FACTOR < device_cu_count() * 4 ? 4 : 8;
+    if (layout == 4)
         return launch_encode_layout<4, false>(d_pcm, pcm_pitch, nch, sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, stream,
                                               d_scratch, scratch_bytes, Ragged{});
     return launch_encode_layout<8, false>(d_pcm, pcm_pitch, nch, sample_count, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, stream,

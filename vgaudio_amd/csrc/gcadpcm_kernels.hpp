@@ -22,8 +22,9 @@ struct Pieces {
 };
 // The encoder's piece schedule for `groups` channel groups (16 channels each) whose longest channel has `frames` frames and
 // which hold `group_frames` frames of work in all (sum over groups of the group's longest channel); persistent = workgroups
-// that take (group, piece) items from a queue.  Returns the number of pieces the longest channel has.
-int plan_encode_pieces(int groups, int frames, int64_t group_frames, bool ragged, bool *persistent, Pieces *seg);
+// that take (group, piece) items from a queue (the (channel, predictor) layout only: layout == 8).  Returns the number of
+// pieces the longest channel has.
+int plan_encode_pieces(int groups, int frames, int64_t group_frames, bool ragged, bool *persistent, Pieces *seg, int layout = 8);
 
 struct Ragged {
     // the encoder's items (channel group | piece << 20), biggest first, when the host has planned them (ragged batches)
