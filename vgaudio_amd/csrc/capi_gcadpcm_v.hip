@@ -385,8 +385,8 @@ struct RaggedCall {
     }
 };
 
-int encode_batch_v_one(const int16_t *const *pcm, const int *counts, int nch, const int16_t *hist1, const int16_t *hist2,
-                       int16_t *coefs_out, uint8_t *const *adpcm_out, bool with_coefs, const int16_t *coefs_in)
+int encode_batch_v_rows(const int16_t *const *pcm, const int *counts, int nch, const int16_t *hist1, const int16_t *hist2,
+                        int16_t *coefs_out, uint8_t *const *adpcm_out, bool with_coefs, const int16_t *coefs_in)
 {
     if (int rc = check_counts(counts, nch, "sample_counts")) return rc;
     if (int rc = check_rows((const void *const *)pcm, counts, nch, "pcm")) return rc;
@@ -447,8 +447,8 @@ int encode_batch_v_one(const int16_t *const *pcm, const int *counts, int nch, co
     return VGA_OK;
 }
 
-int decode_batch_v_one(const uint8_t *const *adpcm, const int16_t *coefs, const int *counts, int nch, const int16_t *hist1,
-                       const int16_t *hist2, int16_t *const *pcm_out)
+int decode_batch_v_rows(const uint8_t *const *adpcm, const int16_t *coefs, const int *counts, int nch, const int16_t *hist1,
+                        const int16_t *hist2, int16_t *const *pcm_out)
 {
     if (int rc = check_counts(counts, nch, "sample_counts")) return rc;
     if (int rc = check_rows((const void *const *)adpcm, counts, nch, "adpcm")) return rc;
@@ -497,6 +497,85 @@ int decode_batch_v_one(const uint8_t *const *adpcm, const int16_t *coefs, const 
         return VGA_ERR_ARGUMENT;
     }
     return VGA_OK;
+}
+
+// The pipeline works through the rows in order, and what runs after the last upload -- the last chunk's kernels and its
+// download -- is the call's tail.  With the caller's (any) order that chunk holds files of every length, and the
+// coefficient search of a few hundred channels lasts as long as its LONGEST one (one wave per channel: 31 ms for 120 s):
+// the mixed-lengths set of bench.py ended 100 ms after its upload.  The rows are therefore taken longest first (a stable
+// sort of pointers; results go back to the caller's rows, coefficients and histories are gathered / scattered here): the
+// long files' kernels run under the uploads that follow them and the tail is a chunk of short files.
+struct LongestFirst {
+    std::vector<int> order;                           // position -> the caller's index
+    bool identity = true;
+    LongestFirst(const int *counts, int n)
+    {
+        order.resize(n > 0 ? n : 0);
+        for (int i = 0; i < n; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return counts[a] > counts[b]; });
+        for (int i = 0; i < n && identity; i++) identity = order[i] == i;
+    }
+    template <class T> std::vector<T> gather(const T *v) const
+    {
+        std::vector<T> out(order.size());
+        for (size_t i = 0; i < order.size(); i++) out[i] = v[order[i]];
+        return out;
+    }
+    // rows of `width` elements
+    template <class T> std::vector<T> gather_rows(const T *v, int width) const
+    {
+        std::vector<T> out(order.size() * (size_t)width);
+        for (size_t i = 0; i < order.size(); i++) std::copy(v + (size_t)order[i] * width, v + (size_t)(order[i] + 1) * width, out.begin() + i * width);
+        return out;
+    }
+};
+
+int encode_batch_v_one(const int16_t *const *pcm, const int *counts, int nch, const int16_t *hist1, const int16_t *hist2,
+                       int16_t *coefs_out, uint8_t *const *adpcm_out, bool with_coefs, const int16_t *coefs_in)
+{
+    // (the argument checks of encode_batch_v_rows, before anything is read through the arrays)
+    if (int rc = check_counts(counts, nch, "sample_counts")) return rc;
+    if (int rc = check_rows((const void *const *)pcm, counts, nch, "pcm")) return rc;
+    if (adpcm_out || !with_coefs)
+        if (int rc = check_rows((const void *const *)adpcm_out, counts, nch, "adpcm_out")) return rc;
+    if (nch > 0 && with_coefs && !coefs_out) { set_error("null coefs_out"); return VGA_ERR_ARGUMENT; }
+    if (nch > 0 && !with_coefs && !coefs_in) { set_error("null coefs"); return VGA_ERR_ARGUMENT; }
+    const LongestFirst lf(counts, nch);
+    if (nch < 2 || lf.identity) return encode_batch_v_rows(pcm, counts, nch, hist1, hist2, coefs_out, adpcm_out, with_coefs, coefs_in);
+    const std::vector<int> n2 = lf.gather(counts);
+    const std::vector<const int16_t *> in2 = lf.gather(pcm);
+    std::vector<uint8_t *> out2;
+    if (adpcm_out) out2 = lf.gather(adpcm_out);
+    std::vector<int16_t> h1, h2, cin, cout;
+    if (hist1) h1 = lf.gather(hist1);
+    if (hist2) h2 = lf.gather(hist2);
+    if (!with_coefs) cin = lf.gather_rows(coefs_in, 16);
+    if (with_coefs) cout.resize((size_t)nch * 16);
+    const int rc = encode_batch_v_rows(in2.data(), n2.data(), nch, hist1 ? h1.data() : nullptr, hist2 ? h2.data() : nullptr,
+                                       with_coefs ? cout.data() : nullptr, adpcm_out ? out2.data() : nullptr, with_coefs,
+                                       with_coefs ? nullptr : cin.data());
+    if (rc == VGA_OK && with_coefs)
+        for (int i = 0; i < nch; i++) std::copy(cout.begin() + (size_t)i * 16, cout.begin() + (size_t)(i + 1) * 16, coefs_out + (size_t)lf.order[i] * 16);
+    return rc;
+}
+
+int decode_batch_v_one(const uint8_t *const *adpcm, const int16_t *coefs, const int *counts, int nch, const int16_t *hist1,
+                       const int16_t *hist2, int16_t *const *pcm_out)
+{
+    if (int rc = check_counts(counts, nch, "sample_counts")) return rc;
+    if (int rc = check_rows((const void *const *)adpcm, counts, nch, "adpcm")) return rc;
+    if (int rc = check_rows((const void *const *)pcm_out, counts, nch, "pcm_out")) return rc;
+    if (nch > 0 && !coefs) { set_error("null coefs"); return VGA_ERR_ARGUMENT; }
+    const LongestFirst lf(counts, nch);
+    if (nch < 2 || lf.identity) return decode_batch_v_rows(adpcm, coefs, counts, nch, hist1, hist2, pcm_out);
+    const std::vector<int> n2 = lf.gather(counts);
+    const std::vector<const uint8_t *> in2 = lf.gather(adpcm);
+    const std::vector<int16_t *> out2 = lf.gather(pcm_out);
+    const std::vector<int16_t> c2 = lf.gather_rows(coefs, 16);
+    std::vector<int16_t> h1, h2;
+    if (hist1) h1 = lf.gather(hist1);
+    if (hist2) h2 = lf.gather(hist2);
+    return decode_batch_v_rows(in2.data(), c2.data(), n2.data(), nch, hist1 ? h1.data() : nullptr, hist2 ? h2.data() : nullptr, out2.data());
 }
 
 }  // namespace
