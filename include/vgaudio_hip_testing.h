@@ -36,6 +36,12 @@ int vga_testing_gc_encoder_segments_this_thread(int segments);
  * a queue.  Results must not depend on it.  Returns the previous value. */
 int vga_testing_gc_encoder_persistent_this_thread(int mode);
 
+/* The GC-ADPCM encoder's piece schedule (gc::plan_encode_pieces, vgaudio_amd/csrc/gc_encode_kernel.hip) for a device of
+ * `cus` compute units: `groups` channel groups of sixteen whose longest channel has `frames` frames and whose longest
+ * channels hold `group_frames` frames in all.  Host arithmetic, needs no GPU.  out5 = {pieces, big, nb, small, persistent}:
+ * piece k begins at frame min(k, nb) * big + max(k - nb, 0) * small.  The pieces must cover `frames`.  Returns 0. */
+int vga_testing_gc_plan_pieces(int cus, int groups, int frames, long long group_frames, int ragged, int *out5);
+
 /* The host-pointer entry points (vga_*_batch) move data through a pipeline of feeder threads, pinned rings, per-chunk
  * kernel launches and drainer threads (vgaudio_amd/csrc/host_pipeline.hpp); its shape normally follows the volume of
  * the call.  Non-zero arguments override it for calls made FROM THE CALLING THREAD (0 = automatic): feeder / drainer

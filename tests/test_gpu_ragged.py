@@ -145,6 +145,23 @@ def test_persistent_workgroups_and_plain_grid_give_the_oracles_bytes(mode, force
         assert coefs[c].tolist() == wc.tolist() and np.array_equal(adpcm[c], wa), (c, lens[c])
 
 
+def test_a_channel_longer_than_the_two_size_schedule_holds_is_encoded_to_its_end():
+    """A 21-minute channel in a batch of one group: the persistent schedule's two piece sizes would need more than the 1024
+    pieces the scratch holds (tests/test_host_gc_piece_plan.py); until round 5 the plan was cut off there and the tail of the
+    channel kept whatever the output row held.  ~20 s of oracle time."""
+    lens = [60_000_000 + 9, 1000, 14 * 4000 + 3]
+    chans = _channels(lens, first_channel=93)          # (channel 93: the slowest-closing seams of the synthetic set)
+    coefs, adpcm = _encode_v(chans)
+    for c, pcm in enumerate(chans):
+        wc, wa = _oracle(pcm)
+        assert coefs[c].tolist() == wc.tolist(), (c, lens[c])
+        bad = np.flatnonzero(adpcm[c] != wa)
+        assert bad.size == 0, (c, lens[c], "first differing byte", int(bad[0]), "of", wa.size)
+    back = _decode_v(adpcm, coefs, lens)
+    for c in range(len(chans)):
+        assert np.array_equal(back[c], po.gc_decode(adpcm[c], coefs[c], lens[c])), (c, lens[c])
+
+
 def test_equal_lengths_through_the_ragged_entry_point_equal_the_batch_entry_point():
     L = _lib.lib()
     n = 14 * 5000 + 9

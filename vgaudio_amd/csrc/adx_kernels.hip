@@ -1026,7 +1026,9 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
         }
         // the fix-up's persistent waves: one per SIMD, fewer when there are not that many seams
         int fixup_waves = cus * 4 * ADX_FIXUP_WAVES_PER_SIMD;
-        if (const char *e = std::getenv("VGA_HIP_ADX_FIXUP_WAVES")) fixup_waves = std::max(1, std::atoi(e));   // tuning (tools/)
+#ifdef VGA_TUNING   // tools/build_variants.sh only
+        if (const char *e = std::getenv("VGA_HIP_ADX_FIXUP_WAVES")) fixup_waves = std::max(1, std::atoi(e));
+#endif
         fixup_waves = (int)std::min<int64_t>(fixup_waves, ((int64_t)nch * (segments - 1) + 63) / 64);
         if (fixup_waves < 1) fixup_waves = 1;
 #define VGA_ADX_ENC_T(V, E)                                                                                              \

@@ -179,6 +179,19 @@ int vga_testing_gc_encoder_persistent_this_thread(int mode)
     g_encoder_persistent = mode >= 0 && mode <= 2 ? mode : 0;
     return before;
 }
+int vga_testing_gc_plan_pieces(int cus, int groups, int frames, long long group_frames, int ragged, int *out5)
+{
+    if (!out5 || cus <= 0 || groups <= 0 || frames <= 0) return -1;
+    bool persistent = false;
+    gc::Pieces seg;
+    const int segments = gc::plan_encode_pieces_on(cus, groups, frames, group_frames, ragged != 0, &persistent, &seg);
+    out5[0] = segments;
+    out5[1] = seg.big;
+    out5[2] = seg.nb;
+    out5[3] = seg.small;
+    out5[4] = persistent ? 1 : 0;
+    return 0;
+}
 int vga_testing_hca_frames_per_group_this_thread(int frames)
 {
     const int old = g_hca_frames_per_group;

@@ -1058,6 +1058,7 @@ constexpr int PERSISTENT_ITEMS_PER_WORKGROUP = 4;      // uniform pieces (the te
 constexpr int PERSISTENT_BIG_ROUNDS = 3;       // a workgroup's share of the frames in this many big items ...
 constexpr int PERSISTENT_SMALL_ROUNDS = 2;     // ... followed by this many rounds of short items
 constexpr int PERSISTENT_SMALL_FRAMES = 4096;  // ... of this many frames
+constexpr int MAX_PIECES = 1024;               // what encode_scratch_bytes() and the ragged item list (capi_gcadpcm_v.hip) are sized for
 
 // The piece schedule (see Pieces, gcadpcm_kernels.hpp).  Plain grid: as many equal pieces as put two encoder waves on
 // every SIMD, each at least MIN_PIECE_FRAMES long.  Persistent workgroups: a workgroup's share of the frames in
@@ -1066,8 +1067,13 @@ constexpr int PERSISTENT_SMALL_FRAMES = 4096;  // ... of this many frames
 // 136 ms + d / 2).
 int plan_encode_pieces(int groups, int frames, int64_t group_frames, bool ragged, bool *persistent_out, Pieces *seg_out, int layout)
 {
-    constexpr int CS = 16;
-    const int cus = device_cu_count();
+    return plan_encode_pieces_on(device_cu_count(), groups, frames, group_frames, ragged, persistent_out, seg_out, layout);
+}
+
+// (the schedule as a function of the compute-unit count: no device needed, the CPU suite walks it through
+// vga_testing_gc_plan_pieces)
+int plan_encode_pieces_on(int cus, int groups, int frames, int64_t group_frames, bool ragged, bool *persistent_out, Pieces *seg_out, int layout)
+{
     // persistent workgroups taking (channel group, piece) items from a queue (gc_encode_persistent_kernel) once the batch
     // has enough channel groups; test hook: 1 = never, 2 = always
     const int pmode = encoder_persistent_mode();
@@ -1083,8 +1089,8 @@ int plan_encode_pieces(int groups, int frames, int64_t group_frames, bool ragged
     }
     if (segments > frames / MIN_PIECE_FRAMES) segments = frames / MIN_PIECE_FRAMES;
     if (segments < 1) segments = 1;
-    if (segments > 1024) segments = 1024;
-    if (encoder_segments_override() > 0) segments = imin(imax(frames / 64, 1), encoder_segments_override());   // test hook
+    if (segments > MAX_PIECES) segments = MAX_PIECES;
+    if (encoder_segments_override() > 0) segments = imin(imin(imax(frames / 64, 1), encoder_segments_override()), MAX_PIECES);   // test hook
     Pieces seg;
     seg.big = (frames + segments - 1) / segments;
     seg.nb = segments;
@@ -1093,7 +1099,9 @@ int plan_encode_pieces(int groups, int frames, int64_t group_frames, bool ragged
         (ragged || groups * PERSISTENT_SCHEDULE_GROUPS_FACTOR >= cus * 4)) {
         // (ragged batches, mixed-lengths set of bench.py: 4 rounds 151.7 ms, 3: 158.2, 6: 154.5, 8: 169.5; profiles/r04_a_ragged_schedules.log)
         int big_rounds = ragged ? PERSISTENT_BIG_ROUNDS + 1 : PERSISTENT_BIG_ROUNDS, small_rounds = PERSISTENT_SMALL_ROUNDS, small = PERSISTENT_SMALL_FRAMES;
-        if (const char *e = std::getenv("VGA_HIP_GC_SCHEDULE")) std::sscanf(e, "%d,%d,%d", &big_rounds, &small_rounds, &small);   // tuning (tools/)
+#ifdef VGA_TUNING   // tools/build_variants.sh only: the product never reads its schedule from the environment
+        if (const char *e = std::getenv("VGA_HIP_GC_SCHEDULE")) std::sscanf(e, "%d,%d,%d", &big_rounds, &small_rounds, &small);
+#endif
         small = imax(small, MIN_PIECE_FRAMES);
         big_rounds = imax(big_rounds, 1);
         const int wgs = cus * 4;
@@ -1110,9 +1118,20 @@ int plan_encode_pieces(int groups, int frames, int64_t group_frames, bool ragged
         seg.small = small;
         segments = nb + ns;
         while (segments > 1 && seg.first(segments - 1) >= frames) segments--;
-        if (segments > 1024) segments = 1024;
+        if (segments > MAX_PIECES) {
+            // A long channel in a batch of few groups: the two sizes would need more pieces than the scratch arrays and the
+            // host's item list hold.  Equal pieces instead -- the pieces must COVER the channel (nobody encodes what lies
+            // past seg.first(segments)).
+            segments = MAX_PIECES;
+            seg.big = seg.small = (frames + segments - 1) / segments;
+            seg.nb = segments;
+            while (segments > 1 && seg.first(segments - 1) >= frames) segments--;
+        }
     }
-    (void)CS;
+    if (seg.first(segments) < frames) {                // (cannot happen: every branch above covers; a plan that does not must never launch)
+        std::fprintf(stderr, "vgaudio_hip: piece plan covers %lld of %d frames\n", (long long)seg.first(segments), frames);
+        std::abort();
+    }
     *persistent_out = persistent;
     *seg_out = seg;
     return segments;

@@ -25,6 +25,8 @@ struct Pieces {
 // that take (group, piece) items from a queue (the (channel, predictor) layout only: layout == 8).  Returns the number of
 // pieces the longest channel has.
 int plan_encode_pieces(int groups, int frames, int64_t group_frames, bool ragged, bool *persistent, Pieces *seg, int layout = 8);
+// ... on a device with `cus` compute units (host arithmetic only)
+int plan_encode_pieces_on(int cus, int groups, int frames, int64_t group_frames, bool ragged, bool *persistent, Pieces *seg, int layout = 8);
 
 struct Ragged {
     // the encoder's items (channel group | piece << 20), biggest first, when the host has planned them (ragged batches)
