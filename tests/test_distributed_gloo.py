@@ -128,6 +128,32 @@ def test_launcher_reports_a_failing_rank_and_stops_the_others(tmp_path):
     assert time.monotonic() - t0 < 30
 
 
+def test_launcher_retries_a_taken_rendezvous_port_and_nothing_else(tmp_path):
+    """A deterministic failure of rank 0 is final at the first attempt (round 4's advisor: it used to be run three times
+    when it happened within 15 s); a rendezvous port somebody else holds gives rank 0 the exit code the launcher retries on."""
+    import socket
+    import time
+    from vgaudio_amd.distributed import RENDEZVOUS_PORT_TAKEN, launch_local_ranks
+    marker = tmp_path / "attempts"
+    script = tmp_path / "fail0.py"
+    script.write_text("import os, sys\n"
+                      "if os.environ['RANK'] == '0':\n"
+                      "    open(%r, 'a').write('x')\n    sys.exit(9)\n"
+                      "import time; time.sleep(30)\n" % str(marker))
+    t0 = time.monotonic()
+    assert launch_local_ranks([str(script)], 2, timeout=60) == 9
+    assert marker.read_text() == "x" and time.monotonic() - t0 < 20          # one attempt
+    busy = socket.socket()
+    busy.bind(("127.0.0.1", 0))
+    busy.listen(1)
+    try:
+        script2 = tmp_path / "init.py"
+        script2.write_text("import sys\nsys.path.insert(0, %r)\nfrom vgaudio_amd import distributed as d\nd.init('gloo', timeout_s=20)\n" % ROOT)
+        assert launch_local_ranks([str(script2)], 2, master_port=busy.getsockname()[1], timeout=90) == RENDEZVOUS_PORT_TAKEN
+    finally:
+        busy.close()
+
+
 def test_launcher_passes_rank_zero_stdout_through(tmp_path):
     script = tmp_path / "echo.py"
     script.write_text("import os\nprint('line from rank', os.environ['RANK'], os.environ['LOCAL_RANK'], flush=True)\n")

@@ -317,6 +317,28 @@ def test_adx_ragged_encode_and_decode_match_the_oracle_per_channel():
         assert pcm_out[c][-1] == 0x7777 and np.array_equal(pcm_out[c][:-1], want), (c, lens[c])
 
 
+@pytest.mark.parametrize("kw", [dict(type=4, padding=10), dict(type=2, filter=2, padding=10), dict(padding=33), dict(padding=32)])
+def test_adx_ragged_empty_channels_with_padding_keep_the_skipped_frame_zero(kw):
+    """An empty channel whose padding ends inside a frame: the reference skips that frame (`samplesToCopy == 0`,
+    CriAdxCodec.cs:84) and leaves zeros; a zero-padded run of a longer channel would put silence's header there.  Empty
+    channels therefore never share a bucket with longer ones (round 4's advisor)."""
+    L = _lib.lib()
+    lens = [0, 500, 0, 900, 64, 0, 1000]
+    chans = _channels(lens, first_channel=700)
+    nch = len(lens)
+    params = (_lib.AdxParams * nch)()
+    for c in range(nch):
+        L.vga_adx_default_params(C.byref(params[c]))
+        for k, v in kw.items():
+            setattr(params[c], k, v)
+    counts = np.array(lens, dtype=np.int32)
+    outs = [np.full(L.vga_adx_encoded_byte_count(n, C.byref(params[c])) + 1, 0xEE, dtype=np.uint8) for c, n in enumerate(lens)]
+    _lib.check(L.vga_adx_encode_batch_v(_ptrs(i16p, chans), counts.ctypes.data_as(C.POINTER(C.c_int)), nch, params, _ptrs(u8p, outs), None))
+    for c, pcm in enumerate(chans):
+        want = po.adx_encode(pcm, po.adx_params(**kw))
+        assert outs[c][-1] == 0xEE and np.array_equal(outs[c][:-1], want), (c, lens[c], kw, outs[c][:40].tolist(), want[:40].tolist())
+
+
 def test_adx_ragged_rejects_what_the_reference_rejects():
     L = _lib.lib()
     params = (_lib.AdxParams * 2)()

@@ -304,7 +304,11 @@ int adx_encode_batch_v_one(const int16_t *const *pcm, const int *lengths, int nc
         adx::AdxDeviceParams d;
         memset(&d, 0, sizeof d);
         d = device_params(&params[c], true);
-        group[c] = group_of(dps, d);
+        // An empty channel keeps buckets of its own: with padding % samplesPerFrame != 0 the reference SKIPS the frame in
+        // which the padding ends (`if (samplesToCopy == 0) continue`, CriAdxCodec.cs:84) and leaves zero bytes there, while
+        // the zero-padded run of a longer bucket would encode silence into it (a non-zero header for the Exponential and
+        // Fixed types) -- the one case in which a channel's output is not a prefix of the padded channel's.
+        group[c] = 2 * group_of(dps, d) + (lengths[c] == 0 ? 1 : 0);
         length[c] = lengths[c];
     }
     if (int rc = require_device()) return rc;

@@ -28,6 +28,9 @@ def shard_channels(total_channels, world, rank):
     return first, count
 
 
+RENDEZVOUS_PORT_TAKEN = 98      # exit code of a rank 0 whose rendezvous port was taken (EADDRINUSE): launch_local_ranks tries again
+
+
 def init(backend, device=None, timeout_s=None):
     """timeout_s: how long a collective may wait for a rank that never arrives (default: torch's ten minutes for RCCL)"""
     import datetime
@@ -36,10 +39,21 @@ def init(backend, device=None, timeout_s=None):
     if dist.is_initialized():
         return
     kw = {} if timeout_s is None else {"timeout": datetime.timedelta(seconds=timeout_s)}
-    if backend == "nccl":
-        dist.init_process_group("nccl", device_id=device, **kw)
-    else:
-        dist.init_process_group(backend, **kw)
+    try:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device, **kw)
+        else:
+            dist.init_process_group(backend, **kw)
+    except Exception as e:  # noqa: BLE001 -- only to give ONE failure an exit code of its own, everything else re-raises
+        # rank 0 hosts the rendezvous store: a port somebody else took between launch_local_ranks' look-up and this bind is
+        # the one failure a relaunch on another port cures -- the launcher retries on this exit code and on nothing else
+        text = str(e).lower()
+        if env_world()[0] == 0 and ("address already in use" in text or "eaddrinuse" in text):
+            import sys
+            print("rendezvous port %s is taken: %s" % (os.environ.get("MASTER_PORT"), e), file=sys.stderr, flush=True)
+            sys.stderr.flush()
+            os._exit(RENDEZVOUS_PORT_TAKEN)
+        raise
 
 
 def gather_channel_metadata(local, counts):
@@ -69,8 +83,9 @@ def launch_local_ranks(argv, nproc, master_port=None, extra_env=None, timeout=No
     `grace` seconds after rank 0 had finished cleanly (they are killed; rank 0's line is out by then).
 
     The rendezvous port: when the caller names none, a free loop-back port is looked up and released again before the
-    ranks bind it -- another process can take it in between, so a launch whose rank 0 dies within the first seconds is
-    tried again on another port (twice).  HSA_ENABLE_IPC_MODE_LEGACY=0 is set for the ranks when the caller's environment
+    ranks bind it -- another process can take it in between; rank 0 then leaves with RENDEZVOUS_PORT_TAKEN (init() above)
+    and the launch is tried again on another port (twice).  Any other failure -- an import error, a failed assertion, a
+    digest that differs -- is final at the first attempt.  HSA_ENABLE_IPC_MODE_LEGACY=0 is set for the ranks when the caller's environment
     does not set it: this image's driver only supports dmabuf IPC, and RCCL fails with hipIpcGetMemHandle errors without
     it (the variable is read by the ROCm runtime of the rank processes only; the launcher's own process is not touched)."""
     import socket
@@ -108,7 +123,7 @@ def launch_local_ranks(argv, nproc, master_port=None, extra_env=None, timeout=No
                     rank0_done_at = time.monotonic()
                 if code != 0 and rc == 0:
                     rc = code
-                    early_rank0_failure = p is procs[0] and time.monotonic() - started < 15.0
+                    early_rank0_failure = p is procs[0] and code == RENDEZVOUS_PORT_TAKEN
             straggling = rank0_done_at is not None and time.monotonic() > rank0_done_at + grace
             if rc != 0 or straggling or (deadline is not None and time.monotonic() > deadline):
                 for p in live:
