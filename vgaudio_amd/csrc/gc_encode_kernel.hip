@@ -307,6 +307,10 @@ __device__ __forceinline__ void gc_encode_piece(
 #pragma unroll
             for (int p = 0; p < 8; p++) {
                 int dmax = 0, dmin = 0;
+#ifdef VGA_GC_ABLATE_HELPER_PRESCAN                                  // timing only: what the helper's 96 distances per frame cost the launch
+                dmax = in[2 + p] & 1023;
+                dmin = -(in[3 + p] & 1023);
+#else
 #pragma unroll
                 for (int k = 0; k < 12; k++) {
                     const int predicted = div2048(__builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, pair[k]),
@@ -315,6 +319,7 @@ __device__ __forceinline__ void gc_encode_piece(
                     dmax = imax(dmax, d);
                     dmin = imin(dmin, d);
                 }
+#endif
                 pre[p] = (uint32_t)(clamp16i(dmax) & 0xFFFF) | ((uint32_t)clamp16i(dmin) << 16);
             }
             uint4 *pr = reinterpret_cast<uint4 *>(&T.pre[grp][hfr][0]);
@@ -1065,6 +1070,15 @@ constexpr int MAX_PIECES = 1024;               // what encode_scratch_bytes() an
 // PERSISTENT_BIG_ROUNDS big items followed by PERSISTENT_SMALL_ROUNDS rounds of short ones -- with items of one size d
 // the workgroups end spread over the last d of the launch (152 ms at configs[1] with 16 pieces of 35 ms: mean life
 // 136 ms + d / 2).
+// persistent workgroups per compute unit: four (two encoder waves and a helper on every SIMD)
+static int persistent_wgs_per_cu()
+{
+#ifdef VGA_TUNING   // tools/time_corun.py: fewer workgroups leave registers and LDS for another kernel's waves
+    if (const char *e = std::getenv("VGA_HIP_GC_WGS_PER_CU")) return imin(imax(std::atoi(e), 1), 4);
+#endif
+    return 4;
+}
+
 int plan_encode_pieces(int groups, int frames, int64_t group_frames, bool ragged, bool *persistent_out, Pieces *seg_out, int layout)
 {
     return plan_encode_pieces_on(device_cu_count(), groups, frames, group_frames, ragged, persistent_out, seg_out, layout);
@@ -1104,7 +1118,7 @@ int plan_encode_pieces_on(int cus, int groups, int frames, int64_t group_frames,
 #endif
         small = imax(small, MIN_PIECE_FRAMES);
         big_rounds = imax(big_rounds, 1);
-        const int wgs = cus * 4;
+        const int wgs = cus * persistent_wgs_per_cu();
         const int64_t per_wg = group_frames / wgs + 1;                                      // a workgroup's share of the frames
         int ns = (small_rounds * wgs + groups / 2) / groups;                                // piece indices that make small_rounds rounds of items
         if ((int64_t)ns * small > frames / 2) ns = frames / (2 * small);
@@ -1191,7 +1205,7 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
     }
     if (persistent) {
         const int items = RAGGED && rg.items ? rg.n_items : groups * segments;
-        const int wgs = imin(items, cus * 4);
+        const int wgs = imin(items, cus * persistent_wgs_per_cu());
         if constexpr (CPW == 8)
             hipLaunchKernelGGL((gc_encode_persistent_kernel<CPW, RAGGED>), dim3(wgs), dim3(ENC_THREADS), 0, stream, d_pcm, pcm_pitch, nch,
                                sample_count, seg, d_coefs, d_hist1, d_hist2, d_adpcm, adpcm_pitch, seg_state, rg, groups, segments, queue,
