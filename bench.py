@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-pointer ABI measurement")
     ap.add_argument("--e2e-channels", type=int, default=0, help="channels of the e2e call (0 = as many of --channels as host memory allows)")
     ap.add_argument("--no-mixed", action="store_true", help="gc: skip the mixed-lengths block (ragged batch of files)")
+    ap.add_argument("--no-signals", action="store_true", help="gc: skip the signal_sensitivity block (the step on other signal classes)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="gc: skip the short ADX (configs[2]) and HCA (configs[3]) runs appended to the line as `other_configs`")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -541,6 +542,113 @@ def measure_mixed_lengths(cx, args, equal_length_value):
     return out
 
 
+def measure_signal_sensitivity(cx, args):
+    """The step on signals other than the synthetic generator's (vgaudio_amd/signals.py): the encoders'
+    work depends on the data -- third trips of the retry loop (GcAdpcmEncoder.cs:127-170), how soon the seams between time
+    pieces close -- so every class runs BASELINE configs[1]'s shape device-resident: coefficient search + encode between HIP
+    events, the encoder's own counters (vga_testing_gc_encode_stats: wave-frames that took the cold block, seams closed inside
+    their piece / left to gc_encode_chain_kernel, frames re-encoded by seam runs), the GC-ADPCM decoder and the ADX
+    encoder + decoder on the same rows, and a sample of channels bit for bit against the oracle."""
+    import numpy as np
+    torch, vdev, L, lib = cx.torch, cx.vdev, cx.L, cx.lib
+    from vgaudio_amd import signals
+    nch = args.channels
+    n = int(round(args.seconds * 48000))
+    pcm = vdev.alloc_pcm(nch, n, cx.dev)
+    adpcm = vdev.alloc_adpcm(nch, n, cx.dev)
+    back = vdev.alloc_pcm(nch, n, cx.dev)
+    ws = torch.empty(max(L.vga_gcadpcm_coefs_workspace_bytes(nch, n), 16), dtype=torch.uint8, device=cx.dev)
+    p = lib.AdxParams()
+    L.vga_adx_default_params(C.byref(p))
+    anb = L.vga_adx_encoded_byte_count(n, C.byref(p))
+    apitch = (anb + 15) // 16 * 16
+    adx = torch.zeros((nch, apitch), dtype=torch.uint8, device=cx.dev)
+    hist = torch.zeros(nch, dtype=torch.int16, device=cx.dev)
+    status = torch.zeros(1, dtype=torch.int32, device=cx.dev)
+    nb = vdev.gc_byte_count(n)
+    reps = 2
+    check_channels = 0 if args.no_cpu_baseline else 16
+    threads, _ = usable_cpus()
+    if check_channels:
+        from oracle import pyoracle as po                 # the checker, after the timed launches of each class
+    raw = (C.c_ulonglong * 8)()
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
+    classes = {}
+    for cls in ("synthetic",) + tuple(signals.CLASSES):
+        if cls == "synthetic":
+            vdev.synth_pcm(nch, n, cx.dev, out=pcm)
+        else:
+            signals.device(cls, nch, n, cx.dev, out=pcm)
+        coefs = vdev.gc_coefs(pcm, n, workspace=ws)            # (the first launches on fresh rows: not timed)
+        vdev.gc_encode(pcm, n, coefs, out=adpcm)
+        have_stats = L.vga_testing_gc_encode_stats(None, 1) == 0
+        e = [ev() for _ in range(3 * reps)]
+        for r in range(reps):
+            e[3 * r].record()
+            coefs = vdev.gc_coefs(pcm, n, workspace=ws)
+            e[3 * r + 1].record()
+            vdev.gc_encode(pcm, n, coefs, out=adpcm)
+            e[3 * r + 2].record()
+        torch.cuda.synchronize()
+        coef_ms = min(e[3 * r].elapsed_time(e[3 * r + 1]) for r in range(reps))
+        enc_ms = min(e[3 * r + 1].elapsed_time(e[3 * r + 2]) for r in range(reps))
+        st = None
+        if have_stats and L.vga_testing_gc_encode_stats(raw, 1) == 0:
+            v = [int(x) / reps for x in raw]
+            seams = v[0] + v[1]
+            st = {"cold_block_wave_frame_rate": round(v[4] / v[3], 4) if v[3] else None,
+                  "seams_per_launch": round(seams), "seams_left_to_chain_kernel": round(v[1]),
+                  "channels_walked_by_chain_kernel": round(v[5]),
+                  "frames_reencoded_per_seam": round(v[2] / seams, 1) if seams else None,
+                  "frames_reencoded_frac": round(v[2] / (nch * ((n + 13) // 14)), 5)}
+        a = [ev() for _ in range(4)]
+        a[0].record()
+        vdev.gc_decode(adpcm, coefs, n, out=back)
+        a[1].record()
+        lib.check(L.vga_adx_encode_device(pcm.data_ptr(), pcm.stride(0), nch, n, C.byref(p), adx.data_ptr(), apitch, hist.data_ptr(), cx.st()))
+        a[2].record()
+        lib.check(L.vga_adx_decode_device(adx.data_ptr(), apitch, anb, nch, n, C.byref(p), back.data_ptr(), back.stride(0), status.data_ptr(), cx.st()))
+        a[3].record()
+        # (second pass of the three: the timed one)
+        b = [ev() for _ in range(4)]
+        b[0].record()
+        vdev.gc_decode(adpcm, coefs, n, out=back)
+        b[1].record()
+        lib.check(L.vga_adx_encode_device(pcm.data_ptr(), pcm.stride(0), nch, n, C.byref(p), adx.data_ptr(), apitch, hist.data_ptr(), cx.st()))
+        b[2].record()
+        lib.check(L.vga_adx_decode_device(adx.data_ptr(), apitch, anb, nch, n, C.byref(p), back.data_ptr(), back.stride(0), status.data_ptr(), cx.st()))
+        b[3].record()
+        torch.cuda.synchronize()
+        row = {"coefs_ms": round(coef_ms, 2), "encode_ms": round(enc_ms, 2), "step_ms": round(coef_ms + enc_ms, 2),
+               "gc_decode_ms": round(min(a[0].elapsed_time(a[1]), b[0].elapsed_time(b[1])), 2),
+               "adx_encode_ms": round(min(a[1].elapsed_time(a[2]), b[1].elapsed_time(b[2])), 2),
+               "adx_decode_ms": round(min(a[2].elapsed_time(a[3]), b[2].elapsed_time(b[3])), 2), "encoder": st}
+        if check_channels:
+            idx = torch.linspace(0, nch - 1, check_channels, device=cx.dev).round().to(torch.int64)
+            host = pcm[idx, :n].cpu().numpy()
+            wc, wa = po.gc_encode_batch(host, threads=threads)
+            want_adx, _ = po.adx_encode_batch(host, po.adx_params(), threads=threads)
+            ok = (np.array_equal(coefs[idx].cpu().numpy().reshape(-1, 16), np.asarray(wc).reshape(-1, 16)) and
+                  np.array_equal(adpcm[idx, :nb].cpu().numpy(), np.asarray(wa)[:, :nb]) and
+                  np.array_equal(adx[idx, :anb].cpu().numpy(), want_adx))
+            if not ok:
+                raise SystemExit(f"PARITY FAILURE: signal class {cls}: GPU output differs from the CPU restatement")
+            row["bit_exact_channels_checked"] = check_channels
+        classes[cls] = row
+    base = classes["synthetic"]["step_ms"]
+    for row in classes.values():
+        row["step_vs_synthetic"] = round(row["step_ms"] / base, 3) if base else None
+    worst = max(classes, key=lambda k: classes[k]["step_ms"])
+    return {"what": f"{nch} channels x {n} samples of each signal class (vgaudio_amd/signals.py), device-resident: coefficient "
+                    f"search + encode (best of {reps} after one untimed pass), the encoder's counters per launch, GC-ADPCM decode, "
+                    "ADX encode / decode on the same rows; sampled channels bit for bit against the oracle",
+            "classes": classes, "slowest_class": worst, "slowest_step_vs_synthetic": classes[worst]["step_vs_synthetic"],
+            "no_class_slower_than_1_5x_synthetic": bool(classes[worst]["step_vs_synthetic"] is not None and classes[worst]["step_vs_synthetic"] <= 1.5)}
+
+
 def guarded(cx, line, fn, limit_s=240.0):
     """Runs fn() -- the N > 1 extras, which every rank takes part in -- so that rank 0's result line survives them: an
     exception becomes {"error": ...} in place of fn's result, and on rank 0 (line is not None) a watchdog thread prints
@@ -806,6 +914,14 @@ def run_gc(args, cx):
             raise
         except Exception as e:                          # noqa: BLE001 -- the line is worth more than this block
             out["mixed_lengths"] = {"error": f"{type(e).__name__}: {e}"}
+    if not args.no_signals and cx.world == 1:
+        torch.cuda.empty_cache()
+        try:
+            out["signal_sensitivity"] = measure_signal_sensitivity(cx, args)
+        except SystemExit:
+            raise
+        except Exception as e:                          # noqa: BLE001 -- the line is worth more than this block
+            out["signal_sensitivity"] = {"error": f"{type(e).__name__}: {e}"}
     if not args.no_e2e and cx.world > 1:
         # one process, N GPUs: the same 4096-channel call as the N = 1 line's e2e block, its channels spread over all
         # GPUs of the job by the library (the other ranks are idle at the final barrier meanwhile)

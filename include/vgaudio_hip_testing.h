@@ -42,6 +42,13 @@ int vga_testing_gc_encoder_persistent_this_thread(int mode);
  * piece k begins at frame min(k, nb) * big + max(k - nb, 0) * small.  The pieces must cover `frames`.  Returns 0. */
 int vga_testing_gc_plan_pieces(int cus, int groups, int frames, long long group_frames, int ragged, int *out5);
 
+/* Diagnostics of the GC-ADPCM encoder's data-dependent parts, summed over every launch of the process on the current
+ * device since the last reset (the call synchronises the device first): out8 = {seams closed inside their piece, seams left
+ * open for the chain kernel, frames re-encoded by seam runs, wave-frames encoded, wave-frames that took the cold block
+ * (third trips of the retry loop, GcAdpcmEncoder.cs:127-170), channels the chain kernel walked, pieces encoded, 0}.
+ * reset != 0 clears the counters afterwards.  Returns 0, or -1 when the device cannot be read. */
+int vga_testing_gc_encode_stats(unsigned long long *out8, int reset);
+
 /* The host-pointer entry points (vga_*_batch) move data through a pipeline of feeder threads, pinned rings, per-chunk
  * kernel launches and drainer threads (vgaudio_amd/csrc/host_pipeline.hpp); its shape normally follows the volume of
  * the call.  Non-zero arguments override it for calls made FROM THE CALLING THREAD (0 = automatic): feeder / drainer

@@ -168,6 +168,7 @@ SIGNATURES = {
     "vga_testing_last_pipeline_stats": (ci, [vp, ci]),
     "vga_testing_host_pipeline_tail_this_thread": (None, [ci]),
     "vga_testing_hca_device_info": (ci, [vp, vp, ci]),
+    "vga_testing_gc_encode_stats": (ci, [C.POINTER(C.c_ulonglong), ci]),
     "vga_testing_gc_plan_pieces": (ci, [ci, ci, ci, C.c_longlong, ci, C.POINTER(ci)]),
     "vga_set_devices": (ci, [vp, ci]),
     "vga_set_progress_callback": (ci, [vp, vp]),

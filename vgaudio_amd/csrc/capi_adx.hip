@@ -363,7 +363,7 @@ int adx_encode_batch_v_one(const int16_t *const *pcm, const int *lengths, int nc
     job.d_out = d_out.as<char>();
     job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
         const int k = plan.chunk_of(first);
-        const int rc = adx::launch_encode(d_pcm.as<int16_t>() + pcm_base[k], pcm_pitch[k], count, plan.chunk_length[k], dps[plan.chunk_group[k]],
+        const int rc = adx::launch_encode(d_pcm.as<int16_t>() + pcm_base[k], pcm_pitch[k], count, plan.chunk_length[k], dps[plan.chunk_group[k] / 2],
                                           d_out.as<uint8_t>() + out_base[k], out_pitch[k], d_hist.as<int16_t>() + first, s);
         if (rc) why = vga_last_error();
         return rc;

@@ -81,6 +81,23 @@ extern "C" int vga_debug_encode_timestamps(unsigned long long *out, int n)
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vga_enc_ts), (size_t)n * sizeof(unsigned long long));
 }
 #endif
+// Diagnostics of the data-dependent parts (vga_testing_gc_encode_stats, include/vgaudio_hip_testing.h; bench.py's
+// signal_sensitivity block): counted with a handful of atomics per piece and per seam -- nothing in the frame loop but one
+// scalar add inside the cold block.  Summed over every launch of the process since the last reset.
+//   [0] seams closed inside their piece   [1] seams left open for gc_encode_chain_kernel   [2] frames re-encoded by seam runs
+//   [3] wave-frames encoded by the piece kernels   [4] ... of which took the cold block (third trips / rare / wide)
+//   [5] channels gc_encode_chain_kernel had to walk   [6] pieces encoded
+__device__ unsigned long long g_vga_gc_stats[8];
+extern "C" int vga_testing_gc_encode_stats(unsigned long long *out8, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_vga_gc_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_vga_gc_stats), zero, sizeof zero) != hipSuccess) return -1;
+    }
+    return 0;
+}
 constexpr int SW = 2;              // encoder (serial) waves per workgroup; one helper wave serves them all
 constexpr int ENC_THREADS = 64 * (SW + 1);
 // Two lane layouts of the encoder wave (template parameter CPW = channels per encoder wave):
@@ -373,6 +390,7 @@ __device__ __forceinline__ void gc_encode_piece(
     VGA_OPAQUE(h0);
     VGA_OPAQUE(h1);
 
+    int n_cold = 0;                                    // wave-uniform: cold blocks this piece (diagnostics, g_vga_gc_stats)
     struct Row { int x[16]; int m[14]; int mp[14]; uint32_t pre; };
     auto read_row = [&](const GcTile &T, int j, Row &R) {
         const int4 *xr = reinterpret_cast<const int4 *>(&T.x[grp][j][0]);
@@ -480,7 +498,8 @@ __device__ __forceinline__ void gc_encode_piece(
             VGA_OPAQUE(h1);                      // asks for (the compiler otherwise widens them to 64-bit mads)
         };
         if (__builtin_expect(__any(rare || resume || wide), 0)) {
-            // ---- cold block (third trips: ~10 % of wave-frames on audio; rare: hostile input only)
+            // ---- cold block (third trips: a third of the wave-frames on the synthetic set, LABNOTES 8.4; rare: hostile input only)
+            n_cold++;
             ColdState st;
 #pragma unroll
             for (int i = 0; i < 16; i++) st.x[i] = x[i];
@@ -577,6 +596,7 @@ __device__ __forceinline__ void gc_encode_piece(
             VGA_OPAQUE(h1);
         };
         if (__builtin_expect(__any(rare || resume || wide), 0)) {
+            n_cold++;
             ColdState st;
 #pragma unroll
             for (int i = 0; i < 16; i++) st.x[i] = x[i];
@@ -622,6 +642,11 @@ __device__ __forceinline__ void gc_encode_piece(
         st[0] = (int16_t)h0;
         st[1] = (int16_t)h1;
     }
+    if (lane == 0) {
+        atomicAdd(&g_vga_gc_stats[3], (unsigned long long)frames_wg);
+        atomicAdd(&g_vga_gc_stats[4], (unsigned long long)n_cold);
+        if (wave == 0) atomicAdd(&g_vga_gc_stats[6], 1ull);
+    }
 #ifdef VGA_DEBUG_TIMESTAMPS
     if (!repair && tid == 0 && gridDim.y != 1) g_vga_enc_ts[2 * ((blockIdx.y * gridDim.x + blockIdx.x) & 32767) + 1] = wall_clock64();
 #endif
@@ -653,7 +678,7 @@ __device__ __forceinline__ void store_frame_bytes(uint8_t *dst, uint32_t d0, uin
 // open == true when the piece ended first; (h0, h1) is then the true history at the piece's end.
 __device__ __forceinline__ void seam_run(const int16_t *__restrict__ src, uint8_t *__restrict__ dst, int c0, int c1, bool coef_ok,
                                          int pr, int ch, int k, int64_t f0, int total_samples, int piece_frames, int max_frames, int force_open,
-                                         int &h0, int &h1, int g2, int g1, bool &open)
+                                         int &h0, int &h1, int g2, int g1, bool &open, int &frames_run)
 {
     const int full_frames = total_samples / 14;
     // The frame loop is one wave's dependent chain (nothing else runs on its SIMD for long: the slowest seam IS the
@@ -676,6 +701,7 @@ __device__ __forceinline__ void seam_run(const int16_t *__restrict__ src, uint8_
         const bool in_range = f < f_end;
         if (!__any(open && in_range)) break;
         const bool act = open && in_range;
+        frames_run += act ? 1 : 0;
         fetch(f + 1, wn, oldn);                         // in flight during this frame
         int x[16], m[14], mp[14];
         x[0] = h0;
@@ -858,10 +884,13 @@ __device__ __forceinline__ void seam_piece(
     int h1 = valid ? seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1] : 0;
     const int g2 = valid ? src[f0 * 14 - 2] : 0, g1 = valid ? src[f0 * 14 - 1] : 0;   // the guessed run's history (g1 = newest)
     bool open = valid;                                  // uniform inside a group of eight
-    seam_run(src, dst, c0, c1, coef_ok, pr, ch, k, f0, total_samples, seg.frames(k), seg.frames(k), force_open, h0, h1, g2, g1, open);
+    int frames_run = 0;
+    seam_run(src, dst, c0, c1, coef_ok, pr, ch, k, f0, total_samples, seg.frames(k), seg.frames(k), force_open, h0, h1, g2, g1, open, frames_run);
     // still open at the piece's end (half the seams close within nine frames, one in a hundred needs more than 400, a
     // few channels never meet)
     if (valid && pr == 0) {
+        atomicAdd(&g_vga_gc_stats[open ? 1 : 0], 1ull);
+        atomicAdd(&g_vga_gc_stats[2], (unsigned long long)frames_run);
         seam_flag[(int64_t)(k - 1) * nch + ch] = open ? 1 : 0;
         if (open) {
             seam_end[(int64_t)(k - 1) * nch + ch] = (int)(((unsigned)h1 << 16) | ((unsigned)h0 & 0xFFFFu));
@@ -989,6 +1018,8 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) kmin = imin(kmin, __shfl_xor(kmin, o));
     if (kmin >= segments) return;                       // no open seam among these eight channels
+    if (live && pr == 0 && mine < segments) atomicAdd(&g_vga_gc_stats[5], 1ull);
+    int frames_run = 0;
     const int16_t *src = pcm + (rg.order ? rg.pcm_off[ch] : (int64_t)ch * pcm_pitch);
     uint8_t *dst = adpcm + (rg.order ? rg.adpcm_off[ch] : (int64_t)ch * adpcm_pitch);
     const int16_t *cf = coefs + ch * 16;
@@ -1017,7 +1048,7 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
                 seg_state[idx * 2] = (int16_t)v0;
                 seg_state[idx * 2 + 1] = (int16_t)v1;
             }
-            seam_run(src, dst, c0, c1, coef_ok, pr, ch, k, f0, total_samples, seg.frames(k), seg.frames(k), force_open, h0, h1, g2, g1, open);
+            seam_run(src, dst, c0, c1, coef_ok, pr, ch, k, f0, total_samples, seg.frames(k), seg.frames(k), force_open, h0, h1, g2, g1, open, frames_run);
         }
         if (!exists) {
         } else if (ran && open) {                       // still apart at the piece's end: carry on into the next one
@@ -1035,6 +1066,7 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
     if (__any(live && have && total_samples % 14 != 0))
         encode_tail_frame(src, dst, c0, c1, coef_ok, pr, total_samples, v0, v1, live && have && total_samples % 14 != 0);
     (void)last_k;
+    if (live && pr == 0 && frames_run) atomicAdd(&g_vga_gc_stats[2], (unsigned long long)frames_run);
     if (live && pr == 0) first_open[ch] = 0x7f7f7f7f;
 }
 
