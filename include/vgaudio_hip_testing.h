@@ -12,7 +12,9 @@ extern "C" {
 /* GC-ADPCM encode/decode and ADX encode/decode cut long channels into time segments that run side by side and
  * close the seams afterwards (LABNOTES.md 4.3).  mode = 1: calls made FROM THE CALLING THREAD never accept a seam
  * as closed; 2: only the even seams of every third channel are kept open (a mix of open and closed seams inside
- * one workgroup); 0: normal operation.  The serial fall-backs then produce the output, which must not change.
+ * one workgroup); 3: every seam, and the decoders count them as seams that would not close, so that their REPAIR launch
+ * (one piece per wave from the first open seam on; round 5) produces the output instead of the chained tail kernel;
+ * 0: normal operation.  The serial fall-backs then produce the output, which must not change.
  * The setting is thread-local (no other thread's calls see it) and is passed to the kernels as a launch argument.
  * Returns the calling thread's previous mode. */
 int vga_testing_force_open_seams_this_thread(int mode);

@@ -38,6 +38,21 @@ int emu_compare_pass(const int16_t *x16, int c0, int c1, int scale_power)
     return same ? 0 : 1;
 }
 
+// the 64-bit-sum form of the fast pass (the kernel's cold block, round 5) against the literal pass: whatever the overflow,
+// as long as the coefficients cannot wrap int32.  Returns 0 ok, 1 mismatch, 2 not exact (coefficients too large)
+int emu_compare_pass_wide(const int16_t *x16, int c0, int c1, int scale_power)
+{
+    int x[16], m[14], mp[14];
+    for (int i = 0; i < 16; i++) x[i] = x16[i];
+    for (int s = 0; s < 14; s++) { m[s] = x[s + 2] * 2048; mp[s] = m[s] + 1024; }
+    const PassOut f = pass_fast_core_wide(x, m, mp, c0, c1, scale_power);
+    if (!f.exact) return 2;
+    const PassOut l = pass_literal(x, c0, c1, scale_power);
+    bool same = f.total == l.total && f.max_overflow == l.max_overflow && f.o12 == l.o12 && f.o13 == l.o13;
+    for (int s = 0; s < 14; s++) same = same && f.q[s] == l.q[s];
+    return same ? 0 : 1;
+}
+
 // stats[0] frames, [1] lanes whose fast pass was inexact, [2] pairs resolved by A, [3] by B,
 // [4] pairs needing resume, [5] pre-scan ties, [6] frames taking the 64-bit argmin path
 int emu_encode(const int16_t *pcm, int sample_count, const int16_t *coefs, int16_t hist1, int16_t hist2,
@@ -98,6 +113,103 @@ int emu_encode(const int16_t *pcm, int sample_count, const int16_t *coefs, int16
         memcpy(out + (size_t)f * 8, frame, (size_t)nbytes);
         x[0] = best.o12;
         x[1] = best.o13;
+    }
+    return 0;
+}
+
+// The (channel, predictor) layout's frame as the kernel resolves it since round 5 (encode_frame8 + encode_frame_cold in
+// gc_encode_kernel.hip): both candidate passes, then per lane -- the bump loop entered (the reference's loop as written from
+// the scale it moves to), hostile coefficients (the whole loop), a final pass at the cap that overflowed by more than 3 (same
+// pass, 64-bit sum), third trips -- and the argmin over keys that saturate at 2^28 with the 64-bit keys as fall-back.
+// stats: [0] frames [1] generic lanes [2] inexact-sum lanes [3] resume lanes [4] frames whose best key saturated
+int emu_encode8(const int16_t *pcm, int sample_count, const int16_t *coefs, int16_t hist1, int16_t hist2, uint8_t *out, uint64_t *stats)
+{
+    int x[16];
+    x[0] = hist2;
+    x[1] = hist1;
+    const int full_frames = sample_count / 14;
+    const int tail = sample_count - full_frames * 14;
+    const int frames = full_frames + (tail ? 1 : 0);
+    for (int f = 0; f < frames; f++) {
+        for (int s = 0; s < 14; s++) {
+            const int idx = f * 14 + s;
+            x[2 + s] = idx < sample_count ? pcm[idx] : 0;
+        }
+        stats[0]++;
+        int m[14], mp[14];
+        for (int s = 0; s < 14; s++) { m[s] = x[s + 2] * 2048; mp[s] = m[s] + 1024; }
+        PassOut fin[8];
+        int fin_sp[8];
+        for (int p = 0; p < 8; p++) {
+            const int c0 = coefs[2 * p], c1 = coefs[2 * p + 1];
+            const bool coef_ok = (c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1) <= 32767;
+            int dmax = 0, dmin = 0;
+            prescan_range(x, c0, c1, 0, 14, dmax, dmin);
+            int s1 = first_scale_power_from_range(dmax, dmin);
+            if (s1 == -100) s1 = first_scale_power_from_md(prescan_sequential(x, c0, c1));
+            const int sp_a = imin(s1, 12), sp_b = imin(s1 + 1, 12);
+            const PassOut rb = pass_fast_core(x, m, mp, c0, c1, sp_b), ra = pass_fast_core(x, m, mp, c0, c1, sp_a);
+            const bool cap_a = sp_a >= 12, cap_b = sp_b >= 12;
+            const int eff_a = cap_a ? 0 : ra.max_overflow, eff_b = cap_b ? 0 : rb.max_overflow;
+            const bool fin_a = eff_a < 2;
+            const bool bump_a = !cap_a && (unsigned)ra.max_overflow > 248u;
+            const bool bump_b = !fin_a && !cap_b && (unsigned)rb.max_overflow > 248u;
+            const bool generic = !coef_ok || bump_a || bump_b;
+            const bool inexact = !generic && (fin_a ? (cap_a && (unsigned)ra.max_overflow > 3u) : (cap_b && (unsigned)rb.max_overflow > 3u));
+            const bool resume = !generic && !fin_a && eff_b >= 2;
+            PassOut r = fin_a ? ra : rb;
+            int fsp = fin_a ? sp_a : sp_b;
+            if (generic) {
+                const int start = !coef_ok ? s1 - 1 : (bump_a ? apply_bumps(s1, ra.max_overflow) : apply_bumps(s1 + 1, rb.max_overflow));
+                r = resume_passes(x, c0, c1, start, fsp);
+                stats[1]++;
+            }
+            if (inexact) {
+                const PassOut w = pass_fast_core_wide(x, m, mp, c0, c1, fsp);
+                r.total = w.total;
+                stats[2]++;
+            }
+            if (resume) {
+                int sp = s1 + 1;
+                for (;;) {
+                    sp++;
+                    r = pass_fast_core(x, m, mp, c0, c1, sp);
+                    const bool cap = sp >= 12;
+                    if ((unsigned)r.max_overflow > (cap ? 3u : 248u)) { r = resume_passes(x, c0, c1, sp - 1, fsp); break; }
+                    fsp = sp;
+                    if (cap || r.max_overflow <= 1) break;
+                }
+                stats[3]++;
+            }
+            fin[p] = r;
+            fin_sp[p] = fsp;
+        }
+        const unsigned SAT = (1u << 28) - 1;
+        unsigned best32 = 0xFFFFFFFFu;
+        for (int p = 0; p < 8; p++) {
+            const unsigned tot = (fin[p].total >> 32) ? SAT : ((unsigned)fin[p].total < SAT ? (unsigned)fin[p].total : SAT);
+            const unsigned key = (tot << 3) | (unsigned)p;
+            if (key < best32) best32 = key;
+        }
+        int winner = (int)(best32 & 7u);
+        if ((best32 >> 3) >= SAT) {
+            stats[4]++;
+            uint64_t best = ~0ull;
+            for (int p = 0; p < 8; p++) {
+                const uint64_t key = (fin[p].total << 3) | (uint64_t)p;
+                if (key < best) best = key;
+            }
+            winner = (int)(best & 7u);
+        }
+        uint8_t frame[8];
+        uint32_t d0, d1;
+        frame_words(fin[winner], winner, fin_sp[winner], d0, d1);
+        memcpy(frame, &d0, 4);
+        memcpy(frame + 4, &d1, 4);
+        const int nbytes = f < full_frames ? 8 : (tail + 2 + 1) / 2;
+        memcpy(out + (size_t)f * 8, frame, (size_t)nbytes);
+        x[0] = fin[winner].o12;
+        x[1] = fin[winner].o13;
     }
     return 0;
 }

@@ -98,7 +98,7 @@ def test_ragged_with_per_channel_history():
         assert np.array_equal(back[c], po.gc_decode(adpcm[c], coefs[c], lens[c], hist1=int(h1[c]), hist2=int(h2[c]))), c
 
 
-@pytest.mark.parametrize("force_open", [0, 1, 2])
+@pytest.mark.parametrize("force_open", [0, 1, 2, 3])
 def test_ragged_many_pieces_and_open_seams(force_open):
     """few long channels next to many short ones: the long ones are cut into many time pieces; with the seam hook every
     seam (or every other one) is refused, so the chain / tail paths produce the output"""

@@ -98,3 +98,35 @@ def test_adx_full_batch_of_a_signal_class_matches_the_oracle(cls):
     assert bad.size == 0, (cls, "channels", idx.cpu().numpy()[bad][:8].tolist())
     assert np.array_equal(hist[idx].cpu().numpy(), whist), cls
     assert np.array_equal(dec[idx, :N].cpu().numpy(), po.adx_decode_batch(want, N, po.adx_params(), threads=THREADS)), cls
+
+
+@pytest.mark.parametrize("nch,n,pieces", [(70, 14 * 9000 + 5, 12), (130, 14 * 20000, 0), (64, 14 * 4096 * 3 + 13, 5)])
+@pytest.mark.parametrize("mode", [0, 3])
+def test_gc_decoder_repair_launch_on_seams_that_never_close(nch, n, pieces, mode):
+    """Pure tones (mode 0: the 440 Hz sine's predictor has its poles on the unit circle, a run from a wrong history never falls
+    into step) and any signal with the hook's mode 3 (every seam refused and counted): the decoder's REPAIR launch -- the
+    affected waves decoded again as one piece -- produces the samples.  The oracle's, sample for sample."""
+    d = torch.device("cuda:0")
+    L = _lib.lib()
+    host = signals.host("sine440", nch, n) if mode == 0 else np.ascontiguousarray(po.synth_generate(nch, n, first_channel=60))
+    pcm = vdev.alloc_pcm(nch, n, d)
+    pcm[:, :n] = torch.from_numpy(host).to(d)
+    coefs = vdev.gc_coefs(pcm, n)
+    adpcm = vdev.gc_encode(pcm, n, coefs)
+    torch.cuda.synchronize()
+    nb = vdev.gc_byte_count(n)
+    wc, wa = po.gc_encode_batch(host, threads=THREADS)
+    assert np.array_equal(adpcm[:, :nb].cpu().numpy(), np.asarray(wa)[:, :nb])
+    want = po.gc_decode_batch(np.asarray(wa)[:, :nb], np.asarray(wc).reshape(nch, 16), n, threads=THREADS)
+    L.vga_testing_gc_encoder_segments_this_thread(pieces)
+    old = L.vga_testing_force_open_seams_this_thread(mode)
+    try:
+        dec, status = vdev.gc_decode(adpcm, coefs, n)
+        torch.cuda.synchronize()
+    finally:
+        L.vga_testing_force_open_seams_this_thread(old)
+        L.vga_testing_gc_encoder_segments_this_thread(0)
+    assert int(status.item()) == 0
+    got = dec[:, :n].cpu().numpy()
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, (bad[:8].tolist(), int(np.nonzero(got[bad[0]] != want[bad[0]])[0][0]))

@@ -27,6 +27,7 @@ def emu():
     L.emu_encode.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int16, C.c_int16,
                              C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]
     L.emu_compare_pass.argtypes = [C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int]
+    L.emu_compare_pass_wide.argtypes = [C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int]
     return L
 
 
@@ -42,6 +43,81 @@ def _emu_encode(L, pcm, coefs, h1=0, h2=0):
 
 def test_halvings_closed_form_exhaustive(emu):
     assert emu.emu_check_halvings() == 0
+
+
+@pytest.mark.parametrize("cls", ["synthetic", "sine440", "white_full_scale", "noise_3lsb", "silence", "clipped_square", "slow_channel_93"])
+def test_frame_resolution_of_the_channel_predictor_layout_on_every_signal_class(emu, cls):
+    """the kernel's round-5 control flow (per-lane bump / hostile / inexact-sum / third-trip handling, saturating argmin keys)
+    restated on the host against the oracle, on the signal classes that exercise each branch"""
+    from vgaudio_amd import signals
+    emu.emu_encode8.argtypes = emu.emu_encode.argtypes
+    n = 14 * 3000 + 5
+    seen = np.zeros(8, np.uint64)
+    for ch in (0, 17, 93):
+        pcm = (synth.generate(1, n, first_channel=ch) if cls == "synthetic" else signals.host(cls, 1, n, first_channel=ch))[0]
+        coefs = po.gc_calculate_coefficients(pcm)
+        want = po.gc_encode(pcm, coefs)
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        co = np.ascontiguousarray(coefs, np.int16)
+        out = np.zeros(po.gc_sample_count_to_byte_count(len(pcm)), np.uint8)
+        stats = np.zeros(8, np.uint64)
+        emu.emu_encode8(pcm.ctypes.data_as(C.POINTER(C.c_int16)), len(pcm), co.ctypes.data_as(C.POINTER(C.c_int16)), 0, 0,
+                        out.ctypes.data_as(C.POINTER(C.c_uint8)), stats.ctypes.data_as(C.POINTER(C.c_uint64)))
+        bad = np.flatnonzero(out != want)
+        assert bad.size == 0, (cls, ch, "first differing byte", int(bad[0]), stats.tolist())
+        seen += stats
+    if cls == "sine440":
+        assert seen[1] > 0            # the bump loop is entered
+    if cls in ("white_full_scale", "clipped_square"):
+        assert seen[2] > 0            # final passes at the cap with an overflow above 3
+    if cls == "synthetic":
+        assert seen[3] > 0            # third trips
+
+
+def test_hostile_coefficients_and_rail_to_rail_frames_through_the_same_resolution(emu):
+    emu.emu_encode8.argtypes = emu.emu_encode.argtypes
+    rng = np.random.default_rng(11)
+    seen = np.zeros(8, np.uint64)
+    for trial in range(12):
+        n = 14 * 400 + int(rng.integers(0, 14))
+        pcm = (rng.integers(-32768, 32768, n) if trial % 2 else np.where(rng.integers(0, 2, n) > 0, 32767, -32768)).astype(np.int16)
+        coefs = rng.integers(-32768, 32768, 16).astype(np.int16) if trial % 3 == 0 else rng.integers(-6000, 6000, 16).astype(np.int16)
+        want = po.gc_encode(pcm, coefs)
+        out = np.zeros(po.gc_sample_count_to_byte_count(n), np.uint8)
+        stats = np.zeros(8, np.uint64)
+        emu.emu_encode8(pcm.ctypes.data_as(C.POINTER(C.c_int16)), n, coefs.ctypes.data_as(C.POINTER(C.c_int16)), 0, 0,
+                        out.ctypes.data_as(C.POINTER(C.c_uint8)), stats.ctypes.data_as(C.POINTER(C.c_uint64)))
+        bad = np.flatnonzero(out != want)
+        assert bad.size == 0, (trial, int(bad[0]), stats.tolist())
+        seen += stats
+    assert seen[1] > 0 and seen[2] > 0 and seen[4] > 0, seen.tolist()
+
+
+def test_wide_sum_pass_equals_literal_whatever_the_overflow(emu):
+    """the cold block's pass for a final pass at the cap that overflowed by more than 3 (loud noise, clipped waves: the
+    32-bit error sum of the fast pass may have wrapped): every scale, rail-to-rail frames, any coefficients that cannot wrap"""
+    rng = np.random.default_rng(7)
+    checked = big = 0
+    for trial in range(40000):
+        kind = trial % 4
+        if kind == 0:
+            x = rng.integers(-32768, 32768, 16).astype(np.int16)
+        elif kind == 1:
+            x = np.where(rng.integers(0, 2, 16) > 0, 32767, -32768).astype(np.int16)
+        elif kind == 2:
+            x = (32767 * np.sign(np.sin(np.arange(16) * rng.uniform(0.05, 3.0) + rng.uniform(0, 6.3)))).astype(np.int16)
+        else:
+            x = rng.integers(-3000, 3000, 16).astype(np.int16)
+        c0 = int(rng.integers(-16384, 16384))
+        c1 = int(rng.integers(-(32767 - abs(c0)), 32767 - abs(c0) + 1))
+        sp = int(rng.integers(0, 13)) if trial % 3 else 12
+        rc = emu.emu_compare_pass_wide(x.ctypes.data_as(C.POINTER(C.c_int16)), c0, c1, sp)
+        assert rc == 0, (x.tolist(), c0, c1, sp, rc)
+        checked += 1
+    assert checked == 40000
+    # and coefficients that can wrap are refused
+    x = rng.integers(-32768, 32768, 16).astype(np.int16)
+    assert emu.emu_compare_pass_wide(x.ctypes.data_as(C.POINTER(C.c_int16)), 30000, 30000, 12) == 2
 
 
 def test_fast_pass_equals_literal_when_it_claims_exactness(emu):

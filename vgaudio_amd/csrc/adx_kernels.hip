@@ -248,22 +248,42 @@ __global__ __launch_bounds__(64) void adx_decode_kernel(
 // skips it takes 7.7 ms: the kernel is bound by its stores -- 23.6 GB at 3.0 TB/s, 43 % of what a plain fill reaches on
 // this box (tools/bench_fill.py): 65 536 slow sequential streams, one per channel and piece (LABNOTES.md 4.3).
 constexpr int ADX_DECODE_WARM_FRAMES = 512;           // even: a piece's frames keep their alignment
+constexpr int ADX_DECODE_SLOW_SEAM = 1024;            // frames a seam may stay open before it counts as slow (a multiple of 128)
 template <bool V4>
 __global__ __launch_bounds__(64) void adx_decode_fs18_direct_kernel(
     const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, AdxDeviceParams p,
-    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ status)
+    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ status, const int *__restrict__ first_open,
+    const int *__restrict__ slow_seams)
 {
-    const int64_t first_frame = (int64_t)blockIdx.y * seg_frames;          // even (seg_frames is)
+    const int ch_raw = blockIdx.x * 64 + threadIdx.x;
+    const bool live = ch_raw < nch;
+    const int ch = live ? ch_raw : nch - 1;
+    // REPAIR launch (first_open != nullptr; round 5, as gc_decode_direct_kernel's): many seams of the batch would not close
+    // (tones, clipped waves); the wave decodes its 64 channels again as one piece from the first piece any of them left
+    // open, from the samples before it.
+    const bool repair = first_open != nullptr;
+    int repair_piece = 0;
+    if (repair) {
+        if (slow_seams[0] < slow_seams[1]) return;                        // few: adx_decode_fs18_tail_kernel has them
+        int k = live ? first_open[ch] : 0x7f000000;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) k = min(k, __shfl_xor(k, o));
+        if (k <= 0 || k >= 0x7f000000) return;
+        repair_piece = k;
+    }
+    const int64_t first_frame = (int64_t)(repair ? repair_piece : (int)blockIdx.y) * seg_frames;   // even (seg_frames is)
+    if (repair) seg_frames = 0x7fffff00 / 32;                              // ... to the end of the stream
     if (first_frame * 32 >= total_samples) return;
     const int sample_count = (int)((int64_t)total_samples - first_frame * 32 < (int64_t)seg_frames * 32
                                        ? (int64_t)total_samples - first_frame * 32 : (int64_t)seg_frames * 32);
     const int frame_count = (sample_count + 31) / 32;
-    const int ch_raw = blockIdx.x * 64 + threadIdx.x;
-    const bool live = ch_raw < nch;
-    const int ch = live ? ch_raw : nch - 1;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(adpcm + (int64_t)ch * in_pitch + first_frame * 18);
     int16_t *dst = pcm + (int64_t)ch * pcm_pitch + first_frame * 32;
     int hist1 = blockIdx.y > 0 ? 0 : p.history, hist2 = hist1;             // later pieces: the guess (0, 0)
+    if (repair) {
+        hist1 = dst[-1];
+        hist2 = dst[-2];
+    }
     bool bad = false;
     // Output: lane = channel holds one 64-byte line per frame; stored as it is, every store instruction would touch 64
     // rows, 16 bytes of each (measured: 20 of the kernel's 23 ms).  TURN frames of every channel (TURN x 64 contiguous
@@ -352,7 +372,7 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_direct_kernel(
     // piece itself starts from a history that has, as a rule, already fallen into step with the true run (the decoder
     // forgets a wrong history within 2000 samples on audio): its seam then closes on the first frame the fix-up launch
     // checks (15 seams per channel at configs[2]: 3.7 ms of fix-up without this, against 7.9 ms for the decode itself)
-    if (blockIdx.y > 0) {
+    if (!repair && blockIdx.y > 0) {
         const int warm = (int)(first_frame < ADX_DECODE_WARM_FRAMES ? first_frame : ADX_DECODE_WARM_FRAMES);      // even
         const uint32_t *wsrc = src - (int64_t)warm / 2 * 9;
 #pragma unroll 1
@@ -456,7 +476,8 @@ __device__ __forceinline__ void adx_decode_frame_serial(const uint8_t *fr, const
 template <bool V4>
 __global__ __launch_bounds__(64) void adx_decode_fs18_fixup_kernel(
     const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, AdxDeviceParams p,
-    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ first_open, int *__restrict__ seam_open, int force_open)
+    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ first_open, int *__restrict__ seam_open, int force_open,
+    int *__restrict__ slow_seams)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     const int k = blockIdx.y + 1;
@@ -468,6 +489,11 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_fixup_kernel(
     // (gc_decode_kernel.hip): a seam that closes leaves the piece's last samples with the values they already hold,
     // one that stays open hands pieces k.. to the tail kernel, which redoes them from the final samples.
     int hist1 = dst[f0 * 32 - 1], hist2 = dst[f0 * 32 - 2];
+    // (round 5, as gc_decode_fixup_kernel: a seam still open after ADX_DECODE_SLOW_SEAM frames counts as slow; once the batch
+    // holds slow_seams[1] of them the lanes give up and the REPAIR launch of the direct kernel decodes from their pieces on)
+    int walked = 0;
+    bool counted = false, gave_up = false;
+    const bool countable = !seam_forced_open(force_open, ch, k) || force_open == 3;
     for (int64_t f = f0; f < f0 + seg_frames && f * 32 < total_samples; f++) {
         const int valid = (int)((int64_t)total_samples - f * 32 < 32 ? (int64_t)total_samples - f * 32 : 32);
         int16_t *o = dst + f * 32;
@@ -476,9 +502,20 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_fixup_kernel(
         adx_decode_frame_serial<V4>(src + f * 18, p, valid, hist1, hist2, o);
         if (valid == 32 && hist1 == g1 && hist2 == g2 && !seam_forced_open(force_open, ch, k)) return;
         if (valid < 32) return;                         // the stream's last, partial frame: nothing follows
+        if (++walked == ADX_DECODE_SLOW_SEAM && countable) {
+            atomicAdd(&slow_seams[0], 1);
+            counted = true;
+        }
+        if (walked >= ADX_DECODE_SLOW_SEAM && (walked & 127) == 0 &&
+            __hip_atomic_load(&slow_seams[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= slow_seams[1]) {
+            gave_up = true;
+            break;
+        }
     }
-    if (f0 + seg_frames < ((int64_t)total_samples + 31) / 32) {   // open, and a piece follows
-        seam_open[(int64_t)(k - 1) * nch + ch] = 1;
+    const bool piece_follows = f0 + seg_frames < ((int64_t)total_samples + 31) / 32;
+    if (!counted && piece_follows && countable) atomicAdd(&slow_seams[0], 1);
+    if (piece_follows || gave_up) {                     // open (and a piece follows), or this piece itself is left unfinished
+        if (piece_follows) seam_open[(int64_t)(k - 1) * nch + ch] = 1;
         atomicMin(&first_open[ch], k);
     }
 }
@@ -491,10 +528,11 @@ template <bool V4>
 __global__ __launch_bounds__(64) void adx_decode_fs18_tail_kernel(
     const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, int segments, AdxDeviceParams p,
     int16_t *__restrict__ pcm, int64_t pcm_pitch, const int *__restrict__ first_open, const int *__restrict__ seam_open,
-    int force_open)
+    int force_open, const int *__restrict__ slow_seams)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= nch) return;
+    if (slow_seams[0] >= slow_seams[1]) return;         // many seams that would not close: the REPAIR launch has them
     const int k0 = first_open[ch];
     if (k0 <= 0 || k0 >= 0x7f000000) return;
     const uint8_t *src = adpcm + (int64_t)ch * in_pitch;
@@ -1084,28 +1122,36 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
         int seg_frames = (frames + segments - 1) / segments;
         seg_frames += seg_frames & 1;
         AsyncBuf scratch;                              // freed (stream-ordered) on every exit path
-        int *first_open = nullptr, *seam_open = nullptr;
+        int *first_open = nullptr, *seam_open = nullptr, *slow_seams = nullptr;
         if (segments > 1) {
             const size_t flag_bytes = (size_t)(segments - 1) * nch * sizeof(int);
-            VGA_HIP_TRY(scratch.alloc((size_t)nch * sizeof(int) + flag_bytes, stream));
+            VGA_HIP_TRY(scratch.alloc((size_t)nch * sizeof(int) + flag_bytes + 16, stream));
             first_open = scratch.as<int>();
             seam_open = first_open + nch;
+            slow_seams = seam_open + (size_t)(segments - 1) * nch;         // [0] seams that stayed open, [1] how many make "many"
             VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
-            VGA_HIP_TRY(hipMemsetAsync(seam_open, 0, flag_bytes, stream));
+            VGA_HIP_TRY(hipMemsetAsync(seam_open, 0, flag_bytes + 16, stream));
+            const int many = (int)std::min<int64_t>(0x7fffffff, std::max<int64_t>(8, (int64_t)nch * (segments - 1) / 64));   // (gc_decode_kernel.hip)
+            VGA_HIP_TRY(hipMemcpyAsync(slow_seams + 1, &many, sizeof(int), hipMemcpyHostToDevice, stream));
         }
 #define VGA_ADX_DEC_T(V)                                                                                                 \
         {                                                                                                                \
             hipLaunchKernelGGL(adx_decode_fs18_direct_kernel<V>, dim3(groups, segments), dim3(64), 0, stream, d_adpcm,   \
-                               in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status);                  \
+                               in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status, (const int *)nullptr, \
+                               (const int *)nullptr);                                                                    \
             VGA_HIP_TRY(hipGetLastError());                                                                              \
             if (segments > 1) {                                                                                          \
                 hipLaunchKernelGGL(adx_decode_fs18_fixup_kernel<V>, dim3(groups, segments - 1), dim3(64), 0, stream,    \
                                    d_adpcm, in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, first_open,   \
-                                   seam_open, force_open_seams());                                                      \
+                                   seam_open, force_open_seams(), slow_seams);                                          \
                 VGA_HIP_TRY(hipGetLastError());                                                                          \
                 hipLaunchKernelGGL(adx_decode_fs18_tail_kernel<V>, dim3(groups), dim3(64), 0, stream, d_adpcm, in_pitch, \
                                    nch, sample_count, seg_frames, segments, p, d_pcm, pcm_pitch, first_open, seam_open,  \
-                                   force_open_seams());                                                                  \
+                                   force_open_seams(), (const int *)slow_seams);                                        \
+                VGA_HIP_TRY(hipGetLastError());                                                                          \
+                hipLaunchKernelGGL(adx_decode_fs18_direct_kernel<V>, dim3(groups, 1), dim3(64), 0, stream, d_adpcm,      \
+                                   in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status,               \
+                                   (const int *)first_open, (const int *)slow_seams);                                   \
             }                                                                                                            \
         }
         if (p.version == 4) VGA_ADX_DEC_T(true)

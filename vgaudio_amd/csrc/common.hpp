@@ -226,7 +226,8 @@ inline int device_cu_count()
 
 // test hook (vga_testing_force_open_seams_this_thread, include/vgaudio_hip_testing.h): the seam kernels of the time-segmented codecs then never accept a seam as
 // closed, so that their fall-back (re-computing the rest of the channel serially) is what produces the output
-int force_open_seams();          // 0 = off, 1 = every seam, 2 = seams with an even index of every third channel
+int force_open_seams();          // 0 = off, 1 = every seam, 2 = seams with an even index of every third channel, 3 = every seam, and the
+                                 // decoders count them as seams that would not close (their REPAIR launch takes over)
 
 // lane layout of the GC-ADPCM encoder wave (gc_encode_kernel.hip): 8 = (channel, predictor); 4 = (channel, predictor,
 // candidate); 0 = the launcher's choice (4 for batches too small for persistent workgroups, 8 otherwise).  Thread-local
@@ -240,7 +241,7 @@ int hca_frames_per_group_override();   // > 0: frames per workgroup of hca_frame
 // the per-(channel, seam) reading of that mode inside the seam kernels
 __host__ __device__ inline bool seam_forced_open(int mode, int channel, int seam)
 {
-    return mode == 1 || (mode == 2 && channel % 3 == 0 && seam % 2 == 0);
+    return mode == 1 || mode == 3 || (mode == 2 && channel % 3 == 0 && seam % 2 == 0);
 }
 
 }  // namespace vga

@@ -248,10 +248,16 @@ VGA_HD int round_through_f32(int d)
 // bound to stay <= 17 500 (14 * 17500^2 < 2^32), which also rules out int32 overflow in u.
 // in2048v[s] = x[s + 2] * 2048 and in2048p[s] = x[s + 2] * 2048 + 1024 are supplied by the caller (the
 // kernel's helper wave precomputes them per tile).
-VGA_HD PassOut pass_fast_core(const int (&x)[16], const int (&in2048v)[14], const int (&in2048p)[14], int c0, int c1,
-                              int scale_power)
+// WIDE_TOTAL: the error sum in 64 bits (a multiply and an add with carry per sample instead of one mad) -- exact whatever
+// the overflow as long as the predictor cannot wrap (|c0| + |c1| <= 32767: then |d| < 2^30 + 2^26, u cannot leave int32, and
+// |in - recon| <= 65535 squares into 32 bits).  For the one case the 32-bit sum cannot serve: a pass at the cap (scale 12 ends
+// the reference's loop whatever it overflowed, :170) whose overflow exceeds 3 -- loud noise, clipped waves.
+template <bool WIDE_TOTAL>
+VGA_HD PassOut pass_fast_core_t(const int (&x)[16], const int (&in2048v)[14], const int (&in2048p)[14], int c0, int c1,
+                                int scale_power)
 {
     PassOut r;
+    uint64_t total64 = 0;
     const int k = scale_power + 11;
     const int km11 = scale_power;
     int bias = (1 << (k - 1)) - 1;
@@ -284,18 +290,33 @@ VGA_HD PassOut pass_fast_core(const int (&x)[16], const int (&in2048v)[14], cons
         const int pr11 = (int)((uint32_t)in2048p[s] - (uint32_t)d) >> 11;
         const int recon = clamp16i(pr11 + (int)((uint32_t)q << km11));
         const int e = x[s + 2] - recon;
-        total = VGA_MAD24_ACC(e, total);                            // total += e * e, one v_mad_i32_i24
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (WIDE_TOTAL) total64 += (uint64_t)(uint32_t)__mul24(e, e);   // |e| <= 65535: the product's low 32 bits are the square
+#else
+        if (WIDE_TOTAL) total64 += (uint64_t)((int64_t)e * (int64_t)e);
+#endif
+        else total = VGA_MAD24_ACC(e, total);                       // total += e * e, one v_mad_i32_i24
         o0 = o1;
         o1 = recon;
     }
     r.hist_pair = (unsigned)(o0 & 0xFFFF) | ((unsigned)o1 << 16);
     const int ov = imax(imax(umax - 7, -8 - umin), 0);
     const int ac0 = c0 < 0 ? -c0 : c0, ac1 = c1 < 0 ? -c1 : c1;
-    r.exact = ac0 + ac1 <= 32767 && ov <= 17497 && (((2 * ov + 1) << (k - 11)) <= 34996);
-    r.total = total;
+    r.exact = ac0 + ac1 <= 32767 && (WIDE_TOTAL || (ov <= 17497 && (((2 * ov + 1) << (k - 11)) <= 34996)));
+    r.total = WIDE_TOTAL ? total64 : (uint64_t)total;
     r.max_overflow = ov;
     r.o12 = o0; r.o13 = o1;
     return r;
+}
+VGA_HD PassOut pass_fast_core(const int (&x)[16], const int (&in2048v)[14], const int (&in2048p)[14], int c0, int c1,
+                              int scale_power)
+{
+    return pass_fast_core_t<false>(x, in2048v, in2048p, c0, c1, scale_power);
+}
+VGA_HD PassOut pass_fast_core_wide(const int (&x)[16], const int (&in2048v)[14], const int (&in2048p)[14], int c0, int c1,
+                                   int scale_power)
+{
+    return pass_fast_core_t<true>(x, in2048v, in2048p, c0, c1, scale_power);
 }
 
 VGA_HD PassOut pass_fast(const int (&x)[16], int c0, int c1, int scale_power)

@@ -151,7 +151,13 @@ __device__ __noinline__ GenericOut resume_generic(X16 xs, int c0, int c1, int sc
 struct ColdState {
     int x[16], m[14], mp[14];
     int c0, c1, s1;
-    int cand_b, rare, resume;
+    // what this lane needs (any of them in any lane sends the wave here):
+    //   generic: the reference's loop as written from `start` (the scalePower its loop continues from): the bump loop
+    //            (:166-168) was entered, or the coefficients can wrap int32
+    //   drop:    (lane-per-candidate layout) the pair's other lane redoes the whole loop: this lane is out
+    //   wide:    the final pass ran at the cap with an overflow above 3: same pass again with a 64-bit error sum
+    //   resume:  third and later trips
+    int generic, start, drop, wide, resume;
 };
 struct ColdOut { PassOut r; int final_sp; int fin; };
 // inline: 370 ms out of line (the by-value state goes through scratch) vs 209 inline (round 1)
@@ -163,28 +169,41 @@ ColdOut encode_frame_cold(ColdState st, PassOut r, int final_sp, int fin)
     for (int i = 0; i < 16; i++) x[i] = st.x[i];
 #pragma unroll
     for (int i = 0; i < 14; i++) { m[i] = st.m[i]; mp[i] = st.mp[i]; }
-    const bool redo = __any(st.rare != 0);         // whole frame again, the reference's loop as written
-    if (redo) {
-        fin = 0;
-        if (!st.cand_b) {
-            r = resume_passes(x, st.c0, st.c1, st.s1 - 1, final_sp);
+    if (st.drop) fin = 0;
+    if (__any(st.generic != 0)) {                  // hostile input, and tones the first scale misjudges by 2^5 and more
+        if (st.generic) {
+            r = resume_passes(x, st.c0, st.c1, st.start, final_sp);
             fin = 1;
         }
-    } else if (st.resume) {
-        // third and later trips of the A lane, same straight-line tests as the first trip
-        int sp = st.s1 + 1;                        // < 12: neither candidate was at the cap
-        for (;;) {
-            sp++;
-            r = pass_fast_core(x, m, mp, st.c0, st.c1, sp);
-            const bool cap = sp >= 12;
-            if ((unsigned)r.max_overflow > (cap ? 3u : 248u)) {      // bump loop / inexact sum: generic
-                r = resume_passes(x, st.c0, st.c1, sp - 1, final_sp);
-                break;
-            }
-            final_sp = sp;
-            if (cap || r.max_overflow <= 1) break;
+    }
+    // Round 5: until then any lane whose pass at the cap overflowed by more than 3 sent the whole wave through the
+    // reference's loop from its start (three to four passes, the literal f32 / f64 one among them) -- 96 % of the wave-frames of
+    // full-scale white noise and of a clipped square (bench.py signal_sensitivity: 316 and 343 ms against 146).  The pass
+    // itself is right (gc_encode_core.hpp S2 holds for every int32 distance); only its 32-bit error sum may have wrapped.
+    if (__any(st.wide != 0)) {
+        if (st.wide) {
+            const PassOut w = pass_fast_core_wide(x, m, mp, st.c0, st.c1, final_sp);
+            r.total = w.total;
+            fin = 1;
         }
-        fin = 1;
+    }
+    if (__any(st.resume != 0)) {
+        if (st.resume) {
+            // third and later trips, same straight-line tests as the first trip
+            int sp = st.s1 + 1;                    // < 12: neither candidate was at the cap
+            for (;;) {
+                sp++;
+                r = pass_fast_core(x, m, mp, st.c0, st.c1, sp);
+                const bool cap = sp >= 12;
+                if ((unsigned)r.max_overflow > (cap ? 3u : 248u)) {      // bump loop / inexact sum: generic
+                    r = resume_passes(x, st.c0, st.c1, sp - 1, final_sp);
+                    break;
+                }
+                final_sp = sp;
+                if (cap || r.max_overflow <= 1) break;
+            }
+            fin = 1;
+        }
     }
     ColdOut o;
     o.r = r;
@@ -248,6 +267,7 @@ __device__ __forceinline__ void gc_encode_piece(
     __shared__ GcTile s_tile[2];
     // the winner's frame, unpacked: q[0..13], predictor, scale; the helper packs it (pack_frame) when it flushes
     __shared__ int4 s_out[2][CS][TF][4];
+    __shared__ int s_ncold[SW];
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
     const bool helper = wave == SW;
@@ -390,7 +410,7 @@ __device__ __forceinline__ void gc_encode_piece(
     VGA_OPAQUE(h0);
     VGA_OPAQUE(h1);
 
-    int n_cold = 0;                                    // wave-uniform: cold blocks this piece (diagnostics, g_vga_gc_stats)
+    if (lane == 0) s_ncold[wave] = 0;                  // cold blocks this piece (diagnostics, g_vga_gc_stats)
     struct Row { int x[16]; int m[14]; int mp[14]; uint32_t pre; };
     auto read_row = [&](const GcTile &T, int j, Row &R) {
         const int4 *xr = reinterpret_cast<const int4 *>(&T.x[grp][j][0]);
@@ -447,19 +467,31 @@ __device__ __forceinline__ void gc_encode_piece(
         //   * (total << 4) of the final lanes fits the 32-bit argmin key (`wide` otherwise; lanes that
         //     overflowed are not final and their error sums -- often huge -- are never looked at).
         // eff = overflow as the loop condition sees it (a pass at the cap ends the loop whatever it overflowed).
-        const unsigned total32 = (unsigned)r.total;
-        const bool rare = !coef_ok || (unsigned)r.max_overflow > ov_limit;
+        // `rare`: the bump loop can start, or the coefficients can wrap -- the pair's A lane redoes the reference's loop
+        // as written, for the whole wave (hostile input).  A pass at the cap that overflowed by more than 3 (loud noise,
+        // clipped waves) is right except for its 32-bit error sum: `inexact`, the same pass again with a 64-bit sum.
+        const bool rare = !coef_ok || (!at_cap && (unsigned)r.max_overflow > ov_limit);
         const int eff = at_cap ? 0 : r.max_overflow;
         const int eff_other = dpp<DPP_QUAD_XOR1>(eff);
         // A is final iff its pass did not overflow by more than 1; B is final iff A is not and B did not.
         bool fin = eff < 2 && (eff_other | (cand_b ? 0 : 2)) >= 2;
         const bool resume = !cand_b && imin(eff, eff_other) >= 2;     // both overflowed: A carries on at s1+2
-        const bool wide = fin && total32 >= (1u << 28);
+        const bool inexact = fin && at_cap && (unsigned)r.max_overflow > ov_limit;
         // ---- the frame's tail: argmin over the 8 predictors (first index wins ties, :66-76), winner's history
         // broadcast, winner's record to LDS.  A lambda so that the hot and the cold branch each get their own
         // copy: merging the two branches' PassOut registers instead put the copies on the hot path.
         auto finish = [&](const PassOut &r, int final_sp, bool fin, bool need64) __attribute__((always_inline)) {
-            int winner;
+            int winner = 0;
+            // 32-bit keys: error sums from 2^28 on share one key (such a predictor loses to any below -- as a rule it is one
+            // of several wild ones); only when a channel's BEST is that large do the 64-bit keys decide
+            constexpr unsigned SAT = (1u << 28) - 1;
+            if (!need64) {
+                const unsigned tot = umin32((unsigned)(r.total >> 32) ? SAT : (unsigned)r.total, SAT);
+                const unsigned key = fin ? ((tot << 4) | (unsigned)l16) : 0xFFFFFFFFu;
+                const unsigned best = row16_reduce(key, [](unsigned a, unsigned b) { return a < b ? a : b; });
+                winner = (int)(best & 15u);
+                need64 = __any((best >> 4) >= SAT);
+            }
             if (__builtin_expect(need64, 0)) {
                 uint64_t key = fin ? ((r.total << 4) | (uint64_t)l16) : ~0ull;
 #define VGA_MIN64_STAGE(CTRL)                                                          \
@@ -475,10 +507,6 @@ __device__ __forceinline__ void gc_encode_piece(
                 VGA_MIN64_STAGE(DPP_ROW_MIRROR)
 #undef VGA_MIN64_STAGE
                 winner = (int)(key & 15u);
-            } else {
-                const unsigned key = fin ? (((unsigned)r.total << 4) | (unsigned)l16) : 0xFFFFFFFFu;
-                const unsigned best = row16_reduce(key, [](unsigned a, unsigned b) { return a < b ? a : b; });
-                winner = (int)(best & 15u);
             }
             const bool won = l16 == winner;
             const unsigned pay = row16_reduce(won ? r.hist_pair : 0u,
@@ -497,18 +525,20 @@ __device__ __forceinline__ void gc_encode_piece(
             VGA_OPAQUE(h0);                      // hide the 16-bit range: keeps the 24-bit multiplies the next frame
             VGA_OPAQUE(h1);                      // asks for (the compiler otherwise widens them to 64-bit mads)
         };
-        if (__builtin_expect(__any(rare || resume || wide), 0)) {
-            // ---- cold block (third trips: a third of the wave-frames on the synthetic set, LABNOTES 8.4; rare: hostile input only)
-            n_cold++;
+        if (__builtin_expect(__any(rare || resume || inexact), 0)) {
+            // ---- cold block (third trips: a third of the wave-frames on the synthetic set, LABNOTES 8.4)
+            if (lane == 0) atomicAdd(&s_ncold[wave], 1);   // diagnostics (LDS: no register lives across the frame loop for it)
             ColdState st;
 #pragma unroll
             for (int i = 0; i < 16; i++) st.x[i] = x[i];
 #pragma unroll
             for (int i = 0; i < 14; i++) { st.m[i] = R.m[i]; st.mp[i] = R.mp[i]; }
             st.c0 = c0; st.c1 = c1; st.s1 = s1;
-            st.cand_b = cand_b; st.rare = rare; st.resume = resume;
+            const bool redo = __any(rare);             // (this layout: every pair's A lane walks the whole loop again, B lanes are out)
+            st.generic = redo && !cand_b; st.start = s1 - 1; st.drop = redo && cand_b;
+            st.wide = !redo && inexact; st.resume = !redo && resume;
             const ColdOut o = encode_frame_cold(st, r, final_sp, fin);
-            finish(o.r, o.final_sp, o.fin != 0, __any(o.fin != 0 && (o.r.total >> 28) != 0));
+            finish(o.r, o.final_sp, o.fin != 0, false);
         } else
             finish(r, final_sp, fin, false);
     };
@@ -534,14 +564,23 @@ __device__ __forceinline__ void gc_encode_piece(
         const PassOut rb = pass_fast_core(x, R.m, R.mp, c0, c1, sp_b);
         const PassOut ra = pass_fast_core(x, R.m, R.mp, c0, c1, sp_a);
         const bool cap_a = sp_a >= 12, cap_b = sp_b >= 12;         // a pass at the cap ends the loop whatever it overflowed
-        // `rare` as in the four-channel layout (see there): either pass could start the bump loop or has an inexact sum
-        const bool rare = !coef_ok || (unsigned)ra.max_overflow > (cap_a ? 3u : 248u) || (unsigned)rb.max_overflow > (cap_b ? 3u : 248u);
         const int eff_a = cap_a ? 0 : ra.max_overflow, eff_b = cap_b ? 0 : rb.max_overflow;
         const bool fin_a = eff_a < 2;                              // the reference stops after the pass at s1
+        // Which of the two passes the reference ends on, and what can stand in the way (each lane for itself; round 5 --
+        // until then any of these in any lane redid the whole wave's frame from scratch):
+        //   * bump_a / bump_b: the pass the loop has reached overflowed by more than 248, the bump loop (:166-168) moves the
+        //     scale by more than one step -- the reference's loop as written, from the scale it moves to;
+        //   * hostile coefficients (they can wrap int32): the whole loop as written;
+        //   * inexact: the final pass ran at the cap and overflowed by more than 3 -- its 32-bit error sum may have wrapped
+        //     (gc_encode_core.hpp S3); the pass again with a 64-bit sum.  (B's overflow is nobody's business when A is final.)
+        const bool bump_a = !cap_a && (unsigned)ra.max_overflow > 248u;
+        const bool bump_b = !fin_a && !cap_b && (unsigned)rb.max_overflow > 248u;
+        const bool generic = !coef_ok || bump_a || bump_b;
+        const bool inexact = !generic && (fin_a ? (cap_a && (unsigned)ra.max_overflow > 3u) : (cap_b && (unsigned)rb.max_overflow > 3u));
 #ifdef VGA_GC_ABLATE_THIRD_TRIPS                                     // timing only (tools/build_variants.sh): what the cold block costs
         const bool resume = false;
 #else
-        const bool resume = !fin_a && eff_b >= 2;                  // both overflowed: on to s1 + 2 in the cold block
+        const bool resume = !generic && !fin_a && eff_b >= 2;      // both overflowed: on to s1 + 2 in the cold block
 #endif
         PassOut r;
 #pragma unroll
@@ -552,9 +591,20 @@ __device__ __forceinline__ void gc_encode_piece(
         r.o12 = r.o13 = 0;
         r.exact = true;
         const int final_sp = fin_a ? sp_a : sp_b;
-        const bool wide = !resume && (unsigned)r.total >= (1u << 28);
         auto finish = [&](const PassOut &r, int final_sp, bool fin, bool need64) __attribute__((always_inline)) {
-            int winner;
+            int winner = 0;
+            // 32-bit keys: error sums from 2^28 on share one key (such a predictor loses to any below); only when a channel's
+            // BEST is that large do the 64-bit keys decide
+            constexpr unsigned SAT = (1u << 28) - 1;
+            if (!need64) {
+                const unsigned tot = umin32((unsigned)(r.total >> 32) ? SAT : (unsigned)r.total, SAT);
+                unsigned key = fin ? ((tot << 3) | (unsigned)p) : 0xFFFFFFFFu;
+                key = umin32(key, (unsigned)dpp<DPP_QUAD_XOR1>((int)key));
+                key = umin32(key, (unsigned)dpp<DPP_QUAD_XOR2>((int)key));
+                key = umin32(key, (unsigned)dpp<DPP_ROW_HALF_MIRROR>((int)key));
+                winner = (int)(key & 7u);
+                need64 = __any((key >> 3) >= SAT);
+            }
             if (__builtin_expect(need64, 0)) {
                 uint64_t key = fin ? ((r.total << 3) | (uint64_t)p) : ~0ull;
 #define VGA_MIN64_STAGE(CTRL)                                                          \
@@ -568,12 +618,6 @@ __device__ __forceinline__ void gc_encode_piece(
                 VGA_MIN64_STAGE(DPP_QUAD_XOR2)
                 VGA_MIN64_STAGE(DPP_ROW_HALF_MIRROR)
 #undef VGA_MIN64_STAGE
-                winner = (int)(key & 7u);
-            } else {
-                unsigned key = fin ? (((unsigned)r.total << 3) | (unsigned)p) : 0xFFFFFFFFu;
-                key = umin32(key, (unsigned)dpp<DPP_QUAD_XOR1>((int)key));
-                key = umin32(key, (unsigned)dpp<DPP_QUAD_XOR2>((int)key));
-                key = umin32(key, (unsigned)dpp<DPP_ROW_HALF_MIRROR>((int)key));
                 winner = (int)(key & 7u);
             }
             const bool won = p == winner;
@@ -595,17 +639,20 @@ __device__ __forceinline__ void gc_encode_piece(
             VGA_OPAQUE(h0);
             VGA_OPAQUE(h1);
         };
-        if (__builtin_expect(__any(rare || resume || wide), 0)) {
-            n_cold++;
+        if (__builtin_expect(__any(generic || resume || inexact), 0)) {
+            if (lane == 0) atomicAdd(&s_ncold[wave], 1);   // diagnostics (LDS: no register lives across the frame loop for it)
             ColdState st;
 #pragma unroll
             for (int i = 0; i < 16; i++) st.x[i] = x[i];
 #pragma unroll
             for (int i = 0; i < 14; i++) { st.m[i] = R.m[i]; st.mp[i] = R.mp[i]; }
             st.c0 = c0; st.c1 = c1; st.s1 = s1;
-            st.cand_b = 0; st.rare = rare; st.resume = resume;
-            const ColdOut o = encode_frame_cold(st, r, final_sp, resume ? 0 : 1);
-            finish(o.r, o.final_sp, o.fin != 0, __any(o.fin != 0 && (o.r.total >> 28) != 0));
+            st.generic = generic; st.drop = 0; st.wide = inexact; st.resume = resume;
+            // where the reference's loop stands (the value of scalePower before its next ++): at its start for hostile
+            // coefficients; behind the bumps of the pass that started them otherwise
+            st.start = !coef_ok ? s1 - 1 : (bump_a ? apply_bumps(s1, ra.max_overflow) : apply_bumps(s1 + 1, rb.max_overflow));
+            const ColdOut o = encode_frame_cold(st, r, final_sp, (generic || resume) ? 0 : 1);
+            finish(o.r, o.final_sp, o.fin != 0, false);
         } else
             finish(r, final_sp, true, false);
     };
@@ -644,7 +691,7 @@ __device__ __forceinline__ void gc_encode_piece(
     }
     if (lane == 0) {
         atomicAdd(&g_vga_gc_stats[3], (unsigned long long)frames_wg);
-        atomicAdd(&g_vga_gc_stats[4], (unsigned long long)n_cold);
+        atomicAdd(&g_vga_gc_stats[4], (unsigned long long)s_ncold[wave]);
         if (wave == 0) atomicAdd(&g_vga_gc_stats[6], 1ull);
     }
 #ifdef VGA_DEBUG_TIMESTAMPS

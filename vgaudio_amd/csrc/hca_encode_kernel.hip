@@ -44,24 +44,44 @@ struct EncTab {
     double dequant_scale[64];          // DequantizerScalingTable (FindScaleFactor)
     double quant_scale[64];            // QuantizerScalingTable
     double inv_step[16];               // QuantizerInverseStepSize
-    double dead_zone[16];              // QuantizerDeadZone (CriHcaTables.cs:68-78)
-    uint8_t enc_bits[8][16], enc_value[8][16];   // QuantizeSpectrumBits / Value (index q + 8)
-    uint8_t enc_pair[8][16];                     // value << 4 | bits
+    uint8_t enc_pair[8][16];                     // QuantizeSpectrumValue << 4 | QuantizeSpectrumBits (index q + 8)
     uint8_t max_bits[16];
     uint8_t res_curve[64];
-    // Resolutions 1..7: the code length of a coefficient depends on its quantised magnitude only, and steps up ONCE
-    // (QuantizeSpectrumBits: 1: |q| >= 1, 2: >= 2, 3: >= 1, 4: >= 4, 5: >= 3, 6: >= 2, 7: >= 1).  The quantiser
-    // q = (int)(x * inv + up) - down (CriHcaEncoder.cs:589-591) is non-decreasing in x -- a product with a positive
-    // constant, a sum and a truncation of a positive value are, rounding included -- so "|q| >= k" is exactly
-    // "x >= thr_pos or x <= thr_neg" for two doubles found by bisection with the quantiser's own arithmetic
-    // (threshold_init).  A band's cost at such a resolution is 8 * base_bits + the number of coefficients outside.
-    double thr_pos[8], thr_neg[8];
-    uint8_t base_bits[8];
 };
 
-// lane r = 1..7 of the first wave: the two thresholds of resolution r
-__device__ __forceinline__ void threshold_init(EncTab &T, int r)
+// CalculateUsedBits (:554-597) needs, per band and for each of the sixteen resolutions, the bits its eight scaled coefficients
+// cost.  Resolutions 1..7: the code length of a coefficient depends on its quantised magnitude only and steps up ONCE
+// (QuantizeSpectrumBits: 1: |q| >= 1, 2: >= 2, 3: >= 1, 4: >= 4, 5: >= 3, 6: >= 2, 7: >= 1).  The quantiser
+// q = (int)(x * inv + up) - down (CriHcaEncoder.cs:589-591) is non-decreasing in x -- a product with a positive constant, a
+// sum and a truncation of a positive value are, rounding included -- so "|q| >= k" is exactly "x >= thr_pos or x <= thr_neg"
+// for two doubles found by bisection with the quantiser's own arithmetic (threshold_of).  Resolutions 8..15 cost one bit
+// more outside the dead zone (|x| >= QuantizerDeadZone, CriHcaTables.cs:68-78).  A band's cost at resolution r is therefore
+// a constant plus the NUMBER of its coefficients beyond r's threshold: fifteen thresholds for positive x, fifteen for
+// negative x.
+//
+// Round 5: one coefficient used to be compared with all 22 thresholds (352 f64 compare / carry-add pairs per band).  Sorted,
+// the fifteen thresholds of a sign cut the magnitudes into sixteen ranks, and a coefficient's contribution to all sixteen
+// costs is a function of (sign, rank): one 128-bit pattern of 0/1 bytes.  The rank comes from the magnitude's own bits:
+// exponent + top four mantissa bits name one of ~200 buckets, a byte per bucket says how many thresholds lie at or below
+// the bucket's lower edge, and -- at most ONE threshold lies inside a bucket (the closest pair of thresholds is 29 %
+// apart, a bucket is at most 6.25 % wide; checked when the table is built) -- one exact f64 compare against that threshold
+// decides the rest.  Per coefficient: a byte read, a threshold read, one f64 compare, a pattern read, four adds.
+constexpr int COST_BUCKETS = 208;      // 13 octaves below 1.0 x 16
+struct CostLut {
+    uint4 pat[2][16];                  // [sign][rank]: byte r = 1 if the threshold of resolution r is among the `rank` smallest
+    double thr[2][16];                 // [sign][k]: the (k + 1)-th smallest threshold (magnitude); [15] = +inf
+    uint8_t rank_base[2][COST_BUCKETS];// thresholds at or below the bucket's lower edge
+    uint4 base;                        // byte r: 8 x the code length inside the threshold (QuantizeSpectrumBits / max bits - 1)
+    int key_base;                      // bucket = (high dword of |x| >> 16) - key_base, clamped
+};
+
+// the magnitude from which resolution r (1..15) costs a coefficient of sign `neg` one bit more
+__device__ __forceinline__ double threshold_of(int r, int neg)
 {
+    if (r >= 8) {                                              // QuantizerDeadZone (CriHcaTables.cs:68-78)
+        const double st = f64_bits(HCA_QuantizerStepSizeBits[r]);
+        return __longlong_as_double(__double_as_longlong(st / 2) - (long long)(HCA_ResolutionMaxValue[r] + 1));
+    }
     const double inv = f64_bits(HCA_QuantizerInverseStepSizeBits[r]);
     const double up = inv + 1;
     const int down = (int)(inv + 0.5 - 8);
@@ -72,21 +92,81 @@ __device__ __forceinline__ void threshold_init(EncTab &T, int r)
     auto index_of = [&](double x) { return (int)(x * inv + up) - down; };
     // ScaleSpectra clamps to +-0.999999999999 (:668): the largest magnitude a coefficient can have
     const long long top = __double_as_longlong(0.999999999999);
-    long long lo = 0, hi = top;                               // idx(lo) < 8 + k <= idx(hi); doubles >= 0 order like their bits
+    long long lo = 0, hi = top;                               // doubles >= 0 order like their bits
     while (hi - lo > 1) {
         const long long mid = (lo + hi) / 2;
-        if (index_of(__longlong_as_double(mid)) >= 8 + k) hi = mid;
+        const double m = __longlong_as_double(mid);
+        const bool beyond = neg ? index_of(-m) <= 8 - k : index_of(m) >= 8 + k;
+        if (beyond) hi = mid;
         else lo = mid;
     }
-    T.thr_pos[r] = __longlong_as_double(hi);
-    lo = 0, hi = top;
-    while (hi - lo > 1) {
-        const long long mid = (lo + hi) / 2;
-        if (index_of(-__longlong_as_double(mid)) <= 8 - k) hi = mid;
-        else lo = mid;
+    return __longlong_as_double(hi);
+}
+
+// Threads 0..127 of the workgroup, once: `tmp` = 64 doubles of scratch LDS.  Returns false (to every thread) when two
+// thresholds share a bucket -- the tables would be wrong; never with the reference's constants.
+__device__ __forceinline__ bool cost_lut_build(CostLut &Q, double *tmp, int tid)
+{
+    double *val = tmp;                                         // [2][16] unsorted: index r - 1
+    int *order = reinterpret_cast<int *>(tmp + 32);            // [2][16]: resolution of the k-th smallest threshold
+    __shared__ int s_bad;
+    if (tid < 30) val[(tid / 15) * 16 + tid % 15] = threshold_of(tid % 15 + 1, tid / 15);
+    if (tid == 30) s_bad = 0;
+    __syncthreads();
+    if (tid < 30) {
+        const int sg = tid / 15, i = tid % 15;
+        const double v = val[sg * 16 + i];
+        int rank = 0;
+        for (int j = 0; j < 15; j++) {
+            const double w = val[sg * 16 + j];
+            rank += (w < v || (w == v && j < i)) ? 1 : 0;
+        }
+        Q.thr[sg][rank] = v;
+        order[sg * 16 + rank] = i + 1;
+    } else if (tid < 32) {
+        Q.thr[tid - 30][15] = __longlong_as_double(0x7FF0000000000000ll);      // +inf: rank 15 is the last
     }
-    T.thr_neg[r] = -__longlong_as_double(hi);
-    T.base_bits[r] = (uint8_t)b0;
+    __syncthreads();
+    if (tid < 32) {                                            // pat[sign][rank]
+        const int sg = tid >> 4, k = tid & 15;
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int j = 0; j < k; j++) {
+            const int r = order[sg * 16 + j];
+            w[r >> 2] |= 1u << (8 * (r & 3));
+        }
+        Q.pat[sg][k] = make_uint4(w[0], w[1], w[2], w[3]);
+    } else if (tid == 32) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int r = 1; r < 16; r++) {
+            const int len = r < 8 ? HCA_QuantizeSpectrumBits[r][8] : HCA_QuantizedSpectrumMaxBits[r] - 1;
+            w[r >> 2] |= (uint32_t)(8 * len) << (8 * (r & 3));
+        }
+        Q.base = make_uint4(w[0], w[1], w[2], w[3]);
+        const double smallest = Q.thr[0][0] < Q.thr[1][0] ? Q.thr[0][0] : Q.thr[1][0];
+        Q.key_base = (int)((uint32_t)__double2hiint(smallest) >> 16) - 1;       // bucket 0: everything below every threshold
+    }
+    __syncthreads();
+    const int kb = Q.key_base;
+    for (int i = tid; i < 2 * COST_BUCKETS; i += ENC_THREADS) {
+        const int sg = i / COST_BUCKETS, b = i % COST_BUCKETS;
+        // bucket b holds the magnitudes whose high dword >> 16 is kb + b (b = 0: that and everything below)
+        const double lower = b == 0 ? 0.0 : __hiloint2double((kb + b) << 16, 0);
+        const double upper = __hiloint2double((kb + b + 1) << 16, 0);
+        int at_or_below = 0, inside = 0;
+        for (int j = 0; j < 15; j++) {
+            const double t = Q.thr[sg][j];
+            at_or_below += t <= lower ? 1 : 0;
+            inside += (t > lower && t < upper) ? 1 : 0;
+        }
+        if (inside > 1 || (b == 0 && (at_or_below | inside) != 0)) s_bad = 1;
+        Q.rank_base[sg][b] = (uint8_t)at_or_below;
+    }
+    if (tid == 33) {                                           // the largest magnitude (:668) must have a bucket
+        const int top = (int)((uint32_t)__double2hiint(0.999999999999) >> 16) - kb;
+        if (top >= COST_BUCKETS) s_bad = 1;
+    }
+    __syncthreads();
+    return s_bad == 0;
 }
 
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -122,72 +202,25 @@ __device__ __forceinline__ unsigned gf_mul(unsigned a, unsigned b)
     return r;
 }
 
-// CalculateUsedBits (:554-597) for one band: the bits its eight scaled coefficients cost at resolution `res`
-__device__ __forceinline__ int band_cost(const EncTab &T, const double (&x)[8], int res)
+// All sixteen costs of one band (each <= 8 * 12 bits: a byte; no byte can carry) from the look-up described at CostLut.
+__device__ __forceinline__ uint4 band_cost_table(const CostLut &Q, const double (&x)[8])
 {
-    int cost = 0;
-    if (res >= 8) {
-        const int bits = T.max_bits[res] - 1;
-        const double d = T.dead_zone[res];
+    uint32_t a0 = Q.base.x, a1 = Q.base.y, a2 = Q.base.z, a3 = Q.base.w;
+    const int kb = Q.key_base;
 #pragma unroll
-        for (int sf = 0; sf < 8; sf++) cost += bits + (fabs(x[sf]) >= d ? 1 : 0);
-    } else {
-        // QuantizeSpectrumBits[res][(int)(x * inv + up) - down] through the two thresholds (see EncTab): two compares
-        // and two carry-adds per coefficient instead of a multiply, an add, a conversion and a dependent table read
-        const double tp = T.thr_pos[res], tn = T.thr_neg[res];
-        cost = 8 * T.base_bits[res];
-#pragma unroll
-        for (int sf = 0; sf < 8; sf++) cost += (x[sf] >= tp ? 1 : 0) + (x[sf] <= tn ? 1 : 0);
+    for (int sf = 0; sf < 8; sf++) {
+        const uint32_t hi = (uint32_t)__double2hiint(x[sf]);
+        const int sg = (int)(hi >> 31);
+        const int b = min(max((int)((hi & 0x7FFFFFFFu) >> 16) - kb, 0), COST_BUCKETS - 1);
+        const int rb = Q.rank_base[sg][b];
+        const int rank = rb + (fabs(x[sf]) >= Q.thr[sg][rb] ? 1 : 0);
+        const uint4 p = Q.pat[sg][rank];
+        a0 += p.x;
+        a1 += p.y;
+        a2 += p.z;
+        a3 += p.w;
     }
-    return cost;
-}
-
-// All sixteen costs of one band (each <= 8 * 12 bits: a byte; band_cost above is the same thing one resolution at a time,
-// kept for the block-wide fall-back).  A band's cost at resolution r is a constant (8 x the base length) plus the NUMBER of
-// its coefficients beyond the threshold(s): the table is two 64-bit constants plus fifteen byte-wide counts, each count
-// eight (or sixteen) compare + carry-add pairs against thresholds fetched up front -- first the fourteen of resolutions
-// 1..7, then the eight dead zones (all 22 at once, next to the band's coefficients, do not fit the 168 VGPRs three waves
-// per SIMD allow).  No byte can carry: a cost is at most 96.
-__device__ __forceinline__ uint4 band_cost_table(const EncTab &T, const double (&x)[8])
-{
-    uint64_t lo = 0, hi = 0;
-    {
-        double tp[8], tn[8];
-        uint64_t base = 0;
-#pragma unroll
-        for (int r = 1; r < 8; r++) {                          // resolution 0 costs nothing
-            tp[r] = T.thr_pos[r];
-            tn[r] = T.thr_neg[r];
-            base |= (uint64_t)(8 * T.base_bits[r]) << (8 * r);
-        }
-#pragma unroll
-        for (int r = 1; r < 8; r++) {
-            int cnt = 0;
-#pragma unroll
-            for (int sf = 0; sf < 8; sf++) cnt += (x[sf] >= tp[r] ? 1 : 0) + (x[sf] <= tn[r] ? 1 : 0);
-            lo |= (uint64_t)cnt << (8 * r);
-        }
-        lo += base;
-    }
-    asm volatile("" ::: "memory");                             // the second half's loads stay behind the first half
-    {
-        double dz[8];
-        uint64_t base = 0;
-#pragma unroll
-        for (int r = 8; r < 16; r++) {
-            dz[r - 8] = T.dead_zone[r];
-            base |= (uint64_t)(8 * (T.max_bits[r] - 1)) << (8 * (r - 8));
-        }
-#pragma unroll
-        for (int r = 8; r < 16; r++) {
-            int cnt = 0;
-#pragma unroll
-            for (int sf = 0; sf < 8; sf++) cnt += fabs(x[sf]) >= dz[r - 8] ? 1 : 0;
-            hi |= (uint64_t)cnt << (8 * (r - 8));
-        }
-        hi += base;
-    }
-    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+    return make_uint4(a0, a1, a2, a3);
 }
 
 __device__ __forceinline__ int cost_at(const uint4 &t, int res)
@@ -289,20 +322,22 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
 {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
     __shared__ EncTab T;
+    __shared__ CostLut Q;
     const int nch = info.nch;
     // LDS: spectra [nch][8] rows of RS doubles | cost tables uint4 [nch][128] | small arrays | frame bits | sfac, ires
+    // (launch_encode computes the same sizes; six workgroups share a CU's 160 KB at two channels: every table here counts)
     double *spectra = s_mem;
     uint4 *costs = reinterpret_cast<uint4 *>(spectra + (size_t)nch * 8 * RS);
     double *hfr_avg = reinterpret_cast<double *>(costs + nch * 128);      // [nch][8]
     double *eratio = hfr_avg + nch * 8;                                   // [nch][8]
-    int *red = reinterpret_cast<int *>(eratio + nch * 8);                 // [32]: slots of the block-wide reductions, search result
-    int *hlb = red + 32;                                                  // [8] header length bits
+    int *red = reinterpret_cast<int *>(eratio + nch * 8);                 // [8]: slots of the block-wide reductions (0..3), search result (4, 5), CRC (6, 7)
+    int *hlb = red + 8;                                                   // [8] header length bits
     int *dbits = hlb + 8;                                                 // [8] scale-factor delta bits
-    int *cand = dbits + 8;                                                // [nch][8]
-    int *empty = cand + 64;                                               // [8]
-    int *intensity = empty + 8;                                           // [nch][8]
-    int *hfrs = intensity + 64;                                           // [nch][8]
-    uint32_t *fbuf = reinterpret_cast<uint32_t *>(hfrs + 64);             // frame bits, big-endian words [fwords]
+    int *empty = dbits + 8;                                               // [8]
+    int *cand = empty + 8;                                                // [nch][8]
+    int *intensity = cand + nch * 8;                                      // [nch][8]
+    int *hfrs = intensity + nch * 8;                                      // [nch][8]
+    uint32_t *fbuf = reinterpret_cast<uint32_t *>(hfrs + nch * 8);        // frame bits, big-endian words [fwords]
     const int fwords = ((info.frame_size + 3) / 4 + 3) & ~1;              // even: what follows stays 8-byte aligned
     uint8_t *sfac = reinterpret_cast<uint8_t *>(fbuf + fwords);           // [nch][128] scale factors (0..63)
     uint8_t *ires = sfac + nch * 128;                                     // [nch][128] resolutions (0..15)
@@ -318,15 +353,10 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         T.res_curve[i] = i < 59 ? HCA_ScaleToResolutionCurve[i] : 0;
     }
     if (tid < 16) {
-        const double st = f64_bits(HCA_QuantizerStepSizeBits[tid]);
         T.inv_step[tid] = f64_bits(HCA_QuantizerInverseStepSizeBits[tid]);
-        T.dead_zone[tid] = __longlong_as_double(__double_as_longlong(st / 2) - (long long)(HCA_ResolutionMaxValue[tid] + 1));
         T.max_bits[tid] = HCA_QuantizedSpectrumMaxBits[tid];
     }
-    if (tid >= 1 && tid < 8) threshold_init(T, tid);
-    (&T.enc_bits[0][0])[tid] = (&HCA_QuantizeSpectrumBits[0][0])[tid];
     (&T.enc_pair[0][0])[tid] = (uint8_t)(((&HCA_QuantizeSpectrumValue[0][0])[tid] << 4) | (&HCA_QuantizeSpectrumBits[0][0])[tid]);
-    (&T.enc_value[0][0])[tid] = (&HCA_QuantizeSpectrumValue[0][0])[tid];
     if (tid < 8) {
         int cc = 0, ct = 0;
 #pragma unroll
@@ -334,6 +364,10 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
             if (tid == k) { cc = info.coded_count[k]; ct = info.channel_type[k]; }
         s_coded[tid] = cc;
         s_ctype[tid] = ct;
+    }
+    if (!cost_lut_build(Q, s_mem, tid)) {                      // (s_mem: nothing lives there before the first frame)
+        if (tid == 0 && status) atomicOr(status, 16);
+        return;
     }
     const int L = tid & 7;
     const DctUniform U = make_dct_uniform(MDCT_SinBits, MDCT_CosBits);
@@ -534,7 +568,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
                         x[sf] = sfv != 0 ? clampd(x[sf] * qs, -0.999999999999, 0.999999999999) : 0.0;
                         col[(size_t)sf * RS] = x[sf];
                     }
-                    ct = band_cost_table(T, x);
+                    ct = band_cost_table(Q, x);
                 }
                 sfac[c * 128 + b] = (uint8_t)sfv;
                 costs[c * 128 + b] = ct;
@@ -744,11 +778,11 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
                     else bd = probe_boundary(hi2) > available ? lo2 : hi2;
                 }
 #undef probe
-                if (lane == 0) { red[28] = lv; red[29] = bd; }
+                if (lane == 0) { red[4] = lv; red[5] = bd; }
             }
             __syncthreads();
-            level = red[28];
-            boundary = red[29];
+            level = red[4];
+            boundary = red[5];
             searched = level >= 0;                     // level < 0 (bands must be dropped): the block-wide form below
         }
         if (!searched) {
@@ -884,8 +918,9 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
                 const int down = trunc_i(inv + 0.5);
                 const int q = trunc_i(spectra[((size_t)c * 8 + sf) * RS + band] * inv + up) - down;
                 if (res < 8) {
-                    nbits = T.enc_bits[res][q + 8];
-                    code = T.enc_value[res][q + 8];
+                    const unsigned pair = T.enc_pair[res][q + 8];   // value << 4 | bits
+                    nbits = (int)(pair & 15u);
+                    code = pair >> 4;
                 } else {
                     nbits = T.max_bits[res] - 1;
                     code = (unsigned)abs(q);
@@ -967,10 +1002,10 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
             }
             unsigned part = (begin < end) ? gf_mul(crc, crc_pow[nbytes - end]) : 0u;
             part = (unsigned)wave_xor((int)part);
-            if (lane == 0) red[30 + wave] = (int)part;
+            if (lane == 0) red[6 + wave] = (int)part;
             __syncthreads();
             if (tid == 0) {
-                const unsigned total = (unsigned)(red[30] ^ red[31]) & 0xFFFFu;
+                const unsigned total = (unsigned)(red[6] ^ red[7]) & 0xFFFFu;
                 const int pos = nbytes;        // big-endian 16-bit value at the last two bytes
                 fbuf[pos >> 2] |= (total >> 8) << (24 - 8 * (pos & 3));
                 fbuf[(pos + 1) >> 2] |= (total & 0xFF) << (24 - 8 * ((pos + 1) & 3));
@@ -1008,7 +1043,7 @@ int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, 
     if (nstreams <= 0 || info.frame_count <= 0) return VGA_OK;
     const int nch = info.nch;
     const size_t doubles = (size_t)nch * 8 * RS + (size_t)nch * 16;
-    const size_t ints = 32 + 8 + 8 + 64 + 8 + 64 + 64;
+    const size_t ints = 8 + 8 + 8 + 8 + 3 * (size_t)nch * 8;
     const size_t lds = doubles * 8 + (size_t)nch * 128 * 16 + ints * 4 + (size_t)((((info.frame_size + 3) / 4 + 3) & ~1) * 4) + (size_t)nch * 256;
     if (lds > 32 * 1024) VGA_HIP_TRY(allow_dynamic_lds(hca_encode_kernel, lds));
     // frames per workgroup: long runs amortise the per-workgroup set-up (tables, twiddles), short ones keep small inputs
