@@ -43,6 +43,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+XGMI_LINK_GBS = 153.0          # one xGMI link, per direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, point to point)
 ENC_BYTES_PER_SAMPLE = 2.0 + 8.0 / 14.0
 COEF_BYTES_PER_SAMPLE = 2.0
 PIPE_BYTES_PER_SAMPLE = 4.0 + 8.0 / 14.0
@@ -738,6 +739,8 @@ def run_gc(args, cx):
         g.gather(adpcm, coefs, nbytes=nb)
         torch.cuda.synchronize()
         verified = g.verify(adpcm, coefs, nb) if cx.rank == 0 else None
+        if verified is not None and verified.startswith("MISMATCH"):
+            raise SystemExit("PARITY FAILURE: the rows rank 0 gathered are not the rows the ranks sent: " + verified)
         # every shard's output against the digest committed for it (tests/golden/gc_shard_oracle_digests.json: what the
         # ORACLE produces for the shard's 4096 channels, written in the build container): the first 8-GPU run has expected values
         mine = cx.vdist.rows_digest(adpcm[:nch], nb, coefs[:nch], first_channel)
@@ -770,9 +773,17 @@ def run_gc(args, cx):
             torch.cuda.synchronize()
             alone_ms = e0.elapsed_time(e1) / reps
         cx.dist.barrier()
+        job = cx.vdist.describe_job(cx.dev)                 # (a collective: every rank calls it)
+        peers = cx.world - 1
+        gather_gbs = (nch * nb + nch * 32) * peers / (ms_alone * 1e-3) / 1e9 if ms_alone > 0 else 0.0
         gather = {"what": "all ranks' ADPCM rows + coefficients to rank 0 (grouped send/recv in 512-channel chunks; the gather "
                           "of step k overlaps the kernels of step k+1)",
                   "backend": cx.backend + (" (rows staged through host memory)" if g.via_host else ""),
+                  "job": job,
+                  # rank 0 receives from every peer at once: seven peers = seven xGMI links of ~153 GB/s each on an 8-GPU node
+                  "into_rank0_GBps_alone": round(gather_gbs, 2),
+                  "xgmi_links_into_rank0": peers, "xgmi_link_GBps": XGMI_LINK_GBS,
+                  "frac_of_xgmi_into_rank0": round(gather_gbs / (peers * XGMI_LINK_GBS), 4) if peers else None,
                   "bytes_per_peer": nch * nb + nch * 32, "ms_alone": round(ms_alone, 3),
                   "ms_per_step_with_gather": round(ms_g, 3), "ms_hidden": round(max(0.0, ms_alone - max(0.0, ms_g - ms_per_step)), 3),
                   "ms_exposed": round(max(0.0, ms_g - ms_per_step), 3),

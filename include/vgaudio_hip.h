@@ -422,6 +422,26 @@ int vga_hca_encode_batch(const int16_t *const *pcm, int nstreams, const vga_hca_
  * VGA_ERR_INVALID_DATA ("Invalid frame header"). */
 int vga_hca_decode_batch(const vga_hca_info *info, const uint8_t *const *frames, int nstreams,
                          int16_t *const *pcm_out);
+/* The reference's streaming encoder object (CriHcaEncoder.InitializeNew / Encode / GetPendingFrame / PendingFrameCount /
+ * FramesProcessed / FrameSize, VGAudio/Codecs/CriHca/CriHcaEncoder.cs:20-31, :46-51, :126-163): a host that produces its PCM
+ * 1024 samples at a time.  vga_hca_stream_create = InitializeNew (same errors as vga_hca_encoder_initialize;
+ * info_out may be NULL).  vga_hca_stream_encode = Encode(short[][] pcm, byte[] hcaOut): pcm = channel_count pointers to
+ * 1024 samples each (a block that reaches past the stream's last sample is read whole, as the reference's SaveLoopAudio does,
+ * :244-254); *frames_output = the number of frames the block completed -- 0 while the encoder's buffer fills, several when
+ * pre-audio or post-audio flush whole frames -- the first written to hca_out (frame_size bytes), the others queued for
+ * vga_hca_stream_get_pending_frame (= GetPendingFrame; VGA_ERR_INVALID_OP "There are no pending frames" when none).
+ * Encode after the last frame -> VGA_ERR_INVALID_OP ("All audio frames have already been output by the encoder").  The
+ * frames are byte for byte those of vga_hca_encode_batch on the same PCM.  One stream per object, calls on one object from
+ * one thread at a time; the object holds the stream's PCM and frames in HBM (a 60 s stereo stream: 14 MB). */
+typedef struct vga_hca_stream vga_hca_stream;
+int vga_hca_stream_create(const vga_hca_params *config, vga_hca_info *info_out, vga_hca_stream **stream_out);
+int vga_hca_stream_encode(vga_hca_stream *stream, const int16_t *const *pcm, uint8_t *hca_out, int *frames_output);
+int vga_hca_stream_pending_frame_count(const vga_hca_stream *stream);
+int vga_hca_stream_get_pending_frame(vga_hca_stream *stream, uint8_t *frame_out);
+int vga_hca_stream_frames_processed(const vga_hca_stream *stream);
+int vga_hca_stream_frame_size(const vga_hca_stream *stream);
+void vga_hca_stream_destroy(vga_hca_stream *stream);
+
 /* Ragged batches: streams of different shapes in one call (a worker per file, VGAudio.Cli/Batch.cs:24-25).  configs /
  * infos_out: nstreams entries; pcm: the streams' channels one after the other (sum of the channel counts pointers);
  * frames_out[s]: infos_out[s].frame_count * frame_size bytes.  Streams that differ in length only (not looping) share

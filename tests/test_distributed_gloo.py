@@ -154,6 +154,22 @@ def test_launcher_retries_a_taken_rendezvous_port_and_nothing_else(tmp_path):
         busy.close()
 
 
+def test_job_description_lists_every_rank(tmp_path):
+    """bench.py's N > 1 line carries what the backend itself reports: world size, one entry per rank (gathered with the job's
+    own collective), the backend's name -- the first run on real multi-GPU hardware must be checkable from its line alone"""
+    import json
+    from vgaudio_amd.distributed import launch_local_ranks
+    script = tmp_path / "job.py"
+    script.write_text("import json, os, sys\nsys.path.insert(0, %r)\nimport torch\nfrom vgaudio_amd import distributed as d\n"
+                      "d.init('gloo', timeout_s=60)\njob = d.describe_job(torch.device('cpu'))\n"
+                      "if os.environ['RANK'] == '0':\n    json.dump(job, open(%r, 'w'))\n" % (ROOT, str(tmp_path / "job.json")))
+    assert launch_local_ranks([str(script)], 3, timeout=120) == 0
+    job = json.load(open(tmp_path / "job.json"))
+    assert job["backend"] == "gloo" and job["world_size_reported_by_backend"] == 3 and job["world_size_env"] == 3
+    assert sorted(r["rank"] for r in job["ranks"]) == [0, 1, 2] and len({r["pid"] for r in job["ranks"]}) == 3
+    assert job["rccl_version"] is None and job["shared_devices"] is False
+
+
 def test_launcher_passes_rank_zero_stdout_through(tmp_path):
     script = tmp_path / "echo.py"
     script.write_text("import os\nprint('line from rank', os.environ['RANK'], os.environ['LOCAL_RANK'], flush=True)\n")

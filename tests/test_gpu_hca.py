@@ -235,3 +235,67 @@ def test_long_streams_carry_the_overlap_across_frame_runs():
             _lib.lib().vga_testing_hca_frames_per_group_this_thread(old)
         for k in range(ns):
             assert np.array_equal(np.stack(dec[k]), want[k]), (run, k)
+
+
+def _feed(enc, stream, n, nch, frame_size, garbage_tail):
+    """drives CriHcaEncoder.Encode the way CriHcaFormat.EncodeFromPcm16 does (CriHcaFormat.cs:50-68): 1024-sample blocks from
+    ONE reused buffer (a block the PCM does not fill keeps the previous block's tail) -- or, garbage_tail, with a marker there"""
+    frames, per_call = [], []
+    buf = np.zeros((nch, 1024), dtype=np.int16)
+    out = np.zeros(frame_size, dtype=np.uint8)
+    pos = 0
+    while enc.FramesProcessed < enc.Hca.FrameCount:
+        take = max(0, min(1024, n - pos))
+        if garbage_tail:
+            buf[:] = 12345
+        buf[:, :take] = stream[:, pos:pos + take]
+        pos += 1024
+        got = enc.Encode(list(buf), out)
+        per_call.append(got)
+        if got:
+            frames.append(out.copy())
+            assert enc.PendingFrameCount == got - 1
+            while enc.PendingFrameCount:
+                frames.append(enc.GetPendingFrame())
+    return np.stack(frames), per_call
+
+
+@pytest.mark.parametrize("nch,quality,n,loop", [
+    (2, "High", 20000, None), (1, "Middle", 1024 * 5, None), (2, "High", 1024 * 7 - 128, None), (2, "Low", 300, None),
+    (2, "High", 20000, (3000, 18000)), (1, "Middle", 9000, (1, 8999)), (2, "High", 3000, (2990, 3000)), (2, "Low", 5000, (4700, 4990))])
+def test_streaming_encoder_object_matches_the_batch_encoder_and_the_reference_call_pattern(nch, quality, n, loop):
+    """CriHcaEncoder.Encode / GetPendingFrame (CriHcaEncoder.cs:126-163): the frames a host receives 1024 samples at a time are
+    the batch encoder's (the oracle's), and every call reports the number of frames the reference's counters give it -- checked
+    against the independent Python restatement of the streaming shell (oracle/pyref/crihca.py, counters only)."""
+    from vgaudio_amd import _lib
+    stream = _streams(1, nch, n, "synth")[0]
+    kw = dict(looping=True, loop_start=loop[0], loop_end=loop[1]) if loop else {}
+    rc, info, want = po.hca_encode(stream, po.hca_params(nch, n, quality=quality, **kw))
+    assert rc == 0
+    cfg = CriHcaParameters(Quality=Q[quality], ChannelCount=nch, SampleRate=48000, SampleCount=n,
+                           Looping=bool(loop), LoopStart=loop[0] if loop else 0, LoopEnd=loop[1] if loop else 0)
+    enc = CriHcaEncoder.InitializeNew(cfg)
+    assert enc.Hca.FrameCount == want.shape[0] and enc.FrameSize == want.shape[1]
+    got, per_call = _feed(enc, stream, n, nch, enc.FrameSize, garbage_tail=False)
+    assert got.shape == want.shape
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, (bad[0].tolist(), len(bad))
+    # the reference's counters, restated independently: frames per Encode call
+    from oracle.pyref import crihca as ref
+    r = ref.Encoder(ref.Params(nch, 48000, n, quality=quality, **kw))
+    r.encode_frame = lambda pcm: b""                             # counters only: no frame is computed
+    want_calls = []
+    while r.frames_processed < r.hca.frame_count:
+        want_calls.append(len(r.encode([[0] * 1024 for _ in range(nch)])))
+    assert per_call == want_calls
+    with pytest.raises(_lib.InvalidOperationError):
+        enc.Encode([np.zeros(1024, np.int16)] * nch, np.zeros(enc.FrameSize, np.uint8))
+    with pytest.raises(_lib.InvalidOperationError):
+        enc.GetPendingFrame()
+    enc.close()
+    if not loop:
+        # what lies behind the stream's last sample in the last block is never read when nothing loops
+        enc2 = CriHcaEncoder.InitializeNew(cfg)
+        got2, _ = _feed(enc2, stream, n, nch, enc2.FrameSize, garbage_tail=True)
+        assert np.array_equal(got2, want)
+        enc2.close()

@@ -168,6 +168,13 @@ SIGNATURES = {
     "vga_testing_last_pipeline_stats": (ci, [vp, ci]),
     "vga_testing_host_pipeline_tail_this_thread": (None, [ci]),
     "vga_testing_hca_device_info": (ci, [vp, vp, ci]),
+    "vga_hca_stream_create": (ci, [vp, vp, C.POINTER(vp)]),
+    "vga_hca_stream_encode": (ci, [vp, vp, u8p, C.POINTER(ci)]),
+    "vga_hca_stream_pending_frame_count": (ci, [vp]),
+    "vga_hca_stream_get_pending_frame": (ci, [vp, u8p]),
+    "vga_hca_stream_frames_processed": (ci, [vp]),
+    "vga_hca_stream_frame_size": (ci, [vp]),
+    "vga_hca_stream_destroy": (None, [vp]),
     "vga_testing_gc_encode_stats": (ci, [C.POINTER(C.c_ulonglong), ci]),
     "vga_testing_gc_plan_pieces": (ci, [ci, ci, ci, C.c_longlong, ci, C.POINTER(ci)]),
     "vga_set_devices": (ci, [vp, ci]),

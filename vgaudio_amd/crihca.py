@@ -71,11 +71,14 @@ class HcaInfo:
 
 
 class CriHcaEncoder:
-    """Only the parameter derivation is exposed per stream; frames are produced by the batched
-    CriHcaFormat.EncodeFromPcm16 (the reference's encoder is a stateful serial object)."""
+    """CriHcaEncoder (Codecs/CriHca/CriHcaEncoder.cs): InitializeNew derives the stream's parameters; Encode / GetPendingFrame /
+    PendingFrameCount / FramesProcessed are the reference's streaming shell (:126-163) over vga_hca_stream_* -- the frames
+    themselves come from the same kernel the batched CriHcaFormat.EncodeFromPcm16 uses."""
 
-    def __init__(self, hca):
+    def __init__(self, hca, config=None):
         self.Hca = hca
+        self._config = config
+        self._stream = None
 
     @property
     def FrameSize(self):
@@ -86,7 +89,55 @@ class CriHcaEncoder:
         info = _lib.HcaInfoC()
         cp = config._c()
         check(_lib.lib().vga_hca_encoder_initialize(C.byref(cp), C.byref(info)))
-        return CriHcaEncoder(HcaInfo(info))
+        return CriHcaEncoder(HcaInfo(info), config)
+
+    def _open(self):
+        if self._stream is None:
+            if self._config is None:
+                raise _lib.InvalidOperationError("encoder was not created by InitializeNew")
+            cp = self._config._c()
+            h = C.c_void_p()
+            check(_lib.lib().vga_hca_stream_create(C.byref(cp), None, C.byref(h)))
+            self._stream = h
+        return self._stream
+
+    def Encode(self, pcm, hcaOut):
+        """pcm: [ChannelCount][1024] (or longer rows); hcaOut: a writable uint8 array of FrameSize bytes.  Returns the number
+        of frames output: the first in hcaOut, the others through GetPendingFrame."""
+        st = self._open()
+        rows = [np.ascontiguousarray(np.asarray(r, dtype=np.int16)[:1024]) for r in pcm]
+        if any(len(r) < 1024 for r in rows):
+            raise _lib.ArgumentError("Encode takes [ChannelCount][1024] samples")
+        ptrs = (_lib.i16p * len(rows))(*[r.ctypes.data_as(_lib.i16p) for r in rows])
+        n = C.c_int(0)
+        check(_lib.lib().vga_hca_stream_encode(st, ptrs, hcaOut.ctypes.data_as(_lib.u8p), C.byref(n)))
+        return n.value
+
+    @property
+    def PendingFrameCount(self):
+        return _lib.lib().vga_hca_stream_pending_frame_count(self._stream) if self._stream else 0
+
+    @property
+    def FramesProcessed(self):
+        return _lib.lib().vga_hca_stream_frames_processed(self._stream) if self._stream else 0
+
+    def GetPendingFrame(self):
+        if not self._stream:
+            raise _lib.InvalidOperationError("There are no pending frames")
+        out = np.zeros(self.FrameSize, dtype=np.uint8)
+        check(_lib.lib().vga_hca_stream_get_pending_frame(self._stream, out.ctypes.data_as(_lib.u8p)))
+        return out
+
+    def close(self):
+        if self._stream:
+            _lib.lib().vga_hca_stream_destroy(self._stream)
+            self._stream = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 class CriHcaDecoder:

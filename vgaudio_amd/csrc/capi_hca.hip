@@ -2,6 +2,8 @@
 // Host side: CriHcaEncoder.Initialize (stream parameters), channel typing, ATH curve; the per-frame
 // work is entirely in hca_encode_kernel.hip / hca_decode_kernels.hip.
 #include "common.hpp"
+#include <deque>
+#include <memory>
 #include "host_batch.hpp"
 #include "hca_kernels.hpp"
 
@@ -195,9 +197,188 @@ int status_to_error(int status)
     return VGA_OK;
 }
 
+// the encoder's input stream (hca_device.hpp PcmMap), from the fields CriHcaEncoder.Initialize derived
+int make_pcm_map(const vga_hca_info &h, int pcm_length, hca::PcmMap &m)
+{
+    const int input_samples = h.frame_count * hca::SPF - h.inserted_samples - h.appended_samples;
+    const int pre = h.inserted_samples - hca::SPSF;
+    if (pre < 0 || h.sample_count < 0 || h.sample_count > pcm_length || input_samples < h.sample_count) {
+        set_error("HcaInfo does not describe this PCM (sample count %d of %d, inserted %d, appended %d)", h.sample_count,
+                  pcm_length, h.inserted_samples, h.appended_samples);
+        return VGA_ERR_ARGUMENT;
+    }
+    m.zero_pre = pre > hca::SPF ? (divide_by_round_up(pre, hca::SPF) - 1) * hca::SPF : 0;
+    m.pre_end = pre;
+    m.main_end = pre + h.sample_count;
+    m.post_end = m.main_end + (h.looping ? input_samples - h.sample_count : 0);   // not looping: _postAudio is all zero
+    m.loop_start = h.loop_start_frame * hca::SPF + h.pre_loop_samples - h.inserted_samples;
+    m.last_chunk = h.sample_count > 0 ? (h.sample_count - 1) / hca::SPF : 0;
+    m.raw_len = pcm_length;
+    return VGA_OK;
+}
+
 }  // namespace
 
+// ---------------------------------------------------------------- CriHcaEncoder's streaming shell (CriHcaEncoder.cs:126-269)
+// The reference's encoder is a stateful object fed [channels][1024] blocks; Encode() returns how many frames the block
+// completed -- none while the 1024-sample buffer fills, several when the pre-audio of a looping stream or the post-audio at
+// the end flush whole frames -- the first into the caller's buffer, the rest into a queue (GetPendingFrame).  Here a frame is
+// a function of the stream's PCM alone (hca_device.hpp PcmMap; every frame independent), so the shell keeps what the caller
+// has fed in HBM (whole blocks: SaveLoopAudio :244-254 reads a block beyond the stream's last sample), walks the reference's
+// counters to know which frames this call completes, and runs hca_encode_kernel on exactly those.
+struct vga_hca_stream {
+    vga_hca_info info;
+    hca::DeviceInfo dev;
+    hca::PcmMap map;
+    int device = 0;
+    int nch = 0, chunks = 0, chunks_fed = 0;
+    // the reference's counters (Initialize :61-114): BufferPreSamples, BufferPosition, SamplesProcessed, FramesProcessed, PostSamples
+    int buffer_pre = 0, buffer_pos = 0, samples_processed = 0, frames_processed = 0, post_samples = 0;
+    std::deque<std::vector<uint8_t>> pending;
+    DevBuf d_pcm, d_frames, d_status;
+    std::vector<uint8_t> host_frames;
+    hipStream_t s = nullptr;
+};
+
 extern "C" {
+
+int vga_hca_stream_create(const vga_hca_params *c, vga_hca_info *info_out, vga_hca_stream **out)
+{
+    if (!out) { set_error("null output"); return VGA_ERR_ARGUMENT; }
+    *out = nullptr;
+    vga_hca_info h;
+    if (int rc = vga_hca_encoder_initialize(c, &h)) return rc;
+    if (info_out) *info_out = h;
+    if (h.channel_count >= 1 && h.frame_size * 8 < 48 + 3 * h.channel_count + 16) {       // (vga_hca_encode_device)
+        set_error("Bitrate is set too low.");
+        return VGA_ERR_INVALID_DATA;
+    }
+    if (int rc = require_device()) return rc;
+    std::unique_ptr<vga_hca_stream> st(new vga_hca_stream);
+    st->info = h;
+    if (int rc = make_device_info(h, st->dev)) return rc;
+    st->nch = h.channel_count;
+    // the blocks the reference consumes: one per started 1024 samples of the (loop-trimmed) stream, at least one
+    st->chunks = std::max(1, divide_by_round_up(h.sample_count, hca::SPF));
+    if (int rc = make_pcm_map(h, st->chunks * hca::SPF, st->map)) return rc;
+    st->map.last_chunk = st->chunks - 1;
+    const int input_samples = h.frame_count * hca::SPF - h.inserted_samples - h.appended_samples;
+    st->post_samples = h.looping ? input_samples - h.sample_count : hca::SPSF;           // :70, :99
+    st->buffer_pre = h.inserted_samples - hca::SPSF;                                        // :113
+    (void)hipGetDevice(&st->device);
+    const size_t pcm_bytes = (size_t)st->nch * st->chunks * hca::SPF * 2;
+    VGA_HIP_TRY(st->d_pcm.alloc(pcm_bytes));
+    VGA_HIP_TRY(hipMemset(st->d_pcm.p, 0, pcm_bytes));
+    VGA_HIP_TRY(st->d_frames.alloc((size_t)round_up((int64_t)h.frame_count * h.frame_size + 8, 16)));
+    VGA_HIP_TRY(st->d_status.alloc(sizeof(int)));
+    VGA_HIP_TRY(hipMemset(st->d_status.p, 0, sizeof(int)));
+    VGA_HIP_TRY(hipStreamCreateWithFlags(&st->s, hipStreamNonBlocking));
+    *out = st.release();
+    return VGA_OK;
+}
+
+void vga_hca_stream_destroy(vga_hca_stream *st)
+{
+    if (!st) return;
+    if (st->s) (void)hipStreamDestroy(st->s);
+    delete st;
+}
+
+int vga_hca_stream_frame_size(const vga_hca_stream *st) { return st ? st->info.frame_size : 0; }
+int vga_hca_stream_frames_processed(const vga_hca_stream *st) { return st ? st->frames_processed : 0; }
+int vga_hca_stream_pending_frame_count(const vga_hca_stream *st) { return st ? (int)st->pending.size() : 0; }
+
+int vga_hca_stream_get_pending_frame(vga_hca_stream *st, uint8_t *frame_out)
+{
+    if (!st || !frame_out) { set_error("null argument"); return VGA_ERR_ARGUMENT; }
+    if (st->pending.empty()) { set_error("There are no pending frames"); return VGA_ERR_INVALID_OP; }    // :158
+    std::memcpy(frame_out, st->pending.front().data(), st->pending.front().size());
+    st->pending.pop_front();
+    return VGA_OK;
+}
+
+int vga_hca_stream_encode(vga_hca_stream *st, const int16_t *const *pcm, uint8_t *hca_out, int *frames_output)
+{
+    if (!st || !pcm || !hca_out || !frames_output) { set_error("null argument"); return VGA_ERR_ARGUMENT; }
+    *frames_output = 0;
+    const vga_hca_info &h = st->info;
+    if (st->frames_processed >= h.frame_count) {                                            // :128-131
+        set_error("All audio frames have already been output by the encoder");
+        return VGA_ERR_INVALID_OP;
+    }
+    for (int c = 0; c < st->nch; c++)
+        if (!pcm[c]) { set_error("pcm[%d] is null", c); return VGA_ERR_ARGUMENT; }
+    int device = -1;
+    (void)hipGetDevice(&device);
+    if (device != st->device) { set_error("the stream was created on device %d, the current one is %d", st->device, device); return VGA_ERR_ARGUMENT; }
+    // the block joins the stream's PCM in HBM (blocks past the stream's end carry nothing the reference reads)
+    if (st->chunks_fed < st->chunks) {
+        const int64_t ch_pitch = (int64_t)st->chunks * hca::SPF;
+        for (int c = 0; c < st->nch; c++)
+            VGA_HIP_TRY(hipMemcpyAsync(st->d_pcm.as<int16_t>() + c * ch_pitch + (int64_t)st->chunks_fed * hca::SPF, pcm[c],
+                                       hca::SPF * sizeof(int16_t), hipMemcpyHostToDevice, st->s));
+        st->chunks_fed++;
+    }
+    // ---- the reference's counters through this call (Encode :126-156 and what it calls): how many frames does it complete?
+    const int first = st->frames_processed;
+    auto flush = [&]() {                                                                    // OutputFrame :256-269
+        if (st->buffer_pos != hca::SPF) return;
+        st->buffer_pos = 0;
+        st->frames_processed++;
+    };
+    int pcm_pos = 0;
+    if (st->buffer_pre > 0) {                                                               // EncodePreAudio :163-183
+        while (st->buffer_pre > hca::SPF) {
+            st->buffer_pos = hca::SPF;
+            flush();
+            st->buffer_pre -= hca::SPF;
+        }
+        st->buffer_pos = st->buffer_pre;
+        st->buffer_pre = 0;
+    }
+    while (hca::SPF - pcm_pos > 0 && h.sample_count > st->samples_processed) {              // EncodeMainAudio :185-200
+        int n = std::min(hca::SPF - st->buffer_pos, hca::SPF - pcm_pos);
+        n = std::min(n, h.sample_count - st->samples_processed);
+        st->buffer_pos += n;
+        st->samples_processed += n;
+        pcm_pos += n;
+        flush();
+    }
+    if (h.sample_count == st->samples_processed) {                                          // EncodePostAudio :202-242
+        int post_pos = 0;
+        while (post_pos < st->post_samples) {
+            const int n = std::min(hca::SPF - st->buffer_pos, st->post_samples - post_pos);
+            st->buffer_pos += n;
+            post_pos += n;
+            flush();
+        }
+        while (st->frames_processed < h.frame_count) {
+            st->buffer_pos = hca::SPF;
+            flush();
+        }
+    }
+    const int count = st->frames_processed - first;
+    *frames_output = count;
+    if (count == 0) return VGA_OK;
+    const uint16_t *pow = nullptr;
+    if (int rc = crc_pow_table(&pow)) return rc;
+    const int64_t ch_pitch = (int64_t)st->chunks * hca::SPF;
+    const int64_t frames_pitch = round_up((int64_t)h.frame_count * h.frame_size + 8, 16);
+    if (int rc = hca::launch_encode(st->d_pcm.as<int16_t>(), ch_pitch * st->nch, ch_pitch, 1, st->map, st->dev, st->d_frames.as<uint8_t>(),
+                                    frames_pitch, pow, st->d_status.as<int>(), st->s, first, count))
+        return rc;
+    st->host_frames.resize((size_t)count * h.frame_size);
+    int status = 0;
+    VGA_HIP_TRY(hipMemcpyAsync(st->host_frames.data(), st->d_frames.as<uint8_t>() + (size_t)first * h.frame_size, st->host_frames.size(),
+                               hipMemcpyDeviceToHost, st->s));
+    VGA_HIP_TRY(hipMemcpyAsync(&status, st->d_status.p, sizeof(int), hipMemcpyDeviceToHost, st->s));
+    VGA_HIP_TRY(hipStreamSynchronize(st->s));
+    if (int rc = status_to_error(status)) return rc;
+    std::memcpy(hca_out, st->host_frames.data(), (size_t)h.frame_size);
+    for (int k = 1; k < count; k++)
+        st->pending.emplace_back(st->host_frames.begin() + (size_t)k * h.frame_size, st->host_frames.begin() + (size_t)(k + 1) * h.frame_size);
+    return VGA_OK;
+}
 
 // CriHcaEncoder.Initialize (CriHcaEncoder.cs:61-114)
 int vga_hca_encoder_initialize(const vga_hca_params *c, vga_hca_info *h)
@@ -298,22 +479,8 @@ int vga_hca_encode_device(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch
         set_error("bad sizes / pitches for vga_hca_encode_device");
         return VGA_ERR_ARGUMENT;
     }
-    // the encoder's input stream (hca_device.hpp PcmMap), from the fields CriHcaEncoder.Initialize derived
     hca::PcmMap m;
-    const int input_samples = h->frame_count * hca::SPF - h->inserted_samples - h->appended_samples;
-    const int pre = h->inserted_samples - hca::SPSF;
-    if (pre < 0 || h->sample_count < 0 || h->sample_count > pcm_length || input_samples < h->sample_count) {
-        set_error("HcaInfo does not describe this PCM (sample count %d of %d, inserted %d, appended %d)", h->sample_count,
-                  pcm_length, h->inserted_samples, h->appended_samples);
-        return VGA_ERR_ARGUMENT;
-    }
-    m.zero_pre = pre > hca::SPF ? (divide_by_round_up(pre, hca::SPF) - 1) * hca::SPF : 0;
-    m.pre_end = pre;
-    m.main_end = pre + h->sample_count;
-    m.post_end = m.main_end + (h->looping ? input_samples - h->sample_count : 0);   // not looping: _postAudio is all zero
-    m.loop_start = h->loop_start_frame * hca::SPF + h->pre_loop_samples - h->inserted_samples;
-    m.last_chunk = h->sample_count > 0 ? (h->sample_count - 1) / hca::SPF : 0;
-    m.raw_len = pcm_length;
+    if (int rc = make_pcm_map(*h, pcm_length, m)) return rc;
     const uint16_t *pow = nullptr;
     if (int rc = crc_pow_table(&pow)) return rc;
     return hca::launch_encode(d_pcm, stream_pitch, ch_pitch, nstreams, m, d, d_frames, frames_pitch, pow,

@@ -318,7 +318,7 @@ struct Emitter {
 __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void hca_encode_kernel(
     const int16_t *__restrict__ pcm, int64_t stream_pitch, int64_t ch_pitch, int frames_per_group, int groups_per_stream, PcmMap map,
     DeviceInfo info, uint8_t *__restrict__ frames, int64_t frames_pitch, const uint16_t *__restrict__ crc_pow,
-    int *__restrict__ status)
+    int *__restrict__ status, int first_frame, int end_frame)
 {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
     __shared__ EncTab T;
@@ -385,8 +385,8 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     const double w_d = (double)__uint_as_float(HCA_MdctWindowF32Bits[127 - wi]);
 
     const int stream = blockIdx.x / groups_per_stream;
-    const int f0 = (blockIdx.x % groups_per_stream) * frames_per_group;
-    const int f1 = min(f0 + frames_per_group, info.frame_count);
+    const int f0 = first_frame + (blockIdx.x % groups_per_stream) * frames_per_group;     // frames [first_frame, end_frame) of every stream
+    const int f1 = min(f0 + frames_per_group, end_frame);
     const int available = info.frame_size * 8;
     const bool small = nch <= 2;
 
@@ -1038,9 +1038,14 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
 
 int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, const PcmMap &map,
                   const DeviceInfo &info, uint8_t *d_frames, int64_t frames_pitch, const uint16_t *d_crc_pow,
-                  int *d_status, hipStream_t stream)
+                  int *d_status, hipStream_t stream, int first_frame, int frame_limit)
 {
-    if (nstreams <= 0 || info.frame_count <= 0) return VGA_OK;
+    // frames [first_frame, first_frame + frame_limit) of every stream (frame_limit < 0: to the stream's end) -- a frame is a
+    // function of the stream's PCM alone (PcmMap), so the streaming shell (vga_hca_stream_encode) asks for the frames the
+    // reference's encoder would have output by now
+    const int end_frame = frame_limit < 0 ? info.frame_count : std::min(info.frame_count, first_frame + frame_limit);
+    if (nstreams <= 0 || first_frame < 0 || end_frame <= first_frame) return VGA_OK;
+    const int frame_span = end_frame - first_frame;
     const int nch = info.nch;
     const size_t doubles = (size_t)nch * 8 * RS + (size_t)nch * 16;
     const size_t ints = 8 + 8 + 8 + 8 + 3 * (size_t)nch * 8;
@@ -1048,13 +1053,14 @@ int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, 
     if (lds > 32 * 1024) VGA_HIP_TRY(allow_dynamic_lds(hca_encode_kernel, lds));
     // frames per workgroup: long runs amortise the per-workgroup set-up (tables, twiddles), short ones keep small inputs
     // spread over the chip
-    const int64_t total = (int64_t)nstreams * info.frame_count;
+    const int64_t total = (int64_t)nstreams * frame_span;
     int per_group = (int)std::min<int64_t>(MAX_ENC_FRAMES_PER_GROUP, std::max<int64_t>(1, total / 8192));
     if (hca_frames_per_group_override() > 0) per_group = std::min(hca_frames_per_group_override(), 64);
-    per_group = std::min(per_group, info.frame_count);
-    const int groups = (info.frame_count + per_group - 1) / per_group;
+    per_group = std::min(per_group, frame_span);
+    const int groups = (frame_span + per_group - 1) / per_group;
     hipLaunchKernelGGL(hca_encode_kernel, dim3((unsigned)((int64_t)nstreams * groups)), dim3(ENC_THREADS), lds, stream,
-                       d_pcm, stream_pitch, ch_pitch, per_group, groups, map, info, d_frames, frames_pitch, d_crc_pow, d_status);
+                       d_pcm, stream_pitch, ch_pitch, per_group, groups, map, info, d_frames, frames_pitch, d_crc_pow, d_status,
+                       first_frame, end_frame);
     VGA_HIP_TRY(hipGetLastError());
     return VGA_OK;
 }

@@ -20,7 +20,7 @@ int launch_decode(const uint8_t *d_frames, int64_t frames_pitch, int nstreams, c
 // d_crc_pow: uint16[4096], x^(8k) mod 0x18005 (built by the host)
 int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, const PcmMap &map,
                   const DeviceInfo &info, uint8_t *d_frames, int64_t frames_pitch, const uint16_t *d_crc_pow,
-                  int *d_status, hipStream_t stream);
+                  int *d_status, hipStream_t stream, int first_frame = 0, int frame_limit = -1);
 
 }  // namespace hca
 }  // namespace vga

@@ -144,6 +144,56 @@ def launch_local_ranks(argv, nproc, master_port=None, extra_env=None, timeout=No
     return rc
 
 
+def describe_job(device):
+    """What the first run on real multi-GPU hardware should be able to prove from its result line alone: the backend and its
+    version, the world size the BACKEND reports (not the environment's), and for every rank its host, process, device index,
+    device name and PCI bus id (gathered with the job's own collective: the list has one entry per rank only if the
+    collective reached all of them; two ranks on one bus id mean the job shares a GPU)."""
+    import socket
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    backend = dist.get_backend() if dist.is_initialized() else "none"
+    dev = torch.device(device)
+    mine = {"rank": rank, "host": socket.gethostname(), "pid": os.getpid(), "device": str(dev)}
+    if dev.type == "cuda":
+        props = torch.cuda.get_device_properties(dev)
+        bus = None
+        if all(hasattr(props, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            bus = "%04x:%02x:%02x" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        mine.update({"name": props.name, "pci_bus_id": bus, "compute_units": props.multi_processor_count,
+                     "memory_GiB": round(props.total_memory / 2 ** 30, 1)})
+    text = repr(mine).encode()[:255]
+    buf = torch.zeros(256, dtype=torch.uint8)
+    buf[:len(text)] = torch.frombuffer(bytearray(text), dtype=torch.uint8)
+    buf[255] = len(text)
+    on = dev if backend == "nccl" else torch.device("cpu")
+    parts = [torch.zeros(256, dtype=torch.uint8, device=on) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(parts, buf.to(on))
+    else:
+        parts = [buf]
+    import ast
+    ranks = []
+    for t in parts:
+        t = t.cpu()
+        n = int(t[255])
+        try:
+            ranks.append(ast.literal_eval(bytes(t[:n].tolist()).decode()))
+        except (ValueError, SyntaxError):
+            ranks.append({"unreadable": True})
+    version = None
+    if backend == "nccl":
+        try:
+            version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001 -- a missing version string must not cost the result line
+            version = "unknown"
+    buses = [r.get("pci_bus_id") for r in ranks if r.get("pci_bus_id")]
+    return {"backend": backend, "rccl_version": version, "world_size_reported_by_backend": world,
+            "world_size_env": int(os.environ.get("WORLD_SIZE", "1")), "ranks": ranks,
+            "distinct_devices": len(set((r.get("host"), r.get("pci_bus_id") or r.get("device")) for r in ranks)),
+            "shared_devices": len(buses) != len(set(buses))}
+
+
 _GOLD = 0x9E3779B97F4A7C15
 _MIX = 0xC2B2AE3D27D4EB4F
 
