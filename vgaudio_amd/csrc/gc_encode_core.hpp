@@ -38,6 +38,15 @@ static __device__ __forceinline__ uint32_t vga_mad24_acc(int e, uint32_t acc)
     return r;
 }
 #define VGA_MAD24_ACC(e, acc) vga_mad24_acc((e), (acc))
+// e * e for |e| <= 65535 as an unsigned 32-bit value.  NOT __mul24: the device library writes that one as a signed C product,
+// the compiler may then assume it stays below 2^31 -- it folded the first two squares of a 64-bit error sum into one 32-bit
+// mad (round 5: every frame of a full-scale square came out with the wrong predictor).
+static __device__ __forceinline__ uint32_t vga_square24(int e)
+{
+    uint32_t r;
+    asm("v_mul_i32_i24 %0, %1, %1" : "=v"(r) : "v"(e));
+    return r;
+}
 #else
 #define VGA_MAD24_ACC(e, acc) ((acc) + (uint32_t)(e) * (uint32_t)(e))
 #define VGA_MUL24(a, b) ((a) * (b))
@@ -291,7 +300,7 @@ VGA_HD PassOut pass_fast_core_t(const int (&x)[16], const int (&in2048v)[14], co
         const int recon = clamp16i(pr11 + (int)((uint32_t)q << km11));
         const int e = x[s + 2] - recon;
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (WIDE_TOTAL) total64 += (uint64_t)(uint32_t)__mul24(e, e);   // |e| <= 65535: the product's low 32 bits are the square
+        if (WIDE_TOTAL) total64 += (uint64_t)vga_square24(e);           // |e| <= 65535: the product's low 32 bits are the square
 #else
         if (WIDE_TOTAL) total64 += (uint64_t)((int64_t)e * (int64_t)e);
 #endif
