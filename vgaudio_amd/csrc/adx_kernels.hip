@@ -249,6 +249,7 @@ __global__ __launch_bounds__(64) void adx_decode_kernel(
 // this box (tools/bench_fill.py): 65 536 slow sequential streams, one per channel and piece (LABNOTES.md 4.3).
 constexpr int ADX_DECODE_WARM_FRAMES = 512;           // even: a piece's frames keep their alignment
 constexpr int ADX_DECODE_SLOW_SEAM = 1024;            // frames a seam may stay open before it counts as slow (a multiple of 128)
+constexpr int ADX_DECODE_TAIL_BUDGET = 2048;          // frames one lane of the tail kernel decodes again before it hands over
 template <bool V4>
 __global__ __launch_bounds__(64) void adx_decode_fs18_direct_kernel(
     const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, AdxDeviceParams p,
@@ -437,12 +438,23 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_direct_kernel(
     if (bad && live && status) atomicOr(status, 1);
 }
 
-// One frame of CriAdxCodec.Decode (:23-45) from the history (hist1, hist2) into o[0 .. valid).
+// One frame of CriAdxCodec.Decode (:23-45) from the history (hist1, hist2) into o[0 .. valid).  `fr` = the frame's first byte:
+// 2 bytes past a dword boundary for odd frames (rows are dword-aligned in these kernels); the 18 bytes arrive as five dword
+// loads from the boundary at or before them and a whole frame leaves as four 16-byte stores (round 5: a byte load per two
+// samples and a 2-byte store per sample until then -- 4 us a frame on a path that can walk a whole channel).
 template <bool V4>
 __device__ __forceinline__ void adx_decode_frame_serial(const uint8_t *fr, const AdxDeviceParams &p, int valid, int &hist1,
                                                         int &hist2, int16_t *o)
 {
-    const int hb0 = fr[0], hb1 = fr[1];
+    const bool odd = (reinterpret_cast<uintptr_t>(fr) & 2) != 0;
+    const uint32_t *f32 = reinterpret_cast<const uint32_t *>(fr - (odd ? 2 : 0));
+    uint32_t t[5], w[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) t[q] = f32[q];
+#pragma unroll
+    for (int q = 0; q < 4; q++) w[q] = odd ? (t[q] >> 16) | (t[q + 1] << 16) : t[q];
+    w[4] = odd ? t[4] >> 16 : t[4];
+    const int hb0 = w[0] & 0xff, hb1 = (w[0] >> 8) & 0xff;
     int filter_num = ((hb0 >> 4) & 0xF) >> 1;
     int cf0, cf1;
     if (p.type == 2) {                                  // the fixed filters (CriAdxCodec.cs:186-191)
@@ -455,16 +467,28 @@ __device__ __forceinline__ void adx_decode_frame_serial(const uint8_t *fr, const
     }
     int scale = (int)(int16_t)(((hb0 << 8) | hb1) & 0x1FFF);
     scale = (int)(int16_t)(p.type == 4 ? (1 << ((12 - scale) & 31)) : scale + 1);
-    for (int s = 0; s < valid; s++) {
-        const int byte = fr[2 + (s >> 1)];
-        int sample = (s & 1) ? (byte & 0xF) : (byte >> 4);
-        sample = (sample ^ 8) - 8;
+    int out[32];
+#pragma unroll
+    for (int s2 = 0; s2 < 32; s2++) {
+        const int b = 2 + (s2 >> 1);                    // the byte that holds sample s2: high nibble first
+        int sample = __builtin_amdgcn_sbfe((int)w[b >> 2], 8 * (b & 3) + ((s2 & 1) ? 0 : 4), 4);
         if (V4) sample = scale * sample + ((hist1 * cf0 + hist2 * cf1) >> 12);
         else sample = scale * sample + ((hist1 * cf0) >> 12) + ((hist2 * cf1) >> 12);
         const int fin = clamp16(sample);
-        hist2 = hist1;
-        hist1 = fin;
-        o[s] = (int16_t)fin;
+        if (s2 < valid) {
+            hist2 = hist1;
+            hist1 = fin;
+        }
+        out[s2] = fin;
+    }
+    if (valid == 32 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            reinterpret_cast<int4 *>(o)[q] =
+                make_int4((out[8 * q] & 0xFFFF) | (out[8 * q + 1] << 16), (out[8 * q + 2] & 0xFFFF) | (out[8 * q + 3] << 16),
+                          (out[8 * q + 4] & 0xFFFF) | (out[8 * q + 5] << 16), (out[8 * q + 6] & 0xFFFF) | (out[8 * q + 7] << 16));
+    } else {
+        for (int s2 = 0; s2 < valid; s2++) o[s2] = (int16_t)out[s2];
     }
 }
 
@@ -527,14 +551,17 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_fixup_kernel(
 template <bool V4>
 __global__ __launch_bounds__(64) void adx_decode_fs18_tail_kernel(
     const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, int segments, AdxDeviceParams p,
-    int16_t *__restrict__ pcm, int64_t pcm_pitch, const int *__restrict__ first_open, const int *__restrict__ seam_open,
-    int force_open, const int *__restrict__ slow_seams)
+    int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ first_open, const int *__restrict__ seam_open,
+    int force_open, int *__restrict__ slow_seams)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= nch) return;
-    if (slow_seams[0] >= slow_seams[1]) return;         // many seams that would not close: the REPAIR launch has them
+    // many seams that would not close -- or a lane of this launch has handed a channel over (below): the REPAIR launch runs,
+    // and it takes every channel whose first_open is still set, this one included
+    if (__hip_atomic_load(&slow_seams[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= slow_seams[1]) return;
     const int k0 = first_open[ch];
     if (k0 <= 0 || k0 >= 0x7f000000) return;
+    int walked_total = 0;                               // frames this lane has decoded again (see ADX_DECODE_TAIL_BUDGET)
     const uint8_t *src = adpcm + (int64_t)ch * in_pitch;
     int16_t *dst = pcm + (int64_t)ch * pcm_pitch;
     bool carry = false;
@@ -552,12 +579,22 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_tail_kernel(
                 int g1 = 0, g2 = 0;
                 if (valid == 32) { g1 = o[31]; g2 = o[30]; }
                 adx_decode_frame_serial<V4>(src + f * 18, p, valid, hist1, hist2, o);
+                walked_total++;
                 if (valid == 32 && hist1 == g1 && hist2 == g2 && !seam_forced_open(force_open, ch, k)) { apart = false; break; }
             }
         }
         const int64_t f1 = f0 + seg_frames;
         if (apart) {
             carry = true;
+            // A run that has not met after ADX_DECODE_TAIL_BUDGET frames (a tone, a clipped wave: it never will) is not
+            // walked to the end of the stream by ONE lane: pieces up to this one are final now, the REPAIR launch decodes
+            // the channel's wave from the next piece on at the direct kernel's speed (bench.py signal_sensitivity: 43
+            // such channels in 4096 cost this kernel 347 ms).  Seams the test hook holds open do not count.
+            if (walked_total >= ADX_DECODE_TAIL_BUDGET && f1 * 32 < total_samples && (force_open == 0 || force_open == 3)) {
+                first_open[ch] = k + 1;
+                atomicMax(&slow_seams[0], slow_seams[1]);
+                return;
+            }
         } else if (flagged && f1 * 32 < total_samples) {
             carry = true;
             hist1 = dst[f1 * 32 - 1];
@@ -565,6 +602,7 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_tail_kernel(
         } else
             carry = false;
     }
+    first_open[ch] = 0x7f7f7f7f;                        // done: nothing of this channel is left for the REPAIR launch
 }
 
 // A frame's 32 input samples as the 16 dwords they are loaded as; sample j sign-extended (one v_bfe_i32 / v_ashrrev, or an
@@ -1147,7 +1185,7 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
                 VGA_HIP_TRY(hipGetLastError());                                                                          \
                 hipLaunchKernelGGL(adx_decode_fs18_tail_kernel<V>, dim3(groups), dim3(64), 0, stream, d_adpcm, in_pitch, \
                                    nch, sample_count, seg_frames, segments, p, d_pcm, pcm_pitch, first_open, seam_open,  \
-                                   force_open_seams(), (const int *)slow_seams);                                        \
+                                   force_open_seams(), slow_seams);                                                     \
                 VGA_HIP_TRY(hipGetLastError());                                                                          \
                 hipLaunchKernelGGL(adx_decode_fs18_direct_kernel<V>, dim3(groups, 1), dim3(64), 0, stream, d_adpcm,      \
                                    in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status,               \

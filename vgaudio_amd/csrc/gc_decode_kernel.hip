@@ -34,6 +34,7 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 // their seam closes on the first frame gc_decode_fixup_kernel checks.
 constexpr int GC_DECODE_WARM = 512;                  // frames; a multiple of 8
 constexpr int GC_DECODE_SLOW_SEAM = 2048;            // frames a seam may stay open before it counts as slow (a multiple of 256)
+constexpr int GC_DECODE_TAIL_BUDGET = 4096;          // frames one lane of the tail kernel decodes again before it hands over
 // RAGGED (the `*_v` entry points): lane i of workgroup x decodes channel order[64 x + i] (longest first), with its own
 // length and offsets; a piece exists for a lane only as far as its channel reaches, the wave runs as many blocks as its
 // longest lane has (lane 0) and every row of the turned store is guarded by its own block count.
@@ -357,16 +358,19 @@ __global__ __launch_bounds__(64) void gc_decode_fixup_kernel(
 __global__ __launch_bounds__(64) void gc_decode_tail_kernel(
     const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
     int total_samples, int seg_frames, int segments, int16_t *__restrict__ pcm, int64_t pcm_pitch,
-    const int *__restrict__ first_open, const int *__restrict__ seam_open, int force_open, const Ragged rg,
-    const int *__restrict__ slow_seams)
+    int *__restrict__ first_open, const int *__restrict__ seam_open, int force_open, const Ragged rg,
+    int *__restrict__ slow_seams)
 {
     const int slot = blockIdx.x * 64 + threadIdx.x;
     if (slot >= nch) return;
-    if (slow_seams[0] >= slow_seams[1]) return;        // many seams that would not close: the REPAIR launch of the direct kernel has them
+    // many seams that would not close -- or a lane of this launch has handed a channel over (below): the REPAIR launch of the
+    // direct kernel runs, and it takes every channel whose first_open is still set, this one included
+    if (__hip_atomic_load(&slow_seams[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= slow_seams[1]) return;
     const int ch = rg.order ? rg.order[slot] : slot;
     if (rg.order) total_samples = rg.length[ch];
     const int k0 = first_open[ch];
     if (k0 <= 0 || k0 >= 0x7f000000) return;
+    int walked_total = 0;                              // frames this lane has decoded again (see GC_DECODE_TAIL_BUDGET)
     const uint8_t *src = adpcm + (rg.order ? rg.adpcm_off[ch] : (int64_t)ch * adpcm_pitch);
     int16_t *dst = pcm + (rg.order ? rg.pcm_off[ch] : (int64_t)ch * pcm_pitch);
     int cf[16];
@@ -388,12 +392,21 @@ __global__ __launch_bounds__(64) void gc_decode_tail_kernel(
                 int g1 = 0, g2 = 0;
                 if (valid == 14) { g1 = o[13]; g2 = o[12]; }
                 gc_decode_frame_serial(src + f * 8, cf, valid, h1, h2, o);
+                walked_total++;
                 if (valid == 14 && h1 == g1 && h2 == g2 && !seam_forced_open(force_open, ch, k)) { apart = false; break; }
             }
         }
         const int64_t f1 = f0 + seg_frames;            // the next piece's first frame
         if (apart) {
             carry = true;                              // (h1, h2): the true samples at the end of this piece
+            // A run that has not met after GC_DECODE_TAIL_BUDGET frames (a pure tone: it never will) is not walked to the end
+            // of the stream by ONE lane: the pieces up to this one are final now, the REPAIR launch decodes the channel's wave
+            // from the next piece on at the direct kernel's speed.  Seams the test hook holds open do not count.
+            if (walked_total >= GC_DECODE_TAIL_BUDGET && f1 * 14 < total_samples && (force_open == 0 || force_open == 3)) {
+                first_open[ch] = k + 1;
+                atomicMax(&slow_seams[0], slow_seams[1]);
+                return;
+            }
         } else if (flagged && f1 * 14 < total_samples) {
             carry = true;                              // this piece's own seam ran out of frames: the piece is final, its end the truth
             h1 = dst[f1 * 14 - 1];
@@ -401,6 +414,7 @@ __global__ __launch_bounds__(64) void gc_decode_tail_kernel(
         } else
             carry = false;
     }
+    first_open[ch] = 0x7f7f7f7f;                       // done: nothing of this channel is left for the REPAIR launch
 }
 
 int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_coefs, int nch, int sample_count,

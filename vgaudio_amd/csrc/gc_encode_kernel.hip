@@ -274,7 +274,7 @@ __device__ __forceinline__ void gc_encode_piece(
     const int lane = tid & 63;
     // encoder wave: CPW channels x 8 predictors (x 2 candidates when CPW = 4); helper wave: CS channel slots x TF frames
     constexpr int LPC = 64 / CPW;                          // lanes per channel: 16 or 8
-    const int grp = helper ? lane / TF : wave * CPW + lane / LPC;  // channel slot of this lane
+    int grp = helper ? lane / TF : wave * CPW + lane / LPC;        // channel slot of this lane
     const int l16 = lane & (LPC - 1);
     const int hfr = lane % TF;                         // helper lanes: the frame inside the tile
     const int slot_raw = bx * CS + grp;
@@ -393,7 +393,7 @@ __device__ __forceinline__ void gc_encode_piece(
 
     // -------------------------------------------------------------------- serial (encoder) wave
     __builtin_amdgcn_s_setprio(3);                     // its latency is the kernel's run time: win every issue arbitration
-    const int p = CPW == 4 ? l16 >> 1 : l16;
+    int p = CPW == 4 ? l16 >> 1 : l16;
     const bool cand_b = CPW == 4 && (l16 & 1) != 0;
     const int c0 = coefs[ch * 16 + 2 * p];
     const int c1 = coefs[ch * 16 + 2 * p + 1];
@@ -480,34 +480,36 @@ __device__ __forceinline__ void gc_encode_piece(
         // ---- the frame's tail: argmin over the 8 predictors (first index wins ties, :66-76), winner's history
         // broadcast, winner's record to LDS.  A lambda so that the hot and the cold branch each get their own
         // copy: merging the two branches' PassOut registers instead put the copies on the hot path.
-        auto finish = [&](const PassOut &r, int final_sp, bool fin, bool need64) __attribute__((always_inline)) {
-            int winner = 0;
-            // 32-bit keys: error sums from 2^28 on share one key (such a predictor loses to any below -- as a rule it is one
-            // of several wild ones); only when a channel's BEST is that large do the 64-bit keys decide
-            constexpr unsigned SAT = (1u << 28) - 1;
-            if (!need64) {
-                const unsigned tot = umin32((unsigned)(r.total >> 32) ? SAT : (unsigned)r.total, SAT);
-                const unsigned key = fin ? ((tot << 4) | (unsigned)l16) : 0xFFFFFFFFu;
-                const unsigned best = row16_reduce(key, [](unsigned a, unsigned b) { return a < b ? a : b; });
-                winner = (int)(best & 15u);
-                need64 = __any((best >> 4) >= SAT);
-            }
-            if (__builtin_expect(need64, 0)) {
-                uint64_t key = fin ? ((r.total << 4) | (uint64_t)l16) : ~0ull;
+        // 32-bit keys: error sums from 2^28 on share one key (such a predictor loses to any below -- as a rule it is one of
+        // several wild ones); only when a channel's BEST is that large (`sat`, wave-uniform) do the 64-bit keys decide -- in
+        // the cold block: the hot copy of the frame's tail holds no 64-bit code.
+        constexpr unsigned SAT = (1u << 28) - 1;
+        auto argmin32 = [&](const PassOut &r, bool fin, bool &sat) __attribute__((always_inline)) -> int {
+            const unsigned tot = umin32((unsigned)(r.total >> 32) ? SAT : (unsigned)r.total, SAT);
+            const unsigned key = fin ? ((tot << 4) | (unsigned)l16) : 0xFFFFFFFFu;
+            const unsigned best = row16_reduce(key, [](unsigned a, unsigned b) { return a < b ? a : b; });
+            sat = __any((best >> 4) >= SAT);
+            return (int)(best & 15u);
+        };
+        auto argmin64 = [&](const PassOut &r, bool fin) __attribute__((always_inline)) -> int {
+            uint64_t key = fin ? ((r.total << 4) | (uint64_t)l16) : ~0ull;
 #define VGA_MIN64_STAGE(CTRL)                                                          \
-                {                                                                          \
-                    const unsigned olo = (unsigned)dpp<CTRL>((int)(uint32_t)key);          \
-                    const unsigned ohi = (unsigned)dpp<CTRL>((int)(uint32_t)(key >> 32));  \
-                    const uint64_t okey = ((uint64_t)ohi << 32) | olo;                     \
-                    key = okey < key ? okey : key;                                         \
-                }
-                VGA_MIN64_STAGE(DPP_QUAD_XOR1)
-                VGA_MIN64_STAGE(DPP_QUAD_XOR2)
-                VGA_MIN64_STAGE(DPP_ROW_HALF_MIRROR)
-                VGA_MIN64_STAGE(DPP_ROW_MIRROR)
-#undef VGA_MIN64_STAGE
-                winner = (int)(key & 15u);
+            {                                                                          \
+                const unsigned olo = (unsigned)dpp<CTRL>((int)(uint32_t)key);          \
+                const unsigned ohi = (unsigned)dpp<CTRL>((int)(uint32_t)(key >> 32));  \
+                const uint64_t okey = ((uint64_t)ohi << 32) | olo;                     \
+                key = okey < key ? okey : key;                                         \
             }
+            VGA_MIN64_STAGE(DPP_QUAD_XOR1)
+            VGA_MIN64_STAGE(DPP_QUAD_XOR2)
+            VGA_MIN64_STAGE(DPP_ROW_HALF_MIRROR)
+            VGA_MIN64_STAGE(DPP_ROW_MIRROR)
+#undef VGA_MIN64_STAGE
+            return (int)(key & 15u);
+        };
+        // ---- the frame's tail: winner's history broadcast, winner's record to LDS.  A lambda so that the hot and the cold
+        // branch each get their own copy: merging the two branches' PassOut registers instead put the copies on the hot path.
+        auto commit = [&](const PassOut &r, int final_sp, int winner) __attribute__((always_inline)) {
             const bool won = l16 == winner;
             const unsigned pay = row16_reduce(won ? r.hist_pair : 0u,
                                               [](unsigned a, unsigned b) { return a | b; });
@@ -525,7 +527,9 @@ __device__ __forceinline__ void gc_encode_piece(
             VGA_OPAQUE(h0);                      // hide the 16-bit range: keeps the 24-bit multiplies the next frame
             VGA_OPAQUE(h1);                      // asks for (the compiler otherwise widens them to 64-bit mads)
         };
-        if (__builtin_expect(__any(rare || resume || inexact), 0)) {
+        bool sat = false;
+        const int winner32 = argmin32(r, fin && !inexact, sat);      // (a lane whose sum is not to be trusted yet is not in it)
+        if (__builtin_expect(__any(rare || resume || inexact) || sat, 0)) {
             // ---- cold block (third trips: a third of the wave-frames on the synthetic set, LABNOTES 8.4)
             if (lane == 0) atomicAdd(&s_ncold[wave], 1);   // diagnostics (LDS: no register lives across the frame loop for it)
             ColdState st;
@@ -538,9 +542,12 @@ __device__ __forceinline__ void gc_encode_piece(
             st.generic = redo && !cand_b; st.start = s1 - 1; st.drop = redo && cand_b;
             st.wide = !redo && inexact; st.resume = !redo && resume;
             const ColdOut o = encode_frame_cold(st, r, final_sp, fin);
-            finish(o.r, o.final_sp, o.fin != 0, false);
+            bool sat2 = false;
+            int winner = argmin32(o.r, o.fin != 0, sat2);
+            if (sat2) winner = argmin64(o.r, o.fin != 0);
+            commit(o.r, o.final_sp, winner);
         } else
-            finish(r, final_sp, fin, false);
+            commit(r, final_sp, winner32);
     };
 
     // ---- CPW = 8: lane = (channel, predictor); candidate B (s1 + 1) and candidate A (s1) are two passes of the SAME lane,
@@ -591,35 +598,34 @@ __device__ __forceinline__ void gc_encode_piece(
         r.o12 = r.o13 = 0;
         r.exact = true;
         const int final_sp = fin_a ? sp_a : sp_b;
-        auto finish = [&](const PassOut &r, int final_sp, bool fin, bool need64) __attribute__((always_inline)) {
-            int winner = 0;
-            // 32-bit keys: error sums from 2^28 on share one key (such a predictor loses to any below); only when a channel's
-            // BEST is that large do the 64-bit keys decide
-            constexpr unsigned SAT = (1u << 28) - 1;
-            if (!need64) {
-                const unsigned tot = umin32((unsigned)(r.total >> 32) ? SAT : (unsigned)r.total, SAT);
-                unsigned key = fin ? ((tot << 3) | (unsigned)p) : 0xFFFFFFFFu;
-                key = umin32(key, (unsigned)dpp<DPP_QUAD_XOR1>((int)key));
-                key = umin32(key, (unsigned)dpp<DPP_QUAD_XOR2>((int)key));
-                key = umin32(key, (unsigned)dpp<DPP_ROW_HALF_MIRROR>((int)key));
-                winner = (int)(key & 7u);
-                need64 = __any((key >> 3) >= SAT);
-            }
-            if (__builtin_expect(need64, 0)) {
-                uint64_t key = fin ? ((r.total << 3) | (uint64_t)p) : ~0ull;
+        // 32-bit keys: error sums from 2^28 on share one key (such a predictor loses to any below); only when a channel's BEST
+        // is that large (`sat`, wave-uniform) do the 64-bit keys decide -- in the cold block
+        constexpr unsigned SAT = (1u << 28) - 1;
+        auto argmin32 = [&](const PassOut &r, bool fin, bool &sat) __attribute__((always_inline)) -> int {
+            const unsigned tot = umin32((unsigned)(r.total >> 32) ? SAT : (unsigned)r.total, SAT);
+            unsigned key = fin ? ((tot << 3) | (unsigned)p) : 0xFFFFFFFFu;
+            key = umin32(key, (unsigned)dpp<DPP_QUAD_XOR1>((int)key));
+            key = umin32(key, (unsigned)dpp<DPP_QUAD_XOR2>((int)key));
+            key = umin32(key, (unsigned)dpp<DPP_ROW_HALF_MIRROR>((int)key));
+            sat = __any((key >> 3) >= SAT);
+            return (int)(key & 7u);
+        };
+        auto argmin64 = [&](const PassOut &r, bool fin) __attribute__((always_inline)) -> int {
+            uint64_t key = fin ? ((r.total << 3) | (uint64_t)p) : ~0ull;
 #define VGA_MIN64_STAGE(CTRL)                                                          \
-                {                                                                          \
-                    const unsigned olo = (unsigned)dpp<CTRL>((int)(uint32_t)key);          \
-                    const unsigned ohi = (unsigned)dpp<CTRL>((int)(uint32_t)(key >> 32));  \
-                    const uint64_t okey = ((uint64_t)ohi << 32) | olo;                     \
-                    key = okey < key ? okey : key;                                         \
-                }
-                VGA_MIN64_STAGE(DPP_QUAD_XOR1)
-                VGA_MIN64_STAGE(DPP_QUAD_XOR2)
-                VGA_MIN64_STAGE(DPP_ROW_HALF_MIRROR)
-#undef VGA_MIN64_STAGE
-                winner = (int)(key & 7u);
+            {                                                                          \
+                const unsigned olo = (unsigned)dpp<CTRL>((int)(uint32_t)key);          \
+                const unsigned ohi = (unsigned)dpp<CTRL>((int)(uint32_t)(key >> 32));  \
+                const uint64_t okey = ((uint64_t)ohi << 32) | olo;                     \
+                key = okey < key ? okey : key;                                         \
             }
+            VGA_MIN64_STAGE(DPP_QUAD_XOR1)
+            VGA_MIN64_STAGE(DPP_QUAD_XOR2)
+            VGA_MIN64_STAGE(DPP_ROW_HALF_MIRROR)
+#undef VGA_MIN64_STAGE
+            return (int)(key & 7u);
+        };
+        auto commit = [&](const PassOut &r, int final_sp, int winner) __attribute__((always_inline)) {
             const bool won = p == winner;
             unsigned pay = won ? r.hist_pair : 0u;
             pay |= (unsigned)dpp<DPP_QUAD_XOR1>((int)pay);
@@ -639,7 +645,9 @@ __device__ __forceinline__ void gc_encode_piece(
             VGA_OPAQUE(h0);
             VGA_OPAQUE(h1);
         };
-        if (__builtin_expect(__any(generic || resume || inexact), 0)) {
+        bool sat = false;
+        const int winner32 = argmin32(r, !(generic || resume || inexact), sat);
+        if (__builtin_expect(__any(generic || resume || inexact) || sat, 0)) {
             if (lane == 0) atomicAdd(&s_ncold[wave], 1);   // diagnostics (LDS: no register lives across the frame loop for it)
             ColdState st;
 #pragma unroll
@@ -652,9 +660,12 @@ __device__ __forceinline__ void gc_encode_piece(
             // coefficients; behind the bumps of the pass that started them otherwise
             st.start = !coef_ok ? s1 - 1 : (bump_a ? apply_bumps(s1, ra.max_overflow) : apply_bumps(s1 + 1, rb.max_overflow));
             const ColdOut o = encode_frame_cold(st, r, final_sp, (generic || resume) ? 0 : 1);
-            finish(o.r, o.final_sp, o.fin != 0, false);
+            bool sat2 = false;
+            int winner = argmin32(o.r, o.fin != 0, sat2);
+            if (sat2) winner = argmin64(o.r, o.fin != 0);
+            commit(o.r, o.final_sp, winner);
         } else
-            finish(r, final_sp, true, false);
+            commit(r, final_sp, winner32);
     };
     auto encode_one = [&](Row &R, int buf, int j, bool upd) __attribute__((always_inline)) {
         if constexpr (CPW == 4) encode_frame(R, buf, j, upd);
@@ -669,6 +680,16 @@ __device__ __forceinline__ void gc_encode_piece(
         const int buf = tile & 1;
         const int nf = imin(TF, frames_wg - tile * TF);
         const int left = frames - tile * TF;           // RAGGED: this slot's own frames in the tile
+#ifndef VGA_GC_NO_TILE_REDERIVE                        // (timing-only switch, tools/build_variants.sh)
+        {
+            // the lane's LDS addresses follow from its slot and predictor: derived again for every tile (three VALU ops) --
+            // kept across the piece they were spilled and came back through scratch loads the tile had to wait for
+            int l = lane;
+            asm volatile("" : "+v"(l));
+            grp = wave * CPW + l / LPC;
+            p = CPW == 4 ? (l & (LPC - 1)) >> 1 : (l & (LPC - 1));
+        }
+#endif
         const GcTile &T = s_tile[buf];
         // two row register sets, ping-pong: the LDS reads of frame j+1 are in flight during frame j
         Row RA, RB;
