@@ -573,6 +573,20 @@ def measure_signal_sensitivity(cx, args):
     if check_channels:
         from oracle import pyoracle as po                 # the checker, after the timed launches of each class
     raw = (C.c_ulonglong * 8)()
+    # the cold-block rates come from the library variant that counts them (the product does not: it costs 1 ms of the launch),
+    # in a process of its own -- same classes, same shape
+    cold_rates, cold_note = {}, "vgaudio_amd/libvgaudio_hip_stats.so (the product built with -DVGA_GC_STATS)"
+    stats_lib = os.path.join(ROOT, "vgaudio_amd", "libvgaudio_hip_stats.so")
+    if os.path.exists(stats_lib):
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "signal_cold_rates.py"), str(nch), repr(args.seconds)],
+                               env=dict(os.environ, VGAUDIO_HIP_LIBRARY=stats_lib), capture_output=True, text=True, timeout=300)
+            cold_rates = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        except Exception as e:                          # noqa: BLE001 -- a diagnostic: the block is worth more than this field
+            cold_note = f"not measured: {type(e).__name__}: {e}"
+    else:
+        cold_note = "not measured: vgaudio_amd/libvgaudio_hip_stats.so is not built (python -m vgaudio_amd.build --stats)"
 
     def ev():
         return torch.cuda.Event(enable_timing=True)
@@ -600,7 +614,7 @@ def measure_signal_sensitivity(cx, args):
         if have_stats and L.vga_testing_gc_encode_stats(raw, 1) == 0:
             v = [int(x) / reps for x in raw]
             seams = v[0] + v[1]
-            st = {"cold_block_wave_frame_rate": round(v[4] / v[3], 4) if v[3] else None,
+            st = {"cold_block_wave_frame_rate": cold_rates.get(cls),
                   "seams_per_launch": round(seams), "seams_left_to_chain_kernel": round(v[1]),
                   "channels_walked_by_chain_kernel": round(v[5]),
                   "frames_reencoded_per_seam": round(v[2] / seams, 1) if seams else None,
@@ -646,7 +660,7 @@ def measure_signal_sensitivity(cx, args):
     return {"what": f"{nch} channels x {n} samples of each signal class (vgaudio_amd/signals.py), device-resident: coefficient "
                     f"search + encode (best of {reps} after one untimed pass), the encoder's counters per launch, GC-ADPCM decode, "
                     "ADX encode / decode on the same rows; sampled channels bit for bit against the oracle",
-            "classes": classes, "slowest_class": worst, "slowest_step_vs_synthetic": classes[worst]["step_vs_synthetic"],
+            "classes": classes, "cold_block_rate_source": cold_note, "slowest_class": worst, "slowest_step_vs_synthetic": classes[worst]["step_vs_synthetic"],
             "no_class_slower_than_1_5x_synthetic": bool(classes[worst]["step_vs_synthetic"] is not None and classes[worst]["step_vs_synthetic"] <= 1.5)}
 
 
@@ -824,7 +838,7 @@ def run_gc(args, cx):
     verified = 0
     enc_bytes = ENC_BYTES_PER_SAMPLE * nch * n
     full = nch == 4096 and n == 2880000
-    pmc, pmc_note = load_profile_json("gc", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
+    pmc, pmc_note = load_profile_json("gc", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
     traffic = None
     enc_key = "gc_encode_persistent_kernel"            # from 2048 channels on (gc_encode_kernel.hip); the plain grid below
     if pmc and full:
@@ -836,7 +850,7 @@ def run_gc(args, cx):
             pass
     # What actually binds the kernel (LABNOTES.md 4.1): wave-instruction issue.  From the committed SQ counter pass.
     issue = None
-    sqj, sq_note = load_profile_json("gc", "r04_sq_counters.json", "r03_sq_counters.json", "r02_b_sq_counters.json")
+    sqj, sq_note = load_profile_json("gc", "r05_sq_counters.json", "r04_sq_counters.json", "r03_sq_counters.json", "r02_b_sq_counters.json")
     if sqj and full:
         try:
             sq = sqj[enc_key if enc_key in sqj else "gc_encode_kernel"]
@@ -983,7 +997,7 @@ def run_adx(args, cx):
         return None
     bytes_launch = ADX_BYTES_PER_SAMPLE * nch * n
     achieved = bytes_launch / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
-    pmc, pmc_note = load_profile_json("adx", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
+    pmc, pmc_note = load_profile_json("adx", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
     traffic = None
     if pmc and nch == 4096 and n == 2880000:
         traffic = (pmc.get("adx_encode_fs18_direct_kernel") or {}).get("traffic_bytes_per_launch")
@@ -1093,7 +1107,7 @@ def run_hca(args, cx):
         return None
     bytes_launch = (2.0 + info.frame_size * info.frame_count / (2.0 * n)) * chs if n else 0.0
     achieved = bytes_launch / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
-    pmc, pmc_note = load_profile_json("hca", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
+    pmc, pmc_note = load_profile_json("hca", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
     traffic = None
     if pmc and ns == 1024 and n == 2880000:
         traffic = (pmc.get("hca_encode_kernel") or {}).get("traffic_bytes_per_launch")

@@ -47,7 +47,8 @@ int vga_testing_gc_plan_pieces(int cus, int groups, int frames, long long group_
 /* Diagnostics of the GC-ADPCM encoder's data-dependent parts, summed over every launch of the process on the current
  * device since the last reset (the call synchronises the device first): out8 = {seams closed inside their piece, seams left
  * open for the chain kernel, frames re-encoded by seam runs, wave-frames encoded, wave-frames that took the cold block
- * (third trips of the retry loop, GcAdpcmEncoder.cs:127-170), channels the chain kernel walked, pieces encoded, 0}.
+ * (third trips of the retry loop, GcAdpcmEncoder.cs:127-170; counted by -DVGA_GC_STATS builds only), channels the chain kernel
+ * walked, pieces encoded, 1 if this build counts the cold blocks}.
  * reset != 0 clears the counters afterwards.  Returns 0, or -1 when the device cannot be read. */
 int vga_testing_gc_encode_stats(unsigned long long *out8, int reset);
 

@@ -81,6 +81,32 @@ def profile_is_current(profile, codec):
     return all(f in stamp and f in now and stamp[f] == now[f] for f in kernel_sources(codec))
 
 
+# A second library whose GC-ADPCM encoder also counts its cold blocks (-DVGA_GC_STATS: five instructions per cold block, 1 ms of
+# the configs[1] launch -- not in the product): bench.py's signal_sensitivity block reads the third-trip rates from it.
+STATS_OUT = os.path.join(HERE, "libvgaudio_hip_stats.so")
+STATS_SRC = "gc_encode_kernel.hip"
+
+
+def build_stats_variant(verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    src = os.path.join(CSRC, STATS_SRC)
+    obj = os.path.join(OBJ, "stats_" + STATS_SRC[:-4] + ".o")
+    newest = max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in headers()])
+    if os.path.exists(STATS_OUT) and os.path.getmtime(STATS_OUT) >= max(newest, os.path.getmtime(OUT)):
+        return STATS_OUT
+    if not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+        cmd = [hipcc] + FLAGS + ["-DVGA_GC_STATS", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    others = [obj_of(s) for s in sources() if os.path.basename(s) != STATS_SRC]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + others + [obj, "-o", STATS_OUT]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return STATS_OUT
+
+
 def obj_of(src):
     return os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
 
@@ -127,3 +153,5 @@ def build(force=False, verbose=False):
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
     print(OUT)
+    if "--stats" in sys.argv:
+        print(build_stats_variant(verbose=True))

@@ -85,13 +85,19 @@ extern "C" int vga_debug_encode_timestamps(unsigned long long *out, int n)
 // signal_sensitivity block): counted with a handful of atomics per piece and per seam -- nothing in the frame loop but one
 // scalar add inside the cold block.  Summed over every launch of the process since the last reset.
 //   [0] seams closed inside their piece   [1] seams left open for gc_encode_chain_kernel   [2] frames re-encoded by seam runs
-//   [3] wave-frames encoded by the piece kernels   [4] ... of which took the cold block (third trips / rare / wide)
-//   [5] channels gc_encode_chain_kernel had to walk   [6] pieces encoded
+//   [3] wave-frames encoded by the piece kernels   [4] ... of which took the cold block (third trips, bump loop, inexact sums;
+//   counted by -DVGA_GC_STATS builds only -- tools/build_variants.sh stats:"-DVGA_GC_STATS" -- 0 otherwise, [7] says which)
+//   [5] channels gc_encode_chain_kernel had to walk   [6] pieces encoded   [7] 1 = this build counts [4]
 __device__ unsigned long long g_vga_gc_stats[8];
 extern "C" int vga_testing_gc_encode_stats(unsigned long long *out8, int reset)
 {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_vga_gc_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+#ifdef VGA_GC_STATS
+    if (out8) out8[7] = 1;
+#else
+    if (out8) out8[7] = 0;
+#endif
     if (reset) {
         const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_vga_gc_stats), zero, sizeof zero) != hipSuccess) return -1;
@@ -170,6 +176,7 @@ ColdOut encode_frame_cold(ColdState st, PassOut r, int final_sp, int fin)
 #pragma unroll
     for (int i = 0; i < 14; i++) { m[i] = st.m[i]; mp[i] = st.mp[i]; }
     if (st.drop) fin = 0;
+    if (__any((st.generic | st.wide) != 0)) {      // (one test in front of both: the common visitor is a third trip)
     if (__any(st.generic != 0)) {                  // hostile input, and tones the first scale misjudges by 2^5 and more
         if (st.generic) {
             r = resume_passes(x, st.c0, st.c1, st.start, final_sp);
@@ -186,6 +193,7 @@ ColdOut encode_frame_cold(ColdState st, PassOut r, int final_sp, int fin)
             r.total = w.total;
             fin = 1;
         }
+    }
     }
     if (__any(st.resume != 0)) {
         if (st.resume) {
@@ -531,7 +539,9 @@ __device__ __forceinline__ void gc_encode_piece(
         const int winner32 = argmin32(r, fin && !inexact, sat);      // (a lane whose sum is not to be trusted yet is not in it)
         if (__builtin_expect(__any(rare || resume || inexact) || sat, 0)) {
             // ---- cold block (third trips: a third of the wave-frames on the synthetic set, LABNOTES 8.4)
-            if (lane == 0) atomicAdd(&s_ncold[wave], 1);   // diagnostics (LDS: no register lives across the frame loop for it)
+#ifdef VGA_GC_STATS                                                  // (a -DVGA_GC_STATS build only: five instructions per cold block = 1 ms of the launch)
+            if (lane == 0) atomicAdd(&s_ncold[wave], 1);
+#endif
             ColdState st;
 #pragma unroll
             for (int i = 0; i < 16; i++) st.x[i] = x[i];
@@ -648,7 +658,9 @@ __device__ __forceinline__ void gc_encode_piece(
         bool sat = false;
         const int winner32 = argmin32(r, !(generic || resume || inexact), sat);
         if (__builtin_expect(__any(generic || resume || inexact) || sat, 0)) {
-            if (lane == 0) atomicAdd(&s_ncold[wave], 1);   // diagnostics (LDS: no register lives across the frame loop for it)
+#ifdef VGA_GC_STATS                                                  // (a -DVGA_GC_STATS build only: five instructions per cold block = 1 ms of the launch)
+            if (lane == 0) atomicAdd(&s_ncold[wave], 1);
+#endif
             ColdState st;
 #pragma unroll
             for (int i = 0; i < 16; i++) st.x[i] = x[i];
