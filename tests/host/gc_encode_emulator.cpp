@@ -38,6 +38,21 @@ int emu_compare_pass(const int16_t *x16, int c0, int c1, int scale_power)
     return same ? 0 : 1;
 }
 
+// the pass without the f32 detour (NO_ROUND) against the fast pass: equal in every field whenever pass_no_round_is_exact says so.
+// Returns 0 equal (trusted), 1 MISMATCH although trusted, 2 not trusted (the kernel runs the exact pass then)
+int emu_compare_pass_no_round(const int16_t *x16, int c0, int c1, int scale_power)
+{
+    int x[16], m[14], mp[14];
+    for (int i = 0; i < 16; i++) x[i] = x16[i];
+    for (int s = 0; s < 14; s++) { m[s] = x[s + 2] * 2048; mp[s] = m[s] + 1024; }
+    const PassOut n = pass_fast_core_no_round(x, m, mp, c0, c1, scale_power);
+    if (!pass_no_round_is_exact(scale_power, n.max_overflow)) return 2;
+    const PassOut f = pass_fast_core(x, m, mp, c0, c1, scale_power);
+    bool same = (uint32_t)f.total == (uint32_t)n.total && f.max_overflow == n.max_overflow && f.hist_pair == n.hist_pair;
+    for (int s = 0; s < 14; s++) same = same && f.q[s] == n.q[s];
+    return same ? 0 : 1;
+}
+
 // the 64-bit-sum form of the fast pass (the kernel's cold block, round 5) against the literal pass: whatever the overflow,
 // as long as the coefficients cannot wrap int32.  Returns 0 ok, 1 mismatch, 2 not exact (coefficients too large)
 int emu_compare_pass_wide(const int16_t *x16, int c0, int c1, int scale_power)
@@ -122,6 +137,7 @@ int emu_encode(const int16_t *pcm, int sample_count, const int16_t *coefs, int16
 // the scale it moves to), hostile coefficients (the whole loop), a final pass at the cap that overflowed by more than 3 (same
 // pass, 64-bit sum), third trips -- and the argmin over keys that saturate at 2^28 with the 64-bit keys as fall-back.
 // stats: [0] frames [1] generic lanes [2] inexact-sum lanes [3] resume lanes [4] frames whose best key saturated
+//        [5] frames encoded with the passes that skip the f32 detour
 int emu_encode8(const int16_t *pcm, int sample_count, const int16_t *coefs, int16_t hist1, int16_t hist2, uint8_t *out, uint64_t *stats)
 {
     int x[16];
@@ -140,15 +156,35 @@ int emu_encode8(const int16_t *pcm, int sample_count, const int16_t *coefs, int1
         for (int s = 0; s < 14; s++) { m[s] = x[s + 2] * 2048; mp[s] = m[s] + 1024; }
         PassOut fin[8];
         int fin_sp[8];
+        // the passes without the f32 detour when every lane (here: every predictor of this channel; on the GPU eight channels
+        // share the decision) quantises at scale 9 or below and every lane can vouch for them from its overflow
+        int s1_of[8];
+        bool short_passes = true;
         for (int p = 0; p < 8; p++) {
             const int c0 = coefs[2 * p], c1 = coefs[2 * p + 1];
-            const bool coef_ok = (c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1) <= 32767;
             int dmax = 0, dmin = 0;
             prescan_range(x, c0, c1, 0, 14, dmax, dmin);
             int s1 = first_scale_power_from_range(dmax, dmin);
             if (s1 == -100) s1 = first_scale_power_from_md(prescan_sequential(x, c0, c1));
+            s1_of[p] = s1;
+            if (imin(s1 + 1, 12) > 9) short_passes = false;
+        }
+        if (short_passes)
+            for (int p = 0; p < 8; p++) {
+                const int c0 = coefs[2 * p], c1 = coefs[2 * p + 1];
+                const bool coef_ok = (c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1) <= 32767;
+                const int sp_a = imin(s1_of[p], 12), sp_b = imin(s1_of[p] + 1, 12);
+                const PassOut nb = pass_fast_core_no_round(x, m, mp, c0, c1, sp_b), na = pass_fast_core_no_round(x, m, mp, c0, c1, sp_a);
+                if (coef_ok && !(pass_no_round_is_exact(sp_a, na.max_overflow) && pass_no_round_is_exact(sp_b, nb.max_overflow))) short_passes = false;
+            }
+        if (short_passes) stats[5]++;
+        for (int p = 0; p < 8; p++) {
+            const int c0 = coefs[2 * p], c1 = coefs[2 * p + 1];
+            const bool coef_ok = (c0 < 0 ? -c0 : c0) + (c1 < 0 ? -c1 : c1) <= 32767;
+            const int s1 = s1_of[p];
             const int sp_a = imin(s1, 12), sp_b = imin(s1 + 1, 12);
-            const PassOut rb = pass_fast_core(x, m, mp, c0, c1, sp_b), ra = pass_fast_core(x, m, mp, c0, c1, sp_a);
+            const PassOut rb = short_passes ? pass_fast_core_no_round(x, m, mp, c0, c1, sp_b) : pass_fast_core(x, m, mp, c0, c1, sp_b);
+            const PassOut ra = short_passes ? pass_fast_core_no_round(x, m, mp, c0, c1, sp_a) : pass_fast_core(x, m, mp, c0, c1, sp_a);
             const bool cap_a = sp_a >= 12, cap_b = sp_b >= 12;
             const int eff_a = cap_a ? 0 : ra.max_overflow, eff_b = cap_b ? 0 : rb.max_overflow;
             const bool fin_a = eff_a < 2;

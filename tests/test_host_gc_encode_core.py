@@ -72,6 +72,10 @@ def test_frame_resolution_of_the_channel_predictor_layout_on_every_signal_class(
         assert seen[2] > 0            # final passes at the cap with an overflow above 3
     if cls == "synthetic":
         assert seen[3] > 0            # third trips
+    if cls in ("synthetic", "noise_3lsb", "slow_channel_93"):
+        assert seen[5] > 0            # frames encoded without the f32 detour
+    if cls in ("white_full_scale", "clipped_square"):
+        assert seen[5] < seen[0]      # ... and frames that are not
 
 
 def test_hostile_coefficients_and_rail_to_rail_frames_through_the_same_resolution(emu):
@@ -91,6 +95,40 @@ def test_hostile_coefficients_and_rail_to_rail_frames_through_the_same_resolutio
         assert bad.size == 0, (trial, int(bad[0]), stats.tolist())
         seen += stats
     assert seen[1] > 0 and seen[2] > 0 and seen[4] > 0, seen.tolist()
+
+
+def test_pass_without_the_f32_detour_is_the_exact_pass_whenever_its_overflow_bound_holds(emu):
+    """NO_ROUND (gc_encode_core.hpp): (int)(float)d is d below 2^24, a larger distance shows in the pass's overflow -- so a pass
+    whose overflow stays under 2^(13 - scale) - 8 is the exact pass.  Random and adversarial frames (distances around 2^24 at
+    every scale), including coefficients that can wrap: trusted passes must equal the fast pass field for field, and both
+    outcomes must occur."""
+    emu.emu_compare_pass_no_round.argtypes = [C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int]
+    rng = np.random.default_rng(23)
+    seen = {0: 0, 2: 0}
+    for trial in range(120000):
+        kind = trial % 5
+        if kind == 0:
+            x = rng.integers(-32768, 32768, 16).astype(np.int16)
+        elif kind == 1:
+            x = rng.integers(-3000, 3000, 16).astype(np.int16)
+        elif kind == 2:                                     # residuals around 8192 = 2^24 / 2048: the boundary itself
+            base = rng.integers(-12000, 12000)
+            x = (base + rng.integers(-9000, 9000, 16)).clip(-32768, 32767).astype(np.int16)
+        elif kind == 3:
+            x = (np.arange(16) * int(rng.integers(-900, 900)) + int(rng.integers(-9000, 9000))).clip(-32768, 32767).astype(np.int16)
+        else:
+            x = np.where(rng.integers(0, 2, 16) > 0, rng.integers(7000, 9500), -rng.integers(7000, 9500)).astype(np.int16)
+        if trial % 7 == 0:
+            c0, c1 = int(rng.integers(-32768, 32768)), int(rng.integers(-32768, 32768))
+        else:
+            c0, c1 = int(rng.integers(-4096, 4097)), int(rng.integers(-2048, 2049))
+        if trial % 11 == 0:
+            c0 = c1 = 0                                     # d = in * 2048 exactly: |in| >= 8192 is the boundary
+        sp = int(rng.integers(0, 13))
+        rc = emu.emu_compare_pass_no_round(x.ctypes.data_as(C.POINTER(C.c_int16)), c0, c1, sp)
+        assert rc != 1, (x.tolist(), c0, c1, sp)
+        seen[rc] += 1
+    assert seen[0] > 10000 and seen[2] > 20000, seen
 
 
 def test_wide_sum_pass_equals_literal_whatever_the_overflow(emu):

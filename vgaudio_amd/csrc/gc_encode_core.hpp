@@ -261,7 +261,13 @@ VGA_HD int round_through_f32(int d)
 // the overflow as long as the predictor cannot wrap (|c0| + |c1| <= 32767: then |d| < 2^30 + 2^26, u cannot leave int32, and
 // |in - recon| <= 65535 squares into 32 bits).  For the one case the 32-bit sum cannot serve: a pass at the cap (scale 12 ends
 // the reference's loop whatever it overflowed, :170) whose overflow exceeds 3 -- loud noise, clipped waves.
-template <bool WIDE_TOTAL>
+// NO_ROUND (round 5): the pass without the detour through f32 -- r = d instead of r = (int)(float)d, two conversions a
+// sample less.  (int)(float)d IS d while |d| < 2^24, and a sample with |d| >= 2^24 shows: its unclamped nibble has
+// |u| >= 2^(24-k), so the pass's overflow is at least 2^(13 - scale_power) - 8.  A pass whose overflow stays BELOW that bound
+// (pass_no_round_is_exact) therefore never met such a sample -- by induction over the samples it is the exact pass, nibble
+// for nibble -- and one that does not must be run again with the conversions.  The kernel takes this form for a frame when
+// every lane of the wave quantises at scale 9 or below (70 % of the synthetic set's wave-frames).
+template <bool WIDE_TOTAL, bool NO_ROUND = false>
 VGA_HD PassOut pass_fast_core_t(const int (&x)[16], const int (&in2048v)[14], const int (&in2048p)[14], int c0, int c1,
                                 int scale_power)
 {
@@ -285,7 +291,7 @@ VGA_HD PassOut pass_fast_core_t(const int (&x)[16], const int (&in2048v)[14], co
         int base = VGA_MUL24(o0, nc1) + in2048v[s];                 // off the dependent chain (o0 is one step old)
         VGA_OPAQUE(base);
         const int d = VGA_MUL24(o1, nc0) + base;                    // == in2048 - predicted (mod 2^32)
-        const int rd = round_through_f32(d);
+        const int rd = NO_ROUND ? d : round_through_f32(d);
         const int u = (int)((uint32_t)rd + (uint32_t)bias + ((uint32_t)d >> 31)) >> k;
         const int q = imin(imax(u, -8), 7);
         if (s & 1) {
@@ -321,6 +327,16 @@ VGA_HD PassOut pass_fast_core(const int (&x)[16], const int (&in2048v)[14], cons
                               int scale_power)
 {
     return pass_fast_core_t<false>(x, in2048v, in2048p, c0, c1, scale_power);
+}
+VGA_HD PassOut pass_fast_core_no_round(const int (&x)[16], const int (&in2048v)[14], const int (&in2048p)[14], int c0, int c1,
+                                       int scale_power)
+{
+    return pass_fast_core_t<false, true>(x, in2048v, in2048p, c0, c1, scale_power);
+}
+// the bound under which a NO_ROUND pass is the exact pass (scale_power <= 12: the bound is positive up to scale 9)
+VGA_HD bool pass_no_round_is_exact(int scale_power, int max_overflow)
+{
+    return scale_power <= 9 && max_overflow < (1 << (13 - scale_power)) - 8;
 }
 VGA_HD PassOut pass_fast_core_wide(const int (&x)[16], const int (&in2048v)[14], const int (&in2048p)[14], int c0, int c1,
                                    int scale_power)

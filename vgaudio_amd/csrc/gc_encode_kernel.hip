@@ -578,8 +578,27 @@ __device__ __forceinline__ void gc_encode_piece(
             }
         }
         const int sp_a = imin(s1, 12), sp_b = imin(s1 + 1, 12);
-        const PassOut rb = pass_fast_core(x, R.m, R.mp, c0, c1, sp_b);
-        const PassOut ra = pass_fast_core(x, R.m, R.mp, c0, c1, sp_a);
+        // Round 5: when every lane of the wave quantises at scale 9 or below (70 % of the synthetic set's wave-frames) the two
+        // passes run without the detour through f32 -- (int)(float)d is d below 2^24, two conversions a sample less -- and each
+        // lane checks from its overflow that no distance reached 2^24 (gc_encode_core.hpp: NO_ROUND); a lane that cannot
+        // tell sends the wave through the passes as they always were.
+        PassOut ra, rb;
+#ifdef VGA_GC_NO_FAST_PASSES                                        // (timing-only switch, tools/build_variants.sh)
+        bool short_passes = false;
+#else
+        bool short_passes = !__any(sp_b > 9);
+#endif
+        if (short_passes) {
+            rb = pass_fast_core_no_round(x, R.m, R.mp, c0, c1, sp_b);
+            ra = pass_fast_core_no_round(x, R.m, R.mp, c0, c1, sp_a);
+            // (hostile coefficients: the lane walks the reference's loop as written whatever these passes say)
+            const bool trusted = !coef_ok || (pass_no_round_is_exact(sp_a, ra.max_overflow) && pass_no_round_is_exact(sp_b, rb.max_overflow));
+            short_passes = !__any(!trusted);
+        }
+        if (!short_passes) {
+            rb = pass_fast_core(x, R.m, R.mp, c0, c1, sp_b);
+            ra = pass_fast_core(x, R.m, R.mp, c0, c1, sp_a);
+        }
         const bool cap_a = sp_a >= 12, cap_b = sp_b >= 12;         // a pass at the cap ends the loop whatever it overflowed
         const int eff_a = cap_a ? 0 : ra.max_overflow, eff_b = cap_b ? 0 : rb.max_overflow;
         const bool fin_a = eff_a < 2;                              // the reference stops after the pass at s1
