@@ -538,9 +538,84 @@ def measure_mixed_lengths(cx, args, equal_length_value):
                                 "unit": "Msamples/s", "errors": len(errors)}
     if best:
         out["one_call_per_file"]["ragged_call_speedup"] = round((samples_used / best) / (done / dt), 1)
-    del host, outs
+    del outs
+    # ---- the same files through the other two codecs' ragged entry points ("a mixed-lengths measurement for
+    # them"): ONE vga_adx_encode_batch_v / vga_hca_encode_batch_v call on pageable host rows (their kernels take one length a
+    # launch: the rows travel in length buckets a quarter wide, zero-padded on the device -- DESIGN.md 4.6).  Both codecs are
+    # PCIe-bound through host pointers; what a bucketed call loses shows as its ratio to that bound, next to the equal-length
+    # calls' (the `e2e` blocks of the adx / hca lines).  A sample of files bit for bit against the oracle.
+    try:
+        out["other_codecs_one_ragged_call_host_pointers"] = mixed_other_codecs(cx, args, host, counts, rates)
+    except SystemExit:
+        raise
+    except Exception as e:                              # noqa: BLE001 -- the line is worth more than this block
+        out["other_codecs_one_ragged_call_host_pointers"] = {"error": f"{type(e).__name__}: {e}"}
+    del host
     rb.close()
     return out
+
+
+def mixed_other_codecs(cx, args, host, counts, rates):
+    import numpy as np
+    L, lib = cx.L, cx.lib
+    use = len(host)
+    samples = int(np.asarray(counts, dtype=np.int64).sum())
+    res = {}
+    check = 0 if args.no_cpu_baseline else 8
+    if check:
+        from oracle import pyoracle as po                 # the checker, after the timed calls
+    pp = (lib.i16p * use)(*[a.ctypes.data_as(lib.i16p) for a in host])
+    cp = np.asarray(counts, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int))
+    pick = [int(i) for i in np.argsort(counts)[:: max(1, use // 8)]][:8]      # short files first: the oracle's time
+    # ---- CRI ADX
+    params = (lib.AdxParams * use)()
+    for i in range(use):
+        L.vga_adx_default_params(C.byref(params[i]))
+    sizes = [L.vga_adx_encoded_byte_count(int(counts[i]), C.byref(params[i])) for i in range(use)]
+    outs = [np.zeros(max(n_, 1), dtype=np.uint8) for n_ in sizes]
+    op = (lib.u8p * use)(*[a.ctypes.data_as(lib.u8p) for a in outs])
+    hist = np.zeros(use, dtype=np.int16)
+    L.vga_release_cached_memory()
+    lib.check(L.vga_adx_encode_batch_v(pp, cp, use, params, op, hist.ctypes.data_as(lib.i16p)))       # warm-up: fills the device cache
+    t0 = time.perf_counter()
+    lib.check(L.vga_adx_encode_batch_v(pp, cp, use, params, op, hist.ctypes.data_as(lib.i16p)))
+    dt = time.perf_counter() - t0
+    bound = pcie_bound_ms(rates, 2 * samples, int(sum(sizes)))
+    res["adx"] = {"entry_point": "vga_adx_encode_batch_v", "files": use, "samples": samples, "ms": round(dt * 1e3, 1),
+                  "value": round(samples / dt / 1e6, 1), "unit": "Msamples/s", "pcie_bound_ms": round(bound, 1),
+                  "ratio_to_pcie_bound": round(dt * 1e3 / bound, 2)}
+    for i in pick[:check]:
+        if not np.array_equal(outs[i][:sizes[i]], po.adx_encode(host[i], po.adx_params())):
+            raise SystemExit(f"PARITY FAILURE: ragged ADX call, file {i} ({int(counts[i])} samples) differs from the CPU restatement")
+    res["adx"]["bit_exact_files_checked"] = len(pick[:check])
+    del outs, op
+    # ---- CRI HCA: every file a mono stream, quality High
+    cps = (lib.HcaParamsC * use)()
+    infos = (lib.HcaInfoC * use)()
+    for i in range(use):
+        cps[i] = lib.HcaParamsC(2, 0, 0, 1, 48000, int(counts[i]), 0, 0, 0)
+        lib.check(L.vga_hca_encoder_initialize(C.byref(cps[i]), C.byref(infos[i])))
+    fsz = [infos[i].frame_count * infos[i].frame_size for i in range(use)]
+    outs = [np.zeros(max(n_, 1), dtype=np.uint8) for n_ in fsz]
+    op = (lib.u8p * use)(*[a.ctypes.data_as(lib.u8p) for a in outs])
+    L.vga_release_cached_memory()
+    lib.check(L.vga_hca_encode_batch_v(pp, use, cps, infos, op))
+    t0 = time.perf_counter()
+    lib.check(L.vga_hca_encode_batch_v(pp, use, cps, infos, op))
+    dt = time.perf_counter() - t0
+    bound = pcie_bound_ms(rates, 2 * samples, int(sum(fsz)))
+    res["hca"] = {"entry_point": "vga_hca_encode_batch_v (every file a mono stream, quality High)", "files": use, "samples": samples,
+                  "ms": round(dt * 1e3, 1), "value": round(samples / dt / 1e6, 1), "unit": "Msamples/s",
+                  "pcie_bound_ms": round(bound, 1), "ratio_to_pcie_bound": round(dt * 1e3 / bound, 2)}
+    done = 0
+    for i in pick[:max(0, check - 4)]:
+        rc, _, want = po.hca_encode(host[i][None, :], po.hca_params(1, int(counts[i])))
+        if rc != 0 or not np.array_equal(outs[i][:fsz[i]], want.reshape(-1)):
+            raise SystemExit(f"PARITY FAILURE: ragged HCA call, file {i} ({int(counts[i])} samples) differs from the CPU restatement")
+        done += 1
+    res["hca"]["bit_exact_files_checked"] = done
+    L.vga_release_cached_memory()
+    return res
 
 
 def measure_signal_sensitivity(cx, args):

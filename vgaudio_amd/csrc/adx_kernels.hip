@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64) void adx_decode_kernel(
 constexpr int ADX_DECODE_WARM_FRAMES = 512;           // even: a piece's frames keep their alignment
 constexpr int ADX_DECODE_SLOW_SEAM = 1024;            // frames a seam may stay open before it counts as slow (a multiple of 128)
 constexpr int ADX_DECODE_TAIL_BUDGET = 2048;          // frames one lane of the tail kernel decodes again before it hands over
-template <bool V4>
+template <bool V4, bool REPAIR>                       // (REPAIR: a name of its own in profiles, as gc_decode_direct_kernel's)
 __global__ __launch_bounds__(64) void adx_decode_fs18_direct_kernel(
     const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, AdxDeviceParams p,
     int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ status, const int *__restrict__ first_open,
@@ -259,10 +259,10 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_direct_kernel(
     const int ch_raw = blockIdx.x * 64 + threadIdx.x;
     const bool live = ch_raw < nch;
     const int ch = live ? ch_raw : nch - 1;
-    // REPAIR launch (first_open != nullptr; round 5, as gc_decode_direct_kernel's): many seams of the batch would not close
+    // REPAIR launch (round 5, as gc_decode_direct_kernel's): many seams of the batch would not close
     // (tones, clipped waves); the wave decodes its 64 channels again as one piece from the first piece any of them left
     // open, from the samples before it.
-    const bool repair = first_open != nullptr;
+    constexpr bool repair = REPAIR;
     int repair_piece = 0;
     if (repair) {
         if (slow_seams[0] < slow_seams[1]) return;                        // few: adx_decode_fs18_tail_kernel has them
@@ -1174,9 +1174,9 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
         }
 #define VGA_ADX_DEC_T(V)                                                                                                 \
         {                                                                                                                \
-            hipLaunchKernelGGL(adx_decode_fs18_direct_kernel<V>, dim3(groups, segments), dim3(64), 0, stream, d_adpcm,   \
-                               in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status, (const int *)nullptr, \
-                               (const int *)nullptr);                                                                    \
+            hipLaunchKernelGGL((adx_decode_fs18_direct_kernel<V, false>), dim3(groups, segments), dim3(64), 0, stream,   \
+                               d_adpcm, in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status,          \
+                               (const int *)nullptr, (const int *)nullptr);                                              \
             VGA_HIP_TRY(hipGetLastError());                                                                              \
             if (segments > 1) {                                                                                          \
                 hipLaunchKernelGGL(adx_decode_fs18_fixup_kernel<V>, dim3(groups, segments - 1), dim3(64), 0, stream,    \
@@ -1187,8 +1187,8 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
                                    nch, sample_count, seg_frames, segments, p, d_pcm, pcm_pitch, first_open, seam_open,  \
                                    force_open_seams(), slow_seams);                                                     \
                 VGA_HIP_TRY(hipGetLastError());                                                                          \
-                hipLaunchKernelGGL(adx_decode_fs18_direct_kernel<V>, dim3(groups, 1), dim3(64), 0, stream, d_adpcm,      \
-                                   in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status,               \
+                hipLaunchKernelGGL((adx_decode_fs18_direct_kernel<V, true>), dim3(groups, 1), dim3(64), 0, stream,       \
+                                   d_adpcm, in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status,      \
                                    (const int *)first_open, (const int *)slow_seams);                                   \
             }                                                                                                            \
         }

@@ -38,7 +38,9 @@ constexpr int GC_DECODE_TAIL_BUDGET = 4096;          // frames one lane of the t
 // RAGGED (the `*_v` entry points): lane i of workgroup x decodes channel order[64 x + i] (longest first), with its own
 // length and offsets; a piece exists for a lane only as far as its channel reaches, the wave runs as many blocks as its
 // longest lane has (lane 0) and every row of the turned store is guarded by its own block count.
-template <bool TURNED, bool RAGGED>
+// (REPAIR is a template parameter so that the launch carries a name of its own in profiles: it returns at once as a rule and
+// would halve the kernel's average duration)
+template <bool TURNED, bool RAGGED, bool REPAIR>
 __global__ __launch_bounds__(64) void gc_decode_direct_kernel(
     const uint8_t *__restrict__ adpcm, int64_t adpcm_pitch, const int16_t *__restrict__ coefs, int nch,
     int total_samples, int seg_frames, const int16_t *__restrict__ hist1, const int16_t *__restrict__ hist2,
@@ -50,12 +52,12 @@ __global__ __launch_bounds__(64) void gc_decode_direct_kernel(
     const bool live = slot_raw < nch;
     const int slot = live ? slot_raw : nch - 1;
     const int ch = RAGGED ? rg.order[slot] : slot;
-    // REPAIR launch (first_open != nullptr; round 5): the batch holds many seams that would not close -- pure tones, clipped
+    // REPAIR launch (round 5): the batch holds many seams that would not close -- pure tones, clipped
     // waves: a decoder run from a wrong history never falls into step when the predictor's poles sit on the unit circle.  The
     // wave decodes its 64 channels again as ONE piece, from the first piece any of them left open to the end of the stream,
     // from the samples before it (final: every earlier seam of every lane closed).  This is the serial floor -- a lone wave
     // needs ~57 ms for 60 s -- against 1.36 s for the chained tail kernel on a batch of 440 Hz sines (bench.py signal_sensitivity).
-    const bool repair = first_open != nullptr;
+    constexpr bool repair = REPAIR;
     int repair_piece = 0;
     if (repair) {
         if (slow_seams[0] < slow_seams[1]) return;                        // few open seams: gc_decode_tail_kernel has them
@@ -444,18 +446,25 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
     const int seg_frames = ((frames + segments - 1) / segments + 7) / 8 * 8;
     // rows of samples on 16-byte boundaries: whole 224-byte runs leave as 16-byte stores
     const bool turned = (pcm_pitch % 8) == 0 && ((uintptr_t)d_pcm % 16) == 0;
+#define VGA_GC_DIRECT(TURNED_, RAGGED_, REPAIR_, PIECES_, OPEN_, SLOW_)                                                          \
+    hipLaunchKernelGGL((gc_decode_direct_kernel<TURNED_, RAGGED_, REPAIR_>), dim3(groups, PIECES_), dim3(64), 0, stream, d_adpcm, \
+                       adpcm_pitch, d_coefs, nch, sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status, rg,     \
+                       (const int *)(OPEN_), (const int *)(SLOW_))
     auto direct = [&](int pieces, const int *first_open, const int *slow_seams) {
-        if (rgp)                                       // (the ragged layout keeps every row on a 16-byte boundary)
-            hipLaunchKernelGGL((gc_decode_direct_kernel<true, true>), dim3(groups, pieces), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
-                               sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status, rg, first_open, slow_seams);
-        else if (turned)
-            hipLaunchKernelGGL((gc_decode_direct_kernel<true, false>), dim3(groups, pieces), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
-                               sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status, rg, first_open, slow_seams);
-        else
-            hipLaunchKernelGGL((gc_decode_direct_kernel<false, false>), dim3(groups, pieces), dim3(64), 0, stream, d_adpcm, adpcm_pitch, d_coefs, nch,
-                               sample_count, seg_frames, d_hist1, d_hist2, d_pcm, pcm_pitch, d_status, rg, first_open, slow_seams);
+        const bool repair = first_open != nullptr;
+        if (rgp) {                                     // (the ragged layout keeps every row on a 16-byte boundary)
+            if (repair) VGA_GC_DIRECT(true, true, true, pieces, first_open, slow_seams);
+            else VGA_GC_DIRECT(true, true, false, pieces, nullptr, nullptr);
+        } else if (turned) {
+            if (repair) VGA_GC_DIRECT(true, false, true, pieces, first_open, slow_seams);
+            else VGA_GC_DIRECT(true, false, false, pieces, nullptr, nullptr);
+        } else {
+            if (repair) VGA_GC_DIRECT(false, false, true, pieces, first_open, slow_seams);
+            else VGA_GC_DIRECT(false, false, false, pieces, nullptr, nullptr);
+        }
         return hipGetLastError();
     };
+#undef VGA_GC_DIRECT
     VGA_HIP_TRY(direct(segments, nullptr, nullptr));
     if (segments > 1) {
         AsyncBuf scratch;                              // freed (stream-ordered) on every exit path
