@@ -318,6 +318,9 @@ int vga_hca_stream_encode(vga_hca_stream *st, const int16_t *const *pcm, uint8_t
             VGA_HIP_TRY(hipMemcpyAsync(st->d_pcm.as<int16_t>() + c * ch_pitch + (int64_t)st->chunks_fed * hca::SPF, pcm[c],
                                        hca::SPF * sizeof(int16_t), hipMemcpyHostToDevice, st->s));
         st->chunks_fed++;
+        // the caller reuses its block buffer for the next call (CriHcaFormat.cs:50-56 does): the block is on the device before
+        // this call returns, whether or not it completes a frame
+        VGA_HIP_TRY(hipStreamSynchronize(st->s));
     }
     // ---- the reference's counters through this call (Encode :126-156 and what it calls): how many frames does it complete?
     const int first = st->frames_processed;
