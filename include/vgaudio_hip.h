@@ -455,7 +455,7 @@ int vga_hca_decode_batch_v(const vga_hca_info *infos, const uint8_t *const *fram
                            int16_t *const *pcm_out);
 /* device-resident variants: pcm stream s / channel c at d_pcm + s*stream_pitch + c*ch_pitch (samples);
  * frames of stream s at d_frames + s*frames_pitch (even; decode: 4-byte aligned with >= 8 bytes of
- * slack after frame_count*frame_size).  *d_status receives flag bits (1 bad sync, 2 bad scale-factor
+ * slack after frame_count*frame_size).  *d_status receives flag bits (16 internal: cost table; 1 bad sync, 2 bad scale-factor
  * delta, 4 bitrate too low, 8 boundary search failed). */
 size_t vga_hca_decode_workspace_bytes(const vga_hca_info *info, int nstreams);
 int vga_hca_encode_device(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams,

@@ -209,7 +209,12 @@ int emu_encode8(const int16_t *pcm, int sample_count, const int16_t *coefs, int1
                 int sp = s1 + 1;
                 for (;;) {
                     sp++;
-                    r = pass_fast_core(x, m, mp, c0, c1, sp);
+                    bool short_pass = sp <= 9;             // (the kernel: when every lane still in the loop is at scale 9 or below)
+                    if (short_pass) {
+                        r = pass_fast_core_no_round(x, m, mp, c0, c1, sp);
+                        short_pass = pass_no_round_is_exact(sp, r.max_overflow);
+                    }
+                    if (!short_pass) r = pass_fast_core(x, m, mp, c0, c1, sp);
                     const bool cap = sp >= 12;
                     if ((unsigned)r.max_overflow > (cap ? 3u : 248u)) { r = resume_passes(x, c0, c1, sp - 1, fsp); break; }
                     fsp = sp;

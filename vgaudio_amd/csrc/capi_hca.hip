@@ -190,6 +190,7 @@ using vga::hca::crc_pow_table;
 
 int status_to_error(int status)
 {
+    if (status & 16) { set_error("internal: the encoder's bit-cost table could not be built"); return VGA_ERR_DEVICE; }   // (hca_encode_kernel.hip: cost_lut_build)
     if (status & 4) { set_error("Bitrate is set too low."); return VGA_ERR_INVALID_DATA; }     // CriHcaEncoder.cs:471
     if (status & 8) { set_error("evaluation boundary search failed (NotImplementedException in the reference)"); return VGA_ERR_INVALID_OP; }
     if (status & 1) { set_error("Invalid frame header"); return VGA_ERR_INVALID_DATA; }        // CriHcaPacking.cs:76

@@ -201,7 +201,16 @@ ColdOut encode_frame_cold(ColdState st, PassOut r, int final_sp, int fin)
             int sp = st.s1 + 1;                    // < 12: neither candidate was at the cap
             for (;;) {
                 sp++;
-                r = pass_fast_core(x, m, mp, st.c0, st.c1, sp);
+#if defined(VGA_GC_NO_FAST_PASSES) || defined(VGA_GC_NO_FAST_THIRD)  // (timing-only switches, tools/build_variants.sh)
+                bool short_pass = false;
+#else
+                bool short_pass = !__any(sp > 9);  // (over the lanes still in this loop) without the f32 detour, as the first two passes
+#endif
+                if (short_pass) {
+                    r = pass_fast_core_no_round(x, m, mp, st.c0, st.c1, sp);
+                    short_pass = !__any(!pass_no_round_is_exact(sp, r.max_overflow));
+                }
+                if (!short_pass) r = pass_fast_core(x, m, mp, st.c0, st.c1, sp);
                 const bool cap = sp >= 12;
                 if ((unsigned)r.max_overflow > (cap ? 3u : 248u)) {      // bump loop / inexact sum: generic
                     r = resume_passes(x, st.c0, st.c1, sp - 1, final_sp);
@@ -1273,9 +1282,9 @@ int plan_encode_pieces_on(int cus, int groups, int frames, int64_t group_frames,
             while (segments > 1 && seg.first(segments - 1) >= frames) segments--;
         }
     }
-    if (seg.first(segments) < frames) {                // (cannot happen: every branch above covers; a plan that does not must never launch)
-        std::fprintf(stderr, "vgaudio_hip: piece plan covers %lld of %d frames\n", (long long)seg.first(segments), frames);
-        std::abort();
+    if (seg.first(segments) < frames) {                // (every branch above covers; should one ever not: equal pieces do)
+        seg.big = seg.small = (frames + segments - 1) / segments;
+        seg.nb = segments;
     }
     *persistent_out = persistent;
     *seg_out = seg;
