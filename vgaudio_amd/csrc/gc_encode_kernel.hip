@@ -476,19 +476,7 @@ __device__ __forceinline__ void gc_encode_piece(
         int final_sp = imin(s1 + (cand_b ? 1 : 0), 12);
         const bool at_cap = final_sp >= 12;            // the loop never goes past 12: this pass ends it
         const unsigned ov_limit = at_cap ? 3u : 248u;  // see `rare` below
-        // (round 5, as encode_frame8 below: without the detour through f32 when every lane of the wave quantises at scale 9 or
-        // below and can vouch for its pass from its overflow; the two conversions sit on the sample-to-sample chain)
-        PassOut r;
-#ifdef VGA_GC_NO_FAST_PASSES
-        bool short_pass = false;
-#else
-        bool short_pass = !__any(final_sp > 9);
-#endif
-        if (short_pass) {
-            r = pass_fast_core_no_round(x, R.m, R.mp, c0, c1, final_sp);
-            short_pass = !__any(coef_ok && !pass_no_round_is_exact(final_sp, r.max_overflow));
-        }
-        if (!short_pass) r = pass_fast_core(x, R.m, R.mp, c0, c1, final_sp);
+        PassOut r = pass_fast_core(x, R.m, R.mp, c0, c1, final_sp);
         // Straight-line resolution, valid when no lane is `rare`:
         //   * no overflow can start the bump loop (:166-168 needs max_overflow + 8 > 256),
         //   * the 32-bit error sum of every lane that can become final is exact (gc_encode_core.hpp S3:
@@ -861,23 +849,9 @@ __device__ __forceinline__ void seam_run(const int16_t *__restrict__ src, uint8_
             if (s1 == -100) s1 = first_scale_power_from_md(prescan_sequential(x, c0, c1));
         }
         const int sp_a = imin(s1, 12), sp_b = imin(s1 + 1, 12);
-        // (the passes without the f32 detour where every lane can vouch for them, as in encode_frame8: a seam is one wave's
-        // dependent chain, and the two conversions sit on it)
-        PassOut ra, rb;
-#ifdef VGA_GC_NO_FAST_PASSES
-        bool short_passes = false;
-#else
-        bool short_passes = !__any(sp_b > 9);
-#endif
-        if (short_passes) {
-            rb = pass_fast_core_no_round(x, m, mp, c0, c1, sp_b);
-            ra = pass_fast_core_no_round(x, m, mp, c0, c1, sp_a);
-            short_passes = !__any(coef_ok && !(pass_no_round_is_exact(sp_a, ra.max_overflow) && pass_no_round_is_exact(sp_b, rb.max_overflow)));
-        }
-        if (!short_passes) {
-            rb = pass_fast_core(x, m, mp, c0, c1, sp_b);
-            ra = pass_fast_core(x, m, mp, c0, c1, sp_a);
-        }
+        // (the passes as they always were: without the f32 detour -- tried in round 5 -- a seam run is no faster, LABNOTES 9.7)
+        const PassOut rb = pass_fast_core(x, m, mp, c0, c1, sp_b);
+        const PassOut ra = pass_fast_core(x, m, mp, c0, c1, sp_a);
         const bool cap_a = sp_a >= 12, cap_b = sp_b >= 12;
         const bool rare = !coef_ok || (unsigned)ra.max_overflow > (cap_a ? 3u : 248u) || (unsigned)rb.max_overflow > (cap_b ? 3u : 248u);
         const int eff_a = cap_a ? 0 : ra.max_overflow, eff_b = cap_b ? 0 : rb.max_overflow;
