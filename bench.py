@@ -951,6 +951,9 @@ def run_gc(args, cx):
     roofline = {"bound": "hbm", "kernel": "gc_encode_persistent_kernel" if persistent else "gc_encode_kernel", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "traffic_source": pmc_note, "algorithmic_bytes_per_launch": enc_bytes, "launch_ms": round(enc_ms, 3),
+                # every timed step's launch, in order (launch_ms is their mean): back-to-back steps run a few ms slower than a
+                # lone one on a box whose clock settles under sustained load
+                "launch_ms_each": [round(e[1].elapsed_time(e[2]), 2) for e in evs],
                 "launch_parts": (["gc_encode_persistent_kernel (pieces from a queue, seams inside)"] if persistent else
                                  ["gc_encode_kernel<false>", "gc_encode_seam_kernel"]) + ["gc_encode_chain_kernel", "gc_encode_kernel<true>"],
                 "other_kernels": {"gc_coefs_kernel": {
