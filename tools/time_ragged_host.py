@@ -1,0 +1,109 @@
+"""One ragged call of the ADX and the HCA encoder on bench.py's mixed-lengths file set (10 008 mono files, log-uniform 1-120 s,
+pageable host rows), with the chunks of plan_buckets (vgaudio_amd/csrc/host_batch.hpp) shortest first -- the order until round 5
+-- and longest first, in one process on one box: wall time, where the pipeline's threads spent it
+(vga_testing_last_pipeline_stats), and that both orders write the same bytes.
+
+    python tools/time_ragged_host.py [--files N] [--codecs adx hca]"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+NAMES = ["total", "setup", "feeders_memcpy", "feeders_wait_slot", "feeders_issue", "slowest_feeder", "caller_wait_upload",
+         "caller_launch", "caller_tail_sync", "drainers_wait_compute", "drainers_wait_download", "drainers_memcpy",
+         "slowest_drainer", "feeders", "drainers", "chunks", "units_per_chunk", "device_alloc", "entry_point",
+         "feeders_chunk_boundary", "feeders_final_sync", "drainers_register"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--files", type=int, default=0, help="use only the first N files (0: all)")
+    ap.add_argument("--codecs", nargs="+", default=["adx", "hca"])
+    ap.add_argument("--reps", type=int, default=2)
+    args = ap.parse_args()
+    import torch
+    from vgaudio_amd import _lib as lib, device as vdev
+    L = lib.lib()
+    dev = torch.device("cuda", 0)
+    lib.check(L.vga_set_device(0))
+    rng = np.random.default_rng(0xBA7C4)                     # bench.py measure_mixed_lengths
+    target = 4096 * 2_880_000
+    lens, total = [], 0
+    while total < target:
+        n = int(np.exp(rng.uniform(np.log(48000.0), np.log(120 * 48000.0))))
+        lens.append(n)
+        total += n
+    if args.files:
+        lens = lens[:args.files]
+    use = len(lens)
+    rb = vdev.GcRaggedBatch(lens, dev)
+    pcm = rb.synth(first_channel=1 << 20)
+    host = [pcm[int(rb.pcm_offsets[i]):int(rb.pcm_offsets[i]) + lens[i]].cpu().numpy() for i in range(use)]
+    del pcm
+    rb.close()
+    torch.cuda.empty_cache()
+    samples = int(np.sum(np.asarray(lens, dtype=np.int64)))
+    counts = np.asarray(lens, dtype=np.int32)
+    pp = (lib.i16p * use)(*[a.ctypes.data_as(lib.i16p) for a in host])
+    cp = counts.ctypes.data_as(C.POINTER(C.c_int))
+    st = (C.c_double * 32)()
+    print(f"{use} files, {samples} samples, {2 * samples / 1e9:.2f} GB of PCM")
+
+    def run(name, call, outs):
+        keep = {}
+        for shortest_first in (1, 0, 1, 0):
+            L.vga_testing_buckets_shortest_first_this_thread(shortest_first)
+            try:
+                L.vga_release_cached_memory()
+                call()                                        # warm-up: fills the library's cache of device blocks
+                best = None
+                for _ in range(args.reps):
+                    t0 = time.perf_counter()
+                    call()
+                    dt = time.perf_counter() - t0
+                    best = dt if best is None else min(best, dt)
+                nf = L.vga_testing_last_pipeline_stats(st, 32)
+            finally:
+                L.vga_testing_buckets_shortest_first_this_thread(0)
+            b = {k: (int(st[i]) if 13 <= i <= 16 else round(st[i] * 1e3, 1)) for i, k in enumerate(NAMES[:nf])}
+            digest = [hash(o.tobytes()) for o in outs[::97]] + [int(sum(int(o[:64].sum()) for o in outs))]
+            tag = "shortest first" if shortest_first else "longest first "
+            print(f"{name} {tag}  {best * 1e3:7.1f} ms   upload (slowest feeder) {b['slowest_feeder']:6.1f}  after it "
+                  f"{b['total'] - b['slowest_feeder']:6.1f}  chunks {b['chunks']}  drainers' memcpy {b['drainers_memcpy']:6.1f}  "
+                  f"feeders' issue {b['feeders_issue']:6.1f}", flush=True)
+            if keep.setdefault("digest", digest) != digest:
+                raise SystemExit(f"{name}: the two chunk orders wrote different bytes")
+            for o in outs:
+                o[:] = 0
+
+    if "adx" in args.codecs:
+        params = (lib.AdxParams * use)()
+        for i in range(use):
+            L.vga_adx_default_params(C.byref(params[i]))
+        sizes = [L.vga_adx_encoded_byte_count(int(counts[i]), C.byref(params[i])) for i in range(use)]
+        outs = [np.zeros(max(n_, 1), dtype=np.uint8) for n_ in sizes]
+        op = (lib.u8p * use)(*[a.ctypes.data_as(lib.u8p) for a in outs])
+        hist = np.zeros(use, dtype=np.int16)
+        run("adx", lambda: lib.check(L.vga_adx_encode_batch_v(pp, cp, use, params, op, hist.ctypes.data_as(lib.i16p))), outs)
+        del outs, op
+    if "hca" in args.codecs:
+        cps = (lib.HcaParamsC * use)()
+        infos = (lib.HcaInfoC * use)()
+        for i in range(use):
+            cps[i] = lib.HcaParamsC(2, 0, 0, 1, 48000, int(counts[i]), 0, 0, 0)
+            lib.check(L.vga_hca_encoder_initialize(C.byref(cps[i]), C.byref(infos[i])))
+        fsz = [infos[i].frame_count * infos[i].frame_size for i in range(use)]
+        outs = [np.zeros(max(n_, 1), dtype=np.uint8) for n_ in fsz]
+        op = (lib.u8p * use)(*[a.ctypes.data_as(lib.u8p) for a in outs])
+        run("hca", lambda: lib.check(L.vga_hca_encode_batch_v(pp, use, cps, infos, op)), outs)
+    L.vga_release_cached_memory()
+
+
+if __name__ == "__main__":
+    main()

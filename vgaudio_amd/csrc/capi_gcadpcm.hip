@@ -206,6 +206,22 @@ void vga_testing_host_pipeline_this_thread(int feeders, int drainers, int chunk_
     g_pipe_override.slot_bytes = slot_bytes;
 }
 void vga_testing_host_pipeline_tail_this_thread(int tail_units) { g_pipe_override.tail_units = tail_units > 0 ? tail_units : 0; }
+void vga_testing_buckets_shortest_first_this_thread(int on) { g_pipe_override.buckets_shortest_first = on ? 1 : 0; }
+int vga_testing_plan_buckets(const int *group, const int *length, int n, int max_units, long long max_volume, int *order_out,
+                             int *chunk_begin_out, int *chunk_length_out, int *chunk_group_out, int max_chunks)
+{
+    if (n < 0 || (n > 0 && (!group || !length))) return -1;
+    const BucketPlan plan = plan_buckets(std::vector<int>(group, group + n), std::vector<int>(length, length + n), max_units, max_volume);
+    const int chunks = (int)plan.chunk_begin.size() - 1;
+    if (chunks > max_chunks) return -1;
+    for (int i = 0; i < n && order_out; i++) order_out[i] = plan.order[i];
+    for (int k = 0; k <= chunks && chunk_begin_out; k++) chunk_begin_out[k] = plan.chunk_begin[k];
+    for (int k = 0; k < chunks; k++) {
+        if (chunk_length_out) chunk_length_out[k] = plan.chunk_length[k];
+        if (chunk_group_out) chunk_group_out[k] = plan.chunk_group[k];
+    }
+    return chunks;
+}
 int vga_testing_last_pipeline_stats(double *out, int n)
 {
     const PipeReport &r = g_pipe_report;

@@ -10,7 +10,10 @@ namespace vga {
 
 // Per-thread overrides of the pipeline's shape (vga_testing_host_pipeline_this_thread): the tests force many feeders,
 // one-row slots and small chunks on small inputs so that every hand-off of the pipeline is exercised on the GPU box.
-struct PipeOverride { int feeders = 0, drainers = 0, chunk_units = 0, slot_bytes = 0, tail_units = 0; };   // slot_bytes < 0: direct copies (no staging ring); > 0: staged
+struct PipeOverride {
+    int feeders = 0, drainers = 0, chunk_units = 0, slot_bytes = 0, tail_units = 0;   // slot_bytes < 0: direct copies (no staging ring); > 0: staged
+    int buckets_shortest_first = 0;          // plan_buckets: the order the ragged ADX / HCA calls had until round 5 (timing comparisons)
+};
 PipeOverride &pipe_override();                       // capi_gcadpcm.hip
 // the calling thread's last pipeline run, plus what the entry point spent around it (device allocation, small copies)
 struct PipeReport { pipe::Stats stats; double t_alloc = 0, t_entry = 0; };
@@ -188,7 +191,11 @@ struct BucketPlan {
     std::vector<int> chunk_group;    // the chunk's parameter group
     int chunk_of(int first) const { return (int)(std::upper_bound(chunk_begin.begin(), chunk_begin.end(), first) - chunk_begin.begin()) - 1; }
 };
-// group[i]: units of different groups never share a chunk; max_units / max_volume (sum of padded lengths) bound a chunk
+// group[i]: units of different groups never share a chunk; max_units / max_volume (sum of padded lengths) bound a chunk.
+// The chunks run LONGEST FIRST (inside a chunk the units stay in ascending order, its longest last): a call is as long as
+// its upload plus whatever the last chunk still has to compute and hand back, and the last chunk of a length-sorted batch is
+// then its smallest (round 5: with the longest files last, the ragged ADX call of bench.py's 10 008 files ended with
+// 4.8 GB of PCM to encode and 1.35 GB of frames to bring back after the upload was over).
 inline BucketPlan plan_buckets(const std::vector<int> &group, const std::vector<int> &length, int max_units, int64_t max_volume)
 {
     BucketPlan b;
@@ -216,7 +223,18 @@ inline BucketPlan plan_buckets(const std::vector<int> &group, const std::vector<
         }
     }
     b.chunk_begin.push_back(n);
-    return b;
+    if (o.buckets_shortest_first) return b;
+    BucketPlan r;
+    const int chunks = (int)b.chunk_length.size();
+    r.order.reserve(n);
+    for (int k = chunks - 1; k >= 0; k--) {
+        r.chunk_begin.push_back((int)r.order.size());
+        r.chunk_length.push_back(b.chunk_length[k]);
+        r.chunk_group.push_back(b.chunk_group[k]);
+        r.order.insert(r.order.end(), b.order.begin() + b.chunk_begin[k], b.order.begin() + b.chunk_begin[k + 1]);
+    }
+    r.chunk_begin.push_back(n);
+    return r;
 }
 
 }  // namespace vga
