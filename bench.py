@@ -555,6 +555,14 @@ def measure_mixed_lengths(cx, args, equal_length_value):
     return out
 
 
+def pipeline_summary(L):
+    """the calling thread's last pipelined call (vga_testing_last_pipeline_stats): when its upload ended, and the call"""
+    st = (C.c_double * 32)()
+    L.vga_testing_last_pipeline_stats(st, 32)
+    return {"upload_done": round(st[5] * 1e3, 1), "total": round(st[0] * 1e3, 1), "chunks": int(st[15]),
+            "drainers_memcpy_sum": round(st[11] * 1e3, 1)}
+
+
 def mixed_other_codecs(cx, args, host, counts, rates):
     import numpy as np
     L, lib = cx.L, cx.lib
@@ -583,7 +591,7 @@ def mixed_other_codecs(cx, args, host, counts, rates):
     bound = pcie_bound_ms(rates, 2 * samples, int(sum(sizes)))
     res["adx"] = {"entry_point": "vga_adx_encode_batch_v", "files": use, "samples": samples, "ms": round(dt * 1e3, 1),
                   "value": round(samples / dt / 1e6, 1), "unit": "Msamples/s", "pcie_bound_ms": round(bound, 1),
-                  "ratio_to_pcie_bound": round(dt * 1e3 / bound, 2)}
+                  "ratio_to_pcie_bound": round(dt * 1e3 / bound, 2), "pipeline_ms": pipeline_summary(L)}
     for i in pick[:check]:
         if not np.array_equal(outs[i][:sizes[i]], po.adx_encode(host[i], po.adx_params())):
             raise SystemExit(f"PARITY FAILURE: ragged ADX call, file {i} ({int(counts[i])} samples) differs from the CPU restatement")
@@ -606,7 +614,7 @@ def mixed_other_codecs(cx, args, host, counts, rates):
     bound = pcie_bound_ms(rates, 2 * samples, int(sum(fsz)))
     res["hca"] = {"entry_point": "vga_hca_encode_batch_v (every file a mono stream, quality High)", "files": use, "samples": samples,
                   "ms": round(dt * 1e3, 1), "value": round(samples / dt / 1e6, 1), "unit": "Msamples/s",
-                  "pcie_bound_ms": round(bound, 1), "ratio_to_pcie_bound": round(dt * 1e3 / bound, 2)}
+                  "pcie_bound_ms": round(bound, 1), "ratio_to_pcie_bound": round(dt * 1e3 / bound, 2), "pipeline_ms": pipeline_summary(L)}
     done = 0
     for i in pick[:max(0, check - 4)]:
         rc, _, want = po.hca_encode(host[i][None, :], po.hca_params(1, int(counts[i])))

@@ -428,3 +428,41 @@ def test_adx_and_hca_files_of_different_shapes_in_one_call():
         want = crihca.CriHcaFormat().EncodeFromPcm16(pcm16)
         assert g.Hca.FrameCount == want.Hca.FrameCount and g.Hca.Looping == want.Hca.Looping
         assert np.array_equal(g.AudioData, want.AudioData), f
+
+
+@pytest.mark.parametrize("pieces,force_open", [(0, 0), (12, 0), (12, 1), (40, 0), (40, 1)])
+def test_adx_ragged_bucket_padding_is_nobodys_output(pieces, force_open):
+    """Channels of one length bucket are zero-padded on the device to the bucket's longest and run through the equal-length
+    kernels cut into time pieces; a seam that lies in a channel's padding -- or runs into it -- is left alone (round 5: in
+    digital silence two runs need never meet, and the ragged call of bench.py's 10 008 files spent 100 ms per bucket chaining
+    them).  Every channel must still be its own encoding / decoding, with short pieces and with every seam held open too
+    (CriAdxCodec.cs:56-104, :9-54)."""
+    L = _lib.lib()
+    # one bucket (within a quarter of each other), lengths that end inside different pieces, one a multiple of 32
+    lens = [100_000 + 997 * i for i in range(23)] + [3200 * 32]
+    chans = _channels(lens, first_channel=90)          # channel 93 (the slowest to fall into step) among them
+    chans[5] = (12000 * np.sign(np.sin(np.arange(lens[5]) * (2 * np.pi / 64)))).astype(np.int16)      # a frame-periodic square: never meets
+    nch = len(lens)
+    params = (_lib.AdxParams * nch)()
+    for c in range(nch):
+        L.vga_adx_default_params(C.byref(params[c]))
+    counts = np.array(lens, dtype=np.int32)
+    outs = [np.full(L.vga_adx_encoded_byte_count(n, C.byref(params[c])) + 1, 0xEE, dtype=np.uint8) for c, n in enumerate(lens)]
+    old_p = L.vga_testing_gc_encoder_segments_this_thread(pieces)
+    old_f = L.vga_testing_force_open_seams_this_thread(force_open)
+    try:
+        _lib.check(L.vga_adx_encode_batch_v(_ptrs(i16p, chans), counts.ctypes.data_as(C.POINTER(C.c_int)), nch, params, _ptrs(u8p, outs), None))
+        enc = []
+        for c, pcm in enumerate(chans):
+            want = po.adx_encode(pcm, po.adx_params())
+            assert outs[c][-1] == 0xEE and np.array_equal(outs[c][:-1], want), (c, lens[c])
+            enc.append(want.copy())
+        alens = np.array([len(e) for e in enc], dtype=np.int32)
+        pcm_out = [np.full(n + 1, 0x7777, dtype=np.int16) for n in lens]
+        _lib.check(L.vga_adx_decode_batch_v(_ptrs(u8p, enc), alens.ctypes.data_as(C.POINTER(C.c_int)), nch,
+                                            counts.ctypes.data_as(C.POINTER(C.c_int)), params, _ptrs(i16p, pcm_out)))
+        for c in range(nch):
+            assert pcm_out[c][-1] == 0x7777 and np.array_equal(pcm_out[c][:-1], po.adx_decode(enc[c], lens[c], po.adx_params())), (c, lens[c])
+    finally:
+        L.vga_testing_gc_encoder_segments_this_thread(old_p)
+        L.vga_testing_force_open_seams_this_thread(old_f)

@@ -501,12 +501,17 @@ template <bool V4>
 __global__ __launch_bounds__(64) void adx_decode_fs18_fixup_kernel(
     const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, AdxDeviceParams p,
     int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ first_open, int *__restrict__ seam_open, int force_open,
-    int *__restrict__ slow_seams)
+    int *__restrict__ slow_seams, const int *__restrict__ own_samples)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     const int k = blockIdx.y + 1;
     const int64_t f0 = (int64_t)k * seg_frames;
     if (ch >= nch || f0 * 32 >= total_samples) return;
+    // own_samples (the ragged entry point's length buckets, capi_adx.hip): the channel is a shorter stream padded to
+    // total_samples; a seam in its padding is nobody's output, and neither is what a run does once it has passed the
+    // channel's own samples (two runs through zero frames need never meet: -1 is a fixed point of the predictor's floor)
+    const int64_t own = own_samples ? (int64_t)own_samples[ch] : (int64_t)total_samples;
+    if (f0 * 32 >= own) return;
     const uint8_t *src = adpcm + (int64_t)ch * in_pitch;
     int16_t *dst = pcm + (int64_t)ch * pcm_pitch;
     // Seed read concurrently with seam k-1's lane rewriting piece k-1 -- same invariant as gc_decode_fixup_kernel
@@ -526,6 +531,7 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_fixup_kernel(
         adx_decode_frame_serial<V4>(src + f * 18, p, valid, hist1, hist2, o);
         if (valid == 32 && hist1 == g1 && hist2 == g2 && !seam_forced_open(force_open, ch, k)) return;
         if (valid < 32) return;                         // the stream's last, partial frame: nothing follows
+        if ((f + 1) * 32 >= own) return;                // the channel's own samples are all final
         if (++walked == ADX_DECODE_SLOW_SEAM && countable) {
             atomicAdd(&slow_seams[0], 1);
             counted = true;
@@ -552,10 +558,11 @@ template <bool V4>
 __global__ __launch_bounds__(64) void adx_decode_fs18_tail_kernel(
     const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int total_samples, int seg_frames, int segments, AdxDeviceParams p,
     int16_t *__restrict__ pcm, int64_t pcm_pitch, int *__restrict__ first_open, const int *__restrict__ seam_open,
-    int force_open, int *__restrict__ slow_seams)
+    int force_open, int *__restrict__ slow_seams, const int *__restrict__ own_samples)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= nch) return;
+    const int64_t own = own_samples ? (int64_t)own_samples[ch] : (int64_t)total_samples;       // (see the fix-up kernel)
     // many seams that would not close -- or a lane of this launch has handed a channel over (below): the REPAIR launch runs,
     // and it takes every channel whose first_open is still set, this one included
     if (__hip_atomic_load(&slow_seams[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= slow_seams[1]) return;
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_tail_kernel(
     int hist1 = 0, hist2 = 0;
     for (int k = k0; k < segments; k++) {
         const int64_t f0 = (int64_t)k * seg_frames;
-        if (f0 * 32 >= total_samples) break;
+        if (f0 * 32 >= total_samples || f0 * 32 >= own) break;
         const bool flagged = seam_open[(int64_t)(k - 1) * nch + ch] != 0;
         bool apart = false;
         if (carry) {
@@ -581,6 +588,7 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_tail_kernel(
                 adx_decode_frame_serial<V4>(src + f * 18, p, valid, hist1, hist2, o);
                 walked_total++;
                 if (valid == 32 && hist1 == g1 && hist2 == g2 && !seam_forced_open(force_open, ch, k)) { apart = false; break; }
+                if ((f + 1) * 32 >= own) { apart = false; break; }          // past the channel's own samples: as good as met
             }
         }
         const int64_t f1 = f0 + seg_frames;
@@ -914,19 +922,25 @@ template <bool V4, bool EXPONENTIAL>
 __global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, int segments, AdxDeviceParams p,
     uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state, const uint2 *__restrict__ crumbs,
-    int *__restrict__ first_open, int *__restrict__ seam_open, int *__restrict__ seam_end, int force_open, int *__restrict__ queue)
+    int *__restrict__ first_open, int *__restrict__ seam_open, int *__restrict__ seam_end, int force_open, int *__restrict__ queue,
+    const int *__restrict__ own_frames)
 {
     const int lane = threadIdx.x;
     const int c0 = p.coef0, c1 = p.coef1;
     const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
     const int64_t frames = ((int64_t)total_length + 31) / 32;
     const int64_t full_frames = total_length / 32;     // frames with all 32 samples (>= 64 here: pieces are that long at least)
+    // own_frames (the ragged entry points' length buckets, capi_adx.hip): channel ch is a shorter stream zero-padded to
+    // total_length and only its first own_frames[ch] frames are anybody's output.  What a seam does past them is nobody's
+    // business -- and in digital silence the two runs need never meet (the run from the true history settles on a small
+    // non-zero fixed point of the predictor's floors, the guessed run on zero): round 5's ragged call of 10 008 files spent
+    // 100 ms per bucket chaining such seams through the padding of the bucket's shortest file.
     // the pieces that exist: seam k (1 .. pieces - 1) starts piece k
     const int pieces = (int)((frames + seg_frames - 1) / seg_frames) < segments ? (int)((frames + seg_frames - 1) / seg_frames) : segments;
     const int items = nch * (pieces - 1);
     bool active = false, have = false, drained = false;
     int ch = 0, k = 0, ta = 0, tb = 0;
-    int64_t f = 0, fend = 0;
+    int64_t f = 0, fend = 0, own_end = 0;
     const int16_t *src = pcm;
     uint8_t *dst = out;
     uint4 cur[4], nxt[4];
@@ -947,11 +961,12 @@ __global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
                     ch = idx - (k - 1) * nch;
                     f = (int64_t)k * seg_frames;
                     fend = f + seg_frames < frames ? f + seg_frames : frames;
+                    own_end = own_frames ? (int64_t)own_frames[ch] : frames;
                     src = pcm + (int64_t)ch * pcm_pitch;
                     dst = out + (int64_t)ch * out_pitch;
                     ta = seg_state[((int64_t)(k - 1) * nch + ch) * 2];
                     tb = seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1];
-                    active = true;
+                    active = f < own_end;               // a seam in the channel's padding: nothing to do
                     have = false;
                 }
             }
@@ -989,6 +1004,8 @@ __global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
             f++;
             if (ta == sa && tb == sb && !seam_forced_open(force_open, ch, k)) {
                 active = false;                         // closed: the rest of the piece stands
+            } else if (f >= own_end) {
+                active = false;                         // the channel's own frames are all written: the rest is padding
             } else if (f >= fend) {
                 // still open at the end of its piece: the chain launch carries on from the history reached here
                 seam_open[(int64_t)(k - 1) * nch + ch] = 1;
@@ -1016,12 +1033,13 @@ template <bool V4, bool EXPONENTIAL>
 __global__ __launch_bounds__(64) void adx_encode_fs18_tail_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, int segments, AdxDeviceParams p,
     uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state, const int *__restrict__ first_open,
-    const int *__restrict__ seam_open, const int *__restrict__ seam_end, int force_open)
+    const int *__restrict__ seam_open, const int *__restrict__ seam_end, int force_open, const int *__restrict__ own_frames)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= nch) return;
     const int k0 = first_open[ch];
     if (k0 <= 0 || k0 >= 0x7f000000) return;
+    const int64_t own_end = own_frames ? (int64_t)own_frames[ch] : ((int64_t)total_length + 31) / 32;   // (see the fix-up kernel)
     const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
     uint8_t *dst = out + (int64_t)ch * out_pitch;
     const int c0 = p.coef0, c1 = p.coef1;
@@ -1030,7 +1048,7 @@ __global__ __launch_bounds__(64) void adx_encode_fs18_tail_kernel(
     int ta = 0, tb = 0;
     for (int k = k0; k < segments; k++) {
         const int64_t f0 = (int64_t)k * seg_frames;
-        if (f0 * 32 >= total_length) break;
+        if (f0 * 32 >= total_length || f0 >= own_end) break;
         const int64_t idx = (int64_t)(k - 1) * nch + ch;
         bool apart = false;
         if (carry)
@@ -1058,7 +1076,7 @@ constexpr int ADX_DIRECT_MIN_PIECE_FRAMES = 2560;
 constexpr int ADX_FIXUP_WAVES_PER_SIMD = 1;
 
 int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_length, const AdxDeviceParams &p,
-                  uint8_t *d_out, int64_t out_pitch, int16_t *d_history_out, hipStream_t stream)
+                  uint8_t *d_out, int64_t out_pitch, int16_t *d_history_out, hipStream_t stream, const int *d_own_frames)
 {
     if (nch <= 0) return VGA_OK;
     const dim3 grid((nch + 63) / 64), block(64);
@@ -1115,11 +1133,11 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
             if (segments > 1) {                                                                                          \
                 hipLaunchKernelGGL((adx_encode_fs18_fixup_kernel<V, E>), dim3(fixup_waves), dim3(64), 0, stream,         \
                                    d_pcm, pcm_pitch, nch, pcm_length, seg_frames, segments, p, d_out, out_pitch, seg_state, crumbs, \
-                                   first_open, seam_open, seam_end, force_open_seams(), queue);                         \
+                                   first_open, seam_open, seam_end, force_open_seams(), queue, d_own_frames);           \
                 VGA_HIP_TRY(hipGetLastError());                                                                          \
                 hipLaunchKernelGGL((adx_encode_fs18_tail_kernel<V, E>), dim3(groups64), dim3(64), 0, stream, d_pcm,     \
                                    pcm_pitch, nch, pcm_length, seg_frames, segments, p, d_out, out_pitch, seg_state,    \
-                                   first_open, seam_open, seam_end, force_open_seams());                                \
+                                   first_open, seam_open, seam_end, force_open_seams(), d_own_frames);                  \
             }                                                                                                            \
         }
         if (v4 && ex) VGA_ADX_ENC_T(true, true)
@@ -1136,7 +1154,7 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
 }
 
 int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_count, const AdxDeviceParams &p,
-                  int16_t *d_pcm, int64_t pcm_pitch, int *d_status, hipStream_t stream)
+                  int16_t *d_pcm, int64_t pcm_pitch, int *d_status, hipStream_t stream, const int *d_own_samples)
 {
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
     const bool fast = p.frame_size == 18 && p.padding == 0 && (pcm_pitch % 8) == 0 && ((uintptr_t)d_pcm % 16) == 0 &&
@@ -1181,11 +1199,11 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
             if (segments > 1) {                                                                                          \
                 hipLaunchKernelGGL(adx_decode_fs18_fixup_kernel<V>, dim3(groups, segments - 1), dim3(64), 0, stream,    \
                                    d_adpcm, in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, first_open,   \
-                                   seam_open, force_open_seams(), slow_seams);                                          \
+                                   seam_open, force_open_seams(), slow_seams, d_own_samples);                           \
                 VGA_HIP_TRY(hipGetLastError());                                                                          \
                 hipLaunchKernelGGL(adx_decode_fs18_tail_kernel<V>, dim3(groups), dim3(64), 0, stream, d_adpcm, in_pitch, \
                                    nch, sample_count, seg_frames, segments, p, d_pcm, pcm_pitch, first_open, seam_open,  \
-                                   force_open_seams(), slow_seams);                                                     \
+                                   force_open_seams(), slow_seams, d_own_samples);                                      \
                 VGA_HIP_TRY(hipGetLastError());                                                                          \
                 hipLaunchKernelGGL((adx_decode_fs18_direct_kernel<V, true>), dim3(groups, 1), dim3(64), 0, stream,       \
                                    d_adpcm, in_pitch, nch, sample_count, seg_frames, p, d_pcm, pcm_pitch, d_status,      \

@@ -341,7 +341,12 @@ int adx_encode_batch_v_one(const int16_t *const *pcm, const int *lengths, int nc
             max_in = std::max(max_in, (size_t)pcm_pitch[k] * 2);
             max_out = std::max(max_out, (size_t)out_pitch[k]);
         }
-    DevBuf d_pcm, d_out, d_hist;
+    DevBuf d_pcm, d_out, d_hist, d_own;
+    // every channel's own frame count, in the plan's order: the seams in a channel's padding are left alone (adx_kernels.hpp)
+    std::vector<int> own(nch);
+    for (int i = 0; i < nch; i++) own[i] = divide_by_round_up(lengths[plan.order[i]], 32);
+    VGA_HIP_TRY(d_own.alloc((size_t)nch * sizeof(int)));
+    VGA_HIP_TRY(hipMemcpy(d_own.p, own.data(), (size_t)nch * sizeof(int), hipMemcpyHostToDevice));
     VGA_HIP_TRY(d_pcm.alloc((size_t)pcm_base[chunks] * 2 + 64));
     VGA_HIP_TRY(hipMemset(d_pcm.p, 0, (size_t)pcm_base[chunks] * 2 + 64));           // the padding behind every row is silence
     VGA_HIP_TRY(d_out.alloc((size_t)out_base[chunks] + 64));
@@ -364,7 +369,8 @@ int adx_encode_batch_v_one(const int16_t *const *pcm, const int *lengths, int nc
     job.compute = [&](int first, int count, hipStream_t s, std::string &why) -> int {
         const int k = plan.chunk_of(first);
         const int rc = adx::launch_encode(d_pcm.as<int16_t>() + pcm_base[k], pcm_pitch[k], count, plan.chunk_length[k], dps[plan.chunk_group[k] / 2],
-                                          d_out.as<uint8_t>() + out_base[k], out_pitch[k], d_hist.as<int16_t>() + first, s);
+                                          d_out.as<uint8_t>() + out_base[k], out_pitch[k], d_hist.as<int16_t>() + first, s,
+                                          d_own.as<int>() + first);
         if (rc) why = vga_last_error();
         return rc;
     };
@@ -433,7 +439,11 @@ int adx_decode_batch_v_one(const uint8_t *const *adpcm, const int *adpcm_lengths
             max_in = std::max(max_in, (size_t)in_pitch[k]);
             max_out = std::max(max_out, (size_t)pcm_pitch[k] * 2);
         }
-    DevBuf d_in, d_pcm, d_status;
+    DevBuf d_in, d_pcm, d_status, d_own;
+    std::vector<int> own(nch);                                                      // (as the encoder's: the plan's order)
+    for (int i = 0; i < nch; i++) own[i] = sample_counts[plan.order[i]];
+    VGA_HIP_TRY(d_own.alloc((size_t)nch * sizeof(int)));
+    VGA_HIP_TRY(hipMemcpy(d_own.p, own.data(), (size_t)nch * sizeof(int), hipMemcpyHostToDevice));
     VGA_HIP_TRY(d_in.alloc((size_t)in_base[chunks] + 64));
     VGA_HIP_TRY(hipMemset(d_in.p, 0, (size_t)in_base[chunks] + 64));                 // frames behind a row's end: scale 0, filter 0
     VGA_HIP_TRY(d_pcm.alloc((size_t)pcm_base[chunks] * 2 + 64));
@@ -459,7 +469,7 @@ int adx_decode_batch_v_one(const uint8_t *const *adpcm, const int *adpcm_lengths
         int rc = VGA_OK;
         if (plan.chunk_length[k] > 0)
             rc = adx::launch_decode(d_in.as<uint8_t>() + in_base[k], in_pitch[k], count, plan.chunk_length[k], dps[plan.chunk_group[k]],
-                                    d_pcm.as<int16_t>() + pcm_base[k], pcm_pitch[k], d_status.as<int>(), s);
+                                    d_pcm.as<int16_t>() + pcm_base[k], pcm_pitch[k], d_status.as<int>(), s, d_own.as<int>() + first);
         if (rc) why = vga_last_error();
         return rc;
     };
