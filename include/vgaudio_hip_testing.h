@@ -63,15 +63,15 @@ void vga_testing_host_pipeline_this_thread(int feeders, int drainers, int chunk_
 void vga_testing_host_pipeline_tail_this_thread(int tail_units);
 
 /* The ragged ADX / HCA entry points (vga_adx_*_batch_v, vga_hca_encode_batch_v) sort their units into chunks of one parameter
- * group and similar length (vgaudio_amd/csrc/host_batch.hpp, plan_buckets) and run the chunks longest first.
- * vga_testing_plan_buckets() returns that plan for n units -- order_out[n]: position -> unit; chunk_begin_out[chunks + 1]:
- * positions; chunk_length_out / chunk_group_out[chunks]: a chunk's largest length and its group -- and the number of chunks
- * (-1: bad arguments or more than max_chunks).  Host code, no GPU.  vga_testing_buckets_shortest_first_this_thread(1)
- * restores, for calls made from the calling thread, the order used until round 5 (timing comparisons; results must not
- * depend on it). */
-int vga_testing_plan_buckets(const int *group, const int *length, int n, int max_units, long long max_volume, int *order_out,
-                             int *chunk_begin_out, int *chunk_length_out, int *chunk_group_out, int max_chunks);
-void vga_testing_buckets_shortest_first_this_thread(int on);
+ * group and similar length (vgaudio_amd/csrc/host_batch.hpp, plan_buckets) and run the chunks shortest first (ADX) or longest
+ * first (HCA).  vga_testing_plan_buckets() returns that plan for n units -- order_out[n]: position -> unit;
+ * chunk_begin_out[chunks + 1]: positions; chunk_length_out / chunk_group_out[chunks]: a chunk's largest length and its group --
+ * and the number of chunks (-1: bad arguments or more than max_chunks).  Host code, no GPU.
+ * vga_testing_buckets_order_this_thread(1 | 2) forces shortest / longest first for calls made from the calling thread
+ * (0: the entry point's own order; timing comparisons -- results must not depend on it). */
+int vga_testing_plan_buckets(const int *group, const int *length, int n, int max_units, long long max_volume, int longest_first,
+                             int *order_out, int *chunk_begin_out, int *chunk_length_out, int *chunk_group_out, int max_chunks);
+void vga_testing_buckets_order_this_thread(int order);
 
 /* Where the wall time of the calling thread's last pipelined call went, in seconds (diagnostics for bench.py's e2e
  * block): [0] total [1] set-up [2] feeders' memcpy (sum over threads) [3] feeders waiting for a ring slot [4] feeders

@@ -1,8 +1,9 @@
 """The ragged ADX / HCA entry points cut a batch into chunks of one parameter group and similar length
 (plan_buckets, vgaudio_amd/csrc/host_batch.hpp; the reference runs a worker per FILE, VGAudio.Cli/Batch.cs:24-25, and
 has no such plan).  Host arithmetic, no GPU: every unit in exactly one chunk, a chunk's units within a quarter of each
-other, never two groups in a chunk, the bounds respected -- and, from round 5, the chunks LONGEST FIRST, so that what is left
-to compute and download when the upload ends is the batch's smallest chunk."""
+other, never two groups in a chunk, the bounds respected -- and the chunks in either order (HCA runs them longest first, so
+that what is left to compute and download when the upload ends is the batch's smallest chunk; ADX shortest first:
+host_batch.hpp has the measurement)."""
 import ctypes as C
 
 import numpy as np
@@ -22,12 +23,8 @@ def plan(group, length, max_units=1024, max_volume=1024 * 2880000, shortest_firs
     clen = np.zeros(cap, dtype=np.int32)
     cgrp = np.zeros(cap, dtype=np.int32)
     ip = C.POINTER(C.c_int)
-    L.vga_testing_buckets_shortest_first_this_thread(int(shortest_first))
-    try:
-        k = L.vga_testing_plan_buckets(g.ctypes.data_as(ip), ln.ctypes.data_as(ip), n, max_units, max_volume, order.ctypes.data_as(ip),
-                                       begin.ctypes.data_as(ip), clen.ctypes.data_as(ip), cgrp.ctypes.data_as(ip), cap)
-    finally:
-        L.vga_testing_buckets_shortest_first_this_thread(0)
+    k = L.vga_testing_plan_buckets(g.ctypes.data_as(ip), ln.ctypes.data_as(ip), n, max_units, max_volume, int(not shortest_first),
+                                   order.ctypes.data_as(ip), begin.ctypes.data_as(ip), clen.ctypes.data_as(ip), cgrp.ctypes.data_as(ip), cap)
     assert k >= 0
     return order[:n], begin[:k + 1], clen[:k], cgrp[:k]
 
@@ -62,7 +59,7 @@ def test_every_unit_in_one_chunk_of_its_group_and_length(n, groups, max_units, s
     check(group, length, *plan(group, length, max_units, vol, shortest_first=True), max_units, vol)
 
 
-def test_chunks_run_longest_first_within_a_group():
+def test_both_orders_hold_the_same_chunks():
     length = log_uniform_lengths(10008, 5)
     group = np.zeros(len(length), dtype=np.int32)
     order, begin, clen, cgrp = plan(group, length)
@@ -93,3 +90,16 @@ def test_volume_bound_and_empty_units():
     assert sorted(cgrp.tolist()) == [0, 0, 1]
     order, begin, clen, cgrp = plan([], [])
     assert len(order) == 0 and len(clen) == 0
+
+
+def test_the_order_hook_wins_over_the_entry_points_choice():
+    L = _lib.lib()
+    length = log_uniform_lengths(2000, 6)
+    group = np.zeros(len(length), dtype=np.int32)
+    try:
+        L.vga_testing_buckets_order_this_thread(1)
+        assert np.all(np.diff(plan(group, length)[2]) >= 0)                        # asked for longest first, forced shortest first
+        L.vga_testing_buckets_order_this_thread(2)
+        assert np.all(np.diff(plan(group, length, shortest_first=True)[2]) <= 0)
+    finally:
+        L.vga_testing_buckets_order_this_thread(0)

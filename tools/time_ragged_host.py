@@ -1,6 +1,5 @@
 """One ragged call of the ADX and the HCA encoder on bench.py's mixed-lengths file set (10 008 mono files, log-uniform 1-120 s,
-pageable host rows), with the chunks of plan_buckets (vgaudio_amd/csrc/host_batch.hpp) shortest first -- the order until round 5
--- and longest first, in one process on one box: wall time, where the pipeline's threads spent it
+pageable host rows), with the chunks of plan_buckets (vgaudio_amd/csrc/host_batch.hpp) shortest first and longest first, in one process on one box: wall time, where the pipeline's threads spent it
 (vga_testing_last_pipeline_stats), and that both orders write the same bytes.
 
     python tools/time_ragged_host.py [--files N] [--codecs adx hca]"""
@@ -26,6 +25,9 @@ def main():
     ap.add_argument("--files", type=int, default=0, help="use only the first N files (0: all)")
     ap.add_argument("--codecs", nargs="+", default=["adx", "hca"])
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--orders", type=int, nargs="+", default=[1, 0], help="1: shortest chunks first, 0: longest first")
+    ap.add_argument("--feeders", type=int, nargs="+", default=[0], help="feeder threads (0: the pipeline's one; negative: a stream each)")
+    ap.add_argument("--chunk-units", type=int, nargs="+", default=[0], help="largest number of units in a chunk (0: the entry point's 1024)")
     args = ap.parse_args()
     import torch
     from vgaudio_amd import _lib as lib, device as vdev
@@ -57,8 +59,9 @@ def main():
 
     def run(name, call, outs):
         keep = {}
-        for shortest_first in (1, 0, 1, 0):
-            L.vga_testing_buckets_shortest_first_this_thread(shortest_first)
+        for shortest_first, units, feeders in [(o, u, f) for f in args.feeders for u in args.chunk_units for o in args.orders] * 2:
+            L.vga_testing_buckets_order_this_thread(1 if shortest_first else 2)
+            L.vga_testing_host_pipeline_this_thread(feeders, 0, units, 0)
             try:
                 L.vga_release_cached_memory()
                 call()                                        # warm-up: fills the library's cache of device blocks
@@ -70,11 +73,12 @@ def main():
                     best = dt if best is None else min(best, dt)
                 nf = L.vga_testing_last_pipeline_stats(st, 32)
             finally:
-                L.vga_testing_buckets_shortest_first_this_thread(0)
+                L.vga_testing_buckets_order_this_thread(0)
+                L.vga_testing_host_pipeline_this_thread(0, 0, 0, 0)
             b = {k: (int(st[i]) if 13 <= i <= 16 else round(st[i] * 1e3, 1)) for i, k in enumerate(NAMES[:nf])}
             digest = [hash(o.tobytes()) for o in outs[::97]] + [int(sum(int(o[:64].sum()) for o in outs))]
             tag = "shortest first" if shortest_first else "longest first "
-            print(f"{name} {tag}  {best * 1e3:7.1f} ms   upload (slowest feeder) {b['slowest_feeder']:6.1f}  after it "
+            print(f"{name} {tag} units/chunk<={units or 1024:5d} feeders {feeders:2d} {best * 1e3:7.1f} ms   upload (slowest feeder) {b['slowest_feeder']:6.1f}  after it "
                   f"{b['total'] - b['slowest_feeder']:6.1f}  chunks {b['chunks']}  drainers' memcpy {b['drainers_memcpy']:6.1f}  "
                   f"feeders' issue {b['feeders_issue']:6.1f}", flush=True)
             if keep.setdefault("digest", digest) != digest:

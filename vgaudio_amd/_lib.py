@@ -167,8 +167,8 @@ SIGNATURES = {
     "vga_testing_gc_encoder_persistent_this_thread": (ci, [ci]),
     "vga_testing_last_pipeline_stats": (ci, [vp, ci]),
     "vga_testing_host_pipeline_tail_this_thread": (None, [ci]),
-    "vga_testing_buckets_shortest_first_this_thread": (None, [ci]),
-    "vga_testing_plan_buckets": (ci, [C.POINTER(ci), C.POINTER(ci), ci, ci, C.c_longlong, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci),
+    "vga_testing_buckets_order_this_thread": (None, [ci]),
+    "vga_testing_plan_buckets": (ci, [C.POINTER(ci), C.POINTER(ci), ci, ci, C.c_longlong, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci),
                                  C.POINTER(ci), ci]),
     "vga_testing_hca_device_info": (ci, [vp, vp, ci]),
     "vga_hca_stream_create": (ci, [vp, vp, C.POINTER(vp)]),

@@ -312,7 +312,7 @@ int adx_encode_batch_v_one(const int16_t *const *pcm, const int *lengths, int nc
         length[c] = lengths[c];
     }
     if (int rc = require_device()) return rc;
-    const BucketPlan plan = plan_buckets(group, length, ADX_CHUNK_CHANNELS, ADX_BUCKET_VOLUME);
+    const BucketPlan plan = plan_buckets(group, length, ADX_CHUNK_CHANNELS, ADX_BUCKET_VOLUME, false);
     const int chunks = (int)plan.chunk_begin.size() - 1;
     // device layout: chunk k's rows pitch_k apart behind the chunks before it
     std::vector<int64_t> pcm_base(chunks + 1, 0), out_base(chunks + 1, 0), pcm_pitch(chunks), out_pitch(chunks);
@@ -410,7 +410,7 @@ int adx_decode_batch_v_one(const uint8_t *const *adpcm, const int *adpcm_lengths
         length[c] = sample_counts[c];
     }
     if (int rc = require_device()) return rc;
-    const BucketPlan plan = plan_buckets(group, length, ADX_CHUNK_CHANNELS, ADX_BUCKET_VOLUME);
+    const BucketPlan plan = plan_buckets(group, length, ADX_CHUNK_CHANNELS, ADX_BUCKET_VOLUME, false);
     const int chunks = (int)plan.chunk_begin.size() - 1;
     std::vector<int64_t> in_base(chunks + 1, 0), pcm_base(chunks + 1, 0), in_pitch(chunks), pcm_pitch(chunks);
     for (int k = 0; k < chunks; k++) {

@@ -206,12 +206,12 @@ void vga_testing_host_pipeline_this_thread(int feeders, int drainers, int chunk_
     g_pipe_override.slot_bytes = slot_bytes;
 }
 void vga_testing_host_pipeline_tail_this_thread(int tail_units) { g_pipe_override.tail_units = tail_units > 0 ? tail_units : 0; }
-void vga_testing_buckets_shortest_first_this_thread(int on) { g_pipe_override.buckets_shortest_first = on ? 1 : 0; }
-int vga_testing_plan_buckets(const int *group, const int *length, int n, int max_units, long long max_volume, int *order_out,
-                             int *chunk_begin_out, int *chunk_length_out, int *chunk_group_out, int max_chunks)
+void vga_testing_buckets_order_this_thread(int order) { g_pipe_override.buckets_order = order == 1 || order == 2 ? order : 0; }
+int vga_testing_plan_buckets(const int *group, const int *length, int n, int max_units, long long max_volume, int longest_first,
+                             int *order_out, int *chunk_begin_out, int *chunk_length_out, int *chunk_group_out, int max_chunks)
 {
     if (n < 0 || (n > 0 && (!group || !length))) return -1;
-    const BucketPlan plan = plan_buckets(std::vector<int>(group, group + n), std::vector<int>(length, length + n), max_units, max_volume);
+    const BucketPlan plan = plan_buckets(std::vector<int>(group, group + n), std::vector<int>(length, length + n), max_units, max_volume, longest_first != 0);
     const int chunks = (int)plan.chunk_begin.size() - 1;
     if (chunks > max_chunks) return -1;
     for (int i = 0; i < n && order_out; i++) order_out[i] = plan.order[i];

@@ -688,7 +688,7 @@ int hca_encode_v_job(const std::vector<int> &units, int nch, const int16_t *cons
         group[i] = hca_group_of(keys, configs[units[i]]);
         length[i] = configs[units[i]].sample_count;
     }
-    const BucketPlan plan = plan_buckets(group, length, HCA_CHUNK_STREAMS, HCA_BUCKET_VOLUME);
+    const BucketPlan plan = plan_buckets(group, length, HCA_CHUNK_STREAMS, HCA_BUCKET_VOLUME, true);
     const int chunks = (int)plan.chunk_begin.size() - 1;
     std::vector<vga_hca_info> chunk_info(chunks);
     std::vector<int64_t> pcm_base(chunks + 1, 0), fr_base(chunks + 1, 0), ch_pitch(chunks), fr_pitch(chunks);

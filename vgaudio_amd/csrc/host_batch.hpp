@@ -12,7 +12,7 @@ namespace vga {
 // one-row slots and small chunks on small inputs so that every hand-off of the pipeline is exercised on the GPU box.
 struct PipeOverride {
     int feeders = 0, drainers = 0, chunk_units = 0, slot_bytes = 0, tail_units = 0;   // slot_bytes < 0: direct copies (no staging ring); > 0: staged
-    int buckets_shortest_first = 0;          // plan_buckets: the order the ragged ADX / HCA calls had until round 5 (timing comparisons)
+    int buckets_order = 0;                   // plan_buckets: 0 = the entry point's own order, 1 = shortest chunks first, 2 = longest first
 };
 PipeOverride &pipe_override();                       // capi_gcadpcm.hip
 // the calling thread's last pipeline run, plus what the entry point spent around it (device allocation, small copies)
@@ -138,14 +138,14 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     const size_t out_row_typical = job.out_row_sizes ? out_total / std::max<size_t>(1, (size_t)job.units * job.out_rows_per_unit) : job.out_row_bytes;
     // Measured on the MI355X box (tools/bench_h2d_modes.hip, tools/bench_overlap.hip, tools/sweep_host_pipeline.py;
     // profiles/r02_*): page-locking the caller's rows for the call (hipHostRegister) lets ONE stream of direct copies
-    // run at the link's rate (~56 GB/s) on the DMA engines next to the kernels; copies issued on several streams at once
-    // were held back until the kernels ended, and a ring filled by memcpy threads was no faster than its four threads.
+    // run at the link's rate (~56 GB/s) on the DMA engines next to the kernels; copies issued on FOUR streams at once
+    // were held back until the kernels ended (two: measured again in round 5, below), and a ring filled by memcpy threads was no faster than its four threads.
     // Downloads are rows of a megabyte or two; issued one by one next to two lanes of kernels they were left waiting
     // until the kernels ended (118 ms after the last kernel), so they go through the page-locked ring in 32 MB copies and
     // two drainer threads hand the rows out.  So: one feeder with direct uploads, two drainers behind a ring, all
     // uploads on one stream and all downloads on another (a slot = the rows a worker takes at a time); slot_bytes < 0
     // (testing hook) makes both directions direct, > 0 both staged.
-    job.feeders = o.feeders > 0 ? o.feeders : 1;
+    job.feeders = o.feeders > 0 ? o.feeders : (o.feeders < 0 ? -o.feeders : 1);   // (test hook, negative: that many feeders, a stream each)
     job.drainers = o.drainers > 0 ? o.drainers : (out_total >= ((size_t)256 << 20) ? 2 : 1);
     // rows worth page-locking one by one: from 256 KB on (smaller rows are cheap to copy into the ring)
     job.direct = o.slot_bytes < 0 || (o.slot_bytes == 0 && in_row_typical >= ((size_t)256 << 10));
@@ -153,7 +153,17 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     // when they are the larger one (a decode: 23.6 GB of PCM through two memcpy threads would be the bottleneck;
     // tools/time_decode_batches.py: ADX 582 -> 527 ms, HCA 323 -> 271 ms)
     job.direct_out = o.slot_bytes < 0 || (o.slot_bytes == 0 && out_row_typical >= ((size_t)256 << 10) && out_total > in_total);
-    job.shared_streams = true;
+    job.shared_streams = o.feeders >= 0;
+    // Ragged jobs in direct mode: thousands of rows, many of them small, and every hipMemcpyAsync leaves the copy engine idle
+    // for ~11 us before the next one of its stream starts (10 008 files, 23.6 GB: 526 ms on one stream against 412 ms at the
+    // link's rate).  Two feeders with a stream each keep two copies in flight: 526 -> 481-488 ms, the ragged ADX call 593-603
+    // -> 554-568 ms; three streams are no better, and the equal-length calls (rows of 5.8 MB) gain 8 ms of 515, inside their
+    // spread, and stay as they are (tools/time_ragged_host.py --feeders 0 -2 -3, tools/sweep_host_pipeline.py;
+    // profiles/r05_t_upload_streams.log).
+    if (o.feeders == 0 && job.in_row_sizes && job.direct) {
+        job.feeders = 2;
+        job.shared_streams = false;
+    }
     job.slot_bytes = o.slot_bytes > 0 ? (size_t)o.slot_bytes : (o.slot_bytes < -1 ? (size_t)(-o.slot_bytes) : (size_t)32 << 20);
     job.chunk_units = planned_chunk_units(job, default_chunk_units);
     // the last chunk is split once, into (5/8, 3/8) of a chunk: the first part's kernels end about when the second part's
@@ -192,11 +202,14 @@ struct BucketPlan {
     int chunk_of(int first) const { return (int)(std::upper_bound(chunk_begin.begin(), chunk_begin.end(), first) - chunk_begin.begin()) - 1; }
 };
 // group[i]: units of different groups never share a chunk; max_units / max_volume (sum of padded lengths) bound a chunk.
-// The chunks run LONGEST FIRST (inside a chunk the units stay in ascending order, its longest last): a call is as long as
-// its upload plus whatever the last chunk still has to compute and hand back, and the last chunk of a length-sorted batch is
-// then its smallest (round 5: with the longest files last, the ragged ADX call of bench.py's 10 008 files ended with
-// 4.8 GB of PCM to encode and 1.35 GB of frames to bring back after the upload was over).
-inline BucketPlan plan_buckets(const std::vector<int> &group, const std::vector<int> &length, int max_units, int64_t max_volume)
+// longest_first: the order the chunks run in (inside a chunk the units stay in ascending order, its longest last).  A call is
+// as long as its upload plus what the last chunk still has to compute and hand back, so the smallest chunk should come last
+// -- as long as the downloads keep up: measured on bench.py's 10 008 files (tools/time_ragged_host.py,
+// profiles/r05_q_ragged_host_orders.log), an HCA call (output a tenth of its input) gains 14 ms of 559 that way, but an ADX
+// call (output 0.28 of its input) loses 135 ms of 592: while gigabyte chunks of uploads are queued, the downloads of the first
+// big chunks crawl (1.35 GB in 410 ms) and everything is handed back after the upload has ended.
+inline BucketPlan plan_buckets(const std::vector<int> &group, const std::vector<int> &length, int max_units, int64_t max_volume,
+                               bool longest_first)
 {
     BucketPlan b;
     const int n = (int)group.size();
@@ -223,7 +236,7 @@ inline BucketPlan plan_buckets(const std::vector<int> &group, const std::vector<
         }
     }
     b.chunk_begin.push_back(n);
-    if (o.buckets_shortest_first) return b;
+    if (o.buckets_order ? o.buckets_order == 1 : !longest_first) return b;
     BucketPlan r;
     const int chunks = (int)b.chunk_length.size();
     r.order.reserve(n);
