@@ -12,3 +12,6 @@ for cls in clipped_square sine440; do
   grep -v amdgpu.ids $O/signal_$cls.log | grep " ms"
   f=$(find $O/prof_$cls -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_signal_$cls.csv
 done
+# the ragged ADX / HCA host calls as the product runs them (two upload streams) with the buckets in both orders
+cd $GRAFT_REPO_ROOT
+timeout 600 python tools/time_ragged_host.py > $O/ragged_host_final.log 2>&1; grep -v amdgpu $O/ragged_host_final.log | tail -9
