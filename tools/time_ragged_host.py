@@ -65,12 +65,14 @@ def main():
             try:
                 L.vga_release_cached_memory()
                 call()                                        # warm-up: fills the library's cache of device blocks
-                best = None
+                best, every = None, []
                 for _ in range(args.reps):
                     t0 = time.perf_counter()
                     call()
                     dt = time.perf_counter() - t0
                     best = dt if best is None else min(best, dt)
+                    L.vga_testing_last_pipeline_stats(st, 32)
+                    every.append("%.0f (upload %.0f)" % (dt * 1e3, st[5] * 1e3))
                 nf = L.vga_testing_last_pipeline_stats(st, 32)
             finally:
                 L.vga_testing_buckets_order_this_thread(0)
@@ -80,7 +82,7 @@ def main():
             tag = "shortest first" if shortest_first else "longest first "
             print(f"{name} {tag} units/chunk<={units or 1024:5d} feeders {feeders:2d} {best * 1e3:7.1f} ms   upload (slowest feeder) {b['slowest_feeder']:6.1f}  after it "
                   f"{b['total'] - b['slowest_feeder']:6.1f}  chunks {b['chunks']}  drainers' memcpy {b['drainers_memcpy']:6.1f}  "
-                  f"feeders' issue {b['feeders_issue']:6.1f}", flush=True)
+                  f"feeders' issue {b['feeders_issue']:6.1f}" + ("   every call: " + ", ".join(every) if args.reps > 2 else ""), flush=True)
             if keep.setdefault("digest", digest) != digest:
                 raise SystemExit(f"{name}: the two chunk orders wrote different bytes")
             for o in outs:

@@ -312,7 +312,10 @@ int adx_encode_batch_v_one(const int16_t *const *pcm, const int *lengths, int nc
         length[c] = lengths[c];
     }
     if (int rc = require_device()) return rc;
-    const BucketPlan plan = plan_buckets(group, length, ADX_CHUNK_CHANNELS, ADX_BUCKET_VOLUME, false);
+    // chunks of at most 256 channels: what is left after the upload (the last, largest chunk's kernels and its download) is
+    // shorter, and the equal-length kernels still fill their launch (10 008 files: 578 ms against 591-601 with 1024, 647-651
+    // with 128 -- 79 launches of ~10 ms are more than the upload hides; profiles/r05_q_ragged_host_orders.log)
+    const BucketPlan plan = plan_buckets(group, length, 256, ADX_BUCKET_VOLUME, false);
     const int chunks = (int)plan.chunk_begin.size() - 1;
     // device layout: chunk k's rows pitch_k apart behind the chunks before it
     std::vector<int64_t> pcm_base(chunks + 1, 0), out_base(chunks + 1, 0), pcm_pitch(chunks), out_pitch(chunks);

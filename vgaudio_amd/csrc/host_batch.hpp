@@ -154,16 +154,11 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     // tools/time_decode_batches.py: ADX 582 -> 527 ms, HCA 323 -> 271 ms)
     job.direct_out = o.slot_bytes < 0 || (o.slot_bytes == 0 && out_row_typical >= ((size_t)256 << 10) && out_total > in_total);
     job.shared_streams = o.feeders >= 0;
-    // Ragged jobs in direct mode: thousands of rows, many of them small, and every hipMemcpyAsync leaves the copy engine idle
-    // for ~11 us before the next one of its stream starts (10 008 files, 23.6 GB: 526 ms on one stream against 412 ms at the
-    // link's rate).  Two feeders with a stream each keep two copies in flight: 526 -> 481-488 ms, the ragged ADX call 593-603
-    // -> 554-568 ms; three streams are no better, and the equal-length calls (rows of 5.8 MB) gain 8 ms of 515, inside their
-    // spread, and stay as they are (tools/time_ragged_host.py --feeders 0 -2 -3, tools/sweep_host_pipeline.py;
-    // profiles/r05_t_upload_streams.log).
-    if (o.feeders == 0 && job.in_row_sizes && job.direct) {
-        job.feeders = 2;
-        job.shared_streams = false;
-    }
+    // Ragged jobs pay ~11 us of idle copy engine per row (10 008 files, 23.6 GB: 528 ms on the one stream against 412 ms at
+    // the link's rate).  Two feeders with a stream each (the test hook's negative feeder count) were measured in round 5
+    // (tools/time_ragged_host.py --feeders 1 0 -2 -3, profiles/r05_t_upload_streams.log): the upload then takes EITHER 447-485 ms
+    // OR 535-545 ms, call by call in one process (ADX: 4 calls of 6 slow, HCA 2 of 6), and one call inside bench.py took 809 ms
+    // -- against 528 +- 3 ms on one stream.  Not used: a steady 600 ms beats 545-620 with outliers.
     job.slot_bytes = o.slot_bytes > 0 ? (size_t)o.slot_bytes : (o.slot_bytes < -1 ? (size_t)(-o.slot_bytes) : (size_t)32 << 20);
     job.chunk_units = planned_chunk_units(job, default_chunk_units);
     // the last chunk is split once, into (5/8, 3/8) of a chunk: the first part's kernels end about when the second part's
