@@ -55,7 +55,9 @@ int vga_testing_gc_encode_stats(unsigned long long *out8, int reset);
 /* The host-pointer entry points (vga_*_batch) move data through a pipeline of feeder threads, pinned rings, per-chunk
  * kernel launches and drainer threads (vgaudio_amd/csrc/host_pipeline.hpp); its shape normally follows the volume of
  * the call.  Non-zero arguments override it for calls made FROM THE CALLING THREAD (0 = automatic): feeder / drainer
- * thread counts, units (channels, streams) per chunk, bytes per ring slot.  Results must not depend on any of them. */
+ * thread counts (a NEGATIVE feeder count: that many feeders with an upload stream each instead of one shared stream, and a
+ * download stream per drainer), units (channels, streams) per chunk, bytes per ring slot.  Results must not depend on any of
+ * them. */
 void vga_testing_host_pipeline_this_thread(int feeders, int drainers, int chunk_units, int slot_bytes);
 
 /* ... and the size of the call's LAST chunk (the last regular chunk is split once into (rest, tail); 0 = automatic: 3/8 of a
