@@ -43,6 +43,15 @@ def main():
         total += n
     if args.files:
         lens = lens[:args.files]
+    # host memory: the PCM rows, (adxdec) as many bytes again for the decoded rows, the encoded rows -- keep to a third of what is free
+    try:
+        avail = [int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0]
+    except (OSError, IndexError):
+        avail = 64 << 30
+    need = 2 * np.cumsum(np.asarray(lens, dtype=np.int64)) * (2.4 if "adxdec" in args.codecs else 1.4)
+    if need[-1] > avail / 2:
+        lens = lens[:max(1, int(np.searchsorted(need, avail / 2)))]
+        print(f"host memory ({avail / 2**30:.0f} GiB available): the first {len(lens)} files only")
     use = len(lens)
     rb = vdev.GcRaggedBatch(lens, dev)
     pcm = rb.synth(first_channel=1 << 20)
@@ -97,6 +106,15 @@ def main():
         op = (lib.u8p * use)(*[a.ctypes.data_as(lib.u8p) for a in outs])
         hist = np.zeros(use, dtype=np.int16)
         run("adx", lambda: lib.check(L.vga_adx_encode_batch_v(pp, cp, use, params, op, hist.ctypes.data_as(lib.i16p))), outs)
+        if "adxdec" in args.codecs:                       # the same files back: vga_adx_decode_batch_v on what the call above wrote
+            lib.check(L.vga_adx_encode_batch_v(pp, cp, use, params, op, hist.ctypes.data_as(lib.i16p)))
+            enc = outs
+            alens = np.asarray(sizes, dtype=np.int32)
+            back = [np.zeros(max(int(n_), 1), dtype=np.int16) for n_ in counts]
+            bp = (lib.i16p * use)(*[a.ctypes.data_as(lib.i16p) for a in back])
+            ep = (lib.u8p * use)(*[a.ctypes.data_as(lib.u8p) for a in enc])
+            run("adxdec", lambda: lib.check(L.vga_adx_decode_batch_v(ep, alens.ctypes.data_as(C.POINTER(C.c_int)), use, cp, params, bp)), back)
+            del back, bp
         del outs, op
     if "hca" in args.codecs:
         cps = (lib.HcaParamsC * use)()
