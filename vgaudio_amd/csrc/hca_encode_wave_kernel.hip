@@ -1,0 +1,822 @@
+// hca_encode_wave_kernel.hip -- CRI HCA frame encoder for one- and two-channel streams: ONE WAVE encodes a frame.
+//
+// Replaces CriHcaEncoder.EncodeFrame and its stages (VGAudio/Codecs/CriHca/CriHcaEncoder.cs:271-286, :420-858),
+// CriHcaPacking.PackFrame (CriHcaPacking.cs:17-58, :231-295) and Mdct.RunMdct (VGAudio/Utilities/Mdct.cs:63-92) for
+// streams of up to two channels -- what hca_encode_kernel.hip did with a workgroup of two waves, ~20 block-wide barriers a
+// frame, stages that ran on one of the two waves, and every intermediate (spectra, scale factors, cost tables,
+// resolutions) parked in LDS.  HCA frames have no recurrence: frame k is a function of samples [1024 k - 128, 1024 k + 1024)
+// of the encoder's input stream (PcmMap, hca_device.hpp).
+//
+// A wave owns a run of consecutive frames of one stream and never waits for another wave (four waves share a workgroup
+// only for the tables: one barrier per workgroup, none per frame).  Per frame, wave-synchronously:
+//   * samples: lane l loads sample 64 k + l (k = 0..17) of both channels as one packed register each, already one frame
+//     ahead; the mirrored operand of the fold (sample 64 k + 63 - l) comes across the crossbar (ds_bpermute);
+//   * per channel: window + fold into the transform's input rows (8 sub-frames = 8 rows of LDS), the 128-point DCT-IV on
+//     8 lanes per transform -- all eight sub-frames of a channel at once --, twiddles from a shared LDS table;
+//   * then the frame lives in REGISTERS in band order: lane l holds bands l and l + 64 of both channels, all eight
+//     sub-frames (32 doubles), its four scale factors, four 128-bit cost tables and resolutions -- scale factors,
+//     scaling, bit costs, the header's length, both binary searches of the bit allocation and the quantiser need no LDS
+//     array and no barrier; the sums over bands are DPP reductions;
+//   * the codes (value + length in 16 bits) are turned through LDS into stream order -- 32 consecutive codes per lane --,
+//     one scan gives the lanes' bit offsets and each lane ORs whole dwords into the frame; CRC-16 from per-lane partial
+//     CRCs; the frame leaves as aligned dwords.
+// LDS per wave: 9 KB (the eight rows; the turned codes and the frame's bits reuse them) -- three to four waves per SIMD.
+// Intensity stereo and HFR (the order-dependent f64 sums of :711-832) take a detour through the rows: one lane per sum.
+// All arithmetic is the reference's f64 in the same operation order (-ffp-contract=off).
+#include "common.hpp"
+#include "hca_device.hpp"
+#include "hca_decode_core.hpp"
+#include "hca_kernels.hpp"
+#include "hca_encode_core.hpp"
+
+namespace vga {
+namespace hca {
+
+using namespace enc;
+
+namespace {
+
+#ifndef VGA_HCA_ENC_STOP_AFTER
+#define VGA_HCA_ENC_STOP_AFTER 99
+#endif
+// (the frame lives in registers: a timing-only build has to keep what it computed alive -- `sink` is folded into a store that
+// never happens)
+#define WAVE_STOP_AFTER(n, sink)                                          \
+    if (VGA_HCA_ENC_STOP_AFTER == (n)) {                                  \
+        if ((int)(sink) == 0x7A5C3E19 && status) atomicOr(status, 1 << 20); \
+        continue;                                                         \
+    }
+
+constexpr int WG_WAVES = 4;
+constexpr int WG_THREADS = 64 * WG_WAVES;
+constexpr int MAX_WAVE_FRAMES = 16;
+constexpr int ROWS_BYTES = 8 * ROW_BYTES;              // one channel's eight transforms
+
+// what the waves of a workgroup share (static LDS)
+struct alignas(16) WaveShared {
+    EncTab T;
+    CostLut Q;
+    alignas(16) Twiddle tw[127];                   // [0, 63): the stage tables of sizes 1..32 (size 2^b starts at 2^b - 1); [63, 127): the pre-rotation
+    double window[128];                // MdctWindow / 32768 (exact: PcmToFloat's scaling folded in, see fold below)
+};
+
+template <int NCH>
+struct Layout {
+    static constexpr int PT = 16 * NCH;                // codes per lane in stream order: 8 sub-frames x NCH x 128 / 64
+    static constexpr int STRIDE = 2 * PT + 16;         // bytes between two lanes' runs of codes: 16-byte reads, four lanes per bank group
+    static constexpr int CODES_BYTES = 64 * STRIDE;
+};
+
+__device__ __forceinline__ int wave_shr1(int v)       // lane l receives lane l - 1's value, lane 0 receives 0
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false);          // wave_shr:1
+}
+
+__device__ __forceinline__ double minmax_clamp(double v, double lo, double hi)
+{
+    return v < lo ? lo : (v > hi ? hi : v);
+}
+
+// pre-rotation + stages 0..2 (hca_decode_core.hpp: dct_first_half) with the lane's twiddles from the shared table
+__device__ __forceinline__ void dct_first_half_lds(char *row, int L, const Twiddle *tw)
+{
+    Cx z[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const double2 p = *reinterpret_cast<const double2 *>(row + slot_byte_offset(L + 8 * k));
+        const Twiddle t = tw[63 + L + 8 * k];
+        z[k].re = p.x * t.c + p.y * t.s;               // Mdct.cs:145-146
+        z[k].im = p.x * t.s - p.y * t.c;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) butterfly(z[k], z[k + 4], tw[31 + L + 8 * k]);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const Twiddle t = tw[15 + L + 8 * k];
+        butterfly(z[k], z[k + 2], t);
+        butterfly(z[k + 4], z[k + 6], t);
+    }
+    {
+        const Twiddle t = tw[7 + L];
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) butterfly(z[k], z[k + 1], t);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        *reinterpret_cast<double2 *>(row + slot_byte_offset(L + 8 * k)) = make_double2(z[k].re, z[k].im);
+}
+
+// stages 3..5 (dct_second_half) + the output permutation and scale (dct_store)
+__device__ __forceinline__ void dct_second_half_lds(char *row, int L, const Twiddle *tw, int out_even, int out_odd)
+{
+    Cx z[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const double2 p = *reinterpret_cast<const double2 *>(row + slot_byte_offset(8 * L + m));
+        z[m].re = p.x;
+        z[m].im = p.y;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) butterfly(z[m], z[m + 4], tw[3 + m]);
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const Twiddle t = tw[1 + m];
+        butterfly(z[m], z[m + 2], t);
+        butterfly(z[m + 4], z[m + 6], t);
+    }
+    {
+        const Twiddle t = tw[0];
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) butterfly(z[m], z[m + 1], t);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every lane of the row has read its slots
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const double y = (j & 1) ? z[j >> 1].im : z[j >> 1].re;
+        const int base = parity4(j) ? out_odd : out_even;
+        *reinterpret_cast<double *>(row + 64 * out_block_of(j) + base) = y * 0.125;     // Scale = sqrt(2 / 128)
+    }
+}
+
+}  // namespace
+
+template <int NCH>
+__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3))) void hca_encode_wave_kernel(
+    const int16_t *__restrict__ pcm, int64_t stream_pitch, int64_t ch_pitch, int frames_per_run, int runs_per_stream, int total_runs,
+    PcmMap map, DeviceInfo info, uint8_t *__restrict__ frames, int64_t frames_pitch, const uint16_t *__restrict__ crc_pow,
+    int *__restrict__ status, int first_frame, int end_frame, int wave_bytes)
+{
+    using Lay = Layout<NCH>;
+    constexpr int PT = Lay::PT;
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+    __shared__ WaveShared S;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    // ---- once per workgroup: tables
+    for (int i = tid; i < 64; i += WG_THREADS) {
+        S.T.dequant_scale[i] = f64_bits(HCA_DequantizerScalingTableBits[i]);
+        S.T.quant_scale[i] = f64_bits(HCA_QuantizerScalingTableBits[i]);
+        S.T.res_curve[i] = i < 59 ? HCA_ScaleToResolutionCurve[i] : 0;
+    }
+    if (tid < 16) {
+        S.T.inv_step[tid] = f64_bits(HCA_QuantizerInverseStepSizeBits[tid]);
+        S.T.max_bits[tid] = HCA_QuantizedSpectrumMaxBits[tid];
+    }
+    if (tid < 128) {
+        (&S.T.enc_pair[0][0])[tid] = (uint8_t)(((&HCA_QuantizeSpectrumValue[0][0])[tid] << 4) | (&HCA_QuantizeSpectrumBits[0][0])[tid]);
+        // PcmToFloat (:845-858) multiplies every sample by 2^-15 and the fold (Mdct.cs:80-89) multiplies the result by a
+        // window value: w * (x * 2^-15) and (w * 2^-15) * x round to the same double (a power of two scales exactly;
+        // nothing here is near the subnormal range: |w| >= 6.9e-4, |x| >= 1 or x = 0)
+        S.window[tid] = (double)__uint_as_float(HCA_MdctWindowF32Bits[tid]) * (1.0 / 32768.0);
+    }
+    if (tid < 127) {
+        const int src = tid < 63 ? tid : tid + 64;                  // 63.. -> entries 127.. of the reference's table (size 128, i < 64)
+        S.tw[tid] = Twiddle{f64_bits(MDCT_SinBits[src]), f64_bits(MDCT_CosBits[src])};
+    }
+    if (!cost_lut_build<WG_THREADS>(S.Q, reinterpret_cast<double *>(s_dyn), tid)) {       // (s_dyn: nothing lives there before the first frame)
+        if (tid == 0 && status) atomicOr(status, 16);
+        return;
+    }
+    __syncthreads();
+    const EncTab &T = S.T;
+    const CostLut &Q = S.Q;
+
+    const int run = blockIdx.x * WG_WAVES + wave;
+    if (run >= total_runs) return;
+    const int stream = run / runs_per_stream;
+    const int f0 = first_frame + (run % runs_per_stream) * frames_per_run;                  // frames [first_frame, end_frame) of every stream
+    const int f1 = min(f0 + frames_per_run, end_frame);
+
+    char *rows = s_dyn + (size_t)wave * wave_bytes;                 // eight transform rows; later the turned codes + the frame's bits
+    uint32_t *fbuf = reinterpret_cast<uint32_t *>(rows + Lay::CODES_BYTES);
+    const int fwords = ((info.frame_size + 3) / 4 + 3) & ~1;
+    const int available = info.frame_size * 8;
+
+    // lane constants
+    const int L = lane & 7;
+    char *my_row = rows + (lane >> 3) * ROW_BYTES;
+    int out_even, out_odd;
+    {
+        const int rev = ((L & 1) << 2) | (L & 2) | ((L >> 2) & 1);
+        const int v = rev ^ (rev >> 1) ^ (rev >> 2);
+        out_even = 8 * v;
+        out_odd = 8 * (v ^ 7);
+    }
+    const int fold_lo = spec_byte_offset(lane), fold_hi = spec_byte_offset(64 + lane);
+    const int mirror_addr = (63 - lane) * 4;
+    int coded[NCH], ctype[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        coded[c] = info.coded_count[c];
+        ctype[c] = info.channel_type[c];
+    }
+    const int nbytes = info.frame_size - 2;
+    const int crc_chunk = (nbytes + 63) / 64;
+    const int crc_begin = lane * crc_chunk, crc_end = min(crc_begin + crc_chunk, nbytes);
+    const unsigned crc_shift = crc_begin < crc_end ? crc_pow[nbytes - crc_end] : 0u;
+
+    const int16_t *spcm = pcm + (int64_t)stream * stream_pitch;
+    // sample 64 k + lane of the frame's window (its 1024 samples and the 128 before them), k = 0..17: channel 0 in the low
+    // half, channel 1 in the high half.  Loaded one frame ahead (while the previous frame is packed) when the whole window
+    // lies inside the caller's PCM; the stream's first and last frames go through the stream map.
+    uint32_t pk[18];
+    bool pk_valid = false;
+    auto prefetch = [&](int frame) __attribute__((always_inline)) {
+        const int64_t u0 = (int64_t)frame * SPF - SPSF;
+        pk_valid = u0 >= map.pre_end && u0 + SPF + SPSF <= map.main_end;
+        if (pk_valid) {
+            const int16_t *p = spcm + (u0 - map.pre_end) + lane;
+#pragma unroll
+            for (int k = 0; k < 18; k++) {
+                uint32_t v = (uint16_t)p[64 * k];
+                if (NCH == 2) v |= (uint32_t)(uint16_t)p[ch_pitch + 64 * k] << 16;
+                pk[k] = v;
+            }
+        }
+    };
+    prefetch(f0);
+
+    for (int frame = f0; frame < f1; frame++) {
+        uint32_t a[18];
+        if (pk_valid) {
+#pragma unroll
+            for (int k = 0; k < 18; k++) a[k] = pk[k];
+        } else {
+            // through the stream map, staged in the rows (int16 [channel][18][64])
+            const int64_t u0 = (int64_t)frame * SPF - SPSF;
+            int16_t *stage = reinterpret_cast<int16_t *>(rows);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+            for (int i = 0; i < 18 * NCH; i++)
+                stage[i * 64 + lane] = fetch_pcm(map, spcm + (int64_t)(i / 18) * ch_pitch, u0 + 64 * (i % 18) + lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 18; k++) {
+                uint32_t v = (uint16_t)stage[k * 64 + lane];
+                if (NCH == 2) v |= (uint32_t)(uint16_t)stage[(18 + k) * 64 + lane] << 16;
+                a[k] = v;
+            }
+        }
+        // the fold's mirrored operands: sample 64 k + 63 - lane, k = 1..16
+        uint32_t m[18];
+#pragma unroll
+        for (int k = 1; k <= 16; k++) m[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(mirror_addr, (int)a[k]);
+
+        // ---- PcmToFloat (:845-858), RunMdct (Mdct.cs:63-92): per channel the fold of its eight sub-frames into the eight
+        // rows, the eight transforms at once, and the spectra into registers in band order: x[c][h][sf] = band lane + 64 h
+        double x[NCH][2][8];
+        {
+            const double w_a = S.window[63 - lane], w_b = S.window[64 + lane], w_c = S.window[lane], w_d = S.window[127 - lane];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the previous user of the rows is done reading
+#pragma unroll
+                for (int sf = 0; sf < 8; sf++) {
+                    auto half_of = [&](uint32_t v) { return c == 0 ? (int)(int16_t)(v & 0xFFFFu) : (int)v >> 16; };
+                    const int x_pv_lo = half_of(a[2 * sf]);                  // p[wi]
+                    const int x_pv_hi = half_of(m[2 * sf + 1]);              // p[127 - wi]
+                    const int x_in_lo = half_of(m[2 * sf + 2]);              // p[128 + 63 - wi]
+                    const int x_in_hi = half_of(a[2 * sf + 3]);              // p[128 + 64 + wi]
+                    const double fa = w_a * -(double)x_in_hi;
+                    const double fb = w_b * (double)x_in_lo;
+                    const double fc = w_c * (double)x_pv_lo;
+                    const double fd = w_d * (double)x_pv_hi;
+                    *reinterpret_cast<double *>(rows + sf * ROW_BYTES + fold_lo) = fa - fb;
+                    *reinterpret_cast<double *>(rows + sf * ROW_BYTES + fold_hi) = fc - fd;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dct_first_half_lds(my_row, L, S.tw);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dct_second_half_lds(my_row, L, S.tw, out_even, out_odd);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int sf = 0; sf < 8; sf++)
+                        x[c][h][sf] = *reinterpret_cast<const double *>(rows + sf * ROW_BYTES + 8 * (lane + 64 * h));
+            }
+        }
+        WAVE_STOP_AFTER(2, [&] { double t = 0; for (int c = 0; c < NCH; c++) for (int h = 0; h < 2; h++) for (int sf = 0; sf < 8; sf++) t += x[c][h][sf]; return __double2loint(t); }());
+
+        // ---- EncodeIntensityStereo (:711-764): the energies are sums over the bands in order -- one lane per (sub-frame, sum)
+        // walks them in a plain [sub-frame][band] array of the rows, one of the three terms at a time
+        uint32_t intensity_pack = 0;                   // eight 4-bit ratios of the secondary channel
+        if (NCH == 2 && info.stereo_band_count > 0 && ctype[0] == CH_STEREO_PRIMARY) {
+            double *plain = reinterpret_cast<double *>(rows);          // [8][128]
+            double energy[3] = {0, 0, 0};              // lanes 0..7: sub-frame `lane`: L, R, total
+#pragma unroll
+            for (int term = 0; term < 3; term++) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int sf = 0; sf < 8; sf++) {
+                        const double l = x[0][h][sf], r = x[NCH - 1][h][sf];
+                        plain[sf * 128 + lane + 64 * h] = term == 0 ? fabs(l) : (term == 1 ? fabs(r) : fabs(l + r));
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < 8) {
+                    double e = 0;
+                    for (int b = info.base_band_count; b < info.total_band_count; b++) e += plain[lane * 128 + b];
+                    energy[term] = e;
+                }
+            }
+            double ratio = 1;
+            int quantized = 0;
+            if (lane < 8) {
+                const double energy_l = energy[0], energy_r = energy[1];
+                const double energy_total = energy[2] * 2;
+                const double energy_lr = energy_r + energy_l;
+                const double stored = 2 * energy_l / energy_lr;
+                ratio = energy_lr / energy_total;
+                ratio = minmax_clamp(ratio, 0.5, 1.4142135623730951 / 2);
+                quantized = 1;
+                if (energy_r > 0 || energy_l > 0) {
+                    while (quantized < 13 && f64_bits(HCA_IntensityRatioBoundsTableBits[quantized]) >= stored) quantized++;
+                } else {
+                    quantized = 0;
+                    ratio = 1;
+                }
+            }
+#pragma unroll
+            for (int sf = 0; sf < 8; sf++) {
+                const double rt = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ratio), sf),
+                                                   __builtin_amdgcn_readlane(__double2loint(ratio), sf));
+                intensity_pack |= (uint32_t)__builtin_amdgcn_readlane(quantized, sf) << (4 * sf);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int b = lane + 64 * h;
+                    if (b >= info.base_band_count && b < info.total_band_count) {
+                        x[0][h][sf] = (x[0][h][sf] + x[NCH - 1][h][sf]) * rt;
+                        x[NCH - 1][h][sf] = 0;
+                    }
+                }
+            }
+        }
+
+        // ---- CalculateScaleFactors (:673-689), ScaleSpectra (:651-671) and the band's bit costs at all sixteen resolutions
+        // (CalculateUsedBits :554-597) in one pass over the band's eight coefficients.  Bands >= the coded count keep their
+        // unscaled values (the HFR group averages read exactly those).
+        int sfv[NCH][2];
+        uint4 cost[NCH][2];
+        uint32_t hfr_lo[NCH] = {}, hfr_hi[NCH] = {};   // the channel's HFR scales, 6 bits each: groups 0..4 | groups 5..7
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int b = lane + 64 * h;
+                sfv[c][h] = 0;
+                cost[c][h] = make_uint4(0, 0, 0, 0);
+                if (b < coded[c]) {
+                    double mx = 0;
+#pragma unroll
+                    for (int sf = 0; sf < 8; sf++) {
+                        const double coeff = fabs(x[c][h][sf]);
+                        mx = coeff > mx ? coeff : mx;
+                    }
+                    const int s = find_scale_factor(T, mx);
+                    const double qs = T.quant_scale[s];
+#pragma unroll
+                    for (int sf = 0; sf < 8; sf++)
+                        x[c][h][sf] = s != 0 ? minmax_clamp(x[c][h][sf] * qs, -0.999999999999, 0.999999999999) : 0.0;
+                    sfv[c][h] = s;
+                    cost[c][h] = band_cost_table(Q, x[c][h]);
+                }
+            }
+            // ---- CalculateHfrGroupAverages (:766-793) + CalculateHfrScale (:795-832): one lane per group walks the plain array
+            if (info.hfr_group_count > 0 && ctype[c] != CH_STEREO_SECONDARY) {
+                double *plain = reinterpret_cast<double *>(rows);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int sf = 0; sf < 8; sf++) plain[sf * 128 + lane + 64 * h] = x[c][h][sf];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                int scale = 0;
+                if (lane < info.hfr_group_count) {
+                    const int group = lane;
+                    const int hfr_start = info.stereo_band_count + info.base_band_count;
+                    double sum = 0.0;
+                    int count = 0;
+                    int band = hfr_start + group * info.bands_per_hfr_group;
+                    for (int i = 0; i < info.bands_per_hfr_group && band < SPSF; band++, i++) {
+                        for (int sf = 0; sf < 8; sf++) sum += fabs(plain[sf * 128 + band]);
+                        count += 8;
+                    }
+                    double avg = sum / count;
+                    const int lim = min(info.hfr_band_count, info.total_band_count - info.hfr_band_count);
+                    sum = 0.0;
+                    count = 0;
+                    band = group * info.bands_per_hfr_group;
+                    for (int i = 0; i < info.bands_per_hfr_group && band < lim; band++, i++) {
+                        for (int sf = 0; sf < 8; sf++) sum += fabs(plain[sf * 128 + (hfr_start - band - 1)]);
+                        count += 8;
+                    }
+                    const double average = sum / count;
+                    if (average > 0.0) {
+                        const double inv = 1.0 / average;
+                        avg *= inv < 1.4142135623730951 ? inv : 1.4142135623730951;
+                    }
+                    scale = find_scale_factor(T, avg);
+                }
+#pragma unroll
+                for (int g = 0; g < 8; g++) {
+                    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane(scale, g);
+                    if (g < 5) hfr_lo[c] |= v << (6 * g);
+                    else hfr_hi[c] |= v << (6 * (g - 5));
+                }
+            }
+        }
+        WAVE_STOP_AFTER(3, [&] { double t = 0; for (int c = 0; c < NCH; c++) for (int h = 0; h < 2; h++) for (int sf = 0; sf < 8; sf++) t += x[c][h][sf]; return __double2loint(t); }() + (int)(cost[0][0].x ^ cost[0][1].y ^ cost[NCH - 1][0].z ^ cost[NCH - 1][1].w) + sfv[0][0] + sfv[NCH - 1][1]);
+
+        // ---- CalculateFrameHeaderLength (:599-649): a channel's five candidate delta widths' lengths are sums packed two to a
+        // register and reduced with DPP; everything after the sums is wave-uniform
+        int hlb[NCH], dbits[NCH];
+        auto header_lengths = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                int pa = 0, pb = 0, pe = 0;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int band = lane + 64 * h;
+                    const bool in = band < coded[c];
+                    const int sf = sfv[c][h];
+                    int prev = wave_shr1(sf);
+                    if (h == 1) {
+                        const int wrap = __builtin_amdgcn_readlane(sfv[c][0], 63);
+                        prev = lane == 0 ? wrap : prev;
+                    }
+                    const bool counted = in && band >= 1;
+                    const int delta = counted ? abs(sf - prev) : 0;
+                    // per-lane costs <= 22, 64 lanes: 16-bit fields cannot carry into each other
+                    if (counted) {
+                        pa += (delta > 0 ? 7 : 1) | ((delta > 1 ? 8 : 2) << 16);
+                        pb += (delta > 3 ? 9 : 3) | ((delta > 7 ? 10 : 4) << 16);
+                        pe += delta > 15 ? 11 : 5;
+                    }
+                    pe += (in && sf != 0) ? 1 << 16 : 0;                       // non-zero scale factors: "empty channel" test
+                }
+                pa = wave_sum(pa);
+                pb = wave_sum(pb);
+                pe = wave_sum(pe);
+                const int cand_len[6] = {0, 9 + (pa & 0xFFFF), 9 + (pa >> 16), 9 + (pb & 0xFFFF), 9 + (pb >> 16), 9 + (pe & 0xFFFF)};
+                int len, db;
+                if ((pe >> 16) == 0) { len = 3; db = 0; }
+                else {
+                    db = 6;
+                    len = 3 + 6 * coded[c];
+#pragma unroll
+                    for (int k = 1; k < 6; k++)
+                        if (cand_len[k] < len) { len = cand_len[k]; db = k; }
+                }
+                if (ctype[c] == CH_STEREO_SECONDARY) len += 32;
+                else if (info.hfr_group_count > 0) len += 6 * info.hfr_group_count;
+                hlb[c] = len;
+                dbits[c] = db;
+            }
+        };
+        header_lengths();
+        WAVE_STOP_AFTER(4, [&] { double t = 0; for (int c = 0; c < NCH; c++) for (int h = 0; h < 2; h++) for (int sf = 0; sf < 8; sf++) t += x[c][h][sf]; return __double2loint(t); }() + (int)(cost[0][0].x ^ cost[0][1].y ^ cost[NCH - 1][0].z ^ cost[NCH - 1][1].w) + hlb[0] + dbits[NCH - 1]);
+
+        // ---- CalculateNoiseLevel (:457-485) / BinarySearchLevel (:502-523) and CalculateEvaluationBoundary (:487-500) /
+        // BinarySearchBoundary (:525-552).  Slot k = (channel k >> 1, band lane + 64 (k & 1)).
+        constexpr int NS = 2 * NCH;
+        uint64_t clo[NS], chi[NS];
+        int off[NS], bnd[NS];
+        bool on[NS];
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            const uint4 cw = cost[k >> 1][k & 1];
+            clo[k] = ((uint64_t)cw.y << 32) | cw.x;
+            chi[k] = ((uint64_t)cw.w << 32) | cw.z;
+            bnd[k] = lane + 64 * (k & 1);
+        }
+        int level = 0, boundary = 0;
+        bool too_low = false;
+        int highest_band = info.base_band_count + info.stereo_band_count - 1;
+        for (;;) {
+            int hsum = 48;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) hsum += hlb[c];
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                const int sf = sfv[k >> 1][k & 1];
+                on[k] = sf != 0 && bnd[k] < coded[k >> 1];
+                off[k] = 2 - 5 * sf / 2;
+            }
+            auto probe = [&](int noise_level) __attribute__((always_inline)) -> int {
+                int partial = 0;
+#pragma unroll
+                for (int k = 0; k < NS; k++) {
+                    const int res = T.res_curve[min(max(noise_level + off[k], 0), 58)];
+                    const uint64_t half = res >= 8 ? chi[k] : clo[k];
+                    partial += on[k] ? (int)((half >> (8 * (res & 7))) & 0xFFu) : 0;
+                }
+                return wave_sum(partial) + hsum;
+            };
+            int low = 0, high = 255, mid_value = 0;
+            while (low != high) {
+                const int mid = (low + high) / 2;
+                mid_value = probe(mid);
+                if (mid_value > available) low = mid + 1;
+                else high = mid;
+            }
+            level = (low == 255 && mid_value > available) ? -1 : low;
+            if (level >= 0) break;
+            // CalculateNoiseLevel (:469-484): drop the two highest bands and try again
+            highest_band -= 2;
+            if (highest_band < 0) { too_low = true; break; }
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int b = lane + 64 * h;
+                    if (b == highest_band + 1 || b == highest_band + 2) sfv[c][h] = 0;
+                }
+            header_lengths();
+        }
+        if (too_low) {                                 // InvalidDataException("Bitrate is set too low.")
+            if (lane == 0 && status) atomicOr(status, 4);
+            level = 255;
+        }
+        if (level > 0 && !too_low) {
+            // BinarySearchBoundary (:525-552) probes CalculateUsedBits(level, boundary): the bands below the boundary at
+            // level - 1, the others at level -- the frame's bits at `level` plus, for every band below the boundary, what the
+            // band costs more at level - 1: ONE exclusive scan over the bands gives the value of every possible probe and the
+            // search's dependent probes are lane reads -- the same probes and decisions in the reference's order (the bits
+            // need not be monotone in the boundary and nothing here assumes it)
+            int hsum = 48;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) hsum += hlb[c];
+            int at_level = 0, d_lo = 0, d_hi = 0;
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                const int r1 = T.res_curve[min(max(level + off[k], 0), 58)], r0 = T.res_curve[min(max(level - 1 + off[k], 0), 58)];
+                const int c1 = (int)(((r1 >= 8 ? chi[k] : clo[k]) >> (8 * (r1 & 7))) & 0xFFu);
+                const int c0 = (int)(((r0 >= 8 ? chi[k] : clo[k]) >> (8 * (r0 & 7))) & 0xFFu);
+                at_level += on[k] ? c1 : 0;
+                const int more = on[k] ? c0 - c1 : 0;
+                if (k & 1) d_hi += more;
+                else d_lo += more;
+            }
+            const int base = wave_sum(at_level) + hsum;
+            const int in_lo = wave_inclusive_scan(d_lo), in_hi = wave_inclusive_scan(d_hi);
+            const int all_lo = __builtin_amdgcn_readlane(in_lo, 63);
+            const int ex_lo = base + in_lo - d_lo, ex_hi = base + all_lo + in_hi - d_hi;      // probe(level, band)
+            auto probe_boundary = [&](int eb) {                       // eb is wave-uniform, 0 .. 127
+                const int pa = __builtin_amdgcn_readlane(ex_lo, __builtin_amdgcn_readfirstlane(eb) & 63);
+                const int pb = __builtin_amdgcn_readlane(ex_hi, __builtin_amdgcn_readfirstlane(eb) & 63);
+                return eb < 64 ? pa : pb;
+            };
+            int lo2 = 0, hi2 = 127;
+            while (abs(hi2 - lo2) > 1) {
+                const int mid = (lo2 + hi2) / 2;
+                const int mid_value2 = probe_boundary(mid);
+                if (available < mid_value2) hi2 = mid - 1;
+                else lo2 = mid;
+            }
+            if (lo2 == hi2) boundary = lo2 < 127 ? lo2 : -1;
+            else boundary = probe_boundary(hi2) > available ? lo2 : hi2;
+        }
+        WAVE_STOP_AFTER(5, [&] { double t = 0; for (int c = 0; c < NCH; c++) for (int h = 0; h < 2; h++) for (int sf = 0; sf < 8; sf++) t += x[c][h][sf]; return __double2loint(t); }() + level + boundary);
+        if (boundary < 0) {                            // NotImplementedException in the reference
+            if (lane == 0 && status) atomicOr(status, 8);
+            boundary = 0;
+        }
+
+        // ---- CalculateFrameResolutions (:441-455)
+        int res[NCH][2];
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int b = lane + 64 * h;
+                res[c][h] = b < coded[c] ? resolution_of(T, sfv[c][h], b < boundary ? level - 1 : level) : 0;
+            }
+
+        // ---- QuantizeSpectra (:420-439): code and length of every coefficient in 16 bits (code << 4 | bits; 12 + 4 at most),
+        // written where the lane that owns the code in stream order -- (sub-frame, channel, band): WriteSpectra
+        // (CriHcaPacking.cs:238-260) -- will read it.  The quantiser's constants need no table: QuantizerInverseStepSize[r] =
+        // ResolutionMaxValue[r] + 0.5 (CriHcaTables.cs:57), shiftUp = inv + 1, shiftDown = (int)(inv + 0.5) = max + 1, and
+        // QuantizedSpectrumMaxBits[r] = r - 3 from resolution 8 on.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the rows' last readers are done
+        {
+            const int turn_addr = (lane / PT) * Lay::STRIDE + (lane % PT) * 2;
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int r = res[c][h];
+                    const int maxv = r < 8 ? r : (1 << max(r - 4, 0)) - 1;
+                    const double inv = (double)maxv + 0.5;
+                    const double up = inv + 1;
+                    const uint8_t *pair_row = T.enc_pair[min(r, 7)];
+#pragma unroll
+                    for (int sf = 0; sf < 8; sf++) {
+                        const int q = trunc_i(x[c][h][sf] * inv + up) - (maxv + 1);
+                        const unsigned small_pair = pair_row[(q + 8) & 15];                   // value << 4 | bits
+                        const unsigned mag = (unsigned)abs(q);
+                        const unsigned large_pair = q != 0 ? ((((mag << 1) | (q > 0 ? 0u : 1u)) << 4) | (unsigned)(r - 3))
+                                                           : (unsigned)(r - 4);
+                        const unsigned pair = r == 0 ? 0u : (r < 8 ? small_pair : large_pair);
+                        const int base_slot = ((sf * NCH + c) * 128 + 64 * h);          // + lane: a multiple of 64 (PT divides 64)
+                        *reinterpret_cast<uint16_t *>(rows + (base_slot / PT) * Lay::STRIDE + turn_addr) = (uint16_t)pair;
+                    }
+                }
+        }
+        // the next frame's samples: their latency hides under the packing
+        if (frame + 1 < f1) prefetch(frame + 1);
+        for (int i = lane; i < fwords; i += 64) fbuf[i] = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WAVE_STOP_AFTER(6, fbuf[lane] + reinterpret_cast<uint32_t *>(rows)[lane * 7] + level);
+
+        auto put_bits = [&](int bit, unsigned value, int nbits) __attribute__((always_inline)) {
+            if (nbits <= 0) return;
+            const uint64_t win = (uint64_t)value << (64 - nbits - (bit & 31));
+            const unsigned hi = (unsigned)(win >> 32), lo = (unsigned)win;
+            if (hi) atomicOr(&fbuf[bit >> 5], hi);
+            if (lo) atomicOr(&fbuf[(bit >> 5) + 1], lo);
+        };
+        int header_bits = 32;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) header_bits += hlb[c];
+        if (!too_low) {
+            // ---- PackFrame (CriHcaPacking.cs:17-58): sync word, noise level, evaluation boundary
+            if (lane == 0) atomicOr(&fbuf[0], 0xFFFF0000u | ((unsigned)level << 7) | (unsigned)boundary);
+            // WriteScaleFactors (:262-295): bands in order = lanes in order, first half then second half
+            int bit0 = 32;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const int db = dbits[c];
+                unsigned code[2] = {0, 0};
+                int nb2[2] = {0, 0};
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int band = lane + 64 * h;
+                    const int sf = sfv[c][h];
+                    int prev = wave_shr1(sf);
+                    if (h == 1) {
+                        const int wrap = __builtin_amdgcn_readlane(sfv[c][0], 63);
+                        prev = lane == 0 ? wrap : prev;
+                    }
+                    if (band == 0) {                           // the 3-bit delta width, then the first scale factor
+                        code[h] = (unsigned)db;
+                        nb2[h] = 3;
+                        if (db != 0) { code[h] = (code[h] << 6) | (unsigned)sf; nb2[h] = 9; }
+                    } else if (band < coded[c] && db != 0) {
+                        if (db == 6) { code[h] = (unsigned)sf; nb2[h] = 6; }
+                        else {
+                            const int max_delta = (1 << (db - 1)) - 1;
+                            const int delta = sf - prev;
+                            if (abs(delta) > max_delta) { code[h] = ((((1u << db) - 1)) << 6) | (unsigned)sf; nb2[h] = db + 6; }
+                            else { code[h] = (unsigned)(max_delta + delta); nb2[h] = db; }
+                        }
+                    }
+                }
+                const int incl0 = wave_inclusive_scan(nb2[0]);
+                const int total0 = __builtin_amdgcn_readlane(incl0, 63);
+                const int incl1 = wave_inclusive_scan(nb2[1]);
+                const int total1 = __builtin_amdgcn_readlane(incl1, 63);
+                put_bits(bit0 + incl0 - nb2[0], code[0], nb2[0]);
+                put_bits(bit0 + total0 + incl1 - nb2[1], code[1], nb2[1]);
+                if (lane < 8) {                                // intensity / HFR scales follow the scale factors
+                    const int at = bit0 + total0 + total1;
+                    if (ctype[c] == CH_STEREO_SECONDARY) put_bits(at + 4 * lane, (intensity_pack >> (4 * lane)) & 15u, 4);
+                    else if (lane < info.hfr_group_count)
+                        put_bits(at + 6 * lane, (lane < 5 ? hfr_lo[c] >> (6 * lane) : hfr_hi[c] >> (6 * (lane - 5))) & 63u, 6);
+                }
+                bit0 += hlb[c];
+            }
+            // ---- WriteSpectra (:238-260): PT consecutive codes per lane
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            uint32_t cw[PT / 2];
+            {
+                const uint4 *src = reinterpret_cast<const uint4 *>(rows + lane * Lay::STRIDE);
+#pragma unroll
+                for (int i = 0; i < PT / 8; i++) {
+                    const uint4 v = src[i];
+                    cw[4 * i] = v.x;
+                    cw[4 * i + 1] = v.y;
+                    cw[4 * i + 2] = v.z;
+                    cw[4 * i + 3] = v.w;
+                }
+            }
+            uint32_t nib = 0;
+#pragma unroll
+            for (int i = 0; i < PT / 2; i++) nib += cw[i] & 0x000F000Fu;       // <= 16 x 12 per half
+            const int local = (int)((nib & 0xFFFFu) + (nib >> 16));
+            const int incl = wave_inclusive_scan(local);
+            const int bit = header_bits + incl - local;
+            uint64_t acc = 0;
+            int word = bit >> 5, p = bit & 31;
+#pragma unroll
+            for (int i = 0; i < PT; i++) {
+                const uint32_t pair = (i & 1) ? cw[i >> 1] >> 16 : cw[i >> 1] & 0xFFFFu;
+                const int nbits = (int)(pair & 15u);
+                acc |= (uint64_t)(pair >> 4) << ((64 - p - nbits) & 63);       // p < 32, nbits <= 12; nbits = 0: the code is 0
+                p += nbits;
+                if (p >= 32) {
+                    const unsigned hi = (unsigned)(acc >> 32);
+                    if (hi) atomicOr(&fbuf[word], hi);
+                    acc <<= 32;
+                    word++;
+                    p -= 32;
+                }
+            }
+            const unsigned hi = (unsigned)(acc >> 32);
+            if (hi) atomicOr(&fbuf[word], hi);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WAVE_STOP_AFTER(7, fbuf[lane]);
+
+        // ---- WriteChecksum (:231-236): CRC-16 (poly 0x8005, init 0) over the first frame_size - 2 bytes: per-lane partial
+        // CRCs of consecutive chunks, shifted to their place with x^(8k) mod P and XORed
+        {
+            unsigned crc = 0;
+            for (int i = crc_begin; i < crc_end; i++) {
+                const unsigned byte = (fbuf[i >> 2] >> (24 - 8 * (i & 3))) & 0xFFu;
+                // eight shift-and-xor steps of x^16 + x^15 + x^2 + 1 at once: with t = the byte entering the register,
+                // t * x^16 mod P = t << 1 ^ t << 2 ^ (parity(t) ? 0x8003 : 0)   (tests/test_oracle_hca.py)
+                const unsigned t = ((crc >> 8) ^ byte) & 0xFFu;
+                crc = ((crc << 8) & 0xFFFFu) ^ ((__popc(t) & 1) ? 0x8003u : 0u) ^ (t << 1) ^ (t << 2);
+            }
+            unsigned part = (crc_begin < crc_end) ? gf_mul(crc, crc_shift) : 0u;
+            const unsigned total = (unsigned)wave_xor((int)part) & 0xFFFFu;
+            if (lane == 0) {
+                const int pos = nbytes;                // big-endian 16-bit value at the last two bytes
+                fbuf[pos >> 2] |= (total >> 8) << (24 - 8 * (pos & 3));
+                fbuf[(pos + 1) >> 2] |= (total & 0xFF) << (24 - 8 * ((pos + 1) & 3));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WAVE_STOP_AFTER(8, fbuf[lane]);
+
+        // ---- store the frame: whole aligned dwords (the frame starts at any byte: its k-th dword is a funnel shift of two
+        // big-endian words of fbuf), the few bytes before the first and after the last aligned dword one by one
+        {
+            uint8_t *dst = frames + (int64_t)stream * frames_pitch + (int64_t)frame * info.frame_size;
+            const int lead = (int)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3);       // bytes before the first aligned dword
+            const int ndw = (info.frame_size - lead) / 4;
+            auto byte_at = [&](int b) { return (fbuf[b >> 2] >> (24 - 8 * (b & 3))) & 0xFFu; };
+            uint32_t *dw = reinterpret_cast<uint32_t *>(dst + lead);
+            for (int k = lane; k < ndw; k += 64) {
+                const int b = lead + 4 * k;                                                   // frame byte of the dword's first byte
+                const uint32_t hi = fbuf[b >> 2], lo = fbuf[(b >> 2) + 1];
+                const int sh = 8 * (b & 3);
+                const uint32_t be = sh ? (hi << sh) | (lo >> (32 - sh)) : hi;                 // frame bytes b .. b+3, first byte on top
+                dw[k] = bswap32(be);
+            }
+            const int tail0 = lead + 4 * ndw;
+            if (lane < lead) dst[lane] = (uint8_t)byte_at(lane);
+            if (lane >= 32 && lane - 32 < info.frame_size - tail0) dst[tail0 + lane - 32] = (uint8_t)byte_at(tail0 + lane - 32);
+        }
+    }
+}
+
+// bytes of dynamic LDS one wave of the kernel needs for streams of this shape
+static size_t wave_lds_bytes(const DeviceInfo &info)
+{
+    const size_t fwords = (size_t)(((info.frame_size + 3) / 4 + 3) & ~1);
+    const size_t codes = info.nch == 2 ? Layout<2>::CODES_BYTES : Layout<1>::CODES_BYTES;
+    return (std::max<size_t>(ROWS_BYTES, codes + fwords * 4 + 8) + 15) & ~(size_t)15;
+}
+
+bool encode_wave_kernel_takes(const DeviceInfo &info)
+{
+    // one or two channels; frames whose bits fit next to the turned codes without pushing a workgroup past the LDS of a CU
+    return (info.nch == 1 || info.nch == 2) && WG_WAVES * wave_lds_bytes(info) + sizeof(WaveShared) + 64 <= 64 * 1024;
+}
+
+int launch_encode_wave(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, const PcmMap &map,
+                       const DeviceInfo &info, uint8_t *d_frames, int64_t frames_pitch, const uint16_t *d_crc_pow,
+                       int *d_status, hipStream_t stream, int first_frame, int end_frame, int frames_per_run_override)
+{
+    const int frame_span = end_frame - first_frame;
+    const size_t wave_bytes = wave_lds_bytes(info);
+    const size_t lds = WG_WAVES * wave_bytes;
+    // frames per wave: long runs amortise the per-workgroup set-up (tables), short ones keep small inputs spread over the chip
+    const int64_t total = (int64_t)nstreams * frame_span;
+    int per_run = (int)std::min<int64_t>(MAX_WAVE_FRAMES, std::max<int64_t>(1, total / 16384));
+    if (frames_per_run_override > 0) per_run = std::min(frames_per_run_override, 64);
+    per_run = std::min(per_run, frame_span);
+    const int runs = (frame_span + per_run - 1) / per_run;
+    const int64_t total_runs = (int64_t)nstreams * runs;
+    const unsigned grid = (unsigned)((total_runs + WG_WAVES - 1) / WG_WAVES);
+    if (info.nch == 2) {
+        if (lds > 32 * 1024) VGA_HIP_TRY(allow_dynamic_lds(hca_encode_wave_kernel<2>, lds));
+        hipLaunchKernelGGL(hca_encode_wave_kernel<2>, dim3(grid), dim3(WG_THREADS), lds, stream, d_pcm, stream_pitch, ch_pitch, per_run,
+                           runs, (int)total_runs, map, info, d_frames, frames_pitch, d_crc_pow, d_status, first_frame, end_frame,
+                           (int)wave_bytes);
+    } else {
+        if (lds > 32 * 1024) VGA_HIP_TRY(allow_dynamic_lds(hca_encode_wave_kernel<1>, lds));
+        hipLaunchKernelGGL(hca_encode_wave_kernel<1>, dim3(grid), dim3(WG_THREADS), lds, stream, d_pcm, stream_pitch, ch_pitch, per_run,
+                           runs, (int)total_runs, map, info, d_frames, frames_pitch, d_crc_pow, d_status, first_frame, end_frame,
+                           (int)wave_bytes);
+    }
+    VGA_HIP_TRY(hipGetLastError());
+    return VGA_OK;
+}
+
+}  // namespace hca
+}  // namespace vga

@@ -22,5 +22,11 @@ int launch_encode(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, 
                   const DeviceInfo &info, uint8_t *d_frames, int64_t frames_pitch, const uint16_t *d_crc_pow,
                   int *d_status, hipStream_t stream, int first_frame = 0, int frame_limit = -1);
 
+// hca_encode_wave_kernel.hip: one wave per run of frames, one or two channels (launch_encode hands such streams over)
+bool encode_wave_kernel_takes(const DeviceInfo &info);
+int launch_encode_wave(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, const PcmMap &map,
+                       const DeviceInfo &info, uint8_t *d_frames, int64_t frames_pitch, const uint16_t *d_crc_pow,
+                       int *d_status, hipStream_t stream, int first_frame, int end_frame, int frames_per_run_override);
+
 }  // namespace hca
 }  // namespace vga
