@@ -47,7 +47,14 @@ namespace {
         continue;                                                         \
     }
 
-constexpr int WG_WAVES = 4;
+// (tuning builds: tools/build_variants.sh)
+#ifndef VGA_HCA_WG_WAVES
+#define VGA_HCA_WG_WAVES 4
+#endif
+#ifndef VGA_HCA_WAVE_EU
+#define VGA_HCA_WAVE_EU 3
+#endif
+constexpr int WG_WAVES = VGA_HCA_WG_WAVES;
 constexpr int WG_THREADS = 64 * WG_WAVES;
 constexpr int MAX_WAVE_FRAMES = 16;
 constexpr int ROWS_BYTES = 8 * ROW_BYTES;              // one channel's eight transforms
@@ -72,6 +79,15 @@ __device__ __forceinline__ int wave_shr1(int v)       // lane l receives lane l 
     return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false);          // wave_shr:1
 }
 
+// The lane number, opaque to hipcc: what a stage of the frame derives from it (LDS addresses, band numbers, masks) is then
+// computed where the stage starts and dies with it, instead of being hoisted out of the frame loop into registers that
+// stay occupied through every other stage (45 VGPRs of such values at the first count).
+__device__ __forceinline__ int fresh(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ double minmax_clamp(double v, double lo, double hi)
 {
     return v < lo ? lo : (v > hi ? hi : v);
@@ -88,14 +104,17 @@ __device__ __forceinline__ void dct_first_half_lds(char *row, int L, const Twidd
         z[k].re = p.x * t.c + p.y * t.s;               // Mdct.cs:145-146
         z[k].im = p.x * t.s - p.y * t.c;
     }
+    stage_fence();                                     // (keeps hipcc from fetching every stage's twiddles up front: 60 VGPRs)
 #pragma unroll
     for (int k = 0; k < 4; k++) butterfly(z[k], z[k + 4], tw[31 + L + 8 * k]);
+    stage_fence();
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const Twiddle t = tw[15 + L + 8 * k];
         butterfly(z[k], z[k + 2], t);
         butterfly(z[k + 4], z[k + 6], t);
     }
+    stage_fence();
     {
         const Twiddle t = tw[7 + L];
 #pragma unroll
@@ -116,8 +135,10 @@ __device__ __forceinline__ void dct_second_half_lds(char *row, int L, const Twid
         z[m].re = p.x;
         z[m].im = p.y;
     }
+    stage_fence();
 #pragma unroll
     for (int m = 0; m < 4; m++) butterfly(z[m], z[m + 4], tw[3 + m]);
+    stage_fence();
 #pragma unroll
     for (int m = 0; m < 2; m++) {
         const Twiddle t = tw[1 + m];
@@ -141,7 +162,7 @@ __device__ __forceinline__ void dct_second_half_lds(char *row, int L, const Twid
 }  // namespace
 
 template <int NCH>
-__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3))) void hca_encode_wave_kernel(
+__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_HCA_WAVE_EU))) void hca_encode_wave_kernel(
     const int16_t *__restrict__ pcm, int64_t stream_pitch, int64_t ch_pitch, int frames_per_run, int runs_per_stream, int total_runs,
     PcmMap map, DeviceInfo info, uint8_t *__restrict__ frames, int64_t frames_pitch, const uint16_t *__restrict__ crc_pow,
     int *__restrict__ status, int first_frame, int end_frame, int wave_bytes)
@@ -151,7 +172,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
     __shared__ WaveShared S;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane0 = tid & 63, wave = tid >> 6;
 
     // ---- once per workgroup: tables
     for (int i = tid; i < 64; i += WG_THREADS) {
@@ -193,18 +214,6 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
     const int fwords = ((info.frame_size + 3) / 4 + 3) & ~1;
     const int available = info.frame_size * 8;
 
-    // lane constants
-    const int L = lane & 7;
-    char *my_row = rows + (lane >> 3) * ROW_BYTES;
-    int out_even, out_odd;
-    {
-        const int rev = ((L & 1) << 2) | (L & 2) | ((L >> 2) & 1);
-        const int v = rev ^ (rev >> 1) ^ (rev >> 2);
-        out_even = 8 * v;
-        out_odd = 8 * (v ^ 7);
-    }
-    const int fold_lo = spec_byte_offset(lane), fold_hi = spec_byte_offset(64 + lane);
-    const int mirror_addr = (63 - lane) * 4;
     int coded[NCH], ctype[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
@@ -213,11 +222,11 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
     }
     const int nbytes = info.frame_size - 2;
     const int crc_chunk = (nbytes + 63) / 64;
-    const int crc_begin = lane * crc_chunk, crc_end = min(crc_begin + crc_chunk, nbytes);
-    const unsigned crc_shift = crc_begin < crc_end ? crc_pow[nbytes - crc_end] : 0u;
+    // x^(8 k) mod P for the k bytes that follow this lane's chunk of the frame
+    const unsigned crc_shift = lane0 * crc_chunk < nbytes ? crc_pow[nbytes - min(lane0 * crc_chunk + crc_chunk, nbytes)] : 0u;
 
     const int16_t *spcm = pcm + (int64_t)stream * stream_pitch;
-    // sample 64 k + lane of the frame's window (its 1024 samples and the 128 before them), k = 0..17: channel 0 in the low
+    // sample 64 k + lane0 of the frame's window (its 1024 samples and the 128 before them), k = 0..17: channel 0 in the low
     // half, channel 1 in the high half.  Loaded one frame ahead (while the previous frame is packed) when the whole window
     // lies inside the caller's PCM; the stream's first and last frames go through the stream map.
     uint32_t pk[18];
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
         const int64_t u0 = (int64_t)frame * SPF - SPSF;
         pk_valid = u0 >= map.pre_end && u0 + SPF + SPSF <= map.main_end;
         if (pk_valid) {
-            const int16_t *p = spcm + (u0 - map.pre_end) + lane;
+            const int16_t *p = spcm + (u0 - map.pre_end) + fresh(lane0);
 #pragma unroll
             for (int k = 0; k < 18; k++) {
                 uint32_t v = (uint16_t)p[64 * k];
@@ -238,46 +247,48 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
     prefetch(f0);
 
     for (int frame = f0; frame < f1; frame++) {
-        uint32_t a[18];
-        if (pk_valid) {
-#pragma unroll
-            for (int k = 0; k < 18; k++) a[k] = pk[k];
-        } else {
+        const int ln_in = fresh(lane0);
+        if (!pk_valid) {
             // through the stream map, staged in the rows (int16 [channel][18][64])
             const int64_t u0 = (int64_t)frame * SPF - SPSF;
             int16_t *stage = reinterpret_cast<int16_t *>(rows);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 1
             for (int i = 0; i < 18 * NCH; i++)
-                stage[i * 64 + lane] = fetch_pcm(map, spcm + (int64_t)(i / 18) * ch_pitch, u0 + 64 * (i % 18) + lane);
+                stage[i * 64 + ln_in] = fetch_pcm(map, spcm + (int64_t)(i / 18) * ch_pitch, u0 + 64 * (i % 18) + ln_in);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int k = 0; k < 18; k++) {
-                uint32_t v = (uint16_t)stage[k * 64 + lane];
-                if (NCH == 2) v |= (uint32_t)(uint16_t)stage[(18 + k) * 64 + lane] << 16;
-                a[k] = v;
+                uint32_t v = (uint16_t)stage[k * 64 + ln_in];
+                if (NCH == 2) v |= (uint32_t)(uint16_t)stage[(18 + k) * 64 + ln_in] << 16;
+                pk[k] = v;
             }
         }
-        // the fold's mirrored operands: sample 64 k + 63 - lane, k = 1..16
-        uint32_t m[18];
-#pragma unroll
-        for (int k = 1; k <= 16; k++) m[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(mirror_addr, (int)a[k]);
 
         // ---- PcmToFloat (:845-858), RunMdct (Mdct.cs:63-92): per channel the fold of its eight sub-frames into the eight
-        // rows, the eight transforms at once, and the spectra into registers in band order: x[c][h][sf] = band lane + 64 h
+        // rows, the eight transforms at once, and the spectra into registers in band order: x[c][h][sf] = band ln_in + 64 h.
+        // (What only this stage needs -- window values, LDS addresses -- is derived from the ln_in number here, per channel,
+        // instead of living in registers through the rest of the frame: `ln` is laundered so that hipcc does not hoist it.)
         double x[NCH][2][8];
-        {
-            const double w_a = S.window[63 - lane], w_b = S.window[64 + lane], w_c = S.window[lane], w_d = S.window[127 - lane];
 #pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the previous user of the rows is done reading
+        for (int c = 0; c < NCH; c++) {
+            int ln = ln_in;
+            asm volatile("" : "+v"(ln));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the previous user of the rows is done reading
+            {
+                const double w_a = S.window[63 - ln], w_b = S.window[64 + ln], w_c = S.window[ln], w_d = S.window[127 - ln];
+                const int fold_lo = spec_byte_offset(ln), fold_hi = spec_byte_offset(64 + ln);
+                const int mirror_addr = (63 - ln) * 4;
+                auto half_of = [&](uint32_t v) { return c == 0 ? (int)(int16_t)(v & 0xFFFFu) : (int)v >> 16; };
 #pragma unroll
                 for (int sf = 0; sf < 8; sf++) {
-                    auto half_of = [&](uint32_t v) { return c == 0 ? (int)(int16_t)(v & 0xFFFFu) : (int)v >> 16; };
-                    const int x_pv_lo = half_of(a[2 * sf]);                  // p[wi]
-                    const int x_pv_hi = half_of(m[2 * sf + 1]);              // p[127 - wi]
-                    const int x_in_lo = half_of(m[2 * sf + 2]);              // p[128 + 63 - wi]
-                    const int x_in_hi = half_of(a[2 * sf + 3]);              // p[128 + 64 + wi]
+                    // the fold's mirrored operands (sample 64 k + 63 - ln_in) come across the crossbar
+                    const uint32_t m_odd = (uint32_t)__builtin_amdgcn_ds_bpermute(mirror_addr, (int)pk[2 * sf + 1]);
+                    const uint32_t m_even = (uint32_t)__builtin_amdgcn_ds_bpermute(mirror_addr, (int)pk[2 * sf + 2]);
+                    const int x_pv_lo = half_of(pk[2 * sf]);                 // p[wi]
+                    const int x_pv_hi = half_of(m_odd);                      // p[127 - wi]
+                    const int x_in_lo = half_of(m_even);                     // p[128 + 63 - wi]
+                    const int x_in_hi = half_of(pk[2 * sf + 3]);             // p[128 + 64 + wi]
                     const double fa = w_a * -(double)x_in_hi;
                     const double fb = w_b * (double)x_in_lo;
                     const double fc = w_c * (double)x_pv_lo;
@@ -285,26 +296,33 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
                     *reinterpret_cast<double *>(rows + sf * ROW_BYTES + fold_lo) = fa - fb;
                     *reinterpret_cast<double *>(rows + sf * ROW_BYTES + fold_hi) = fc - fd;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            {
+                const int L = ln & 7;
+                char *my_row = rows + (ln >> 3) * ROW_BYTES;
                 dct_first_half_lds(my_row, L, S.tw);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                dct_second_half_lds(my_row, L, S.tw, out_even, out_odd);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int h = 0; h < 2; h++)
-#pragma unroll
-                    for (int sf = 0; sf < 8; sf++)
-                        x[c][h][sf] = *reinterpret_cast<const double *>(rows + sf * ROW_BYTES + 8 * (lane + 64 * h));
+                const int rev = ((L & 1) << 2) | (L & 2) | ((L >> 2) & 1);
+                const int v = rev ^ (rev >> 1) ^ (rev >> 2);
+                dct_second_half_lds(my_row, L, S.tw, 8 * v, 8 * (v ^ 7));
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int sf = 0; sf < 8; sf++)
+                    x[c][h][sf] = *reinterpret_cast<const double *>(rows + sf * ROW_BYTES + 8 * (ln + 64 * h));
         }
         WAVE_STOP_AFTER(2, [&] { double t = 0; for (int c = 0; c < NCH; c++) for (int h = 0; h < 2; h++) for (int sf = 0; sf < 8; sf++) t += x[c][h][sf]; return __double2loint(t); }());
 
-        // ---- EncodeIntensityStereo (:711-764): the energies are sums over the bands in order -- one lane per (sub-frame, sum)
+        // ---- EncodeIntensityStereo (:711-764): the energies are sums over the bands in order -- one ln_in per (sub-frame, sum)
         // walks them in a plain [sub-frame][band] array of the rows, one of the three terms at a time
+        const int ln_is = fresh(lane0);
         uint32_t intensity_pack = 0;                   // eight 4-bit ratios of the secondary channel
         if (NCH == 2 && info.stereo_band_count > 0 && ctype[0] == CH_STEREO_PRIMARY) {
             double *plain = reinterpret_cast<double *>(rows);          // [8][128]
-            double energy[3] = {0, 0, 0};              // lanes 0..7: sub-frame `lane`: L, R, total
+            double energy[3] = {0, 0, 0};              // lanes 0..7: sub-frame `ln_is`: L, R, total
 #pragma unroll
             for (int term = 0; term < 3; term++) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -313,18 +331,18 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 #pragma unroll
                     for (int sf = 0; sf < 8; sf++) {
                         const double l = x[0][h][sf], r = x[NCH - 1][h][sf];
-                        plain[sf * 128 + lane + 64 * h] = term == 0 ? fabs(l) : (term == 1 ? fabs(r) : fabs(l + r));
+                        plain[sf * 128 + ln_is + 64 * h] = term == 0 ? fabs(l) : (term == 1 ? fabs(r) : fabs(l + r));
                     }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane < 8) {
+                if (ln_is < 8) {
                     double e = 0;
-                    for (int b = info.base_band_count; b < info.total_band_count; b++) e += plain[lane * 128 + b];
+                    for (int b = info.base_band_count; b < info.total_band_count; b++) e += plain[ln_is * 128 + b];
                     energy[term] = e;
                 }
             }
             double ratio = 1;
             int quantized = 0;
-            if (lane < 8) {
+            if (ln_is < 8) {
                 const double energy_l = energy[0], energy_r = energy[1];
                 const double energy_total = energy[2] * 2;
                 const double energy_lr = energy_r + energy_l;
@@ -346,7 +364,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
                 intensity_pack |= (uint32_t)__builtin_amdgcn_readlane(quantized, sf) << (4 * sf);
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const int b = lane + 64 * h;
+                    const int b = ln_is + 64 * h;
                     if (b >= info.base_band_count && b < info.total_band_count) {
                         x[0][h][sf] = (x[0][h][sf] + x[NCH - 1][h][sf]) * rt;
                         x[NCH - 1][h][sf] = 0;
@@ -358,6 +376,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
         // ---- CalculateScaleFactors (:673-689), ScaleSpectra (:651-671) and the band's bit costs at all sixteen resolutions
         // (CalculateUsedBits :554-597) in one pass over the band's eight coefficients.  Bands >= the coded count keep their
         // unscaled values (the HFR group averages read exactly those).
+        const int ln_sc = fresh(lane0);
         int sfv[NCH][2];
         uint4 cost[NCH][2];
         uint32_t hfr_lo[NCH] = {}, hfr_hi[NCH] = {};   // the channel's HFR scales, 6 bits each: groups 0..4 | groups 5..7
@@ -365,7 +384,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
         for (int c = 0; c < NCH; c++) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const int b = lane + 64 * h;
+                const int b = ln_sc + 64 * h;
                 sfv[c][h] = 0;
                 cost[c][h] = make_uint4(0, 0, 0, 0);
                 if (b < coded[c]) {
@@ -384,18 +403,18 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
                     cost[c][h] = band_cost_table(Q, x[c][h]);
                 }
             }
-            // ---- CalculateHfrGroupAverages (:766-793) + CalculateHfrScale (:795-832): one lane per group walks the plain array
+            // ---- CalculateHfrGroupAverages (:766-793) + CalculateHfrScale (:795-832): one ln_sc per group walks the plain array
             if (info.hfr_group_count > 0 && ctype[c] != CH_STEREO_SECONDARY) {
                 double *plain = reinterpret_cast<double *>(rows);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int h = 0; h < 2; h++)
 #pragma unroll
-                    for (int sf = 0; sf < 8; sf++) plain[sf * 128 + lane + 64 * h] = x[c][h][sf];
+                    for (int sf = 0; sf < 8; sf++) plain[sf * 128 + ln_sc + 64 * h] = x[c][h][sf];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 int scale = 0;
-                if (lane < info.hfr_group_count) {
-                    const int group = lane;
+                if (ln_sc < info.hfr_group_count) {
+                    const int group = ln_sc;
                     const int hfr_start = info.stereo_band_count + info.base_band_count;
                     double sum = 0.0;
                     int count = 0;
@@ -434,18 +453,19 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
         // register and reduced with DPP; everything after the sums is wave-uniform
         int hlb[NCH], dbits[NCH];
         auto header_lengths = [&]() __attribute__((always_inline)) {
+            const int ln_h = fresh(lane0);
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
                 int pa = 0, pb = 0, pe = 0;
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const int band = lane + 64 * h;
+                    const int band = ln_h + 64 * h;
                     const bool in = band < coded[c];
                     const int sf = sfv[c][h];
                     int prev = wave_shr1(sf);
                     if (h == 1) {
                         const int wrap = __builtin_amdgcn_readlane(sfv[c][0], 63);
-                        prev = lane == 0 ? wrap : prev;
+                        prev = ln_h == 0 ? wrap : prev;
                     }
                     const bool counted = in && band >= 1;
                     const int delta = counted ? abs(sf - prev) : 0;
@@ -480,7 +500,8 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
         WAVE_STOP_AFTER(4, [&] { double t = 0; for (int c = 0; c < NCH; c++) for (int h = 0; h < 2; h++) for (int sf = 0; sf < 8; sf++) t += x[c][h][sf]; return __double2loint(t); }() + (int)(cost[0][0].x ^ cost[0][1].y ^ cost[NCH - 1][0].z ^ cost[NCH - 1][1].w) + hlb[0] + dbits[NCH - 1]);
 
         // ---- CalculateNoiseLevel (:457-485) / BinarySearchLevel (:502-523) and CalculateEvaluationBoundary (:487-500) /
-        // BinarySearchBoundary (:525-552).  Slot k = (channel k >> 1, band lane + 64 (k & 1)).
+        // BinarySearchBoundary (:525-552).  Slot k = (channel k >> 1, band ln_h + 64 (k & 1)).
+        const int ln_se = fresh(lane0);
         constexpr int NS = 2 * NCH;
         uint64_t clo[NS], chi[NS];
         int off[NS], bnd[NS];
@@ -490,7 +511,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
             const uint4 cw = cost[k >> 1][k & 1];
             clo[k] = ((uint64_t)cw.y << 32) | cw.x;
             chi[k] = ((uint64_t)cw.w << 32) | cw.z;
-            bnd[k] = lane + 64 * (k & 1);
+            bnd[k] = ln_se + 64 * (k & 1);
         }
         int level = 0, boundary = 0;
         bool too_low = false;
@@ -531,20 +552,20 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
             for (int c = 0; c < NCH; c++)
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const int b = lane + 64 * h;
+                    const int b = ln_se + 64 * h;
                     if (b == highest_band + 1 || b == highest_band + 2) sfv[c][h] = 0;
                 }
             header_lengths();
         }
         if (too_low) {                                 // InvalidDataException("Bitrate is set too low.")
-            if (lane == 0 && status) atomicOr(status, 4);
+            if (ln_se == 0 && status) atomicOr(status, 4);
             level = 255;
         }
         if (level > 0 && !too_low) {
             // BinarySearchBoundary (:525-552) probes CalculateUsedBits(level, boundary): the bands below the boundary at
             // level - 1, the others at level -- the frame's bits at `level` plus, for every band below the boundary, what the
             // band costs more at level - 1: ONE exclusive scan over the bands gives the value of every possible probe and the
-            // search's dependent probes are lane reads -- the same probes and decisions in the reference's order (the bits
+            // search's dependent probes are ln_se reads -- the same probes and decisions in the reference's order (the bits
             // need not be monotone in the boundary and nothing here assumes it)
             int hsum = 48;
 #pragma unroll
@@ -581,28 +602,29 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
         }
         WAVE_STOP_AFTER(5, [&] { double t = 0; for (int c = 0; c < NCH; c++) for (int h = 0; h < 2; h++) for (int sf = 0; sf < 8; sf++) t += x[c][h][sf]; return __double2loint(t); }() + level + boundary);
         if (boundary < 0) {                            // NotImplementedException in the reference
-            if (lane == 0 && status) atomicOr(status, 8);
+            if (ln_se == 0 && status) atomicOr(status, 8);
             boundary = 0;
         }
 
         // ---- CalculateFrameResolutions (:441-455)
+        const int ln_q = fresh(lane0);
         int res[NCH][2];
 #pragma unroll
         for (int c = 0; c < NCH; c++)
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const int b = lane + 64 * h;
+                const int b = ln_q + 64 * h;
                 res[c][h] = b < coded[c] ? resolution_of(T, sfv[c][h], b < boundary ? level - 1 : level) : 0;
             }
 
         // ---- QuantizeSpectra (:420-439): code and length of every coefficient in 16 bits (code << 4 | bits; 12 + 4 at most),
-        // written where the lane that owns the code in stream order -- (sub-frame, channel, band): WriteSpectra
+        // written where the ln_q that owns the code in stream order -- (sub-frame, channel, band): WriteSpectra
         // (CriHcaPacking.cs:238-260) -- will read it.  The quantiser's constants need no table: QuantizerInverseStepSize[r] =
         // ResolutionMaxValue[r] + 0.5 (CriHcaTables.cs:57), shiftUp = inv + 1, shiftDown = (int)(inv + 0.5) = max + 1, and
         // QuantizedSpectrumMaxBits[r] = r - 3 from resolution 8 on.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the rows' last readers are done
         {
-            const int turn_addr = (lane / PT) * Lay::STRIDE + (lane % PT) * 2;
+            const int turn_addr = (ln_q / PT) * Lay::STRIDE + (ln_q % PT) * 2;
 #pragma unroll
             for (int c = 0; c < NCH; c++)
 #pragma unroll
@@ -620,30 +642,31 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
                         const unsigned large_pair = q != 0 ? ((((mag << 1) | (q > 0 ? 0u : 1u)) << 4) | (unsigned)(r - 3))
                                                            : (unsigned)(r - 4);
                         const unsigned pair = r == 0 ? 0u : (r < 8 ? small_pair : large_pair);
-                        const int base_slot = ((sf * NCH + c) * 128 + 64 * h);          // + lane: a multiple of 64 (PT divides 64)
+                        const int base_slot = ((sf * NCH + c) * 128 + 64 * h);          // + ln_q: a multiple of 64 (PT divides 64)
                         *reinterpret_cast<uint16_t *>(rows + (base_slot / PT) * Lay::STRIDE + turn_addr) = (uint16_t)pair;
                     }
                 }
         }
+        const int ln_pk = fresh(lane0);
         // the next frame's samples: their latency hides under the packing
         if (frame + 1 < f1) prefetch(frame + 1);
-        for (int i = lane; i < fwords; i += 64) fbuf[i] = 0;
+        for (int i = ln_pk; i < fwords; i += 64) fbuf[i] = 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        WAVE_STOP_AFTER(6, fbuf[lane] + reinterpret_cast<uint32_t *>(rows)[lane * 7] + level);
+        WAVE_STOP_AFTER(6, fbuf[ln_pk] + reinterpret_cast<uint32_t *>(rows)[ln_pk * 7] + level);
 
+        const int ln_hd = fresh(lane0);
         auto put_bits = [&](int bit, unsigned value, int nbits) __attribute__((always_inline)) {
-            if (nbits <= 0) return;
-            const uint64_t win = (uint64_t)value << (64 - nbits - (bit & 31));
+            const uint64_t win = (uint64_t)value << ((64 - nbits - (bit & 31)) & 63);      // nbits = 0: the value is 0
             const unsigned hi = (unsigned)(win >> 32), lo = (unsigned)win;
-            if (hi) atomicOr(&fbuf[bit >> 5], hi);
-            if (lo) atomicOr(&fbuf[(bit >> 5) + 1], lo);
+            atomicOr(&fbuf[bit >> 5], hi);
+            atomicOr(&fbuf[(bit >> 5) + 1], lo);
         };
         int header_bits = 32;
 #pragma unroll
         for (int c = 0; c < NCH; c++) header_bits += hlb[c];
         if (!too_low) {
             // ---- PackFrame (CriHcaPacking.cs:17-58): sync word, noise level, evaluation boundary
-            if (lane == 0) atomicOr(&fbuf[0], 0xFFFF0000u | ((unsigned)level << 7) | (unsigned)boundary);
+            if (ln_hd == 0) atomicOr(&fbuf[0], 0xFFFF0000u | ((unsigned)level << 7) | (unsigned)boundary);
             // WriteScaleFactors (:262-295): bands in order = lanes in order, first half then second half
             int bit0 = 32;
 #pragma unroll
@@ -653,12 +676,12 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
                 int nb2[2] = {0, 0};
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const int band = lane + 64 * h;
+                    const int band = ln_hd + 64 * h;
                     const int sf = sfv[c][h];
                     int prev = wave_shr1(sf);
                     if (h == 1) {
                         const int wrap = __builtin_amdgcn_readlane(sfv[c][0], 63);
-                        prev = lane == 0 ? wrap : prev;
+                        prev = ln_hd == 0 ? wrap : prev;
                     }
                     if (band == 0) {                           // the 3-bit delta width, then the first scale factor
                         code[h] = (unsigned)db;
@@ -680,19 +703,20 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
                 const int total1 = __builtin_amdgcn_readlane(incl1, 63);
                 put_bits(bit0 + incl0 - nb2[0], code[0], nb2[0]);
                 put_bits(bit0 + total0 + incl1 - nb2[1], code[1], nb2[1]);
-                if (lane < 8) {                                // intensity / HFR scales follow the scale factors
+                if (ln_hd < 8) {                                // intensity / HFR scales follow the scale factors
                     const int at = bit0 + total0 + total1;
-                    if (ctype[c] == CH_STEREO_SECONDARY) put_bits(at + 4 * lane, (intensity_pack >> (4 * lane)) & 15u, 4);
-                    else if (lane < info.hfr_group_count)
-                        put_bits(at + 6 * lane, (lane < 5 ? hfr_lo[c] >> (6 * lane) : hfr_hi[c] >> (6 * (lane - 5))) & 63u, 6);
+                    if (ctype[c] == CH_STEREO_SECONDARY) put_bits(at + 4 * ln_hd, (intensity_pack >> (4 * ln_hd)) & 15u, 4);
+                    else if (ln_hd < info.hfr_group_count)
+                        put_bits(at + 6 * ln_hd, (ln_hd < 5 ? hfr_lo[c] >> (6 * ln_hd) : hfr_hi[c] >> (6 * (ln_hd - 5))) & 63u, 6);
                 }
                 bit0 += hlb[c];
             }
-            // ---- WriteSpectra (:238-260): PT consecutive codes per lane
+            const int ln_ws = fresh(lane0);
+            // ---- WriteSpectra (:238-260): PT consecutive codes per ln_ws
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             uint32_t cw[PT / 2];
             {
-                const uint4 *src = reinterpret_cast<const uint4 *>(rows + lane * Lay::STRIDE);
+                const uint4 *src = reinterpret_cast<const uint4 *>(rows + ln_ws * Lay::STRIDE);
 #pragma unroll
                 for (int i = 0; i < PT / 8; i++) {
                     const uint4 v = src[i];
@@ -702,37 +726,52 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
                     cw[4 * i + 3] = v.w;
                 }
             }
-            uint32_t nib = 0;
+            // A ln_ws's codes are consecutive in the stream.  They are concatenated inside the ln_ws as a tree -- pairs (at most 24
+            // bits), then fours (at most 48 bits, with their lengths) -- and every four is ORed into the frame at its
+            // bit position as three dwords, whatever they hold: no branch per code, and an LDS atomic that ORs zeros costs
+            // less than finding out that it would (the first and last dword of a ln_ws are shared with its neighbours).
+            constexpr int UNITS = PT / 4;
+            uint64_t unit[UNITS];
+            int ulen[UNITS];
+            int local = 0;
 #pragma unroll
-            for (int i = 0; i < PT / 2; i++) nib += cw[i] & 0x000F000Fu;       // <= 16 x 12 per half
-            const int local = (int)((nib & 0xFFFFu) + (nib >> 16));
-            const int incl = wave_inclusive_scan(local);
-            const int bit = header_bits + incl - local;
-            uint64_t acc = 0;
-            int word = bit >> 5, p = bit & 31;
+            for (int j = 0; j < UNITS; j++) {
+                uint32_t u2[2];
+                int n2[2];
 #pragma unroll
-            for (int i = 0; i < PT; i++) {
-                const uint32_t pair = (i & 1) ? cw[i >> 1] >> 16 : cw[i >> 1] & 0xFFFFu;
-                const int nbits = (int)(pair & 15u);
-                acc |= (uint64_t)(pair >> 4) << ((64 - p - nbits) & 63);       // p < 32, nbits <= 12; nbits = 0: the code is 0
-                p += nbits;
-                if (p >= 32) {
-                    const unsigned hi = (unsigned)(acc >> 32);
-                    if (hi) atomicOr(&fbuf[word], hi);
-                    acc <<= 32;
-                    word++;
-                    p -= 32;
+                for (int e = 0; e < 2; e++) {
+                    const uint32_t w = cw[2 * j + e];
+                    const uint32_t c0 = (w >> 4) & 0xFFFu, c1 = w >> 20;
+                    const int n0 = (int)(w & 15u), n1 = (int)((w >> 16) & 15u);
+                    u2[e] = (c0 << n1) | c1;
+                    n2[e] = n0 + n1;
                 }
+                unit[j] = ((uint64_t)u2[0] << n2[1]) | u2[1];
+                ulen[j] = n2[0] + n2[1];
+                local += ulen[j];
             }
-            const unsigned hi = (unsigned)(acc >> 32);
-            if (hi) atomicOr(&fbuf[word], hi);
+            const int incl = wave_inclusive_scan(local);
+            int bit = header_bits + incl - local;
+#pragma unroll
+            for (int j = 0; j < UNITS; j++) {
+                const uint64_t v = unit[j] << ((64 - ulen[j]) & 63);           // left-aligned (an empty unit is 0)
+                const uint32_t v_hi = (uint32_t)(v >> 32), v_lo = (uint32_t)v;
+                const int sh = bit & 31;
+                uint32_t *dst = fbuf + (bit >> 5);
+                atomicOr(dst, v_hi >> sh);
+                atomicOr(dst + 1, (uint32_t)(v >> sh));
+                atomicOr(dst + 2, (uint32_t)(((uint64_t)v_lo << 32) >> sh));
+                bit += ulen[j];
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        WAVE_STOP_AFTER(7, fbuf[lane]);
+        WAVE_STOP_AFTER(7, fbuf[lane0]);
 
-        // ---- WriteChecksum (:231-236): CRC-16 (poly 0x8005, init 0) over the first frame_size - 2 bytes: per-lane partial
+        const int ln_crc = fresh(lane0);
+        // ---- WriteChecksum (:231-236): CRC-16 (poly 0x8005, init 0) over the first frame_size - 2 bytes: per-ln_crc partial
         // CRCs of consecutive chunks, shifted to their place with x^(8k) mod P and XORed
         {
+            const int crc_begin = ln_crc * crc_chunk, crc_end = min(crc_begin + crc_chunk, nbytes);
             unsigned crc = 0;
             for (int i = crc_begin; i < crc_end; i++) {
                 const unsigned byte = (fbuf[i >> 2] >> (24 - 8 * (i & 3))) & 0xFFu;
@@ -743,15 +782,16 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
             }
             unsigned part = (crc_begin < crc_end) ? gf_mul(crc, crc_shift) : 0u;
             const unsigned total = (unsigned)wave_xor((int)part) & 0xFFFFu;
-            if (lane == 0) {
+            if (ln_crc == 0) {
                 const int pos = nbytes;                // big-endian 16-bit value at the last two bytes
                 fbuf[pos >> 2] |= (total >> 8) << (24 - 8 * (pos & 3));
                 fbuf[(pos + 1) >> 2] |= (total & 0xFF) << (24 - 8 * ((pos + 1) & 3));
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        WAVE_STOP_AFTER(8, fbuf[lane]);
+        WAVE_STOP_AFTER(8, fbuf[ln_crc]);
 
+        const int ln_st = fresh(lane0);
         // ---- store the frame: whole aligned dwords (the frame starts at any byte: its k-th dword is a funnel shift of two
         // big-endian words of fbuf), the few bytes before the first and after the last aligned dword one by one
         {
@@ -760,7 +800,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
             const int ndw = (info.frame_size - lead) / 4;
             auto byte_at = [&](int b) { return (fbuf[b >> 2] >> (24 - 8 * (b & 3))) & 0xFFu; };
             uint32_t *dw = reinterpret_cast<uint32_t *>(dst + lead);
-            for (int k = lane; k < ndw; k += 64) {
+            for (int k = ln_st; k < ndw; k += 64) {
                 const int b = lead + 4 * k;                                                   // frame byte of the dword's first byte
                 const uint32_t hi = fbuf[b >> 2], lo = fbuf[(b >> 2) + 1];
                 const int sh = 8 * (b & 3);
@@ -768,8 +808,8 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
                 dw[k] = bswap32(be);
             }
             const int tail0 = lead + 4 * ndw;
-            if (lane < lead) dst[lane] = (uint8_t)byte_at(lane);
-            if (lane >= 32 && lane - 32 < info.frame_size - tail0) dst[tail0 + lane - 32] = (uint8_t)byte_at(tail0 + lane - 32);
+            if (ln_st < lead) dst[ln_st] = (uint8_t)byte_at(ln_st);
+            if (ln_st >= 32 && ln_st - 32 < info.frame_size - tail0) dst[tail0 + ln_st - 32] = (uint8_t)byte_at(tail0 + ln_st - 32);
         }
     }
 }
@@ -785,7 +825,7 @@ static size_t wave_lds_bytes(const DeviceInfo &info)
 bool encode_wave_kernel_takes(const DeviceInfo &info)
 {
     // one or two channels; frames whose bits fit next to the turned codes without pushing a workgroup past the LDS of a CU
-    return (info.nch == 1 || info.nch == 2) && WG_WAVES * wave_lds_bytes(info) + sizeof(WaveShared) + 64 <= 64 * 1024;
+    return (info.nch == 1 || info.nch == 2) && WG_WAVES * wave_lds_bytes(info) + sizeof(WaveShared) + 64 <= (WG_WAVES > 4 ? 80 : 64) * 1024;
 }
 
 int launch_encode_wave(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pitch, int nstreams, const PcmMap &map,
