@@ -177,6 +177,8 @@ __device__ __forceinline__ unsigned gf_mul(unsigned a, unsigned b)
 }
 
 // All sixteen costs of one band (each <= 8 * 12 bits: a byte; no byte can carry) from the look-up described at CostLut.
+// (GROUP: look-ups in flight at once -- a kernel short of registers takes them four at a time)
+template <int GROUP = 8>
 __device__ __forceinline__ uint4 band_cost_table(const CostLut &Q, const double (&x)[8])
 {
     uint32_t a0 = Q.base.x, a1 = Q.base.y, a2 = Q.base.z, a3 = Q.base.w;
@@ -193,6 +195,7 @@ __device__ __forceinline__ uint4 band_cost_table(const CostLut &Q, const double 
         a1 += p.y;
         a2 += p.z;
         a3 += p.w;
+        if (GROUP < 8 && (sf + 1) % GROUP == 0) stage_fence();
     }
     return make_uint4(a0, a1, a2, a3);
 }

@@ -43,16 +43,19 @@ namespace {
 // never happens)
 #define WAVE_STOP_AFTER(n, sink)                                          \
     if (VGA_HCA_ENC_STOP_AFTER == (n)) {                                  \
-        if ((int)(sink) == 0x7A5C3E19 && status) atomicOr(status, 1 << 20); \
+        if ((int)(sink) == 0x7A5C3E19 && cold_args()->status) atomicOr(cold_args()->status, 1 << 20); \
         continue;                                                         \
     }
 
 // (tuning builds: tools/build_variants.sh)
+// Eight waves a workgroup, two workgroups a CU (2 x (8 x 9 KB + 5.5 KB of tables) = 155 KB of the 160) = four waves per
+// SIMD at 128 VGPRs: 21.0 ms at configs[3] against 22.2 for four-wave workgroups at three waves per SIMD
+// (profiles/r06_c_hca_encode_variants.log).
 #ifndef VGA_HCA_WG_WAVES
-#define VGA_HCA_WG_WAVES 4
+#define VGA_HCA_WG_WAVES 8
 #endif
 #ifndef VGA_HCA_WAVE_EU
-#define VGA_HCA_WAVE_EU 3
+#define VGA_HCA_WAVE_EU 4
 #endif
 constexpr int WG_WAVES = VGA_HCA_WG_WAVES;
 constexpr int WG_THREADS = 64 * WG_WAVES;
@@ -66,6 +69,29 @@ struct alignas(16) WaveShared {
     alignas(16) Twiddle tw[127];                   // [0, 63): the stage tables of sizes 1..32 (size 2^b starts at 2^b - 1); [63, 127): the pre-rotation
     double window[128];                // MdctWindow / 32768 (exact: PcmToFloat's scaling folded in, see fold below)
 };
+
+// Everything the kernel is told, as ONE by-value argument: the kernarg segment then IS this struct, and the stages that run
+// once in a thousand frames (the stream's first and last frames through the stream map, intensity stereo, HFR, error flags)
+// read their fields from it where they need them (cold_args) instead of keeping ~25 SGPRs of them alive through the frame
+// loop, where they were spilled to VGPR lanes and read back lane by lane.
+struct WaveArgs {
+    const int16_t *pcm;
+    int64_t stream_pitch, ch_pitch;
+    uint8_t *frames;
+    int64_t frames_pitch;
+    const uint16_t *crc_pow;
+    int *status;
+    int frames_per_run, runs_per_stream, total_runs, first_frame, end_frame, wave_bytes;
+    PcmMap map;
+    DeviceInfo info;
+};
+typedef const __attribute__((address_space(4))) WaveArgs *ColdArgs;
+__device__ __forceinline__ ColdArgs cold_args()
+{
+    ColdArgs p = (ColdArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));                         // opaque: the loads stay where they are written
+    return p;
+}
 
 template <int NCH>
 struct Layout {
@@ -88,9 +114,11 @@ __device__ __forceinline__ int fresh(int v)
     return v;
 }
 
+// v < lo ? lo : (v > hi ? hi : v) for a v that is not NaN, lo < 0 < hi (two instructions instead of two compares and four
+// selects; the sign of a zero cannot come into it)
 __device__ __forceinline__ double minmax_clamp(double v, double lo, double hi)
 {
-    return v < lo ? lo : (v > hi ? hi : v);
+    return __builtin_fmin(__builtin_fmax(v, lo), hi);
 }
 
 // pre-rotation + stages 0..2 (hca_decode_core.hpp: dct_first_half) with the lane's twiddles from the shared table
@@ -103,8 +131,8 @@ __device__ __forceinline__ void dct_first_half_lds(char *row, int L, const Twidd
         const Twiddle t = tw[63 + L + 8 * k];
         z[k].re = p.x * t.c + p.y * t.s;               // Mdct.cs:145-146
         z[k].im = p.x * t.s - p.y * t.c;
-    }
-    stage_fence();                                     // (keeps hipcc from fetching every stage's twiddles up front: 60 VGPRs)
+        if ((k & 3) == 3) stage_fence();               // four operand pairs in flight, not eight
+    }                                     // (keeps hipcc from fetching every stage's twiddles up front: 60 VGPRs)
 #pragma unroll
     for (int k = 0; k < 4; k++) butterfly(z[k], z[k + 4], tw[31 + L + 8 * k]);
     stage_fence();
@@ -162,13 +190,15 @@ __device__ __forceinline__ void dct_second_half_lds(char *row, int L, const Twid
 }  // namespace
 
 template <int NCH>
-__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_HCA_WAVE_EU))) void hca_encode_wave_kernel(
-    const int16_t *__restrict__ pcm, int64_t stream_pitch, int64_t ch_pitch, int frames_per_run, int runs_per_stream, int total_runs,
-    PcmMap map, DeviceInfo info, uint8_t *__restrict__ frames, int64_t frames_pitch, const uint16_t *__restrict__ crc_pow,
-    int *__restrict__ status, int first_frame, int end_frame, int wave_bytes)
+__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_HCA_WAVE_EU))) void hca_encode_wave_kernel(const WaveArgs args)
 {
     using Lay = Layout<NCH>;
     constexpr int PT = Lay::PT;
+    const int16_t *__restrict__ pcm = args.pcm;
+    uint8_t *__restrict__ frames = args.frames;
+    const int64_t stream_pitch = args.stream_pitch, ch_pitch = args.ch_pitch, frames_pitch = args.frames_pitch;
+    const int frame_size = args.info.frame_size, hfr_group_count = args.info.hfr_group_count;
+    const int map_pre_end = args.map.pre_end, map_main_end = args.map.main_end;
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
     __shared__ WaveShared S;
     const int tid = threadIdx.x;
@@ -196,7 +226,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
         S.tw[tid] = Twiddle{f64_bits(MDCT_SinBits[src]), f64_bits(MDCT_CosBits[src])};
     }
     if (!cost_lut_build<WG_THREADS>(S.Q, reinterpret_cast<double *>(s_dyn), tid)) {       // (s_dyn: nothing lives there before the first frame)
-        if (tid == 0 && status) atomicOr(status, 16);
+        if (tid == 0 && cold_args()->status) atomicOr(cold_args()->status, 16);
         return;
     }
     __syncthreads();
@@ -204,54 +234,59 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
     const CostLut &Q = S.Q;
 
     const int run = blockIdx.x * WG_WAVES + wave;
-    if (run >= total_runs) return;
-    const int stream = run / runs_per_stream;
-    const int f0 = first_frame + (run % runs_per_stream) * frames_per_run;                  // frames [first_frame, end_frame) of every stream
-    const int f1 = min(f0 + frames_per_run, end_frame);
+    if (run >= args.total_runs) return;
+    const int stream = run / args.runs_per_stream;
+    const int f0 = args.first_frame + (run % args.runs_per_stream) * args.frames_per_run;   // frames [first_frame, end_frame) of every stream
+    const int f1 = min(f0 + args.frames_per_run, args.end_frame);
 
-    char *rows = s_dyn + (size_t)wave * wave_bytes;                 // eight transform rows; later the turned codes + the frame's bits
+    char *rows = s_dyn + (size_t)wave * args.wave_bytes;                 // eight transform rows; later the turned codes + the frame's bits
     uint32_t *fbuf = reinterpret_cast<uint32_t *>(rows + Lay::CODES_BYTES);
-    const int fwords = ((info.frame_size + 3) / 4 + 3) & ~1;
-    const int available = info.frame_size * 8;
+    const int fwords = ((frame_size + 3) / 4 + 3) & ~1;
+    const int available = frame_size * 8;
 
     int coded[NCH], ctype[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-        coded[c] = info.coded_count[c];
-        ctype[c] = info.channel_type[c];
+        coded[c] = args.info.coded_count[c];
+        ctype[c] = args.info.channel_type[c];
     }
-    const int nbytes = info.frame_size - 2;
+    const bool has_intensity = NCH == 2 && args.info.stereo_band_count > 0 && ctype[0] == CH_STEREO_PRIMARY;
+    const int nbytes = frame_size - 2;
     const int crc_chunk = (nbytes + 63) / 64;
     // x^(8 k) mod P for the k bytes that follow this lane's chunk of the frame
-    const unsigned crc_shift = lane0 * crc_chunk < nbytes ? crc_pow[nbytes - min(lane0 * crc_chunk + crc_chunk, nbytes)] : 0u;
+    const unsigned crc_shift = lane0 * crc_chunk < nbytes ? args.crc_pow[nbytes - min(lane0 * crc_chunk + crc_chunk, nbytes)] : 0u;
 
     const int16_t *spcm = pcm + (int64_t)stream * stream_pitch;
-    // sample 64 k + lane0 of the frame's window (its 1024 samples and the 128 before them), k = 0..17: channel 0 in the low
-    // half, channel 1 in the high half.  Loaded one frame ahead (while the previous frame is packed) when the whole window
-    // lies inside the caller's PCM; the stream's first and last frames go through the stream map.
-    uint32_t pk[18];
-    bool pk_valid = false;
-    auto prefetch = [&](int frame) __attribute__((always_inline)) {
+    for (int frame = f0; frame < f1; frame++) {
+        // sample 64 k + lane of the frame's window (its 1024 samples and the 128 before them), k = 0..17: channel 0 in the low
+        // half, channel 1 in the high half -- straight from the caller's PCM when the whole window lies inside it (every
+        // frame but a stream's first and last few).  (Loading them a frame ahead, under the previous frame's packing, was
+        // measured: 18 registers held through the packing cost more than the exposed latency, 26.1 against 22.1 ms.)
+        uint32_t pk[18];
+        const int ln_in = fresh(lane0);
         const int64_t u0 = (int64_t)frame * SPF - SPSF;
-        pk_valid = u0 >= map.pre_end && u0 + SPF + SPSF <= map.main_end;
-        if (pk_valid) {
-            const int16_t *p = spcm + (u0 - map.pre_end) + fresh(lane0);
+        if (u0 >= map_pre_end && u0 + SPF + SPSF <= map_main_end) {
+            const int16_t *p = spcm + (u0 - map_pre_end) + ln_in;
 #pragma unroll
             for (int k = 0; k < 18; k++) {
                 uint32_t v = (uint16_t)p[64 * k];
                 if (NCH == 2) v |= (uint32_t)(uint16_t)p[ch_pitch + 64 * k] << 16;
                 pk[k] = v;
             }
-        }
-    };
-    prefetch(f0);
-
-    for (int frame = f0; frame < f1; frame++) {
-        const int ln_in = fresh(lane0);
-        if (!pk_valid) {
+        } else {
             // through the stream map, staged in the rows (int16 [channel][18][64])
-            const int64_t u0 = (int64_t)frame * SPF - SPSF;
             int16_t *stage = reinterpret_cast<int16_t *>(rows);
+            PcmMap map;
+            {
+                ColdArgs k = cold_args();
+                map.zero_pre = k->map.zero_pre;
+                map.pre_end = k->map.pre_end;
+                map.main_end = k->map.main_end;
+                map.post_end = k->map.post_end;
+                map.loop_start = k->map.loop_start;
+                map.last_chunk = k->map.last_chunk;
+                map.raw_len = k->map.raw_len;
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 1
             for (int i = 0; i < 18 * NCH; i++)
@@ -320,7 +355,8 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
         // walks them in a plain [sub-frame][band] array of the rows, one of the three terms at a time
         const int ln_is = fresh(lane0);
         uint32_t intensity_pack = 0;                   // eight 4-bit ratios of the secondary channel
-        if (NCH == 2 && info.stereo_band_count > 0 && ctype[0] == CH_STEREO_PRIMARY) {
+        if (NCH == 2 && has_intensity) {
+            const int base_band_count = cold_args()->info.base_band_count, total_band_count = cold_args()->info.total_band_count;
             double *plain = reinterpret_cast<double *>(rows);          // [8][128]
             double energy[3] = {0, 0, 0};              // lanes 0..7: sub-frame `ln_is`: L, R, total
 #pragma unroll
@@ -336,7 +372,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (ln_is < 8) {
                     double e = 0;
-                    for (int b = info.base_band_count; b < info.total_band_count; b++) e += plain[ln_is * 128 + b];
+                    for (int b = base_band_count; b < total_band_count; b++) e += plain[ln_is * 128 + b];
                     energy[term] = e;
                 }
             }
@@ -365,7 +401,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const int b = ln_is + 64 * h;
-                    if (b >= info.base_band_count && b < info.total_band_count) {
+                    if (b >= base_band_count && b < total_band_count) {
                         x[0][h][sf] = (x[0][h][sf] + x[NCH - 1][h][sf]) * rt;
                         x[NCH - 1][h][sf] = 0;
                     }
@@ -404,8 +440,17 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
                 }
             }
             // ---- CalculateHfrGroupAverages (:766-793) + CalculateHfrScale (:795-832): one ln_sc per group walks the plain array
-            if (info.hfr_group_count > 0 && ctype[c] != CH_STEREO_SECONDARY) {
+            if (hfr_group_count > 0 && ctype[c] != CH_STEREO_SECONDARY) {
                 double *plain = reinterpret_cast<double *>(rows);
+                struct { int stereo_band_count, base_band_count, bands_per_hfr_group, hfr_band_count, total_band_count; } info;
+                {
+                    ColdArgs k = cold_args();
+                    info.stereo_band_count = k->info.stereo_band_count;
+                    info.base_band_count = k->info.base_band_count;
+                    info.bands_per_hfr_group = k->info.bands_per_hfr_group;
+                    info.hfr_band_count = k->info.hfr_band_count;
+                    info.total_band_count = k->info.total_band_count;
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int h = 0; h < 2; h++)
@@ -413,7 +458,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
                     for (int sf = 0; sf < 8; sf++) plain[sf * 128 + ln_sc + 64 * h] = x[c][h][sf];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 int scale = 0;
-                if (ln_sc < info.hfr_group_count) {
+                if (ln_sc < hfr_group_count) {
                     const int group = ln_sc;
                     const int hfr_start = info.stereo_band_count + info.base_band_count;
                     double sum = 0.0;
@@ -491,7 +536,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
                         if (cand_len[k] < len) { len = cand_len[k]; db = k; }
                 }
                 if (ctype[c] == CH_STEREO_SECONDARY) len += 32;
-                else if (info.hfr_group_count > 0) len += 6 * info.hfr_group_count;
+                else len += 6 * hfr_group_count;
                 hlb[c] = len;
                 dbits[c] = db;
             }
@@ -515,7 +560,8 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
         }
         int level = 0, boundary = 0;
         bool too_low = false;
-        int highest_band = info.base_band_count + info.stereo_band_count - 1;
+        int highest_band = 0;
+        bool dropping = false;
         for (;;) {
             int hsum = 48;
 #pragma unroll
@@ -546,6 +592,8 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
             level = (low == 255 && mid_value > available) ? -1 : low;
             if (level >= 0) break;
             // CalculateNoiseLevel (:469-484): drop the two highest bands and try again
+            if (!dropping) highest_band = cold_args()->info.base_band_count + cold_args()->info.stereo_band_count - 1;
+            dropping = true;
             highest_band -= 2;
             if (highest_band < 0) { too_low = true; break; }
 #pragma unroll
@@ -558,7 +606,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
             header_lengths();
         }
         if (too_low) {                                 // InvalidDataException("Bitrate is set too low.")
-            if (ln_se == 0 && status) atomicOr(status, 4);
+            if (ln_se == 0 && cold_args()->status) atomicOr(cold_args()->status, 4);
             level = 255;
         }
         if (level > 0 && !too_low) {
@@ -602,7 +650,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
         }
         WAVE_STOP_AFTER(5, [&] { double t = 0; for (int c = 0; c < NCH; c++) for (int h = 0; h < 2; h++) for (int sf = 0; sf < 8; sf++) t += x[c][h][sf]; return __double2loint(t); }() + level + boundary);
         if (boundary < 0) {                            // NotImplementedException in the reference
-            if (ln_se == 0 && status) atomicOr(status, 8);
+            if (ln_se == 0 && cold_args()->status) atomicOr(cold_args()->status, 8);
             boundary = 0;
         }
 
@@ -648,8 +696,6 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
                 }
         }
         const int ln_pk = fresh(lane0);
-        // the next frame's samples: their latency hides under the packing
-        if (frame + 1 < f1) prefetch(frame + 1);
         for (int i = ln_pk; i < fwords; i += 64) fbuf[i] = 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         WAVE_STOP_AFTER(6, fbuf[ln_pk] + reinterpret_cast<uint32_t *>(rows)[ln_pk * 7] + level);
@@ -706,7 +752,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
                 if (ln_hd < 8) {                                // intensity / HFR scales follow the scale factors
                     const int at = bit0 + total0 + total1;
                     if (ctype[c] == CH_STEREO_SECONDARY) put_bits(at + 4 * ln_hd, (intensity_pack >> (4 * ln_hd)) & 15u, 4);
-                    else if (ln_hd < info.hfr_group_count)
+                    else if (ln_hd < hfr_group_count)
                         put_bits(at + 6 * ln_hd, (ln_hd < 5 ? hfr_lo[c] >> (6 * ln_hd) : hfr_hi[c] >> (6 * (ln_hd - 5))) & 63u, 6);
                 }
                 bit0 += hlb[c];
@@ -795,9 +841,9 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
         // ---- store the frame: whole aligned dwords (the frame starts at any byte: its k-th dword is a funnel shift of two
         // big-endian words of fbuf), the few bytes before the first and after the last aligned dword one by one
         {
-            uint8_t *dst = frames + (int64_t)stream * frames_pitch + (int64_t)frame * info.frame_size;
+            uint8_t *dst = frames + (int64_t)stream * frames_pitch + (int64_t)frame * frame_size;
             const int lead = (int)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3);       // bytes before the first aligned dword
-            const int ndw = (info.frame_size - lead) / 4;
+            const int ndw = (frame_size - lead) / 4;
             auto byte_at = [&](int b) { return (fbuf[b >> 2] >> (24 - 8 * (b & 3))) & 0xFFu; };
             uint32_t *dw = reinterpret_cast<uint32_t *>(dst + lead);
             for (int k = ln_st; k < ndw; k += 64) {
@@ -809,7 +855,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
             }
             const int tail0 = lead + 4 * ndw;
             if (ln_st < lead) dst[ln_st] = (uint8_t)byte_at(ln_st);
-            if (ln_st >= 32 && ln_st - 32 < info.frame_size - tail0) dst[tail0 + ln_st - 32] = (uint8_t)byte_at(tail0 + ln_st - 32);
+            if (ln_st >= 32 && ln_st - 32 < frame_size - tail0) dst[tail0 + ln_st - 32] = (uint8_t)byte_at(tail0 + ln_st - 32);
         }
     }
 }
@@ -843,16 +889,28 @@ int launch_encode_wave(const int16_t *d_pcm, int64_t stream_pitch, int64_t ch_pi
     const int runs = (frame_span + per_run - 1) / per_run;
     const int64_t total_runs = (int64_t)nstreams * runs;
     const unsigned grid = (unsigned)((total_runs + WG_WAVES - 1) / WG_WAVES);
+    WaveArgs args{};
+    args.pcm = d_pcm;
+    args.stream_pitch = stream_pitch;
+    args.ch_pitch = ch_pitch;
+    args.frames = d_frames;
+    args.frames_pitch = frames_pitch;
+    args.crc_pow = d_crc_pow;
+    args.status = d_status;
+    args.frames_per_run = per_run;
+    args.runs_per_stream = runs;
+    args.total_runs = (int)total_runs;
+    args.first_frame = first_frame;
+    args.end_frame = end_frame;
+    args.wave_bytes = (int)wave_bytes;
+    args.map = map;
+    args.info = info;
     if (info.nch == 2) {
         if (lds > 32 * 1024) VGA_HIP_TRY(allow_dynamic_lds(hca_encode_wave_kernel<2>, lds));
-        hipLaunchKernelGGL(hca_encode_wave_kernel<2>, dim3(grid), dim3(WG_THREADS), lds, stream, d_pcm, stream_pitch, ch_pitch, per_run,
-                           runs, (int)total_runs, map, info, d_frames, frames_pitch, d_crc_pow, d_status, first_frame, end_frame,
-                           (int)wave_bytes);
+        hipLaunchKernelGGL(hca_encode_wave_kernel<2>, dim3(grid), dim3(WG_THREADS), lds, stream, args);
     } else {
         if (lds > 32 * 1024) VGA_HIP_TRY(allow_dynamic_lds(hca_encode_wave_kernel<1>, lds));
-        hipLaunchKernelGGL(hca_encode_wave_kernel<1>, dim3(grid), dim3(WG_THREADS), lds, stream, d_pcm, stream_pitch, ch_pitch, per_run,
-                           runs, (int)total_runs, map, info, d_frames, frames_pitch, d_crc_pow, d_status, first_frame, end_frame,
-                           (int)wave_bytes);
+        hipLaunchKernelGGL(hca_encode_wave_kernel<1>, dim3(grid), dim3(WG_THREADS), lds, stream, args);
     }
     VGA_HIP_TRY(hipGetLastError());
     return VGA_OK;
