@@ -1193,11 +1193,11 @@ def run_hca(args, cx):
         return None
     bytes_launch = (2.0 + info.frame_size * info.frame_count / (2.0 * n)) * chs if n else 0.0
     achieved = bytes_launch / (enc_ms * 1e-3) / 1e9 if enc_ms > 0 else 0.0
-    pmc, pmc_note = load_profile_json("hca", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
+    pmc, pmc_note = load_profile_json("hca", "r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json")
     traffic = None
     if pmc and ns == 1024 and n == 2880000:
-        traffic = (pmc.get("hca_encode_kernel") or {}).get("traffic_bytes_per_launch")
-    roofline = {"bound": "hbm", "kernel": "hca_encode_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        traffic = (pmc.get("hca_encode_wave_kernel") or pmc.get("hca_encode_kernel") or {}).get("traffic_bytes_per_launch")
+    roofline = {"bound": "hbm", "kernel": "hca_encode_wave_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": pmc_note,
                 "algorithmic_bytes_per_launch": bytes_launch, "launch_ms": round(enc_ms, 3),
                 "other_kernels": {"hca_scan_kernel + hca_frames_kernel (decode)": {

@@ -47,7 +47,7 @@ def source_hashes():
 KERNEL_FILES = {
     "gc": ["gc_encode_kernel.hip", "gcadpcm_kernels.hip", "gc_decode_kernel.hip"],
     "adx": ["adx_kernels.hip"],
-    "hca": ["hca_encode_kernel.hip", "hca_decode_kernels.hip"],
+    "hca": ["hca_encode_wave_kernel.hip", "hca_encode_kernel.hip", "hca_decode_kernels.hip"],
 }
 
 

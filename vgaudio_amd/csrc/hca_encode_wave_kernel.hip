@@ -62,12 +62,22 @@ constexpr int WG_THREADS = 64 * WG_WAVES;
 constexpr int MAX_WAVE_FRAMES = 16;
 constexpr int ROWS_BYTES = 8 * ROW_BYTES;              // one channel's eight transforms
 
+// FindScaleFactor (:691-709) returns how many of the table's first 63 entries are <= value.  The table is geometric (ratio
+// 2^(53/128) = 1.33), so the value's exponent and top three mantissa bits (a bucket 2^(1/8) = 1.09 wide) leave at most one
+// entry undecided: a byte per bucket says how many entries lie at or below the bucket's lower edge and ONE exact compare with
+// the next entry decides the rest -- two dependent LDS reads instead of the binary search's six (checked when the workgroup
+// builds the table; entry 63 of the workgroup's copy of the table is +inf: the count stops at 63).
+constexpr int SF_BUCKETS = 216;
+
 // what the waves of a workgroup share (static LDS)
 struct alignas(16) WaveShared {
     EncTab T;
     CostLut Q;
     alignas(16) Twiddle tw[127];                   // [0, 63): the stage tables of sizes 1..32 (size 2^b starts at 2^b - 1); [63, 127): the pre-rotation
     double window[128];                // MdctWindow / 32768 (exact: PcmToFloat's scaling folded in, see fold below)
+    uint8_t sf_rank[SF_BUCKETS];       // FindScaleFactor by look-up (find_scale_factor_lut)
+    int sf_key_base;
+    int bad;
 };
 
 // Everything the kernel is told, as ONE by-value argument: the kernarg segment then IS this struct, and the stages that run
@@ -187,6 +197,14 @@ __device__ __forceinline__ void dct_second_half_lds(char *row, int L, const Twid
     }
 }
 
+// value >= 0, not NaN
+__device__ __forceinline__ int find_scale_factor_lut(const WaveShared &S, double value)
+{
+    const int key = (int)((uint32_t)__double2hiint(value) >> 17) - S.sf_key_base;
+    const int rb = S.sf_rank[min(max(key, 0), SF_BUCKETS - 1)];
+    return rb + (value >= S.T.dequant_scale[rb] ? 1 : 0);
+}
+
 }  // namespace
 
 template <int NCH>
@@ -225,7 +243,26 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
         const int src = tid < 63 ? tid : tid + 64;                  // 63.. -> entries 127.. of the reference's table (size 128, i < 64)
         S.tw[tid] = Twiddle{f64_bits(MDCT_SinBits[src]), f64_bits(MDCT_CosBits[src])};
     }
-    if (!cost_lut_build<WG_THREADS>(S.Q, reinterpret_cast<double *>(s_dyn), tid)) {       // (s_dyn: nothing lives there before the first frame)
+    if (tid == 0) S.bad = 0;
+    __syncthreads();
+    S.sf_key_base = (int)(HCA_DequantizerScalingTableBits[0] >> 49) - 1;       // (every thread writes the same value)
+    if (tid == 63) S.T.dequant_scale[63] = __longlong_as_double(0x7FF0000000000000ll);
+    if (tid < SF_BUCKETS) {
+        const int kb = (int)(HCA_DequantizerScalingTableBits[0] >> 49) - 1;
+        // bucket 0: everything below the table's first entry; bucket b: keys kb + b (the last one: that and everything above)
+        const double lower = tid == 0 ? 0.0 : __hiloint2double((kb + tid) << 17, 0);
+        const double upper = __hiloint2double((kb + tid + 1) << 17, 0);
+        int at_or_below = 0, inside = 0;
+        for (int j = 0; j < 63; j++) {
+            const double t = f64_bits(HCA_DequantizerScalingTableBits[j]);
+            at_or_below += t <= lower ? 1 : 0;
+            inside += (t > lower && t < upper) ? 1 : 0;
+        }
+        if (inside > 1 || (tid == 0 && (at_or_below | inside) != 0) || (tid == SF_BUCKETS - 1 && at_or_below != 63)) S.bad = 1;
+        S.sf_rank[tid] = (uint8_t)at_or_below;
+    }
+    __syncthreads();
+    if (S.bad || !cost_lut_build<WG_THREADS>(S.Q, reinterpret_cast<double *>(s_dyn), tid)) {       // (s_dyn: nothing lives there before the first frame)
         if (tid == 0 && cold_args()->status) atomicOr(cold_args()->status, 16);
         return;
     }
@@ -261,7 +298,8 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
         // sample 64 k + lane of the frame's window (its 1024 samples and the 128 before them), k = 0..17: channel 0 in the low
         // half, channel 1 in the high half -- straight from the caller's PCM when the whole window lies inside it (every
         // frame but a stream's first and last few).  (Loading them a frame ahead, under the previous frame's packing, was
-        // measured: 18 registers held through the packing cost more than the exposed latency, 26.1 against 22.1 ms.)
+        // measured: 18 registers held through the packing cost more than the exposed latency, 26.1 against 22.1 ms; touching
+        // the next frame's lines with one load into an unused corner of LDS: 20.8 against 20.6 ms, nothing.)
         uint32_t pk[18];
         const int ln_in = fresh(lane0);
         const int64_t u0 = (int64_t)frame * SPF - SPSF;
@@ -430,7 +468,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
                         const double coeff = fabs(x[c][h][sf]);
                         mx = coeff > mx ? coeff : mx;
                     }
-                    const int s = find_scale_factor(T, mx);
+                    const int s = find_scale_factor_lut(S, mx);
                     const double qs = T.quant_scale[s];
 #pragma unroll
                     for (int sf = 0; sf < 8; sf++)
