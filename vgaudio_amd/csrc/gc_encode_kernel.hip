@@ -138,19 +138,11 @@ VGA_COLD int prescan_sequential_cold(X16 xs, int c0, int c1)
     return prescan_sequential(x, c0, c1);
 }
 
-// The reference's loop as written (bump loop, literal f32/f64 pass): hostile input only.  Out of line ON
-// PURPOSE: inlined, hipcc hoists its loop-invariant set-up (14 shifts, 64-bit mads) into every third trip.
-struct GenericOut { PassOut r; int final_sp; };
-__device__ __noinline__ GenericOut resume_generic(X16 xs, int c0, int c1, int scale_power)
-{
-    int x[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = xs.v[i];
-    GenericOut o;
-    o.r = resume_passes(x, c0, c1, scale_power, o.final_sp);
-    return o;
-}
-
+#ifdef VGA_GC_R05_COLD
+#define VGA_COLD_OPAQUE(v) ((void)0)
+#else
+#define VGA_COLD_OPAQUE(v) VGA_OPAQUE(v)
+#endif
 // Third and later trips / the generic redo for one frame.  Its mere presence in the frame loop costs the hot
 // path (a build with the block compiled in but never run: 172 ms vs 140 ms without it), which is why the
 // frame's tail is instantiated once per branch below instead of merging the two branches' results.
@@ -163,7 +155,11 @@ struct ColdState {
     //   drop:    (lane-per-candidate layout) the pair's other lane redoes the whole loop: this lane is out
     //   wide:    the final pass ran at the cap with an overflow above 3: same pass again with a 64-bit error sum
     //   resume:  third and later trips
+    // start: -100 = not known yet: the loop stands behind the bumps of the pass that started them (bump_a: the pass at s1
+    // with overflow ov_a, else the pass at s1 + 1 with ov_b) -- worked out only by a lane that goes that way (round 6: the
+    // bump loops ran, under an empty exec mask as a rule, on every visit of the cold block)
     int generic, start, drop, wide, resume;
+    int bump_a, ov_a, ov_b;
 };
 struct ColdOut { PassOut r; int final_sp; int fin; };
 // inline: 370 ms out of line (the by-value state goes through scratch) vs 209 inline (round 1)
@@ -179,7 +175,14 @@ ColdOut encode_frame_cold(ColdState st, PassOut r, int final_sp, int fin)
     if (__any((st.generic | st.wide) != 0)) {      // (one test in front of both: the common visitor is a third trip)
     if (__any(st.generic != 0)) {                  // hostile input, and tones the first scale misjudges by 2^5 and more
         if (st.generic) {
-            r = resume_passes(x, st.c0, st.c1, st.start, final_sp);
+            // (the frame is made opaque here: hipcc otherwise hoists the literal pass's set-up -- fourteen shifts, 64-bit
+            // mads -- out of this branch into every visit of the cold block)
+            int xg[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) { xg[i] = x[i]; VGA_COLD_OPAQUE(xg[i]); }
+            const int start = st.start != -100 ? st.start
+                                               : (st.bump_a ? apply_bumps(st.s1, st.ov_a) : apply_bumps(st.s1 + 1, st.ov_b));
+            r = resume_passes(xg, st.c0, st.c1, start, final_sp);
             fin = 1;
         }
     }
@@ -213,7 +216,10 @@ ColdOut encode_frame_cold(ColdState st, PassOut r, int final_sp, int fin)
                 if (!short_pass) r = pass_fast_core(x, m, mp, st.c0, st.c1, sp);
                 const bool cap = sp >= 12;
                 if ((unsigned)r.max_overflow > (cap ? 3u : 248u)) {      // bump loop / inexact sum: generic
-                    r = resume_passes(x, st.c0, st.c1, sp - 1, final_sp);
+                    int xg[16];                                          // (opaque: see above)
+#pragma unroll
+                    for (int i = 0; i < 16; i++) { xg[i] = x[i]; VGA_COLD_OPAQUE(xg[i]); }
+                    r = resume_passes(xg, st.c0, st.c1, sp - 1, final_sp);
                     break;
                 }
                 final_sp = sp;
@@ -560,6 +566,7 @@ __device__ __forceinline__ void gc_encode_piece(
             const bool redo = __any(rare);             // (this layout: every pair's A lane walks the whole loop again, B lanes are out)
             st.generic = redo && !cand_b; st.start = s1 - 1; st.drop = redo && cand_b;
             st.wide = !redo && inexact; st.resume = !redo && resume;
+            st.bump_a = 0; st.ov_a = 0; st.ov_b = 0;
             const ColdOut o = encode_frame_cold(st, r, final_sp, fin);
             bool sat2 = false;
             int winner = argmin32(o.r, o.fin != 0, sat2);
@@ -627,6 +634,9 @@ __device__ __forceinline__ void gc_encode_piece(
 #else
         const bool resume = !generic && !fin_a && eff_b >= 2;      // both overflowed: on to s1 + 2 in the cold block
 #endif
+        // (Round 6, measured and taken out again: the winning lanes storing the right pass's nibbles under their own masks
+        // instead of fourteen selects in every lane -- 18 VALU instructions a frame less, two more exec-masked branches on
+        // the wave's critical path: 148.5 ms against 146.0, profiles/r06_e_encode_variants.log.)
         PassOut r;
 #pragma unroll
         for (int i = 0; i < 14; i++) r.q[i] = fin_a ? ra.q[i] : rb.q[i];
@@ -697,8 +707,13 @@ __device__ __forceinline__ void gc_encode_piece(
             st.c0 = c0; st.c1 = c1; st.s1 = s1;
             st.generic = generic; st.drop = 0; st.wide = inexact; st.resume = resume;
             // where the reference's loop stands (the value of scalePower before its next ++): at its start for hostile
-            // coefficients; behind the bumps of the pass that started them otherwise
+            // coefficients; behind the bumps of the pass that started them otherwise (encode_frame_cold works that out)
+#ifdef VGA_GC_R05_COLD                                                // (timing only: the cold block's entry as it was in round 5)
             st.start = !coef_ok ? s1 - 1 : (bump_a ? apply_bumps(s1, ra.max_overflow) : apply_bumps(s1 + 1, rb.max_overflow));
+#else
+            st.start = !coef_ok ? s1 - 1 : -100;
+#endif
+            st.bump_a = bump_a; st.ov_a = ra.max_overflow; st.ov_b = rb.max_overflow;
             const ColdOut o = encode_frame_cold(st, r, final_sp, (generic || resume) ? 0 : 1);
             bool sat2 = false;
             int winner = argmin32(o.r, o.fin != 0, sat2);
