@@ -111,3 +111,24 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "pyoracle" not in src and "liboracle" not in src and "oracle/" not in src, f
+
+
+def test_hca_stream_encode_mirror_rejects_short_arguments_before_the_library_sees_them():
+    """CriHcaEncoder.Encode (vgaudio_amd/crihca.py): the C side reads ChannelCount row pointers and writes FrameSize bytes;
+    the reference would throw IndexOutOfRange -- the mirror raises ArgumentError, on a box without a GPU too (the checks
+    come before the stream is opened)."""
+    import numpy as np
+    from vgaudio_amd import _lib
+    from vgaudio_amd.crihca import CriHcaEncoder, CriHcaParameters
+    p = CriHcaParameters()
+    p.ChannelCount, p.SampleRate, p.SampleCount = 2, 48000, 4096
+    enc = CriHcaEncoder.InitializeNew(p)
+    block = [np.zeros(1024, dtype=np.int16) for _ in range(2)]
+    good = np.zeros(enc.FrameSize, dtype=np.uint8)
+    for pcm, out in ((block[:1], good),                                             # a row short
+                     (block, np.zeros(enc.FrameSize - 1, dtype=np.uint8)),           # a byte short
+                     (block, np.zeros(enc.FrameSize, dtype=np.int16)),               # wrong element type
+                     (block, np.zeros(2 * enc.FrameSize, dtype=np.uint8)[::2]),      # not contiguous
+                     ([block[0], block[1][:1000]], good)):                            # a short row
+        with pytest.raises(_lib.ArgumentError):
+            enc.Encode(pcm, out)

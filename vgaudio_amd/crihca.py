@@ -104,10 +104,17 @@ class CriHcaEncoder:
     def Encode(self, pcm, hcaOut):
         """pcm: [ChannelCount][1024] (or longer rows); hcaOut: a writable uint8 array of FrameSize bytes.  Returns the number
         of frames output: the first in hcaOut, the others through GetPendingFrame."""
-        st = self._open()
         rows = [np.ascontiguousarray(np.asarray(r, dtype=np.int16)[:1024]) for r in pcm]
+        # the library reads ChannelCount row pointers and writes FrameSize bytes: what the reference would answer with an
+        # IndexOutOfRangeException must not become an out-of-bounds access behind the C ABI
+        if len(rows) != self.Hca.ChannelCount:
+            raise _lib.ArgumentError("Encode takes [ChannelCount][1024] samples: %d rows for %d channels" % (len(rows), self.Hca.ChannelCount))
         if any(len(r) < 1024 for r in rows):
             raise _lib.ArgumentError("Encode takes [ChannelCount][1024] samples")
+        if not (isinstance(hcaOut, np.ndarray) and hcaOut.dtype == np.uint8 and hcaOut.ndim == 1 and hcaOut.flags.c_contiguous
+                and hcaOut.flags.writeable and hcaOut.size >= self.FrameSize):
+            raise _lib.ArgumentError("hcaOut must be a writable, contiguous uint8 array of at least FrameSize (%d) bytes" % self.FrameSize)
+        st = self._open()
         ptrs = (_lib.i16p * len(rows))(*[r.ctypes.data_as(_lib.i16p) for r in rows])
         n = C.c_int(0)
         check(_lib.lib().vga_hca_stream_encode(st, ptrs, hcaOut.ctypes.data_as(_lib.u8p), C.byref(n)))

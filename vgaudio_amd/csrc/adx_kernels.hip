@@ -1188,7 +1188,8 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
             VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
             VGA_HIP_TRY(hipMemsetAsync(seam_open, 0, flag_bytes + 16, stream));
             const int many = (int)std::min<int64_t>(0x7fffffff, std::max<int64_t>(8, (int64_t)nch * (segments - 1) / 64));   // (gc_decode_kernel.hip)
-            VGA_HIP_TRY(hipMemcpyAsync(slow_seams + 1, &many, sizeof(int), hipMemcpyHostToDevice, stream));
+            // (a fill, not a copy from this stack frame: a pageable host-to-device copy makes the call wait for the stream)
+            VGA_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(slow_seams + 1), many, 1, stream));
         }
 #define VGA_ADX_DEC_T(V)                                                                                                 \
         {                                                                                                                \

@@ -324,6 +324,18 @@ int vga_hca_stream_encode(vga_hca_stream *st, const int16_t *const *pcm, uint8_t
         VGA_HIP_TRY(hipStreamSynchronize(st->s));
     }
     // ---- the reference's counters through this call (Encode :126-156 and what it calls): how many frames does it complete?
+    // They are walked on the object and put back if the frames they promise cannot be delivered (launch, copy or status
+    // failure): a caller that retries then gets the same frames instead of skipping them.
+    const int saved_pre = st->buffer_pre, saved_pos = st->buffer_pos, saved_samples = st->samples_processed,
+              saved_frames = st->frames_processed;
+    auto roll_back = [&](int rc) {
+        st->buffer_pre = saved_pre;
+        st->buffer_pos = saved_pos;
+        st->samples_processed = saved_samples;
+        st->frames_processed = saved_frames;
+        *frames_output = 0;
+        return rc;
+    };
     const int first = st->frames_processed;
     auto flush = [&]() {                                                                    // OutputFrame :256-269
         if (st->buffer_pos != hca::SPF) return;
@@ -365,19 +377,27 @@ int vga_hca_stream_encode(vga_hca_stream *st, const int16_t *const *pcm, uint8_t
     *frames_output = count;
     if (count == 0) return VGA_OK;
     const uint16_t *pow = nullptr;
-    if (int rc = crc_pow_table(&pow)) return rc;
+    if (int rc = crc_pow_table(&pow)) return roll_back(rc);
     const int64_t ch_pitch = (int64_t)st->chunks * hca::SPF;
     const int64_t frames_pitch = round_up((int64_t)h.frame_count * h.frame_size + 8, 16);
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e == hipSuccess) return true;
+        set_error("%s failed: %s", what, hipGetErrorString(e));
+        return false;
+    };
+    // the status word is this call's: an error of an earlier call was reported by that call
+    if (!hip_ok(hipMemsetAsync(st->d_status.p, 0, sizeof(int), st->s), "hipMemsetAsync")) return roll_back(VGA_ERR_DEVICE);
     if (int rc = hca::launch_encode(st->d_pcm.as<int16_t>(), ch_pitch * st->nch, ch_pitch, 1, st->map, st->dev, st->d_frames.as<uint8_t>(),
                                     frames_pitch, pow, st->d_status.as<int>(), st->s, first, count))
-        return rc;
+        return roll_back(rc);
     st->host_frames.resize((size_t)count * h.frame_size);
     int status = 0;
-    VGA_HIP_TRY(hipMemcpyAsync(st->host_frames.data(), st->d_frames.as<uint8_t>() + (size_t)first * h.frame_size, st->host_frames.size(),
-                               hipMemcpyDeviceToHost, st->s));
-    VGA_HIP_TRY(hipMemcpyAsync(&status, st->d_status.p, sizeof(int), hipMemcpyDeviceToHost, st->s));
-    VGA_HIP_TRY(hipStreamSynchronize(st->s));
-    if (int rc = status_to_error(status)) return rc;
+    if (!hip_ok(hipMemcpyAsync(st->host_frames.data(), st->d_frames.as<uint8_t>() + (size_t)first * h.frame_size, st->host_frames.size(),
+                               hipMemcpyDeviceToHost, st->s), "hipMemcpyAsync") ||
+        !hip_ok(hipMemcpyAsync(&status, st->d_status.p, sizeof(int), hipMemcpyDeviceToHost, st->s), "hipMemcpyAsync") ||
+        !hip_ok(hipStreamSynchronize(st->s), "hipStreamSynchronize"))
+        return roll_back(VGA_ERR_DEVICE);
+    if (int rc = status_to_error(status)) return roll_back(rc);
     std::memcpy(hca_out, st->host_frames.data(), (size_t)h.frame_size);
     for (int k = 1; k < count; k++)
         st->pending.emplace_back(st->host_frames.begin() + (size_t)k * h.frame_size, st->host_frames.begin() + (size_t)(k + 1) * h.frame_size);

@@ -479,7 +479,8 @@ int launch_decode(const uint8_t *d_adpcm, int64_t adpcm_pitch, const int16_t *d_
         // runs meet again after a while; a batch of tones has every seam open)
         const int many = std::max<int64_t>(8, (int64_t)nch * (segments - 1) / 64) > 0x7fffffff ? 0x7fffffff
                        : (int)std::max<int64_t>(8, (int64_t)nch * (segments - 1) / 64);
-        VGA_HIP_TRY(hipMemcpyAsync(slow_seams + 1, &many, sizeof(int), hipMemcpyHostToDevice, stream));
+        // (a fill, not a copy from this stack frame: a pageable host-to-device copy makes the call wait for the stream)
+        VGA_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(slow_seams + 1), many, 1, stream));
         hipLaunchKernelGGL(gc_decode_fixup_kernel, dim3((nch + 63) / 64, segments - 1), dim3(64), 0, stream, d_adpcm, adpcm_pitch,
                            d_coefs, nch, sample_count, seg_frames, d_pcm, pcm_pitch, first_open, seam_open, force_open_seams(), rg, slow_seams);
         VGA_HIP_TRY(hipGetLastError());

@@ -162,12 +162,15 @@ def describe_job(device):
             bus = "%04x:%02x:%02x" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
         mine.update({"name": props.name, "pci_bus_id": bus, "compute_units": props.multi_processor_count,
                      "memory_GiB": round(props.total_memory / 2 ** 30, 1)})
-    text = repr(mine).encode()[:255]
-    buf = torch.zeros(256, dtype=torch.uint8)
+    # 1022 bytes of text + a two-byte length: a long host name next to a long device name still parses on the other side
+    SLOT = 1024
+    text = repr(mine).encode()[:SLOT - 2]
+    buf = torch.zeros(SLOT, dtype=torch.uint8)
     buf[:len(text)] = torch.frombuffer(bytearray(text), dtype=torch.uint8)
-    buf[255] = len(text)
+    buf[SLOT - 2] = len(text) & 0xFF
+    buf[SLOT - 1] = len(text) >> 8
     on = dev if backend == "nccl" else torch.device("cpu")
-    parts = [torch.zeros(256, dtype=torch.uint8, device=on) for _ in range(world)]
+    parts = [torch.zeros(SLOT, dtype=torch.uint8, device=on) for _ in range(world)]
     if world > 1:
         dist.all_gather(parts, buf.to(on))
     else:
@@ -176,7 +179,7 @@ def describe_job(device):
     ranks = []
     for t in parts:
         t = t.cpu()
-        n = int(t[255])
+        n = int(t[SLOT - 2]) | (int(t[SLOT - 1]) << 8)
         try:
             ranks.append(ast.literal_eval(bytes(t[:n].tolist()).decode()))
         except (ValueError, SyntaxError):
@@ -187,7 +190,7 @@ def describe_job(device):
             version = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:  # noqa: BLE001 -- a missing version string must not cost the result line
             version = "unknown"
-    buses = [r.get("pci_bus_id") for r in ranks if r.get("pci_bus_id")]
+    buses = [(r.get("host"), r.get("pci_bus_id")) for r in ranks if r.get("pci_bus_id")]     # the same bus id on two hosts is two GPUs
     return {"backend": backend, "rccl_version": version, "world_size_reported_by_backend": world,
             "world_size_env": int(os.environ.get("WORLD_SIZE", "1")), "ranks": ranks,
             "distinct_devices": len(set((r.get("host"), r.get("pci_bus_id") or r.get("device")) for r in ranks)),
