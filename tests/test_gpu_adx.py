@@ -13,7 +13,11 @@ pytestmark = pytest.mark.gpu
 CASES = [dict(Type=3), dict(Type=4), dict(Type=2, Filter=0), dict(Type=2, Filter=1), dict(Type=2, Filter=2),
          dict(Type=2, Filter=3), dict(Type=3, Version=3), dict(Type=4, Version=3), dict(Type=3, FrameSize=34),
          dict(Type=3, Padding=70), dict(Type=4, Padding=33), dict(Type=2, Filter=2, Padding=64),
-         dict(Type=3, SampleRate=22050)]
+         dict(Type=3, SampleRate=22050),
+         # padded (looping) streams through the time-piece kernels (round 6): a padding inside the first frame, of exactly
+         # one frame, reaching into the second, a multiple of the load width and not
+         dict(Type=3, Padding=1), dict(Type=3, Padding=8), dict(Type=3, Padding=31), dict(Type=4, Version=3, Padding=32),
+         dict(Type=3, Version=3, Padding=24), dict(Type=2, Filter=1, Padding=63)]
 
 
 def _op(kw):
@@ -125,10 +129,11 @@ def test_encoder_pieces_and_seams_on_random_shapes():
     st = torch.cuda.current_stream().cuda_stream
     rng = np.random.default_rng(20260927)
     cases = []
-    for _ in range(14):
+    for _ in range(22):
         cases.append((int(rng.integers(1, 200)), 32 * int(rng.integers(130, 900)) + int(rng.choice([0, 0, 1, 13, 31])),
                       int(rng.choice([2, 3, 5, 8, 13, 1000])), int(rng.choice([0, 0, 1, 2])),
-                      [dict(Type=3), dict(Type=4), dict(Type=3, Version=3), dict(Type=2, Filter=2), dict(Type=4, Version=3)][int(rng.integers(0, 5))]))
+                      [dict(Type=3), dict(Type=4), dict(Type=3, Version=3), dict(Type=2, Filter=2), dict(Type=4, Version=3),
+                       dict(Type=3, Padding=24), dict(Type=4, Padding=57), dict(Type=3, Version=3, Padding=33)][int(rng.integers(0, 8))]))
     for nch, n, pieces, mode, kw in cases:
         host = np.stack([synth.generate(1, n, first_channel=int(rng.integers(0, 4096)))[0] for _ in range(min(nch, 6))])
         host = np.concatenate([host, rng.integers(-32768, 32768, (nch - len(host), n)).astype(np.int16)]) if nch > len(host) else host
@@ -137,7 +142,7 @@ def test_encoder_pieces_and_seams_on_random_shapes():
         cfg = CriAdxParameters(**kw)
         p = _lib.AdxParams()
         L.vga_adx_default_params(C.byref(p))
-        p.type, p.version, p.filter = cfg.Type, cfg.Version, cfg.Filter
+        p.type, p.version, p.filter, p.padding = cfg.Type, cfg.Version, cfg.Filter, cfg.Padding
         nb = L.vga_adx_encoded_byte_count(n, C.byref(p))
         pitch = (nb + 15) // 16 * 16
         adx = torch.zeros((nch, pitch), dtype=torch.uint8, device=d)

@@ -690,12 +690,15 @@ __device__ __forceinline__ void adx_encode_frame_words(const uint32_t (&xw)[16],
 }
 
 // A frame with fewer than 32 samples left (zero padded, :86-91), or any frame a sample at a time
-__device__ __forceinline__ void adx_load_frame_slow(const int16_t *src, int64_t f, int total_length, uint32_t (&xw)[16])
+// (first: the stream's first real sample -- the positions before it are the reference's untouched, zero, buffer slots of a
+// padded stream, CriAdxCodec.cs:78-91, and `src` must not be read there)
+__device__ __forceinline__ void adx_load_frame_slow(const int16_t *src, int64_t f, int total_length, uint32_t (&xw)[16], int first = 0)
 {
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const int64_t i0 = f * 32 + 2 * j;
-        const uint32_t lo = i0 < total_length ? (uint16_t)src[i0] : 0u, hi = i0 + 1 < total_length ? (uint16_t)src[i0 + 1] : 0u;
+        const uint32_t lo = (i0 >= first && i0 < total_length) ? (uint16_t)src[i0] : 0u;
+        const uint32_t hi = (i0 + 1 >= first && i0 + 1 < total_length) ? (uint16_t)src[i0 + 1] : 0u;
         xw[j] = lo | (hi << 16);
     }
 }
@@ -713,7 +716,19 @@ __device__ __forceinline__ void adx_load_frame_slow(const int16_t *src, int64_t 
 // tiles in LDS, hence two encoder waves per CU -- took 19.7 ms, 17.5 ms with this file's arithmetic.
 // Crumbs: 8 bytes per frame and channel in a scratch array [frame][channel] -- what a seam run needs to know about the
 // guessed run it replaces (see adx_encode_fs18_fixup_kernel).
+// Round 6: PADDED streams (CriAdxFormat.cs:59-62: every looping file whose loop start is not a multiple of the alignment gets
+// Padding = alignmentSamples, up to 63 zero samples in front) take these kernels too.  They work in STREAM positions: `pcm`
+// arrives moved back by the padding (launch_encode), total_length counts the padding, and a position below p.padding is
+// never read: the frames of piece 0 that reach into the padding are loaded a sample at a time -- those lying wholly inside
+// it are skipped, their bytes zero (:84-86) -- and nothing else comes near it.  A frame of a padded stream starts at any
+// 2-byte boundary, hence the 2-byte alignment of the 16-byte loads (the same global_load_dwordx4 either way).
 typedef uint32_t adx_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t adx_u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+__device__ __forceinline__ uint4 adx_load16(const int16_t *q)
+{
+    const adx_u32x4_a2 v = *reinterpret_cast<const adx_u32x4_a2 *>(q);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 template <bool V4, bool EXPONENTIAL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void adx_encode_fs18_direct_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, AdxDeviceParams p,
@@ -734,7 +749,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         b = src[f0 * 32 - 1];
     } else {
         int hist = p.history;
-        if (V4 && total_length > 0) { a = b = src[0]; hist = a; }                      // :69-74
+        if (V4 && total_length > 0 && p.padding == 0) { a = b = src[0]; hist = a; }    // :69-74
         if (history_out) history_out[ch] = (int16_t)hist;
     }
     const int64_t frames = ((int64_t)total_length + 31) / 32, full_frames = total_length / 32;
@@ -744,9 +759,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     auto fetch2 = [&](int64_t f, uint4 (&px)[8]) {     // unconditional, clamped to the last full frames
         const int64_t fc = f + 1 < full_frames ? f : (full_frames >= 2 ? full_frames - 2 : 0);
         if (full_frames >= 2) {
-            const uint4 *q = reinterpret_cast<const uint4 *>(src + fc * 32);
 #pragma unroll
-            for (int i = 0; i < 8; i++) px[i] = q[i];
+            for (int i = 0; i < 8; i++) px[i] = adx_load16(src + fc * 32 + 8 * i);
         } else {
 #pragma unroll
             for (int i = 0; i < 8; i++) px[i] = make_uint4(0, 0, 0, 0);
@@ -777,8 +791,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // Eight frames at a time: their 144 bytes leave as nine 16-byte stores (whole lines for the L2 to write back, where 36
     // bytes per pair of frames left partial ones: 17.0 GB written for 9.6)
     const int64_t fe8 = fe < full_frames ? fe : full_frames;                           // groups of eight need full frames
+    auto encode_slow = [&](int64_t f) {                 // a frame loaded a sample at a time (zero outside the stream's samples)
+        uint32_t xw[16], hdr, nib[4];
+        adx_load_frame_slow(src, f, total_length, xw, p.padding);
+        encode_x(f, xw, hdr, nib);
+        uint16_t *d = reinterpret_cast<uint16_t *>(dst + f * 18);
+        d[0] = (uint16_t)hdr;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            d[1 + 2 * i] = (uint16_t)(nib[i] & 0xFFFFu);
+            d[2 + 2 * i] = (uint16_t)(nib[i] >> 16);
+        }
+    };
     uint4 cur[8], nxt[8];
     int64_t f = f0;
+    if (k == 0 && p.padding > 0) {
+        // the head of a padded stream: frames up to the first even one that lies wholly behind the padding
+        int64_t fh = ((int64_t)p.padding + 31) / 32;
+        fh += fh & 1;
+        for (; f < fh && f < fe; f++) {
+            const int64_t end = (f + 1) * 32 < total_length ? (f + 1) * 32 : total_length;
+            if (end <= p.padding) {                     // wholly inside the padding: skipped, its bytes stay zero (:84-86)
+                uint16_t *d = reinterpret_cast<uint16_t *>(dst + f * 18);
+#pragma unroll
+                for (int i = 0; i < 9; i++) d[i] = 0;
+            } else
+                encode_slow(f);
+        }
+    }
     if (f + 8 <= fe8) fetch2(f, cur);
     for (; f + 8 <= fe8; f += 8) {
         uint32_t w[36];
@@ -822,18 +862,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
 #endif
     }
-    for (; f < fe; f++) {                               // what is left of the piece, the zero-padded last frame included
-        uint32_t xw[16], hdr, nib[4];
-        adx_load_frame_slow(src, f, total_length, xw);
-        encode_x(f, xw, hdr, nib);
-        uint16_t *d = reinterpret_cast<uint16_t *>(dst + f * 18);
-        d[0] = (uint16_t)hdr;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            d[1 + 2 * i] = (uint16_t)(nib[i] & 0xFFFFu);
-            d[2 + 2 * i] = (uint16_t)(nib[i] >> 16);
-        }
-    }
+    for (; f < fe; f++) encode_slow(f);                 // what is left of the piece, the zero-padded last frame included
     if (seg_state) {
         int16_t *st = seg_state + ((int64_t)k * nch + ch) * 2;
         st[0] = (int16_t)a;
@@ -855,9 +884,8 @@ __device__ __forceinline__ bool adx_encode_seam_run(const int16_t *__restrict__ 
     const int64_t full_frames = total_length / 32;     // frames with all 32 samples (>= 64 here: pieces are that long at least)
     auto fetch = [&](int64_t f, uint4 (&px)[4], uint32_t (&fw)[9]) {
         const int64_t fc = f < full_frames ? f : full_frames - 1;
-        const uint4 *p = reinterpret_cast<const uint4 *>(src + fc * 32);
 #pragma unroll
-        for (int i = 0; i < 4; i++) px[i] = p[i];
+        for (int i = 0; i < 4; i++) px[i] = adx_load16(src + fc * 32 + 8 * i);
         const uint16_t *q = reinterpret_cast<const uint16_t *>(dst + fc * 18);
 #pragma unroll
         for (int i = 0; i < 9; i++) fw[i] = q[i];
@@ -979,9 +1007,8 @@ __global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
         if (active) {                                   // the frame after this one (a new seam: its first), clamped
             const int64_t fl = have ? f + 1 : f;
             const int64_t fc = fl < full_frames ? fl : full_frames - 1;
-            const uint4 *q = reinterpret_cast<const uint4 *>(src + fc * 32);
 #pragma unroll
-            for (int i = 0; i < 4; i++) nxt[i] = q[i];
+            for (int i = 0; i < 4; i++) nxt[i] = adx_load16(src + fc * 32 + 8 * i);
             ncr = crumbs[fc * nch + ch];
         }
         if (active && have) {
@@ -1082,10 +1109,14 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
     const dim3 grid((nch + 63) / 64), block(64);
     // pcm rows must be 16-byte aligned for the vector loads, output rows 4-byte aligned for the dword stores
     // (and coefficients of the size the reference can produce: adx_quantise_step's 32-bit bound)
-    const bool fast = p.frame_size == 18 && p.padding == 0 && (pcm_pitch % 8) == 0 && ((uintptr_t)d_pcm % 16) == 0 &&
+    // (padding: at most two frames of it -- CriAdxFormat.cs:59-62 never asks for more than 63 samples; the kernels see the
+    // stream, i.e. the rows moved back by the padding and a length that counts it)
+    const bool fast = p.frame_size == 18 && p.padding >= 0 && p.padding <= 64 && (pcm_pitch % 8) == 0 && ((uintptr_t)d_pcm % 16) == 0 &&
                       (out_pitch % 4) == 0 && ((uintptr_t)d_out % 4) == 0 && std::abs((int)p.coef0) <= 16384 &&
                       std::abs((int)p.coef1) <= 16384;
     if (fast) {
+        d_pcm -= p.padding;                            // from here on d_pcm / pcm_length are the STREAM's
+        pcm_length += p.padding;
         const bool v4 = p.version == 4, ex = p.type == 4;
         // as many time segments as put ADX_DIRECT_WAVES_PER_SIMD waves on every SIMD, each an even number of frames and at
         // least ADX_DIRECT_MIN_PIECE_FRAMES long

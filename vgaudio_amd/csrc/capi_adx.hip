@@ -347,7 +347,7 @@ int adx_encode_batch_v_one(const int16_t *const *pcm, const int *lengths, int nc
     DevBuf d_pcm, d_out, d_hist, d_own;
     // every channel's own frame count, in the plan's order: the seams in a channel's padding are left alone (adx_kernels.hpp)
     std::vector<int> own(nch);
-    for (int i = 0; i < nch; i++) own[i] = divide_by_round_up(lengths[plan.order[i]], 32);
+    for (int i = 0; i < nch; i++) own[i] = divide_by_round_up(lengths[plan.order[i]] + params[plan.order[i]].padding, 32);   // (frames of the padded stream)
     VGA_HIP_TRY(d_own.alloc((size_t)nch * sizeof(int)));
     VGA_HIP_TRY(hipMemcpy(d_own.p, own.data(), (size_t)nch * sizeof(int), hipMemcpyHostToDevice));
     VGA_HIP_TRY(d_pcm.alloc((size_t)pcm_base[chunks] * 2 + 64));
