@@ -160,3 +160,59 @@ def test_encoder_pieces_and_seams_on_random_shapes():
         got = adx[:, :nb].cpu().numpy()
         assert np.array_equal(got, want), (nch, n, pieces, mode, kw, int(np.argmax((got != want).any(axis=1))))
         assert np.array_equal(hist.cpu().numpy(), whist), (nch, n, pieces, mode, kw)
+
+
+def test_padded_streams_decode_in_pieces():
+    """Padded (looping) streams through the time-piece decoder (round 6): random bitstreams, paddings inside the first frame /
+    of one frame / reaching into the second, lengths whose last samples the reference leaves zero (it reads
+    ceil(sampleCount / 32) frames from the one the padding ends in, CriAdxCodec.cs:18-34), piece counts from the hook,
+    seams forced open in none / all / a pattern of the places."""
+    import ctypes as C
+
+    import torch
+
+    from vgaudio_amd import _lib
+    L = _lib.lib()
+    d = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(20261001)
+    for case in range(16):
+        nch = int(rng.integers(1, 150))
+        n = 32 * int(rng.integers(40, 400)) + int(rng.choice([0, 0, 1, 13, 31]))
+        padding = int(rng.choice([1, 7, 8, 24, 31, 32, 33, 57, 63, 64]))
+        pieces = int(rng.choice([0, 2, 3, 5, 8]))
+        mode = int(rng.choice([0, 0, 1, 2]))
+        kw = [dict(Type=3), dict(Type=4), dict(Type=3, Version=3), dict(Type=2)][int(rng.integers(0, 4))]
+        p = _lib.AdxParams()
+        L.vga_adx_default_params(C.byref(p))
+        cfg = CriAdxParameters(Padding=padding, **kw)
+        p.type, p.version, p.padding = cfg.Type, cfg.Version, padding
+        nb = (padding // 32 + -(-n // 32)) * 18
+        data = rng.integers(0, 256, (nch, nb)).astype(np.uint8)
+        if cfg.Type == 4:
+            data[:, 0::18] = 0
+            data[:, 1::18] %= 13
+        elif cfg.Type == 2:
+            data[:, 0::18] = rng.integers(0, 4, data[:, 0::18].shape).astype(np.uint8) << 5
+        else:
+            data[:, 0::18] &= 0x1F
+        pitch = (nb + 15) // 16 * 16
+        adx = torch.zeros((nch, pitch), dtype=torch.uint8, device=d)
+        adx[:, :nb] = torch.from_numpy(data).to(d)
+        opitch = (n + 7) // 8 * 8
+        out = torch.full((nch, opitch), 0x5A5A, dtype=torch.int16, device=d)
+        status = torch.zeros(1, dtype=torch.int32, device=d)
+        L.vga_testing_gc_encoder_segments_this_thread(pieces)
+        old = L.vga_testing_force_open_seams_this_thread(mode)
+        try:
+            _lib.check(L.vga_adx_decode_device(adx.data_ptr(), pitch, nb, nch, n, C.byref(p), out.data_ptr(), opitch, status.data_ptr(), st))
+            torch.cuda.synchronize()
+        finally:
+            L.vga_testing_force_open_seams_this_thread(old)
+            L.vga_testing_gc_encoder_segments_this_thread(0)
+        got = out[:, :n].cpu().numpy()
+        okw = dict(kw)
+        okw["Padding"] = padding
+        for c in range(nch):
+            want = po.adx_decode(data[c], n, _op(okw))
+            assert np.array_equal(got[c], want), (case, nch, n, padding, pieces, mode, kw, c, int(np.argmax(got[c] != want)))

@@ -177,6 +177,16 @@ __global__ __launch_bounds__(64) void adx_encode_kernel(
     }
 }
 
+// 16 bytes to / from any 2-byte boundary (the rows of a padded stream, see adx_encode_fs18_direct_kernel): one
+// global_store_dwordx4 / global_load_dwordx4 either way, the type only tells hipcc not to assume more
+typedef int adx_i32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+__device__ __forceinline__ void adx_store16(int16_t *q, int4 v)
+{
+    adx_i32x4_a2 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    *reinterpret_cast<adx_i32x4_a2 *>(q) = t;
+}
+
 // Decode (CriAdxCodec.cs:9-54)
 __global__ __launch_bounds__(64) void adx_decode_kernel(
     const uint8_t *__restrict__ adpcm, int64_t in_pitch, int nch, int sample_count, AdxDeviceParams p,
@@ -303,8 +313,9 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_direct_kernel(
         return pcm + (int64_t)(c < nch ? c : nch - 1) * pcm_pitch + first_frame * 32 + (lane % LPR) * 8;
     };
     // one frame whose 18 bytes are w[0 .. 4] (little-endian dwords, two bytes of slack)
-    auto decode_frame = [&](const uint32_t (&w)[5], auto mode_tag, int frame, int valid) {
+    auto decode_frame = [&](const uint32_t (&w)[5], auto mode_tag, int frame, int valid, int skip = 0) {
         constexpr int MODE = decltype(mode_tag)::value;          // 0: whole frame, stored turned; 1: whole frame, stored by its lane; 2: partial; 3: not stored (warm-up)
+                                                                 // 4: samples [skip, valid) only: the frame in which a padded stream's samples begin
         const int hb0 = w[0] & 0xff, hb1 = (w[0] >> 8) & 0xff;
         int filter_num = ((hb0 >> 4) & 0xF) >> 1;
         int cf0, cf1;
@@ -335,8 +346,10 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_direct_kernel(
                 sample = (__mul24(hist1, cf0) >> 12) + rest;
             }
             const int fin = clamp16(sample);
-            hist2 = hist1;                             // a partial last frame runs on: nothing reads the history after it
-            hist1 = fin;
+            if (MODE != 4 || s >= skip) {              // (a padded stream's first samples are not decoded at all, :21-33)
+                hist2 = hist1;                         // a partial last frame runs on: nothing reads the history after it
+                hist1 = fin;
+            }
             o[s] = fin;
         }
         if (MODE == 0) {
@@ -349,8 +362,8 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_direct_kernel(
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int i = 0; i < LPR; i++)            // read, wait, store -- one at a time: LPR stores back to back were
-                    *reinterpret_cast<int4 *>(turned_row(i) + (int64_t)(frame - (TURN - 1)) * 32) =       // 5 ms slower
-                        s_turn[(lane / LPR + RPI * i) * (LPR + 1) + lane % LPR];
+                    adx_store16(turned_row(i) + (int64_t)(frame - (TURN - 1)) * 32,                       // 5 ms slower
+                                s_turn[(lane / LPR + RPI * i) * (LPR + 1) + lane % LPR]);
                 asm volatile("" ::: "memory");
             }
         } else if (MODE == 1) {
@@ -358,17 +371,49 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_direct_kernel(
                 int16_t *d = dst + (int64_t)frame * 32;
 #pragma unroll
                 for (int q = 0; q < 4; q++)
-                    reinterpret_cast<int4 *>(d)[q] =
-                        make_int4((o[8 * q] & 0xFFFF) | (o[8 * q + 1] << 16), (o[8 * q + 2] & 0xFFFF) | (o[8 * q + 3] << 16),
-                                  (o[8 * q + 4] & 0xFFFF) | (o[8 * q + 5] << 16), (o[8 * q + 6] & 0xFFFF) | (o[8 * q + 7] << 16));
+                    adx_store16(d + 8 * q,
+                                make_int4((o[8 * q] & 0xFFFF) | (o[8 * q + 1] << 16), (o[8 * q + 2] & 0xFFFF) | (o[8 * q + 3] << 16),
+                                          (o[8 * q + 4] & 0xFFFF) | (o[8 * q + 5] << 16), (o[8 * q + 6] & 0xFFFF) | (o[8 * q + 7] << 16)));
             }
-        } else if (MODE == 2 && live) {
+        } else if ((MODE == 2 || MODE == 4) && live) {
             int16_t *d = dst + (int64_t)frame * 32;
 #pragma unroll
             for (int s2 = 0; s2 < 32; s2++)
-                if (s2 < valid) d[s2] = (int16_t)o[s2];
+                if (s2 >= skip && s2 < valid) d[s2] = (int16_t)o[s2];
         }
     };
+    // one frame of the row by its index (it starts on a dword for even i, two bytes after one for odd i)
+    auto load_frame = [&](int i, uint32_t (&w)[5]) {
+        const uint32_t *f = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint16_t *>(src) + (int64_t)i * 9 - (i & 1));
+        uint32_t t[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) t[q] = f[q];
+        if (i & 1) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) w[q] = (t[q] >> 16) | (t[q + 1] << 16);
+            w[4] = t[4] >> 16;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 5; q++) w[q] = t[q];
+        }
+    };
+    // ---- Round 6: the head of a PADDED stream (launch_decode: `pcm` arrives moved back by the padding and total_samples counts
+    // it, as in the encoder): the frames before the one the padding ends in are not read at all, that frame is decoded from
+    // its nibble p.padding % 32 on, from the stream's start history (CriAdxCodec.cs:21-33); a frame at a time up to the first
+    // even frame behind it, where the pairs below take over.
+    int head_frames = 0;
+    if (!repair && blockIdx.y == 0 && p.padding > 0) {
+        const int fp = p.padding / 32;
+        head_frames = fp + 1 + ((fp + 1) & 1);
+        if (head_frames > frame_count) head_frames = frame_count;
+#pragma unroll 1
+        for (int i = fp; i < head_frames; i++) {
+            uint32_t w[5];
+            load_frame(i, w);
+            const int valid = min(32, sample_count - i * 32);
+            decode_frame(w, std::integral_constant<int, 4>{}, i, valid, i == fp ? p.padding % 32 : 0);
+        }
+    }
     // ---- warm-up of a later piece: the WARM frames before it are decoded from the guess (0, 0) and not stored, so that the
     // piece itself starts from a history that has, as a rule, already fallen into step with the true run (the decoder
     // forgets a wrong history within 2000 samples on audio): its seam then closes on the first frame the fix-up launch
@@ -391,9 +436,10 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_direct_kernel(
     // ---- whole pairs of full frames: 36 bytes from a dword boundary, the next pair's loads in flight meanwhile
     const int full_pairs = (sample_count / 32) / TURN * (TURN / 2);          // whole blocks of TURN full frames
     uint32_t cur[9], nxt[9];
+    const int first_pair = head_frames / 2;                                // (0 but for a padded stream's first piece)
     {
-        const uint32_t *f = src;                                           // pair 0 (or, with no pair at all, five dwords of
-        const int nq = full_pairs > 0 ? 9 : 5;                             // the row's first frame: unused)
+        const uint32_t *f = src + (int64_t)min(first_pair, max(full_pairs - 1, 0)) * 9;   // the first pair (or, with no pair at all,
+        const int nq = full_pairs > 0 ? 9 : 5;                             // five dwords of the row's first frame: unused)
 #pragma unroll
         for (int q = 0; q < 9; q++) cur[q] = q < nq ? f[q] : 0u;
         // the first pair is waited for HERE: left to the loop header, the wait would also sit on the back edge, where it
@@ -402,7 +448,7 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_direct_kernel(
         for (int q = 0; q < 9; q++) asm volatile("" : "+v"(cur[q]));
     }
 #pragma unroll 1
-    for (int k = 0; k < full_pairs; k++) {
+    for (int k = first_pair; k < full_pairs; k++) {
         const uint32_t *f = src + (int64_t)min(k + 1, full_pairs - 1) * 9;
 #pragma unroll
         for (int q = 0; q < 9; q++) nxt[q] = f[q];
@@ -417,20 +463,9 @@ __global__ __launch_bounds__(64) void adx_decode_fs18_direct_kernel(
     }
     // ---- what is left of the piece: fewer than TURN full frames and a partial one
 #pragma unroll 1
-    for (int i = 2 * full_pairs; i < frame_count; i++) {
-        // frame i starts at byte 18 i: on a dword for even i, two bytes after one for odd i
-        const uint32_t *f = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint16_t *>(src) + (int64_t)i * 9 - (i & 1));
-        uint32_t t[5], w[5];
-#pragma unroll
-        for (int q = 0; q < 5; q++) t[q] = f[q];
-        if (i & 1) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) w[q] = (t[q] >> 16) | (t[q + 1] << 16);
-            w[4] = t[4] >> 16;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 5; q++) w[q] = t[q];
-        }
+    for (int i = max(2 * full_pairs, head_frames); i < frame_count; i++) {
+        uint32_t w[5];
+        load_frame(i, w);
         const int valid = min(32, sample_count - i * 32);
         if (valid == 32) decode_frame(w, std::integral_constant<int, 1>{}, i, 32);
         else decode_frame(w, std::integral_constant<int, 2>{}, i, valid);
@@ -481,12 +516,12 @@ __device__ __forceinline__ void adx_decode_frame_serial(const uint8_t *fr, const
         }
         out[s2] = fin;
     }
-    if (valid == 32 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+    if (valid == 32) {                                  // (a padded stream's frames start at any 2-byte boundary: adx_store16)
 #pragma unroll
         for (int q = 0; q < 4; q++)
-            reinterpret_cast<int4 *>(o)[q] =
-                make_int4((out[8 * q] & 0xFFFF) | (out[8 * q + 1] << 16), (out[8 * q + 2] & 0xFFFF) | (out[8 * q + 3] << 16),
-                          (out[8 * q + 4] & 0xFFFF) | (out[8 * q + 5] << 16), (out[8 * q + 6] & 0xFFFF) | (out[8 * q + 7] << 16));
+            adx_store16(o + 8 * q,
+                        make_int4((out[8 * q] & 0xFFFF) | (out[8 * q + 1] << 16), (out[8 * q + 2] & 0xFFFF) | (out[8 * q + 3] << 16),
+                                  (out[8 * q + 4] & 0xFFFF) | (out[8 * q + 5] << 16), (out[8 * q + 6] & 0xFFFF) | (out[8 * q + 7] << 16)));
     } else {
         for (int s2 = 0; s2 < valid; s2++) o[s2] = (int16_t)out[s2];
     }
@@ -1188,9 +1223,22 @@ int launch_decode(const uint8_t *d_adpcm, int64_t in_pitch, int nch, int sample_
                   int16_t *d_pcm, int64_t pcm_pitch, int *d_status, hipStream_t stream, const int *d_own_samples)
 {
     if (nch <= 0 || sample_count <= 0) return VGA_OK;
-    const bool fast = p.frame_size == 18 && p.padding == 0 && (pcm_pitch % 8) == 0 && ((uintptr_t)d_pcm % 16) == 0 &&
-                      (in_pitch % 4) == 0 && ((uintptr_t)d_adpcm % 4) == 0;
+    // (padded streams: up to two frames of padding, equal-length batches, at least two frames of output)
+    const bool fast = p.frame_size == 18 && (p.padding == 0 || (p.padding > 0 && p.padding <= 64 && !d_own_samples && sample_count >= 64)) &&
+                      (pcm_pitch % 8) == 0 && ((uintptr_t)d_pcm % 16) == 0 && (in_pitch % 4) == 0 && ((uintptr_t)d_adpcm % 4) == 0;
     if (fast) {
+        if (p.padding > 0) {
+            // The reference reads ceil(sampleCount / 32) frames from the frame the padding ends in and takes 32 - padding % 32
+            // samples from the first of them (CriAdxCodec.cs:18-34): when that is not enough for sampleCount, the last samples
+            // stay zero.  In stream positions: samples [padding, padding + decoded) are decoded, `pcm` moves back by the padding.
+            const int out_count = sample_count;
+            const int decoded = std::min(out_count, (out_count + 31) / 32 * 32 - p.padding % 32);
+            if (decoded < out_count)
+                VGA_HIP_TRY(hipMemset2DAsync(d_pcm + decoded, (size_t)pcm_pitch * sizeof(int16_t), 0,
+                                             (size_t)(out_count - decoded) * sizeof(int16_t), (size_t)nch, stream));
+            d_pcm -= p.padding;
+            sample_count = decoded + p.padding;
+        }
         // as many time pieces as put ONE wave on every SIMD (a wave = 64 channels of one piece), each at least 512 frames long
         // and an even number of frames.  The kernel is bound by its stores, and what the memory system holds open is one
         // row position per (channel, piece): at configs[2] 8 / 16 / 32 / 64 pieces take 8.5 / 8.0 / 13.1 / 12.1 ms (and 12 or
