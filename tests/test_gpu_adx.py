@@ -131,7 +131,7 @@ def test_encoder_pieces_and_seams_on_random_shapes():
     cases = []
     for _ in range(22):
         cases.append((int(rng.integers(1, 200)), 32 * int(rng.integers(130, 900)) + int(rng.choice([0, 0, 1, 13, 31])),
-                      int(rng.choice([2, 3, 5, 8, 13, 1000])), int(rng.choice([0, 0, 1, 2])),
+                      int(rng.choice([2, 3, 5, 8, 13, 1000])), int(rng.choice([0, 0, 1, 2, 3])),
                       [dict(Type=3), dict(Type=4), dict(Type=3, Version=3), dict(Type=2, Filter=2), dict(Type=4, Version=3),
                        dict(Type=3, Padding=24), dict(Type=4, Padding=57), dict(Type=3, Version=3, Padding=33)][int(rng.integers(0, 8))]))
     for nch, n, pieces, mode, kw in cases:

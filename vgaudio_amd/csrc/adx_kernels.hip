@@ -764,22 +764,44 @@ __device__ __forceinline__ uint4 adx_load16(const int16_t *q)
     const adx_u32x4_a2 v = *reinterpret_cast<const adx_u32x4_a2 *>(q);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
-template <bool V4, bool EXPONENTIAL>
+// REPAIR (round 6, the decoders' scheme): a launch of ONE piece row after the fix-up.  When many seams of the batch stayed open
+// to the end of their pieces (a batch of tones or clipped waves: the run from the true history and the guessed one stay one
+// LSB apart for good, LABNOTES 8.7) the chained tail kernel would walk every such channel piece after piece with one lane
+// (254 ms for 60 s of a 440 Hz tone in every channel).  Here a wave that holds such a channel encodes its 64 channels again as
+// ONE piece, from the first piece any of them left open to the end of the stream, from seg_state of the piece before --
+// the true history for all 64 (every seam before that piece closed) -- at this kernel's own rate: the serial floor.
+template <bool V4, bool EXPONENTIAL, bool REPAIR = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void adx_encode_fs18_direct_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, AdxDeviceParams p,
     uint8_t *__restrict__ out, int64_t out_pitch, int16_t *__restrict__ history_out, int16_t *__restrict__ seg_state,
-    uint2 *__restrict__ crumbs)
+    uint2 *__restrict__ crumbs, const int *__restrict__ first_open, const int *__restrict__ open_seams, int many)
 {
-    const int ch = blockIdx.x * 64 + threadIdx.x;
-    const int k = blockIdx.y;
+    const int ch_raw = blockIdx.x * 64 + threadIdx.x;
+    int k = blockIdx.y;
+    if (REPAIR) {
+        if (open_seams[0] < many) return;              // few: adx_encode_fs18_tail_kernel has chained them
+        int ko = ch_raw < nch ? first_open[ch_raw] : 0x7f000000;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) ko = min(ko, __shfl_xor(ko, o));
+        if (ko <= 0 || ko >= 0x7f000000) return;       // no open seam among this wave's channels
+        k = ko;
+    }
+    const int ch = ch_raw;
     const int64_t f0 = (int64_t)k * seg_frames;
     if (ch >= nch || (k > 0 && f0 * 32 >= total_length)) return;
+    if (REPAIR) {
+        seg_frames = 0x7fffff00 / 32 - (int)f0;        // ... to the end of the stream
+        crumbs = nullptr;
+    }
     const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
     uint8_t *dst = out + (int64_t)ch * out_pitch;
     const int c0 = p.coef0, c1 = p.coef1;
     const int filter_bits = p.type == 2 ? ((p.filter << 5) & 0xff) : 0;
     int a = 0, b = 0;
-    if (k > 0) {                                       // the guess: the input just before this piece
+    if (REPAIR) {                                      // the true history at the start of piece k
+        a = seg_state[((int64_t)(k - 1) * nch + ch) * 2];
+        b = seg_state[((int64_t)(k - 1) * nch + ch) * 2 + 1];
+    } else if (k > 0) {                                // the guess: the input just before this piece
         a = src[f0 * 32 - 2];
         b = src[f0 * 32 - 1];
     } else {
@@ -840,7 +862,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     };
     uint4 cur[8], nxt[8];
     int64_t f = f0;
-    if (k == 0 && p.padding > 0) {
+    if (!REPAIR && k == 0 && p.padding > 0) {
         // the head of a padded stream: frames up to the first even one that lies wholly behind the padding
         int64_t fh = ((int64_t)p.padding + 31) / 32;
         fh += fh & 1;
@@ -898,7 +920,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #endif
     }
     for (; f < fe; f++) encode_slow(f);                 // what is left of the piece, the zero-padded last frame included
-    if (seg_state) {
+    if (seg_state && !REPAIR) {
         int16_t *st = seg_state + ((int64_t)k * nch + ch) * 2;
         st[0] = (int16_t)a;
         st[1] = (int16_t)b;
@@ -986,7 +1008,7 @@ __global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, int segments, AdxDeviceParams p,
     uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state, const uint2 *__restrict__ crumbs,
     int *__restrict__ first_open, int *__restrict__ seam_open, int *__restrict__ seam_end, int force_open, int *__restrict__ queue,
-    const int *__restrict__ own_frames)
+    const int *__restrict__ own_frames, int *__restrict__ open_seams)
 {
     const int lane = threadIdx.x;
     const int c0 = p.coef0, c1 = p.coef1;
@@ -1073,6 +1095,8 @@ __global__ __launch_bounds__(64) void adx_encode_fs18_fixup_kernel(
                 seam_open[(int64_t)(k - 1) * nch + ch] = 1;
                 seam_end[(int64_t)(k - 1) * nch + ch] = (int)(((unsigned)tb << 16) | ((unsigned)ta & 0xFFFFu));
                 atomicMin(&first_open[ch], k);
+                // (seams the test hook holds open count only in its REPAIR mode, 3: the chained tail has tests of its own)
+                if (!seam_forced_open(force_open, ch, k) || force_open == 3) atomicAdd(open_seams, 1);
                 active = false;
             }
         }
@@ -1095,10 +1119,12 @@ template <bool V4, bool EXPONENTIAL>
 __global__ __launch_bounds__(64) void adx_encode_fs18_tail_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_length, int seg_frames, int segments, AdxDeviceParams p,
     uint8_t *__restrict__ out, int64_t out_pitch, const int16_t *__restrict__ seg_state, const int *__restrict__ first_open,
-    const int *__restrict__ seam_open, const int *__restrict__ seam_end, int force_open, const int *__restrict__ own_frames)
+    const int *__restrict__ seam_open, const int *__restrict__ seam_end, int force_open, const int *__restrict__ own_frames,
+    const int *__restrict__ open_seams, int many)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= nch) return;
+    if (open_seams[0] >= many) return;                 // many seams that would not close: the REPAIR launch takes them all
     const int k0 = first_open[ch];
     if (k0 <= 0 || k0 >= 0x7f000000) return;
     const int64_t own_end = own_frames ? (int64_t)own_frames[ch] : ((int64_t)total_length + 31) / 32;   // (see the fix-up kernel)
@@ -1172,7 +1198,7 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
         if (segments > 1) {
             const size_t state_bytes = round_up((size_t)segments * nch * 2 * sizeof(int16_t), 16);
             const size_t flag_bytes = (size_t)(segments - 1) * nch * sizeof(int);
-            const size_t small_bytes = round_up(state_bytes + (size_t)nch * sizeof(int) + 2 * flag_bytes + 16, 16);   // (+ the fix-up's queue)
+            const size_t small_bytes = round_up(state_bytes + (size_t)nch * sizeof(int) + 2 * flag_bytes + 16, 16);   // (+ the fix-up's queue, the open seams' count)
             VGA_HIP_TRY(scratch.alloc(small_bytes + (size_t)frames * nch * sizeof(uint2), stream));
             seg_state = scratch.as<int16_t>();
             first_open = reinterpret_cast<int *>(scratch.as<unsigned char>() + state_bytes);
@@ -1182,8 +1208,12 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
             crumbs = reinterpret_cast<uint2 *>(scratch.as<unsigned char>() + small_bytes);
             VGA_HIP_TRY(hipMemsetAsync(first_open, 0x7f, (size_t)nch * sizeof(int), stream));
             VGA_HIP_TRY(hipMemsetAsync(seam_open, 0, flag_bytes, stream));
-            VGA_HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int), stream));
+            VGA_HIP_TRY(hipMemsetAsync(queue, 0, 2 * sizeof(int), stream));
         }
+        int *open_seams = queue ? queue + 1 : nullptr; // seams still open at the end of their pieces
+        // "many": one seam in 64, and at least 8 -- as the decoders' threshold (gc_decode_kernel.hip); test hook mode 3 = any
+        const int many = force_open_seams() == 3 ? 1
+                         : (int)std::min<int64_t>(0x7fffffff, std::max<int64_t>(8, (int64_t)nch * (segments - 1) / 64));
         // the fix-up's persistent waves: one per SIMD, fewer when there are not that many seams
         int fixup_waves = cus * 4 * ADX_FIXUP_WAVES_PER_SIMD;
 #ifdef VGA_TUNING   // tools/build_variants.sh only
@@ -1194,16 +1224,21 @@ int launch_encode(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int pcm_leng
 #define VGA_ADX_ENC_T(V, E)                                                                                              \
         {                                                                                                                \
             hipLaunchKernelGGL((adx_encode_fs18_direct_kernel<V, E>), dim3(groups64, segments), dim3(64), 0, stream, d_pcm, \
-                               pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, d_history_out, seg_state, crumbs); \
+                               pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, d_history_out, seg_state, crumbs, \
+                               (const int *)nullptr, (const int *)nullptr, 0);                                          \
             VGA_HIP_TRY(hipGetLastError());                                                                              \
             if (segments > 1) {                                                                                          \
                 hipLaunchKernelGGL((adx_encode_fs18_fixup_kernel<V, E>), dim3(fixup_waves), dim3(64), 0, stream,         \
                                    d_pcm, pcm_pitch, nch, pcm_length, seg_frames, segments, p, d_out, out_pitch, seg_state, crumbs, \
-                                   first_open, seam_open, seam_end, force_open_seams(), queue, d_own_frames);           \
+                                   first_open, seam_open, seam_end, force_open_seams(), queue, d_own_frames, open_seams); \
                 VGA_HIP_TRY(hipGetLastError());                                                                          \
                 hipLaunchKernelGGL((adx_encode_fs18_tail_kernel<V, E>), dim3(groups64), dim3(64), 0, stream, d_pcm,     \
                                    pcm_pitch, nch, pcm_length, seg_frames, segments, p, d_out, out_pitch, seg_state,    \
-                                   first_open, seam_open, seam_end, force_open_seams(), d_own_frames);                  \
+                                   first_open, seam_open, seam_end, force_open_seams(), d_own_frames, open_seams, many); \
+                VGA_HIP_TRY(hipGetLastError());                                                                          \
+                hipLaunchKernelGGL((adx_encode_fs18_direct_kernel<V, E, true>), dim3(groups64, 1), dim3(64), 0, stream, d_pcm, \
+                                   pcm_pitch, nch, pcm_length, seg_frames, p, d_out, out_pitch, (int16_t *)nullptr, seg_state, \
+                                   (uint2 *)nullptr, (const int *)first_open, (const int *)open_seams, many);           \
             }                                                                                                            \
         }
         if (v4 && ex) VGA_ADX_ENC_T(true, true)
