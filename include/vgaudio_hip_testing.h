@@ -74,6 +74,9 @@ void vga_testing_host_pipeline_tail_this_thread(int tail_units);
 int vga_testing_plan_buckets(const int *group, const int *length, int n, int max_units, long long max_volume, int longest_first,
                              int *order_out, int *chunk_begin_out, int *chunk_length_out, int *chunk_group_out, int max_chunks);
 void vga_testing_buckets_order_this_thread(int order);
+/* Page-locked rows of the host-pointer entry points: 0 (default) = moved by transfer kernels on compute units reserved for
+ * them (calls of 256 MB and more), 1 = one hipMemcpyAsync per row as until round 5 -- for calls made from the calling thread. */
+void vga_testing_host_transfer_this_thread(int mode);
 
 /* Where the wall time of the calling thread's last pipelined call went, in seconds (diagnostics for bench.py's e2e
  * block): [0] total [1] set-up [2] feeders' memcpy (sum over threads) [3] feeders waiting for a ring slot [4] feeders

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -86,7 +87,9 @@ inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= 4) return hipErrorInva
 inline hipError_t hipGetDevice(int *d) { *d = mock_current_device(); return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
-static const unsigned hipHostRegisterDefault = 0;
+static const unsigned hipHostRegisterDefault = 0, hipHostRegisterMapped = 2;
+// a page-locked row's device-visible address: the mock's "device" is the host
+inline hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned) { *dev = host; return hipSuccess; }
 inline int &mock_registered() { static int n = 0; return n; }
 // page-locked rows -> copies issued on them that have not completed yet.  Unregistering a row with a copy pending is the
 // bug the real runtime only hides by synchronising every stream inside hipHostUnregister: counted as a violation here.
@@ -115,6 +118,16 @@ inline hipError_t hipHostUnregister(void *p)
 }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new MockStream; return hipSuccess; }
+inline int &mock_masked_streams() { static int n = 0; return n; }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, uint32_t, const uint32_t *)
+{
+    {
+        std::lock_guard<std::mutex> g(mock_mutex());
+        mock_masked_streams()++;
+    }
+    *s = new MockStream;
+    return hipSuccess;
+}
 inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t s) { s->sync(); return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new MockEvent; return hipSuccess; }

@@ -12,6 +12,36 @@ using namespace vga::pipe;
 static int g_taper = 0, g_tail = 0, g_head = 0;
 static bool g_direct = false, g_direct_out = false, g_shared = false;
 static int g_lanes = 1;
+// round 6: direct transfers by a "kernel" (Job::transfer: a closure on the mock stream that copies the pieces) instead of one
+// copy per row, with and without CU masks; g_transfer_fails: the n-th transfer launch from now refuses
+static bool g_transfer = false;
+static int g_transfer_cus = 0;
+static std::atomic<int> g_transfer_launches{0}, g_transfer_pieces{0}, g_transfer_fails{-1};
+static void use_transfer(Job &job, int feeders)
+{
+    if (!g_transfer) return;
+    job.gather_in = true;
+    job.scatter_out = true;
+    job.piece_bytes = 4096;                                  // (the floor: rows of a few KB still come in several pieces)
+    job.transfer_cus = g_transfer_cus;
+    job.total_cus = 64;
+    if (job.direct) job.feeders = 1;                         // (the gather is the one feeder's; more feeders: plain copies)
+    (void)feeders;
+    job.transfer = [](const Job::TransferPiece *pieces, int n, hipStream_t s, std::string &why) -> int {
+        if (g_transfer_fails.load() == 0) {
+            g_transfer_fails = -1;
+            why = "transfer refused";
+            return -9;
+        }
+        if (g_transfer_fails.load() > 0) g_transfer_fails--;
+        g_transfer_launches++;
+        g_transfer_pieces += n;
+        mockLaunch(s, [pieces, n] {
+            for (int i = 0; i < n; i++) std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes);
+        });
+        return 0;
+    };
+}
 static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t out_bytes, int chunk, int feeders, int drainers,
                     size_t slot_bytes, int delay_us, int fail_after, bool compute_fails)
 {
@@ -49,6 +79,7 @@ static int run_case(int units, int in_rpu, int out_rpu, size_t in_bytes, size_t 
     job.direct_out = g_direct_out;
     job.shared_streams = g_shared;
     job.compute_lanes = g_lanes;
+    use_transfer(job, feeders);
     if (in_rows == 0) job.in_rows = nullptr;                 // a job with nothing to upload / nothing to download
     if (out_rows == 0) job.out_rows = nullptr;
     int launches = 0;
@@ -171,6 +202,7 @@ static int run_ragged_case(int units, int seed, int chunks_wanted, int feeders, 
     job.direct_out = g_direct_out;
     job.shared_streams = g_shared;
     job.compute_lanes = g_lanes;
+    use_transfer(job, feeders);
     // chunks by bytes: a boundary whenever a chunk holds its share of the input
     job.chunk_begin.push_back(0);
     size_t acc = 0;
@@ -286,6 +318,45 @@ int main()
         g_lanes = m[3];
         bad += all_cases();
     }
+    // the same shapes with the rows moved by transfer launches (direct modes only use them), CU masks on and off, and a
+    // transfer launch that refuses
+    g_transfer = true;
+    for (int cus : {0, 8}) {
+        g_transfer_cus = cus;
+        for (const auto &m : modes) {
+            g_direct = m[0];
+            g_direct_out = m[1];
+            g_shared = m[2];
+            g_lanes = m[3];
+            bad += all_cases();
+        }
+    }
+    if (g_transfer_launches.load() == 0 || g_transfer_pieces.load() <= g_transfer_launches.load()) { std::printf("no transfer launches\n"); bad++; }
+    if (mock_masked_streams() == 0) { std::printf("no CU-masked streams\n"); bad++; }
+    g_direct = g_direct_out = g_shared = true;
+    for (int nth : {0, 2}) {
+        g_transfer_fails = nth;
+        Job probe;                                           // (run_case reports "expected a failure" through fail_after / compute_fails only)
+        std::vector<std::vector<unsigned char>> in(12, std::vector<unsigned char>(9000, 7)), out(12, std::vector<unsigned char>(9000, 0));
+        std::vector<const void *> ip(12);
+        std::vector<void *> op(12);
+        for (int r = 0; r < 12; r++) { ip[r] = in[r].data(); op[r] = out[r].data(); }
+        std::vector<char> d_in(12 * 9008 + 64), d_out(12 * 9008 + 64);
+        probe.units = 12; probe.chunk_units = 4; probe.in_rows = ip.data(); probe.in_row_bytes = 9000; probe.d_in = d_in.data(); probe.d_in_pitch = 9008;
+        probe.out_rows = op.data(); probe.out_row_bytes = 9000; probe.d_out = d_out.data(); probe.d_out_pitch = 9008;
+        probe.direct = probe.direct_out = probe.shared_streams = true;
+        probe.feeders = 1; probe.drainers = 2;
+        probe.compute = [&](int first, int count, hipStream_t s, std::string &) -> int {
+            mockLaunch(s, [&, first, count] { std::memcpy(d_out.data() + (size_t)first * 9008, d_in.data() + (size_t)first * 9008, (size_t)count * 9008); });
+            return 0;
+        };
+        use_transfer(probe, 1);
+        const Result r = run(probe);
+        if (r.code != -9 || r.why != "transfer refused") { std::printf("a refused transfer launch was not reported: %d %s\n", r.code, r.why.c_str()); bad++; }
+    }
+    g_transfer_fails = -1;
+    g_transfer = false;
+    MaskedStreamPool::get().trim();
     PinnedPool::get().trim();
     if (mock_registered() != 0) { std::printf("%d rows left registered\n", mock_registered()); bad++; }
     if (mock_unregister_violations() != 0) { std::printf("%d rows unregistered with a copy still pending\n", mock_unregister_violations()); bad++; }

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--orders", type=int, nargs="+", default=[1, 0], help="1: shortest chunks first, 0: longest first")
     ap.add_argument("--feeders", type=int, nargs="+", default=[0], help="feeder threads (0: the pipeline's one; negative: a stream each)")
     ap.add_argument("--chunk-units", type=int, nargs="+", default=[0], help="largest number of units in a chunk (0: the entry point's 1024)")
+    ap.add_argument("--transfer", type=int, nargs="+", default=[0], help="page-locked rows: 0 = by transfer kernels (round 6), 1 = one copy per row")
     args = ap.parse_args()
     import torch
     from vgaudio_amd import _lib as lib, device as vdev
@@ -68,7 +69,8 @@ def main():
 
     def run(name, call, outs):
         keep = {}
-        for shortest_first, units, feeders in [(o, u, f) for f in args.feeders for u in args.chunk_units for o in args.orders] * 2:
+        for shortest_first, units, feeders, transfer in [(o, u, f, t) for t in args.transfer for f in args.feeders for u in args.chunk_units for o in args.orders] * 2:
+            L.vga_testing_host_transfer_this_thread(transfer)
             L.vga_testing_buckets_order_this_thread(1 if shortest_first else 2)
             L.vga_testing_host_pipeline_this_thread(feeders, 0, units, 0)
             try:
@@ -86,9 +88,11 @@ def main():
             finally:
                 L.vga_testing_buckets_order_this_thread(0)
                 L.vga_testing_host_pipeline_this_thread(0, 0, 0, 0)
+                L.vga_testing_host_transfer_this_thread(0)
             b = {k: (int(st[i]) if 13 <= i <= 16 else round(st[i] * 1e3, 1)) for i, k in enumerate(NAMES[:nf])}
             digest = [hash(o.tobytes()) for o in outs[::97]] + [int(sum(int(o[:64].sum()) for o in outs))]
             tag = "shortest first" if shortest_first else "longest first "
+            tag += " transfer kernels" if transfer == 0 else " a copy per row  "
             print(f"{name} {tag} units/chunk<={units or 1024:5d} feeders {feeders:2d} {best * 1e3:7.1f} ms   upload (slowest feeder) {b['slowest_feeder']:6.1f}  after it "
                   f"{b['total'] - b['slowest_feeder']:6.1f}  chunks {b['chunks']}  drainers' memcpy {b['drainers_memcpy']:6.1f}  "
                   f"feeders' issue {b['feeders_issue']:6.1f}" + ("   every call: " + ", ".join(every) if args.reps > 2 else ""), flush=True)
@@ -97,6 +101,13 @@ def main():
             for o in outs:
                 o[:] = 0
 
+    if "gc" in args.codecs:
+        nb = [L.vga_gcadpcm_sample_count_to_byte_count(int(n_)) for n_ in counts]
+        outs = [np.zeros(max(n_, 1), dtype=np.uint8) for n_ in nb]
+        op = (lib.u8p * use)(*[a.ctypes.data_as(lib.u8p) for a in outs])
+        coefs = np.zeros((use, 16), dtype=np.int16)
+        run("gc ", lambda: lib.check(L.vga_gcadpcm_encode_batch_v(pp, cp, use, None, None, coefs.ctypes.data_as(lib.i16p), op)), outs)
+        del outs, op
     if "adx" in args.codecs:
         params = (lib.AdxParams * use)()
         for i in range(use):

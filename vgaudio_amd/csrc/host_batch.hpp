@@ -13,7 +13,11 @@ namespace vga {
 struct PipeOverride {
     int feeders = 0, drainers = 0, chunk_units = 0, slot_bytes = 0, tail_units = 0;   // slot_bytes < 0: direct copies (no staging ring); > 0: staged
     int buckets_order = 0;                   // plan_buckets: 0 = the entry point's own order, 1 = shortest chunks first, 2 = longest first
+    int transfer = 0;                        // direct rows: 0 = by transfer kernels on reserved compute units (round 6), 1 = one copy per row
 };
+// transfer_kernels.hip
+int launch_transfer(const pipe::Job::TransferPiece *pieces, int n, hipStream_t stream);
+int device_cu_count();                               // common.hpp
 PipeOverride &pipe_override();                       // capi_gcadpcm.hip
 // the calling thread's last pipeline run, plus what the entry point spent around it (device allocation, small copies)
 struct PipeReport { pipe::Stats stats; double t_alloc = 0, t_entry = 0; };
@@ -172,6 +176,27 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     // chunk's kernels + download after it, whenever the first kernel started (profiles/r03_b_pipeline_timeline_head_chunk.log:
     // 539 and 550 ms against 518-538 ms without).
     job.head_units = 0;
+    // Round 6: page-locked rows travel by transfer kernels (transfer_kernels.hip) on sixteen compute units of their own -- a
+    // ragged call's 10 008 uploads no longer leave the copy engine idle between rows.  Calls of at least 256 MB only: below,
+    // the rows are few and the masked streams' two rounds of persistent workgroups cost more than the copies' gaps.
+    if (o.transfer == 0 && in_total + out_total >= ((size_t)256 << 20)) {
+        job.transfer = [](const pipe::Job::TransferPiece *pieces, int n, hipStream_t s, std::string &why) -> int {
+            const int rc = launch_transfer(pieces, n, s);
+            if (rc) why = vga_last_error();
+            return rc;
+        };
+        job.gather_in = job.direct && job.feeders == 1;
+        // downloads too, whichever way they go: a staged slot's copy (the ring is page-locked already) or, for a decode, the
+        // caller's page-locked rows.  (Left to hipMemcpyAsync next to the gather, chunk 0 of a ragged encode was back after
+        // 410 ms instead of 305: profiles/r06_j_pipeline_timeline_transfer.log.  Page-locking the 10 008 OUTPUT rows of an
+        // encode as well so that they can be written directly costs ~100 ms of hipHostRegister / hipHostUnregister.)
+        job.scatter_out = true;
+        // with the upload a fifth shorter, two threads copying the ring's slots out to the caller's rows (3.4 GB each for
+        // the ragged GC call) end 100 ms after the last kernel: four of them
+        if (o.drainers == 0 && !job.direct_out && out_total >= ((size_t)1 << 30)) job.drainers = 4;
+        job.total_cus = device_cu_count();
+        job.transfer_cus = 16;
+    }
     if (ProgressSink *sink = current_progress_sink())  // vga_set_progress_callback(): one report per chunk
         job.chunk_done = [sink](int, int count) { sink->add(count); };
     const pipe::Result r = pipe::run(job);

@@ -1,17 +1,23 @@
 // host_pipeline.hpp -- what a P/Invoke caller actually gets: the host-pointer entry points of the C ABI as a
-// three-stage pipeline (caller memory -> pinned ring -> HBM -> kernels -> HBM -> pinned ring -> caller memory).
+// three-stage pipeline over CHUNKS of units (caller memory -> HBM -> kernels -> HBM -> caller memory).
 //
 // The reference fans channels out with Parallel.For over managed arrays (Formats/GcAdpcm/GcAdpcmFormat.cs:65-68,
 // Formats/CriAdx/CriAdxFormat.cs:67-81) -- arrays that are pinned for the garbage collector but PAGEABLE for a DMA engine.
 // One hipMemcpyAsync per channel from such memory goes through the runtime's single staging thread (round 1:
-// 8-11 Gsamples/s through the ABI against 52 Gsamples/s in HBM).  Here:
-//   * F feeder threads copy the caller's rows into their own ring of page-locked slots (a row = one channel's PCM; the slot
-//     has the DEVICE pitch, so a slot goes to HBM with one contiguous hipMemcpyAsync on the feeder's own stream) -- the
-//     CPU fills slot i+1 while the DMA engine moves slot i;
-//   * the calling thread launches the kernels of a CHUNK of units (channels / streams) on the compute stream as soon as
-//     every feeder has recorded that chunk's event -- chunk k computes while chunk k+1 uploads;
-//   * D drainer threads wait for the chunk's compute event, pull its output rows through their own pinned rings on their
-//     own streams and copy them out to the caller's arrays -- chunk k-1 downloads while chunk k computes.
+// 8-11 Gsamples/s through the ABI against 52 Gsamples/s in HBM).  What run_batch_pipeline() (host_batch.hpp) sets up since
+// round 3, and what run() below does by default (Job::direct, Job::register_rows):
+//   * ONE feeder thread page-locks the caller's rows where they lie (hipHostRegister, for the duration of the call) and
+//     moves them to HBM chunk by chunk -- round 6: with ONE gather kernel per chunk that pulls the rows over PCIe from a
+//     table of (page-locked row piece, device address) on a stream whose CU mask keeps a few compute units free of the
+//     call's other kernels (Job::gather_in / transfer_cus: 57 GB/s against 45 GB/s for one hipMemcpyAsync per row, whose
+//     copy engine idles ~11 us per row; tools/bench_h2d_gather.hip); rows that cannot be mapped take a plain copy;
+//   * the calling thread launches the kernels of a chunk on one of two compute streams as soon as the chunk's upload
+//     event is recorded -- chunk k computes while chunk k+1 uploads;
+//   * D drainer threads wait for the chunk's compute event and bring its output rows back: through their own rings of
+//     page-locked slots (32 MB copies, then memcpy into the caller's rows: encodes, whose output is the smaller
+//     direction), or straight into the caller's page-locked rows (decodes; Job::direct_out).
+// The staged mode of rounds 1-2 (F feeder threads filling page-locked ring slots with memcpy, one contiguous copy per
+// slot) is still here for rows too small to be worth page-locking (Job::direct = false: rows under 256 KB).
 // Page-locked memory comes from a process-wide pool (hipHostMalloc costs ~0.3 s per GB; the rings are a few hundred MB
 // and are reused by later calls).  No caller pointer is retained past return.
 //
@@ -100,6 +106,60 @@ private:
     std::vector<Block> blocks_;
 };
 
+// ---------------------------------------------------------------- streams with a CU mask (process-wide)
+// A stream with a CU mask is a hardware queue of its own: creating and destroying four of them per call cost the ragged GC
+// call ~150 ms (round 6).  They are kept, idle, between calls -- keyed by device and mask -- and handed to the next call.
+class MaskedStreamPool {
+public:
+    static MaskedStreamPool &get()
+    {
+        static MaskedStreamPool pool;
+        return pool;
+    }
+    hipError_t acquire(hipStream_t *out, int device, const std::vector<uint32_t> &mask)
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            for (auto &e : entries_)
+                if (!e.busy && e.device == device && e.mask == mask) {
+                    e.busy = true;
+                    *out = e.s;
+                    return hipSuccess;
+                }
+        }
+        const hipError_t err = hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
+        if (err != hipSuccess) return err;
+        std::lock_guard<std::mutex> g(m_);
+        entries_.push_back({*out, device, mask, true});
+        return hipSuccess;
+    }
+    // true: the stream is the pool's (it stays alive); false: the caller destroys it
+    bool release(hipStream_t s)
+    {
+        std::lock_guard<std::mutex> g(m_);
+        for (auto &e : entries_)
+            if (e.s == s) {
+                e.busy = false;
+                return true;
+            }
+        return false;
+    }
+    void trim()                                            // destroys every idle stream (tests; vga_release_cached_memory)
+    {
+        std::lock_guard<std::mutex> g(m_);
+        for (int i = (int)entries_.size() - 1; i >= 0; i--)
+            if (!entries_[i].busy) {
+                (void)hipStreamDestroy(entries_[i].s);
+                entries_.erase(entries_.begin() + i);
+            }
+    }
+
+private:
+    struct Entry { hipStream_t s; int device; std::vector<uint32_t> mask; bool busy; };
+    std::mutex m_;
+    std::vector<Entry> entries_;
+};
+
 struct PinnedBlock {
     void *p = nullptr;
     ~PinnedBlock() { if (p) PinnedPool::get().release(p); }
@@ -161,6 +221,19 @@ struct Job {
     bool register_rows = true;             // direct mode: hipHostRegister each row for the duration of the call
     bool shared_streams = false;           // every feeder issues on one stream, every drainer on another (3 streams in all)
     int device = 0;
+    // Round 6: direct mode with a kernel instead of one copy per row.  transfer(pieces, n, stream, why) enqueues ONE launch
+    // that copies n pieces (at most piece_bytes each; device-visible addresses on both sides: a page-locked row's mapped
+    // address, an address in d_in / d_out); `pieces` lies in page-locked memory that stays valid until run() returns.
+    // gather_in: the feeder (one feeder only) maps each row it page-locks and launches one transfer per chunk instead of a
+    // hipMemcpyAsync per row; scatter_out: the drainers likewise (direct_out jobs).  transfer_cus > 0: that many of the
+    // device's total_cus compute units are kept free of the job's kernels (the compute streams' CU mask) and the transfer
+    // streams are confined to them -- a transfer kernel launched while other kernels hold every CU would start only when
+    // their workgroups end (tools/bench_h2d_gather.hip: 11 GB/s instead of 57).
+    struct TransferPiece { const void *src; void *dst; unsigned bytes, pad; };
+    std::function<int(const TransferPiece *pieces, int n, hipStream_t stream, std::string &why)> transfer;
+    bool gather_in = false, scatter_out = false;
+    int transfer_cus = 0, total_cus = 0;
+    size_t piece_bytes = (size_t)256 << 10;
 };
 
 // Where the wall time of one run() went (seconds): per-thread sums, and the slowest thread of each kind.
@@ -331,17 +404,73 @@ inline Result run(const Job &job)
             res.why = hip_msg(what, e);
         }
     };
-    for (auto &c : cstreams) check(hipStreamCreateWithFlags(&c, hipStreamNonBlocking), "hipStreamCreate");
+    // the transfer kernels' own compute units (Job::transfer_cus): bits [0, transfer_cus) of the CU mask for the transfer
+    // streams, the rest for the compute streams
+    const bool gather_in = has_in && job.direct && job.gather_in && job.transfer && F == 1;
+    const bool scatter_out = has_out && job.direct_out && job.scatter_out && job.transfer;
+    // staged downloads: the ring slot's one contiguous copy by a transfer launch as well (the ring is page-locked and
+    // device-visible already: nothing of the caller's has to be page-locked for it)
+    const bool scatter_ring = has_out && !job.direct_out && job.scatter_out && job.transfer;
+    const bool masked = (gather_in || scatter_out || scatter_ring) && job.transfer_cus > 0 && job.total_cus > 2 * job.transfer_cus;
+    std::vector<uint32_t> cmask, tmask;
+    if (masked) {
+        const int words = (job.total_cus + 31) / 32;
+        cmask.assign(words, 0xFFFFFFFFu);
+        tmask.assign(words, 0u);
+        for (int b = 0; b < job.transfer_cus; b++) {
+            cmask[b / 32] &= ~(1u << (b % 32));
+            tmask[b / 32] |= 1u << (b % 32);
+        }
+    }
+    auto make_stream = [&](hipStream_t *st, bool transfer_side) {
+        if (masked) {
+            return MaskedStreamPool::get().acquire(st, job.device, transfer_side ? tmask : cmask);
+        }
+        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    };
+    for (auto &c : cstreams) check(make_stream(&c, false), "hipStreamCreate");
     const bool shared_streams = job.shared_streams;
+    auto make_side = [&](hipStream_t *st, bool uses_transfer) {
+        return uses_transfer ? make_stream(st, true) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    };
     if (shared_streams) {
-        if (F > 0) check(hipStreamCreateWithFlags(&fstream[0], hipStreamNonBlocking), "hipStreamCreate");
-        if (D > 0) check(hipStreamCreateWithFlags(&dstream[0], hipStreamNonBlocking), "hipStreamCreate");
+        if (F > 0) check(make_side(&fstream[0], gather_in), "hipStreamCreate");
+        if (D > 0) check(make_side(&dstream[0], scatter_out || scatter_ring), "hipStreamCreate");
         for (auto &s : fstream) s = fstream[0];
         for (auto &s : dstream) s = dstream[0];
     } else {
-        for (auto &s : fstream) check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
-        for (auto &s : dstream) check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+        for (auto &s : fstream) check(make_side(&s, gather_in), "hipStreamCreate");
+        for (auto &s : dstream) check(make_side(&s, scatter_out || scatter_ring), "hipStreamCreate");
     }
+    // piece tables (page-locked, device-visible): every row in pieces of at most piece_bytes; a drainer copies whatever
+    // rows it claims, so each drainer's table can hold them all
+    const size_t piece = std::max<size_t>(job.piece_bytes, 4096);
+    auto pieces_of = [&](bool have, int rows_per_unit, const size_t *sizes, size_t uniform) {
+        size_t n = 0;
+        if (!have) return n;
+        const int rows = job.units * rows_per_unit;
+        for (int r = 0; r < rows; r++) n += ((sizes ? sizes[r] : uniform) + piece - 1) / piece;
+        return n;
+    };
+    const size_t in_pieces = gather_in ? pieces_of(has_in, job.in_rows_per_unit, job.in_row_sizes, job.in_row_bytes) : 0;
+    size_t out_pieces = scatter_out ? pieces_of(has_out, job.out_rows_per_unit, job.out_row_sizes, job.out_row_bytes) : 0;
+    if (scatter_ring)                                  // a slot's copy covers its rows' device extent, gaps included
+        for (int k = 0; k < chunks; k++)
+            for (int gi = gout.gfirst[k]; gi < gout.gfirst[k + 1]; gi++) {
+                int r, n;
+                group_rows(gout, k, gi, job.out_rows_per_unit, r, n);
+                out_pieces += (out_off(r + n - 1) - out_off(r) + out_size(r + n - 1) + piece - 1) / piece;
+            }
+    PinnedBlock in_table, out_table;
+    if (ok && in_pieces && !in_table.alloc(in_pieces * sizeof(Job::TransferPiece))) check(hipErrorOutOfMemory, "hipHostMalloc (piece table)");
+    if (ok && out_pieces && !out_table.alloc((size_t)D * out_pieces * sizeof(Job::TransferPiece))) check(hipErrorOutOfMemory, "hipHostMalloc (piece table)");
+    // output rows page-locked and mapped so far (scatter_out): the device-visible address, nullptr until some drainer has it
+    std::vector<std::atomic<void *>> mapped_out(scatter_out ? (size_t)job.units * job.out_rows_per_unit : 0);
+    for (auto &m : mapped_out) m.store(nullptr);
+    auto append_pieces = [&](Job::TransferPiece *table, size_t &np, const char *src, char *dst, size_t bytes) {
+        for (size_t o = 0; o < bytes; o += piece)
+            table[np++] = Job::TransferPiece{src + o, dst + o, (unsigned)std::min(piece, bytes - o), 0u};
+    };
     const bool timeline = std::getenv("VGA_HIP_PIPELINE_TIMELINE") != nullptr;
     std::vector<hipEvent_t> cstart(chunks + 1, nullptr), dlev(timeline ? D * chunks : 0, nullptr);
     for (auto *v : {&fslot, &dslot})
@@ -386,6 +515,8 @@ inline Result run(const Job &job)
                         sh.st.feed_boundary += b; sh.st.feed_final += f;
                         sh.st.feed_max = std::max(sh.st.feed_max, now() - t0); }
         } report{sh, t_copy, t_wait, t_issue, t_boundary, t_final, t_start};
+        Job::TransferPiece *table = static_cast<Job::TransferPiece *>(in_table.p);   // gather_in: this (the only) feeder's pieces
+        size_t np = 0, np_sent = 0;
         for (int k = 0; k < chunks && !sh.err.load(); k++) {
             // row groups are handed out on demand: a feeder that runs on a core far from the caller's pages (or shares
             // its core) simply takes fewer of them -- with a fixed split the slowest thread set the upload time
@@ -404,10 +535,20 @@ inline Result run(const Job &job)
                         void *row = const_cast<void *>(job.in_rows[r + i]);
                         const size_t bytes = in_size(r + i);
                         if (bytes == 0) continue;
-                        if (job.register_rows && hipHostRegister(row, bytes, hipHostRegisterDefault) == hipSuccess)
+                        bool locked = false;
+                        if (job.register_rows && hipHostRegister(row, bytes, gather_in ? hipHostRegisterMapped : hipHostRegisterDefault) == hipSuccess) {
                             registered.push_back(row);
-                        else
+                            locked = true;
+                        } else
                             (void)hipGetLastError();
+                        if (gather_in && locked) {         // the chunk's gather kernel fetches it (below)
+                            void *dev_view = nullptr;
+                            if (hipHostGetDevicePointer(&dev_view, row, 0) == hipSuccess && dev_view) {
+                                append_pieces(table, np, static_cast<const char *>(dev_view), job.d_in + in_off(r + i), bytes);
+                                continue;
+                            }
+                            (void)hipGetLastError();
+                        }
                         VGA_PIPE_TRY(hipMemcpyAsync(job.d_in + in_off(r + i), row, bytes, hipMemcpyHostToDevice, fstream[t]));
                     }
                     t_issue += now() - ta;
@@ -435,6 +576,15 @@ inline Result run(const Job &job)
                 used++;
             }
             const double tb0 = now();
+            if (gather_in && np > np_sent && !sh.err.load()) {
+                std::string why;
+                const int rc = job.transfer(table + np_sent, (int)(np - np_sent), fstream[t], why);
+                if (rc) {
+                    sh.fail(rc, why);
+                    return;
+                }
+                np_sent = np;
+            }
             VGA_PIPE_TRY(hipEventRecord(upl[t * chunks + k], fstream[t]));
             {
                 std::lock_guard<std::mutex> g(sh.m);
@@ -457,6 +607,8 @@ inline Result run(const Job &job)
         int64_t used = 0;
         int reported = 0;                                  // progress: chunks [0, reported) of this drainer are complete
         std::vector<void *> &registered = locked_out[u];
+        Job::TransferPiece *otable = static_cast<Job::TransferPiece *>(out_table.p) + (size_t)u * out_pieces;   // scatter_out: this drainer's pieces
+        size_t onp = 0;
         double t_wait_comp = 0, t_wait_copy = 0, t_copy = 0, t_register = 0;
         const double t_start = now();
         struct Report {
@@ -473,9 +625,12 @@ inline Result run(const Job &job)
             for (int r = u; r < total_rows; r += D) {
                 void *row = job.out_rows[r];
                 if (out_size(r) == 0) continue;
-                if (hipHostRegister(row, out_size(r), hipHostRegisterDefault) == hipSuccess)
+                if (hipHostRegister(row, out_size(r), scatter_out ? hipHostRegisterMapped : hipHostRegisterDefault) == hipSuccess) {
                     registered.push_back(row);
-                else
+                    void *dev_view = nullptr;
+                    if (scatter_out && hipHostGetDevicePointer(&dev_view, row, 0) == hipSuccess && dev_view) mapped_out[r].store(dev_view);
+                    else if (scatter_out) (void)hipGetLastError();
+                } else
                     (void)hipGetLastError();
             }
             t_register = now() - ta;
@@ -521,10 +676,24 @@ inline Result run(const Job &job)
                 group_rows(gout, k, gi, job.out_rows_per_unit, r, n);
                 if (job.direct_out) {
                     const double ta = now();
+                    const size_t np0 = onp;
                     for (int i = 0; i < n; i++) {
                         void *row = job.out_rows[r + i];
                         if (out_size(r + i) == 0) continue;
+                        void *dev_view = scatter_out ? mapped_out[r + i].load() : nullptr;
+                        if (dev_view) {                    // this group's scatter kernel writes it (below)
+                            append_pieces(otable, onp, job.d_out + out_off(r + i), static_cast<char *>(dev_view), out_size(r + i));
+                            continue;
+                        }
                         VGA_PIPE_TRY(hipMemcpyAsync(row, job.d_out + out_off(r + i), out_size(r + i), hipMemcpyDeviceToHost, dstream[u]));
+                    }
+                    if (onp > np0) {
+                        std::string why;
+                        const int rc = job.transfer(otable + np0, (int)(onp - np0), dstream[u], why);
+                        if (rc) {
+                            sh.fail(rc, why);
+                            return;
+                        }
                     }
                     t_copy += now() - ta;
                     continue;
@@ -533,7 +702,17 @@ inline Result run(const Job &job)
                 if (!flush(s)) return;
                 char *slot = ring + (size_t)s * gout.slot_cap;
                 const size_t bytes = out_off(r + n - 1) - out_off(r) + out_size(r + n - 1);
-                if (bytes) VGA_PIPE_TRY(hipMemcpyAsync(slot, job.d_out + out_off(r), bytes, hipMemcpyDeviceToHost, dstream[u]));
+                if (bytes && scatter_ring) {
+                    const size_t np0 = onp;
+                    append_pieces(otable, onp, job.d_out + out_off(r), slot, bytes);
+                    std::string why;
+                    const int rc = job.transfer(otable + np0, (int)(onp - np0), dstream[u], why);
+                    if (rc) {
+                        sh.fail(rc, why);
+                        return;
+                    }
+                } else if (bytes)
+                    VGA_PIPE_TRY(hipMemcpyAsync(slot, job.d_out + out_off(r), bytes, hipMemcpyDeviceToHost, dstream[u]));
                 VGA_PIPE_TRY(hipEventRecord(dslot[u * R + s], dstream[u]));
                 pend[s].row = r;
                 pend[s].n = n;
@@ -646,9 +825,9 @@ inline Result run(const Job &job)
     for (auto *v : {&fslot, &dslot, &upl, &comp, &cstart, &dlev, &dend})
         for (auto e : *v) if (e) (void)hipEventDestroy(e);
     if (shared_streams) { fstream.resize(F > 0 ? 1 : 0); dstream.resize(D > 0 ? 1 : 0); }
-    for (auto s : fstream) if (s) (void)hipStreamDestroy(s);
-    for (auto s : dstream) if (s) (void)hipStreamDestroy(s);
-    for (auto c : cstreams) if (c) (void)hipStreamDestroy(c);
+    for (auto *v : {&fstream, &dstream, &cstreams})      // (masked streams go back to their pool, idle: everything above has synchronised them)
+        for (auto st : *v)
+            if (st && !MaskedStreamPool::get().release(st)) (void)hipStreamDestroy(st);
     res.stats = sh.st;
     res.stats.setup = t_setup_done - t_begin;
     res.stats.total = now() - t_begin;
