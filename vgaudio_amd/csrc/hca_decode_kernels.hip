@@ -385,10 +385,17 @@ int launch_decode(const uint8_t *d_frames, int64_t frames_pitch, int nstreams, c
     if (lds1 > 32 * 1024) VGA_HIP_TRY(allow_dynamic_lds(hca_scan_kernel, lds1));
     hipLaunchKernelGGL(hca_scan_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), lds1, stream, d_frames, frames_pitch,
                        nstreams, info, lay, records, d_status);
+    // (test hook as in launch_encode: n > 0 = frames per group; 1000 + n means the same here.  A wave-per-frame form of this
+    // launch, the encoder's scheme, was built and measured in round 6 and is not used: 20.0 ms against this kernel's 18.7 --
+    // 7.5 G VALU instructions at 0.61 of the issue slots, 13.7 KB of LDS a wave = two waves per SIMD, and the 16-code chunks'
+    // serial VLC chains have nothing to overlap with inside one wave (tools/experiments/hca_decode_wave_kernel.hip,
+    // profiles/r06_l_sq_counters_hca_decode_wave_experiment.json).)
+    const int hook = hca_frames_per_group_override();
+    const int group_override = hook >= 1000 ? hook - 1000 : hook;
     // frames per workgroup: long runs amortise the table set-up and the recomputed sub-frame before the run, short ones
     // keep small inputs spread over the chip
     int per_group = (int)std::min<int64_t>(MAX_FRAMES_PER_GROUP, std::max<int64_t>(1, total / 8192));
-    if (hca_frames_per_group_override() > 0) per_group = std::min(hca_frames_per_group_override(), 64);
+    if (group_override > 0) per_group = std::min(group_override, 64);
     per_group = std::min(per_group, info.frame_count);
     const int groups = (info.frame_count + per_group - 1) / per_group;
     const size_t lds2 = (size_t)info.nch * 9 * ROW_BYTES + (size_t)info.nch * 128 * 9 +

@@ -36,6 +36,13 @@ using namespace enc;
 
 namespace {
 
+// bytes between two of the wave's eight transform rows (hca_decode_core.hpp's row of 1152 bytes + what keeps the eight rows,
+// which the wave accesses in lockstep, off each other's banks)
+#ifndef VGA_HCA_WAVE_ROW
+#define VGA_HCA_WAVE_ROW 1152
+#endif
+constexpr int WROW_BYTES = VGA_HCA_WAVE_ROW;
+
 #ifndef VGA_HCA_ENC_STOP_AFTER
 #define VGA_HCA_ENC_STOP_AFTER 99
 #endif
@@ -60,7 +67,7 @@ namespace {
 constexpr int WG_WAVES = VGA_HCA_WG_WAVES;
 constexpr int WG_THREADS = 64 * WG_WAVES;
 constexpr int MAX_WAVE_FRAMES = 16;
-constexpr int ROWS_BYTES = 8 * ROW_BYTES;              // one channel's eight transforms
+constexpr int ROWS_BYTES = 8 * WROW_BYTES;              // one channel's eight transforms
 
 // FindScaleFactor (:691-709) returns how many of the table's first 63 entries are <= value.  The table is geometric (ratio
 // 2^(53/128) = 1.33), so the value's exponent and top three mantissa bits (a bucket 2^(1/8) = 1.09 wide) leave at most one
@@ -366,14 +373,14 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
                     const double fb = w_b * (double)x_in_lo;
                     const double fc = w_c * (double)x_pv_lo;
                     const double fd = w_d * (double)x_pv_hi;
-                    *reinterpret_cast<double *>(rows + sf * ROW_BYTES + fold_lo) = fa - fb;
-                    *reinterpret_cast<double *>(rows + sf * ROW_BYTES + fold_hi) = fc - fd;
+                    *reinterpret_cast<double *>(rows + sf * WROW_BYTES + fold_lo) = fa - fb;
+                    *reinterpret_cast<double *>(rows + sf * WROW_BYTES + fold_hi) = fc - fd;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             {
                 const int L = ln & 7;
-                char *my_row = rows + (ln >> 3) * ROW_BYTES;
+                char *my_row = rows + (ln >> 3) * WROW_BYTES;
                 dct_first_half_lds(my_row, L, S.tw);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const int rev = ((L & 1) << 2) | (L & 2) | ((L >> 2) & 1);
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(VGA_
             for (int h = 0; h < 2; h++)
 #pragma unroll
                 for (int sf = 0; sf < 8; sf++)
-                    x[c][h][sf] = *reinterpret_cast<const double *>(rows + sf * ROW_BYTES + 8 * (ln + 64 * h));
+                    x[c][h][sf] = *reinterpret_cast<const double *>(rows + sf * WROW_BYTES + 8 * (ln + 64 * h));
         }
         WAVE_STOP_AFTER(2, [&] { double t = 0; for (int c = 0; c < NCH; c++) for (int h = 0; h < 2; h++) for (int sf = 0; sf < 8; sf++) t += x[c][h][sf]; return __double2loint(t); }());
 
