@@ -390,6 +390,8 @@ int launch_decode(const uint8_t *d_frames, int64_t frames_pitch, int nstreams, c
     // 7.5 G VALU instructions at 0.61 of the issue slots, 13.7 KB of LDS a wave = two waves per SIMD, and the 16-code chunks'
     // serial VLC chains have nothing to overlap with inside one wave (tools/experiments/hca_decode_wave_kernel.hip,
     // profiles/r06_l_sq_counters_hca_decode_wave_experiment.json).)
+    // Also measured and not used (round 6): the batch in two halves with the second half's scan on a side stream underneath
+    // the first half's frames launch -- 24.7 ms, the same as back to back: the frames launch leaves the scan's waves no room.
     const int hook = hca_frames_per_group_override();
     const int group_override = hook >= 1000 ? hook - 1000 : hook;
     // frames per workgroup: long runs amortise the table set-up and the recomputed sub-frame before the run, short ones
