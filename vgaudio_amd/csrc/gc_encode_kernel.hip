@@ -799,10 +799,18 @@ __device__ __forceinline__ void store_frame_bytes(uint8_t *dst, uint32_t d0, uin
 // bytes the piece holds (decoding its frames from ITS start history (g2, g1), before they are overwritten), until both
 // histories coincide at a frame end: from there on the piece holds what the serial encoder writes.  Returns with
 // open == true when the piece ended first; (h0, h1) is then the true history at the piece's end.
+// LPC (round 6): lanes per channel.  8: a lane per predictor, the two speculative passes of a frame one after the other in the
+// same lane (two chains for the instruction stream to interleave: the layout of the seams inside the persistent kernel,
+// where every SIMD holds other waves).  16: a lane per (predictor, candidate) -- pass A (scale s1) in the even lane, pass B
+// (s1 + 1) in the odd one, as the encoder's CPW = 4 layout -- half the instructions per frame on the frame's critical
+// path: for the seam and chain launches of batches below 512 channels, whose run time IS their slowest seam's.
+template <int LPC>
 __device__ __forceinline__ void seam_run(const int16_t *__restrict__ src, uint8_t *__restrict__ dst, int c0, int c1, bool coef_ok,
                                          int pr, int ch, int k, int64_t f0, int total_samples, int piece_frames, int max_frames, int force_open,
                                          int &h0, int &h1, int g2, int g1, bool &open, int &frames_run)
 {
+    static_assert(LPC == 8 || LPC == 16, "a lane per predictor, or per (predictor, candidate)");
+    const bool cand_b = LPC == 16 && (threadIdx.x & 1) != 0;
     const int full_frames = total_samples / 14;
     // The frame loop is one wave's dependent chain (nothing else runs on its SIMD for long: the slowest seam IS the
     // kernel's run time), so it is the encoder's fast path -- range pre-scan, the two speculative passes of the
@@ -810,6 +818,10 @@ __device__ __forceinline__ void seam_run(const int16_t *__restrict__ src, uint8_
     // reference's loop as written (resume_passes) only behind the same `rare` / `resume` conditions as there.
     const int64_t f_end = imin((int)imin((int)(f0 + piece_frames), (int)(f0 + max_frames)), full_frames);   // frames [f0, f_end)
     const int64_t f_last = full_frames > 0 ? full_frames - 1 : 0;
+    // (Round 6, measured and taken out again: the frames a block of LPC at a time -- lane j of the group loading frame fb + j,
+    // the next block in flight, a frame's nine dwords handed round through the crossbar.  Nothing gained, 5 % lost at 512
+    // channels: the loop does not wait for its loads -- a frame of a seam run is ~1000 instructions of a lone wave at
+    // 2.3 ns each (replay 200, pre-scan 160, passes 220-450, argmin / pack / store 120), profiles/r06_m_channel_scaling.log.)
     auto fetch = [&](int64_t f, uint32_t (&w)[7], uint2 &old) {
         const int64_t fc = f < f_last ? f : f_last;     // clamped: always a valid full frame (unconditional loads)
         const uint32_t *p32 = reinterpret_cast<const uint32_t *>(src + fc * 14);
@@ -844,7 +856,8 @@ __device__ __forceinline__ void seam_run(const int16_t *__restrict__ src, uint8_
             const int ps = (int)(old.x & 0xFFu);
             const int scale = (1 << (ps & 0xF)) * 2048;
             const int pred = (ps >> 4) & 7;
-            const int k1 = __shfl(c0, pred, 8), k2 = __shfl(c1, pred, 8);     // that predictor's pair sits in lane `pred` of the group
+            // that predictor's pair sits in lane `pred` (LPC = 16: lanes 2 pred, 2 pred + 1) of the group
+            const int k1 = __shfl(c0, LPC == 16 ? 2 * pred : pred, LPC), k2 = __shfl(c1, LPC == 16 ? 2 * pred : pred, LPC);
             const uint64_t bits = ((uint64_t)old.y << 32) | old.x;            // byte b of the frame = bits >> 8b
 #pragma unroll
             for (int s2 = 0; s2 < 14; s2++) {
@@ -864,6 +877,10 @@ __device__ __forceinline__ void seam_run(const int16_t *__restrict__ src, uint8_
             if (s1 == -100) s1 = first_scale_power_from_md(prescan_sequential(x, c0, c1));
         }
         const int sp_a = imin(s1, 12), sp_b = imin(s1 + 1, 12);
+        PassOut r;
+        int final_sp;
+        bool fin = true;                               // LPC = 16: this lane's pass is the one the reference ends on
+        if (LPC == 8) {
         // (the passes as they always were: without the f32 detour -- tried in round 5 -- a seam run is no faster, LABNOTES 9.7)
         const PassOut rb = pass_fast_core(x, m, mp, c0, c1, sp_b);
         const PassOut ra = pass_fast_core(x, m, mp, c0, c1, sp_a);
@@ -872,12 +889,11 @@ __device__ __forceinline__ void seam_run(const int16_t *__restrict__ src, uint8_
         const int eff_a = cap_a ? 0 : ra.max_overflow, eff_b = cap_b ? 0 : rb.max_overflow;
         const bool fin_a = eff_a < 2;
         const bool resume = !fin_a && eff_b >= 2;
-        PassOut r;
 #pragma unroll
         for (int i = 0; i < 14; i++) r.q[i] = fin_a ? ra.q[i] : rb.q[i];
         r.total = fin_a ? ra.total : rb.total;
         r.hist_pair = fin_a ? ra.hist_pair : rb.hist_pair;
-        int final_sp = fin_a ? sp_a : sp_b;
+        final_sp = fin_a ? sp_a : sp_b;
         if (__any(rare || resume)) {
             if (rare || resume) {
                 const PassOut rc = resume_passes(x, c0, c1, rare ? s1 - 1 : s1 + 1, final_sp);
@@ -887,8 +903,32 @@ __device__ __forceinline__ void seam_run(const int16_t *__restrict__ src, uint8_
                 r.hist_pair = rc.hist_pair;
             }
         }
-        // totals are below 2^60 (14 squares of 17-bit errors): the predictor rides in the low bits
-        uint64_t key = act ? ((r.total << 3) | (uint64_t)pr) : ~0ull;
+        } else {
+            // one pass per lane: A at s1 (even lane), B at s1 + 1 (odd lane); the pair decides from the two overflows which of
+            // them the reference's loop ends on (encode_frame, CPW = 4); anything else -- both overflowed, a bump, an inexact
+            // sum, hostile coefficients -- and the A lane walks the reference's loop as written, the B lane is out
+            final_sp = cand_b ? sp_b : sp_a;
+            r = pass_fast_core(x, m, mp, c0, c1, final_sp);
+            const bool cap = final_sp >= 12;
+            const bool rare_mine = !coef_ok || (unsigned)r.max_overflow > (cap ? 3u : 248u);
+            const int eff = cap ? 0 : r.max_overflow;
+            const int eff_other = dpp<DPP_QUAD_XOR1>(eff);
+            const bool rare = rare_mine || dpp<DPP_QUAD_XOR1>(rare_mine ? 1 : 0) != 0;
+            const int eff_a = cand_b ? eff_other : eff, eff_b = cand_b ? eff : eff_other;
+            const bool fin_a = eff_a < 2;
+            const bool resume = !fin_a && eff_b >= 2;
+            fin = cand_b ? !fin_a : fin_a;
+            if (__any(rare || resume)) {
+                if (rare || resume) {
+                    fin = !cand_b;
+                    if (!cand_b) r = resume_passes(x, c0, c1, rare ? s1 - 1 : s1 + 1, final_sp);
+                }
+            }
+        }
+        // totals are below 2^60 (14 squares of 17-bit errors): the predictor (LPC = 16: the lane of the group, predictor-major
+        // -- one lane of a pair at most is in it) rides in the low bits
+        const int lidx = LPC == 16 ? (int)(threadIdx.x & 15) : pr;
+        uint64_t key = (act && fin) ? ((r.total << 4) | (uint64_t)lidx) : ~0ull;
 #define VGA_MIN64_STAGE(CTRL)                                                          \
         {                                                                              \
             const unsigned olo = (unsigned)dpp<CTRL>((int)(uint32_t)key);              \
@@ -899,12 +939,14 @@ __device__ __forceinline__ void seam_run(const int16_t *__restrict__ src, uint8_
         VGA_MIN64_STAGE(DPP_QUAD_XOR1)
         VGA_MIN64_STAGE(DPP_QUAD_XOR2)
         VGA_MIN64_STAGE(DPP_ROW_HALF_MIRROR)
+        if (LPC == 16) VGA_MIN64_STAGE(DPP_ROW_MIRROR)
 #undef VGA_MIN64_STAGE
-        const bool won = act && pr == (int)(key & 7u);
+        const bool won = act && fin && lidx == (int)(key & 15u);
         unsigned pay = won ? r.hist_pair : 0u;
         pay |= (unsigned)dpp<DPP_QUAD_XOR1>((int)pay);
         pay |= (unsigned)dpp<DPP_QUAD_XOR2>((int)pay);
         pay |= (unsigned)dpp<DPP_ROW_HALF_MIRROR>((int)pay);
+        if (LPC == 16) pay |= (unsigned)dpp<DPP_ROW_MIRROR>((int)pay);
         if (won) {
             uint32_t d0, d1;
             pack_frame(r.q, pr, final_sp, d0, d1);
@@ -924,6 +966,7 @@ __device__ __forceinline__ void seam_run(const int16_t *__restrict__ src, uint8_
 // The zero-padded partial last frame of a stream (GcAdpcmEncoder.cs:32-38) from the true history (h0, h1), by the eight
 // lanes of a channel exactly as seam_run encodes a frame; SampleCountToByteCount(tail) bytes are stored.  For the chain
 // kernel: a run that is still apart at the very end of the stream has only this frame left to correct.
+template <int LPC>
 __device__ __forceinline__ void encode_tail_frame(const int16_t *__restrict__ src, uint8_t *__restrict__ dst, int c0, int c1,
                                                   bool coef_ok, int pr, int total_samples, int h0, int h1, bool act)
 {
@@ -964,7 +1007,9 @@ __device__ __forceinline__ void encode_tail_frame(const int16_t *__restrict__ sr
         for (int i = 0; i < 14; i++) r.q[i] = rc.q[i];
         r.total = rc.total;
     }
-    uint64_t key = act ? ((r.total << 3) | (uint64_t)pr) : ~0ull;
+    // (LPC = 16: both lanes of a predictor hold the same frame -- the even one is in the argmin and stores)
+    const bool in_it = act && (LPC == 8 || (threadIdx.x & 1) == 0);
+    uint64_t key = in_it ? ((r.total << 3) | (uint64_t)pr) : ~0ull;
 #define VGA_MIN64_STAGE(CTRL)                                                          \
     {                                                                                  \
         const unsigned olo = (unsigned)dpp<CTRL>((int)(uint32_t)key);                  \
@@ -975,8 +1020,9 @@ __device__ __forceinline__ void encode_tail_frame(const int16_t *__restrict__ sr
     VGA_MIN64_STAGE(DPP_QUAD_XOR1)
     VGA_MIN64_STAGE(DPP_QUAD_XOR2)
     VGA_MIN64_STAGE(DPP_ROW_HALF_MIRROR)
+    if (LPC == 16) VGA_MIN64_STAGE(DPP_ROW_MIRROR)
 #undef VGA_MIN64_STAGE
-    if (act && pr == (int)(key & 7u)) {
+    if (in_it && pr == (int)(key & 7u)) {
         uint32_t d0, d1;
         pack_frame(r.q, pr, final_sp, d0, d1);
         const int nibbles = tail + 2;                                   // SampleCountToNibbleCount of the tail (GcAdpcmMath.cs:24-30)
@@ -987,13 +1033,15 @@ __device__ __forceinline__ void encode_tail_frame(const int16_t *__restrict__ sr
 // All seams at once, each from the history the piece before ended on (seg_state: the real one provided THAT piece's own
 // seam closes).  A seam still open at the end of its piece leaves a flag and the true history it arrived at
 // (seam_flag / seam_end) and its index in first_open[channel]: gc_encode_chain_kernel carries on from there.
+template <int LPC>
 __device__ __forceinline__ void seam_piece(
     const int slot_raw, const int k, const int lane,
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, const Pieces seg,
     const int16_t *__restrict__ coefs, uint8_t *adpcm, int64_t adpcm_pitch,
     const int16_t *seg_state, int *first_open, int *seam_flag, int *seam_end, int force_open, const Ragged &rg)
 {
-    const int pr = lane & 7;                            // this lane's predictor
+    const int pr = LPC == 16 ? (lane >> 1) & 7 : lane & 7;        // this lane's predictor
+    const bool lead = (lane & (LPC - 1)) == 0;          // one lane per channel: flags, statistics
     const int64_t f0 = seg.first(k);
     const int slot = slot_raw < nch ? slot_raw : nch - 1;
     const int ch = rg.order ? rg.order[slot] : slot;
@@ -1009,10 +1057,10 @@ __device__ __forceinline__ void seam_piece(
     const int g2 = valid ? src[f0 * 14 - 2] : 0, g1 = valid ? src[f0 * 14 - 1] : 0;   // the guessed run's history (g1 = newest)
     bool open = valid;                                  // uniform inside a group of eight
     int frames_run = 0;
-    seam_run(src, dst, c0, c1, coef_ok, pr, ch, k, f0, total_samples, seg.frames(k), seg.frames(k), force_open, h0, h1, g2, g1, open, frames_run);
+    seam_run<LPC>(src, dst, c0, c1, coef_ok, pr, ch, k, f0, total_samples, seg.frames(k), seg.frames(k), force_open, h0, h1, g2, g1, open, frames_run);
     // still open at the piece's end (half the seams close within nine frames, one in a hundred needs more than 400, a
     // few channels never meet)
-    if (valid && pr == 0) {
+    if (valid && lead) {
         atomicAdd(&g_vga_gc_stats[open ? 1 : 0], 1ull);
         atomicAdd(&g_vga_gc_stats[2], (unsigned long long)frames_run);
         seam_flag[(int64_t)(k - 1) * nch + ch] = open ? 1 : 0;
@@ -1023,13 +1071,14 @@ __device__ __forceinline__ void seam_piece(
     }
 }
 
+template <int LPC>
 __global__ __launch_bounds__(64) void gc_encode_seam_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, const Pieces seg,
     const int16_t *__restrict__ coefs, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch,
     const int16_t *__restrict__ seg_state, int *__restrict__ first_open, int *__restrict__ seam_flag,
     int *__restrict__ seam_end, int force_open, const Ragged rg)
 {
-    seam_piece(blockIdx.x * 8 + (threadIdx.x >> 3), blockIdx.y + 1, threadIdx.x, pcm, pcm_pitch, nch, total_samples, seg, coefs, adpcm,
+    seam_piece<LPC>(blockIdx.x * (64 / LPC) + (threadIdx.x / LPC), blockIdx.y + 1, threadIdx.x, pcm, pcm_pitch, nch, total_samples, seg, coefs, adpcm,
                adpcm_pitch, seg_state, first_open, seam_flag, seam_end, force_open, rg);
 }
 
@@ -1108,10 +1157,10 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
             if (wave < SW) {
                 const int slot = g * CS + wave * CPW + (lane >> 3);
                 if (seam_a)
-                    seam_piece(slot, seam_a, lane, pcm, pcm_pitch, nch, total_samples, seg, coefs, adpcm, adpcm_pitch, seg_state,
+                    seam_piece<8>(slot, seam_a, lane, pcm, pcm_pitch, nch, total_samples, seg, coefs, adpcm, adpcm_pitch, seg_state,
                                first_open, seam_flag, seam_end, force_open, rg);
                 if (seam_b)
-                    seam_piece(slot, seam_b, lane, pcm, pcm_pitch, nch, total_samples, seg, coefs, adpcm, adpcm_pitch, seg_state,
+                    seam_piece<8>(slot, seam_b, lane, pcm, pcm_pitch, nch, total_samples, seg, coefs, adpcm, adpcm_pitch, seg_state,
                                first_open, seam_flag, seam_end, force_open, rg);
             }
         }
@@ -1124,6 +1173,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
 // channel was left open too (then V is that seam's recorded end).  Only a run that is still apart at the very end of a
 // stream with a partial last frame goes to the serial repair launch (first_open[channel] = last piece; seg_state gets
 // that piece's true start), which also remains the fall-back when the scratch cannot hold the flags.
+template <int LPC>
 __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int total_samples, const Pieces seg, int segments,
     const int16_t *__restrict__ coefs, uint8_t *__restrict__ adpcm, int64_t adpcm_pitch,
@@ -1131,8 +1181,9 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
     const int *__restrict__ seam_end, int force_open, const Ragged rg)
 {
     const int lane = threadIdx.x;
-    const int pr = lane & 7;
-    const int slot_raw = blockIdx.x * 8 + (lane >> 3);
+    const int pr = LPC == 16 ? (lane >> 1) & 7 : lane & 7;
+    const bool lead = (lane & (LPC - 1)) == 0;          // one lane per channel
+    const int slot_raw = blockIdx.x * (64 / LPC) + lane / LPC;
     const bool live = slot_raw < nch;
     const int slot = live ? slot_raw : nch - 1;
     const int ch = rg.order ? rg.order[slot] : slot;
@@ -1140,9 +1191,9 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
     const int mine = live ? first_open[ch] : 0x7f7f7f7f;
     int kmin = mine;
 #pragma unroll
-    for (int o = 8; o < 64; o <<= 1) kmin = imin(kmin, __shfl_xor(kmin, o));
-    if (kmin >= segments) return;                       // no open seam among these eight channels
-    if (live && pr == 0 && mine < segments) atomicAdd(&g_vga_gc_stats[5], 1ull);
+    for (int o = LPC; o < 64; o <<= 1) kmin = imin(kmin, __shfl_xor(kmin, o));
+    if (kmin >= segments) return;                       // no open seam among this wave's channels
+    if (live && lead && mine < segments) atomicAdd(&g_vga_gc_stats[5], 1ull);
     int frames_run = 0;
     const int16_t *src = pcm + (rg.order ? rg.pcm_off[ch] : (int64_t)ch * pcm_pitch);
     uint8_t *dst = adpcm + (rg.order ? rg.adpcm_off[ch] : (int64_t)ch * adpcm_pitch);
@@ -1168,11 +1219,11 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
         int h0 = v0, h1 = v1;
         if (__any(ran)) {
             const int g2 = seg_state[idx * 2], g1 = seg_state[idx * 2 + 1];      // T: what the piece's bytes were encoded from
-            if (ran && pr == 0 && is_last) {                                     // the repair launch would start here
+            if (ran && lead && is_last) {                                     // the repair launch would start here
                 seg_state[idx * 2] = (int16_t)v0;
                 seg_state[idx * 2 + 1] = (int16_t)v1;
             }
-            seam_run(src, dst, c0, c1, coef_ok, pr, ch, k, f0, total_samples, seg.frames(k), seg.frames(k), force_open, h0, h1, g2, g1, open, frames_run);
+            seam_run<LPC>(src, dst, c0, c1, coef_ok, pr, ch, k, f0, total_samples, seg.frames(k), seg.frames(k), force_open, h0, h1, g2, g1, open, frames_run);
         }
         if (!exists) {
         } else if (ran && open) {                       // still apart at the piece's end: carry on into the next one
@@ -1188,10 +1239,10 @@ __global__ __launch_bounds__(64) void gc_encode_chain_kernel(
     // apart to the very end: only the partial last frame is left to encode from V -- here, by the channel's eight lanes (the
     // serial repair launch that used to take over re-ran the whole last piece: 4.9 ms of a 256-channel encode's 31)
     if (__any(live && have && total_samples % 14 != 0))
-        encode_tail_frame(src, dst, c0, c1, coef_ok, pr, total_samples, v0, v1, live && have && total_samples % 14 != 0);
+        encode_tail_frame<LPC>(src, dst, c0, c1, coef_ok, pr, total_samples, v0, v1, live && have && total_samples % 14 != 0);
     (void)last_k;
-    if (live && pr == 0 && frames_run) atomicAdd(&g_vga_gc_stats[2], (unsigned long long)frames_run);
-    if (live && pr == 0) first_open[ch] = 0x7f7f7f7f;
+    if (live && lead && frames_run) atomicAdd(&g_vga_gc_stats[2], (unsigned long long)frames_run);
+    if (live && lead) first_open[ch] = 0x7f7f7f7f;
 }
 
 // A piece must be longer than the slowest seam of the batch takes to close, or that channel's seams all stay open and the
@@ -1373,15 +1424,31 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
     VGA_HIP_TRY(hipGetLastError());
     if (segments > 1) {
         if (!persistent) {                             // (the persistent workgroups close the seams themselves)
-            hipLaunchKernelGGL(gc_encode_seam_kernel, dim3((nch + 7) / 8, segments - 1), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
-                               sample_count, seg, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
-                               force_open_seams(), rg);
+            // The seam runs in the lane-per-candidate layout (seam_run<16>) where the launch lasts as long as its slowest seam
+            // and a batch is likely to hold one: more than 64 channels of the encoder's CPW = 4 layout.  Measured at 60 s per
+            // channel (profiles/r06_m_channel_scaling.log): 96 channels 18.3 -> 16.4 ms (seam launch 4.8 + chain 4.6 ms, the
+            // synthetic set's slow-closing tone among them), 256: 23.2 -> 23.4, 384: 25.5 -> 25.1; 1 / 8 / 64 channels lose
+            // 0.2-0.4 ms (3.06 -> 3.47, 3.48 -> 3.84, 6.79 -> 7.00) and keep the lane-per-predictor runs.
+            const bool wide = CPW == 4 && nch > 64;
+            if (wide)
+                hipLaunchKernelGGL(gc_encode_seam_kernel<16>, dim3((nch + 3) / 4, segments - 1), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
+                                   sample_count, seg, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
+                                   force_open_seams(), rg);
+            else
+                hipLaunchKernelGGL(gc_encode_seam_kernel<8>, dim3((nch + 7) / 8, segments - 1), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
+                                   sample_count, seg, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
+                                   force_open_seams(), rg);
             VGA_HIP_TRY(hipGetLastError());
         }
         // the seams that were still open at the end of their piece, chained piece after piece (none: every wave returns)
-        hipLaunchKernelGGL(gc_encode_chain_kernel, dim3((nch + 7) / 8), dim3(64), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
-                           seg, segments, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
-                           force_open_seams(), rg);
+        if (CPW == 4 && nch > 64)
+            hipLaunchKernelGGL(gc_encode_chain_kernel<16>, dim3((nch + 3) / 4), dim3(64), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
+                               seg, segments, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
+                               force_open_seams(), rg);
+        else
+            hipLaunchKernelGGL(gc_encode_chain_kernel<8>, dim3((nch + 7) / 8), dim3(64), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
+                               seg, segments, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
+                               force_open_seams(), rg);
         VGA_HIP_TRY(hipGetLastError());
         // repair: the same encoder, serially over the last piece, for a channel the chain could not finish (a partial
         // last frame after a run that never met; none: every workgroup returns)
