@@ -913,7 +913,10 @@ __device__ __forceinline__ void seam_run(const int16_t *__restrict__ src, uint8_
             const bool rare_mine = !coef_ok || (unsigned)r.max_overflow > (cap ? 3u : 248u);
             const int eff = cap ? 0 : r.max_overflow;
             const int eff_other = dpp<DPP_QUAD_XOR1>(eff);
-            const bool rare = rare_mine || dpp<DPP_QUAD_XOR1>(rare_mine ? 1 : 0) != 0;
+            // (the exchange on its own line: behind `rare_mine ||` it would run only in the lanes whose own flag is clear, and
+            // read their partners -- the lanes it is there to hear from -- as inactive)
+            const int rare_other = dpp<DPP_QUAD_XOR1>(rare_mine ? 1 : 0);
+            const bool rare = rare_mine || rare_other != 0;
             const int eff_a = cand_b ? eff_other : eff, eff_b = cand_b ? eff : eff_other;
             const bool fin_a = eff_a < 2;
             const bool resume = !fin_a && eff_b >= 2;
@@ -1429,7 +1432,11 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
             // channel (profiles/r06_m_channel_scaling.log): 96 channels 18.3 -> 16.4 ms (seam launch 4.8 + chain 4.6 ms, the
             // synthetic set's slow-closing tone among them), 256: 23.2 -> 23.4, 384: 25.5 -> 25.1; 1 / 8 / 64 channels lose
             // 0.2-0.4 ms (3.06 -> 3.47, 3.48 -> 3.84, 6.79 -> 7.00) and keep the lane-per-predictor runs.
+#ifdef VGA_GC_SEAM16_ALWAYS                                          // (debug builds)
+            const bool wide = CPW == 4;
+#else
             const bool wide = CPW == 4 && nch > 64;
+#endif
             if (wide)
                 hipLaunchKernelGGL(gc_encode_seam_kernel<16>, dim3((nch + 3) / 4, segments - 1), dim3(64), 0, stream, d_pcm, pcm_pitch, nch,
                                    sample_count, seg, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
@@ -1441,7 +1448,11 @@ static int launch_encode_layout(const int16_t *d_pcm, int64_t pcm_pitch, int nch
             VGA_HIP_TRY(hipGetLastError());
         }
         // the seams that were still open at the end of their piece, chained piece after piece (none: every wave returns)
+#ifdef VGA_GC_SEAM16_ALWAYS
+        if (CPW == 4)
+#else
         if (CPW == 4 && nch > 64)
+#endif
             hipLaunchKernelGGL(gc_encode_chain_kernel<16>, dim3((nch + 3) / 4), dim3(64), 0, stream, d_pcm, pcm_pitch, nch, sample_count,
                                seg, segments, d_coefs, d_adpcm, adpcm_pitch, seg_state, first_open, seam_flag, seam_end,
                                force_open_seams(), rg);
