@@ -179,7 +179,11 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     // Round 6: page-locked rows travel by transfer kernels (transfer_kernels.hip) on sixteen compute units of their own -- a
     // ragged call's 10 008 uploads no longer leave the copy engine idle between rows.  Calls of at least 256 MB only: below,
     // the rows are few and the masked streams' two rounds of persistent workgroups cost more than the copies' gaps.
-    if (o.transfer == 0 && in_total + out_total >= ((size_t)256 << 20)) {
+    // And only where the rows are many for their bytes: the copy engine loses ~11 us per row, the kernels ~30 ms per call
+    // (sixteen compute units less for the call's own kernels, the link shared with the scatter) -- the 4096 rows of 5.8 MB of
+    // configs[1]'s equal-length call are better off with a copy each (519-535 ms against 590), the 10 008 files of a ragged
+    // batch (2.4 MB on average) with the kernels (597 -> 556 ms): rows under 4 MB on average.
+    if (o.transfer == 0 && in_total + out_total >= ((size_t)256 << 20) && in_row_typical < ((size_t)4 << 20)) {
         job.transfer = [](const pipe::Job::TransferPiece *pieces, int n, hipStream_t s, std::string &why) -> int {
             const int rc = launch_transfer(pieces, n, s);
             if (rc) why = vga_last_error();
