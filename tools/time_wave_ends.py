@@ -46,6 +46,8 @@ def main():
     t0 = t[:, 0].min()
     print(json.dumps({"kernel": "gc_coefs_kernel", "waves": int(t.shape[0]), "start_ms": dist(t[:, 0] - t0), "pass0_end_ms": dist(t[:, 1] - t0),
                       "end_ms": dist(t[:, 2] - t0), "life_ms": dist(t[:, 2] - t[:, 0])}))
+    if not hasattr(raw, "vga_debug_encode_timestamps"):     # a build of gcadpcm_kernels.hip only
+        return
     out = vdev.alloc_adpcm(nch, n, dev)
     L.vga_testing_gc_encoder_persistent_this_thread(a.persistent)
     L.vga_testing_gc_encoder_segments_this_thread(a.pieces)

@@ -324,7 +324,7 @@ size_t vga_gcadpcm_coefs_workspace_bytes(int nch, int length)
 {
     if (nch <= 0 || length < 0) return 0;
     const size_t frames = ((size_t)length + 13) / 14;
-    return (size_t)nch * (frames ? frames : 1) * 16;
+    return (size_t)nch * (size_t)vga::gc::coef_record_pitch((int64_t)frames) * 16;
 }
 
 static int check_pcm_layout(const void *p, int64_t pitch, int n, const char *what)

@@ -60,7 +60,7 @@ struct RaggedShape {
             const int64_t frames = ((int64_t)length[c] + 13) / 14;
             pcm_base += round_up(length[c], 8);
             adpcm_base += round_up(vga_gcadpcm_sample_count_to_byte_count(length[c]), 16);
-            records += frames ? frames : 1;
+            records += vga::gc::coef_record_pitch(frames);
             total_frames += frames;
             max_length = std::max(max_length, length[c]);
             uniform = uniform && length[c] == length[0];

@@ -106,6 +106,15 @@ extern "C" int vga_testing_gc_encode_stats(unsigned long long *out8, int reset)
 }
 constexpr int SW = 2;              // encoder (serial) waves per workgroup; one helper wave serves them all
 constexpr int ENC_THREADS = 64 * (SW + 1);
+// issue priorities (s_setprio) of the encoder waves and of the helper wave.  Round 6 (profiles/r06_t_encode_priority*.log):
+// helper at 1 or 2, or at priorities that differ between the helpers of a SIMD (by wave slot, rotating per piece or per
+// tile): 143.7-144.9 ms against 144.0-144.4; helper at 3: 148.5; encoder waves below the helper: 150 ms.
+#ifndef VGA_GC_ENCODER_PRIO
+#define VGA_GC_ENCODER_PRIO 3
+#endif
+#ifndef VGA_GC_HELPER_PRIO
+#define VGA_GC_HELPER_PRIO 0
+#endif
 // Two lane layouts of the encoder wave (template parameter CPW = channels per encoder wave):
 //   CPW = 4: lane = (channel, predictor, scale candidate A/B) -- the candidates of the retry loop run side by side;
 //   CPW = 8: lane = (channel, predictor) -- candidate B (s1 + 1) and candidate A (s1) run one after the other in the
@@ -316,6 +325,7 @@ __device__ __forceinline__ void gc_encode_piece(
 
     if (helper) {
         // ---------------------------------------------------------------- helper wave
+        __builtin_amdgcn_s_setprio(VGA_GC_HELPER_PRIO);
         uint32_t cpk[8];                               // (c1, c0) of predictor p as a packed pair: low half c1
 #pragma unroll
         for (int p = 0; p < 8; p++)
@@ -415,7 +425,7 @@ __device__ __forceinline__ void gc_encode_piece(
     }
 
     // -------------------------------------------------------------------- serial (encoder) wave
-    __builtin_amdgcn_s_setprio(3);                     // its latency is the kernel's run time: win every issue arbitration
+    __builtin_amdgcn_s_setprio(VGA_GC_ENCODER_PRIO);   // its latency is the kernel's run time: win every issue arbitration
     int p = CPW == 4 ? l16 >> 1 : l16;
     const bool cand_b = CPW == 4 && (l16 & 1) != 0;
     const int c0 = coefs[ch * 16 + 2 * p];

@@ -68,18 +68,19 @@ __device__ __forceinline__ FrameSums frame_sums(const int (&x)[16])
 // Every value is an exact integer below 2^53, so the f64 additions are exact in any order.  A pair sum can
 // be +2^31 (two products of -32768 * -32768): the accumulator input -1 keeps it inside int32.
 typedef short short2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double dot2_f64(uint32_t a, uint32_t b)
+__device__ __forceinline__ int dot2_less1(uint32_t a, uint32_t b)
 {
-    return (double)__builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), -1, false) + 1.0;
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), -1, false);
 }
 __device__ __forceinline__ FrameSums frame_sums_packed(const uint32_t (&w)[8])
 {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    // every term is (pair sum - 1): the seven missing ones are added back at the end (exact integers throughout)
+    double s0 = 7.0, s1 = 7.0, s2 = 7.0;
 #pragma unroll
     for (int i = 0; i < 7; i++) {
-        s0 += dot2_f64(w[i + 1], w[i + 1]);
-        s1 += dot2_f64(w[i], __builtin_amdgcn_alignbit(w[i + 1], w[i], 16));
-        s2 += dot2_f64(w[i], w[i + 1]);
+        s0 += (double)dot2_less1(w[i + 1], w[i + 1]);
+        s1 += (double)dot2_less1(w[i], __builtin_amdgcn_alignbit(w[i + 1], w[i], 16));
+        s2 += (double)dot2_less1(w[i], w[i + 1]);
     }
     const int x0 = (int)(int16_t)(w[0] & 0xFFFF), x1 = (int)w[0] >> 16;
     const int x14 = (int)(int16_t)(w[7] & 0xFFFF), x15 = (int)w[7] >> 16;
@@ -298,6 +299,29 @@ __device__ __forceinline__ int lane_rank(uint64_t mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
+// Exclusive prefix sum over the wave's lanes of a word of 8-bit fields (no field of the result may pass 255): the lane
+// totals move up one lane (wave_shr:1), then Hillis-Steele inside each 16-lane row and the row totals handed on.
+__device__ __forceinline__ uint32_t scan_fields(uint32_t v)
+{
+    uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0: + 0)
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);            // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);            // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);            // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);            // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);            // row_bcast:15 into rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);            // row_bcast:31 into rows 2, 3
+    return x;
+}
+__device__ __forceinline__ uint64_t scan_fields(uint64_t v)
+{
+    return (uint64_t)scan_fields((uint32_t)v) | ((uint64_t)scan_fields((uint32_t)(v >> 32)) << 32);
+}
+__device__ __forceinline__ uint32_t last_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ __forceinline__ uint64_t last_lane(uint64_t v)
+{
+    return (uint64_t)last_lane((uint32_t)v) | ((uint64_t)last_lane((uint32_t)(v >> 32)) << 32);
+}
+
 // acc += sd[0] + sd[1] + ... + sd[n-1], strictly in that order (the reference's running sums are
 // order-dependent f64 adds, GcAdpcmCoefficients.cs:68-71 / :374-380).  sd is the 64-byte aligned start of a
 // bucket whose slots n .. ceil8(n)-1 hold +0.0 (adding +0.0 leaves a sum that started at +0.0 unchanged bit
@@ -333,9 +357,6 @@ extern "C" int vga_debug_coefs_timestamps(unsigned long long *out, int n)
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vga_coef_ts), (size_t)n * sizeof(unsigned long long));
 }
 #endif
-#ifndef VGA_COEFS_PF_REC
-#define VGA_COEFS_PF_REC 2
-#endif
 // timing-only ablations for tools/build_variants.sh (wrong results): 1 = no ordered sums in the Lloyd passes, 2 = no
 // nearest-codeword evaluation, 4 = no partition (every record to bucket 0's slots), 8 = pass 0 without the record
 // arithmetic, 16 = pass 0 without its ordered sum, 32 = no Lloyd passes at all
@@ -346,7 +367,6 @@ extern "C" int vga_debug_coefs_timestamps(unsigned long long *out, int n)
 #define VGA_COEFS_PF_PCM 1
 #endif
 constexpr int COEF_PF_PCM = VGA_COEFS_PF_PCM;      // chunks of PCM in flight per wave in pass 0
-constexpr int COEF_PF_REC = VGA_COEFS_PF_REC;
 // Lloyd passes: records per chunk of the one-wave-per-channel kernel, in units of 64.  K x 64: every lane classifies K
 // records, the stable partition takes the K groups in record order, the ordered sums run over up to 64 K records per
 // bucket -- the per-chunk costs (loop, LDS fill, hand-over) are paid once per 64 K records and the sums' batches of eight
@@ -355,6 +375,45 @@ constexpr int COEF_PF_REC = VGA_COEFS_PF_REC;
 #define VGA_COEFS_CHUNKS 4
 #endif
 constexpr int COEF_K = VGA_COEFS_CHUNKS;
+static_assert(COEF_K >= 1 && COEF_K <= 4 && COEF_RECORD_BLOCK % (64 * COEF_K) == 0, "the partition's 8-bit fields hold 63 K + K - 1");
+// Where pass 0 stores record f: inside every block of 64 K records the Lloyd passes' lane l owns records K l .. K l + K - 1
+// (lane-major order: one scan ranks the block), and their k-th load reads positions 64 k + l -- coalesced.
+__device__ __forceinline__ int record_position(int f)
+{
+    const int j = f % (64 * COEF_K);
+    return f - j + 64 * (j % COEF_K) + j / COEF_K;
+}
+
+// Issue priority of the four waves a SIMD holds (round 6).  The arbiter serves the oldest wave first: at equal priorities
+// the waves of one SIMD left pass 0 between 6 and 22 ms and ended between 15 and 35 ms, the last one running alone at two
+// thirds of the four-wave rate (LABNOTES 8.2 d, profiles/r06_s_coefs_wave_ends.log).  VGA_COEFS_PRIO:
+//   0: no priorities                                                              35.1 ms at configs[1]
+//   1: priorities rotate with the wall clock (wave slot + epoch of 2^SHIFT x 10 ns)  31.4-31.8 ms
+//   3: priority by pass (pass 0: 3, two codewords: 2, four: 1, eight: 0) -- a wave that is ahead yields  30.7-31.0 ms
+// Also measured and removed: the ordered sums at priority 3 and everything else at 0 (35.0 against 37.2 before the scan
+// partition, does not add to the others); the steps one pass later (3 3 2 2 1 1 0): 31.0; priority from the progress
+// through the whole job with steps that shrink towards the end (1/1024 units from the ISA's instruction counts,
+// thresholds 440/711/911, 532/798/960, 600/850/975, 300/624/900): 30.5-31.0 -- the waves still end between 22.3 and
+// 30.7 ms (p95 28.5), what is left is not the order inside a SIMD (profiles/r06_s_coefs_priority_maps*.log).
+#ifndef VGA_COEFS_PRIO
+#define VGA_COEFS_PRIO 3
+#endif
+#ifndef VGA_COEFS_PRIO_SHIFT
+#define VGA_COEFS_PRIO_SHIFT 13
+#endif
+__device__ __forceinline__ void set_priority(uint32_t p)
+{
+    switch (p & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+__device__ __forceinline__ void rotate_priority(uint32_t slot)
+{
+    if (VGA_COEFS_PRIO == 1) set_priority(slot + (uint32_t)(wall_clock64() >> VGA_COEFS_PRIO_SHIFT));
+}
 constexpr int COEF_SLOTS = (64 * COEF_K + 56 + 63) / 64 * 64;   // 64 K + 8 x 7 slots of padding, a multiple of 64      // chunks of records in flight per wave in the Lloyd passes
 
 __global__ __launch_bounds__(64) void gc_coefs_kernel(
@@ -380,9 +439,13 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     const int lane = threadIdx.x;
     const int16_t *src = pcm + (rg.order ? rg.pcm_off[ch] : (int64_t)ch * pcm_pitch);
     const int frames = (length + 13) / 14;
-    double2 *rec = records + (rg.order ? rg.rec_off[ch] : (int64_t)ch * frames);
+    const int rec_pitch = (int)coef_record_pitch(frames);
+    double2 *rec = records + (rg.order ? rg.rec_off[ch] : (int64_t)ch * rec_pitch);
     const int my_bucket = lane >> 1;   // accumulator lanes: lane < 16
     const int my_comp = lane & 1;
+    uint32_t wave_slot = 0;
+    if (VGA_COEFS_PRIO == 1) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(wave_slot));
+    if (VGA_COEFS_PRIO == 3) __builtin_amdgcn_s_setprio(3);
 
     // one wave: its LDS operations execute in program order, so the fill needs no barrier before the writes
     auto zero_fill = [&](int par) {
@@ -440,7 +503,7 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
             // passes need -- ContrastVectors' `val` (:335-342) is the same expression as mtx[1][1] = dst[1]
             // (:295-296) and its second term, -r1*val + -r2, the same as dst[2] (sign flips are exact; a
             // -0.0 / +0.0 difference cannot change a comparison or a sum that started at +0.0).
-            rec[f] = valid ? make_double2(d1, d2) : make_double2(__builtin_nan(""), 0.0);
+            rec[record_position(f)] = valid ? make_double2(d1, d2) : make_double2(__builtin_nan(""), 0.0);
         }
         const uint64_t mask = __ballot(valid);
         const int n = __popcll(mask);
@@ -452,6 +515,7 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
         }
         wave_lds_sync();
         if (lane < 2 && !(VGA_COEFS_ABLATE & 16)) acc = ordered_sum(acc, p0(par, lane), n, n);
+        rotate_priority(wave_slot);
         cnt += n;
         par ^= 1;
     };
@@ -489,6 +553,7 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     auto lloyd_iterations = [&](auto exp_c) {
         constexpr int EXP = decltype(exp_c)::value;
         for (int iter = 0; iter < 2; iter++) {
+            if (VGA_COEFS_PRIO == 3) set_priority(EXP == 2 ? 2 : (EXP == 4 ? 1 : 0));
             if (lane < EXP) {
                 const double a = s_vb[lane][0], b = s_vb[lane][1], c = s_vb[lane][2];
                 s_cw[lane][0] = (a * a) + (b * b) + (c * c);
@@ -506,64 +571,16 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
 
             acc = 0.0;
             cnt = 0;
-            // record prefetch, COEF_PF_REC chunks ahead (a ring of registers; the chunk loop is unrolled by the ring's
-            // length so that the ring is indexed statically).  The loads are unconditional (clamped index): a load
-            // under a lane-divergent condition makes the compiler wait for it right at the join.
-            double2 ring[COEF_PF_REC];
-#pragma unroll
-            for (int q = 0; q < COEF_PF_REC; q++) ring[q] = rec[max(min(lane + 64 * q, frames - 1), 0)];   // (an empty channel still owns one slot)
-            auto lloyd_chunk = [&](int base, const double2 r) __attribute__((always_inline)) {
-                const int f = base + lane;
-                bool valid = false;
-                int idx = 0;
-                double d1 = 0.0, d2 = 0.0;
-                if (f < frames && r.x == r.x) {
-                    valid = true;
-                    // r = (dst[1], dst[2]) of MatrixFilter, stored by pass 0 (one f64 divide per frame there,
-                    // none here)
-                    const double val_x2 = 2.0 * r.x, bterm_x2 = 2.0 * r.y;
-                    double value = 1.0e30;
-                    if (!(VGA_COEFS_ABLATE & 2)) {
-#pragma unroll
-                    for (int i = 0; i < EXP; i++) {
-                        const double t = cw1[i] + (val_x2 * cw2[i]) + (bterm_x2 * cw3[i]);
-                        if (t < value) { value = t; idx = i; }
-                    }
-                    } else idx = (int)(__double_as_longlong(val_x2) >> 40) & (EXP - 1);
-                    d1 = r.x;
-                    d2 = r.y;
-                }
-                // stable partition by bucket
-                int slot = 0, my_start = 0, my_n = 0, start = 0, max_n = 0;
-#pragma unroll
-                for (int b = 0; b < ((VGA_COEFS_ABLATE & 4) ? 1 : EXP); b++) {
-                    const bool mine = valid && idx == b;
-                    const uint64_t m = __ballot(mine);
-                    const int n_b = __popcll(m);
-                    if (mine) slot = start + lane_rank(m);
-                    if (my_bucket == b) { my_start = start; my_n = n_b; }
-                    start += (n_b + 7) & ~7;
-                    max_n = max(max_n, n_b);
-                }
-                zero_fill(par);
-                if (valid) {
-                    p0(par, 0)[slot] = d1;
-                    p0(par, 1)[slot] = d2;
-                }
-                wave_lds_sync();
-                if (lane < 2 * EXP && !(VGA_COEFS_ABLATE & 1)) {
-                    acc = ordered_sum(acc, p0(par, my_comp) + my_start, my_n, max_n);
-                    cnt += my_n;
-                }
-                par ^= 1;
-            };
             auto classify = [&](int f, const double2 r, bool &valid, int &idx) __attribute__((always_inline)) {
                 valid = false;
                 idx = 0;
                 if (f < frames && r.x == r.x) {
                     valid = true;
+                    // r = (dst[1], dst[2]) of MatrixFilter, stored by pass 0 (one f64 divide per frame there, none here)
                     const double val_x2 = 2.0 * r.x, bterm_x2 = 2.0 * r.y;
                     double value = 1.0e30;
+                    if (VGA_COEFS_ABLATE & 2) idx = (int)(__double_as_longlong(val_x2) >> 40) & (EXP - 1);
+                    else {
 #pragma unroll
                     for (int i = 0; i < EXP; i++) {
                         const double t = cw1[i] + (val_x2 * cw2[i]) + (bterm_x2 * cw3[i]);
@@ -573,29 +590,35 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
                         idx = t < value ? i : idx;
                         asm("v_min_f64 %0, %1, %2" : "=v"(value) : "v"(value), "v"(t));
                     }
+                    }
                 }
             };
-            // K chunks at once: lane = records base + 64 k + lane, k = 0 .. K-1
+            // One chunk = 64 K records, record base + K lane + k in r[k] (pass 0 stored them so that this is a coalesced
+            // load, see record_position).  Stable partition by bucket: every lane adds a one-hot word of 8-bit fields per
+            // record (its own K records in order), ONE exclusive scan over the lanes ranks all 64 K records in all
+            // buckets at once (fields <= 63 K + K - 1 <= 255), the last lane's words give the bucket sizes.
+            // (round 6; before: a ballot + mbcnt per bucket and group of 64, 6 VALU + 4 SALU x EXP x K per chunk)
+            using Fields = std::conditional_t<(EXP > 4), uint64_t, uint32_t>;
+            auto field = [](Fields w, int i) __attribute__((always_inline)) { return (int)((w >> (8 * i)) & 0xFF); };
             auto lloyd_chunks = [&](int base, const double2 (&r)[COEF_K]) __attribute__((always_inline)) {
                 bool v[COEF_K];
-                int ix[COEF_K], slot[COEF_K];
+                int ix[COEF_K];
+                Fields before[COEF_K], mine = 0;
 #pragma unroll
                 for (int k = 0; k < COEF_K; k++) {
-                    classify(base + 64 * k + lane, r[k], v[k], ix[k]);
-                    slot[k] = 0;
+                    classify(base + COEF_K * lane + k, r[k], v[k], ix[k]);
+                    if (VGA_COEFS_ABLATE & 4) ix[k] = 0;
+                    before[k] = mine;
+                    mine += v[k] ? (Fields)1 << (8 * ix[k]) : (Fields)0;
                 }
-                int my_start = 0, my_n = 0, start = 0, max_n = 0;
+                const Fields lower = scan_fields(mine);                    // the lanes below this one
+                const Fields lower63 = last_lane(lower), mine63 = last_lane(mine);
+                int start = 0, max_n = 0;
+                Fields starts = 0;                                         // bucket starts / 8
 #pragma unroll
                 for (int b = 0; b < EXP; b++) {
-                    int n = 0;
-#pragma unroll
-                    for (int k = 0; k < COEF_K; k++) {                     // record order: group 0's records first
-                        const bool mine = v[k] && ix[k] == b;
-                        const uint64_t mask = __ballot(mine);
-                        if (mine) slot[k] = start + n + lane_rank(mask);
-                        n += __popcll(mask);
-                    }
-                    if (my_bucket == b) { my_start = start; my_n = n; }
+                    const int n = field(lower63, b) + field(mine63, b);    // (<= 256: two terms, a field holds 255)
+                    starts |= (Fields)(start >> 3) << (8 * b);
                     start += (n + 7) & ~7;
                     max_n = max(max_n, n);
                 }
@@ -603,38 +626,31 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
 #pragma unroll
                 for (int k = 0; k < COEF_K; k++)
                     if (v[k]) {
-                        ll(0)[slot[k]] = r[k].x;
-                        ll(1)[slot[k]] = r[k].y;
+                        const int slot = 8 * field(starts, ix[k]) + field(lower + before[k], ix[k]);
+                        ll(0)[slot] = r[k].x;
+                        ll(1)[slot] = r[k].y;
                     }
                 wave_lds_sync();
-                if (lane < 2 * EXP) {
-                    acc = ordered_sum(acc, ll(my_comp) + my_start, my_n, max_n);
+                        if (lane < 2 * EXP && !(VGA_COEFS_ABLATE & 1)) {
+                    const int my_n = field(lower63, my_bucket) + field(mine63, my_bucket);
+                    acc = ordered_sum(acc, ll(my_comp) + 8 * field(starts, my_bucket), my_n, max_n);
                     cnt += my_n;
                 }
+                        rotate_priority(wave_slot);
             };
-            if (COEF_K > 1) {
-                double2 nxt[COEF_K];
+            // record prefetch, one chunk (K loads) ahead.  The loads are unconditional (every position below rec_pitch
+            // exists): a load under a lane-divergent condition makes the compiler wait for it right at the join.
+            double2 nxt[COEF_K];
 #pragma unroll
-                for (int k = 0; k < COEF_K; k++) nxt[k] = rec[max(min(lane + 64 * k, frames - 1), 0)];
-                for (int base = 0; base < frames; base += 64 * COEF_K) {
-                    double2 cur[COEF_K];
+            for (int k = 0; k < COEF_K; k++) nxt[k] = rec[lane + 64 * k];
+            for (int base = 0; base < frames; base += 64 * COEF_K) {
+                double2 cur[COEF_K];
 #pragma unroll
-                    for (int k = 0; k < COEF_K; k++) {
-                        cur[k] = nxt[k];
-                        nxt[k] = rec[min(base + 64 * (COEF_K + k) + lane, frames - 1)];    // in flight during this chunk
-                    }
-                    lloyd_chunks(base, cur);
+                for (int k = 0; k < COEF_K; k++) {
+                    cur[k] = nxt[k];
+                    nxt[k] = rec[min(base + 64 * (COEF_K + k) + lane, rec_pitch - 1)];    // in flight during this chunk
                 }
-            } else
-            for (int base = 0; base < frames; base += 64 * COEF_PF_REC) {
-#pragma unroll
-                for (int q = 0; q < COEF_PF_REC; q++) {
-                    if (base + 64 * q < frames) {                    // wave-uniform
-                        const double2 r = ring[q];
-                        ring[q] = rec[min(base + 64 * (q + COEF_PF_REC) + lane, frames - 1)];   // in flight during the next COEF_PF_REC chunks
-                        lloyd_chunk(base + 64 * q, r);
-                    }
-                }
+                lloyd_chunks(base, cur);
             }
             __syncthreads();
             if (lane < 2 * EXP) {
@@ -979,7 +995,9 @@ __global__ __launch_bounds__(256) void synth_kernel(int16_t *__restrict__ pcm, i
 }
 
 // ---------------------------------------------------------------- launchers
-constexpr int SOLO_MAX_CHANNELS = 896;                      // 768 channels: 15.2 vs 19.2 ms, 1024: 24.1 vs 19.2 (profiles/r03_d_coefs_variants.log)
+// five waves on ONE channel (gc_coefs_kernel4<true>) up to three workgroups per CU: 768 channels 15.0 against 18.5 ms for
+// one wave per channel, 896: 22.7 against 18.3 (profiles/r06_u_coefs_variants_small.log)
+constexpr int SOLO_WORKGROUPS_PER_CU = 3;
 
 int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, int16_t *d_coefs,
                  void *d_workspace, hipStream_t stream, const Ragged *rg)
@@ -992,17 +1010,13 @@ int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, i
         VGA_HIP_TRY(hipGetLastError());
         return VGA_OK;
     }
-    // One wave per channel is the faster kernel only when it fills the chip (4 waves per SIMD at 4096 channels: 41.7 vs
-    // 43.1 ms for 60 s channels); with fewer channels the workgroups of four channels + summing wave win, because a chunk
-    // costs max(records, sums) instead of their sum: 3072 channels 31.1 vs 34.4 ms, 2048: 24.7 vs 28.3, 1024: 19.1 vs
-    // 23.9, one channel: 15.7 vs 18.6 (tools/time_coefs_variants.py, profiles/r02_c_coefs_variants.log).  A third variant
-    // -- the same roles with the chunks handed over through a ring of LDS slots and producer / consumer counters instead
-    // of a workgroup barrier per chunk -- was measured at 70 ms (polling LDS counters costs more than the barriers) and
-    // dropped.
-    // Round 3: below VGA_SOLO_MAX channels the five waves work on ONE channel (SOLO, see the kernel).
+    // Rounds 2-5: workgroups of four channels + a summing wave (gc_coefs_kernel4<false>) between the two, because a chunk
+    // costs them max(records, sums) instead of the sum.  Since round 6 (scan partition, priorities by pass) one wave per
+    // channel is faster at every size: 4096 channels 31.6 against 43.0 ms, 3072: 26.3 / 30.5, 1024: 18.6 / 18.9, 128:
+    // 16.6 / 18.4 (profiles/r06_u_coefs_variants.log); the four-channel form stays behind the test hook (variant 2).
     const int variant = coefs_kernel_variant();
-    const bool per_channel = variant == 1 || (variant == 0 && nch > device_cu_count() * 14);
-    const bool solo = variant == 3 || (variant == 0 && nch <= SOLO_MAX_CHANNELS);
+    const bool solo = variant == 3 || (variant == 0 && nch <= device_cu_count() * SOLO_WORKGROUPS_PER_CU);
+    const bool per_channel = variant == 1 || (variant == 0 && !solo);
     if (per_channel)
         hipLaunchKernelGGL(gc_coefs_kernel, dim3(nch), dim3(64), 0, stream, d_pcm, pcm_pitch, nch, length,
                            reinterpret_cast<double2 *>(d_workspace), d_coefs, Ragged{});

@@ -42,6 +42,14 @@ struct Ragged {
     int64_t total_frames = 0;           // host-side copy: sum of ceil(length / 14)
 };
 
+// Records of the coefficient search (workspace): a channel of `frames` frames owns coef_record_pitch(frames) slots of 16
+// bytes -- whole blocks of 256, inside which gc_coefs_kernel permutes the records (record_position, gcadpcm_kernels.hip).
+constexpr int COEF_RECORD_BLOCK = 256;
+__host__ __device__ inline int64_t coef_record_pitch(int64_t frames)
+{
+    return (frames > 0 ? frames + COEF_RECORD_BLOCK - 1 : COEF_RECORD_BLOCK) / COEF_RECORD_BLOCK * COEF_RECORD_BLOCK;
+}
+
 // rg != nullptr: pcm_pitch / length (sample_count) are ignored, d_pcm / d_adpcm are the bases the offsets count from
 int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, int16_t *d_coefs,
                  void *d_workspace, hipStream_t stream, const Ragged *rg = nullptr);
