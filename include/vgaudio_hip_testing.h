@@ -77,6 +77,9 @@ void vga_testing_buckets_order_this_thread(int order);
 /* Page-locked rows of the host-pointer entry points: 0 (default) = moved by transfer kernels on compute units reserved for
  * them (calls of 256 MB and more), 1 = one hipMemcpyAsync per row as until round 5 -- for calls made from the calling thread. */
 void vga_testing_host_transfer_this_thread(int mode);
+/* Compute streams of the host-pointer entry points' pipeline (chunk k's kernels on stream k % lanes, at most 4): 0 = the
+ * entry point's own choice -- for calls made from the calling thread (timing comparisons; results must not depend on it). */
+void vga_testing_host_compute_lanes_this_thread(int lanes);
 
 /* Where the wall time of the calling thread's last pipelined call went, in seconds (diagnostics for bench.py's e2e
  * block): [0] total [1] set-up [2] feeders' memcpy (sum over threads) [3] feeders waiting for a ring slot [4] feeders

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--feeders", type=int, nargs="+", default=[0], help="feeder threads (0: the pipeline's one; negative: a stream each)")
     ap.add_argument("--chunk-units", type=int, nargs="+", default=[0], help="largest number of units in a chunk (0: the entry point's 1024)")
     ap.add_argument("--transfer", type=int, nargs="+", default=[0], help="page-locked rows: 0 = by transfer kernels (round 6), 1 = one copy per row")
+    ap.add_argument("--lanes", type=int, nargs="+", default=[0], help="compute streams of the pipeline (0: the entry point's choice)")
     args = ap.parse_args()
     import torch
     from vgaudio_amd import _lib as lib, device as vdev
@@ -69,8 +70,9 @@ def main():
 
     def run(name, call, outs):
         keep = {}
-        for shortest_first, units, feeders, transfer in [(o, u, f, t) for t in args.transfer for f in args.feeders for u in args.chunk_units for o in args.orders] * 2:
+        for shortest_first, units, feeders, transfer, lanes in [(o, u, f, t, cl) for cl in args.lanes for t in args.transfer for f in args.feeders for u in args.chunk_units for o in args.orders] * 2:
             L.vga_testing_host_transfer_this_thread(transfer)
+            L.vga_testing_host_compute_lanes_this_thread(lanes)
             L.vga_testing_buckets_order_this_thread(1 if shortest_first else 2)
             L.vga_testing_host_pipeline_this_thread(feeders, 0, units, 0)
             try:
@@ -89,10 +91,12 @@ def main():
                 L.vga_testing_buckets_order_this_thread(0)
                 L.vga_testing_host_pipeline_this_thread(0, 0, 0, 0)
                 L.vga_testing_host_transfer_this_thread(0)
+                L.vga_testing_host_compute_lanes_this_thread(0)
             b = {k: (int(st[i]) if 13 <= i <= 16 else round(st[i] * 1e3, 1)) for i, k in enumerate(NAMES[:nf])}
             digest = [hash(o.tobytes()) for o in outs[::97]] + [int(sum(int(o[:64].sum()) for o in outs))]
             tag = "shortest first" if shortest_first else "longest first "
             tag += " transfer kernels" if transfer == 0 else " a copy per row  "
+            tag += f" lanes {lanes}"
             print(f"{name} {tag} units/chunk<={units or 1024:5d} feeders {feeders:2d} {best * 1e3:7.1f} ms   upload (slowest feeder) {b['slowest_feeder']:6.1f}  after it "
                   f"{b['total'] - b['slowest_feeder']:6.1f}  chunks {b['chunks']}  drainers' memcpy {b['drainers_memcpy']:6.1f}  "
                   f"feeders' issue {b['feeders_issue']:6.1f}" + ("   every call: " + ", ".join(every) if args.reps > 2 else ""), flush=True)

@@ -169,6 +169,7 @@ SIGNATURES = {
     "vga_testing_host_pipeline_tail_this_thread": (None, [ci]),
     "vga_testing_buckets_order_this_thread": (None, [ci]),
     "vga_testing_host_transfer_this_thread": (None, [ci]),
+    "vga_testing_host_compute_lanes_this_thread": (None, [ci]),
     "vga_testing_plan_buckets": (ci, [C.POINTER(ci), C.POINTER(ci), ci, ci, C.c_longlong, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci),
                                  C.POINTER(ci), ci]),
     "vga_testing_hca_device_info": (ci, [vp, vp, ci]),

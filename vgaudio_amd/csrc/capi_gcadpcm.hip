@@ -208,6 +208,7 @@ void vga_testing_host_pipeline_this_thread(int feeders, int drainers, int chunk_
 void vga_testing_host_pipeline_tail_this_thread(int tail_units) { g_pipe_override.tail_units = tail_units > 0 ? tail_units : 0; }
 void vga_testing_buckets_order_this_thread(int order) { g_pipe_override.buckets_order = order == 1 || order == 2 ? order : 0; }
 void vga_testing_host_transfer_this_thread(int mode) { g_pipe_override.transfer = mode == 1 ? 1 : 0; }
+void vga_testing_host_compute_lanes_this_thread(int lanes) { g_pipe_override.compute_lanes = lanes > 0 ? lanes : 0; }
 int vga_testing_plan_buckets(const int *group, const int *length, int n, int max_units, long long max_volume, int longest_first,
                              int *order_out, int *chunk_begin_out, int *chunk_length_out, int *chunk_group_out, int max_chunks)
 {

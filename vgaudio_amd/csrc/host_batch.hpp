@@ -14,6 +14,7 @@ struct PipeOverride {
     int feeders = 0, drainers = 0, chunk_units = 0, slot_bytes = 0, tail_units = 0;   // slot_bytes < 0: direct copies (no staging ring); > 0: staged
     int buckets_order = 0;                   // plan_buckets: 0 = the entry point's own order, 1 = shortest chunks first, 2 = longest first
     int transfer = 0;                        // direct rows: 0 = by transfer kernels on reserved compute units (round 6), 1 = one copy per row
+    int compute_lanes = 0;                   // > 0: that many compute streams (chunk k on stream k % lanes) whatever the entry point asked for
 };
 // transfer_kernels.hip
 int launch_transfer(const pipe::Job::TransferPiece *pieces, int n, hipStream_t stream);
@@ -149,6 +150,7 @@ inline int run_batch_pipeline(pipe::Job &job, int default_chunk_units)
     // two drainer threads hand the rows out.  So: one feeder with direct uploads, two drainers behind a ring, all
     // uploads on one stream and all downloads on another (a slot = the rows a worker takes at a time); slot_bytes < 0
     // (testing hook) makes both directions direct, > 0 both staged.
+    if (o.compute_lanes > 0) job.compute_lanes = o.compute_lanes;
     job.feeders = o.feeders > 0 ? o.feeders : (o.feeders < 0 ? -o.feeders : 1);   // (test hook, negative: that many feeders, a stream each)
     job.drainers = o.drainers > 0 ? o.drainers : (out_total >= ((size_t)256 << 20) ? 2 : 1);
     // rows worth page-locking one by one: from 256 KB on (smaller rows are cheap to copy into the ring)
