@@ -130,3 +130,62 @@ def test_gc_decoder_repair_launch_on_seams_that_never_close(nch, n, pieces, mode
     got = dec[:, :n].cpu().numpy()
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert bad.size == 0, (bad[:8].tolist(), int(np.nonzero(got[bad[0]] != want[bad[0]])[0][0]))
+
+
+@pytest.mark.parametrize("nch,tone_rows,n", [(200, (77,), 14 * 24000 + 3), (320, (5, 250), 14 * 20000)])
+def test_decoders_hand_a_few_never_closing_channels_from_the_tail_kernel_to_the_repair_launch(nch, tone_rows, n):
+    """A batch of ordinary channels with ONE or two rows whose seams never close (GC-ADPCM: the 440 Hz sine; ADX: the clipped
+    square): far fewer open seams than the fix-up's `many`, so the tail kernel chains them -- and a lane that has walked its
+    budget (4096 frames, ADX 2048) without meeting hands its channel to the REPAIR launch in mid-launch (first_open[ch] = k + 1,
+    slow_seams raised to `many`; gc_decode_kernel.hip / adx_kernels.hip tail kernels).  Every row against the oracle."""
+    d = torch.device("cuda:0")
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    host = np.ascontiguousarray(po.synth_generate(nch, n, first_channel=300))
+    tone = signals.host("sine440", len(tone_rows), n)
+    square = signals.host("clipped_square", len(tone_rows), n)
+    # ---- GC-ADPCM
+    gc_host = host.copy()
+    for i, r in enumerate(tone_rows):
+        gc_host[r] = tone[i]
+    pcm = vdev.alloc_pcm(nch, n, d)
+    pcm[:, :n] = torch.from_numpy(gc_host).to(d)
+    coefs = vdev.gc_coefs(pcm, n)
+    adpcm = vdev.gc_encode(pcm, n, coefs)
+    nb = vdev.gc_byte_count(n)
+    wc, wa = po.gc_encode_batch(gc_host, threads=THREADS)
+    torch.cuda.synchronize()
+    assert np.array_equal(adpcm[:, :nb].cpu().numpy(), np.asarray(wa)[:, :nb])
+    dec, status = vdev.gc_decode(adpcm, coefs, n)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    want = po.gc_decode_batch(np.asarray(wa)[:, :nb], np.asarray(wc).reshape(nch, 16), n, threads=THREADS)
+    got = dec[:, :n].cpu().numpy()
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, ("gc", bad[:8].tolist())
+    # ---- ADX (encode: the same few rows go through the encoder's tail kernel; decode as above)
+    adx_host = host.copy()
+    for i, r in enumerate(tone_rows):
+        adx_host[r] = square[i]
+    pcm[:, :n] = torch.from_numpy(adx_host).to(d)
+    p = _lib.AdxParams()
+    L.vga_adx_default_params(C.byref(p))
+    nba = L.vga_adx_encoded_byte_count(n, C.byref(p))
+    pitch = (nba + 15) // 16 * 16
+    adx = torch.zeros((nch, pitch), dtype=torch.uint8, device=d)
+    hist = torch.zeros(nch, dtype=torch.int16, device=d)
+    status = torch.zeros(1, dtype=torch.int32, device=d)
+    back = vdev.alloc_pcm(nch, n, d)
+    _lib.check(L.vga_adx_encode_device(pcm.data_ptr(), pcm.stride(0), nch, n, C.byref(p), adx.data_ptr(), pitch, hist.data_ptr(), st))
+    _lib.check(L.vga_adx_decode_device(adx.data_ptr(), pitch, nba, nch, n, C.byref(p), back.data_ptr(), back.stride(0), status.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    wadx, whist = po.adx_encode_batch(adx_host, po.adx_params(), threads=THREADS)
+    got = adx[:, :nba].cpu().numpy()
+    bad = np.nonzero((got != wadx).any(axis=1))[0]
+    assert bad.size == 0, ("adx encode", bad[:8].tolist())
+    assert np.array_equal(hist.cpu().numpy(), whist)
+    wback = po.adx_decode_batch(wadx, n, po.adx_params(), threads=THREADS)
+    got = back[:, :n].cpu().numpy()
+    bad = np.nonzero((got != wback).any(axis=1))[0]
+    assert bad.size == 0, ("adx decode", bad[:8].tolist())
