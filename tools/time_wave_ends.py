@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--persistent", type=int, default=0, help="vga_testing_gc_encoder_persistent_this_thread: 0 launcher, 1 grid, 2 persistent")
     ap.add_argument("--pieces", type=int, default=0)
+    ap.add_argument("--signal", default="", help="a class of vgaudio_amd/signals.py instead of the synthetic generator (e.g. slow_channel_93: every row the same)")
     a = ap.parse_args()
     import torch
     from vgaudio_amd import _lib, device as vdev
@@ -36,7 +37,11 @@ def main():
     dev = torch.device("cuda:0")
     n = int(a.seconds * 48000)
     nch = a.channels
-    pcm = vdev.synth_pcm(nch, n, dev)
+    if a.signal:
+        from vgaudio_amd import signals
+        pcm = signals.device(a.signal, nch, n, dev)
+    else:
+        pcm = vdev.synth_pcm(nch, n, dev)
     for _ in range(2):
         coefs = vdev.gc_coefs(pcm, n)
     torch.cuda.synchronize()
@@ -46,6 +51,16 @@ def main():
     t0 = t[:, 0].min()
     print(json.dumps({"kernel": "gc_coefs_kernel", "waves": int(t.shape[0]), "start_ms": dist(t[:, 0] - t0), "pass0_end_ms": dist(t[:, 1] - t0),
                       "end_ms": dist(t[:, 2] - t0), "life_ms": dist(t[:, 2] - t[:, 0])}))
+    # where the spread lives: workgroup i (one wave) goes to XCD i % 8, CU (i / 8) % 32 of it; the sixteen waves of a CU are
+    # i, i + 256, ...; end times by XCD, by CU (its last wave), and by launch order (i / 256: the order in which a CU received them)
+    if t.shape[0] == 4096:
+        e = t[:, 2] - t0
+        by_cu = e.reshape(16, 256)
+        print(json.dumps({"end_ms_by_xcd_mean": [round(float(e[x::8].mean()), 2) for x in range(8)],
+                          "end_ms_by_xcd_max": [round(float(e[x::8].max()), 2) for x in range(8)],
+                          "last_wave_of_a_cu_ms": dist(by_cu.max(axis=0)), "first_wave_of_a_cu_ms": dist(by_cu.min(axis=0)),
+                          "mean_wave_of_a_cu_ms": dist(by_cu.mean(axis=0)),
+                          "end_ms_by_arrival_order_mean": [round(float(by_cu[k].mean()), 2) for k in range(16)]}))
     if not hasattr(raw, "vga_debug_encode_timestamps"):     # a build of gcadpcm_kernels.hip only
         return
     out = vdev.alloc_adpcm(nch, n, dev)
