@@ -170,6 +170,13 @@ namespace {
 
 constexpr int FRAMES_THREADS = 128;
 constexpr int MAX_FRAMES_PER_GROUP = 16;
+// timing-only builds (tools/build_variants.sh dstopN:"-DVGA_HCA_DEC_STOP_AFTER=N", wrong output): the frame loop ends after
+// 1 = the frame's dwords and record are in LDS, 2 = resolutions and gains, 3 = stage A (codes read, dequantised),
+// 4 = stage B (the transforms); 99 = the product.  Round 6 at configs[3] (profiles/r06_y_hca_decode_stages.log), of the
+// launch's 18.8 ms: load 3.2, resolutions + gains 1.0, stage A 6.2, stage B 3.7, stage C 4.7.
+#ifndef VGA_HCA_DEC_STOP_AFTER
+#define VGA_HCA_DEC_STOP_AFTER 99
+#endif
 
 struct FramesTables {
     Symbol sym[16];
@@ -266,6 +273,7 @@ __global__ __launch_bounds__(FRAMES_THREADS) void hca_frames_kernel(
             for (int k = tid; k < lay.record_bytes / 16; k += FRAMES_THREADS) reinterpret_cast<uint4 *>(s_rec)[k] = rec[k];
         }
         __syncthreads();
+        if (VGA_HCA_DEC_STOP_AFTER == 1) continue;
         {   // resolutions (CriHcaPacking.cs:85-93) and gains (CriHcaDecoder.cs:108-114)
             const uint32_t head = *reinterpret_cast<const uint32_t *>(s_rec + lay.header_at);
             const int noise = (int)(head & 0xFFFFu), eval = (int)((head >> 16) & 0xFFu);
@@ -283,6 +291,7 @@ __global__ __launch_bounds__(FRAMES_THREADS) void hca_frames_kernel(
                 }
         }
         __syncthreads();
+        if (VGA_HCA_DEC_STOP_AFTER == 2) continue;
         // stage A: ReadSpectralCoefficients + DequantizeFrame, one 16-code chunk per lane
         for (int id = tid; id < nch * 64; id += FRAMES_THREADS) {
             const int row = id >> 3, q = id & 7, c = row >> 3, sf = row & 7;
@@ -337,6 +346,7 @@ __global__ __launch_bounds__(FRAMES_THREADS) void hca_frames_kernel(
             }
         }
         __syncthreads();
+        if (VGA_HCA_DEC_STOP_AFTER == 3) continue;
         // stage B: RunImdct's Dct4 (Mdct.cs:126-181), 8 lanes per transform; all of a transform's lanes share a wave
         for (int row = tid >> 3; row < nch * 8; row += FRAMES_THREADS / 8) {
             const int c = row >> 3, sf = row & 7;
@@ -352,7 +362,11 @@ __global__ __launch_bounds__(FRAMES_THREADS) void hca_frames_kernel(
             dct_store(r, K, y);
         }
         __syncthreads();
-        // stage C: window + overlap-add (Mdct.cs:112-118), PcmFloatToShort, CopyPcmToOutput (CriHcaDecoder.cs:31-45)
+        if (VGA_HCA_DEC_STOP_AFTER == 4) continue;
+        // stage C: window + overlap-add (Mdct.cs:112-118), PcmFloatToShort, CopyPcmToOutput (CriHcaDecoder.cs:31-45).
+        // (Round 6: a wave's 8 x 64 samples of a channel turned through 1 KB of LDS into one 16-byte store per lane instead of
+        // these eight 2-byte stores per lane -- same samples, 26.9 ms for the decode against 24.8: the stage is bound by the
+        // rows the memory system keeps open (11.8 GB in 4.7 ms), as the ADPCM decoders' stores are, not by the instruction.)
         if (!warm) {
             for (int c = 0; c < nch; c++) {
                 int16_t *dst = spcm + (int64_t)c * ch_pitch;
