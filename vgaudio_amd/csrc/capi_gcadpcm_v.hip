@@ -28,6 +28,7 @@ struct RaggedShape {
     std::vector<int> length, order;
     std::vector<int64_t> pcm_off, adpcm_off, rec_off;
     int max_length = 0;
+    int solo_channels = 0, solo_usable = 0;   // gc::ragged_solo_count: the coefficient search's five-wave channels
     int64_t total_frames = 0, records = 0;     // records: slots of the coefficient workspace (an empty channel owns one)
     bool uniform = false;                      // every channel the same length: the equal-length kernels apply
     int64_t pcm_pitch = 0, adpcm_pitch = 0;    // ... with these pitches
@@ -72,7 +73,11 @@ struct RaggedShape {
         if (pcm_end) *pcm_end = pcm_base;
         if (adpcm_end) *adpcm_end = adpcm_base;
         items.clear();
+        solo_channels = solo_usable = 0;
         if (n > 0 && !uniform && max_length > 0) {
+            std::vector<int> by_length(n);
+            for (int i = 0; i < n; i++) by_length[i] = length[order[i]];
+            solo_channels = gc::ragged_solo_count(by_length.data(), n, total_frames, device_cu_count(), &solo_usable);
             const int groups = (n + 15) / 16;
             std::vector<int> gframes(groups);
             int64_t group_frames = 0;
@@ -121,6 +126,8 @@ struct RaggedShape {
         r.rec_off = r.pcm_off + 2 * count;
         r.max_length = max_length;
         r.total_frames = total_frames;
+        r.solo_channels = solo_channels;
+        r.solo_usable = solo_usable;
         if (!items.empty()) {
             r.items = reinterpret_cast<const uint32_t *>(r.pcm_off + 3 * (size_t)count);
             r.n_items = (int)items.size();

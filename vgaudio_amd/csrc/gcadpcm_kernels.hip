@@ -10,6 +10,7 @@
 #include "common.hpp"
 #include "gcadpcm_kernels.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -351,7 +352,7 @@ __device__ __forceinline__ void wave_lds_sync()
 
 #ifdef VGA_DEBUG_TIMESTAMPS
 // tools/time_wave_ends.py: start, end of pass 0, end of every gc_coefs_kernel wave (100 MHz wall clock)
-__device__ unsigned long long g_vga_coef_ts[3 * 8192];
+__device__ unsigned long long g_vga_coef_ts[3 * 16384];
 extern "C" int vga_debug_coefs_timestamps(unsigned long long *out, int n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vga_coef_ts), (size_t)n * sizeof(unsigned long long));
@@ -446,6 +447,18 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     uint32_t wave_slot = 0;
     if (VGA_COEFS_PRIO == 1) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(wave_slot));
     if (VGA_COEFS_PRIO == 3) __builtin_amdgcn_s_setprio(3);
+    // Ragged batches: the longest channel is the launch's critical path (120 s among files of 1-120 s: twice the mean wave's
+    // work), and by-pass priorities alone would make it yield to every younger wave.  Priority = what the channel still has
+    // to do, in quarters of what the longest channel starts with (frames x passes left): 3 3 2 2 1 1 0 for a longest channel,
+    // a short file never above 0 or 1.  The mixed-lengths set: 38.6-39.1 ms against 39.7 with the priorities by pass; the
+    // channel's length alone, or what is left on a geometric scale (1/2, 1/4, 1/8 of the longest job): 39.0 / 39.4 -- the
+    // launch ends when its 120 s files do, ~32 ms even on their own (profiles/r06_z_coefs_wave_ends_ragged*.log).
+    const int64_t ragged_job = rg.order ? (int64_t)((rg.max_length + 13) / 14) * 7 : 0;
+    auto ragged_priority = [&](int passes_left) __attribute__((always_inline)) {
+        const int64_t q = 4 * (int64_t)frames * passes_left / (ragged_job > 0 ? ragged_job : 1);
+        set_priority((uint32_t)(q > 3 ? 3 : q));
+    };
+    if (VGA_COEFS_PRIO == 3 && rg.order) ragged_priority(7);
 
     // one wave: its LDS operations execute in program order, so the fill needs no barrier before the writes
     auto zero_fill = [&](int par) {
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     };
 
 #ifdef VGA_DEBUG_TIMESTAMPS
-    if (lane == 0) g_vga_coef_ts[3 * (blockIdx.x & 8191)] = wall_clock64();
+    if (lane == 0) g_vga_coef_ts[3 * (blockIdx.x & 16383)] = wall_clock64();
 #endif
     // ---- pass 0: per-frame records (:40-61) + ordered mean of MatrixFilter outputs (:63-74)
     double acc = 0.0;
@@ -532,7 +545,7 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
         }
     }
 #ifdef VGA_DEBUG_TIMESTAMPS
-    if (lane == 0) g_vga_coef_ts[3 * (blockIdx.x & 8191) + 1] = wall_clock64();
+    if (lane == 0) g_vga_coef_ts[3 * (blockIdx.x & 16383) + 1] = wall_clock64();
 #endif
     __syncthreads();
     if (lane < 2) s_sum[0][1 + lane] = acc;
@@ -553,7 +566,10 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
     auto lloyd_iterations = [&](auto exp_c) {
         constexpr int EXP = decltype(exp_c)::value;
         for (int iter = 0; iter < 2; iter++) {
-            if (VGA_COEFS_PRIO == 3) set_priority(EXP == 2 ? 2 : (EXP == 4 ? 1 : 0));
+            if (VGA_COEFS_PRIO == 3) {
+                if (rg.order) ragged_priority((EXP == 2 ? 6 : (EXP == 4 ? 4 : 2)) - iter);
+                else set_priority(EXP == 2 ? 2 : (EXP == 4 ? 1 : 0));
+            }
             if (lane < EXP) {
                 const double a = s_vb[lane][0], b = s_vb[lane][1], c = s_vb[lane][2];
                 s_cw[lane][0] = (a * a) + (b * b) + (c * c);
@@ -699,7 +715,7 @@ __global__ __launch_bounds__(64) void gc_coefs_kernel(
         coefs_out[ch * 16 + lane] = (int16_t)out;
     }
 #ifdef VGA_DEBUG_TIMESTAMPS
-    if (lane == 0) g_vga_coef_ts[3 * (blockIdx.x & 8191) + 2] = wall_clock64();
+    if (lane == 0) g_vga_coef_ts[3 * (blockIdx.x & 16383) + 2] = wall_clock64();
 #endif
 }
 
@@ -725,7 +741,7 @@ constexpr int COEF_THREADS = (COEF_CW + 1) * 64;
 template <bool SOLO>
 __global__ __launch_bounds__(COEF_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void gc_coefs_kernel4(
     const int16_t *__restrict__ pcm, int64_t pcm_pitch, int nch, int length,
-    double2 *__restrict__ records, int16_t *__restrict__ coefs_out)
+    double2 *__restrict__ records, int16_t *__restrict__ coefs_out, const Ragged rg)
 {
     __shared__ __align__(64) double s_d[COEF_CW][2][2][128];       // [channel][chunk parity][component][compacted slot]
     __shared__ int s_meta[2][COEF_CW][8];                          // (start << 8) | n of every bucket
@@ -739,14 +755,17 @@ __global__ __launch_bounds__(COEF_THREADS) __attribute__((amdgpu_waves_per_eu(5,
     const int cs = SOLO ? 0 : ws;                                  // ... and its channel slot (codebooks)
     const int ch_raw = SOLO ? (int)blockIdx.x : (int)blockIdx.x * COEF_CW + cs;
     const bool live = !summer && ch_raw < nch;
-    const int ch = ch_raw < nch ? ch_raw : nch - 1;
-    const int16_t *src = pcm + (int64_t)ch * pcm_pitch;
+    // ragged batch (SOLO only): workgroup i takes channel order[i] with its own length and offsets
+    const bool ragged = SOLO && rg.order != nullptr;
+    const int ch = ragged ? rg.order[blockIdx.x] : (ch_raw < nch ? ch_raw : nch - 1);
+    if (ragged) length = rg.length[ch];
+    const int16_t *src = pcm + (ragged ? rg.pcm_off[ch] : (int64_t)ch * pcm_pitch);
     const int frames = (length + 13) / 14;
     const int chunks = (frames + 63) / 64;
     // a record wave's chunks: c = round (four channels), c = 4 round + wave (SOLO)
     const int rounds = SOLO ? (chunks + COEF_CW - 1) / COEF_CW : chunks;
     const int cstep = SOLO ? COEF_CW : 1, cfirst = SOLO ? ws : 0;
-    double2 *rec = records + (int64_t)ch * frames;
+    double2 *rec = records + (ragged ? rg.rec_off[ch] : (int64_t)ch * frames);
     // summing-wave lane = (channel slot, bucket, component); SOLO: the sixteen lanes of slot 0 carry the one channel
     const int sc = lane >> 4, sb = (lane >> 1) & 7, sk = lane & 1;
 
@@ -999,14 +1018,48 @@ __global__ __launch_bounds__(256) void synth_kernel(int16_t *__restrict__ pcm, i
 // one wave per channel, 896: 22.7 against 18.3 (profiles/r06_u_coefs_variants_small.log)
 constexpr int SOLO_WORKGROUPS_PER_CU = 3;
 
+// How many of a ragged batch's channels (in its longest-first order) get five waves each (gc_coefs_kernel4<true>): all that hold
+// at least one chunk of records, or none.  A ragged launch of one-wave workgroups lasts as long as its longest channel --
+// 29-33 ms for a 120 s file from 16 to 4096 files of 1-120 s -- until the chip's throughput takes over (10 008 files: 39 ms);
+// five waves per channel cut that chain to 20 ms and cost 2.1x the chip time per frame: 16 files 19.9 against 29.3 ms, 768:
+// 22.2 / 30.8, 2304: 23.9 / 32.7, 4096: 27.7 / 32.1 (profiles/r06_z_coefs_ragged_small.log).  The choice compares the two
+// estimates max(longest channel's chain, frames / throughput) with the rates of those runs.  Host arithmetic only
+// (capi_gcadpcm_v.hip calls it when it builds the batch's tables).
+// Round 6 also tried the five-wave form for a big batch's LONGEST channels only, on a side stream next to the one-wave launch
+// of the rest: a five-wave workgroup next to 4096 one-wave workgroups takes 48-50 ms for a 120 s channel at any count from 64
+// to 512, stream and wave priorities at their highest (17 ms alone) -- its five waves meet at a barrier per chunk and each
+// shares its SIMD (profiles/r06_z_ragged_coefs_kernel_timeline.log).  Not kept.
+int ragged_solo_count(const int *lengths_longest_first, int nch, int64_t total_frames, int cus, int *usable_out)
+{
+    const int min_length = 14 * 64;                                 // (at least one chunk of records)
+    int usable = 0;
+    while (usable < nch && lengths_longest_first[usable] >= min_length) usable++;
+    if (usable_out) *usable_out = usable;
+    if (nch <= 0 || usable == 0) return 0;
+    const double scale = 256.0 / (double)(cus > 0 ? cus : 256);     // (the rates below are an MI355X's: 256 CUs)
+    const double longest = (double)((lengths_longest_first[0] + 13) / 14), total = (double)total_frames;
+    const double five_waves = std::max(longest * 4.8e-5, total / 1.27e7 * scale);      // ms
+    const double one_wave = std::max(longest * 7.1e-5, total / 2.16e7 * scale);
+    return five_waves < one_wave ? usable : 0;
+}
+
 int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, int16_t *d_coefs,
                  void *d_workspace, hipStream_t stream, const Ragged *rg)
 {
     if (nch <= 0) return VGA_OK;
     if (rg) {
-        // ragged: one wave per channel whatever the count (the workgroup forms share one `length`), longest channel first
-        hipLaunchKernelGGL(gc_coefs_kernel, dim3(nch), dim3(64), 0, stream, d_pcm, (int64_t)0, nch, 0,
-                           reinterpret_cast<double2 *>(d_workspace), d_coefs, *rg);
+        // ragged: one wave per channel, longest channel first (the workgroup forms of four channels share one `length`); a
+        // batch of at most three workgroups per CU: five waves on every channel that holds a chunk of records, as for a
+        // uniform batch (rg->solo_channels leading slots of the order, ragged_solo_count)
+        const int solo = coefs_kernel_variant() == 1 ? 0 : (coefs_kernel_variant() == 3 ? rg->solo_usable : rg->solo_channels);
+        Ragged rest = *rg;
+        rest.order += solo;
+        if (solo > 0)
+            hipLaunchKernelGGL(gc_coefs_kernel4<true>, dim3(solo), dim3(COEF_THREADS), 0, stream, d_pcm, (int64_t)0, solo, 0,
+                               reinterpret_cast<double2 *>(d_workspace), d_coefs, *rg);
+        if (solo < nch)
+            hipLaunchKernelGGL(gc_coefs_kernel, dim3(nch - solo), dim3(64), 0, stream, d_pcm, (int64_t)0, nch, 0,
+                               reinterpret_cast<double2 *>(d_workspace), d_coefs, rest);
         VGA_HIP_TRY(hipGetLastError());
         return VGA_OK;
     }
@@ -1022,10 +1075,10 @@ int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, i
                            reinterpret_cast<double2 *>(d_workspace), d_coefs, Ragged{});
     else if (solo)
         hipLaunchKernelGGL(gc_coefs_kernel4<true>, dim3(nch), dim3(COEF_THREADS), 0, stream, d_pcm, pcm_pitch, nch, length,
-                           reinterpret_cast<double2 *>(d_workspace), d_coefs);
+                           reinterpret_cast<double2 *>(d_workspace), d_coefs, Ragged{});
     else
         hipLaunchKernelGGL(gc_coefs_kernel4<false>, dim3((nch + COEF_CW - 1) / COEF_CW), dim3(COEF_THREADS), 0, stream, d_pcm, pcm_pitch,
-                           nch, length, reinterpret_cast<double2 *>(d_workspace), d_coefs);
+                           nch, length, reinterpret_cast<double2 *>(d_workspace), d_coefs, Ragged{});
     VGA_HIP_TRY(hipGetLastError());
     return VGA_OK;
 }

@@ -38,6 +38,8 @@ struct Ragged {
     const int64_t *pcm_off = nullptr;   // [nch]
     const int64_t *adpcm_off = nullptr; // [nch]
     const int64_t *rec_off = nullptr;   // [nch]
+    int solo_channels = 0;              // coefficient search: the first n work slots get five waves each (ragged_solo_count)
+    int solo_usable = 0;                // ... and how many could (test hook: coefficient kernel variant 3)
     int max_length = 0;                 // host-side copy: the longest channel
     int64_t total_frames = 0;           // host-side copy: sum of ceil(length / 14)
 };
@@ -50,6 +52,7 @@ __host__ __device__ inline int64_t coef_record_pitch(int64_t frames)
     return (frames > 0 ? frames + COEF_RECORD_BLOCK - 1 : COEF_RECORD_BLOCK) / COEF_RECORD_BLOCK * COEF_RECORD_BLOCK;
 }
 
+int ragged_solo_count(const int *lengths_longest_first, int nch, int64_t total_frames, int cus, int *usable_out = nullptr);
 // rg != nullptr: pcm_pitch / length (sample_count) are ignored, d_pcm / d_adpcm are the bases the offsets count from
 int launch_coefs(const int16_t *d_pcm, int64_t pcm_pitch, int nch, int length, int16_t *d_coefs,
                  void *d_workspace, hipStream_t stream, const Ragged *rg = nullptr);
