@@ -782,6 +782,9 @@ __global__ __launch_bounds__(COEF_THREADS) __attribute__((amdgpu_waves_per_eu(5,
             for (int w4 = 0; w4 < COEF_CW; w4++) {                 // the round's four chunks, in chunk order
                 const int meta = s_meta[par][w4][sb];
                 const int n = (sc == 0 && sb < nb) ? (meta & 0xFF) : 0;
+                // (round 6: the next batch's LDS reads issued before this batch's eight adds -- 9.2 against 8.75 ms for one
+                // channel, 17.4 / 14.9 for 768; four waves per SIMD instead of five: 768 channels 23 ms.
+                // profiles/r06_z_coefs_solo_variants.log)
                 acc = ordered_sum(acc, &s_d[w4][par][sk][meta >> 8], n, s_maxn[par][w4]);
                 cnt += n;
             }
