@@ -193,6 +193,26 @@ def test_ragged_through_every_pipeline_shape(chunk, slot):
         assert np.array_equal(back[c], po.gc_decode(wa, wc, lens[c])), c
 
 
+@pytest.mark.parametrize("variant", [1, 3])
+def test_ragged_coefficients_from_either_kernel_form(variant):
+    """The ragged coefficient search has two forms (gcadpcm_kernels.hip launch_coefs): one wave per channel (hook 1) and five waves
+    per channel for every channel that holds a chunk of records (hook 3; the shorter ones stay on the one-wave kernel in the same
+    call) -- the launcher picks by the batch's shape; both against the oracle, awkward lengths included."""
+    L = _lib.lib()
+    lens = _lengths(60, 20, 90_000, 11, AWKWARD + (14 * 64 - 1, 14 * 64, 14 * 64 + 1, 14 * 256, 14 * 257 + 3))
+    chans = _channels(lens, first_channel=1300)
+    counts = np.array(lens, dtype=np.int32)
+    coefs = np.full((len(lens), 16), 0x5A5A, dtype=np.int16)
+    L.vga_testing_gc_coefs_variant_this_thread(variant)
+    try:
+        _lib.check(L.vga_gcadpcm_calculate_coefficients_batch_v(_ptrs(i16p, chans), counts.ctypes.data_as(C.POINTER(C.c_int)), len(lens),
+                                                                coefs.ctypes.data_as(i16p)))
+    finally:
+        L.vga_testing_gc_coefs_variant_this_thread(0)
+    for c, pcm in enumerate(chans):
+        assert coefs[c].tolist() == po.gc_calculate_coefficients(pcm).tolist(), (c, lens[c])
+
+
 def test_coefficients_only_and_encode_with_given_coefficients():
     L = _lib.lib()
     lens = _lengths(30, 20, 50_000, 6, (0, 13))
