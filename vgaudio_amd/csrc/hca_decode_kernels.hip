@@ -204,7 +204,7 @@ struct Res16 {
 
 }  // namespace
 
-__global__ __launch_bounds__(FRAMES_THREADS) void hca_frames_kernel(
+__global__ __launch_bounds__(FRAMES_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void hca_frames_kernel(
     const uint8_t *__restrict__ frames, int64_t frames_pitch, DeviceInfo info, DecodeLayout lay,
     const uint8_t *__restrict__ records, int frames_per_group, int groups_per_stream, int16_t *__restrict__ pcm,
     int64_t stream_pitch, int64_t ch_pitch)
@@ -251,26 +251,48 @@ __global__ __launch_bounds__(FRAMES_THREADS) void hca_frames_kernel(
     int16_t *spcm = pcm + (int64_t)stream * stream_pitch;
     const int frame_bits = info.frame_size * 8;
 
+    // the next frame's first dwords and record, loaded a frame ahead (unconditional loads at clamped positions)
+    constexpr int FETCH_AHEAD = 2;
+    uint32_t fa[FETCH_AHEAD], fb[FETCH_AHEAD];
+    uint4 frec;
+    auto fetch = [&](int f) {
+        const int64_t w0 = ((int64_t)f * info.frame_size) >> 2;
+#pragma unroll
+        for (int i = 0; i < FETCH_AHEAD; i++) {
+            const int k = min(tid + i * FRAMES_THREADS, lay.frame_dwords - 1);
+            fa[i] = sbase[min(w0 + k, last_word)];
+            fb[i] = sbase[min(w0 + k + 1, last_word)];
+        }
+        frec = reinterpret_cast<const uint4 *>(srec + (size_t)f * lay.record_bytes)[min(tid, lay.record_bytes / 16 - 1)];
+    };
+    fetch(f0 > 0 ? f0 - 1 : f0);
     for (int f = f0 > 0 ? f0 - 1 : f0; f < f1; f++) {
         const bool warm = f < f0;                      // the frame before the run: only its last sub-frame, no output
         const int base = (9 - f % 9) % 9;              // sub-frame sf of frame f lives in slot (base + sf) % 9 of its channel
         __syncthreads();                               // the previous frame's stage C has read its rows; T is written
-        {   // the frame's bytes as big-endian dwords starting at its first bit, zero past its end; its record
+        {   // the frame's bytes as big-endian dwords starting at its first bit, zero past its end; its record.  The first
+            // FETCH_AHEAD x 128 dwords and 128 x 16 bytes of the record were loaded during the frame before (fetch below).
             const int64_t a0 = (int64_t)f * info.frame_size;
             const int64_t w0 = a0 >> 2;
             const int sh8 = (int)(a0 & 3) * 8;
-            for (int k = tid; k <= lay.frame_dwords; k += FRAMES_THREADS) {
+            auto put = [&](int k, uint32_t r0, uint32_t r1) {
                 uint32_t v = 0;
                 if (k < lay.frame_dwords) {
-                    const uint32_t x0 = bswap32(sbase[min(w0 + k, last_word)]);
-                    const uint32_t x1 = bswap32(sbase[min(w0 + k + 1, last_word)]);
+                    const uint32_t x0 = bswap32(r0), x1 = bswap32(r1);
                     v = sh8 ? (x0 << sh8) | (x1 >> (32 - sh8)) : x0;
                     v = mask_past_end(v, k, frame_bits);
                 }
                 s_fb[k] = v;
-            }
+            };
+#pragma unroll
+            for (int i = 0; i < FETCH_AHEAD; i++)
+                if (tid + i * FRAMES_THREADS <= lay.frame_dwords) put(tid + i * FRAMES_THREADS, fa[i], fb[i]);
+            for (int k = tid + FETCH_AHEAD * FRAMES_THREADS; k <= lay.frame_dwords; k += FRAMES_THREADS)
+                put(k, sbase[min(w0 + k, last_word)], sbase[min(w0 + k + 1, last_word)]);
             const uint4 *rec = reinterpret_cast<const uint4 *>(srec + (size_t)f * lay.record_bytes);
-            for (int k = tid; k < lay.record_bytes / 16; k += FRAMES_THREADS) reinterpret_cast<uint4 *>(s_rec)[k] = rec[k];
+            if (tid < lay.record_bytes / 16) reinterpret_cast<uint4 *>(s_rec)[tid] = frec;
+            for (int k = tid + FRAMES_THREADS; k < lay.record_bytes / 16; k += FRAMES_THREADS) reinterpret_cast<uint4 *>(s_rec)[k] = rec[k];
+            fetch(min(f + 1, f1 - 1));                 // in flight during this frame's stages
         }
         __syncthreads();
         if (VGA_HCA_DEC_STOP_AFTER == 1) continue;
