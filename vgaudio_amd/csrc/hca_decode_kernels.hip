@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void hca_scan_kernel(const uint8_t *__restrict_
 namespace {
 
 constexpr int FRAMES_THREADS = 128;
-constexpr int MAX_FRAMES_PER_GROUP = 16;
+constexpr int MAX_FRAMES_PER_GROUP = 32;         // (configs[3]: 8 / 16 / 32 / 64 frames a workgroup = 24.5 / 23.6 / 23.1 / 23.0 ms for the decode)
 // timing-only builds (tools/build_variants.sh dstopN:"-DVGA_HCA_DEC_STOP_AFTER=N", wrong output): the frame loop ends after
 // 1 = the frame's dwords and record are in LDS, 2 = resolutions and gains, 3 = stage A (codes read, dequantised),
 // 4 = stage B (the transforms); 99 = the product.  Round 6 at configs[3] (profiles/r06_y_hca_decode_stages.log), of the
@@ -266,10 +266,13 @@ __global__ __launch_bounds__(FRAMES_THREADS) __attribute__((amdgpu_waves_per_eu(
         frec = reinterpret_cast<const uint4 *>(srec + (size_t)f * lay.record_bytes)[min(tid, lay.record_bytes / 16 - 1)];
     };
     fetch(f0 > 0 ? f0 - 1 : f0);
+    __syncthreads();                                   // T is written
+    // Inside the frame loop the stages talk through LDS only: lds_barrier() (LDS counter + s_barrier) instead of
+    // __syncthreads(), which would also wait for the loads of the next frame and for stage C's stores at every stage boundary.
     for (int f = f0 > 0 ? f0 - 1 : f0; f < f1; f++) {
         const bool warm = f < f0;                      // the frame before the run: only its last sub-frame, no output
         const int base = (9 - f % 9) % 9;              // sub-frame sf of frame f lives in slot (base + sf) % 9 of its channel
-        __syncthreads();                               // the previous frame's stage C has read its rows; T is written
+        lds_barrier();                               // the previous frame's stage C has read its rows; T is written
         {   // the frame's bytes as big-endian dwords starting at its first bit, zero past its end; its record.  The first
             // FETCH_AHEAD x 128 dwords and 128 x 16 bytes of the record were loaded during the frame before (fetch below).
             const int64_t a0 = (int64_t)f * info.frame_size;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(FRAMES_THREADS) __attribute__((amdgpu_waves_per_eu(
             for (int k = tid + FRAMES_THREADS; k < lay.record_bytes / 16; k += FRAMES_THREADS) reinterpret_cast<uint4 *>(s_rec)[k] = rec[k];
             fetch(min(f + 1, f1 - 1));                 // in flight during this frame's stages
         }
-        __syncthreads();
+        lds_barrier();
         if (VGA_HCA_DEC_STOP_AFTER == 1) continue;
         {   // resolutions (CriHcaPacking.cs:85-93) and gains (CriHcaDecoder.cs:108-114)
             const uint32_t head = *reinterpret_cast<const uint32_t *>(s_rec + lay.header_at);
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(FRAMES_THREADS) __attribute__((amdgpu_waves_per_eu(
                     reinterpret_cast<double *>(rows + (size_t)(c * 9 + (base + 8) % 9) * ROW_BYTES)[k] = 0.0;
                 }
         }
-        __syncthreads();
+        lds_barrier();
         if (VGA_HCA_DEC_STOP_AFTER == 2) continue;
         // stage A: ReadSpectralCoefficients + DequantizeFrame, one 16-code chunk per lane
         for (int id = tid; id < nch * 64; id += FRAMES_THREADS) {
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(FRAMES_THREADS) __attribute__((amdgpu_waves_per_eu(
         }
         // ReconstructHighFrequency (CriHcaDecoder.cs:116-145)
         if (info.hfr_group_count > 0) {
-            __syncthreads();
+            lds_barrier();
             const int total_band_count = min(info.total_band_count, 127);
             const int hfr_start = info.base_band_count + info.stereo_band_count;
             const int hfr_bands = min(info.hfr_band_count, total_band_count - info.hfr_band_count);
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(FRAMES_THREADS) __attribute__((amdgpu_waves_per_eu(
         }
         // ApplyIntensityStereo (:147-166)
         if (info.stereo_band_count > 0) {
-            __syncthreads();
+            lds_barrier();
             const int nb = info.total_band_count - info.base_band_count;
             for (int i = tid; i < nch * 8 * nb; i += FRAMES_THREADS) {
                 const int c = i / (8 * nb), sf = (i / nb) % 8, b = info.base_band_count + i % nb;
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(FRAMES_THREADS) __attribute__((amdgpu_waves_per_eu(
                 *l = lv * ratio_l;
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (VGA_HCA_DEC_STOP_AFTER == 3) continue;
         // stage B: RunImdct's Dct4 (Mdct.cs:126-181), 8 lanes per transform; all of a transform's lanes share a wave
         for (int row = tid >> 3; row < nch * 8; row += FRAMES_THREADS / 8) {
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(FRAMES_THREADS) __attribute__((amdgpu_waves_per_eu(
             wave_lds_sync();
             dct_store(r, K, y);
         }
-        __syncthreads();
+        lds_barrier();
         if (VGA_HCA_DEC_STOP_AFTER == 4) continue;
         // stage C: window + overlap-add (Mdct.cs:112-118), PcmFloatToShort, CopyPcmToOutput (CriHcaDecoder.cs:31-45).
         // (Round 6: a wave's 8 x 64 samples of a channel turned through 1 KB of LDS into one 16-byte store per lane instead of
