@@ -2,7 +2,8 @@
 cases of test_gpu_gcadpcm / test_gpu_adx / test_gpu_hca name the shapes somebody thought of; these draw the ones nobody did:
 lengths around the kernels' block sizes (14, 32, 64 x 14, 256 x 14, 1024), paddings, histories, sample rates, bitrates, loop
 points, channel counts, signal kinds, forced time pieces.  VGA_SWEEP_CASES=n (environment) draws n cases per codec instead of
-the default few dozen (round 6 ran 1200 per codec on the final kernels: 3600 passed)."""
+the default few dozen (round 6 ran 1200 per codec on the final kernels: 3600 passed); VGA_SWEEP_BIG=1 draws 60-300 channels x
+3-30 s instead -- the sizes at which the time pieces and the persistent workgroups engage by themselves (30 per codec: 90 passed)."""
 import os
 
 import numpy as np
@@ -16,6 +17,8 @@ from vgaudio_amd.gcadpcm import Pcm16Format
 
 pytestmark = pytest.mark.gpu
 CASES = int(os.environ.get("VGA_SWEEP_CASES", "0"))
+BIG = int(os.environ.get("VGA_SWEEP_BIG", "0"))             # 1: 60-300 channels x 3-30 s (the sizes at which the time pieces engage by themselves)
+THREADS = max(1, min(16, len(os.sched_getaffinity(0))))
 
 
 def _signal(rng, nch, n, first_channel):
@@ -55,6 +58,8 @@ def test_gcadpcm_random_shapes(seed):
     d = torch.device("cuda:0")
     nch = int(rng.integers(1, 40)) if rng.random() < 0.8 else int(rng.integers(60, 140))
     n = _length(rng, 400_000 if nch < 40 else 150_000)
+    if BIG:
+        nch, n = int(rng.integers(60, 300)), int(rng.integers(150_000, 1_500_000))
     host = _signal(rng, nch, n, first_channel=seed * 200)
     pcm = vdev.alloc_pcm(nch, n, d)
     pcm[:, :n] = torch.from_numpy(np.ascontiguousarray(host)).to(d)
@@ -72,10 +77,10 @@ def test_gcadpcm_random_shapes(seed):
         L.vga_testing_gc_encoder_layout_this_thread(0)
     assert int(status.item()) == 0
     nb = vdev.gc_byte_count(n)
-    wc, wa = po.gc_encode_batch(host, threads=4)
+    wc, wa = po.gc_encode_batch(host, threads=THREADS)
     assert np.array_equal(coefs.cpu().numpy().reshape(nch, 16), np.asarray(wc).reshape(nch, 16)), (nch, n)
     assert np.array_equal(adpcm[:, :nb].cpu().numpy(), np.asarray(wa)[:, :nb]), (nch, n)
-    want = po.gc_decode_batch(np.asarray(wa)[:, :nb], np.asarray(wc).reshape(nch, 16), n, threads=4)
+    want = po.gc_decode_batch(np.asarray(wa)[:, :nb], np.asarray(wc).reshape(nch, 16), n, threads=THREADS)
     assert np.array_equal(dec[:, :n].cpu().numpy(), want), (nch, n)
 
 
@@ -91,6 +96,8 @@ def test_adx_random_shapes(seed):
     L = _lib.lib()
     nch = int(rng.integers(1, 12)) if rng.random() < 0.7 else int(rng.integers(60, 140))
     n = _length(rng, 300_000 if nch < 12 else 100_000)
+    if BIG:
+        nch, n = int(rng.integers(60, 300)), int(rng.integers(150_000, 1_500_000))
     kw = dict(Type=int(rng.choice([2, 3, 4])), Version=int(rng.choice([3, 4])))
     if kw["Type"] == 2:
         kw["Filter"] = int(rng.integers(0, 4))
@@ -116,19 +123,19 @@ def test_adx_random_shapes(seed):
     finally:
         L.vga_testing_gc_encoder_segments_this_thread(0)
         L.vga_testing_force_open_seams_this_thread(0)
+    want, whist = po.adx_encode_batch(host, _adx_oracle_params(kw), threads=THREADS)
+    wdec = po.adx_decode_batch(want, n, _adx_oracle_params(dkw), threads=THREADS)
     for c in range(nch):
-        p = _adx_oracle_params(kw)
-        want = po.adx_encode(host[c], p)
-        assert len(enc[c]) == len(want) and (enc[c] == want).all(), (kw, nch, n, c)
-        assert int(np.atleast_1d(cfg.History)[c]) == p.history, (kw, nch, n, c)
-        assert (dec[c] == po.adx_decode(want, n, _adx_oracle_params(dkw))).all(), (kw, nch, n, c)
+        assert len(enc[c]) == want.shape[1] and (enc[c] == want[c]).all(), (kw, nch, n, c)
+        assert int(np.atleast_1d(cfg.History)[c]) == int(whist[c]), (kw, nch, n, c)
+        assert (dec[c] == wdec[c]).all(), (kw, nch, n, c)
 
 
 @pytest.mark.parametrize("seed", range(CASES or 24))
 def test_hca_random_shapes(seed):
     rng = np.random.default_rng(30_000 + seed)
     nch = int(rng.choice([1, 1, 2, 2, 2, 2, 3, 4, 5, 6, 8]))
-    n = _length(rng, 60_000)
+    n = int(rng.integers(100_000, 600_000)) if BIG else _length(rng, 60_000)
     quality = str(rng.choice(["Highest", "High", "Middle", "Low", "Lowest"]))
     q = {"Highest": 1, "High": 2, "Middle": 3, "Low": 4, "Lowest": 5}[quality]
     rate = int(rng.choice([48000, 48000, 44100, 32000, 22050, 16000]))
