@@ -3,6 +3,7 @@ file-level batch (VGAudio.Cli/Batch.cs:24-25: Parallel.ForEach over files, each 
 Formats/GcAdpcm/GcAdpcmFormat.cs:58-74).  Every channel of every call must be what one call of the oracle on that
 channel alone produces: coefficients, bitstream, decoded samples."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -486,3 +487,119 @@ def test_adx_ragged_bucket_padding_is_nobodys_output(pieces, force_open):
     finally:
         L.vga_testing_gc_encoder_segments_this_thread(old_p)
         L.vga_testing_force_open_seams_this_thread(old_f)
+
+
+# ---------------------------------------------------------------------------------------------- seeded random files
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VGA_SWEEP_CASES", "0")) or 10))
+def test_random_files_through_the_three_ragged_entry_points(seed):
+    """Files nobody thought of (tests/test_gpu_random_sweep.py for the equal-length entry points): random counts, lengths on and
+    around the block sizes, per-file ADX parameters (type, version, padding, rate), per-file HCA shapes (channels, quality,
+    rate, loop) -- every file against the oracle."""
+    L = _lib.lib()
+    rng = np.random.default_rng(50_000 + seed)
+
+    def length(top):
+        blocks = (14, 32, 14 * 64, 14 * 256, 1024, 32 * 64, 14 * 3072)
+        if rng.random() < 0.5:
+            return max(1, min(top, int(blocks[rng.integers(0, len(blocks))]) * int(rng.integers(1, 4)) + int(rng.integers(-2, 3))))
+        return int(np.exp(rng.uniform(0.0, np.log(top))))
+
+    # ---- GC-ADPCM
+    nfiles = int(rng.integers(1, 50))
+    lens = [length(200_000) for _ in range(nfiles)]
+    if rng.random() < 0.3:
+        lens[int(rng.integers(0, nfiles))] = 0
+    chans = _channels(lens, first_channel=700 + 60 * seed)
+    coefs, adpcm = _encode_v(chans)
+    for c, pcm in enumerate(chans):
+        wc, wa = _oracle(pcm)
+        assert coefs[c].tolist() == wc.tolist() and np.array_equal(adpcm[c], wa), ("gc", seed, c, lens[c])
+    back = _decode_v(adpcm, coefs, lens)
+    for c in range(nfiles):
+        assert np.array_equal(back[c], po.gc_decode(adpcm[c], coefs[c], lens[c])), ("gc decode", seed, c, lens[c])
+
+    # ---- CRI ADX
+    nfiles = int(rng.integers(1, 40))
+    lens = [length(150_000) for _ in range(nfiles)]
+    chans = _channels(lens, first_channel=900 + 60 * seed)
+    params = (_lib.AdxParams * nfiles)()
+    kws = []
+    for c in range(nfiles):
+        L.vga_adx_default_params(C.byref(params[c]))
+        kw = dict(type=int(rng.choice([2, 3, 4])), version=int(rng.choice([3, 4])))
+        if kw["type"] == 2:
+            kw["filter"] = int(rng.integers(0, 4))
+        if rng.random() < 0.5:
+            kw["padding"] = int(rng.integers(0, 80))
+        if rng.random() < 0.4:
+            kw["sample_rate"] = int(rng.choice([22050, 32000, 44100]))
+        if rng.random() < 0.1:
+            kw["frame_size"] = 34
+        for k, v in kw.items():
+            setattr(params[c], k, v)
+        kws.append(kw)
+    counts = np.array(lens, dtype=np.int32)
+    outs = [np.full(L.vga_adx_encoded_byte_count(n, C.byref(params[c])) + 1, 0xEE, dtype=np.uint8) for c, n in enumerate(lens)]
+    hist = np.full(nfiles, 0x1234, dtype=np.int16)
+    _lib.check(L.vga_adx_encode_batch_v(_ptrs(i16p, chans), counts.ctypes.data_as(C.POINTER(C.c_int)), nfiles, params, _ptrs(u8p, outs),
+                                        hist.ctypes.data_as(i16p)))
+    for c, pcm in enumerate(chans):
+        p = po.adx_params(**kws[c])
+        want = po.adx_encode(pcm, p)
+        assert outs[c][-1] == 0xEE and np.array_equal(outs[c][:-1], want), ("adx", seed, c, lens[c], kws[c])
+        assert int(hist[c]) == int(p.history), ("adx history", seed, c, kws[c])
+    enc = [o[:-1].copy() for o in outs]
+    alens = np.array([len(e) for e in enc], dtype=np.int32)
+    pcm_out = [np.full(n + 1, 0x7777, dtype=np.int16) for n in lens]
+    _lib.check(L.vga_adx_decode_batch_v(_ptrs(u8p, enc), alens.ctypes.data_as(C.POINTER(C.c_int)), nfiles,
+                                        counts.ctypes.data_as(C.POINTER(C.c_int)), params, _ptrs(i16p, pcm_out)))
+    for c in range(nfiles):
+        dk = {k: v for k, v in kws[c].items() if k != "filter"}
+        want = po.adx_decode(enc[c], lens[c], po.adx_params(**kws[c]))
+        assert pcm_out[c][-1] == 0x7777 and np.array_equal(pcm_out[c][:-1], want), ("adx decode", seed, c, lens[c], dk)
+
+    # ---- CRI HCA
+    ns = int(rng.integers(1, 14))
+    shapes = []
+    for s in range(ns):
+        n = max(1, length(40_000))
+        sh = dict(channel_count=int(rng.choice([1, 2, 2, 2, 3, 4, 6])), sample_count=n,
+                  sample_rate=int(rng.choice([48000, 44100, 32000])), quality=str(rng.choice(["Highest", "High", "Middle", "Low", "Lowest"])))
+        if rng.random() < 0.3 and n > 10:
+            sh.update(looping=True, loop_start=int(rng.integers(0, n - 1)))
+            sh["loop_end"] = int(rng.integers(sh["loop_start"] + 1, n + 1))
+        shapes.append(sh)
+    pcm, rows = [], []
+    for s, sh in enumerate(shapes):
+        a = po.synth_generate(sh["channel_count"], sh["sample_count"], first_channel=40 * s + 1000 * seed)
+        pcm.append(a)
+        rows += [a[c] for c in range(sh["channel_count"])]
+    configs = (_lib.HcaParamsC * ns)()
+    want = []
+    for s, sh in enumerate(shapes):
+        op = po.hca_params(**sh)
+        for f, _ in _lib.HcaParamsC._fields_:
+            setattr(configs[s], f, getattr(op, f))
+        rc, info, frames = po.hca_encode(pcm[s], op)
+        assert rc == 0, ("hca oracle", seed, s, sh)
+        want.append((info, frames))
+    infos = (_lib.HcaInfoC * ns)()
+    outs = [np.full(w[0].frame_count * w[0].frame_size + 1, 0xEE, dtype=np.uint8) for w in want]
+    _lib.check(L.vga_hca_encode_batch_v(_ptrs(i16p, rows), ns, configs, infos, _ptrs(u8p, outs)))
+    for s in range(ns):
+        info, frames = want[s]
+        for f, _ in _lib.HcaInfoC._fields_:
+            assert getattr(infos[s], f) == getattr(info, f), ("hca info", seed, s, f)
+        assert outs[s][-1] == 0xEE and np.array_equal(outs[s][:-1], frames.reshape(-1)), ("hca", seed, s, shapes[s])
+    enc = [o[:-1].copy() for o in outs]
+    pcm_out = []
+    for s in range(ns):
+        pcm_out += [np.full(max(infos[s].sample_count, 0) + 1, 0x7777, dtype=np.int16) for _ in range(infos[s].channel_count)]
+    _lib.check(L.vga_hca_decode_batch_v(infos, _ptrs(u8p, enc), ns, _ptrs(i16p, pcm_out)))
+    at = 0
+    for s in range(ns):
+        rc, dec = po.hca_decode(want[s][0], want[s][1])
+        assert rc == 0
+        for c in range(infos[s].channel_count):
+            assert pcm_out[at][-1] == 0x7777 and np.array_equal(pcm_out[at][:-1], dec[c]), ("hca decode", seed, s, c, shapes[s])
+            at += 1
