@@ -10,14 +10,15 @@ for f in vgaudio_amd/csrc/*.hip; do
   b=$(basename $f .hip)
   case " $VARIED " in *" $b "*) continue;; esac
   if [ ! -f tools/variants/obj/$b.o ] || [ $f -nt tools/variants/obj/$b.o ]; then
-    /opt/rocm/bin/hipcc $FLAGS -c $f -o tools/variants/obj/$b.o &
+    /opt/rocm/bin/hipcc $FLAGS $(python3 vgaudio_amd/build.py --file-flags $b.hip) -c $f -o tools/variants/obj/$b.o &
   fi
 done
 wait
 for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}
   for v in $VARIED; do
-    /opt/rocm/bin/hipcc $FLAGS $defs -c vgaudio_amd/csrc/$v.hip -o tools/variants/obj/var_${name}_$v.o &
+    # (the product's per-file options, vgaudio_amd/build.py FILE_FLAGS, unless the variant says NOFILEFLAGS=1)
+    /opt/rocm/bin/hipcc $FLAGS $([ -n "$NOFILEFLAGS" ] || python3 vgaudio_amd/build.py --file-flags $v.hip) $defs -c vgaudio_amd/csrc/$v.hip -o tools/variants/obj/var_${name}_$v.o &
   done
 done
 wait

@@ -34,7 +34,10 @@ def short(name):
 def analyse(path, defs):
     with tempfile.TemporaryDirectory() as tmp:
         base = os.path.join(tmp, "k")
-        r = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + defs + ["-Rpass-analysis=kernel-resource-usage", "--save-temps=obj", "-c",
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from vgaudio_amd.build import FILE_FLAGS              # the product's per-file code generation options
+        r = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + FILE_FLAGS.get(os.path.basename(path), []) + defs +
+                           ["-Rpass-analysis=kernel-resource-usage", "--save-temps=obj", "-c",
                             path, "-o", base + ".o"], capture_output=True, text=True, cwd=tmp)
         if r.returncode:
             raise SystemExit(r.stderr[-3000:])

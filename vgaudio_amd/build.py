@@ -23,6 +23,25 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
+# Per-file code generation options (hipcc -mllvm ..., ROCm 7.2's LLVM 22), measured on the file's own kernels at the BASELINE
+# shapes (round 6, profiles/r06_z_compiler_*.log; same bytes out): the GC-ADPCM encoder's frame loop is one long dependent chain
+# per lane, and the post-RA machine scheduler's reordering of it costs 4 %: 144.2-147.0 ms at configs[1] with the defaults, 139.0-
+# 140.6 without it, 138.6-138.9 with relaxed-occupancy scheduling and without the pre-RA peepholes as well.  The same options on
+# the other kernel files: coefficient kernel 30.4 / 30.1, ADX 17.4 / 17.4 + 7.3 / 7.3, GC decode 8.5-9.3 / 8.5, HCA encode 21.0 /
+# 20.7, HCA decode 24.0 / 23.1 -- nothing or worse, so they keep the defaults.
+FILE_FLAGS = {
+    "gc_encode_kernel.hip": ["-mllvm", "-enable-post-misched=0", "-mllvm", "-amdgpu-schedule-relaxed-occupancy=true",
+                             "-mllvm", "-amdgpu-enable-pre-ra-optimizations=0"],
+}
+
+
+FLAGS_KEY = "@compiler-options"
+
+
+def flags_for(src):
+    return FLAGS + FILE_FLAGS.get(os.path.basename(src), [])
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -38,8 +57,10 @@ def source_hashes():
     a profile's counters only while the files its kernel is built from still match (a changed kernel silently
     invalidates measured traffic)."""
     import hashlib
-    return {f: hashlib.sha256(open(os.path.join(CSRC, f), "rb").read()).hexdigest()
-            for f in sorted(os.listdir(CSRC)) if os.path.isfile(os.path.join(CSRC, f))}
+    out = {f: hashlib.sha256(open(os.path.join(CSRC, f), "rb").read()).hexdigest()
+           for f in sorted(os.listdir(CSRC)) if os.path.isfile(os.path.join(CSRC, f))}
+    out[FLAGS_KEY] = hashlib.sha256(repr((FLAGS, sorted(FILE_FLAGS.items()))).encode()).hexdigest()   # the options are part of the code
+    return out
 
 
 # the .hip files that hold a codec's kernels; the headers come from their #include lines (bench.py: is a committed
@@ -68,7 +89,7 @@ def kernel_sources(codec):
             inc = os.path.basename(inc)
             if os.path.exists(os.path.join(CSRC, inc)):
                 todo.append(inc)
-    return sorted(seen)
+    return sorted(seen) + [FLAGS_KEY]
 
 
 def profile_is_current(profile, codec):
@@ -95,7 +116,7 @@ def build_stats_variant(verbose=False):
     if os.path.exists(STATS_OUT) and os.path.getmtime(STATS_OUT) >= max(newest, os.path.getmtime(OUT)):
         return STATS_OUT
     if not os.path.exists(obj) or os.path.getmtime(obj) < newest:
-        cmd = [hipcc] + FLAGS + ["-DVGA_GC_STATS", "-c", src, "-o", obj]
+        cmd = [hipcc] + flags_for(src) + ["-DVGA_GC_STATS", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -136,7 +157,7 @@ def build(force=False, verbose=False):
     todo = sources() if force else stale_sources()
 
     def compile_one(src):
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj_of(src)]
+        cmd = [hipcc] + flags_for(src) + ["-c", src, "-o", obj_of(src)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -151,6 +172,9 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
+    if "--file-flags" in sys.argv:                      # tools/build_variants.sh, tools/kernel_resources.py: the extra options of one file
+        print(" ".join(FILE_FLAGS.get(os.path.basename(sys.argv[sys.argv.index("--file-flags") + 1]), [])))
+        sys.exit(0)
     build(force="--force" in sys.argv, verbose=True)
     print(OUT)
     if "--stats" in sys.argv:
